@@ -1,0 +1,257 @@
+/*
+ * prgpu.h -- C ABI of the MI355X-native spectral path-tracing backend.
+ *
+ * This is the drop-in boundary for ONE hot path of PearCoding/PearRay: the `direct`
+ * integrator (unidirectional spectral path tracer) together with the ray tracing service
+ * it sits on.  Every entry point cites the reference interface it replaces (paths are
+ * relative to the reference checkout).
+ *
+ *   reference surface                                             replaced by
+ *   ------------------------------------------------------------  ---------------------------
+ *   Scene::Scene / setupScene (Embree BVH build)                  prgpu_scene_create
+ *     src/core/scene/Scene.cpp:61-120, entities/mesh.cpp:96-119
+ *   RenderContext::start (RNG map, LightSampler, sampler tables)  prgpu_scene_create
+ *     src/core/renderer/RenderContext.cpp:65-139
+ *   IIntegratorInstance::onTile over all tiles of N iterations    prgpu_render
+ *     src/core/integrator/IIntegrator.h:11-17,
+ *     src/plugins/main/integrators/direct.cpp:153-166,
+ *     src/core/renderer/RenderThread.cpp:36-70
+ *   RenderTileMap tile hand-out / --itx/--ity image tiles         prgpu_set_tiles
+ *     src/core/renderer/RenderTileMap.cpp:26-134,
+ *     src/core/renderer/RenderFactory.cpp:16-42
+ *   FrameOutputDevice (AOV_Output XYZ + AOV_SampleCount planes)   prgpu_download / prgpu_bind_framebuffer
+ *     src/loader/output/FrameOutputDevice.cpp:83-221
+ *   RenderStatistics (11 counters)                                prgpu_stats
+ *     src/core/renderer/RenderStatistics.h:9-23
+ *   IArchive::traceRays / traceSingleRay / traceShadowRay         prgpu_trace_closest / prgpu_trace_any
+ *     src/core/archive/IArchive.h:14-25, src/core/scene/Scene.cpp:138-280
+ *   loader-side node creation `(refl r g b)` / `(illum r g b)`    prgpu_rgb_to_coeffs
+ *     src/plugins/main/node/SpectralValueNode.cpp:16-47,
+ *     src/core/spectral/SpectralUpsampler.cpp:78-146
+ *
+ * Conventions: plain pointers + sizes, no C++ types, no exceptions across the boundary.
+ * All functions return 0 (PRGPU_OK) on success or a negative PRGPU_E* code; the message is
+ * available from prgpu_last_error() (thread local).  Render-time numeric faults never raise:
+ * NaN/Inf/negative contributions are dropped and flagged in the per-pixel feedback plane,
+ * exactly like LocalFrameOutputDevice.cpp:125-142.
+ * The caller owns every input array (all are copied during prgpu_scene_create); the library
+ * owns device memory behind the opaque prgpu_scene handle.
+ */
+#ifndef PRGPU_H
+#define PRGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRGPU_API_VERSION 1
+#define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
+
+enum {
+	PRGPU_OK          = 0,
+	PRGPU_EINVAL      = -1, /* malformed description (bad index, empty scene, ...) */
+	PRGPU_ENODEVICE   = -2, /* no usable HIP device / device index out of range */
+	PRGPU_EDEVICE     = -3, /* a HIP runtime call failed; see prgpu_last_error() */
+	PRGPU_EUNSUPPORTED = -4 /* valid PearRay feature that this backend does not implement */
+};
+
+/* ---- spectral nodes (flattened shading network) ------------------------------------------
+ * Mirrors the FloatSpectralNode subclasses the hot path evaluates:
+ *   CONST              ConstSpectralNode                 src/loader/shader/ConstNode.cpp:20-40
+ *   PARAMETRIC         ParametricSpectralNode            src/loader/shader/ConstNode.cpp:52-62
+ *   PARAMETRIC_SCALED  ParametricScaledSpectralNode      src/loader/shader/ConstNode.cpp:78-88
+ *   TABLE              EquidistantSpectrum(View)Node     src/loader/shader/EquidistantSpectrumNode.h:19-28
+ *   MUL                MulSpectralMath (`smul`)          src/plugins/main/node/SpectralMathNode.cpp:73,97
+ * MUL operands must have a smaller index than the node itself (topological order). */
+enum { PRGPU_SPEC_CONST = 0, PRGPU_SPEC_PARAMETRIC = 1, PRGPU_SPEC_PARAMETRIC_SCALED = 2,
+       PRGPU_SPEC_TABLE = 3, PRGPU_SPEC_MUL = 4 };
+
+typedef struct prgpu_spectrum {
+	uint32_t kind;
+	float    p[4];          /* CONST: p[0]; PARAMETRIC*: a,b,c (, power) */
+	uint32_t table_offset;  /* TABLE: first sample in prgpu_scene_desc::spectral_tables */
+	uint32_t table_count;   /* TABLE: number of samples (>= 2) */
+	float    wl_start;      /* TABLE: wavelength of first sample [nm] */
+	float    wl_end;        /* TABLE: wavelength of last sample [nm] */
+	uint32_t lhs, rhs;      /* MUL: operand node indices */
+} prgpu_spectrum;
+
+enum { PRGPU_MAT_LAMBERT = 0 }; /* src/plugins/main/materials/lambert.cpp */
+typedef struct prgpu_material {
+	uint32_t kind;
+	uint32_t albedo;     /* spectrum index */
+	uint32_t two_sided;  /* lambert `two_sided`, default true (lambert.cpp:108) */
+	uint32_t reserved;
+} prgpu_material;
+
+enum { PRGPU_EMS_DIFFUSE = 0 }; /* src/plugins/main/emissions/diffuse.cpp */
+typedef struct prgpu_emission {
+	uint32_t kind;
+	uint32_t radiance;   /* spectrum index */
+} prgpu_emission;
+
+/* One mesh entity = one instance of a triangle mesh (src/plugins/main/entities/mesh.cpp).
+ * Geometry is given in LOCAL space; `transform` is the row-major 4x4 of `:transform`
+ * (src/loader/parser/MathParser.cpp:18-26).  Triangles [first_tri, first_tri+n_tris) of the
+ * scene index buffer belong to this entity; primitive id reported for a hit is the index
+ * relative to first_tri (Embree primID, Scene.cpp:184-192). */
+typedef struct prgpu_entity {
+	uint32_t first_tri;
+	uint32_t n_tris;
+	uint32_t emission;     /* emission index or PRGPU_INVALID_ID */
+	uint32_t has_normals;  /* 1: interpolate vertex normals (MeshEntity<*,true>), 0: geometric */
+	float    transform[16];
+} prgpu_entity;
+
+/* PerspectiveCamera, src/plugins/main/cameras/perspective.cpp:16-113 */
+typedef struct prgpu_camera {
+	float transform[16];      /* row-major 4x4 */
+	float width, height;      /* sensor size */
+	float near_t, far_t;      /* ray interval; far_t may be +inf */
+	float local_direction[3], local_right[3], local_up[3];
+	float fstop, aperture_radius; /* DOF active iff both > FLT_EPSILON (perspective.cpp:158) */
+} prgpu_camera;
+
+enum { PRGPU_SAMPLER_RANDOM = 0, PRGPU_SAMPLER_MJITT = 1, PRGPU_SAMPLER_SOBOL = 2 };
+enum { PRGPU_MAPPER_SPD_CMIS = 0, PRGPU_MAPPER_RANDOM = 1, PRGPU_MAPPER_SPD_HERO = 2 };
+enum { PRGPU_FILTER_BLOCK = 0, PRGPU_FILTER_TRIANGLE = 1, PRGPU_FILTER_GAUSSIAN = 2,
+       PRGPU_FILTER_MITCHELL = 3 };
+enum { PRGPU_MIS_BALANCE = 0, PRGPU_MIS_POWER = 1 };
+
+/* RenderSettings (src/core/renderer/RenderSettings.cpp:11-31) + `direct` parameters
+ * (src/plugins/main/integrators/direct.cpp:34-39,500-515).  prgpu_settings_default() fills
+ * the reference defaults. */
+typedef struct prgpu_settings {
+	uint32_t width, height;          /* film size */
+	uint64_t seed;                   /* 42 */
+	uint32_t aa_sampler;             /* PRGPU_SAMPLER_*; default sobol */
+	uint32_t aa_samples;             /* 128; total spp = aa*lens*time*spectral sample counts */
+	uint32_t lens_samples, time_samples, spectral_samples; /* `random` samplers, 1 each */
+	uint32_t mapper;                 /* PRGPU_MAPPER_*; default spd cmis */
+	uint32_t filter;                 /* PRGPU_FILTER_*; default mitchell */
+	uint32_t filter_radius;          /* default 1 (FilterManager.cpp:16) ; <= 3 */
+	uint32_t max_ray_depth;          /* 64 */
+	uint32_t soft_max_ray_depth;     /* 4 */
+	uint32_t mis;                    /* PRGPU_MIS_* */
+	uint32_t nee, direct, emissive_scatter; /* booleans, all true */
+	float    spectral_start, spectral_end;  /* 390, 830 */
+	uint32_t spectral_hero;          /* true */
+	uint32_t spectral_mono;          /* false; true => all four lanes at spectral_start */
+} prgpu_settings;
+
+typedef struct prgpu_scene_desc {
+	uint32_t api_version;            /* PRGPU_API_VERSION */
+	/* geometry */
+	uint32_t n_vertices;
+	const float*    positions;       /* 3*n_vertices, local space */
+	const float*    normals;         /* 3*n_vertices or NULL */
+	uint32_t n_triangles;
+	const uint32_t* indices;         /* 3*n_triangles, into positions/normals */
+	const uint32_t* tri_material;    /* n_triangles, material index or PRGPU_INVALID_ID */
+	uint32_t n_entities;
+	const prgpu_entity* entities;    /* entity id == array index (rtcAttachGeometryByID, Scene.cpp:106) */
+	/* shading */
+	uint32_t n_materials;
+	const prgpu_material* materials;
+	uint32_t n_emissions;
+	const prgpu_emission* emissions;
+	uint32_t n_spectra;
+	const prgpu_spectrum* spectra;
+	uint32_t n_spectral_table_values;
+	const float* spectral_tables;
+	prgpu_camera   camera;
+	prgpu_settings settings;
+} prgpu_scene_desc;
+
+/* Half-open pixel rectangle [x0,x1) x [y0,y1): one RenderTile (src/core/renderer/RenderTile.h). */
+typedef struct prgpu_tile { uint32_t x0, y0, x1, y1; } prgpu_tile;
+
+/* RenderStatisticEntry order, src/core/renderer/RenderStatistics.h:9-23 */
+enum { PRGPU_STAT_CAMERA_RAYS = 0, PRGPU_STAT_LIGHT_RAYS, PRGPU_STAT_PRIMARY_RAYS, PRGPU_STAT_BOUNCE_RAYS,
+       PRGPU_STAT_SHADOW_RAYS, PRGPU_STAT_MONOCHROME_RAYS, PRGPU_STAT_PIXEL_SAMPLES, PRGPU_STAT_ENTITY_HITS,
+       PRGPU_STAT_BACKGROUND_HITS, PRGPU_STAT_CAMERA_DEPTH, PRGPU_STAT_LIGHT_DEPTH, PRGPU_STAT_COUNT };
+
+/* Traversal counters of the device kernels (not a reference concept; feeds the roofline). */
+typedef struct prgpu_trace_counters {
+	uint64_t rays_closest, rays_any;        /* rays traced by each kernel */
+	uint64_t nodes_closest, tris_closest;   /* BVH nodes popped / triangles tested (instrumented runs only) */
+	uint64_t nodes_any, tris_any;
+	uint32_t node_bytes, tri_bytes;         /* record sizes of the device BVH */
+	uint32_t ray_bytes, hit_bytes;          /* queue record sizes */
+} prgpu_trace_counters;
+
+typedef struct prgpu_scene prgpu_scene;
+
+/* -- library ------------------------------------------------------------------------------ */
+const char* prgpu_last_error(void);
+int  prgpu_device_count(void);                  /* >= 0, or PRGPU_ENODEVICE */
+void prgpu_settings_default(prgpu_settings* s); /* reference defaults, see struct comments */
+
+/* (refl r g b)/(illum r g b) node creation: Jakob-Hanika sigmoid-polynomial coefficients for an
+ * sRGB colour (replaces the srgb.coeff table lookup, SpectralUpsampler.cpp:78-146). Host only. */
+int  prgpu_rgb_to_coeffs(const float rgb[3], float coeffs[3]);
+
+/* -- scene -------------------------------------------------------------------------------- */
+/* Validates + uploads the scene to HIP device `device`, builds the two-level LBVH on the device,
+ * the per-pixel RNG map, sampler tables, light selector and wavelength distributions. */
+int  prgpu_scene_create(const prgpu_scene_desc* desc, int device, prgpu_scene** out);
+void prgpu_scene_destroy(prgpu_scene* s);
+
+/* Pixel ownership for multi-GPU / image-tile rendering.  Default: the whole film.  Pixels outside
+ * every tile are never sampled by this scene object (their RNG streams stay untouched), but filter
+ * aprons of owned pixels still spill into them, as in mergeLocal (FrameOutputDevice.cpp:83-123). */
+int  prgpu_set_tiles(prgpu_scene* s, const prgpu_tile* tiles, uint32_t n_tiles);
+
+/* Run the kernels on `hip_stream` (a hipStream_t, e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL selects the library's own stream. */
+int  prgpu_set_stream(prgpu_scene* s, void* hip_stream);
+
+/* Accumulate into caller-owned DEVICE buffers instead of the internal ones:
+ * xyz = W*H*3 fp32 interleaved [pixel*3+c] (FrameBuffer.h:98-147), samples = W*H u32,
+ * feedback = W*H u32 (may be NULL).  Buffers must be zeroed by the caller. */
+int  prgpu_bind_framebuffer(prgpu_scene* s, void* d_xyz, void* d_samples, void* d_feedback);
+
+/* -- render ------------------------------------------------------------------------------- */
+/* Render iterations [iter_begin, iter_end): one camera sample per owned pixel per iteration, and
+ * the per-iteration running mean out = (out*(i-1) + iter)/i of FrameOutputDevice::onEndOfIteration.
+ * Iterations must be rendered in order starting at 0 (pixel RNG streams are sequential).
+ * Asynchronous w.r.t. the host; prgpu_sync / prgpu_download / prgpu_stats synchronise. */
+int  prgpu_render(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end);
+int  prgpu_sync(prgpu_scene* s);
+
+/* Copy the XYZ plane (W*H*3 fp32), sample-count plane (W*H u32) and feedback plane (W*H u32,
+ * OutputFeedback bits, src/core/output/Feedback.h:6-12) to HOST memory; any pointer may be NULL. */
+int  prgpu_download(prgpu_scene* s, float* xyz, uint32_t* samples, uint32_t* feedback);
+int  prgpu_stats(prgpu_scene* s, uint64_t out[PRGPU_STAT_COUNT]);
+int  prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out);
+/* Enable/disable node+triangle counting inside the traversal kernels (slower; default off). */
+int  prgpu_set_instrumentation(prgpu_scene* s, int enabled);
+
+/* -- ray service (IArchive surface) --------------------------------------------------------- */
+/* Closest hit for n rays given as HOST SoA arrays (org/dir: 3*n, AoS xyz per ray).
+ * Outputs (host): entity/prim u32 (PRGPU_INVALID_ID on miss), u,v barycentrics with
+ * P = (1-u-v) v0 + u v1 + v v2 (Triangle.h:22-27), t.  Any output pointer may be NULL. */
+int  prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const float* dir,
+                         const float* tmin, const float* tmax,
+                         uint32_t* entity, uint32_t* prim, float* u, float* v, float* t);
+/* Occlusion test in [tmin, distance-0.001] (Scene.cpp:266-280); occluded[i] = 1 if anything is hit. */
+int  prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* dir,
+                     const float* tmin, const float* distance, uint8_t* occluded);
+
+/* Primary-visibility debug plane of the LAST rendered iteration (entity, prim per pixel; host arrays
+ * of W*H u32).  Used by the hit-id parity tests. */
+int  prgpu_download_primary_hits(prgpu_scene* s, uint32_t* entity, uint32_t* prim);
+
+/* Time the traversal kernels alone on the rays recorded during the last iteration is not part of the
+ * ABI; bench.py measures kernels with HIP events through prgpu_kernel_time_ms(). */
+/* Accumulated HIP-event time [ms] and launch count of a named kernel family since scene creation
+ * ("trace_closest", "trace_any", "shade", "raygen", "resolve", "sort"). Requires prgpu_set_timing(s,1). */
+int  prgpu_set_timing(prgpu_scene* s, int enabled);
+int  prgpu_kernel_time_ms(prgpu_scene* s, const char* family, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRGPU_H */

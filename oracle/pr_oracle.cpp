@@ -1,0 +1,2161 @@
+/*
+ * pr_oracle.cpp -- CPU restatement ("oracle") of PearRay's `direct` integrator hot path.
+ *
+ * TEST INFRASTRUCTURE -- not product code.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this; the product must fail loudly without its HIP
+ * library instead of falling back to anything in this directory.
+ *
+ * Dependency-free C++17 (the reference itself cannot be compiled here: it needs Eigen, Embree 3,
+ * TBB and OpenImageIO, none of which exist in the image).  Every block cites the reference
+ * file:line it follows (paths relative to the reference checkout).
+ *
+ * Pinning status
+ *   pinned by a reference run   : PCG32-fast, Random::get32/get64/getFloat, RNG-map warm-up, tile
+ *                                 slot seeds (oracle/ref/ref_rng_driver.cpp -> tests/golden/ref_rng.json)
+ *   pinned by reference KATs    : tangent frames, cos-hemi, Distribution1D, Morton, normal matrix,
+ *                                 Lambert identities, CIE Y sum, upsampler evaluation, analytic form
+ *                                 factor, white-furnace-style energy checks (tests/test_oracle_*.py)
+ *   UNPINNED (no reference run) : ray/triangle traversal (Embree, un-vendored), bounded-int draws
+ *                                 and std::shuffle order (libstdc++ <= 10 semantics restated by
+ *                                 hand), Eigen reduction orders.  Stated in DESIGN.md.
+ *
+ * Arithmetic contract shared with the device code (so that both produce the same bits): fp32
+ * everywhere, compiled with -ffp-contract=off, dot = (x*x'+y*y')+z*z', blob sum = ((a+b)+c)+d,
+ * normalise = per-component division by sqrtf(dot), sin/cos of 2*pi*u via orc_sincos_2pi.
+ */
+#include "pr_oracle.h"
+
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "pr_tables.inl"
+
+namespace {
+
+thread_local std::string g_error;
+
+constexpr float PR_EPS	   = FLT_EPSILON;			   // config/Constants.inl:4
+constexpr float PR_INF_F   = std::numeric_limits<float>::infinity();
+constexpr float PR_PI_F	   = 3.14159265358979323846f;  // Constants.inl:8
+constexpr float PR_INV_PI_F = 0.31830988618379067154f; // Constants.inl:9
+constexpr uint32_t INVALID = PRGPU_INVALID_ID;
+
+// vcm/Defaults.h:4-13
+constexpr float SHADOW_RAY_MIN = 0.0001f;
+constexpr float BOUNCE_RAY_MIN = 0.0001f;
+constexpr float DISTANCE_EPS   = 1e-5f;
+constexpr float GEOMETRY_EPS   = 1e-5f;
+constexpr float PDF_EPS		   = 1e-6f;
+
+// spectral/CIE.h:18-26 (CIE 2006 branch)
+constexpr int CIE_SAMPLES		 = 441;
+constexpr float CIE_START		 = 390.0f;
+constexpr float CIE_END			 = 830.0f;
+constexpr float CIE_Y_NORM_SUM	 = 113.042314572337f;
+constexpr float CIE_RANGE		 = CIE_END - CIE_START;
+constexpr float CIE_DELTA		 = CIE_RANGE / (CIE_SAMPLES - 1);
+constexpr float CIE_Y_NORM		 = CIE_Y_NORM_SUM * CIE_DELTA;
+
+// ------------------------------------------------------------------------------------------------
+// small vector helpers (fixed evaluation order, see header comment)
+struct V3 {
+	float x, y, z;
+	float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline V3 v3(float x, float y, float z) { return V3{ x, y, z }; }
+inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+inline V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline V3 normalized(V3 a)
+{
+	const float n = std::sqrt(dot(a, a));
+	return v3(a.x / n, a.y / n, a.z / n);
+}
+
+struct Blob {
+	float v[4];
+	float& operator[](int i) { return v[i]; }
+	float operator[](int i) const { return v[i]; }
+};
+inline Blob blob(float a) { return Blob{ { a, a, a, a } }; }
+inline Blob blob4(float a, float b, float c, float d) { return Blob{ { a, b, c, d } }; }
+inline Blob operator*(Blob a, Blob b) { return blob4(a[0] * b[0], a[1] * b[1], a[2] * b[2], a[3] * b[3]); }
+inline Blob operator*(Blob a, float s) { return blob4(a[0] * s, a[1] * s, a[2] * s, a[3] * s); }
+inline Blob operator/(Blob a, Blob b) { return blob4(a[0] / b[0], a[1] / b[1], a[2] / b[2], a[3] / b[3]); }
+inline Blob operator/(Blob a, float s) { return blob4(a[0] / s, a[1] / s, a[2] / s, a[3] / s); }
+inline float bsum(Blob a) { return ((a[0] + a[1]) + a[2]) + a[3]; }
+inline bool all_le(Blob a, float e) { return a[0] <= e && a[1] <= e && a[2] <= e && a[3] <= e; }
+inline bool is_zero(Blob a, float e) // Eigen DenseBase::isZero(prec): all |x| <= prec
+{
+	return std::fabs(a[0]) <= e && std::fabs(a[1]) <= e && std::fabs(a[2]) <= e && std::fabs(a[3]) <= e;
+}
+inline Blob hero_only() { return blob4(1, 0, 0, 0); } // spectral/SpectralBlob.h:19
+
+// ------------------------------------------------------------------------------------------------
+// R: Random = pcg32_fast (core/Random.h:26-179; random/pcg_random.hpp: mcg_xsh_rs_64_32, multiplier
+// 6364136223846793005 :158, seed -> state|3 :484-486, output from the PREVIOUS state, XSH-RS :812-835)
+constexpr uint64_t PCG_MULT = 6364136223846793005ULL;
+struct Rng {
+	uint64_t s;
+};
+inline Rng rng_seed(uint64_t seed) { return Rng{ seed | 3u }; }
+inline uint32_t rng_u32(Rng& r)
+{
+	const uint64_t old = r.s;
+	r.s				   = old * PCG_MULT;
+	const uint32_t rshift = uint32_t(old >> 61) & 7u;
+	const uint64_t x	  = old ^ (old >> 22);
+	return uint32_t(x >> (22u + rshift));
+}
+// Random.h:133-143: bits (v>>9)|0x3F800000 as float in [1,2), minus 1
+inline float u32_to_float(uint32_t v)
+{
+	const uint32_t u = (v >> 9) | 0x3F800000u;
+	float f;
+	std::memcpy(&f, &u, 4);
+	return f - 1.0f;
+}
+inline float rng_float(Rng& r) { return u32_to_float(rng_u32(r)); }
+// Random.h:111-118 get64 = uniform_int_distribution<uint64>()(pcg32_fast): libstdc++ "upscaling"
+// branch: high word first, then low word (bits/uniform_int_dist.h upscaling loop).
+inline uint64_t rng_u64(Rng& r)
+{
+	const uint64_t hi = rng_u32(r);
+	const uint64_t lo = rng_u32(r);
+	return (hi << 32) | lo;
+}
+// MCG jump ahead: state * MULT^delta (replaces the `warmup` loop of RenderRandomMap.cpp:5-9).
+inline uint64_t mcg_advance(uint64_t state, uint64_t delta)
+{
+	uint64_t acc = 1, cur = PCG_MULT;
+	while (delta) {
+		if (delta & 1)
+			acc *= cur;
+		cur *= cur;
+		delta >>= 1;
+	}
+	return state * acc;
+}
+// Random::get32(start,end) = std::uniform_int_distribution<uint32>(start,end-1)(pcg32_fast) with the
+// libstdc++ <= 10 downscaling algorithm (scale + reject, 2 divisions).
+inline uint32_t rng_bounded(Rng& r, uint32_t a, uint32_t b_incl)
+{
+	const uint32_t urngrange = 0xFFFFFFFFu;
+	const uint32_t urange	 = b_incl - a;
+	if (urange == urngrange)
+		return rng_u32(r) + a;
+	const uint32_t uerange = urange + 1;
+	const uint32_t scaling = urngrange / uerange;
+	const uint32_t past	   = uerange * scaling;
+	uint32_t ret;
+	do
+		ret = rng_u32(r);
+	while (ret >= past);
+	return ret / scaling + a;
+}
+// uniform_int_distribution<uint64>(0,b)(Random&) where Random is a 64-bit URBG (operator() = get64)
+inline uint64_t rng_bounded64(Rng& r, uint64_t b_incl)
+{
+	const uint64_t urngrange = ~uint64_t(0);
+	if (b_incl == urngrange)
+		return rng_u64(r);
+	const uint64_t uerange = b_incl + 1;
+	const uint64_t scaling = urngrange / uerange;
+	const uint64_t past	   = uerange * scaling;
+	uint64_t ret;
+	do
+		ret = rng_u64(r);
+	while (ret >= past);
+	return ret / scaling;
+}
+// std::shuffle(first,last,Random&) of libstdc++ (bits/stl_algo.h): two swap positions per draw.
+template <typename T>
+void std_shuffle(std::vector<T>& a, Rng& r)
+{
+	const uint64_t n = a.size();
+	if (n == 0)
+		return;
+	const uint64_t urngrange = ~uint64_t(0);
+	if (urngrange / n >= n) {
+		uint64_t i = 1;
+		if ((n % 2) == 0) {
+			std::swap(a[i], a[rng_bounded64(r, 1)]);
+			++i;
+		}
+		while (i != n) {
+			const uint64_t swap_range = i + 1;
+			const uint64_t b1		  = swap_range + 1;
+			const uint64_t x		  = rng_bounded64(r, swap_range * b1 - 1);
+			std::swap(a[i], a[x / b1]);
+			++i;
+			std::swap(a[i], a[x % b1]);
+			++i;
+		}
+		return;
+	}
+	for (uint64_t i = 1; i < n; ++i)
+		std::swap(a[i], a[rng_bounded64(r, i)]);
+}
+
+// R': RenderRandomMap (renderer/RenderRandomMap.cpp:11-28)
+void build_rng_map(uint64_t seed, uint32_t n, uint32_t delta, bool permute, std::vector<uint64_t>& states)
+{
+	states.resize(n);
+	Rng r0 = rng_seed(seed);
+	states[0] = r0.s;
+	uint64_t jump = mcg_advance(1, delta);
+	for (uint32_t i = 1; i < n; ++i)
+		states[i] = states[i - 1] * jump;
+	if (permute) {
+		Rng first{ states[0] };
+		for (uint32_t i = 1; i < n; ++i) {
+			const uint32_t j = rng_bounded(first, 1, n - 1);
+			std::swap(states[i], states[j]);
+		}
+		states[0] = first.s;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// base/math/Bits.h:36-58,82-124 Morton 2D
+inline uint64_t pack_even(uint64_t x)
+{
+	x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+	x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+	x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+	x = (x | (x << 2)) & 0x3333333333333333ULL;
+	x = (x | (x << 1)) & 0x5555555555555555ULL;
+	return x;
+}
+inline uint32_t unpack_even(uint64_t x)
+{
+	x = x & 0x5555555555555555ULL;
+	x = (x | (x >> 1)) & 0x3333333333333333ULL;
+	x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0FULL;
+	x = (x | (x >> 4)) & 0x00FF00FF00FF00FFULL;
+	x = (x | (x >> 8)) & 0x0000FFFF0000FFFFULL;
+	x = (x | (x >> 16)) & 0x00000000FFFFFFFFULL;
+	return (uint32_t)x;
+}
+inline uint64_t xy_2_morton(uint32_t x, uint32_t y) { return pack_even(x) | (pack_even(y) << 1); }
+inline void morton_2_xy(uint64_t d, uint32_t& x, uint32_t& y)
+{
+	x = unpack_even(d);
+	y = unpack_even(d >> 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic sin/cos(2*pi*u), u in [0,1): quadrant reduction on u (exact) + Cephes minimax
+// polynomials on [-pi/4, pi/4].  Stands in for std::sin/std::cos(2*PR_PI*u) (Sampling.h:42-46,
+// perspective.cpp:68-70) so that CPU and GPU agree bit for bit.
+inline void sincos_2pi(float u, float& s, float& c)
+{
+	const float k  = std::floor(u * 4.0f + 0.5f);
+	const float r  = u - 0.25f * k;
+	const float x  = 6.28318530717958647692f * r;
+	const float x2 = x * x;
+	float ps	   = -1.9515295891e-4f;
+	ps			   = ps * x2 + 8.3321608736e-3f;
+	ps			   = ps * x2 + -1.6666654611e-1f;
+	const float sn = (ps * x2) * x + x;
+	float pc	   = 2.443315711809948e-5f;
+	pc			   = pc * x2 + -1.388731625493765e-3f;
+	pc			   = pc * x2 + 4.166664568298827e-2f;
+	const float cs = (pc * x2) * x2 + (1.0f - 0.5f * x2);
+	switch (int(k) & 3) {
+	case 0: s = sn; c = cs; break;
+	case 1: s = cs; c = -sn; break;
+	case 2: s = -sn; c = -cs; break;
+	default: s = -cs; c = sn; break;
+	}
+}
+
+// base/math/Sampling.h:38-57 cos_hemi
+inline V3 cos_hemi(float u1, float u2)
+{
+	const float cosTheta = std::sqrt(u1);
+	const float sinTheta = std::sqrt(1 - u1);
+	float sinPhi, cosPhi;
+	sincos_2pi(u2, sinPhi, cosPhi);
+	return v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
+
+// base/math/Tangent.h:50-58 frame_duff (= unnormalized_frame)
+inline void frame_duff(V3 N, V3& Nx, V3& Ny)
+{
+	const float sign = std::copysign(1.0f, N.z);
+	const float a	 = -1.0f / (sign + N.z);
+	const float b	 = N.x * N.y * a;
+	Nx				 = v3(1.0f + sign * N.x * N.x * a, sign * b, -sign * N.x);
+	Ny				 = v3(b, sign + N.y * N.y * a, -N.y);
+}
+// Tangent.h:9-21
+inline V3 from_tangent_space(V3 N, V3 Nx, V3 Ny, V3 V) { return normalized((N * V.z + Ny * V.y) + Nx * V.x); }
+inline V3 to_tangent_space(V3 N, V3 Nx, V3 Ny, V3 V) { return normalized(v3(dot(Nx, V), dot(Ny, V), dot(N, V))); }
+
+// base/config/Types.inl:140-167
+inline float next_float_up(float v)
+{
+	if (std::isinf(v) && v > 0.0f)
+		return v;
+	if (v == -0.0f)
+		v = 0.0f;
+	uint32_t ui;
+	std::memcpy(&ui, &v, 4);
+	if (v >= 0)
+		++ui;
+	else
+		--ui;
+	std::memcpy(&v, &ui, 4);
+	return v;
+}
+inline float next_float_down(float v)
+{
+	if (std::isinf(v) && v < 0.0f)
+		return v;
+	if (v == 0.0f)
+		v = -0.0f;
+	uint32_t ui;
+	std::memcpy(&ui, &v, 4);
+	if (v > 0)
+		--ui;
+	else
+		++ui;
+	std::memcpy(&v, &ui, 4);
+	return v;
+}
+// base/math/Transform.h:13-32 safePosition
+inline V3 safe_position(V3 pos, V3 dir, V3 N)
+{
+	const float d = ((std::fabs(N.x) * 0.0001f + std::fabs(N.y) * 0.0001f) + std::fabs(N.z) * 0.0001f);
+	V3 off		  = N * d;
+	if (dot(dir, N) < 0)
+		off = -off;
+	float p[3] = { pos.x + off.x, pos.y + off.y, pos.z + off.z };
+	const float o[3] = { off.x, off.y, off.z };
+	for (int i = 0; i < 3; ++i) {
+		if (o[i] > 0)
+			p[i] = next_float_up(p[i]);
+		else if (o[i] < 0)
+			p[i] = next_float_down(p[i]);
+	}
+	return v3(p[0], p[1], p[2]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// base/math/Distribution1D.inl:15-37 generate, :119-135 sampleDiscrete, :71-86 sampleContinuous,
+// :93-100 continuousPdf; base/container/Interval.h:9-26 binary_search
+void distribution_generate(const float* values, uint32_t n, float* cdf, float* sum)
+{
+	cdf[0] = 0.0f;
+	for (uint32_t i = 0; i < n; ++i)
+		cdf[i + 1] = cdf[i] + values[i];
+	const float intr = cdf[n];
+	if (sum)
+		*sum = intr;
+	if (intr <= PR_EPS) {
+		for (uint32_t i = 1; i < n + 1; ++i)
+			cdf[i] = float(i) / float(n);
+	} else {
+		for (uint32_t i = 1; i < n + 1; ++i)
+			cdf[i] /= intr;
+	}
+	cdf[n] = 1.0f;
+}
+inline uint32_t distribution_sample_discrete(const float* cdf, uint32_t size, float u, float& pdf, float* rem)
+{
+	int first = 0, len = (int)size;
+	while (len > 0) {
+		const int half	 = len / 2;
+		const int middle = first + half;
+		if (cdf[middle] <= u) {
+			first = middle + 1;
+			len -= half + 1;
+		} else {
+			len = half;
+		}
+	}
+	const uint32_t off = (uint32_t)std::max(0, std::min(first - 1, (int)size - 2));
+	if (rem) {
+		*rem		  = u - cdf[off];
+		const float k = cdf[off + 1] - cdf[off];
+		if (k > PR_EPS)
+			*rem /= k;
+	}
+	pdf = cdf[off + 1] - cdf[off];
+	return off;
+}
+inline float distribution_sample_continuous(const float* cdf, uint32_t size, float u, float& pdf)
+{
+	float rem;
+	const uint32_t off = distribution_sample_discrete(cdf, size, u, pdf, &rem);
+	pdf *= float(size - 1);
+	return (float(off) + rem) / float(size - 1);
+}
+inline float distribution_continuous_pdf(const float* cdf, uint32_t size, float x)
+{
+	const size_t off = std::min<size_t>(size - 2, (size_t)(x * (size - 1)));
+	return (cdf[off + 1] - cdf[off]) * float(size - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// spectral/EquidistantSpectrum.inl:34-41 lookup
+inline float equidistant_lookup(const float* data, int count, float start, float delta, float wavelength)
+{
+	const float af	= std::max(0.0f, (wavelength - start) / delta);
+	const int index = (int)std::min<float>(float(count - 2), af);
+	const float t	= std::min<float>(float(count - 1), af) - index;
+	return data[index] * (1 - t) + data[index + 1] * t;
+}
+// spectral/CIE.h:41-62
+inline void cie_eval(float wl, float xyz[3])
+{
+	xyz[0] = equidistant_lookup(PR_CIE2006_X, CIE_SAMPLES, CIE_START, CIE_DELTA, wl) / CIE_Y_NORM * CIE_RANGE;
+	xyz[1] = equidistant_lookup(PR_CIE2006_Y, CIE_SAMPLES, CIE_START, CIE_DELTA, wl) / CIE_Y_NORM * CIE_RANGE;
+	xyz[2] = equidistant_lookup(PR_CIE2006_Z, CIE_SAMPLES, CIE_START, CIE_DELTA, wl) / CIE_Y_NORM * CIE_RANGE;
+}
+// spectral/SpectralUpsampler.h:45-49 compute(ParametricBlob, wvls)
+inline float upsample(const float p[3], float wl)
+{
+	const float x = (p[0] * wl + p[1]) * wl + p[2];
+	return (0.5f * x) * (1.0f / std::sqrt(x * x + 1.0f)) + 0.5f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sampler/MultiJitteredSampler.cpp:21-76 permute (Kensler CMJ)
+inline uint32_t mjitt_permute(uint32_t i, uint32_t l, uint32_t p)
+{
+	uint32_t w = l - 1;
+	if (w == 0)
+		return 0;
+	const bool pow2 = (l & w) == 0;
+	if (!pow2) {
+		w |= w >> 1;
+		w |= w >> 2;
+		w |= w >> 4;
+		w |= w >> 8;
+		w |= w >> 16;
+	}
+	do {
+		i ^= p;
+		i *= 0xe170893d;
+		i ^= p >> 16;
+		i ^= (i & w) >> 4;
+		i ^= p >> 8;
+		i *= 0x0929eb3f;
+		i ^= p >> 23;
+		i ^= (i & w) >> 1;
+		i *= 1 | p >> 27;
+		i *= 0x6935fa69;
+		i ^= (i & w) >> 11;
+		i *= 0x74dcb303;
+		i ^= (i & w) >> 2;
+		i *= 0x9e501cc3;
+		i ^= (i & w) >> 2;
+		i *= 0xc860a3df;
+		i &= w;
+		i ^= i >> 5;
+	} while (!pow2 && i >= l);
+	return pow2 ? ((i + p) & w) : ((i + p) % l);
+}
+
+// filter/FilterCache.h:8-25 over {Block,Triangle,Gaussian,Mitchell}Filter.cpp
+void filter_table(uint32_t kind, uint32_t radius, std::vector<float>& table)
+{
+	const int r = (int)radius, d = 2 * r + 1, half = r + 1;
+	table.assign(size_t(d) * d, 1.0f);
+	if (kind == PRGPU_FILTER_BLOCK) { // BlockFilter.cpp:15
+		for (float& f : table)
+			f = 1.0f / ((2 * r + 1) * (2 * r + 1));
+		return;
+	}
+	if (r == 0) // every cached filter: radius 0 -> weight 1
+		return;
+	std::vector<float> cache(size_t(half) * half);
+	float sum1 = 0, sum2 = 0, sum4 = 0;
+	for (int y = 0; y < half; ++y) {
+		for (int x = 0; x < half; ++x) {
+			const float rr = std::sqrt(float(x * x + y * y));
+			float val	   = 0;
+			if (kind == PRGPU_FILTER_TRIANGLE) { // TriangleFilter.cpp:44
+				val = rr <= r ? 1 - rr / (float)r : 0.0f;
+			} else if (kind == PRGPU_FILTER_GAUSSIAN) { // GaussianFilter.cpp:38-52
+				const float dev2 = 0.2f, alpha = 1 / (2 * dev2);
+				const float q = rr / (float)r;
+				val			  = q <= 1.0f ? std::exp(-alpha * q * q) : 0.0f;
+			} else { // MitchellFilter.cpp:32-52, B = C = 1/3
+				const float B = 1 / 3.0f, C = 1 / 3.0f;
+				float xx = std::fabs(2 * rr / r);
+				if (xx < 1)
+					val = ((12 - 9 * B - 6 * C) * xx * xx * xx + (-18 + 12 * B + 6 * C) * xx * xx + (6 - 2 * B)) / 6;
+				else if (xx < 2)
+					val = ((-B - 6 * C) * xx * xx * xx + (6 * B + 30 * C) * xx * xx + (-12 * B - 48 * C) * xx + (8 * B + 24 * C)) / 6;
+				else
+					val = 0;
+			}
+			cache[y * half + x] = val;
+			if (y == 0 && x == 0)
+				sum1 += val;
+			else if (y == 0 || x == 0)
+				sum2 += val;
+			else
+				sum4 += val;
+		}
+	}
+	const float norm = 1.0f / (sum1 + 2 * sum2 + 4 * sum4);
+	for (float& f : cache)
+		f *= norm;
+	for (int y = -r; y <= r; ++y)
+		for (int x = -r; x <= r; ++x)
+			table[(y + r) * d + (x + r)] = cache[std::abs(y) * half + std::abs(x)];
+}
+
+// ------------------------------------------------------------------------------------------------
+// entity/ITransformable.cpp:8-16: normal matrix (M^-1)^T of the linear part and |det|
+void normal_matrix(const float m[16], float out[9], float& abs_det)
+{
+	const float a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+	const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+	const float c10 = c * h - b * i, c11 = a * i - c * g, c12 = b * g - a * h;
+	const float c20 = b * f - c * e, c21 = c * d - a * f, c22 = a * e - b * d;
+	const float det = (a * c00 + b * c01) + c * c02;
+	abs_det			= std::fabs(det);
+	// inverse = adj/det with adj = cof^T; (inverse)^T = cof/det
+	out[0] = c00 / det; out[1] = c01 / det; out[2] = c02 / det;
+	out[3] = c10 / det; out[4] = c11 / det; out[5] = c12 / det;
+	out[6] = c20 / det; out[7] = c21 / det; out[8] = c22 / det;
+}
+inline V3 mat3_mul(const float m[9], V3 v)
+{
+	return v3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[3] * v.x + m[4] * v.y) + m[5] * v.z, (m[6] * v.x + m[7] * v.y) + m[8] * v.z);
+}
+inline V3 affine_mul(const float m[16], V3 v)
+{
+	return v3(((m[0] * v.x + m[1] * v.y) + m[2] * v.z) + m[3], ((m[4] * v.x + m[5] * v.y) + m[6] * v.z) + m[7],
+			  ((m[8] * v.x + m[9] * v.y) + m[10] * v.z) + m[11]);
+}
+inline V3 linear_mul(const float m[16], V3 v)
+{
+	return v3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z, (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Watertight ray/triangle test (Woop, Benthin, Wald 2013).  Stands in for Embree's robust
+// triangle intersector behind rtcIntersect1/rtcOccluded1 (Scene.cpp:220-280); Embree is an
+// un-vendored dependency, so this is the published algorithm, not a restatement of Embree code.
+struct RayPre {
+	V3 o, d;
+	int kx, ky, kz;
+	float Sx, Sy, Sz;
+	V3 inv_d;
+};
+inline RayPre ray_prepare(V3 o, V3 d)
+{
+	RayPre r;
+	r.o = o;
+	r.d = d;
+	const float ax = std::fabs(d.x), ay = std::fabs(d.y), az = std::fabs(d.z);
+	int kz = 0;
+	if (ay > ax)
+		kz = 1;
+	if (az > (kz == 0 ? ax : ay))
+		kz = 2;
+	int kx = kz + 1 == 3 ? 0 : kz + 1;
+	int ky = kx + 1 == 3 ? 0 : kx + 1;
+	if (d[kz] < 0.0f)
+		std::swap(kx, ky);
+	r.kx = kx;
+	r.ky = ky;
+	r.kz = kz;
+	r.Sx = d[kx] / d[kz];
+	r.Sy = d[ky] / d[kz];
+	r.Sz = 1.0f / d[kz];
+	r.inv_d = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	return r;
+}
+// returns true and t,u,v when the (infinite) ray line crosses the triangle with det != 0
+inline bool woop(const RayPre& r, V3 p0, V3 p1, V3 p2, float& t, float& u, float& v)
+{
+	const V3 A = p0 - r.o, B = p1 - r.o, C = p2 - r.o;
+	const float Ax = A[r.kx] - r.Sx * A[r.kz], Ay = A[r.ky] - r.Sy * A[r.kz];
+	const float Bx = B[r.kx] - r.Sx * B[r.kz], By = B[r.ky] - r.Sy * B[r.kz];
+	const float Cx = C[r.kx] - r.Sx * C[r.kz], Cy = C[r.ky] - r.Sy * C[r.kz];
+	float U = Cx * By - Cy * Bx;
+	float V = Ax * Cy - Ay * Cx;
+	float W = Bx * Ay - By * Ax;
+	if (U == 0.0f || V == 0.0f || W == 0.0f) {
+		U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+		V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+		W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+	}
+	if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
+		return false;
+	const float det = (U + V) + W;
+	if (det == 0.0f)
+		return false;
+	const float Az = r.Sz * A[r.kz], Bz = r.Sz * B[r.kz], Cz = r.Sz * C[r.kz];
+	const float T	= (U * Az + V * Bz) + W * Cz;
+	const float rcp = 1.0f / det;
+	t				= T * rcp;
+	u				= V * rcp; // weight of p1  (P = (1-u-v) p0 + u p1 + v p2, Triangle.h:22-27)
+	v				= W * rcp; // weight of p2
+	return true;
+}
+
+struct Aabb {
+	float lo[3], hi[3];
+};
+// slab test, conservative by construction of the (padded) boxes; entry <= limit keeps ties reachable
+inline bool box_hit(const RayPre& r, const Aabb& b, float tmin, float limit, float& tentry)
+{
+	float t0 = tmin, t1 = limit;
+	const float o[3] = { r.o.x, r.o.y, r.o.z }, id[3] = { r.inv_d.x, r.inv_d.y, r.inv_d.z };
+	for (int a = 0; a < 3; ++a) {
+		float tn = (b.lo[a] - o[a]) * id[a];
+		float tf = (b.hi[a] - o[a]) * id[a];
+		if (tn > tf)
+			std::swap(tn, tf);
+		// NaN (0*inf) compares false -> keeps the interval, i.e. stays conservative
+		if (tn > t0)
+			t0 = tn;
+		if (tf < t1)
+			t1 = tf;
+	}
+	tentry = t0;
+	return t0 <= t1;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Hit {
+	float t, u, v;
+	uint32_t tri; // global triangle index, INVALID on miss
+};
+
+struct BvhNode {
+	Aabb box;
+	uint32_t left;	// inner: left child, right = left+1 ; leaf: first index into tri order
+	uint32_t count; // 0: inner
+};
+
+struct Scene {
+	prgpu_scene_desc d;
+	prgpu_settings cfg;
+	std::vector<float> positions, normals, tables;
+	std::vector<uint32_t> indices, tri_material;
+	std::vector<prgpu_entity> entities;
+	std::vector<prgpu_material> materials;
+	std::vector<prgpu_emission> emissions;
+	std::vector<prgpu_spectrum> spectra;
+	bool has_normals_array = false;
+
+	// derived geometry
+	std::vector<V3> wv;			   // world-space triangle vertices, 3 per triangle
+	std::vector<uint32_t> tri_entity;
+	std::vector<std::array<float, 9>> nmat; // per entity normal matrix
+	std::vector<float> vol_scale;		   // |det linear|
+	std::vector<float> world_area;		   // IEntity::worldSurfaceArea
+	// BVH
+	std::vector<BvhNode> nodes;
+	std::vector<uint32_t> tri_order;
+	// camera cache (perspective.cpp:84-113)
+	V3 cam_o, cam_right, cam_up, cam_focal, cam_xap, cam_yap;
+	bool cam_dof = false;
+	// samplers
+	uint32_t spp = 0;
+	uint32_t mj_x = 1, mj_y = 1, mj_seed = 0;
+	std::vector<float> sobol2d; // 2*spp
+	// lights
+	std::vector<uint32_t> light_entity;	 // light id -> entity
+	std::vector<uint32_t> entity_light;	 // entity -> light id or INVALID
+	std::vector<float> light_cdf, light_intensity;
+	// wavelength distribution (spd mapper)
+	std::vector<float> wl_cdf;
+	// integrator
+	std::vector<float> rr_prob; // by path length
+	std::vector<float> filter;
+	// state
+	std::vector<uint64_t> rng;
+	std::vector<uint8_t> owned; // per pixel ownership mask
+	std::vector<float> xyz;		// running mean, W*H*3
+	std::vector<float> iter_xyz; // per-iteration copy buffer (mCopySpectral)
+	std::vector<float> last_xyz; // unfiltered per-path sums of the last iteration
+	std::vector<uint32_t> samples, feedback, prim_entity, prim_prim;
+	std::atomic<uint64_t> stats[PRGPU_STAT_COUNT];
+	std::atomic<uint64_t> cnt_nodes{ 0 }, cnt_tris{ 0 };
+};
+
+// ---- spectral node evaluation (loader/shader/ConstNode.cpp, EquidistantSpectrumNode.h:19-28,
+// node/SpectralMathNode.cpp:97) --------------------------------------------------------------------
+Blob spectrum_eval(const Scene& s, uint32_t id, const Blob& wl)
+{
+	const prgpu_spectrum& n = s.spectra[id];
+	switch (n.kind) {
+	case PRGPU_SPEC_CONST: return blob(n.p[0]);
+	case PRGPU_SPEC_PARAMETRIC: return blob4(upsample(n.p, wl[0]), upsample(n.p, wl[1]), upsample(n.p, wl[2]), upsample(n.p, wl[3]));
+	case PRGPU_SPEC_PARAMETRIC_SCALED:
+		return blob4(upsample(n.p, wl[0]) * n.p[3], upsample(n.p, wl[1]) * n.p[3], upsample(n.p, wl[2]) * n.p[3], upsample(n.p, wl[3]) * n.p[3]);
+	case PRGPU_SPEC_TABLE: {
+		const float delta = (n.wl_end - n.wl_start) / (n.table_count - 1);
+		const float* data = &s.tables[n.table_offset];
+		Blob b;
+		for (int k = 0; k < 4; ++k)
+			b[k] = equidistant_lookup(data, (int)n.table_count, n.wl_start, delta, wl[k]);
+		return b;
+	}
+	case PRGPU_SPEC_MUL: return spectrum_eval(s, n.lhs, wl) * spectrum_eval(s, n.rhs, wl);
+	}
+	return blob(0);
+}
+// spectral/SpectralRange.h + INode::spectralRange (core/shader/INode.h:48): unbounded = (-1,-1)
+struct Range {
+	float start = -1, end = -1;
+};
+Range range_add(Range a, Range b) // SpectralRange::operator+=, SpectralRange.h:62-68
+{
+	Range r;
+	r.start = a.start < 0 ? b.start : (b.start < 0 ? a.start : std::min(a.start, b.start));
+	r.end	= std::max(a.end, b.end);
+	return r;
+}
+Range spectrum_range(const Scene& s, uint32_t id)
+{
+	const prgpu_spectrum& n = s.spectra[id];
+	if (n.kind == PRGPU_SPEC_TABLE)
+		return Range{ n.wl_start, n.wl_end };
+	if (n.kind == PRGPU_SPEC_MUL)
+		return range_add(spectrum_range(s, n.lhs), spectrum_range(s, n.rhs));
+	return Range{};
+}
+// shader/NodeUtils.cpp:7-47: average over a 32x32 UV grid (UV-independent nodes: 1024 equal terms)
+Blob node_average(const Scene& s, uint32_t id, const Blob& wl)
+{
+	const Blob v = spectrum_eval(s, id, wl);
+	Blob sum	 = v;
+	for (int i = 1; i < 1024; ++i)
+		for (int k = 0; k < 4; ++k)
+			sum[k] += v[k];
+	return sum / 1024.0f;
+}
+
+// ---- BVH build: binned SAH BVH2 over world-space triangles -------------------------------------
+inline void aabb_reset(Aabb& b)
+{
+	for (int a = 0; a < 3; ++a) {
+		b.lo[a] = PR_INF_F;
+		b.hi[a] = -PR_INF_F;
+	}
+}
+inline void aabb_add(Aabb& b, V3 p)
+{
+	const float v[3] = { p.x, p.y, p.z };
+	for (int a = 0; a < 3; ++a) {
+		b.lo[a] = std::min(b.lo[a], v[a]);
+		b.hi[a] = std::max(b.hi[a], v[a]);
+	}
+}
+inline void aabb_merge(Aabb& b, const Aabb& o)
+{
+	for (int a = 0; a < 3; ++a) {
+		b.lo[a] = std::min(b.lo[a], o.lo[a]);
+		b.hi[a] = std::max(b.hi[a], o.hi[a]);
+	}
+}
+inline float aabb_half_area(const Aabb& b)
+{
+	const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2];
+	return x * y + y * z + z * x;
+}
+// pad so that the slab test can never cull a triangle the watertight test would accept
+inline void aabb_pad(Aabb& b)
+{
+	for (int a = 0; a < 3; ++a) {
+		const float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+		const float e = m * 4e-6f + 1e-7f;
+		b.lo[a] -= e;
+		b.hi[a] += e;
+	}
+}
+
+struct BuildCtx {
+	Scene* s;
+	std::vector<Aabb> tbox;
+	std::vector<V3> tcen;
+};
+void bvh_build_rec(BuildCtx& c, uint32_t node, uint32_t first, uint32_t count)
+{
+	Scene& s = *c.s;
+	Aabb box, cbox;
+	aabb_reset(box);
+	aabb_reset(cbox);
+	for (uint32_t i = first; i < first + count; ++i) {
+		aabb_merge(box, c.tbox[s.tri_order[i]]);
+		aabb_add(cbox, c.tcen[s.tri_order[i]]);
+	}
+	s.nodes[node].box = box;
+	aabb_pad(s.nodes[node].box);
+	if (count <= 4) {
+		s.nodes[node].left	= first;
+		s.nodes[node].count = count;
+		return;
+	}
+	constexpr int BINS = 16;
+	int best_axis = -1, best_bin = -1;
+	float best_cost = PR_INF_F;
+	for (int a = 0; a < 3; ++a) {
+		const float lo = cbox.lo[a], ext = cbox.hi[a] - cbox.lo[a];
+		if (!(ext > 0))
+			continue;
+		Aabb bb[BINS];
+		uint32_t bc[BINS] = { 0 };
+		for (auto& b : bb)
+			aabb_reset(b);
+		for (uint32_t i = first; i < first + count; ++i) {
+			const uint32_t t = s.tri_order[i];
+			int bin			 = (int)(BINS * ((c.tcen[t][a] - lo) / ext));
+			bin				 = std::min(BINS - 1, std::max(0, bin));
+			bc[bin]++;
+			aabb_merge(bb[bin], c.tbox[t]);
+		}
+		float la[BINS], ra[BINS];
+		uint32_t ln[BINS], rn[BINS];
+		Aabb acc;
+		aabb_reset(acc);
+		uint32_t n = 0;
+		for (int i = 0; i < BINS; ++i) {
+			if (bc[i])
+				aabb_merge(acc, bb[i]);
+			n += bc[i];
+			la[i] = n ? aabb_half_area(acc) : 0;
+			ln[i] = n;
+		}
+		aabb_reset(acc);
+		n = 0;
+		for (int i = BINS - 1; i >= 0; --i) {
+			if (bc[i])
+				aabb_merge(acc, bb[i]);
+			n += bc[i];
+			ra[i] = n ? aabb_half_area(acc) : 0;
+			rn[i] = n;
+		}
+		for (int i = 0; i < BINS - 1; ++i) {
+			if (!ln[i] || !rn[i + 1])
+				continue;
+			const float cost = la[i] * ln[i] + ra[i + 1] * rn[i + 1];
+			if (cost < best_cost) {
+				best_cost = cost;
+				best_axis = a;
+				best_bin  = i;
+			}
+		}
+	}
+	uint32_t mid;
+	if (best_axis < 0) { // all centroids coincide: split in the middle
+		mid = first + count / 2;
+	} else {
+		const float lo = cbox.lo[best_axis], ext = cbox.hi[best_axis] - cbox.lo[best_axis];
+		auto it = std::partition(s.tri_order.begin() + first, s.tri_order.begin() + first + count, [&](uint32_t t) {
+			int bin = (int)(BINS * ((c.tcen[t][best_axis] - lo) / ext));
+			bin		= std::min(BINS - 1, std::max(0, bin));
+			return bin <= best_bin;
+		});
+		mid = (uint32_t)(it - s.tri_order.begin());
+		if (mid == first || mid == first + count)
+			mid = first + count / 2;
+	}
+	const uint32_t left = (uint32_t)s.nodes.size();
+	s.nodes.push_back(BvhNode{});
+	s.nodes.push_back(BvhNode{});
+	s.nodes[node].left	= left;
+	s.nodes[node].count = 0;
+	bvh_build_rec(c, left, first, mid - first);
+	bvh_build_rec(c, left + 1, mid, first + count - mid);
+}
+void bvh_build(Scene& s)
+{
+	const uint32_t n = s.d.n_triangles;
+	BuildCtx c;
+	c.s = &s;
+	c.tbox.resize(n);
+	c.tcen.resize(n);
+	s.tri_order.resize(n);
+	for (uint32_t t = 0; t < n; ++t) {
+		aabb_reset(c.tbox[t]);
+		for (int k = 0; k < 3; ++k)
+			aabb_add(c.tbox[t], s.wv[3 * t + k]);
+		c.tcen[t]	   = v3(0.5f * (c.tbox[t].lo[0] + c.tbox[t].hi[0]), 0.5f * (c.tbox[t].lo[1] + c.tbox[t].hi[1]),
+						0.5f * (c.tbox[t].lo[2] + c.tbox[t].hi[2]));
+		s.tri_order[t] = t;
+	}
+	s.nodes.clear();
+	s.nodes.reserve(2 * n);
+	s.nodes.push_back(BvhNode{});
+	bvh_build_rec(c, 0, 0, n);
+}
+
+// closest hit: tmin < t <= tmax; equal t -> lower global triangle index wins (documented tie rule)
+inline void test_tri_closest(const Scene& s, const RayPre& r, uint32_t tri, float tmin, Hit& best)
+{
+	float t, u, v;
+	if (!woop(r, s.wv[3 * tri], s.wv[3 * tri + 1], s.wv[3 * tri + 2], t, u, v))
+		return;
+	if (!(t > tmin))
+		return;
+	if (t < best.t || (t == best.t && tri < best.tri)) {
+		best.t	 = t;
+		best.u	 = u;
+		best.v	 = v;
+		best.tri = tri;
+	}
+}
+Hit trace_closest(Scene& s, V3 o, V3 d, float tmin, float tmax, bool brute, bool count = false)
+{
+	const RayPre r = ray_prepare(o, d);
+	Hit best{ tmax, 0, 0, INVALID };
+	// t <= tmax accepted: start with best.t = tmax and tri = INVALID so that t == tmax still wins
+	if (brute) {
+		for (uint32_t t = 0; t < s.d.n_triangles; ++t)
+			test_tri_closest(s, r, t, tmin, best);
+		return best;
+	}
+	uint32_t stack[128];
+	int sp		= 0;
+	stack[sp++] = 0;
+	uint64_t nn = 0, nt = 0;
+	while (sp) {
+		const BvhNode& n = s.nodes[stack[--sp]];
+		float te;
+		if (!box_hit(r, n.box, tmin, best.t, te))
+			continue;
+		++nn;
+		if (n.count) {
+			for (uint32_t i = 0; i < n.count; ++i)
+				test_tri_closest(s, r, s.tri_order[n.left + i], tmin, best);
+			nt += n.count;
+		} else {
+			float t0, t1;
+			const bool h0 = box_hit(r, s.nodes[n.left].box, tmin, best.t, t0);
+			const bool h1 = box_hit(r, s.nodes[n.left + 1].box, tmin, best.t, t1);
+			if (h0 && h1) {
+				if (t0 <= t1) {
+					stack[sp++] = n.left + 1;
+					stack[sp++] = n.left;
+				} else {
+					stack[sp++] = n.left;
+					stack[sp++] = n.left + 1;
+				}
+			} else if (h0)
+				stack[sp++] = n.left;
+			else if (h1)
+				stack[sp++] = n.left + 1;
+		}
+	}
+	if (count) {
+		s.cnt_nodes += nn;
+		s.cnt_tris += nt;
+	}
+	return best;
+}
+// Scene::traceShadowRay (Scene.cpp:266-280): any hit in (tmin, distance - 0.001]
+bool trace_any(Scene& s, V3 o, V3 d, float tmin, float distance, bool brute)
+{
+	const float tmax = distance - 0.001f;
+	const RayPre r	 = ray_prepare(o, d);
+	auto test = [&](uint32_t tri) {
+		float t, u, v;
+		if (!woop(r, s.wv[3 * tri], s.wv[3 * tri + 1], s.wv[3 * tri + 2], t, u, v))
+			return false;
+		return t > tmin && t <= tmax;
+	};
+	if (brute) {
+		for (uint32_t t = 0; t < s.d.n_triangles; ++t)
+			if (test(t))
+				return true;
+		return false;
+	}
+	uint32_t stack[128];
+	int sp		= 0;
+	stack[sp++] = 0;
+	while (sp) {
+		const BvhNode& n = s.nodes[stack[--sp]];
+		float te;
+		if (!box_hit(r, n.box, tmin, tmax, te))
+			continue;
+		if (n.count) {
+			for (uint32_t i = 0; i < n.count; ++i)
+				if (test(s.tri_order[n.left + i]))
+					return true;
+		} else {
+			stack[sp++] = n.left + 1;
+			stack[sp++] = n.left;
+		}
+	}
+	return false;
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry point: MeshEntity::provideGeometryPoint (entities/mesh.cpp:205-250), MeshBase::getFace
+// (mesh/MeshBase.inl:96-134), Triangle::interpolate (geometry/Triangle.h:22-27)
+struct GeomPoint {
+	V3 N, Nx, Ny;
+	uint32_t entity, prim, material, emission;
+};
+inline V3 tri_interp(V3 a0, V3 a1, V3 a2, float u, float v) { return (a1 * u + a2 * v) + a0 * (1 - u - v); }
+inline V3 load3(const std::vector<float>& a, uint32_t i) { return v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+void geometry_point(const Scene& s, uint32_t tri, float u, float v, GeomPoint& g)
+{
+	const uint32_t e	 = s.tri_entity[tri];
+	const prgpu_entity& E = s.entities[e];
+	const uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+	V3 N, Nx, Ny;
+	if (E.has_normals && s.has_normals_array) {
+		N = tri_interp(load3(s.normals, i0), load3(s.normals, i1), load3(s.normals, i2), u, v);
+		frame_duff(N, Nx, Ny); // Tangent::unnormalized_frame on the interpolated (unnormalised) normal
+	} else {
+		// rtcInterpolate dPdu / dPdv of a triangle: p1-p0, p2-p0 (mesh.cpp:51-80,216-219)
+		Nx = load3(s.positions, i1) - load3(s.positions, i0);
+		Ny = load3(s.positions, i2) - load3(s.positions, i0);
+		N  = cross(Nx, Ny);
+	}
+	const float* nm = s.nmat[e].data();
+	g.N		   = normalized(mat3_mul(nm, N));
+	g.Nx	   = normalized(mat3_mul(nm, Nx));
+	g.Ny	   = normalized(mat3_mul(nm, Ny));
+	g.entity   = e;
+	g.prim	   = tri - E.first_tri;
+	g.material = s.tri_material[tri];
+	g.emission = E.emission;
+}
+
+// ------------------------------------------------------------------------------------------------
+// samplers (RenderTile.cpp:33-44 slots; SamplerManager defaults)
+void setup_samplers(Scene& s)
+{
+	const prgpu_settings& c = s.cfg;
+	s.spp = c.aa_samples * c.lens_samples * c.time_samples * c.spectral_samples; // RenderSettings.cpp:76-88
+	// RenderTile.cpp:33-35: slot generators seeded seed ^ (4201321 + slot); AA slot = 1
+	Rng aa = rng_seed(c.seed ^ (uint64_t(4201321) + 1));
+	if (c.aa_sampler == PRGPU_SAMPLER_MJITT) {
+		// MultiJitteredSampler.cpp:100-108,173-176: bins = sample_count, seed = PRIME ^ rnd.get32()
+		const uint32_t bins = std::max(1u, s.spp);
+		s.mj_x				= (uint32_t)std::sqrt((float)bins);
+		s.mj_y				= (bins + s.mj_x - 1) / s.mj_x;
+		s.mj_seed			= 14512081u ^ rng_u32(aa);
+	} else if (c.aa_sampler == PRGPU_SAMPLER_SOBOL) {
+		// SobolSampler.cpp:27-55.  Direction numbers: dimension 0 = van der Corput (2^63 >> k),
+		// dimension 1 = v_k = v_{k-1} ^ (v_{k-1} >> 1) (SobolSamplerData.inl rows 0 and 1).
+		uint64_t V0[64], V1[64];
+		for (int k = 0; k < 64; ++k)
+			V0[k] = uint64_t(1) << (63 - k);
+		V1[0] = uint64_t(1) << 63;
+		for (int k = 1; k < 64; ++k)
+			V1[k] = V1[k - 1] ^ (V1[k - 1] >> 1);
+		auto u64_to_float = [](uint64_t v) { // Random::uint64ToDouble then float cast
+			const uint64_t u = (v >> 12) | 0x3FF0000000000000ULL;
+			double f;
+			std::memcpy(&f, &u, 8);
+			return (float)(f - 1.0);
+		};
+		const uint32_t n = s.spp;
+		std::vector<float> s1(n);
+		std::vector<std::array<float, 2>> s2(n);
+		uint64_t last0 = 0, last1 = 0;
+		if (n) {
+			s1[0] = 0;
+			s2[0] = { 0, 0 };
+		}
+		for (uint32_t i = 1; i < n; ++i) {
+			uint32_t m = i - 1, cin = 1; // irfz: index (from 1) of the first zero bit from the right
+			while (m & 1) {
+				m >>= 1;
+				++cin;
+			}
+			last0 ^= V0[cin - 1];
+			last1 ^= V1[cin - 1];
+			s1[i] = u64_to_float(last0);
+			s2[i] = { s1[i], u64_to_float(last1) };
+		}
+		std_shuffle(s1, aa); // mSamples1D (consumes draws; unused by the AA slot)
+		std_shuffle(s2, aa); // mSamples2D
+		s.sobol2d.resize(2 * size_t(n));
+		for (uint32_t i = 0; i < n; ++i) {
+			s.sobol2d[2 * i]	 = s2[i][0];
+			s.sobol2d[2 * i + 1] = s2[i][1];
+		}
+	}
+}
+inline void aa_sample(const Scene& s, Rng& rnd, uint32_t index, float& x, float& y)
+{
+	switch (s.cfg.aa_sampler) {
+	case PRGPU_SAMPLER_MJITT: { // MultiJitteredSampler.cpp:118-150 (PR_MJS_USE_RANDOM, PR_MJS_CLIP)
+		const uint32_t n  = std::max(1u, s.spp);
+		const uint32_t id = mjitt_permute(index, n, s.mj_seed * 0x51633e2d);
+		const uint32_t sx = mjitt_permute(id % s.mj_x, s.mj_x, s.mj_seed * 0x68bc21eb);
+		const uint32_t sy = mjitt_permute(id / s.mj_x, s.mj_y, s.mj_seed * 0x02e5be93);
+		const float jx	  = rng_float(rnd);
+		const float jy	  = rng_float(rnd);
+		x				  = (sx + (sy + jx) / s.mj_y) / s.mj_x;
+		y				  = (id + jy) / n;
+		break;
+	}
+	case PRGPU_SAMPLER_SOBOL: // SobolSampler.cpp:67-73
+		if (index < s.spp) {
+			x = s.sobol2d[2 * index];
+			y = s.sobol2d[2 * index + 1];
+			break;
+		}
+		[[fallthrough]]; // beyond the table -> rnd.get2D()
+	default: // RandomSampler.cpp:20-21 (left-to-right draw order fixed by the oracle)
+		x = rng_float(rnd);
+		y = rng_float(rnd);
+		break;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// lights: LightSampler ctor (light/LightSampler.cpp:11-132), area lights only
+int setup_lights(Scene& s)
+{
+	const uint32_t ne = (uint32_t)s.entities.size();
+	s.entity_light.assign(ne, INVALID);
+	const float test_wvl_distr[4] = { 0.05f, 0.05f + 1 * ((0.95f - 0.05f) / 3), 0.05f + 2 * ((0.95f - 0.05f) / 3), 0.95f };
+	for (uint32_t e = 0; e < ne; ++e) {
+		const uint32_t ems = s.entities[e].emission;
+		if (ems == INVALID)
+			continue;
+		const Range node = spectrum_range(s, s.emissions[ems].radiance);
+		// range.bounded(cameraRange), SpectralRange.h:33-39
+		const float rs = node.start < 0 ? s.cfg.spectral_start : node.start;
+		const float re = node.end < 0 ? s.cfg.spectral_end : node.end;
+		Blob wl;
+		for (int k = 0; k < 4; ++k)
+			wl[k] = rs + (re - rs) * test_wvl_distr[k];
+		const Blob pw		  = node_average(s, s.emissions[ems].radiance, wl);
+		const float intensity = s.world_area[e] * (bsum(pw) / 4.0f);
+		s.entity_light[e]	  = (uint32_t)s.light_entity.size();
+		s.light_entity.push_back(e);
+		s.light_intensity.push_back(intensity);
+	}
+	const uint32_t nl = (uint32_t)s.light_entity.size();
+	if (nl) {
+		s.light_cdf.resize(nl + 1);
+		float full;
+		distribution_generate(s.light_intensity.data(), nl, s.light_cdf.data(), &full);
+		if (full > PR_EPS) {
+			const float inv = 1 / full;
+			for (float& f : s.light_intensity)
+				f *= inv;
+		}
+	}
+	return 0;
+}
+// spectralmapper/spd.cpp:220-351 buildDistribution (440 bins, normalised lights, CIE XYZ weighting,
+// complete sampling floor 1e-2)
+void setup_wavelengths(Scene& s)
+{
+	const uint32_t bins = 440; // PR_CIE_WAVELENGTH_RANGE
+	const float start = s.cfg.spectral_start, span = s.cfg.spectral_end - s.cfg.spectral_start;
+	auto bin2wvl = [&](uint32_t bin) { return start + (bin / float(bins - 1)) * span; };
+	std::vector<float> full(bins, 0.0f), lp(bins, 0.0f);
+	for (uint32_t l = 0; l < s.light_entity.size(); ++l) {
+		const uint32_t node = s.emissions[s.entities[s.light_entity[l]].emission].radiance;
+		for (uint32_t i = 0; i < bins; i += 4) {
+			const uint32_t k = std::min<uint32_t>(bins - i, 4);
+			Blob wl = blob(0);
+			for (uint32_t j = 0; j < k; ++j)
+				wl[j] = bin2wvl(i + j);
+			for (uint32_t j = k; j < 4; ++j)
+				wl[j] = wl[0];
+			const Blob out = node_average(s, node, wl);
+			for (uint32_t j = 0; j < k; ++j)
+				lp[i + j] = out[j];
+		}
+		const float dt = 1.0f / (bins - 1);
+		float integral = 0;
+		for (float f : lp)
+			integral += f * dt;
+		if (integral > PR_EPS) {
+			const float invnorm = 1 / integral;
+			for (float& f : lp)
+				f *= invnorm;
+		}
+		for (uint32_t i = 0; i < bins; ++i)
+			full[i] += lp[i];
+	}
+	const bool crosses = !(start > CIE_END || s.cfg.spectral_end < CIE_START);
+	if (crosses) {
+		for (uint32_t i = 0; i < bins; ++i) {
+			float xyz[3];
+			cie_eval(bin2wvl(i), xyz);
+			full[i] *= (xyz[0] + xyz[1]) + xyz[2];
+		}
+	}
+	for (float& f : full)
+		f = std::max(1e-2f, f);
+	s.wl_cdf.resize(bins + 1);
+	distribution_generate(full.data(), bins, s.wl_cdf.data(), nullptr);
+}
+
+// camera cache: perspective.cpp:84-113
+void setup_camera(Scene& s)
+{
+	const prgpu_camera& c = s.d.camera;
+	const V3 dir   = linear_mul(c.transform, v3(c.local_direction[0], c.local_direction[1], c.local_direction[2]));
+	V3 right	   = linear_mul(c.transform, v3(c.local_right[0], c.local_right[1], c.local_right[2]));
+	V3 up		   = linear_mul(c.transform, v3(c.local_up[0], c.local_up[1], c.local_up[2]));
+	s.cam_o		   = v3(c.transform[3], c.transform[7], c.transform[11]);
+	s.cam_dof	   = c.aperture_radius > PR_EPS && c.fstop > PR_EPS; // perspective.cpp:158
+	if (!s.cam_dof) {
+		s.cam_focal = dir;
+		s.cam_xap = s.cam_yap = v3(0, 0, 0);
+		s.cam_right = right * (0.5f * c.width);
+		s.cam_up	= up * (0.5f * c.height);
+	} else {
+		s.cam_focal = dir * (c.fstop + 1);
+		s.cam_xap	= right * c.aperture_radius;
+		s.cam_yap	= up * c.aperture_radius;
+		s.cam_right = right * (0.5f * c.width * (c.fstop + 1));
+		s.cam_up	= up * (0.5f * c.height * (c.fstop + 1));
+	}
+}
+// perspective.cpp:45-82
+inline void camera_ray(const Scene& s, float px, float py, float r1, float r2, V3& o, V3& d)
+{
+	const float nx = 2 * (px / (float)s.cfg.width - 0.5f);
+	const float ny = -(2 * (py / (float)s.cfg.height - 0.5f));
+	o			   = s.cam_o;
+	d			   = (s.cam_right * nx + s.cam_up * ny) + s.cam_focal;
+	if (s.cam_dof) {
+		float sn, cs;
+		sincos_2pi(r1, sn, cs);
+		const V3 e = s.cam_xap * (r2 * sn) + s.cam_yap * (r2 * cs);
+		o		   = o + e;
+		d		   = d - e;
+	}
+	d = normalized(d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-thread output of one tile (LocalFrameOutputDevice)
+struct TileOut {
+	int x0, y0, w, h, r; // tile origin, extended size incl. apron
+	std::vector<float> xyz;
+	std::vector<uint32_t> samples, feedback;
+	uint64_t stats[PRGPU_STAT_COUNT] = { 0 };
+};
+
+struct PathCtx { // direct.cpp:47-57 TraversalContext
+	Blob throughput, path_pdf, prev_path_pdf, wvl_pdf;
+	bool last_delta = true, last_emissive = false;
+	V3 last_pos, last_n;
+};
+struct RayState {
+	V3 o, d;
+	float tmin, tmax;
+	Blob wl;
+	uint32_t depth;
+	bool mono;
+	uint32_t pixel;
+};
+
+// RenderTileSession::pushSpectralFragment (RenderTileSession.cpp:133-142) +
+// LocalFrameOutputDevice::commitSpectrals2 (LocalFrameOutputDevice.cpp:88-164)
+inline void push_fragment(const Scene& s, TileOut& out, int lx, int ly, const Blob& mis, const Blob& importance,
+						  const Blob& grp_importance, const Blob& radiance, bool mono, const Blob& grp_wl, float blend, float* path_sum)
+{
+	const Blob imp		  = grp_importance * importance;
+	const Blob heroFactor = mono ? hero_only() : blob(1);
+	const Blob contrib	  = heroFactor * ((mis * imp) * radiance);
+	bool isInf = false, isNaN = false, isNeg = false;
+	for (int k = 0; k < 4; ++k) {
+		isInf |= std::isinf(contrib[k]);
+		isNaN |= std::isnan(contrib[k]);
+		isNeg |= contrib[k] < -PR_EPS;
+	}
+	const int r	 = out.r;
+	const int rx = lx + r, ry = ly + r;
+	if (isInf || isNaN || isNeg) {
+		uint32_t fb = 0; // output/Feedback.h:6-12
+		if (isNaN)
+			fb |= 0x1;
+		if (isInf)
+			fb |= 0x2;
+		if (isNeg)
+			fb |= 0x4;
+		out.feedback[size_t(ry) * out.w + rx] |= fb;
+		return;
+	}
+	float triplet[3] = { 0, 0, 0 };
+	const bool monoSpectrum = s.cfg.spectral_mono != 0; // mMonotonic
+	if (monoSpectrum) {
+		triplet[0] = triplet[1] = triplet[2] = contrib[0];
+	} else {
+		for (int k = 0; k < 4; ++k) {
+			float xyz[3];
+			cie_eval(grp_wl[k], xyz);
+			for (int c = 0; c < 3; ++c)
+				triplet[c] += contrib[k] * xyz[c];
+		}
+	}
+	if (path_sum)
+		for (int c = 0; c < 3; ++c)
+			path_sum[c] += blend * triplet[c];
+	const int d = 2 * r + 1;
+	for (int py = std::max(0, ry - r); py <= std::min(out.h - 1, ry + r); ++py) {
+		for (int px = std::max(0, rx - r); px <= std::min(out.w - 1, rx + r); ++px) {
+			const float fw = s.filter[(py - ry + r) * d + (px - rx + r)];
+			if (fw > PR_EPS) {
+				const float w = fw * blend;
+				for (int c = 0; c < 3; ++c)
+					out.xyz[(size_t(py) * out.w + px) * 3 + c] += w * triplet[c];
+			}
+		}
+	}
+}
+
+// RussianRoulette::probability (vcm/RussianRoulette.h:22-35), table built in scene_create
+inline float rr_probability(const Scene& s, uint32_t path_length)
+{
+	return path_length < s.rr_prob.size() ? s.rr_prob[path_length] : s.rr_prob.back();
+}
+
+// one camera sample: RenderTile::constructCameraRay (RenderTile.cpp:71-132) then the path
+// (direct.cpp:73-464, vcm/Walker.h:23-54)
+void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
+{
+	const prgpu_settings& cfg = s.cfg;
+	const uint32_t pixel = uint32_t(gy) * cfg.width + uint32_t(gx);
+	Rng rnd{ s.rng[pixel] };
+	uint64_t* st = out.stats;
+	const int lx = gx - out.x0, ly = gy - out.y0;
+	float* path_sum = &s.last_xyz[size_t(pixel) * 3];
+	path_sum[0] = path_sum[1] = path_sum[2] = 0;
+
+	st[PRGPU_STAT_PIXEL_SAMPLES]++;
+	float ax, ay;
+	aa_sample(s, rnd, iter, ax, ay);
+	const float px = (float)gx + ax - 0.5f, py = (float)gy + ay - 0.5f;
+	const float l1 = rng_float(rnd), l2 = rng_float(rnd); // lens sampler `random` (RenderTile.cpp:87)
+	(void)rng_float(rnd);								   // time sampler `random` (RenderTile.cpp:88)
+	Blob wl, wl_pdf;
+	float blend = 1.0f;
+	if (cfg.spectral_mono) {
+		wl	   = blob(cfg.spectral_start);
+		wl_pdf = blob(1.0f);
+	} else if (cfg.mapper == PRGPU_MAPPER_SPD_CMIS) { // spd.cpp:40-48
+		const float span = cfg.spectral_end - cfg.spectral_start;
+		for (int k = 0; k < 4; ++k) {
+			float pdf;
+			const float v = distribution_sample_continuous(s.wl_cdf.data(), (uint32_t)s.wl_cdf.size(), rng_float(rnd), pdf);
+			wl[k]		  = v * span + cfg.spectral_start;
+			wl_pdf[k]	  = pdf;
+		}
+	} else if (cfg.mapper == PRGPU_MAPPER_SPD_HERO) { // spd.cpp:103-113 + Standard.h constructHeroWavelength
+		const float span = cfg.spectral_end - cfg.spectral_start;
+		float pdf;
+		const float v	 = distribution_sample_continuous(s.wl_cdf.data(), (uint32_t)s.wl_cdf.size(), rng_float(rnd), pdf);
+		const float hero = v * span + cfg.spectral_start;
+		const float delta = span / 4;
+		wl[0]			  = hero;
+		for (int k = 1; k < 4; ++k)
+			wl[k] = cfg.spectral_start + std::fmod(hero - cfg.spectral_start + k * delta, span);
+		wl_pdf = blob(pdf);
+	} else { // random.cpp:22-36
+		const float u	  = rng_float(rnd);
+		const float span  = cfg.spectral_end - cfg.spectral_start;
+		const float delta = span / 4;
+		const float start = u * span;
+		wl[0]			  = start + cfg.spectral_start;
+		for (int k = 1; k < 4; ++k)
+			wl[k] = cfg.spectral_start + std::fmod(start + k * delta, span);
+		wl_pdf = blob(1.0f);
+	}
+	RayState ray;
+	camera_ray(s, px, py, l1, l2, ray.o, ray.d);
+	ray.tmin  = s.d.camera.near_t;
+	ray.tmax  = s.d.camera.far_t;
+	ray.wl	  = wl;
+	ray.depth = 0;
+	ray.mono  = cfg.spectral_mono || !cfg.spectral_hero; // RenderTile.cpp:123-124
+	ray.pixel = pixel;
+	Blob grp_importance = blob(1.0f);
+	if (ray.mono)
+		grp_importance = grp_importance * hero_only(); // RenderTile.cpp:126-127
+	st[PRGPU_STAT_CAMERA_RAYS]++;
+	st[PRGPU_STAT_PRIMARY_RAYS]++;
+
+	PathCtx cur;
+	cur.throughput = blob(1);
+	cur.path_pdf = blob(1);
+	cur.prev_path_pdf = blob(1);
+	cur.wvl_pdf	 = wl_pdf;
+	cur.last_pos = v3(0, 0, 0);
+	cur.last_n	 = v3(0, 0, 0);
+
+	auto push = [&](const Blob& mis, const Blob& radiance, bool mono) {
+		push_fragment(s, out, lx, ly, mis, cur.throughput, grp_importance, radiance, mono, wl, blend, path_sum);
+	};
+	auto hero_factor = [](bool mono) { return mono ? hero_only() : blob(1); };
+	const bool power_mis = cfg.mis == PRGPU_MIS_POWER;
+	auto mis_f = [&](float a) { return power_mis ? a * a : a; };				  // vcm/MIS.h:13-29
+	auto mis_b = [&](const Blob& a) { return power_mis ? a * a : a; };
+
+	for (;;) {
+		const Hit hit = trace_closest(s, ray.o, ray.d, ray.tmin, ray.tmax, false);
+		if (ray.depth == 0) {
+			s.prim_entity[pixel] = hit.tri == INVALID ? INVALID : s.tri_entity[hit.tri];
+			s.prim_prim[pixel]	 = hit.tri == INVALID ? INVALID : hit.tri - s.entities[s.tri_entity[hit.tri]].first_tri;
+		}
+		if (hit.tri == INVALID) {
+			// depth 0: IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53);
+			// depth>0: handleZero (direct.cpp:459-464).  No infinite lights in this restatement.
+			st[PRGPU_STAT_BACKGROUND_HITS]++;
+			if (ray.depth == 0) {
+				st[PRGPU_STAT_CAMERA_DEPTH]++;
+				const Blob one = blob(1);
+				push_fragment(s, out, lx, ly, one, one, grp_importance, blob(0), ray.mono, wl, blend, path_sum);
+			} else {
+				const Blob hf = hero_factor(ray.mono);
+				push(hf / (cur.wvl_pdf * bsum(hf)), blob(0), ray.mono);
+			}
+			break;
+		}
+		// IntersectionPoint::setForSurface (trace/IntersectionPoint.h:61-75)
+		const V3 P = ray.o + ray.d * hit.t; // Ray::t
+		GeomPoint gp;
+		geometry_point(s, hit.tri, hit.u, hit.v, gp);
+		const V3 N		  = gp.N;
+		const float NdotV = dot(ray.d, N);
+		const V3 dP		  = ray.o - P;
+		const float depth2 = dot(dP, dP);
+
+		// ---- handleCameraVertex (direct.cpp:73-105)
+		const uint32_t pathLength = ray.depth + 1;
+		st[PRGPU_STAT_ENTITY_HITS]++;
+		st[PRGPU_STAT_CAMERA_DEPTH]++;
+		if (pathLength == 1)
+			out.samples[size_t(ly + out.r) * out.w + (lx + out.r)] += 1; // pushSPFragment -> AOV_SampleCount
+		const bool hasEmission = gp.emission != INVALID;
+		if (cfg.direct && hasEmission) {
+			// ---- handleDirectHit (direct.cpp:355-412)
+			const float cosC = -NdotV;
+			if (!(std::fabs(cosC) <= PR_EPS)) {
+				const bool behind = cosC < 0.0f;
+				const Blob radiance = behind ? blob(0) : spectrum_eval(s, s.emissions[gp.emission].radiance, ray.wl);
+				const Blob hf		= hero_factor(ray.mono);
+				if (!cfg.nee || behind || cur.last_delta) {
+					push(hf / (cur.wvl_pdf * bsum(hf)), radiance, ray.mono);
+				} else {
+					const uint32_t lid	= s.entity_light[gp.entity];
+					const float selProb = s.light_cdf[lid + 1] - s.light_cdf[lid]; // pdfEntitySelection
+					float posPDF		= 1.0f / s.world_area[gp.entity];		   // IEntity.h:93-96
+					posPDF				= posPDF * depth2 / std::fabs(cosC);	   // IS::toSolidAngle
+					const float posPDF_S = posPDF * selProb;
+					const float denom	 = bsum(mis_b(cur.prev_path_pdf * posPDF_S)) + bsum(mis_b(cur.path_pdf));
+					const Blob mis		 = (hf * mis_f(cur.path_pdf[0])) / (mis_b(cur.wvl_pdf) * denom);
+					push(mis, radiance, ray.mono);
+				}
+			}
+			if (!cfg.emissive_scatter)
+				break;
+		}
+		if (gp.material == INVALID)
+			break;
+		const prgpu_material& mat = s.materials[gp.material];
+		// tangent-space view vector: MaterialSampleContext::fromIP (MaterialContext.h:27-44)
+		const V3 Vt = to_tangent_space(N, gp.Nx, gp.Ny, -ray.d);
+
+		if (cfg.nee && !hasEmission && !s.light_entity.empty()) {
+			// ---- handleNEE (direct.cpp:233-352)
+			do {
+				float selPdf;
+				const uint32_t lid = distribution_sample_discrete(s.light_cdf.data(), (uint32_t)s.light_cdf.size(), rng_float(rnd), selPdf, nullptr);
+				const uint32_t le  = s.light_entity[lid];
+				const prgpu_entity& LE = s.entities[le];
+				// MeshEntity::sampleParameterPoint (mesh.cpp:187-203) with SplitSample2D (SplitSample.h:6-55)
+				const float u0 = rng_float(rnd), u1 = rng_float(rnd);
+				float k0, k1;
+				const float f0		= std::modf(u0 * LE.n_tris, &k0);
+				const float f1		= std::modf(u1 * LE.n_tris, &k1);
+				const uint32_t face = std::min<uint32_t>((uint32_t)k0, LE.n_tris - 1);
+				(void)k1;
+				const uint32_t tri = LE.first_tri + face;
+				const uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+				const V3 p0 = load3(s.positions, i0), p1 = load3(s.positions, i1), p2 = load3(s.positions, i2);
+				const V3 ee = cross(p1 - p0, p2 - p0);
+				const float area  = 0.5f * std::sqrt(dot(ee, ee)); // Triangle::surfaceArea (local space)
+				const float pdf_a = 1.0f / (LE.n_tris * area * s.vol_scale[le]);
+				float bu, bv; // Triangle::sample (Triangle.h:46-55)
+				if (f1 > f0) {
+					const float x = f0 / 2;
+					bu = x;
+					bv = f1 - x;
+				} else {
+					const float y = f1 / 2;
+					bu = f0 - y;
+					bv = y;
+				}
+				const V3 lp = affine_mul(LE.transform, tri_interp(p0, p1, p2, bu, bv));
+				GeomPoint lgp;
+				geometry_point(s, tri, bu, bv, lgp);
+				// Light::sample area branch (light/Light.cpp:159-225)
+				const V3 L			 = normalized(lp - P);
+				const float cosLight = std::min(1.0f, std::max(-1.0f, -dot(L, lgp.N)));
+				const Blob radiance	 = spectrum_eval(s, s.emissions[LE.emission].radiance, ray.wl);
+				const V3 dLP		 = lp - P;
+				const float sqrD	 = dot(dLP, dLP);
+				const float cosC	 = std::fabs(dot(L, N));
+				const float cosL	 = std::fabs(cosLight);
+				if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
+					break;
+				// LambertMaterial::eval (lambert.cpp:33-42)
+				const V3 Lt		= to_tangent_space(N, gp.Nx, gp.Ny, L);
+				const bool same = std::signbit(Vt.z) == std::signbit(Lt.z);
+				const float dt	= same ? (mat.two_sided ? std::fabs(Lt.z) : std::max(0.0f, Lt.z)) : 0.0f;
+				const Blob weight = (spectrum_eval(s, mat.albedo, ray.wl) * dt) * PR_INV_PI_F;
+				const float bsdf_pdf = dt * PR_INV_PI_F;
+				const bool rayMono	 = ray.mono;
+				const Blob rayHero	 = rayMono ? hero_only() : blob(1);
+				const Blob hf		 = rayMono ? hero_only() : blob(1);
+				const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+				if (all_le(bsdfWvlPdfS, PDF_EPS))
+					break;
+				const Blob connectionW = radiance * weight;
+				const bool worth	   = !is_zero(connectionW, PR_EPS);
+				float lightPdfS		   = pdf_a * sqrD / cosL; // IS::toSolidAngle
+				lightPdfS *= selPdf;
+				if (!std::isnormal(lightPdfS) || lightPdfS <= PDF_EPS)
+					break;
+				const Blob lightPdfS2 = (blob(1) * lightPdfS) * rayHero;
+				if (all_le(lightPdfS2, PDF_EPS))
+					break;
+				Blob mis;
+				if (cfg.direct && !cur.last_emissive) {
+					const float rr		= rr_probability(s, pathLength);
+					const Blob bsdfPdfS = bsdfWvlPdfS * rr;
+					const float denom	= bsum(mis_b(cur.path_pdf * lightPdfS2)) + bsum(mis_b(cur.path_pdf * bsdfPdfS));
+					// NOTE reference quirk (direct.cpp:321): divides by heroFactor -> inf/NaN lanes in mono mode
+					mis = blob(mis_f(cur.path_pdf[0] * lightPdfS2[0])) / ((hf * denom) * mis_b(cur.wvl_pdf));
+				} else {
+					mis = hf / (cur.wvl_pdf * bsum(hf));
+				}
+				const float distance = std::sqrt(sqrD);
+				const V3 oN			 = dot(L, N) < 0 ? -N : N; // IntersectionPoint::nextRay :113-121
+				const V3 so			 = safe_position(P, L, oN);
+				bool visible		 = false;
+				if (worth) {
+					st[PRGPU_STAT_SHADOW_RAYS]++;
+					visible = !trace_any(s, so, L, SHADOW_RAY_MIN, distance, false);
+				}
+				const Blob contrib = visible ? connectionW / lightPdfS2[0] : blob(0);
+				st[PRGPU_STAT_ENTITY_HITS]++;
+				push(mis, contrib, ray.mono);
+			} while (false);
+		}
+		cur.last_emissive = hasEmission;
+
+		// ---- handleScattering (direct.cpp:170-230)
+		cur.last_pos = P;
+		cur.last_n	 = N;
+		const float scatProb = rr_probability(s, pathLength); // RussianRoulette::check :37-48
+		if (scatProb <= PR_EPS)
+			break;
+		if (scatProb < 1.0f) {
+			const float rp = rng_float(rnd);
+			if (rp > scatProb)
+				break;
+		}
+		// LambertMaterial::sample (lambert.cpp:53-73)
+		V3 Lt;
+		Blob integral_weight, pdf_s;
+		if (!mat.two_sided && Vt.z < 0.0f) {
+			Lt = v3(0, 0, 0);
+			integral_weight = blob(0);
+			pdf_s = blob(0);
+		} else {
+			const float s1 = rng_float(rnd), s2 = rng_float(rnd);
+			Lt				= cos_hemi(s1, s2);
+			integral_weight = spectrum_eval(s, mat.albedo, ray.wl);
+			pdf_s			= blob(Lt.z * PR_INV_PI_F);
+			if (std::signbit(Vt.z) != std::signbit(Lt.z)) // ShadingVector::makeSameHemisphere
+				Lt = -Lt;
+		}
+		const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt)); // MaterialSampleOutput::globalL
+		cur.last_delta	  = false;
+		cur.prev_path_pdf = cur.path_pdf;
+		cur.path_pdf	  = cur.path_pdf * (pdf_s * scatProb);
+		if (all_le(cur.path_pdf, PDF_EPS))
+			break;
+		cur.throughput = cur.throughput * integral_weight;
+		if (is_zero(cur.throughput, PR_EPS))
+			break;
+		// next ray (Ray::next, ray/Ray.h:102-122); Walker loop bound (vcm/Walker.h:26)
+		const V3 oN = dot(L, N) < 0 ? -N : N;
+		ray.o		= safe_position(P, L, oN);
+		ray.d		= L;
+		ray.tmin	= BOUNCE_RAY_MIN;
+		ray.tmax	= PR_INF_F;
+		ray.depth += 1;
+		if (ray.depth >= cfg.max_ray_depth)
+			break;
+		st[PRGPU_STAT_CAMERA_RAYS]++;
+		st[PRGPU_STAT_BOUNCE_RAYS]++;
+		if (ray.mono)
+			st[PRGPU_STAT_MONOCHROME_RAYS]++;
+	}
+	s.rng[pixel] = rnd.s;
+}
+
+// tiles: RenderTileMap::init ZOrder (renderer/RenderTileMap.cpp:26-122): rtx x rty grid (8x8),
+// tile size ceil-divided, visited in Morton order
+struct TileRect {
+	int x0, y0, x1, y1;
+};
+std::vector<TileRect> make_tiles(int W, int H)
+{
+	const int tx = std::min(8, W), ty = std::min(8, H);
+	const int tw = (W + tx - 1) / tx, th = (H + ty - 1) / ty;
+	std::vector<TileRect> tiles;
+	for (uint64_t m = 0; m < 64 * 64 && (int)tiles.size() < tx * ty; ++m) {
+		uint32_t x, y;
+		morton_2_xy(m, x, y);
+		if ((int)x >= tx || (int)y >= ty)
+			continue;
+		TileRect t{ (int)x * tw, (int)y * th, std::min(W, (int)(x + 1) * tw), std::min(H, (int)(y + 1) * th) };
+		if (t.x0 < t.x1 && t.y0 < t.y1)
+			tiles.push_back(t);
+	}
+	return tiles;
+}
+
+void render_iteration(Scene& s, uint32_t iter, int threads)
+{
+	const int W = (int)s.cfg.width, H = (int)s.cfg.height, r = (int)s.cfg.filter_radius;
+	const std::vector<TileRect> tiles = make_tiles(W, H);
+	std::vector<TileOut> outs(tiles.size());
+	std::atomic<size_t> next{ 0 };
+	auto worker = [&]() {
+		for (;;) {
+			const size_t ti = next.fetch_add(1);
+			if (ti >= tiles.size())
+				return;
+			const TileRect& t = tiles[ti];
+			TileOut& o		  = outs[ti];
+			o.x0			  = t.x0;
+			o.y0			  = t.y0;
+			o.r				  = r;
+			o.w				  = (t.x1 - t.x0) + 2 * r;
+			o.h				  = (t.y1 - t.y0) + 2 * r;
+			o.xyz.assign(size_t(o.w) * o.h * 3, 0.0f);
+			o.samples.assign(size_t(o.w) * o.h, 0);
+			o.feedback.assign(size_t(o.w) * o.h, 0);
+			// StreamPipeline::fillWithCameraRays (StreamPipeline.cpp:83-133): Morton order over the tile
+			const int tw = t.x1 - t.x0, th = t.y1 - t.y0;
+			const uint64_t total = uint64_t(tw) * th;
+			uint64_t done = 0;
+			for (uint64_t m = 0; done < total; ++m) {
+				uint32_t x, y;
+				morton_2_xy(m, x, y);
+				if ((int)x >= tw || (int)y >= th)
+					continue;
+				++done;
+				const int gx = t.x0 + (int)x, gy = t.y0 + (int)y;
+				if (!s.owned[size_t(gy) * W + gx])
+					continue;
+				trace_sample(s, o, gx, gy, iter);
+			}
+		}
+	};
+	if (threads <= 1) {
+		worker();
+	} else {
+		std::vector<std::thread> pool;
+		for (int i = 0; i < threads; ++i)
+			pool.emplace_back(worker);
+		for (auto& t : pool)
+			t.join();
+	}
+	// FrameOutputDevice::mergeLocal (FrameOutputDevice.cpp:83-200), in tile order
+	for (size_t ti = 0; ti < tiles.size(); ++ti) {
+		const TileOut& o = outs[ti];
+		for (int y = 0; y < o.h; ++y) {
+			const int gy = o.y0 - r + y;
+			if (gy < 0 || gy >= H)
+				continue;
+			for (int x = 0; x < o.w; ++x) {
+				const int gx = o.x0 - r + x;
+				if (gx < 0 || gx >= W)
+					continue;
+				const size_t src = size_t(y) * o.w + x, dst = size_t(gy) * W + gx;
+				for (int c = 0; c < 3; ++c)
+					s.iter_xyz[dst * 3 + c] += o.xyz[src * 3 + c];
+				s.samples[dst] += o.samples[src];
+				s.feedback[dst] |= o.feedback[src];
+			}
+		}
+		for (int k = 0; k < PRGPU_STAT_COUNT; ++k)
+			s.stats[k] += o.stats[k];
+	}
+	// FrameOutputDevice::onEndOfIteration (FrameOutputDevice.cpp:202-221), iteration = iter+1
+	const float it = (float)(iter + 1), itm1 = (float)iter;
+	for (size_t i = 0; i < s.xyz.size(); ++i) {
+		s.xyz[i]	  = (s.xyz[i] * itm1 + s.iter_xyz[i]) / it;
+		s.iter_xyz[i] = 0;
+	}
+}
+
+int fail(const char* msg)
+{
+	g_error = msg;
+	return PRGPU_EINVAL;
+}
+
+int scene_setup(Scene& s, const prgpu_scene_desc* d)
+{
+	if (!d || d->api_version != PRGPU_API_VERSION)
+		return fail("bad api_version");
+	s.d	  = *d;
+	s.cfg = d->settings;
+	if (!d->n_triangles || !d->n_vertices || !d->n_entities)
+		return fail("empty scene");
+	if (!s.cfg.width || !s.cfg.height)
+		return fail("empty film");
+	if (s.cfg.filter_radius > 3)
+		return fail("filter radius > 3");
+	s.positions.assign(d->positions, d->positions + 3 * size_t(d->n_vertices));
+	s.has_normals_array = d->normals != nullptr;
+	if (d->normals)
+		s.normals.assign(d->normals, d->normals + 3 * size_t(d->n_vertices));
+	s.indices.assign(d->indices, d->indices + 3 * size_t(d->n_triangles));
+	s.tri_material.assign(d->tri_material, d->tri_material + d->n_triangles);
+	s.entities.assign(d->entities, d->entities + d->n_entities);
+	s.materials.assign(d->materials, d->materials + d->n_materials);
+	s.emissions.assign(d->emissions, d->emissions + d->n_emissions);
+	s.spectra.assign(d->spectra, d->spectra + d->n_spectra);
+	if (d->n_spectral_table_values)
+		s.tables.assign(d->spectral_tables, d->spectral_tables + d->n_spectral_table_values);
+	for (uint32_t i = 0; i < 3 * d->n_triangles; ++i)
+		if (s.indices[i] >= d->n_vertices)
+			return fail("vertex index out of range");
+	uint32_t expect = 0;
+	s.tri_entity.resize(d->n_triangles);
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& E = s.entities[e];
+		if (E.first_tri != expect || E.n_tris == 0)
+			return fail("entity triangle ranges must be contiguous, ordered and non-empty");
+		expect += E.n_tris;
+		if (E.emission != INVALID && E.emission >= d->n_emissions)
+			return fail("emission index out of range");
+		if (E.has_normals && !s.has_normals_array)
+			return fail("entity wants normals but none given");
+		for (uint32_t t = 0; t < E.n_tris; ++t)
+			s.tri_entity[E.first_tri + t] = e;
+	}
+	if (expect != d->n_triangles)
+		return fail("entity triangle ranges do not cover the index buffer");
+	for (uint32_t t = 0; t < d->n_triangles; ++t)
+		if (s.tri_material[t] != INVALID && s.tri_material[t] >= d->n_materials)
+			return fail("material index out of range");
+	for (uint32_t i = 0; i < d->n_spectra; ++i) {
+		const prgpu_spectrum& n = s.spectra[i];
+		if (n.kind > PRGPU_SPEC_MUL)
+			return fail("unknown spectrum kind");
+		if (n.kind == PRGPU_SPEC_MUL && (n.lhs >= i || n.rhs >= i))
+			return fail("MUL operands must precede the node");
+		if (n.kind == PRGPU_SPEC_TABLE && (n.table_count < 2 || n.table_offset + n.table_count > d->n_spectral_table_values))
+			return fail("spectrum table out of range");
+	}
+	for (const auto& m : s.materials)
+		if (m.kind != PRGPU_MAT_LAMBERT || m.albedo >= d->n_spectra)
+			return fail("bad material");
+	for (const auto& e : s.emissions)
+		if (e.kind != PRGPU_EMS_DIFFUSE || e.radiance >= d->n_spectra)
+			return fail("bad emission");
+
+	// world-space triangles, normal matrices, areas (IEntity::worldSurfaceArea = |det| * local area)
+	s.wv.resize(3 * size_t(d->n_triangles));
+	s.nmat.resize(d->n_entities);
+	s.vol_scale.resize(d->n_entities);
+	s.world_area.resize(d->n_entities);
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& E = s.entities[e];
+		normal_matrix(E.transform, s.nmat[e].data(), s.vol_scale[e]);
+		float area = 0;
+		for (uint32_t t = E.first_tri; t < E.first_tri + E.n_tris; ++t) {
+			V3 p[3];
+			for (int k = 0; k < 3; ++k) {
+				p[k]			 = load3(s.positions, s.indices[3 * t + k]);
+				s.wv[3 * t + k] = affine_mul(E.transform, p[k]);
+			}
+			const V3 ee = cross(p[1] - p[0], p[2] - p[0]);
+			area += 0.5f * std::sqrt(dot(ee, ee)); // MeshBase::surfaceArea (identity transform)
+		}
+		s.world_area[e] = s.vol_scale[e] * area;
+	}
+	bvh_build(s);
+	setup_camera(s);
+	setup_samplers(s);
+	setup_lights(s);
+	setup_wavelengths(s);
+	filter_table(s.cfg.filter, s.cfg.filter_radius, s.filter);
+	// RussianRoulette::probability table: min(1, pow(0.9, L - soft)) with the 1e-4 cut
+	s.rr_prob.resize(std::max<uint32_t>(s.cfg.max_ray_depth, 1) + 2);
+	for (uint32_t L = 0; L < s.rr_prob.size(); ++L) {
+		float p = 1.0f;
+		if (L != 0 && L >= s.cfg.soft_max_ray_depth) {
+			p = std::min<float>(1.0f, (float)std::pow((double)0.9f, (double)(L - s.cfg.soft_max_ray_depth)));
+			p = p <= 1e-4f ? 0.0f : p;
+		}
+		s.rr_prob[L] = p;
+	}
+	const size_t np = size_t(s.cfg.width) * s.cfg.height;
+	build_rng_map(s.cfg.seed, (uint32_t)np, s.spp, true, s.rng);
+	s.owned.assign(np, 1);
+	s.xyz.assign(np * 3, 0.0f);
+	s.iter_xyz.assign(np * 3, 0.0f);
+	s.last_xyz.assign(np * 3, 0.0f);
+	s.samples.assign(np, 0);
+	s.feedback.assign(np, 0);
+	s.prim_entity.assign(np, INVALID);
+	s.prim_prim.assign(np, INVALID);
+	for (auto& a : s.stats)
+		a = 0;
+	return PRGPU_OK;
+}
+
+} // namespace
+
+struct orc_scene {
+	Scene s;
+};
+
+extern "C" {
+
+const char* orc_last_error(void) { return g_error.c_str(); }
+
+orc_scene* orc_scene_create(const prgpu_scene_desc* desc)
+{
+	orc_scene* h = new orc_scene();
+	if (scene_setup(h->s, desc) != PRGPU_OK) {
+		delete h;
+		return nullptr;
+	}
+	return h;
+}
+void orc_scene_destroy(orc_scene* s) { delete s; }
+
+int orc_set_tiles(orc_scene* h, const prgpu_tile* tiles, uint32_t n)
+{
+	Scene& s = h->s;
+	std::fill(s.owned.begin(), s.owned.end(), n == 0 ? 1 : 0);
+	for (uint32_t i = 0; i < n; ++i) {
+		const prgpu_tile& t = tiles[i];
+		if (t.x1 > s.cfg.width || t.y1 > s.cfg.height || t.x0 > t.x1 || t.y0 > t.y1)
+			return fail("tile outside the film");
+		for (uint32_t y = t.y0; y < t.y1; ++y)
+			for (uint32_t x = t.x0; x < t.x1; ++x)
+				s.owned[size_t(y) * s.cfg.width + x] = 1;
+	}
+	return PRGPU_OK;
+}
+
+int orc_render(orc_scene* h, uint32_t iter_begin, uint32_t iter_end, int threads)
+{
+	if (threads <= 0)
+		threads = (int)std::max(1u, std::thread::hardware_concurrency());
+	for (uint32_t it = iter_begin; it < iter_end; ++it)
+		render_iteration(h->s, it, threads);
+	return PRGPU_OK;
+}
+
+int orc_download(orc_scene* h, float* xyz, uint32_t* samples, uint32_t* feedback)
+{
+	Scene& s = h->s;
+	if (xyz)
+		std::memcpy(xyz, s.xyz.data(), s.xyz.size() * 4);
+	if (samples)
+		std::memcpy(samples, s.samples.data(), s.samples.size() * 4);
+	if (feedback)
+		std::memcpy(feedback, s.feedback.data(), s.feedback.size() * 4);
+	return PRGPU_OK;
+}
+int orc_stats(orc_scene* h, uint64_t out[PRGPU_STAT_COUNT])
+{
+	for (int k = 0; k < PRGPU_STAT_COUNT; ++k)
+		out[k] = h->s.stats[k];
+	return PRGPU_OK;
+}
+int orc_download_primary_hits(orc_scene* h, uint32_t* entity, uint32_t* prim)
+{
+	std::memcpy(entity, h->s.prim_entity.data(), h->s.prim_entity.size() * 4);
+	std::memcpy(prim, h->s.prim_prim.data(), h->s.prim_prim.size() * 4);
+	return PRGPU_OK;
+}
+int orc_download_last_iteration_xyz(orc_scene* h, float* xyz)
+{
+	std::memcpy(xyz, h->s.last_xyz.data(), h->s.last_xyz.size() * 4);
+	return PRGPU_OK;
+}
+
+int orc_trace_closest(orc_scene* h, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
+					  uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, int brute)
+{
+	Scene& s = h->s;
+	for (uint32_t i = 0; i < n; ++i) {
+		const Hit hit = trace_closest(s, v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
+									  tmin[i], tmax[i], brute != 0, true);
+		const bool ok = hit.tri != INVALID;
+		if (entity)
+			entity[i] = ok ? s.tri_entity[hit.tri] : INVALID;
+		if (prim)
+			prim[i] = ok ? hit.tri - s.entities[s.tri_entity[hit.tri]].first_tri : INVALID;
+		if (u)
+			u[i] = ok ? hit.u : 0;
+		if (v)
+			v[i] = ok ? hit.v : 0;
+		if (t)
+			t[i] = ok ? hit.t : tmax[i];
+	}
+	return PRGPU_OK;
+}
+int orc_trace_any(orc_scene* h, uint32_t n, const float* org, const float* dir, const float* tmin, const float* distance,
+				  uint8_t* occluded, int brute)
+{
+	for (uint32_t i = 0; i < n; ++i)
+		occluded[i] = trace_any(h->s, v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
+								tmin[i], distance[i], brute != 0)
+						  ? 1
+						  : 0;
+	return PRGPU_OK;
+}
+int orc_trace_counters(orc_scene* h, uint64_t* nodes, uint64_t* tris)
+{
+	*nodes = h->s.cnt_nodes;
+	*tris  = h->s.cnt_tris;
+	return PRGPU_OK;
+}
+
+// ---- KAT helpers -------------------------------------------------------------------------------
+void orc_pcg_seed(uint64_t seed, uint64_t* state) { *state = rng_seed(seed).s; }
+uint32_t orc_pcg_next(uint64_t* state)
+{
+	Rng r{ *state };
+	const uint32_t v = rng_u32(r);
+	*state			 = r.s;
+	return v;
+}
+float orc_pcg_next_float(uint64_t* state)
+{
+	Rng r{ *state };
+	const float v = rng_float(r);
+	*state		  = r.s;
+	return v;
+}
+uint64_t orc_pcg_next64(uint64_t* state)
+{
+	Rng r{ *state };
+	const uint64_t v = rng_u64(r);
+	*state			 = r.s;
+	return v;
+}
+uint64_t orc_pcg_advance(uint64_t state, uint64_t delta) { return mcg_advance(state, delta); }
+uint32_t orc_pcg_bounded(uint64_t* state, uint32_t a, uint32_t b)
+{
+	Rng r{ *state };
+	const uint32_t v = rng_bounded(r, a, b);
+	*state			 = r.s;
+	return v;
+}
+void orc_shuffle_indices(uint64_t* state, uint32_t n, uint32_t* idx)
+{
+	Rng r{ *state };
+	std::vector<uint32_t> a(n);
+	for (uint32_t i = 0; i < n; ++i)
+		a[i] = i;
+	std_shuffle(a, r);
+	std::copy(a.begin(), a.end(), idx);
+	*state = r.s;
+}
+void orc_rng_map(uint64_t seed, uint32_t n, uint32_t delta, int permute, uint64_t* states)
+{
+	std::vector<uint64_t> v;
+	build_rng_map(seed, n, delta, permute != 0, v);
+	std::copy(v.begin(), v.end(), states);
+}
+uint32_t orc_mjitt_permute(uint32_t i, uint32_t l, uint32_t p) { return mjitt_permute(i, l, p); }
+void orc_sampler_2d(orc_scene* h, uint64_t* state, uint32_t index, float out[2])
+{
+	Rng r{ *state };
+	aa_sample(h->s, r, index, out[0], out[1]);
+	*state = r.s;
+}
+void orc_sobol_table(orc_scene* h, uint32_t* n, const float** t)
+{
+	*n = (uint32_t)(h->s.sobol2d.size() / 2);
+	*t = h->s.sobol2d.data();
+}
+float orc_uint_to_float(uint32_t v) { return u32_to_float(v); }
+void orc_distribution_generate(const float* values, uint32_t n, float* cdf, float* sum) { distribution_generate(values, n, cdf, sum); }
+uint32_t orc_distribution_sample_discrete(const float* cdf, uint32_t size, float u, float* pdf, float* rem)
+{
+	float p;
+	const uint32_t off = distribution_sample_discrete(cdf, size, u, p, rem);
+	*pdf			   = p;
+	return off;
+}
+float orc_distribution_sample_continuous(const float* cdf, uint32_t size, float u, float* pdf)
+{
+	float p;
+	const float v = distribution_sample_continuous(cdf, size, u, p);
+	*pdf		  = p;
+	return v;
+}
+float orc_distribution_continuous_pdf(const float* cdf, uint32_t size, float x) { return distribution_continuous_pdf(cdf, size, x); }
+void orc_frame_duff(const float n[3], float nx[3], float ny[3], int norm)
+{
+	V3 a, b;
+	frame_duff(v3(n[0], n[1], n[2]), a, b);
+	if (norm) {
+		a = normalized(a);
+		b = normalized(b);
+	}
+	nx[0] = a.x; nx[1] = a.y; nx[2] = a.z;
+	ny[0] = b.x; ny[1] = b.y; ny[2] = b.z;
+}
+void orc_tangent_align(const float n[3], const float v[3], float out[3])
+{
+	// Tangent::align (Tangent.h:85-90): frame(N) then fromTangentSpace
+	V3 N = v3(n[0], n[1], n[2]), a, b;
+	frame_duff(N, a, b);
+	a		   = normalized(a);
+	b		   = normalized(b);
+	const V3 r = from_tangent_space(N, a, b, v3(v[0], v[1], v[2]));
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_from_tangent_space(const float n[3], const float nx[3], const float ny[3], const float v[3], float out[3])
+{
+	const V3 r = from_tangent_space(v3(n[0], n[1], n[2]), v3(nx[0], nx[1], nx[2]), v3(ny[0], ny[1], ny[2]), v3(v[0], v[1], v[2]));
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_to_tangent_space(const float n[3], const float nx[3], const float ny[3], const float v[3], float out[3])
+{
+	const V3 r = to_tangent_space(v3(n[0], n[1], n[2]), v3(nx[0], nx[1], nx[2]), v3(ny[0], ny[1], ny[2]), v3(v[0], v[1], v[2]));
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_cos_hemi(float u1, float u2, float out[3])
+{
+	const V3 r = cos_hemi(u1, u2);
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_sincos_2pi(float u, float* s, float* c) { sincos_2pi(u, *s, *c); }
+uint64_t orc_xy_2_morton(uint32_t x, uint32_t y) { return xy_2_morton(x, y); }
+void orc_morton_2_xy(uint64_t m, uint32_t* x, uint32_t* y) { morton_2_xy(m, *x, *y); }
+void orc_cie_eval(float wl, float xyz[3]) { cie_eval(wl, xyz); }
+float orc_cie_y_sum(void)
+{
+	double s = 0;
+	for (int i = 0; i < CIE_SAMPLES; ++i)
+		s += PR_CIE2006_Y[i];
+	return (float)s;
+}
+void orc_spectrum_eval(orc_scene* h, uint32_t id, const float wvl[4], float out[4])
+{
+	const Blob r = spectrum_eval(h->s, id, blob4(wvl[0], wvl[1], wvl[2], wvl[3]));
+	for (int k = 0; k < 4; ++k)
+		out[k] = r[k];
+}
+void orc_upsample_eval(const float coeffs[3], const float* wvl, float* out, uint32_t n)
+{
+	for (uint32_t i = 0; i < n; ++i)
+		out[i] = upsample(coeffs, wvl[i]);
+}
+void orc_filter_table(uint32_t kind, uint32_t radius, float* table)
+{
+	std::vector<float> t;
+	filter_table(kind, radius, t);
+	std::copy(t.begin(), t.end(), table);
+}
+void orc_triangle_sample(const float u[2], float out[2])
+{
+	if (u[1] > u[0]) {
+		const float x = u[0] / 2;
+		out[0] = x;
+		out[1] = u[1] - x;
+	} else {
+		const float y = u[1] / 2;
+		out[0] = u[0] - y;
+		out[1] = y;
+	}
+}
+void orc_safe_position(const float p[3], const float d[3], const float n[3], float out[3])
+{
+	const V3 r = safe_position(v3(p[0], p[1], p[2]), v3(d[0], d[1], d[2]), v3(n[0], n[1], n[2]));
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+float orc_rr_probability(orc_scene* h, uint32_t L) { return rr_probability(h->s, L); }
+void orc_camera_ray(orc_scene* h, float px, float py, float r1, float r2, float org[3], float dir[3])
+{
+	V3 o, d;
+	camera_ray(h->s, px, py, r1, r2, o, d);
+	org[0] = o.x; org[1] = o.y; org[2] = o.z;
+	dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+}
+void orc_wavelength_cdf(orc_scene* h, uint32_t* size, const float** cdf)
+{
+	*size = (uint32_t)h->s.wl_cdf.size();
+	*cdf  = h->s.wl_cdf.data();
+}
+void orc_light_selector(orc_scene* h, uint32_t* n, const float** cdf, const float** intens)
+{
+	*n		= (uint32_t)h->s.light_entity.size();
+	*cdf	= h->s.light_cdf.data();
+	*intens = h->s.light_intensity.data();
+}
+void orc_normal_matrix(const float m[16], float out[9], float* abs_det) { normal_matrix(m, out, *abs_det); }
+void orc_lambert_eval(orc_scene* h, uint32_t material, const float wvl[4], const float v[3], const float l[3], float weight[4], float pdf[4])
+{
+	const Scene& s			  = h->s;
+	const prgpu_material& mat = s.materials[material];
+	const bool same			  = std::signbit(v[2]) == std::signbit(l[2]);
+	const float dt			  = same ? (mat.two_sided ? std::fabs(l[2]) : std::max(0.0f, l[2])) : 0.0f;
+	const Blob w			  = (spectrum_eval(s, mat.albedo, blob4(wvl[0], wvl[1], wvl[2], wvl[3])) * dt) * PR_INV_PI_F;
+	for (int k = 0; k < 4; ++k) {
+		weight[k] = w[k];
+		pdf[k]	  = dt * PR_INV_PI_F;
+	}
+}
+void orc_lambert_sample(orc_scene* h, uint32_t material, const float wvl[4], const float v[3], float u1, float u2, float l[3],
+						float iw[4], float pdf[4])
+{
+	const Scene& s			  = h->s;
+	const prgpu_material& mat = s.materials[material];
+	if (!mat.two_sided && v[2] < 0.0f) {
+		for (int k = 0; k < 4; ++k)
+			iw[k] = pdf[k] = 0;
+		l[0] = l[1] = l[2] = 0;
+		return;
+	}
+	V3 L		 = cos_hemi(u1, u2);
+	const Blob a = spectrum_eval(s, mat.albedo, blob4(wvl[0], wvl[1], wvl[2], wvl[3]));
+	for (int k = 0; k < 4; ++k) {
+		iw[k]  = a[k];
+		pdf[k] = L.z * PR_INV_PI_F;
+	}
+	if (std::signbit(v[2]) != std::signbit(L.z))
+		L = -L;
+	l[0] = L.x; l[1] = L.y; l[2] = L.z;
+}
+
+} // extern "C"

@@ -1,0 +1,149 @@
+"""ctypes mirror of include/prgpu.h and loader of the HIP backend library.
+
+The product path has NO fallback: if ``libprgpu.so`` (built by ``__graft_entry__.build()`` /
+``make -C pearray_amd/csrc``) is missing or fails to load, importing the backend raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libprgpu.so")
+
+PRGPU_API_VERSION = 1
+INVALID_ID = 0xFFFFFFFF
+
+SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL = range(5)
+MAT_LAMBERT = 0
+EMS_DIFFUSE = 0
+SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL = range(3)
+MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO = range(3)
+FILTER_BLOCK, FILTER_TRIANGLE, FILTER_GAUSSIAN, FILTER_MITCHELL = range(4)
+MIS_BALANCE, MIS_POWER = range(2)
+
+STAT_NAMES = ("camera_rays", "light_rays", "primary_rays", "bounce_rays", "shadow_rays", "monochrome_rays",
+              "pixel_samples", "entity_hits", "background_hits", "camera_depth", "light_depth")
+STAT_COUNT = len(STAT_NAMES)
+
+
+class Spectrum(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("p", C.c_float * 4), ("table_offset", C.c_uint32),
+                ("table_count", C.c_uint32), ("wl_start", C.c_float), ("wl_end", C.c_float),
+                ("lhs", C.c_uint32), ("rhs", C.c_uint32)]
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("albedo", C.c_uint32), ("two_sided", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Emission(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("radiance", C.c_uint32)]
+
+
+class Entity(C.Structure):
+    _fields_ = [("first_tri", C.c_uint32), ("n_tris", C.c_uint32), ("emission", C.c_uint32),
+                ("has_normals", C.c_uint32), ("transform", C.c_float * 16)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("width", C.c_float), ("height", C.c_float),
+                ("near_t", C.c_float), ("far_t", C.c_float), ("local_direction", C.c_float * 3),
+                ("local_right", C.c_float * 3), ("local_up", C.c_float * 3), ("fstop", C.c_float),
+                ("aperture_radius", C.c_float)]
+
+
+class Settings(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("seed", C.c_uint64),
+                ("aa_sampler", C.c_uint32), ("aa_samples", C.c_uint32), ("lens_samples", C.c_uint32),
+                ("time_samples", C.c_uint32), ("spectral_samples", C.c_uint32), ("mapper", C.c_uint32),
+                ("filter", C.c_uint32), ("filter_radius", C.c_uint32), ("max_ray_depth", C.c_uint32),
+                ("soft_max_ray_depth", C.c_uint32), ("mis", C.c_uint32), ("nee", C.c_uint32),
+                ("direct", C.c_uint32), ("emissive_scatter", C.c_uint32), ("spectral_start", C.c_float),
+                ("spectral_end", C.c_float), ("spectral_hero", C.c_uint32), ("spectral_mono", C.c_uint32)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("api_version", C.c_uint32), ("n_vertices", C.c_uint32), ("positions", C.POINTER(C.c_float)),
+                ("normals", C.POINTER(C.c_float)), ("n_triangles", C.c_uint32),
+                ("indices", C.POINTER(C.c_uint32)), ("tri_material", C.POINTER(C.c_uint32)),
+                ("n_entities", C.c_uint32), ("entities", C.POINTER(Entity)), ("n_materials", C.c_uint32),
+                ("materials", C.POINTER(Material)), ("n_emissions", C.c_uint32),
+                ("emissions", C.POINTER(Emission)), ("n_spectra", C.c_uint32), ("spectra", C.POINTER(Spectrum)),
+                ("n_spectral_table_values", C.c_uint32), ("spectral_tables", C.POINTER(C.c_float)),
+                ("camera", Camera), ("settings", Settings)]
+
+
+class Tile(C.Structure):
+    _fields_ = [("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32)]
+
+
+class TraceCounters(C.Structure):
+    _fields_ = [("rays_closest", C.c_uint64), ("rays_any", C.c_uint64), ("nodes_closest", C.c_uint64),
+                ("tris_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("tris_any", C.c_uint64),
+                ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32), ("ray_bytes", C.c_uint32),
+                ("hit_bytes", C.c_uint32)]
+
+
+def default_settings(width, height):
+    """Reference defaults (RenderSettings.cpp:11-31, direct.cpp:34-39, Sampler/FilterManager defaults)."""
+    s = Settings()
+    s.width, s.height, s.seed = width, height, 42
+    s.aa_sampler, s.aa_samples = SAMPLER_SOBOL, 128
+    s.lens_samples = s.time_samples = s.spectral_samples = 1
+    s.mapper, s.filter, s.filter_radius = MAPPER_SPD_CMIS, FILTER_MITCHELL, 1
+    s.max_ray_depth, s.soft_max_ray_depth, s.mis = 64, 4, MIS_BALANCE
+    s.nee = s.direct = s.emissive_scatter = 1
+    s.spectral_start, s.spectral_end, s.spectral_hero, s.spectral_mono = 390.0, 830.0, 1, 0
+    return s
+
+
+# Entry points declared by include/prgpu.h: name -> (restype, argtypes)
+_VP, _U32P, _F32P, _U8P, _U64P = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
+SYMBOLS = {
+    "prgpu_last_error": (C.c_char_p, []),
+    "prgpu_device_count": (C.c_int, []),
+    "prgpu_settings_default": (None, [C.POINTER(Settings)]),
+    "prgpu_rgb_to_coeffs": (C.c_int, [_F32P, _F32P]),
+    "prgpu_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(_VP)]),
+    "prgpu_scene_destroy": (None, [_VP]),
+    "prgpu_set_tiles": (C.c_int, [_VP, C.POINTER(Tile), C.c_uint32]),
+    "prgpu_set_stream": (C.c_int, [_VP, _VP]),
+    "prgpu_bind_framebuffer": (C.c_int, [_VP, _VP, _VP, _VP]),
+    "prgpu_render": (C.c_int, [_VP, C.c_uint32, C.c_uint32]),
+    "prgpu_sync": (C.c_int, [_VP]),
+    "prgpu_download": (C.c_int, [_VP, _F32P, _U32P, _U32P]),
+    "prgpu_stats": (C.c_int, [_VP, _U64P]),
+    "prgpu_trace_counters_get": (C.c_int, [_VP, C.POINTER(TraceCounters)]),
+    "prgpu_set_instrumentation": (C.c_int, [_VP, C.c_int]),
+    "prgpu_trace_closest": (C.c_int, [_VP, C.c_uint32, _F32P, _F32P, _F32P, _F32P, _U32P, _U32P, _F32P, _F32P, _F32P]),
+    "prgpu_trace_any": (C.c_int, [_VP, C.c_uint32, _F32P, _F32P, _F32P, _F32P, _U8P]),
+    "prgpu_download_primary_hits": (C.c_int, [_VP, _U32P, _U32P]),
+    "prgpu_set_timing": (C.c_int, [_VP, C.c_int]),
+    "prgpu_kernel_time_ms": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_double), _U64P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libprgpu.so and bind every declared symbol.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("HIP backend %s not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if an ABI symbol is missing
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+class PrgpuError(RuntimeError):
+    pass
+
+
+def check(code):
+    if code != 0:
+        raise PrgpuError("prgpu error %d: %s" % (code, load().prgpu_last_error().decode()))

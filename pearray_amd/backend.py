@@ -1,0 +1,139 @@
+"""Python host mirror of the integrator/renderer surface on top of the C ABI (include/prgpu.h).
+
+`RenderContext` follows the call sequence of the reference host (src/client/main.cpp:172-257:
+create -> start -> wait -> save) and the `direct` integrator contract (IIntegrator.h:24-37):
+``start()`` queues every iteration of every owned tile on the GPU, ``waitForFinish()`` synchronises,
+``statistics()`` returns the RenderStatistics counters and ``output()`` the XYZ / sample-count planes.
+All compute goes through ``libprgpu.so``; there is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _cabi as abi
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class RenderContext:
+    """One scene resident on one GPU (mirrors renderer/RenderContext.h + Scene + `direct` integrator)."""
+
+    def __init__(self, scene, device=0):
+        self.lib = abi.load()
+        self.scene = scene
+        self._h = C.c_void_p()
+        abi.check(self.lib.prgpu_scene_create(C.byref(scene.desc), int(device), C.byref(self._h)))
+        self.width, self.height = scene.width, scene.height
+        self.iterations_done = 0
+
+    def close(self):
+        if self._h:
+            self.lib.prgpu_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration ---------------------------------------------------------------------------------
+    def setTiles(self, tiles):
+        """tiles: iterable of (x0, y0, x1, y1); empty -> whole film (RenderTileMap / --itx --ity)."""
+        tiles = list(tiles)
+        arr = (abi.Tile * max(1, len(tiles)))(*[abi.Tile(*t) for t in tiles])
+        abi.check(self.lib.prgpu_set_tiles(self._h, arr, len(tiles)))
+
+    def setStream(self, stream_handle):
+        abi.check(self.lib.prgpu_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def bindFramebuffer(self, xyz_ptr, samples_ptr, feedback_ptr=None):
+        abi.check(self.lib.prgpu_bind_framebuffer(self._h, C.c_void_p(xyz_ptr), C.c_void_p(samples_ptr),
+                                                  C.c_void_p(feedback_ptr) if feedback_ptr else None))
+
+    def setInstrumentation(self, on):
+        abi.check(self.lib.prgpu_set_instrumentation(self._h, 1 if on else 0))
+
+    def setTiming(self, on):
+        abi.check(self.lib.prgpu_set_timing(self._h, 1 if on else 0))
+
+    # -- rendering ----------------------------------------------------------------------------------------
+    def render(self, iterations):
+        """Render the next `iterations` iterations (one camera sample per owned pixel each)."""
+        b = self.iterations_done
+        abi.check(self.lib.prgpu_render(self._h, b, b + int(iterations)))
+        self.iterations_done = b + int(iterations)
+
+    def start(self):
+        """RenderContext::start: queue all spp iterations."""
+        self.render(self.scene.spp - self.iterations_done)
+
+    def waitForFinish(self):
+        abi.check(self.lib.prgpu_sync(self._h))
+
+    def statistics(self):
+        out = (C.c_uint64 * abi.STAT_COUNT)()
+        abi.check(self.lib.prgpu_stats(self._h, out))
+        return {n: int(out[i]) for i, n in enumerate(abi.STAT_NAMES)}
+
+    def traceCounters(self):
+        tc = abi.TraceCounters()
+        abi.check(self.lib.prgpu_trace_counters_get(self._h, C.byref(tc)))
+        return {f: int(getattr(tc, f)) for f, _ in tc._fields_}
+
+    def kernelTime(self, family):
+        ms, n = C.c_double(), C.c_uint64()
+        abi.check(self.lib.prgpu_kernel_time_ms(self._h, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
+
+    def output(self):
+        """(xyz[H,W,3] float32, samples[H,W] uint32, feedback[H,W] uint32) copied to the host."""
+        n = self.width * self.height
+        xyz = np.empty(n * 3, dtype=np.float32)
+        smp = np.empty(n, dtype=np.uint32)
+        fb = np.empty(n, dtype=np.uint32)
+        abi.check(self.lib.prgpu_download(self._h, _f32p(xyz), _u32p(smp), _u32p(fb)))
+        return xyz.reshape(self.height, self.width, 3), smp.reshape(self.height, self.width), fb.reshape(self.height, self.width)
+
+    def primaryHits(self):
+        n = self.width * self.height
+        e = np.empty(n, dtype=np.uint32)
+        p = np.empty(n, dtype=np.uint32)
+        abi.check(self.lib.prgpu_download_primary_hits(self._h, _u32p(e), _u32p(p)))
+        return e.reshape(self.height, self.width), p.reshape(self.height, self.width)
+
+    # -- IArchive surface ------------------------------------------------------------------------------------
+    def traceRays(self, org, direction, tmin, tmax):
+        org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        direction = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+        n = len(org)
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, dtype=np.float32), (n,)))
+        tmax = np.ascontiguousarray(np.broadcast_to(np.asarray(tmax, dtype=np.float32), (n,)))
+        ent, prim = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        u, v, t = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.float32)
+        abi.check(self.lib.prgpu_trace_closest(self._h, n, _f32p(org), _f32p(direction), _f32p(tmin), _f32p(tmax),
+                                               _u32p(ent), _u32p(prim), _f32p(u), _f32p(v), _f32p(t)))
+        return ent, prim, u, v, t
+
+    def traceShadowRays(self, org, direction, tmin, distance):
+        org = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        direction = np.ascontiguousarray(direction, dtype=np.float32).reshape(-1, 3)
+        n = len(org)
+        tmin = np.ascontiguousarray(np.broadcast_to(np.asarray(tmin, dtype=np.float32), (n,)))
+        distance = np.ascontiguousarray(np.broadcast_to(np.asarray(distance, dtype=np.float32), (n,)))
+        occ = np.empty(n, np.uint8)
+        abi.check(self.lib.prgpu_trace_any(self._h, n, _f32p(org), _f32p(direction), _f32p(tmin), _f32p(distance),
+                                           occ.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return occ.astype(bool)
+
+
+def xyz_to_srgb_linear(xyz):
+    """RGBConverter::fromXYZ (spectral/RGBConverter.cpp:15-24): XYZ -> linear sRGB, clamped at 0."""
+    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]], dtype=np.float32)
+    return np.maximum(0.0, xyz @ m.T)

@@ -1,0 +1,369 @@
+// bvh.hip -- device LBVH build (Morton codes + Karras 2012 radix tree), gfx950.
+//
+// Replaces Embree's BVH build behind Scene::setupScene / Mesh::setupOriginal
+// (reference: src/core/scene/Scene.cpp:88-120, src/plugins/main/entities/mesh.cpp:96-119,172-184).
+// The reference builds a two-level hierarchy (one BVH per mesh + an instance per entity).  Here the
+// entity id forms the top bits of a 64-bit sort key and the Morton code is normalised to the entity's
+// own bounds, so one sort + one radix-tree pass yields the same two-level structure: the top of the
+// tree separates entities, each entity's subtree is an LBVH over its own triangles.
+//
+// Layout produced (see pr_device.h): 64-byte BVH2 nodes holding both child boxes, 48-byte triangle
+// records in Morton order, leaves of 1..4 triangles (radix-tree subtrees of <= 4 leaves collapsed).
+#include "bvh.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace prd {
+namespace {
+
+__device__ __forceinline__ uint32_t float_to_ordered(float f)
+{
+	const uint32_t b = __float_as_uint(f);
+	return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u)
+{
+	return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// 1. world-space triangles (entity transform applied, same op order as the checker) + entity bounds
+__global__ void k_world_tris(uint32_t n, const float* __restrict__ positions, const uint32_t* __restrict__ indices,
+							 const uint32_t* __restrict__ tri_entity, const DevEntity* __restrict__ entities,
+							 float4* __restrict__ wv, uint32_t* __restrict__ ebounds /* 6 per entity, ordered uint */)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n)
+		return;
+	const uint32_t e   = tri_entity[t];
+	const DevEntity& E = entities[e];
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (int k = 0; k < 3; ++k) {
+		const uint32_t i = indices[3 * t + k];
+		const V3 p		 = affine_mul(E.m, v3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]));
+		wv[3 * t + k]	 = make_float4(p.x, p.y, p.z, 0.0f);
+		lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+		hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+	}
+	for (int a = 0; a < 3; ++a) {
+		atomicMin(&ebounds[6 * e + a], float_to_ordered(lo[a]));
+		atomicMax(&ebounds[6 * e + 3 + a], float_to_ordered(hi[a]));
+	}
+}
+
+__device__ __forceinline__ uint64_t expand_bits_16(uint32_t v) // 16 bits -> every third bit
+{
+	uint64_t x = v & 0xFFFFu;
+	x = (x | (x << 32)) & 0x001F00000000FFFFull;
+	x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+	x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+	x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+	x = (x | (x << 2)) & 0x1249249249249249ull;
+	return x;
+}
+
+// 2. key = entity (16 bits) | 48-bit Morton code of the triangle-box centre in the entity's bounds
+__global__ void k_morton(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ tri_entity,
+						 const uint32_t* __restrict__ ebounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n)
+		return;
+	const uint32_t e = tri_entity[t];
+	const float4 a = wv[3 * t], b = wv[3 * t + 1], c = wv[3 * t + 2];
+	const float cen[3] = { 0.5f * (fminf(a.x, fminf(b.x, c.x)) + fmaxf(a.x, fmaxf(b.x, c.x))),
+						   0.5f * (fminf(a.y, fminf(b.y, c.y)) + fmaxf(a.y, fmaxf(b.y, c.y))),
+						   0.5f * (fminf(a.z, fminf(b.z, c.z)) + fmaxf(a.z, fmaxf(b.z, c.z))) };
+	uint32_t q[3];
+	for (int k = 0; k < 3; ++k) {
+		const float lo = ordered_to_float(ebounds[6 * e + k]), hi = ordered_to_float(ebounds[6 * e + 3 + k]);
+		const float ext = hi - lo;
+		float f			= ext > 0.0f ? (cen[k] - lo) / ext : 0.0f;
+		f				= fminf(fmaxf(f * 65536.0f, 0.0f), 65535.0f);
+		q[k]			= (uint32_t)f;
+	}
+	const uint64_t morton = (expand_bits_16(q[0]) << 2) | (expand_bits_16(q[1]) << 1) | expand_bits_16(q[2]);
+	keys[t] = (uint64_t(e & 0xFFFFu) << 48) | morton;
+	vals[t] = t;
+}
+
+// Karras: common prefix length of sorted keys i and j (ties broken by index)
+__device__ __forceinline__ int delta(const uint64_t* __restrict__ keys, int n, int i, int j)
+{
+	if (j < 0 || j >= n)
+		return -1;
+	const uint64_t a = keys[i], b = keys[j];
+	if (a == b)
+		return 64 + __clz(uint32_t(i) ^ uint32_t(j));
+	return __clzll((long long)(a ^ b));
+}
+
+// 4. radix tree: internal node i (0..n-2) -> children, range
+__global__ void k_radix_tree(int n, const uint64_t* __restrict__ keys, int* __restrict__ left, int* __restrict__ right,
+							 int* __restrict__ range_first, int* __restrict__ range_last, int* __restrict__ parent /* 2n-1: internal then leaf */)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n - 1)
+		return;
+	const int d		   = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+	const int deltaMin = delta(keys, n, i, i - d);
+	int lmax		   = 2;
+	while (delta(keys, n, i, i + lmax * d) > deltaMin)
+		lmax *= 2;
+	int l = 0;
+	for (int t = lmax / 2; t >= 1; t /= 2)
+		if (delta(keys, n, i, i + (l + t) * d) > deltaMin)
+			l += t;
+	const int j			= i + l * d;
+	const int deltaNode = delta(keys, n, i, j);
+	int s				= 0;
+	int t				= l;
+	do {
+		t = (t + 1) >> 1;
+		if (delta(keys, n, i, i + (s + t) * d) > deltaNode)
+			s += t;
+	} while (t > 1);
+	const int gamma = i + s * d + min(d, 0);
+	const int lo = min(i, j), hi = max(i, j);
+	// child encoding here: >= 0 internal node, < 0 leaf ~index
+	const int lc = (lo == gamma) ? ~gamma : gamma;
+	const int rc = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
+	left[i]		   = lc;
+	right[i]	   = rc;
+	range_first[i] = lo;
+	range_last[i]  = hi;
+	parent[lc >= 0 ? lc : (n - 1) + (~lc)] = i;
+	parent[rc >= 0 ? rc : (n - 1) + (~rc)] = i;
+	if (i == 0)
+		parent[0] = -1;
+}
+
+__device__ __forceinline__ void tri_box(const float4* __restrict__ wv, uint32_t t, float* lo, float* hi)
+{
+	const float4 a = wv[3 * t], b = wv[3 * t + 1], c = wv[3 * t + 2];
+	lo[0] = fminf(a.x, fminf(b.x, c.x)); lo[1] = fminf(a.y, fminf(b.y, c.y)); lo[2] = fminf(a.z, fminf(b.z, c.z));
+	hi[0] = fmaxf(a.x, fmaxf(b.x, c.x)); hi[1] = fmaxf(a.y, fmaxf(b.y, c.y)); hi[2] = fmaxf(a.z, fmaxf(b.z, c.z));
+}
+
+// 5. bottom-up bounds: one thread per leaf climbs; the second thread to arrive at a node merges.
+__global__ void k_fit_bounds(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
+							 const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ parent,
+							 float* __restrict__ boxes /* 6 per internal node */, uint32_t* __restrict__ arrive)
+{
+	const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+	if (leaf >= n)
+		return;
+	int node = parent[(n - 1) + leaf];
+	while (node >= 0) {
+		__threadfence(); // release: boxes written below (previous round) are visible before we arrive
+		const uint32_t old = atomicAdd(&arrive[node], 1u);
+		if (old == 0)
+			return; // first to arrive; the sibling subtree's thread finishes this node
+		__threadfence(); // acquire: see the sibling's box
+		float lo[3], hi[3];
+		for (int side = 0; side < 2; ++side) {
+			const int c = side == 0 ? left[node] : right[node];
+			float clo[3], chi[3];
+			if (c < 0) {
+				tri_box(wv, sorted_tri[~c], clo, chi);
+			} else {
+				for (int a = 0; a < 3; ++a) {
+					clo[a] = __hip_atomic_load(&boxes[6 * c + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					chi[a] = __hip_atomic_load(&boxes[6 * c + 3 + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			for (int a = 0; a < 3; ++a) {
+				lo[a] = side == 0 ? clo[a] : fminf(lo[a], clo[a]);
+				hi[a] = side == 0 ? chi[a] : fmaxf(hi[a], chi[a]);
+			}
+		}
+		for (int a = 0; a < 3; ++a) {
+			__hip_atomic_store(&boxes[6 * node + a], lo[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&boxes[6 * node + 3 + a], hi[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		node = parent[node];
+	}
+}
+
+// pad a box so the slab test can never cull a triangle the watertight test accepts
+__device__ __forceinline__ void pad_box(float* lo, float* hi)
+{
+	for (int a = 0; a < 3; ++a) {
+		const float m = fmaxf(fabsf(lo[a]), fabsf(hi[a]));
+		const float e = m * 4e-6f + 1e-7f;
+		lo[a] -= e;
+		hi[a] += e;
+	}
+}
+
+// 6. traversal nodes: both child boxes inline; subtrees of <= 4 triangles become leaves
+__global__ void k_emit_nodes(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
+							 const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ range_first,
+							 const int* __restrict__ range_last, const float* __restrict__ boxes, BvhNode* __restrict__ nodes)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n - 1)
+		return;
+	BvhNode out;
+	out.pad0 = out.pad1 = 0;
+	for (int side = 0; side < 2; ++side) {
+		const int c = side == 0 ? left[i] : right[i];
+		float lo[3], hi[3];
+		int code;
+		if (c < 0) {
+			tri_box(wv, sorted_tri[~c], lo, hi);
+			code = ~((~c << 2) | 0);
+		} else {
+			for (int a = 0; a < 3; ++a) {
+				lo[a] = boxes[6 * c + a];
+				hi[a] = boxes[6 * c + 3 + a];
+			}
+			const int cnt = range_last[c] - range_first[c] + 1;
+			code		  = cnt <= 4 ? ~((range_first[c] << 2) | (cnt - 1)) : c;
+		}
+		pad_box(lo, hi);
+		for (int a = 0; a < 3; ++a) {
+			if (side == 0) {
+				out.lo0[a] = lo[a];
+				out.hi0[a] = hi[a];
+			} else {
+				out.lo1[a] = lo[a];
+				out.hi1[a] = hi[a];
+			}
+		}
+		if (side == 0)
+			out.child0 = code;
+		else
+			out.child1 = code;
+	}
+	nodes[i] = out;
+}
+
+// 7. triangle records in Morton order
+__global__ void k_emit_tris(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, TriRecord* __restrict__ out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const uint32_t t = sorted_tri[i];
+	TriRecord r;
+	r.v0   = wv[3 * t];
+	r.v1   = wv[3 * t + 1];
+	r.v2   = wv[3 * t + 2];
+	r.v0.w = __uint_as_float(t);
+	out[i] = r;
+}
+
+// tiny scenes (n <= 4): one node, child0 = leaf with everything, child1 = empty box
+__global__ void k_single_node(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, BvhNode* __restrict__ nodes)
+{
+	if (blockIdx.x != 0 || threadIdx.x != 0)
+		return;
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (uint32_t i = 0; i < n; ++i) {
+		float a[3], b[3];
+		tri_box(wv, sorted_tri[i], a, b);
+		for (int k = 0; k < 3; ++k) {
+			lo[k] = fminf(lo[k], a[k]);
+			hi[k] = fmaxf(hi[k], b[k]);
+		}
+	}
+	pad_box(lo, hi);
+	BvhNode out;
+	for (int a = 0; a < 3; ++a) {
+		out.lo0[a] = lo[a];
+		out.hi0[a] = hi[a];
+		out.lo1[a] = INFINITY;
+		out.hi1[a] = -INFINITY;
+	}
+	out.child0 = ~((0 << 2) | int(n - 1));
+	out.child1 = ~0;
+	out.pad0 = out.pad1 = 0;
+	nodes[0]			= out;
+}
+
+#define HIPC(x)                                  \
+	do {                                         \
+		hipError_t _e = (x);                     \
+		if (_e != hipSuccess) {                  \
+			err = std::string(#x) + ": " + hipGetErrorString(_e); \
+			goto done;                           \
+		}                                        \
+	} while (0)
+
+} // namespace
+
+bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err)
+{
+	const uint32_t n = in.n_tris;
+	const int B		 = 256;
+	const uint32_t G = (n + B - 1) / B;
+	float4* wv = nullptr;
+	uint32_t *ebounds = nullptr, *vals = nullptr, *vals_sorted = nullptr, *arrive = nullptr;
+	uint64_t *keys = nullptr, *keys_sorted = nullptr;
+	int *left = nullptr, *right = nullptr, *rf = nullptr, *rl = nullptr, *parent = nullptr;
+	float* boxes = nullptr;
+	void* temp	 = nullptr;
+	size_t temp_bytes = 0;
+	bool ok = false;
+	out.nodes = nullptr;
+	out.tris  = nullptr;
+	const uint32_t n_nodes = n > 1 ? n - 1 : 1;
+	{
+		HIPC(hipMalloc(&wv, sizeof(float4) * 3 * size_t(n)));
+		HIPC(hipMalloc(&ebounds, sizeof(uint32_t) * 6 * in.n_entities));
+		HIPC(hipMalloc(&keys, sizeof(uint64_t) * n));
+		HIPC(hipMalloc(&keys_sorted, sizeof(uint64_t) * n));
+		HIPC(hipMalloc(&vals, sizeof(uint32_t) * n));
+		HIPC(hipMalloc(&vals_sorted, sizeof(uint32_t) * n));
+		HIPC(hipMalloc(&out.nodes, sizeof(BvhNode) * size_t(n_nodes)));
+		HIPC(hipMalloc(&out.tris, sizeof(TriRecord) * size_t(n)));
+		{
+			std::vector<uint32_t> init(6 * size_t(in.n_entities));
+			for (uint32_t e = 0; e < in.n_entities; ++e)
+				for (int a = 0; a < 3; ++a) {
+					init[6 * e + a]		= 0xFFFFFFFFu;
+					init[6 * e + 3 + a] = 0u;
+				}
+			HIPC(hipMemcpyAsync(ebounds, init.data(), init.size() * 4, hipMemcpyHostToDevice, stream));
+			HIPC(hipStreamSynchronize(stream));
+		}
+		hipLaunchKernelGGL(k_world_tris, dim3(G), dim3(B), 0, stream, n, in.positions, in.indices, in.tri_entity, in.entities, wv, ebounds);
+		hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, n, wv, in.tri_entity, ebounds, keys, vals);
+		HIPC(hipGetLastError());
+		HIPC(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
+		HIPC(hipMalloc(&temp, temp_bytes));
+		HIPC(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
+		if (n <= 4) {
+			hipLaunchKernelGGL(k_single_node, dim3(1), dim3(64), 0, stream, n, wv, vals_sorted, out.nodes);
+		} else {
+			HIPC(hipMalloc(&left, sizeof(int) * (n - 1)));
+			HIPC(hipMalloc(&right, sizeof(int) * (n - 1)));
+			HIPC(hipMalloc(&rf, sizeof(int) * (n - 1)));
+			HIPC(hipMalloc(&rl, sizeof(int) * (n - 1)));
+			HIPC(hipMalloc(&parent, sizeof(int) * (2 * size_t(n) - 1)));
+			HIPC(hipMalloc(&boxes, sizeof(float) * 6 * (n - 1)));
+			HIPC(hipMalloc(&arrive, sizeof(uint32_t) * (n - 1)));
+			HIPC(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * (n - 1), stream));
+			hipLaunchKernelGGL(k_radix_tree, dim3(G), dim3(B), 0, stream, (int)n, keys_sorted, left, right, rf, rl, parent);
+			hipLaunchKernelGGL(k_fit_bounds, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, parent, boxes, arrive);
+			hipLaunchKernelGGL(k_emit_nodes, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, out.nodes);
+		}
+		hipLaunchKernelGGL(k_emit_tris, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, out.tris);
+		HIPC(hipGetLastError());
+		HIPC(hipStreamSynchronize(stream));
+		out.n_nodes = n_nodes;
+		ok			= true;
+	}
+done:
+	(void)hipFree(wv); (void)hipFree(ebounds); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted);
+	(void)hipFree(left); (void)hipFree(right); (void)hipFree(rf); (void)hipFree(rl); (void)hipFree(parent); (void)hipFree(boxes); (void)hipFree(arrive); (void)hipFree(temp);
+	if (!ok) {
+		(void)hipFree(out.nodes);
+		(void)hipFree(out.tris);
+		out.nodes = nullptr;
+		out.tris  = nullptr;
+	}
+	return ok;
+}
+
+} // namespace prd

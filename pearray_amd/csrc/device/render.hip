@@ -1,0 +1,839 @@
+// render.hip -- wavefront spectral path tracer kernels for gfx950 (MI355X).
+//
+// One iteration = one camera sample for every owned pixel (RenderTile.cpp:21-22), processed as a
+// wavefront: raygen -> { trace_closest -> shade (emission, NEE setup, RR, BSDF sample; ballot/prefix
+// compaction of the surviving paths and of the shadow queue) -> trace_shadow } per path vertex ->
+// resolve (filter taps + per-iteration running mean).  Each kernel cites the reference code it
+// replaces; the scalar arithmetic lives in pr_device.h.
+//
+// No MFMA: no stage is a dense contraction.  The kernels are latency/bandwidth bound on BVH-node and
+// triangle fetches (64 B + 48 B records, see DESIGN.md for the bytes-per-ray model).
+#include "render.h"
+
+namespace prd {
+
+struct Hit {
+	float t, u, v;
+	uint32_t tri; // original triangle index, INVALID on miss
+};
+
+constexpr int STACK_SIZE = 64;
+
+// ---- traversal ------------------------------------------------------------------------------------------
+// Closest hit, tmin < t <= tmax, equal t -> lower original triangle index wins (tie rule shared with the
+// CPU checker).  Replaces rtcIntersect1 / rtcIntersect16 behind Scene::traceRays / traceSingleRay
+// (src/core/scene/Scene.cpp:138-242).
+template <bool COUNT>
+__device__ __forceinline__ Hit traverse_closest(const DevScene& sc, V3 o, V3 d, float tmin, float tmax, uint32_t& cnt_nodes, uint32_t& cnt_tris)
+{
+	const RayPre r = ray_prepare(o, d);
+	Hit best{ tmax, 0.0f, 0.0f, INVALID };
+	int stack_node[STACK_SIZE];
+	float stack_t[STACK_SIZE];
+	int sp	= 0;
+	int cur = 0;
+	const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+	for (;;) {
+		const float4 q0 = nodes4[4 * cur + 0], q1 = nodes4[4 * cur + 1], q2 = nodes4[4 * cur + 2], q3 = nodes4[4 * cur + 3];
+		if (COUNT)
+			++cnt_nodes;
+		const float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
+		const float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
+		const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+		float t0, t1;
+		bool h0 = box_hit(r, lo0, hi0, tmin, best.t, t0);
+		bool h1 = box_hit(r, lo1, hi1, tmin, best.t, t1);
+#pragma unroll
+		for (int side = 0; side < 2; ++side) {
+			const int c	 = side == 0 ? c0 : c1;
+			const bool h = side == 0 ? h0 : h1;
+			if (h && c < 0) {
+				const uint32_t code	 = uint32_t(~c);
+				const uint32_t first = code >> 2, count = (code & 3u) + 1u;
+				for (uint32_t i = 0; i < count; ++i) {
+					const float4* __restrict__ tp = reinterpret_cast<const float4*>(sc.tris + first + i);
+					const float4 a = tp[0], b = tp[1], c4 = tp[2];
+					if (COUNT)
+						++cnt_tris;
+					float t, u, v;
+					if (!woop(r, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c4.x, c4.y, c4.z), t, u, v))
+						continue;
+					if (!(t > tmin))
+						continue;
+					const uint32_t tri = __float_as_uint(a.w);
+					if (t < best.t || (t == best.t && tri < best.tri)) {
+						best.t	 = t;
+						best.u	 = u;
+						best.v	 = v;
+						best.tri = tri;
+					}
+				}
+			}
+		}
+		h0 = h0 && c0 >= 0 && t0 <= best.t;
+		h1 = h1 && c1 >= 0 && t1 <= best.t;
+		if (h0 && h1) {
+			const bool near0 = t0 <= t1;
+			if (sp < STACK_SIZE) {
+				stack_node[sp] = near0 ? c1 : c0;
+				stack_t[sp]	   = near0 ? t1 : t0;
+				++sp;
+			}
+			cur = near0 ? c0 : c1;
+		} else if (h0) {
+			cur = c0;
+		} else if (h1) {
+			cur = c1;
+		} else {
+			bool found = false;
+			while (sp > 0) {
+				--sp;
+				if (stack_t[sp] <= best.t) {
+					cur	  = stack_node[sp];
+					found = true;
+					break;
+				}
+			}
+			if (!found)
+				break;
+		}
+	}
+	return best;
+}
+
+// Any hit in (tmin, distance - 0.001]: Scene::traceShadowRay (Scene.cpp:266-280, rtcOccluded1).
+template <bool COUNT>
+__device__ __forceinline__ bool traverse_any(const DevScene& sc, V3 o, V3 d, float tmin, float distance, uint32_t& cnt_nodes, uint32_t& cnt_tris)
+{
+	const float tmax = distance - 0.001f;
+	const RayPre r	 = ray_prepare(o, d);
+	int stack_node[STACK_SIZE];
+	int sp	= 0;
+	int cur = 0;
+	const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+	for (;;) {
+		const float4 q0 = nodes4[4 * cur + 0], q1 = nodes4[4 * cur + 1], q2 = nodes4[4 * cur + 2], q3 = nodes4[4 * cur + 3];
+		if (COUNT)
+			++cnt_nodes;
+		const float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
+		const float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
+		const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+		float t0, t1;
+		bool h0 = box_hit(r, lo0, hi0, tmin, tmax, t0);
+		bool h1 = box_hit(r, lo1, hi1, tmin, tmax, t1);
+#pragma unroll
+		for (int side = 0; side < 2; ++side) {
+			const int c	 = side == 0 ? c0 : c1;
+			const bool h = side == 0 ? h0 : h1;
+			if (h && c < 0) {
+				const uint32_t code	 = uint32_t(~c);
+				const uint32_t first = code >> 2, count = (code & 3u) + 1u;
+				for (uint32_t i = 0; i < count; ++i) {
+					const float4* __restrict__ tp = reinterpret_cast<const float4*>(sc.tris + first + i);
+					const float4 a = tp[0], b = tp[1], c4 = tp[2];
+					if (COUNT)
+						++cnt_tris;
+					float t, u, v;
+					if (!woop(r, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c4.x, c4.y, c4.z), t, u, v))
+						continue;
+					if (t > tmin && t <= tmax)
+						return true;
+				}
+			}
+		}
+		h0 = h0 && c0 >= 0;
+		h1 = h1 && c1 >= 0;
+		if (h0 && h1) {
+			if (sp < STACK_SIZE)
+				stack_node[sp++] = c1;
+			cur = c0;
+		} else if (h0) {
+			cur = c0;
+		} else if (h1) {
+			cur = c1;
+		} else {
+			if (sp == 0)
+				break;
+			cur = stack_node[--sp];
+		}
+	}
+	return false;
+}
+
+// ---- shading helpers --------------------------------------------------------------------------------------
+__device__ __forceinline__ Blob spectrum_leaf(const DevScene& sc, const prgpu_spectrum& n, const Blob& wl)
+{
+	switch (n.kind) {
+	case PRGPU_SPEC_CONST: return blob(n.p[0]);
+	case PRGPU_SPEC_PARAMETRIC: return blob4(upsample(n.p, wl.v[0]), upsample(n.p, wl.v[1]), upsample(n.p, wl.v[2]), upsample(n.p, wl.v[3]));
+	case PRGPU_SPEC_PARAMETRIC_SCALED:
+		return blob4(upsample(n.p, wl.v[0]) * n.p[3], upsample(n.p, wl.v[1]) * n.p[3], upsample(n.p, wl.v[2]) * n.p[3], upsample(n.p, wl.v[3]) * n.p[3]);
+	case PRGPU_SPEC_TABLE: {
+		const float delta = (n.wl_end - n.wl_start) / (n.table_count - 1);
+		const float* data = sc.tables + n.table_offset;
+		Blob b;
+		for (int k = 0; k < 4; ++k)
+			b.v[k] = equidistant_lookup(data, (int)n.table_count, n.wl_start, delta, wl.v[k]);
+		return b;
+	}
+	default: return blob(0);
+	}
+}
+// FloatSpectralNode::eval for the flattened network (MUL operands are leaves; validated at scene creation)
+__device__ __forceinline__ Blob spectrum_eval(const DevScene& sc, uint32_t id, const Blob& wl)
+{
+	const prgpu_spectrum& n = sc.spectra[id];
+	if (n.kind == PRGPU_SPEC_MUL)
+		return spectrum_leaf(sc, sc.spectra[n.lhs], wl) * spectrum_leaf(sc, sc.spectra[n.rhs], wl);
+	return spectrum_leaf(sc, n, wl);
+}
+
+struct GeomPoint {
+	V3 N, Nx, Ny;
+	uint32_t entity, prim, material, emission;
+};
+__device__ __forceinline__ V3 load3(const float* a, uint32_t i) { return v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+__device__ __forceinline__ V3 tri_interp(V3 a0, V3 a1, V3 a2, float u, float v) { return (a1 * u + a2 * v) + a0 * (1 - u - v); }
+// MeshEntity::provideGeometryPoint (entities/mesh.cpp:205-250)
+__device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri, float u, float v, GeomPoint& g)
+{
+	const uint32_t e   = sc.tri_entity[tri];
+	const DevEntity& E = sc.entities[e];
+	const uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
+	V3 N, Nx, Ny;
+	if (E.has_normals) {
+		N = tri_interp(load3(sc.normals, i0), load3(sc.normals, i1), load3(sc.normals, i2), u, v);
+		frame_duff(N, Nx, Ny);
+	} else {
+		Nx = load3(sc.positions, i1) - load3(sc.positions, i0);
+		Ny = load3(sc.positions, i2) - load3(sc.positions, i0);
+		N  = cross(Nx, Ny);
+	}
+	g.N		   = normalized(mat3_mul(E.nm, N));
+	g.Nx	   = normalized(mat3_mul(E.nm, Nx));
+	g.Ny	   = normalized(mat3_mul(E.nm, Ny));
+	g.entity   = e;
+	g.prim	   = tri - E.first_tri;
+	g.material = sc.tri_material[tri];
+	g.emission = E.emission;
+}
+
+// RenderTileSession::pushSpectralFragment (RenderTileSession.cpp:133-142) + commitSpectrals2
+// (LocalFrameOutputDevice.cpp:88-164): returns the XYZ addend and the feedback bits of one fragment.
+__device__ __forceinline__ uint32_t fragment_value(const DevScene& sc, const Blob& mis, const Blob& importance, const Blob& grp_importance,
+												  const Blob& radiance, bool mono, const Blob& grp_wl, float blend, float xyz[3])
+{
+	const Blob imp		  = grp_importance * importance;
+	const Blob heroFactor = mono ? hero_only() : blob(1);
+	const Blob contrib	  = heroFactor * ((mis * imp) * radiance);
+	uint32_t fb = 0;
+	for (int k = 0; k < 4; ++k) {
+		if (isnan(contrib.v[k]))
+			fb |= 0x1; // OutputFeedback::NaN, output/Feedback.h:6-12
+		if (isinf(contrib.v[k]))
+			fb |= 0x2;
+		if (contrib.v[k] < -PR_EPS)
+			fb |= 0x4;
+	}
+	xyz[0] = xyz[1] = xyz[2] = 0.0f;
+	if (fb)
+		return fb;
+	float triplet[3] = { 0, 0, 0 };
+	if (sc.cfg.spectral_mono) {
+		triplet[0] = triplet[1] = triplet[2] = contrib.v[0];
+	} else {
+		for (int k = 0; k < 4; ++k) {
+			float c[3];
+			cie_eval(sc.cie, grp_wl.v[k], c);
+			triplet[0] += contrib.v[k] * c[0];
+			triplet[1] += contrib.v[k] * c[1];
+			triplet[2] += contrib.v[k] * c[2];
+		}
+	}
+	const float w = sc.single_tap ? sc.centre_weight * blend : blend;
+	xyz[0] = w * triplet[0];
+	xyz[1] = w * triplet[1];
+	xyz[2] = w * triplet[2];
+	return 0;
+}
+__device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pixel, uint32_t fb, const float xyz[3])
+{
+	if (fb) {
+		ps.feedback[pixel] |= fb;
+	} else {
+		ps.iter_xyz[3 * pixel + 0] += xyz[0];
+		ps.iter_xyz[3 * pixel + 1] += xyz[1];
+		ps.iter_xyz[3 * pixel + 2] += xyz[2];
+	}
+}
+
+__device__ __forceinline__ float rr_probability(const DevScene& sc, uint32_t L)
+{
+	return sc.rr_prob[L < sc.rr_size ? L : sc.rr_size - 1];
+}
+__device__ __forceinline__ bool is_normal(float f)
+{
+	const uint32_t e = (__float_as_uint(f) >> 23) & 0xFFu;
+	return e != 0 && e != 0xFF;
+}
+
+// block-level statistics: LDS counters, one global atomic per counter per block
+struct BlockStats {
+	unsigned int v[PRGPU_STAT_COUNT + 4];
+};
+__device__ __forceinline__ void stats_init(BlockStats& s)
+{
+	if (threadIdx.x < PRGPU_STAT_COUNT + 4)
+		s.v[threadIdx.x] = 0;
+	__syncthreads();
+}
+__device__ __forceinline__ void stats_flush(BlockStats& s, unsigned long long* g)
+{
+	__syncthreads();
+	if (threadIdx.x < PRGPU_STAT_COUNT + 4 && s.v[threadIdx.x])
+		atomicAdd(&g[threadIdx.x], (unsigned long long)s.v[threadIdx.x]);
+}
+// indices into the extra device counters after the 11 statistics
+enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY };
+
+// wave-level stream compaction: ballot + prefix popcount, one atomic per wave
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter)
+{
+	const unsigned long long mask = __ballot(pred);
+	const uint32_t lane			  = threadIdx.x & 63u;
+	const uint32_t prefix		  = __popcll(mask & ((1ull << lane) - 1ull));
+	uint32_t base				  = 0;
+	if (mask != 0ull) {
+		const int leader = __ffsll((long long)mask) - 1;
+		if ((int)lane == leader)
+			base = atomicAdd(counter, (uint32_t)__popcll(mask));
+		base = __shfl(base, leader, 64);
+	}
+	return base + prefix;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------------------
+// RenderTile::constructCameraRay (RenderTile.cpp:71-132) + StreamPipeline::fillWithCameraRays (:83-133)
+__global__ void __launch_bounds__(256) k_raygen(DevScene sc, PathState ps, uint32_t n_slots, uint32_t iter, unsigned long long* gstats)
+{
+	__shared__ BlockStats bs;
+	stats_init(bs);
+	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+	if (slot < n_slots) {
+		const prgpu_settings& cfg = sc.cfg;
+		const uint32_t pixel	  = ps.pixel[slot];
+		const uint32_t gx = pixel % cfg.width, gy = pixel / cfg.width;
+		uint64_t rnd = ps.rng[pixel];
+		float ax, ay;
+		if (cfg.aa_sampler == PRGPU_SAMPLER_MJITT) { // MultiJitteredSampler.cpp:118-150
+			const uint32_t n  = max(1u, sc.spp);
+			const uint32_t id = mjitt_permute(iter, n, sc.mj_seed * 0x51633e2d);
+			const uint32_t sx = mjitt_permute(id % sc.mj_x, sc.mj_x, sc.mj_seed * 0x68bc21eb);
+			const uint32_t sy = mjitt_permute(id / sc.mj_x, sc.mj_y, sc.mj_seed * 0x02e5be93);
+			const float jx	  = rng_float(rnd);
+			const float jy	  = rng_float(rnd);
+			ax				  = (sx + (sy + jx) / sc.mj_y) / sc.mj_x;
+			ay				  = (id + jy) / n;
+		} else if (cfg.aa_sampler == PRGPU_SAMPLER_SOBOL && iter < sc.spp) { // SobolSampler.cpp:67-73
+			ax = sc.sobol2d[2 * iter];
+			ay = sc.sobol2d[2 * iter + 1];
+		} else { // RandomSampler.cpp:20-21
+			ax = rng_float(rnd);
+			ay = rng_float(rnd);
+		}
+		const float px = (float)gx + ax - 0.5f, py = (float)gy + ay - 0.5f;
+		const float l1 = rng_float(rnd), l2 = rng_float(rnd); // lens
+		(void)rng_float(rnd);								   // time
+		Blob wl, wl_pdf;
+		if (cfg.spectral_mono) {
+			wl	   = blob(cfg.spectral_start);
+			wl_pdf = blob(1.0f);
+		} else if (cfg.mapper == PRGPU_MAPPER_SPD_CMIS) { // spd.cpp:40-48
+			const float span = cfg.spectral_end - cfg.spectral_start;
+			for (int k = 0; k < 4; ++k) {
+				float pdf;
+				const float v = distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, rng_float(rnd), pdf);
+				wl.v[k]		  = v * span + cfg.spectral_start;
+				wl_pdf.v[k]	  = pdf;
+			}
+		} else if (cfg.mapper == PRGPU_MAPPER_SPD_HERO) { // spd.cpp:103-113
+			const float span = cfg.spectral_end - cfg.spectral_start;
+			float pdf;
+			const float v	  = distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, rng_float(rnd), pdf);
+			const float hero  = v * span + cfg.spectral_start;
+			const float delta = span / 4;
+			wl.v[0]			  = hero;
+			for (int k = 1; k < 4; ++k)
+				wl.v[k] = cfg.spectral_start + fmodf(hero - cfg.spectral_start + k * delta, span);
+			wl_pdf = blob(pdf);
+		} else { // random.cpp:22-36
+			const float u	  = rng_float(rnd);
+			const float span  = cfg.spectral_end - cfg.spectral_start;
+			const float delta = span / 4;
+			const float start = u * span;
+			wl.v[0]			  = start + cfg.spectral_start;
+			for (int k = 1; k < 4; ++k)
+				wl.v[k] = cfg.spectral_start + fmodf(start + k * delta, span);
+			wl_pdf = blob(1.0f);
+		}
+		// PerspectiveCamera::constructRay (perspective.cpp:45-82)
+		const float nx = 2 * (px / (float)cfg.width - 0.5f);
+		const float ny = -(2 * (py / (float)cfg.height - 0.5f));
+		const DevCamera& cam = sc.cam;
+		V3 o = v3(cam.o[0], cam.o[1], cam.o[2]);
+		V3 d = (v3(cam.right[0], cam.right[1], cam.right[2]) * nx + v3(cam.up[0], cam.up[1], cam.up[2]) * ny) + v3(cam.focal[0], cam.focal[1], cam.focal[2]);
+		if (cam.dof) {
+			float sn, cs;
+			pr_sincos_2pi(l1, sn, cs);
+			const V3 e = v3(cam.xap[0], cam.xap[1], cam.xap[2]) * (l2 * sn) + v3(cam.yap[0], cam.yap[1], cam.yap[2]) * (l2 * cs);
+			o		   = o + e;
+			d		   = d - e;
+		}
+		d = normalized(d);
+		const bool mono	   = cfg.spectral_mono || !cfg.spectral_hero; // RenderTile.cpp:123-124
+		ps.rng[pixel]	   = rnd;
+		ps.ray_o[slot]	   = make_float4(o.x, o.y, o.z, cam.near_t);
+		ps.ray_d[slot]	   = make_float4(d.x, d.y, d.z, cam.far_t);
+		ps.wl[slot]		   = to4(wl);
+		ps.wl_pdf[slot]	   = to4(wl_pdf);
+		ps.throughput[slot] = make_float4(1, 1, 1, 1);
+		ps.path_pdf[slot]  = make_float4(1, 1, 1, 1);
+		ps.prev_pdf[slot]  = make_float4(1, 1, 1, 1);
+		ps.flags[slot]	   = 0u | (mono ? FLAG_MONO : 0u) | FLAG_LAST_DELTA;
+		ps.iter_xyz[3 * pixel + 0] = 0.0f;
+		ps.iter_xyz[3 * pixel + 1] = 0.0f;
+		ps.iter_xyz[3 * pixel + 2] = 0.0f;
+		atomicAdd(&bs.v[PRGPU_STAT_PIXEL_SAMPLES], 1u);
+		atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
+		atomicAdd(&bs.v[PRGPU_STAT_PRIMARY_RAYS], 1u);
+	}
+	stats_flush(bs, gstats);
+}
+
+// Scene::traceRays / traceSingleRay for the active paths
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_closest(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t n_active,
+													  unsigned long long* gstats)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	uint32_t cn = 0, ct = 0;
+	if (i < n_active) {
+		const uint32_t slot = active ? active[i] : i;
+		const float4 o = ps.ray_o[slot], d = ps.ray_d[slot];
+		const Hit h	 = traverse_closest<COUNT>(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w, cn, ct);
+		ps.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+	}
+	if (COUNT) {
+		if (cn)
+			atomicAdd(&gstats[CNT_NODES_CLOSEST], (unsigned long long)cn);
+		if (ct)
+			atomicAdd(&gstats[CNT_TRIS_CLOSEST], (unsigned long long)ct);
+	}
+}
+
+// handleCameraVertex / handleDirectHit / handleNEE / handleScattering (direct.cpp:73-412), Walker::traverse
+// (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53)
+__global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t n_active,
+											  uint32_t* __restrict__ next_active, uint32_t* __restrict__ counters /* [0]=next, [1]=shadow */,
+											  unsigned long long* gstats)
+{
+	__shared__ BlockStats bs;
+	stats_init(bs);
+	const uint32_t i		  = blockIdx.x * blockDim.x + threadIdx.x;
+	const prgpu_settings& cfg = sc.cfg;
+	bool alive = false, want_shadow = false;
+	uint32_t slot = 0;
+	float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
+	if (i < n_active) {
+		slot				 = active ? active[i] : i;
+		const uint32_t pixel = ps.pixel[slot];
+		const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+		const V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
+		const float4 hit4  = ps.hit[slot];
+		const uint32_t tri = __float_as_uint(hit4.w);
+		uint32_t flags	   = ps.flags[slot];
+		const uint32_t depth = flags & 0xFFu;
+		const bool mono		 = (flags & FLAG_MONO) != 0;
+		const Blob wl		 = from4(ps.wl[slot]);
+		const Blob wvl_pdf	 = from4(ps.wl_pdf[slot]);
+		Blob throughput		 = from4(ps.throughput[slot]);
+		Blob path_pdf		 = from4(ps.path_pdf[slot]);
+		Blob prev_pdf		 = from4(ps.prev_pdf[slot]);
+		const Blob grp_imp	 = mono ? hero_only() : blob(1.0f); // RenderTile.cpp:126-127
+		const float blend	 = 1.0f;
+		const bool power_mis = cfg.mis == PRGPU_MIS_POWER;
+		const Blob hf		 = mono ? hero_only() : blob(1.0f);
+
+		if (depth == 0) {
+			ps.prim_entity[pixel] = tri == INVALID ? INVALID : sc.tri_entity[tri];
+			ps.prim_prim[pixel]	  = tri == INVALID ? INVALID : tri - sc.entities[sc.tri_entity[tri]].first_tri;
+		}
+		if (tri == INVALID) {
+			atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
+			float xyz[3];
+			uint32_t fb;
+			if (depth == 0) {
+				atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
+				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, wl, blend, xyz);
+			} else {
+				fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, blob(0), mono, wl, blend, xyz);
+			}
+			apply_fragment(ps, pixel, fb, xyz);
+		} else {
+			const V3 P = ray_o + ray_d * hit4.x;
+			GeomPoint gp;
+			geometry_point(sc, tri, hit4.y, hit4.z, gp);
+			const V3 N		   = gp.N;
+			const float NdotV  = dot(ray_d, N);
+			const V3 dP		   = ray_o - P;
+			const float depth2 = dot(dP, dP);
+			const uint32_t pathLength = depth + 1;
+			atomicAdd(&bs.v[PRGPU_STAT_ENTITY_HITS], 1u);
+			atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
+			if (pathLength == 1)
+				ps.samples[pixel] += 1;
+			const bool hasEmission = gp.emission != INVALID;
+			bool go_on			   = true;
+			if (cfg.direct && hasEmission) {
+				// ---- handleDirectHit
+				const float cosC = -NdotV;
+				if (!(fabsf(cosC) <= PR_EPS)) {
+					const bool behind	= cosC < 0.0f;
+					const Blob radiance = behind ? blob(0) : spectrum_eval(sc, sc.emissions[gp.emission].radiance, wl);
+					float xyz[3];
+					uint32_t fb;
+					if (!cfg.nee || behind || (flags & FLAG_LAST_DELTA)) {
+						fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, radiance, mono, wl, blend, xyz);
+					} else {
+						const uint32_t lid	 = sc.entities[gp.entity].light_id;
+						const float selProb	 = sc.light_cdf[lid + 1] - sc.light_cdf[lid];
+						float posPDF		 = 1.0f / sc.entities[gp.entity].world_area;
+						posPDF				 = posPDF * depth2 / fabsf(cosC);
+						const float posPDF_S = posPDF * selProb;
+						const Blob a		 = prev_pdf * posPDF_S;
+						const float denom	 = bsum(power_mis ? a * a : a) + bsum(power_mis ? path_pdf * path_pdf : path_pdf);
+						const float p0		 = power_mis ? path_pdf.v[0] * path_pdf.v[0] : path_pdf.v[0];
+						const Blob mis		 = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
+						fb					 = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, wl, blend, xyz);
+					}
+					apply_fragment(ps, pixel, fb, xyz);
+				}
+				if (!cfg.emissive_scatter)
+					go_on = false;
+			}
+			if (gp.material == INVALID)
+				go_on = false;
+			if (go_on) {
+				const prgpu_material mat = sc.materials[gp.material];
+				const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
+				uint64_t rnd			 = ps.rng[pixel];
+				if (cfg.nee && !hasEmission && sc.n_lights) {
+					// ---- handleNEE
+					do {
+						float selPdf;
+						const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + 1, rng_float(rnd), selPdf, nullptr);
+						const uint32_t le  = sc.light_entity[lid];
+						const DevEntity& LE = sc.entities[le];
+						const float u0 = rng_float(rnd), u1 = rng_float(rnd);
+						float k0, k1;
+						const float f0		= modff(u0 * LE.n_tris, &k0);
+						const float f1		= modff(u1 * LE.n_tris, &k1);
+						const uint32_t face = min((uint32_t)k0, LE.n_tris - 1);
+						const uint32_t ltri = LE.first_tri + face;
+						const uint32_t i0 = sc.indices[3 * ltri], i1 = sc.indices[3 * ltri + 1], i2 = sc.indices[3 * ltri + 2];
+						const V3 p0 = load3(sc.positions, i0), p1 = load3(sc.positions, i1), p2 = load3(sc.positions, i2);
+						const V3 ee		  = cross(p1 - p0, p2 - p0);
+						const float area  = 0.5f * sqrtf(dot(ee, ee));
+						const float pdf_a = 1.0f / (LE.n_tris * area * LE.vol_scale);
+						float bu, bv;
+						if (f1 > f0) {
+							const float x = f0 / 2;
+							bu = x;
+							bv = f1 - x;
+						} else {
+							const float y = f1 / 2;
+							bu = f0 - y;
+							bv = y;
+						}
+						const V3 lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
+						GeomPoint lgp;
+						geometry_point(sc, ltri, bu, bv, lgp);
+						const V3 L			 = normalized(lp - P);
+						const float cosLight = fminf(1.0f, fmaxf(-1.0f, -dot(L, lgp.N)));
+						const Blob radiance	 = spectrum_eval(sc, sc.emissions[LE.emission].radiance, wl);
+						const V3 dLP		 = lp - P;
+						const float sqrD	 = dot(dLP, dLP);
+						const float cosC	 = fabsf(dot(L, N));
+						const float cosL	 = fabsf(cosLight);
+						if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
+							break;
+						const V3 Lt		  = to_tangent_space(N, gp.Nx, gp.Ny, L);
+						const bool same	  = signbit(Vt.z) == signbit(Lt.z);
+						const float dt	  = same ? (mat.two_sided ? fabsf(Lt.z) : fmaxf(0.0f, Lt.z)) : 0.0f;
+						const Blob weight = (spectrum_eval(sc, mat.albedo, wl) * dt) * PR_INV_PI_F;
+						const float bsdf_pdf   = dt * PR_INV_PI_F;
+						const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+						if (all_le(bsdfWvlPdfS, PDF_EPS))
+							break;
+						const Blob connectionW = radiance * weight;
+						const bool worth	   = !is_zero(connectionW, PR_EPS);
+						float lightPdfS		   = pdf_a * sqrD / cosL;
+						lightPdfS *= selPdf;
+						if (!is_normal(lightPdfS) || lightPdfS <= PDF_EPS)
+							break;
+						const Blob lightPdfS2 = (blob(1) * lightPdfS) * hf;
+						if (all_le(lightPdfS2, PDF_EPS))
+							break;
+						Blob mis;
+						if (cfg.direct && !(flags & FLAG_LAST_EMISSIVE)) {
+							const float rr		= rr_probability(sc, pathLength);
+							const Blob bsdfPdfS = bsdfWvlPdfS * rr;
+							const Blob a = path_pdf * lightPdfS2, b = path_pdf * bsdfPdfS;
+							const float denom = bsum(power_mis ? a * a : a) + bsum(power_mis ? b * b : b);
+							const float num	  = path_pdf.v[0] * lightPdfS2.v[0];
+							mis				  = blob(power_mis ? num * num : num) / ((hf * denom) * (power_mis ? wvl_pdf * wvl_pdf : wvl_pdf));
+						} else {
+							mis = hf / (wvl_pdf * bsum(hf));
+						}
+						const float distance = sqrtf(sqrD);
+						const V3 oN			 = dot(L, N) < 0 ? -N : N;
+						const V3 so			 = safe_position(P, L, oN);
+						float xyz_vis[3], xyz_occ[3];
+						const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, wl, blend, xyz_vis);
+						const uint32_t fb_occ = fragment_value(sc, mis, throughput, grp_imp, blob(0), mono, wl, blend, xyz_occ);
+						atomicAdd(&bs.v[PRGPU_STAT_ENTITY_HITS], 1u);
+						if (worth) {
+							atomicAdd(&bs.v[PRGPU_STAT_SHADOW_RAYS], 1u);
+							want_shadow = true;
+							sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
+							sh_d		= make_float4(L.x, L.y, L.z, distance);
+							sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8)));
+						} else {
+							apply_fragment(ps, pixel, fb_occ, xyz_occ);
+						}
+					} while (false);
+				}
+				flags = hasEmission ? (flags | FLAG_LAST_EMISSIVE) : (flags & ~FLAG_LAST_EMISSIVE);
+
+				// ---- handleScattering
+				const float scatProb = rr_probability(sc, pathLength);
+				bool cont			 = !(scatProb <= PR_EPS);
+				if (cont && scatProb < 1.0f) {
+					const float rp = rng_float(rnd);
+					if (rp > scatProb)
+						cont = false;
+				}
+				if (cont) {
+					V3 Lt;
+					Blob integral_weight, pdf_s;
+					if (!mat.two_sided && Vt.z < 0.0f) {
+						Lt				= v3(0, 0, 0);
+						integral_weight = blob(0);
+						pdf_s			= blob(0);
+					} else {
+						const float s1 = rng_float(rnd), s2 = rng_float(rnd);
+						Lt				= cos_hemi(s1, s2);
+						integral_weight = spectrum_eval(sc, mat.albedo, wl);
+						pdf_s			= blob(Lt.z * PR_INV_PI_F);
+						if (signbit(Vt.z) != signbit(Lt.z))
+							Lt = -Lt;
+					}
+					const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt));
+					flags &= ~FLAG_LAST_DELTA;
+					prev_pdf = path_pdf;
+					path_pdf = path_pdf * (pdf_s * scatProb);
+					if (all_le(path_pdf, PDF_EPS))
+						cont = false;
+					if (cont) {
+						throughput = throughput * integral_weight;
+						if (is_zero(throughput, PR_EPS))
+							cont = false;
+					}
+					if (cont) {
+						const V3 oN		 = dot(L, N) < 0 ? -N : N;
+						const V3 no		 = safe_position(P, L, oN);
+						const uint32_t nd = depth + 1;
+						if (nd < cfg.max_ray_depth) {
+							alive				= true;
+							ps.ray_o[slot]		= make_float4(no.x, no.y, no.z, BOUNCE_RAY_MIN);
+							ps.ray_d[slot]		= make_float4(L.x, L.y, L.z, INFINITY);
+							ps.throughput[slot] = to4(throughput);
+							ps.path_pdf[slot]	= to4(path_pdf);
+							ps.prev_pdf[slot]	= to4(prev_pdf);
+							ps.flags[slot]		= (flags & ~0xFFu) | nd;
+							atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
+							atomicAdd(&bs.v[PRGPU_STAT_BOUNCE_RAYS], 1u);
+							if (mono)
+								atomicAdd(&bs.v[PRGPU_STAT_MONOCHROME_RAYS], 1u);
+						}
+					}
+				}
+				ps.rng[pixel] = rnd;
+			}
+		}
+	}
+	// ballot/prefix-scan compaction of survivors and of the shadow queue
+	const uint32_t pos_next = wave_append(alive, &counters[0]);
+	if (alive)
+		next_active[pos_next] = slot;
+	const uint32_t pos_sh = wave_append(want_shadow, &counters[1]);
+	if (want_shadow) {
+		ps.sh_o[pos_sh]	   = sh_o;
+		ps.sh_d[pos_sh]	   = sh_d;
+		ps.sh_xyz[pos_sh]  = sh_xyz;
+		ps.sh_slot[pos_sh] = slot;
+	}
+	stats_flush(bs, gstats);
+}
+
+// Scene::traceShadowRay for the NEE queue, then the pending fragment (direct.cpp:329-351)
+template <bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_shadow(DevScene sc, PathState ps, const uint32_t* __restrict__ counters, unsigned long long* gstats)
+{
+	const uint32_t n = counters[1];
+	uint32_t cn = 0, ct = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const float4 o = ps.sh_o[i], d = ps.sh_d[i], x = ps.sh_xyz[i];
+		const bool occluded	 = traverse_any<COUNT>(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w, cn, ct);
+		const uint32_t fbs	 = __float_as_uint(x.w);
+		const uint32_t pixel = ps.pixel[ps.sh_slot[i]];
+		if (occluded) {
+			const uint32_t fb = (fbs >> 8) & 0xFFu;
+			if (fb)
+				ps.feedback[pixel] |= fb;
+		} else {
+			const float xyz[3] = { x.x, x.y, x.z };
+			apply_fragment(ps, pixel, fbs & 0xFFu, xyz);
+		}
+	}
+	if (COUNT) {
+		if (cn)
+			atomicAdd(&gstats[CNT_NODES_ANY], (unsigned long long)cn);
+		if (ct)
+			atomicAdd(&gstats[CNT_TRIS_ANY], (unsigned long long)ct);
+	}
+}
+
+// LocalFrameOutputDevice filter taps (LocalFrameOutputDevice.cpp:144-160), mergeLocal clipping at the film
+// border (FrameOutputDevice.cpp:83-123) and onEndOfIteration running mean (:202-221), as one gather pass.
+__global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint32_t iter)
+{
+	const uint32_t W = sc.cfg.width, H = sc.cfg.height;
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= W * H)
+		return;
+	float acc[3];
+	if (sc.single_tap) {
+		acc[0] = ps.iter_xyz[3 * p];
+		acc[1] = ps.iter_xyz[3 * p + 1];
+		acc[2] = ps.iter_xyz[3 * p + 2];
+	} else {
+		const int r = (int)sc.cfg.filter_radius, dd = 2 * r + 1;
+		const int x = (int)(p % W), y = (int)(p / W);
+		acc[0] = acc[1] = acc[2] = 0.0f;
+		for (int sy = y - r; sy <= y + r; ++sy) {
+			if (sy < 0 || sy >= (int)H)
+				continue;
+			for (int sx = x - r; sx <= x + r; ++sx) {
+				if (sx < 0 || sx >= (int)W)
+					continue;
+				// weight of tap (x - sx, y - sy) seen from the source pixel
+				const float fw = sc.filter[(y - sy + r) * dd + (x - sx + r)];
+				if (fw > PR_EPS) {
+					const uint32_t q = (uint32_t)sy * W + (uint32_t)sx;
+					acc[0] += fw * ps.iter_xyz[3 * q];
+					acc[1] += fw * ps.iter_xyz[3 * q + 1];
+					acc[2] += fw * ps.iter_xyz[3 * q + 2];
+				}
+			}
+		}
+	}
+	const float it = (float)(iter + 1), itm1 = (float)iter;
+	for (int c = 0; c < 3; ++c)
+		ps.out_xyz[3 * p + c] = (ps.out_xyz[3 * p + c] * itm1 + acc[c]) / it;
+}
+
+// clears the per-iteration plane of the pixels a path wrote (owned pixels are re-zeroed by raygen; this
+// covers nothing else, the plane is zero-initialised once) -- kept for symmetry with mCopySpectral->clear.
+
+// ---- ray service kernels (IArchive surface) ------------------------------------------------------------
+__global__ void k_service_closest(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
+								  const float* __restrict__ tmin, const float* __restrict__ tmax, uint32_t* entity, uint32_t* prim, float* u,
+								  float* v, float* t, unsigned long long* gstats)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	uint32_t cn = 0, ct = 0;
+	const Hit h	  = traverse_closest<true>(sc, v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), tmin[i],
+									   tmax[i], cn, ct);
+	const bool ok = h.tri != INVALID;
+	const uint32_t e = ok ? sc.tri_entity[h.tri] : INVALID;
+	entity[i]		 = e;
+	prim[i]			 = ok ? h.tri - sc.entities[e].first_tri : INVALID;
+	u[i]			 = ok ? h.u : 0.0f;
+	v[i]			 = ok ? h.v : 0.0f;
+	t[i]			 = ok ? h.t : tmax[i];
+	atomicAdd(&gstats[CNT_NODES_CLOSEST], (unsigned long long)cn);
+	atomicAdd(&gstats[CNT_TRIS_CLOSEST], (unsigned long long)ct);
+}
+__global__ void k_service_any(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir, const float* __restrict__ tmin,
+							  const float* __restrict__ distance, uint8_t* occluded, unsigned long long* gstats)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	uint32_t cn = 0, ct = 0;
+	occluded[i] = traverse_any<true>(sc, v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), tmin[i],
+									 distance[i], cn, ct)
+					  ? 1
+					  : 0;
+	atomicAdd(&gstats[CNT_NODES_ANY], (unsigned long long)cn);
+	atomicAdd(&gstats[CNT_TRIS_ANY], (unsigned long long)ct);
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------
+static inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block - 1) / block); }
+
+void launch_raygen(const DevScene& sc, const PathState& ps, uint32_t n_slots, uint32_t iter, unsigned long long* gstats, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_raygen, grid_for(n_slots), dim3(256), 0, st, sc, ps, n_slots, iter, gstats);
+}
+void launch_trace_closest(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n_active, bool count, unsigned long long* gstats,
+						  hipStream_t st)
+{
+	if (count)
+		hipLaunchKernelGGL(k_trace_closest<true>, grid_for(n_active), dim3(256), 0, st, sc, ps, active, n_active, gstats);
+	else
+		hipLaunchKernelGGL(k_trace_closest<false>, grid_for(n_active), dim3(256), 0, st, sc, ps, active, n_active, gstats);
+}
+void launch_shade(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n_active, uint32_t* next_active, uint32_t* counters,
+				  unsigned long long* gstats, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_shade, grid_for(n_active), dim3(256), 0, st, sc, ps, active, n_active, next_active, counters, gstats);
+}
+void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t max_items, const uint32_t* counters, bool count,
+						 unsigned long long* gstats, hipStream_t st)
+{
+	const dim3 g = grid_for(max_items);
+	if (count)
+		hipLaunchKernelGGL(k_trace_shadow<true>, g, dim3(256), 0, st, sc, ps, counters, gstats);
+	else
+		hipLaunchKernelGGL(k_trace_shadow<false>, g, dim3(256), 0, st, sc, ps, counters, gstats);
+}
+void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_resolve, grid_for(sc.cfg.width * sc.cfg.height), dim3(256), 0, st, sc, ps, iter);
+}
+void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
+							uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, unsigned long long* gstats, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_service_closest, grid_for(n), dim3(256), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, gstats);
+}
+void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* distance,
+						uint8_t* occluded, unsigned long long* gstats, hipStream_t st)
+{
+	hipLaunchKernelGGL(k_service_any, grid_for(n), dim3(256), 0, st, sc, n, org, dir, tmin, distance, occluded, gstats);
+}
+
+} // namespace prd

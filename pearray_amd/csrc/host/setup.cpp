@@ -1,0 +1,595 @@
+// setup.cpp -- host-side tables of the MI355X path-tracing backend.
+//
+// Everything here runs once per scene on the host (it is O(pixels) or O(lights) bookkeeping, not part of
+// the per-sample hot loop) and is uploaded to HBM by prgpu_scene_create:
+//   per-entity matrices/areas         entity/ITransformable.cpp:8-16, entity/IEntity.h:75-96
+//   per-pixel RNG map                 renderer/RenderRandomMap.cpp:11-28
+//   AA sampler parameters / tables    renderer/RenderTile.cpp:33-44, sampler/MultiJitteredSampler.cpp:100-108,173-176,
+//                                     sampler/SobolSampler.cpp:27-55
+//   light selector                    light/LightSampler.cpp:11-132
+//   wavelength distribution           spectralmapper/spd.cpp:220-351
+//   camera cache                      cameras/perspective.cpp:84-113
+//   filter taps                       filter/FilterCache.h:8-25 + plugins/main/filter/*.cpp
+//   Russian-roulette table            vcm/vcm/RussianRoulette.h:22-35
+#include "setup.h"
+
+#include <algorithm>
+#include <array>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "../tables/pr_tables.inl"
+
+namespace prgpu_host {
+namespace {
+
+constexpr float EPS_F = FLT_EPSILON;
+using prd::DevEntity;
+
+// ---- pcg32_fast + the libstdc++ (<= 10) integer distributions the reference draws through ------------
+struct PcgFast {
+	uint64_t state;
+	explicit PcgFast(uint64_t seed) : state(seed | 3u) {}
+	uint32_t next()
+	{
+		const uint64_t old = state;
+		state			   = old * prd::PCG_MULT;
+		const uint64_t x   = old ^ (old >> 22);
+		return uint32_t(x >> (22u + (uint32_t(old >> 61) & 7u)));
+	}
+	uint64_t next64() // uniform_int_distribution<uint64>: high word, then low word
+	{
+		const uint64_t hi = next();
+		return (hi << 32) | next();
+	}
+	// uniform_int_distribution<uint32>(a, b) -- scale + reject
+	uint32_t between(uint32_t a, uint32_t b)
+	{
+		const uint32_t urange = b - a;
+		if (urange == 0xFFFFFFFFu)
+			return next() + a;
+		const uint32_t uerange = urange + 1, scaling = 0xFFFFFFFFu / uerange, past = uerange * scaling;
+		uint32_t r;
+		do
+			r = next();
+		while (r >= past);
+		return r / scaling + a;
+	}
+	// uniform_int_distribution<uint64>(0, b) driven by 64-bit draws (Random::operator())
+	uint64_t below64(uint64_t b)
+	{
+		if (b == ~uint64_t(0))
+			return next64();
+		const uint64_t uerange = b + 1, scaling = ~uint64_t(0) / uerange, past = uerange * scaling;
+		uint64_t r;
+		do
+			r = next64();
+		while (r >= past);
+		return r / scaling;
+	}
+};
+
+// std::shuffle as implemented by libstdc++ (two positions per draw when the generator range allows)
+template <typename It>
+void shuffle_like_libstdcxx(It first, It last, PcgFast& g)
+{
+	const uint64_t n = uint64_t(last - first);
+	if (n == 0)
+		return;
+	if (~uint64_t(0) / n >= n) {
+		It i = first + 1;
+		if ((n % 2) == 0) {
+			std::iter_swap(i, first + g.below64(1));
+			++i;
+		}
+		while (i != last) {
+			const uint64_t range = uint64_t(i - first) + 1, b1 = range + 1;
+			const uint64_t x	 = g.below64(range * b1 - 1);
+			std::iter_swap(i, first + x / b1);
+			++i;
+			std::iter_swap(i, first + x % b1);
+			++i;
+		}
+		return;
+	}
+	for (It i = first + 1; i != last; ++i)
+		std::iter_swap(i, first + g.below64(uint64_t(i - first)));
+}
+
+uint64_t mcg_pow(uint64_t delta)
+{
+	uint64_t acc = 1, cur = prd::PCG_MULT;
+	for (; delta; delta >>= 1, cur *= cur)
+		if (delta & 1)
+			acc *= cur;
+	return acc;
+}
+
+// ---- spectral network on the host (needed for light power / wavelength distribution) -----------------
+struct V4 {
+	float v[4];
+};
+float lookup_table(const float* data, int count, float start, float delta, float wl)
+{
+	const float af	= std::max(0.0f, (wl - start) / delta);
+	const int index = (int)std::min<float>(float(count - 2), af);
+	const float t	= std::min<float>(float(count - 1), af) - index;
+	return data[index] * (1 - t) + data[index + 1] * t;
+}
+float sigmoid_poly(const float* p, float wl)
+{
+	const float x = (p[0] * wl + p[1]) * wl + p[2];
+	return (0.5f * x) * (1.0f / std::sqrt(x * x + 1.0f)) + 0.5f;
+}
+V4 eval_leaf(const prgpu_scene_desc* d, const prgpu_spectrum& n, const V4& wl)
+{
+	V4 r{ { 0, 0, 0, 0 } };
+	for (int k = 0; k < 4; ++k) {
+		switch (n.kind) {
+		case PRGPU_SPEC_CONST: r.v[k] = n.p[0]; break;
+		case PRGPU_SPEC_PARAMETRIC: r.v[k] = sigmoid_poly(n.p, wl.v[k]); break;
+		case PRGPU_SPEC_PARAMETRIC_SCALED: r.v[k] = sigmoid_poly(n.p, wl.v[k]) * n.p[3]; break;
+		case PRGPU_SPEC_TABLE:
+			r.v[k] = lookup_table(d->spectral_tables + n.table_offset, (int)n.table_count, n.wl_start, (n.wl_end - n.wl_start) / (n.table_count - 1), wl.v[k]);
+			break;
+		default: break;
+		}
+	}
+	return r;
+}
+V4 eval_spectrum(const prgpu_scene_desc* d, uint32_t id, const V4& wl)
+{
+	const prgpu_spectrum& n = d->spectra[id];
+	if (n.kind != PRGPU_SPEC_MUL)
+		return eval_leaf(d, n, wl);
+	const V4 a = eval_leaf(d, d->spectra[n.lhs], wl), b = eval_leaf(d, d->spectra[n.rhs], wl);
+	return V4{ { a.v[0] * b.v[0], a.v[1] * b.v[1], a.v[2] * b.v[2], a.v[3] * b.v[3] } };
+}
+// NodeUtils::average over the 32x32 UV grid (shader/NodeUtils.cpp:7-47); nodes here do not depend on UV
+V4 average_power(const prgpu_scene_desc* d, uint32_t id, const V4& wl)
+{
+	const V4 v = eval_spectrum(d, id, wl);
+	V4 sum	   = v;
+	for (int i = 1; i < 1024; ++i)
+		for (int k = 0; k < 4; ++k)
+			sum.v[k] += v.v[k];
+	for (int k = 0; k < 4; ++k)
+		sum.v[k] /= 1024.0f;
+	return sum;
+}
+void spectral_range(const prgpu_scene_desc* d, uint32_t id, float& start, float& end) // -1 = unbounded
+{
+	const prgpu_spectrum& n = d->spectra[id];
+	start = end = -1.0f;
+	if (n.kind == PRGPU_SPEC_TABLE) {
+		start = n.wl_start;
+		end	  = n.wl_end;
+	} else if (n.kind == PRGPU_SPEC_MUL) {
+		float s0, e0, s1, e1;
+		spectral_range(d, n.lhs, s0, e0);
+		spectral_range(d, n.rhs, s1, e1);
+		start = s0 < 0 ? s1 : (s1 < 0 ? s0 : std::min(s0, s1)); // SpectralRange::operator+=
+		end	  = std::max(e0, e1);
+	}
+}
+
+void make_cdf(const std::vector<float>& values, std::vector<float>& cdf, float* total) // Distribution1D::generate
+{
+	const size_t n = values.size();
+	cdf.assign(n + 1, 0.0f);
+	for (size_t i = 0; i < n; ++i)
+		cdf[i + 1] = cdf[i] + values[i];
+	const float sum = cdf[n];
+	if (total)
+		*total = sum;
+	for (size_t i = 1; i <= n; ++i)
+		cdf[i] = sum <= EPS_F ? float(i) / float(n) : cdf[i] / sum;
+	cdf[n] = 1.0f;
+}
+
+void cie_xyz(float wl, float xyz[3])
+{
+	const float* planes[3] = { PR_CIE2006_X, PR_CIE2006_Y, PR_CIE2006_Z };
+	for (int c = 0; c < 3; ++c)
+		xyz[c] = lookup_table(planes[c], prd::CIE_SAMPLES, prd::CIE_START, prd::CIE_DELTA, wl) / prd::CIE_Y_NORM * prd::CIE_RANGE;
+}
+
+void entity_tables(const prgpu_scene_desc* d, HostTables& t)
+{
+	t.entities.resize(d->n_entities);
+	t.tri_entity.resize(d->n_triangles);
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& src = d->entities[e];
+		DevEntity& E			= t.entities[e];
+		std::memcpy(E.m, src.transform, sizeof(float) * 12);
+		const float* m = src.transform;
+		const float a = m[0], b = m[1], c = m[2], dd = m[4], ee = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+		const float cof[9] = { ee * i - f * h, f * g - dd * i, dd * h - ee * g, c * h - b * i, a * i - c * g, b * g - a * h, b * f - c * ee, c * dd - a * f, a * ee - b * dd };
+		const float det	   = (a * cof[0] + b * cof[1]) + c * cof[2];
+		for (int k = 0; k < 9; ++k)
+			E.nm[k] = cof[k] / det; // (M^-1)^T = cofactor / det
+		E.vol_scale	  = std::fabs(det);
+		E.first_tri	  = src.first_tri;
+		E.n_tris	  = src.n_tris;
+		E.emission	  = src.emission;
+		E.has_normals = (src.has_normals && d->normals) ? 1u : 0u;
+		E.light_id	  = PRGPU_INVALID_ID;
+		E.pad		  = 0;
+		float area	  = 0;
+		for (uint32_t tri = src.first_tri; tri < src.first_tri + src.n_tris; ++tri) {
+			t.tri_entity[tri] = e;
+			const float* p0	  = d->positions + 3 * d->indices[3 * tri];
+			const float* p1	  = d->positions + 3 * d->indices[3 * tri + 1];
+			const float* p2	  = d->positions + 3 * d->indices[3 * tri + 2];
+			const float e1[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] }, e2[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
+			const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+			area += 0.5f * std::sqrt((cx * cx + cy * cy) + cz * cz);
+		}
+		E.world_area = E.vol_scale * area;
+	}
+}
+
+void sampler_tables(const prgpu_scene_desc* d, HostTables& t)
+{
+	const prgpu_settings& c = d->settings;
+	t.spp					= c.aa_samples * c.lens_samples * c.time_samples * c.spectral_samples;
+	PcgFast aa(c.seed ^ (uint64_t(4201321) + 1)); // RandomSlot::AA
+	if (c.aa_sampler == PRGPU_SAMPLER_MJITT) {
+		const uint32_t bins = std::max(1u, t.spp);
+		t.mj_x				= (uint32_t)std::sqrt((float)bins);
+		t.mj_y				= (bins + t.mj_x - 1) / t.mj_x;
+		t.mj_seed			= 14512081u ^ aa.next();
+	} else if (c.aa_sampler == PRGPU_SAMPLER_SOBOL) {
+		const uint32_t n = t.spp;
+		auto to_unit	 = [](uint64_t v) {
+			const uint64_t bits = (v >> 12) | 0x3FF0000000000000ULL;
+			double f;
+			std::memcpy(&f, &bits, 8);
+			return (float)(f - 1.0);
+		};
+		uint64_t dir0[64], dir1[64]; // direction numbers: van der Corput, and x+1 (v ^= v >> 1)
+		for (int k = 0; k < 64; ++k)
+			dir0[k] = uint64_t(1) << (63 - k);
+		dir1[0] = uint64_t(1) << 63;
+		for (int k = 1; k < 64; ++k)
+			dir1[k] = dir1[k - 1] ^ (dir1[k - 1] >> 1);
+		std::vector<float> one(n, 0.0f);
+		std::vector<std::array<float, 2>> two(n, std::array<float, 2>{ 0.0f, 0.0f });
+		uint64_t x0 = 0, x1 = 0;
+		for (uint32_t i = 1; i < n; ++i) {
+			int bit = 0;
+			for (uint32_t m = i - 1; m & 1; m >>= 1)
+				++bit;
+			x0 ^= dir0[bit];
+			x1 ^= dir1[bit];
+			one[i] = to_unit(x0);
+			two[i] = { one[i], to_unit(x1) };
+		}
+		shuffle_like_libstdcxx(one.begin(), one.end(), aa);
+		shuffle_like_libstdcxx(two.begin(), two.end(), aa);
+		t.sobol2d.resize(2 * size_t(n));
+		for (uint32_t i = 0; i < n; ++i) {
+			t.sobol2d[2 * i]	 = two[i][0];
+			t.sobol2d[2 * i + 1] = two[i][1];
+		}
+	}
+	if (t.sobol2d.empty())
+		t.sobol2d.assign(2, 0.0f);
+}
+
+void light_tables(const prgpu_scene_desc* d, HostTables& t)
+{
+	const float probe[4] = { 0.05f, 0.05f + 1 * ((0.95f - 0.05f) / 3), 0.05f + 2 * ((0.95f - 0.05f) / 3), 0.95f };
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const uint32_t ems = d->entities[e].emission;
+		if (ems == PRGPU_INVALID_ID)
+			continue;
+		float rs, re;
+		spectral_range(d, d->emissions[ems].radiance, rs, re);
+		if (rs < 0)
+			rs = d->settings.spectral_start;
+		if (re < 0)
+			re = d->settings.spectral_end;
+		V4 wl;
+		for (int k = 0; k < 4; ++k)
+			wl.v[k] = rs + (re - rs) * probe[k];
+		const V4 pw		 = average_power(d, d->emissions[ems].radiance, wl);
+		const float mean = (((pw.v[0] + pw.v[1]) + pw.v[2]) + pw.v[3]) / 4.0f;
+		t.entities[e].light_id = (uint32_t)t.light_entity.size();
+		t.light_entity.push_back(e);
+		t.light_intensity.push_back(t.entities[e].world_area * mean);
+	}
+	if (!t.light_entity.empty()) {
+		float total;
+		make_cdf(t.light_intensity, t.light_cdf, &total);
+		if (total > EPS_F)
+			for (float& f : t.light_intensity)
+				f *= 1 / total;
+	} else {
+		t.light_cdf.assign(2, 0.0f);
+		t.light_entity.assign(1, 0);
+	}
+}
+
+void wavelength_table(const prgpu_scene_desc* d, HostTables& t, size_t n_lights)
+{
+	const uint32_t bins = 440;
+	const float start = d->settings.spectral_start, span = d->settings.spectral_end - d->settings.spectral_start;
+	auto wavelength_of = [&](uint32_t bin) { return start + (bin / float(bins - 1)) * span; };
+	std::vector<float> total(bins, 0.0f), one(bins, 0.0f);
+	for (size_t l = 0; l < n_lights; ++l) {
+		const uint32_t node = d->emissions[d->entities[t.light_entity[l]].emission].radiance;
+		for (uint32_t i = 0; i < bins; i += 4) {
+			const uint32_t k = std::min<uint32_t>(bins - i, 4);
+			V4 wl{ { 0, 0, 0, 0 } };
+			for (uint32_t j = 0; j < k; ++j)
+				wl.v[j] = wavelength_of(i + j);
+			for (uint32_t j = k; j < 4; ++j)
+				wl.v[j] = wl.v[0];
+			const V4 p = average_power(d, node, wl);
+			for (uint32_t j = 0; j < k; ++j)
+				one[i + j] = p.v[j];
+		}
+		const float dt = 1.0f / (bins - 1);
+		float integral = 0;
+		for (float f : one)
+			integral += f * dt;
+		if (integral > EPS_F) {
+			const float inv = 1 / integral;
+			for (float& f : one)
+				f *= inv;
+		}
+		for (uint32_t i = 0; i < bins; ++i)
+			total[i] += one[i];
+	}
+	if (!(start > prd::CIE_END || d->settings.spectral_end < prd::CIE_START)) {
+		for (uint32_t i = 0; i < bins; ++i) {
+			float xyz[3];
+			cie_xyz(wavelength_of(i), xyz);
+			total[i] *= (xyz[0] + xyz[1]) + xyz[2];
+		}
+	}
+	for (float& f : total)
+		f = std::max(1e-2f, f);
+	make_cdf(total, t.wl_cdf, nullptr);
+}
+
+void camera_cache(const prgpu_scene_desc* d, HostTables& t)
+{
+	const prgpu_camera& c = d->camera;
+	auto lin = [&](const float v[3], float out[3]) {
+		for (int r = 0; r < 3; ++r)
+			out[r] = (c.transform[4 * r] * v[0] + c.transform[4 * r + 1] * v[1]) + c.transform[4 * r + 2] * v[2];
+	};
+	float dir[3], right[3], up[3];
+	lin(c.local_direction, dir);
+	lin(c.local_right, right);
+	lin(c.local_up, up);
+	prd::DevCamera& o = t.cam;
+	o.o[0] = c.transform[3];
+	o.o[1] = c.transform[7];
+	o.o[2] = c.transform[11];
+	o.dof	 = (c.aperture_radius > EPS_F && c.fstop > EPS_F) ? 1u : 0u;
+	o.near_t = c.near_t;
+	o.far_t	 = c.far_t;
+	for (int k = 0; k < 3; ++k) {
+		if (!o.dof) {
+			o.focal[k] = dir[k];
+			o.xap[k] = o.yap[k] = 0.0f;
+			o.right[k]			= right[k] * (0.5f * c.width);
+			o.up[k]				= up[k] * (0.5f * c.height);
+		} else {
+			o.focal[k] = dir[k] * (c.fstop + 1);
+			o.xap[k]   = right[k] * c.aperture_radius;
+			o.yap[k]   = up[k] * c.aperture_radius;
+			o.right[k] = right[k] * (0.5f * c.width * (c.fstop + 1));
+			o.up[k]	   = up[k] * (0.5f * c.height * (c.fstop + 1));
+		}
+	}
+}
+
+void filter_taps(const prgpu_scene_desc* d, HostTables& t)
+{
+	const int r = (int)d->settings.filter_radius, dia = 2 * r + 1, half = r + 1;
+	const uint32_t kind = d->settings.filter;
+	t.filter.assign(size_t(dia) * dia, 1.0f);
+	if (kind == PRGPU_FILTER_BLOCK) {
+		for (float& f : t.filter)
+			f = 1.0f / ((2 * r + 1) * (2 * r + 1));
+	} else if (r > 0) {
+		std::vector<float> quadrant(size_t(half) * half);
+		float s1 = 0, s2 = 0, s4 = 0;
+		for (int y = 0; y < half; ++y)
+			for (int x = 0; x < half; ++x) {
+				const float dist = std::sqrt(float(x * x + y * y));
+				float val		 = 0;
+				if (kind == PRGPU_FILTER_TRIANGLE) {
+					val = dist <= r ? 1 - dist / (float)r : 0.0f;
+				} else if (kind == PRGPU_FILTER_GAUSSIAN) {
+					const float dev2 = 0.2f, alpha = 1 / (2 * dev2), q = dist / (float)r;
+					val = q <= 1.0f ? std::exp(-alpha * q * q) : 0.0f;
+				} else {
+					const float B = 1 / 3.0f, C = 1 / 3.0f;
+					const float xx = std::fabs(2 * dist / r);
+					if (xx < 1)
+						val = ((12 - 9 * B - 6 * C) * xx * xx * xx + (-18 + 12 * B + 6 * C) * xx * xx + (6 - 2 * B)) / 6;
+					else if (xx < 2)
+						val = ((-B - 6 * C) * xx * xx * xx + (6 * B + 30 * C) * xx * xx + (-12 * B - 48 * C) * xx + (8 * B + 24 * C)) / 6;
+				}
+				quadrant[y * half + x] = val;
+				if (x == 0 && y == 0)
+					s1 += val;
+				else if (x == 0 || y == 0)
+					s2 += val;
+				else
+					s4 += val;
+			}
+		const float norm = 1.0f / (s1 + 2 * s2 + 4 * s4);
+		for (float& f : quadrant)
+			f *= norm;
+		for (int y = -r; y <= r; ++y)
+			for (int x = -r; x <= r; ++x)
+				t.filter[(y + r) * dia + (x + r)] = quadrant[std::abs(y) * half + std::abs(x)];
+	}
+	// does only the centre tap survive the `weight > eps` test of commitSpectrals2?
+	uint32_t live = 0;
+	for (float f : t.filter)
+		live += f > EPS_F ? 1 : 0;
+	t.centre_weight = t.filter[size_t(r) * dia + r];
+	t.single_tap	= (live == 1 && t.centre_weight > EPS_F) ? 1u : 0u;
+}
+
+} // namespace
+
+int validate_desc(const prgpu_scene_desc* d, std::string& err)
+{
+	auto bad = [&](const char* m, int code = PRGPU_EINVAL) {
+		err = m;
+		return code;
+	};
+	if (!d)
+		return bad("null scene description");
+	if (d->api_version != PRGPU_API_VERSION)
+		return bad("scene description has a different api_version");
+	if (!d->n_vertices || !d->n_triangles || !d->n_entities || !d->positions || !d->indices || !d->tri_material || !d->entities)
+		return bad("empty scene (vertices, triangles and entities are required)");
+	const prgpu_settings& c = d->settings;
+	if (!c.width || !c.height)
+		return bad("film size is zero");
+	if (uint64_t(c.width) * c.height > 0x7FFFFFFFull)
+		return bad("film too large");
+	if (c.filter_radius > 3)
+		return bad("filter radius > 3 is not supported", PRGPU_EUNSUPPORTED);
+	if (c.aa_sampler > PRGPU_SAMPLER_SOBOL || c.mapper > PRGPU_MAPPER_SPD_HERO || c.filter > PRGPU_FILTER_MITCHELL || c.mis > PRGPU_MIS_POWER)
+		return bad("unknown sampler / mapper / filter / mis selector");
+	if (!c.aa_samples || !c.lens_samples || !c.time_samples || !c.spectral_samples)
+		return bad("sample counts must be positive");
+	if (!(c.spectral_end > c.spectral_start))
+		return bad("spectral domain is empty");
+	if (c.max_ray_depth == 0 || c.max_ray_depth > 255)
+		return bad("max_ray_depth must be in 1..255");
+	if (d->n_entities > 0xFFFF)
+		return bad("more than 65535 entities", PRGPU_EUNSUPPORTED);
+	for (uint64_t i = 0; i < 3ull * d->n_triangles; ++i)
+		if (d->indices[i] >= d->n_vertices)
+			return bad("vertex index out of range");
+	uint32_t expect = 0;
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& E = d->entities[e];
+		if (E.first_tri != expect || E.n_tris == 0)
+			return bad("entity triangle ranges must be contiguous, ordered and non-empty");
+		expect += E.n_tris;
+		if (E.emission != PRGPU_INVALID_ID && E.emission >= d->n_emissions)
+			return bad("emission index out of range");
+		if (E.has_normals && !d->normals)
+			return bad("entity wants normals but the scene has none");
+		const float* m	= E.transform;
+		const float det = (m[0] * (m[5] * m[10] - m[6] * m[9]) + m[1] * (m[6] * m[8] - m[4] * m[10])) + m[2] * (m[4] * m[9] - m[5] * m[8]);
+		if (!(std::fabs(det) > 0.0f) || !std::isfinite(det))
+			return bad("singular entity transform");
+	}
+	if (expect != d->n_triangles)
+		return bad("entity triangle ranges do not cover the index buffer");
+	for (uint32_t t = 0; t < d->n_triangles; ++t)
+		if (d->tri_material[t] != PRGPU_INVALID_ID && d->tri_material[t] >= d->n_materials)
+			return bad("material index out of range");
+	for (uint32_t i = 0; i < d->n_spectra; ++i) {
+		const prgpu_spectrum& n = d->spectra[i];
+		if (n.kind > PRGPU_SPEC_MUL)
+			return bad("unknown spectrum kind");
+		if (n.kind == PRGPU_SPEC_TABLE && (n.table_count < 2 || uint64_t(n.table_offset) + n.table_count > d->n_spectral_table_values || !(n.wl_end > n.wl_start)))
+			return bad("spectrum table out of range");
+		if (n.kind == PRGPU_SPEC_MUL) {
+			if (n.lhs >= i || n.rhs >= i)
+				return bad("MUL operands must precede the node");
+			if (d->spectra[n.lhs].kind == PRGPU_SPEC_MUL || d->spectra[n.rhs].kind == PRGPU_SPEC_MUL)
+				return bad("nested MUL spectral nodes are not supported", PRGPU_EUNSUPPORTED);
+		}
+	}
+	for (uint32_t i = 0; i < d->n_materials; ++i) {
+		if (d->materials[i].kind != PRGPU_MAT_LAMBERT)
+			return bad("only lambert materials are implemented", PRGPU_EUNSUPPORTED);
+		if (d->materials[i].albedo >= d->n_spectra)
+			return bad("material albedo index out of range");
+	}
+	for (uint32_t i = 0; i < d->n_emissions; ++i) {
+		if (d->emissions[i].kind != PRGPU_EMS_DIFFUSE)
+			return bad("only diffuse emissions are implemented", PRGPU_EUNSUPPORTED);
+		if (d->emissions[i].radiance >= d->n_spectra)
+			return bad("emission radiance index out of range");
+	}
+	return PRGPU_OK;
+}
+
+int build_tables(const prgpu_scene_desc* d, HostTables& t, std::string& err)
+{
+	(void)err;
+	entity_tables(d, t);
+	sampler_tables(d, t);
+	light_tables(d, t);
+	size_t n_lights = 0;
+	for (uint32_t e = 0; e < d->n_entities; ++e)
+		n_lights += d->entities[e].emission != PRGPU_INVALID_ID;
+	wavelength_table(d, t, n_lights);
+	camera_cache(d, t);
+	filter_taps(d, t);
+	// Russian roulette: min(1, 0.9^(L - soft)) with the 1e-4 cut, indexed by path length
+	const prgpu_settings& c = d->settings;
+	t.rr_prob.resize(size_t(c.max_ray_depth) + 2);
+	for (uint32_t L = 0; L < t.rr_prob.size(); ++L) {
+		float p = 1.0f;
+		if (L != 0 && L >= c.soft_max_ray_depth) {
+			p = std::min<float>(1.0f, (float)std::pow((double)0.9f, (double)(L - c.soft_max_ray_depth)));
+			if (p <= 1e-4f)
+				p = 0.0f;
+		}
+		t.rr_prob[L] = p;
+	}
+	t.cie.resize(3 * prd::CIE_SAMPLES);
+	std::copy(PR_CIE2006_X, PR_CIE2006_X + prd::CIE_SAMPLES, t.cie.begin());
+	std::copy(PR_CIE2006_Y, PR_CIE2006_Y + prd::CIE_SAMPLES, t.cie.begin() + prd::CIE_SAMPLES);
+	std::copy(PR_CIE2006_Z, PR_CIE2006_Z + prd::CIE_SAMPLES, t.cie.begin() + 2 * prd::CIE_SAMPLES);
+	// per-pixel generators: pixel i = pixel i-1 advanced by spp draws, then the pseudo-shuffle driven by pixel 0
+	const uint32_t np = c.width * c.height;
+	t.rng.resize(np);
+	t.rng[0]			= PcgFast(c.seed).state;
+	const uint64_t jump = mcg_pow(t.spp);
+	for (uint32_t i = 1; i < np; ++i)
+		t.rng[i] = t.rng[i - 1] * jump;
+	PcgFast first(0);
+	first.state = t.rng[0];
+	for (uint32_t i = 1; i < np; ++i)
+		std::swap(t.rng[i], t.rng[first.between(1, np - 1)]);
+	t.rng[0] = first.state;
+	return PRGPU_OK;
+}
+
+void owned_pixels_morton(uint32_t W, uint32_t H, const prgpu_tile* tiles, uint32_t n_tiles, std::vector<uint32_t>& pixels)
+{
+	std::vector<uint8_t> owned(size_t(W) * H, n_tiles == 0 ? 1 : 0);
+	for (uint32_t i = 0; i < n_tiles; ++i)
+		for (uint32_t y = tiles[i].y0; y < tiles[i].y1; ++y)
+			for (uint32_t x = tiles[i].x0; x < tiles[i].x1; ++x)
+				owned[size_t(y) * W + x] = 1;
+	auto spread = [](uint64_t x) {
+		x = (x | (x << 16)) & 0x0000FFFF0000FFFFULL;
+		x = (x | (x << 8)) & 0x00FF00FF00FF00FFULL;
+		x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0FULL;
+		x = (x | (x << 2)) & 0x3333333333333333ULL;
+		x = (x | (x << 1)) & 0x5555555555555555ULL;
+		return x;
+	};
+	std::vector<std::pair<uint64_t, uint32_t>> order;
+	order.reserve(size_t(W) * H);
+	for (uint32_t y = 0; y < H; ++y)
+		for (uint32_t x = 0; x < W; ++x)
+			if (owned[size_t(y) * W + x])
+				order.emplace_back(spread(x) | (spread(y) << 1), y * W + x);
+	std::sort(order.begin(), order.end());
+	pixels.resize(order.size());
+	for (size_t i = 0; i < order.size(); ++i)
+		pixels[i] = order[i].second;
+}
+
+} // namespace prgpu_host

@@ -1,0 +1,38 @@
+// setup.h -- host-side preparation of the render tables (everything RenderContext::start and the tile /
+// sampler / mapper constructors do once per render in the reference).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/prgpu.h"
+#include "../device/pr_device.h"
+
+namespace prgpu_host {
+
+void rgb_to_coeffs(const float rgb[3], float out[3]);
+
+struct HostTables {
+	std::vector<prd::DevEntity> entities;
+	std::vector<uint32_t> tri_entity;
+	std::vector<uint32_t> light_entity;
+	std::vector<float> light_cdf, light_intensity;
+	std::vector<float> wl_cdf;
+	std::vector<float> sobol2d;
+	std::vector<float> rr_prob;
+	std::vector<float> filter;
+	std::vector<float> cie; // X,Y,Z planes
+	std::vector<uint64_t> rng;
+	prd::DevCamera cam;
+	uint32_t spp = 0, mj_x = 1, mj_y = 1, mj_seed = 0;
+	uint32_t single_tap = 0;
+	float centre_weight = 1.0f;
+};
+
+// returns PRGPU_OK or an error code with `err` set
+int validate_desc(const prgpu_scene_desc* d, std::string& err);
+int build_tables(const prgpu_scene_desc* d, HostTables& t, std::string& err);
+// Morton-ordered list of the owned pixels (StreamPipeline.cpp:83-133 walks each tile in Morton order)
+void owned_pixels_morton(uint32_t W, uint32_t H, const prgpu_tile* tiles, uint32_t n_tiles, std::vector<uint32_t>& pixels);
+
+} // namespace prgpu_host

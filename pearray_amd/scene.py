@@ -1,0 +1,343 @@
+"""Host-side scene assembly: flattens meshes / materials / spectra into ``prgpu_scene_desc``.
+
+Mirrors what PearRay's loader hands to ``Scene`` and ``RenderContext`` for the `direct` path
+(src/loader/SceneLoader.cpp:446-739 entity/material/emission/node creation), restricted to what the
+hot path evaluates.  The description is plain data; the same object can be given to the HIP backend
+(``pearray_amd.backend``) and, in tests, to the CPU checker.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import _cabi as abi
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+IDENTITY = np.eye(4, dtype=np.float32)
+
+
+def _d65_table():
+    with open(os.path.join(_DATA, "illuminants.json")) as f:
+        return json.load(f)["D65"]
+
+
+def rgb_to_coeffs(rgb):
+    """`(refl r g b)` coefficient lookup (SpectralValueNode.cpp:16-30) through the backend library."""
+    lib = abi.load()
+    src = (C.c_float * 3)(*[float(x) for x in rgb])
+    dst = (C.c_float * 3)()
+    abi.check(lib.prgpu_rgb_to_coeffs(src, dst))
+    return [dst[0], dst[1], dst[2]]
+
+
+class SceneBuilder:
+    def __init__(self, width, height):
+        self.settings = abi.default_settings(width, height)
+        self.camera = abi.Camera()
+        self.spectra, self.tables = [], []
+        self.materials, self.emissions, self.entities = [], [], []
+        self._pos, self._nrm, self._idx, self._trimat = [], [], [], []
+        self._n_vertices = 0
+        self._any_normals = False
+        self.set_camera(IDENTITY)
+
+    # ---- spectral nodes -------------------------------------------------------------------------
+    def _add_spec(self, **kw):
+        s = abi.Spectrum()
+        for k, v in kw.items():
+            if k == "p":
+                for i, x in enumerate(v):
+                    s.p[i] = x
+            else:
+                setattr(s, k, v)
+        self.spectra.append(s)
+        return len(self.spectra) - 1
+
+    def spectrum_const(self, value):
+        return self._add_spec(kind=abi.SPEC_CONST, p=[value])
+
+    def spectrum_coeffs(self, coeffs, power=None):
+        if power is None:
+            return self._add_spec(kind=abi.SPEC_PARAMETRIC, p=list(coeffs))
+        return self._add_spec(kind=abi.SPEC_PARAMETRIC_SCALED, p=list(coeffs) + [power])
+
+    def refl(self, r, g, b):
+        """(refl r g b), SpectralValueNode.cpp:16-30"""
+        return self.spectrum_coeffs(rgb_to_coeffs((r, g, b)))
+
+    def illum(self, r, g, b):
+        """(illum r g b), SpectralValueNode.cpp:31-47: scaled so the fitted colour has max 0.5"""
+        rgb = np.array([r, g, b], dtype=np.float32)
+        mx = np.float32(rgb.max())
+        if mx <= 0:
+            return self.spectrum_coeffs(rgb_to_coeffs(rgb), power=1.0)
+        scale = np.float32(2) * mx
+        return self.spectrum_coeffs(rgb_to_coeffs(rgb / scale), power=float(scale))
+
+    def spectrum_table(self, start, end, values):
+        """(spectrum :start :end v...), SpectralConstNode.cpp:12-33 (values clamped to >= 0)"""
+        off = len(self.tables)
+        self.tables.extend(max(0.0, float(v)) for v in values)
+        return self._add_spec(kind=abi.SPEC_TABLE, table_offset=off, table_count=len(values), wl_start=start, wl_end=end)
+
+    def illuminant_d65(self):
+        """(illuminant "D65"), IlluminantNode.cpp:59,89-90: 107 samples 300..830 nm"""
+        return self.spectrum_table(300.0, 830.0, _d65_table())
+
+    def smul(self, a, b):
+        return self._add_spec(kind=abi.SPEC_MUL, lhs=a, rhs=b)
+
+    # ---- materials / emissions ---------------------------------------------------------------------
+    def lambert(self, albedo, two_sided=True):
+        m = abi.Material(abi.MAT_LAMBERT, albedo, 1 if two_sided else 0, 0)
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    def diffuse_emission(self, radiance):
+        self.emissions.append(abi.Emission(abi.EMS_DIFFUSE, radiance))
+        return len(self.emissions) - 1
+
+    # ---- geometry ------------------------------------------------------------------------------------
+    def add_mesh(self, positions, faces, material, normals=None, emission=None, transform=IDENTITY, face_materials=None):
+        """One `(entity :type 'mesh')`.  Quads are split like Embree quads: (v0,v1,v3) and (v2,v3,v1)."""
+        positions = np.asarray(positions, dtype=np.float32).reshape(-1, 3)
+        tris, tmat = [], []
+        for fi, f in enumerate(faces):
+            m = material if face_materials is None else face_materials[fi]
+            if len(f) == 3:
+                tris.append(list(f)); tmat.append(m)
+            elif len(f) == 4:
+                tris.append([f[0], f[1], f[3]]); tmat.append(m)
+                tris.append([f[2], f[3], f[1]]); tmat.append(m)
+            else:
+                raise ValueError("only triangles and quads")
+        tris = np.asarray(tris, dtype=np.uint32).reshape(-1, 3)
+        e = abi.Entity()
+        e.first_tri = sum(len(i) for i in self._idx)
+        e.n_tris = len(tris)
+        e.emission = abi.INVALID_ID if emission is None else emission
+        e.has_normals = 0 if normals is None else 1
+        t = np.asarray(transform, dtype=np.float32).reshape(16)
+        for i in range(16):
+            e.transform[i] = float(t[i])
+        self.entities.append(e)
+        self._pos.append(positions)
+        if normals is not None:
+            self._any_normals = True
+            self._nrm.append(np.asarray(normals, dtype=np.float32).reshape(-1, 3))
+        else:
+            self._nrm.append(np.zeros_like(positions))
+        self._idx.append(tris + np.uint32(self._n_vertices))
+        self._trimat.append(np.asarray([abi.INVALID_ID if m is None else m for m in tmat], dtype=np.uint32))
+        self._n_vertices += len(positions)
+        return len(self.entities) - 1
+
+    def set_camera(self, transform, width=1.0, height=1.0, near=1e-6, far=float("inf"), local_direction=(0, 0, 1),
+                   local_right=(1, 0, 0), local_up=(0, 1, 0), fstop=0.0, aperture_radius=0.05):
+        c = self.camera
+        t = np.asarray(transform, dtype=np.float32).reshape(16)
+        for i in range(16):
+            c.transform[i] = float(t[i])
+        c.width, c.height, c.near_t, c.far_t = width, height, near, far
+        for i in range(3):
+            c.local_direction[i] = local_direction[i]
+            c.local_right[i] = local_right[i]
+            c.local_up[i] = local_up[i]
+        c.fstop, c.aperture_radius = fstop, aperture_radius
+
+    def build(self):
+        return SceneData(self)
+
+
+class SceneData:
+    """Owns the numpy/ctypes storage behind one ``prgpu_scene_desc``."""
+
+    def __init__(self, b):
+        self.positions = np.ascontiguousarray(np.concatenate(b._pos), dtype=np.float32)
+        self.normals = np.ascontiguousarray(np.concatenate(b._nrm), dtype=np.float32) if b._any_normals else None
+        self.indices = np.ascontiguousarray(np.concatenate(b._idx), dtype=np.uint32)
+        self.tri_material = np.ascontiguousarray(np.concatenate(b._trimat), dtype=np.uint32)
+        self.entities = (abi.Entity * len(b.entities))(*b.entities)
+        self.materials = (abi.Material * max(1, len(b.materials)))(*b.materials)
+        self.emissions = (abi.Emission * max(1, len(b.emissions)))(*b.emissions)
+        self.spectra = (abi.Spectrum * max(1, len(b.spectra)))(*b.spectra)
+        self.tables = np.ascontiguousarray(np.asarray(b.tables if b.tables else [0.0], dtype=np.float32))
+        d = abi.SceneDesc()
+        d.api_version = abi.PRGPU_API_VERSION
+        d.n_vertices = len(self.positions)
+        d.positions = self.positions.ctypes.data_as(C.POINTER(C.c_float))
+        d.normals = self.normals.ctypes.data_as(C.POINTER(C.c_float)) if self.normals is not None else None
+        d.n_triangles = len(self.indices)
+        d.indices = self.indices.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.tri_material = self.tri_material.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.n_entities = len(b.entities)
+        d.entities = self.entities
+        d.n_materials = len(b.materials)
+        d.materials = self.materials
+        d.n_emissions = len(b.emissions)
+        d.emissions = self.emissions
+        d.n_spectra = len(b.spectra)
+        d.spectra = self.spectra
+        d.n_spectral_table_values = len(b.tables)
+        d.spectral_tables = self.tables.ctypes.data_as(C.POINTER(C.c_float))
+        d.camera = b.camera
+        d.settings = b.settings
+        self.desc = d
+
+    @property
+    def settings(self):
+        return self.desc.settings
+
+    @property
+    def width(self):
+        return self.desc.settings.width
+
+    @property
+    def height(self):
+        return self.desc.settings.height
+
+    @property
+    def spp(self):
+        s = self.desc.settings
+        return s.aa_samples * s.lens_samples * s.time_samples * s.spectral_samples
+
+
+# ---- stock scenes (BASELINE.json configs) -----------------------------------------------------------------
+
+def _cornell_into(b, data=None):
+    if data is None:
+        with open(os.path.join(_DATA, "cornell_box.json")) as f:
+            data = json.load(f)
+    cam = data["camera"]
+    b.set_camera(np.asarray(cam["transform"], dtype=np.float32).reshape(4, 4), width=cam["width"][0], height=cam["height"][0],
+                 near=cam["near"][0], far=cam["far"][0], local_direction=cam["local_direction"],
+                 local_right=cam["local_right"], local_up=cam["local_up"])
+    mats = {name: b.lambert(b.refl(*m["refl"])) for name, m in data["materials"].items()}
+    radiance = b.smul(b.illuminant_d65(), b.illum(*data["emission"]["illum"]))  # (smul (illuminant "D65") (illum 17 12 4))
+    ems = b.diffuse_emission(radiance)
+    for e in data["entities"]:
+        b.add_mesh(e["p"], e["faces"], mats[e["material"]], normals=e["n"], emission=ems if e["emission"] else None,
+                   transform=np.asarray(e["transform"], dtype=np.float32).reshape(4, 4))
+    return mats
+
+
+def cornell_box(width=256, height=256, spp=16, sampler=abi.SAMPLER_MJITT, **settings):
+    """C1/C3: examples/cornellbox.prc geometry + materials with the `direct` integrator."""
+    b = SceneBuilder(width, height)
+    b.settings.aa_sampler, b.settings.aa_samples = sampler, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+    _cornell_into(b)
+    return b.build()
+
+
+def pcg32_fast_floats(seed, n):
+    """n floats in [0,1) from pcg32_fast(seed) (vectorised MCG: state_k = state_0 * M^k)."""
+    mult = np.uint64(6364136223846793005)
+    with np.errstate(over="ignore"):
+        states = np.empty(n, dtype=np.uint64)
+        states[0] = np.uint64(seed) | np.uint64(3)
+        # cumulative products in blocks to stay vectorised
+        block = 1 << 16
+        pw = np.empty(block, dtype=np.uint64)
+        pw[0] = np.uint64(1)
+        pw[1:] = mult
+        pw = np.multiply.accumulate(pw)
+        jump = pw[-1] * mult
+        base = states[0]
+        for s in range(0, n, block):
+            e = min(n, s + block)
+            states[s:e] = base * pw[: e - s]
+            base = base * jump
+        x = states ^ (states >> np.uint64(22))
+        out = (x >> (np.uint64(22) + (states >> np.uint64(61)))).astype(np.uint32)
+    bits = (out >> np.uint32(9)) | np.uint32(0x3F800000)
+    return bits.view(np.float32) - np.float32(1.0)
+
+
+def triangle_soup(n, seed=42, size=0.01, lo=(-0.95, -0.95, 0.05), hi=(0.95, 0.95, 1.90)):
+    """SURVEY 8(d) C4 soup: centroid ~ U(box), two edge vectors ~ U([-s,s]^3), vertices c, c+e1, c+e2."""
+    u = pcg32_fast_floats(seed, 9 * n).reshape(n, 9)
+    lo, hi = np.asarray(lo, dtype=np.float32), np.asarray(hi, dtype=np.float32)
+    c = lo + u[:, 0:3] * (hi - lo)
+    e1 = (u[:, 3:6] * np.float32(2) - np.float32(1)) * np.float32(size)
+    e2 = (u[:, 6:9] * np.float32(2) - np.float32(1)) * np.float32(size)
+    pos = np.stack([c, c + e1, c + e2], axis=1).reshape(-1, 3).astype(np.float32)
+    faces = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    return pos, faces
+
+
+def cornell_soup(width=1920, height=1080, spp=1024, n_triangles=1_000_000, sampler=abi.SAMPLER_SOBOL, **settings):
+    """C4 (headline): the 32 Cornell triangles + (n_triangles - 32) soup triangles with the white Lambert."""
+    b = SceneBuilder(width, height)
+    b.settings.aa_sampler, b.settings.aa_samples = sampler, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+    mats = _cornell_into(b)
+    n_soup = max(0, n_triangles - 32)
+    if n_soup:
+        pos, faces = triangle_soup(n_soup)
+        b.add_mesh(pos, faces, mats["backWall"])
+    return b.build()
+
+
+def sphere_light(width=512, height=512, spp=64, **settings):
+    """C2: tessellated unit sphere (64x128 lat-long) on a 10x10 ground quad under a 1x1 D65x10 area light."""
+    b = SceneBuilder(width, height)
+    s = b.settings
+    s.aa_sampler, s.aa_samples, s.filter, s.filter_radius, s.mapper = abi.SAMPLER_MJITT, spp, abi.FILTER_BLOCK, 0, abi.MAPPER_RANDOM
+    for k, v in settings.items():
+        setattr(s, k, v)
+    grey = b.lambert(b.spectrum_const(0.8))
+    ems = b.diffuse_emission(b.smul(b.illuminant_d65(), b.spectrum_const(10.0)))
+    nlat, nlon = 64, 128
+    th = np.linspace(0, np.pi, nlat + 1, dtype=np.float64)
+    ph = np.linspace(0, 2 * np.pi, nlon, endpoint=False, dtype=np.float64)
+    P = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.sin(th), np.sin(ph)), np.outer(np.cos(th), np.ones_like(ph))], axis=-1)
+    pos = P.reshape(-1, 3).astype(np.float32)
+    faces = []
+    for i in range(nlat):
+        for j in range(nlon):
+            a, bb = i * nlon + j, i * nlon + (j + 1) % nlon
+            c, d = (i + 1) * nlon + j, (i + 1) * nlon + (j + 1) % nlon
+            if i != 0:
+                faces.append([a, c, bb])
+            if i != nlat - 1:
+                faces.append([bb, c, d])
+    b.add_mesh(pos, faces, grey, normals=pos.copy())
+    b.add_mesh([[-5, -5, -1], [5, -5, -1], [5, 5, -1], [-5, 5, -1]], [[0, 1, 2], [0, 2, 3]], grey)
+    b.add_mesh([[-0.5, -0.5, 3], [-0.5, 0.5, 3], [0.5, 0.5, 3], [0.5, -0.5, 3]], [[0, 1, 2], [0, 2, 3]], grey, emission=ems)
+    # camera at (0,-4,1.5) looking at the origin
+    eye = np.array([0, -4, 1.5]); fwd = -eye / np.linalg.norm(eye)
+    right = np.cross(fwd, [0, 0, 1]); right /= np.linalg.norm(right)
+    up = np.cross(right, fwd)
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = right, up, fwd, eye
+    b.set_camera(T, width=0.72, height=0.72)
+    return b.build()
+
+
+def cbox_eval(width=256, height=256, spp=128, **settings):
+    """examples/evaluation/scene.prc (Mitsuba-2 comparison scene): measured spectra, quads, sobol 128, depth 6."""
+    with open(os.path.join(_DATA, "cbox_eval.json")) as f:
+        data = json.load(f)
+    b = SceneBuilder(width, height)
+    s = b.settings
+    s.aa_sampler, s.aa_samples, s.max_ray_depth, s.mapper, s.filter, s.filter_radius = abi.SAMPLER_SOBOL, spp, 6, abi.MAPPER_RANDOM, abi.FILTER_TRIANGLE, 0
+    for k, v in settings.items():
+        setattr(s, k, v)
+    mats = {n: b.lambert(b.spectrum_table(m["start"], m["end"], m["values"])) for n, m in data["materials"].items()}
+    e = data["emission"]
+    ems = b.diffuse_emission(b.spectrum_table(e["start"], e["end"], e["values"]))
+    for ent in data["entities"]:
+        T = np.eye(4, dtype=np.float32)
+        if ent["position"]:
+            T[:3, 3] = ent["position"]
+        b.add_mesh(ent["p"], ent["faces"], mats[ent["material"]], emission=ems if ent["emission"] else None, transform=T)
+    cam = data["camera"]
+    T = np.eye(4, dtype=np.float32)
+    T[:3, 3] = cam["position"]
+    b.set_camera(T, width=cam["width"][0], height=cam["height"][0], near=cam["near"][0], far=cam["far"][0],
+                 local_direction=cam["local_direction"], local_right=cam["local_right"], local_up=cam["local_up"])
+    return b.build()
