@@ -561,10 +561,12 @@ struct RayPre {
 	int kx, ky, kz;
 	float Sx, Sy, Sz;
 	V3 inv_d;
+	float eps_t; // absolute slack of the slab test, see box_hit
 };
-inline RayPre ray_prepare(V3 o, V3 d)
+inline RayPre ray_prepare(V3 o, V3 d, float eps_t)
 {
 	RayPre r;
+	r.eps_t = eps_t;
 	r.o = o;
 	r.d = d;
 	const float ax = std::fabs(d.x), ay = std::fabs(d.y), az = std::fabs(d.z);
@@ -635,7 +637,11 @@ inline bool box_hit(const RayPre& r, const Aabb& b, float tmin, float limit, flo
 			t1 = tf;
 	}
 	tentry = t0;
-	return t0 <= t1;
+	// The slab test must never cull a triangle whose COMPUTED t passes the watertight test.  Three slacks:
+	// the padded box absorbs the rounding of its own coordinates, the factor the relative error of the slab
+	// distances, and eps_t (= 8e-6 * largest scene coordinate) the absolute error of the triangle test's t,
+	// which is a barycentric mix of per-vertex distances as large as the scene itself.
+	return t0 <= t1 * 1.000001f + r.eps_t;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -667,6 +673,7 @@ struct Scene {
 	std::vector<std::array<float, 9>> nmat; // per entity normal matrix
 	std::vector<float> vol_scale;		   // |det linear|
 	std::vector<float> world_area;		   // IEntity::worldSurfaceArea
+	float eps_t = 0;					   // slab-test slack, 8e-6 * max |coordinate| (world vertices, camera origin)
 	// BVH
 	std::vector<BvhNode> nodes;
 	std::vector<uint32_t> tri_order;
@@ -695,6 +702,9 @@ struct Scene {
 	std::vector<uint32_t> samples, feedback, prim_entity, prim_prim;
 	std::atomic<uint64_t> stats[PRGPU_STAT_COUNT];
 	std::atomic<uint64_t> cnt_nodes{ 0 }, cnt_tris{ 0 };
+	// debugging aid: rays of one pixel (kind, iter, o[3], d[3], tmin, tmax|distance, result)
+	int64_t dbg_pixel = -1;
+	std::vector<float> dbg_rays;
 };
 
 // ---- spectral node evaluation (loader/shader/ConstNode.cpp, EquidistantSpectrumNode.h:19-28,
@@ -922,7 +932,7 @@ inline void test_tri_closest(const Scene& s, const RayPre& r, uint32_t tri, floa
 }
 Hit trace_closest(Scene& s, V3 o, V3 d, float tmin, float tmax, bool brute, bool count = false)
 {
-	const RayPre r = ray_prepare(o, d);
+	const RayPre r = ray_prepare(o, d, s.eps_t);
 	Hit best{ tmax, 0, 0, INVALID };
 	// t <= tmax accepted: start with best.t = tmax and tri = INVALID so that t == tmax still wins
 	if (brute) {
@@ -972,7 +982,7 @@ Hit trace_closest(Scene& s, V3 o, V3 d, float tmin, float tmax, bool brute, bool
 bool trace_any(Scene& s, V3 o, V3 d, float tmin, float distance, bool brute)
 {
 	const float tmax = distance - 0.001f;
-	const RayPre r	 = ray_prepare(o, d);
+	const RayPre r	 = ray_prepare(o, d, s.eps_t);
 	auto test = [&](uint32_t tri) {
 		float t, u, v;
 		if (!woop(r, s.wv[3 * tri], s.wv[3 * tri + 1], s.wv[3 * tri + 2], t, u, v))
@@ -1414,6 +1424,10 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 
 	for (;;) {
 		const Hit hit = trace_closest(s, ray.o, ray.d, ray.tmin, ray.tmax, false);
+		if ((int64_t)pixel == s.dbg_pixel) {
+			const float rec[12] = { 0.0f, (float)iter, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tmin, ray.tmax, (float)(int32_t)hit.tri, hit.t };
+			s.dbg_rays.insert(s.dbg_rays.end(), rec, rec + 12);
+		}
 		if (ray.depth == 0) {
 			s.prim_entity[pixel] = hit.tri == INVALID ? INVALID : s.tri_entity[hit.tri];
 			s.prim_prim[pixel]	 = hit.tri == INVALID ? INVALID : hit.tri - s.entities[s.tri_entity[hit.tri]].first_tri;
@@ -1558,6 +1572,10 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				if (worth) {
 					st[PRGPU_STAT_SHADOW_RAYS]++;
 					visible = !trace_any(s, so, L, SHADOW_RAY_MIN, distance, false);
+					if ((int64_t)pixel == s.dbg_pixel) {
+						const float rec[12] = { 1.0f, (float)iter, so.x, so.y, so.z, L.x, L.y, L.z, SHADOW_RAY_MIN, distance, visible ? 0.0f : 1.0f, 0.0f };
+						s.dbg_rays.insert(s.dbg_rays.end(), rec, rec + 12);
+					}
 				}
 				const Blob contrib = visible ? connectionW / lightPdfS2[0] : blob(0);
 				st[PRGPU_STAT_ENTITY_HITS]++;
@@ -1804,8 +1822,14 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 		}
 		s.world_area[e] = s.vol_scale[e] * area;
 	}
-	bvh_build(s);
 	setup_camera(s);
+	{
+		float scale = std::max(std::fabs(s.cam_o.x), std::max(std::fabs(s.cam_o.y), std::fabs(s.cam_o.z)));
+		for (const V3& p : s.wv)
+			scale = std::max(scale, std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z))));
+		s.eps_t = 8e-6f * scale;
+	}
+	bvh_build(s);
 	setup_samplers(s);
 	setup_lights(s);
 	setup_wavelengths(s);
@@ -1939,6 +1963,16 @@ int orc_trace_any(orc_scene* h, uint32_t n, const float* org, const float* dir, 
 						  ? 1
 						  : 0;
 	return PRGPU_OK;
+}
+void orc_debug_pixel(orc_scene* h, int64_t pixel)
+{
+	h->s.dbg_pixel = pixel;
+	h->s.dbg_rays.clear();
+}
+uint32_t orc_debug_rays(orc_scene* h, const float** rays)
+{
+	*rays = h->s.dbg_rays.data();
+	return (uint32_t)(h->s.dbg_rays.size() / 12);
 }
 int orc_trace_counters(orc_scene* h, uint64_t* nodes, uint64_t* tris)
 {

@@ -38,6 +38,10 @@ int  orc_trace_closest(orc_scene* s, uint32_t n, const float* org, const float* 
                        int brute_force);
 int  orc_trace_any(orc_scene* s, uint32_t n, const float* org, const float* dir, const float* tmin,
                    const float* distance, uint8_t* occluded, int brute_force);
+/* Debug aid: record every ray of one pixel (12 floats each: kind 0 closest/1 shadow, iteration, o, d, tmin,
+ * tmax|distance, hit triangle|occluded, t).  pixel < 0 disables. */
+void orc_debug_pixel(orc_scene* s, int64_t pixel);
+uint32_t orc_debug_rays(orc_scene* s, const float** rays);
 /* Traversal work of the oracle BVH for the given rays (for the algorithmic-bytes model). */
 int  orc_trace_counters(orc_scene* s, uint64_t* nodes, uint64_t* tris);
 

@@ -91,6 +91,7 @@ struct DevScene {
 	uint32_t spp, mj_x, mj_y, mj_seed;
 	uint32_t single_tap; // filter has exactly one weight > eps (the centre): splat is per-pixel
 	float centre_weight;
+	float eps_t; // slab-test slack: 8e-6 * max |coordinate| over world vertices and the camera origin
 };
 
 // Per-path state, SoA, indexed by slot (= position of the pixel in the Morton-ordered owned list).
@@ -376,10 +377,12 @@ struct RayPre {
 	int kx, ky, kz;
 	float Sx, Sy, Sz;
 	V3 inv_d;
+	float eps_t; // absolute slack of the slab test, see box_hit
 };
-__device__ __forceinline__ RayPre ray_prepare(V3 o, V3 d)
+__device__ __forceinline__ RayPre ray_prepare(V3 o, V3 d, float eps_t)
 {
 	RayPre r;
+	r.eps_t		   = eps_t;
 	r.o			   = o;
 	const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
 	int kz = 0;
@@ -454,7 +457,15 @@ __device__ __forceinline__ bool box_hit(const RayPre& r, const float* lo, const 
 		if (tf < t1) t1 = tf;
 	}
 	tentry = t0;
-	return t0 <= t1;
+	// The slab test must never cull a triangle whose COMPUTED t passes the watertight test: the padded box
+	// absorbs the rounding of its own coordinates, the factor the relative error of the slab distances and
+	// eps_t (8e-6 * largest scene coordinate) the absolute error of the triangle test's t.
+	return t0 <= t1 * 1.000001f + r.eps_t;
+}
+// same acceptance rule for a box entry distance that was computed earlier (stack entries, re-checks)
+__device__ __forceinline__ bool still_reachable(const RayPre& r, float tentry, float limit)
+{
+	return tentry <= limit * 1.000001f + r.eps_t;
 }
 
 } // namespace prd

@@ -26,7 +26,7 @@ constexpr int STACK_SIZE = 64;
 template <bool COUNT>
 __device__ __forceinline__ Hit traverse_closest(const DevScene& sc, V3 o, V3 d, float tmin, float tmax, uint32_t& cnt_nodes, uint32_t& cnt_tris)
 {
-	const RayPre r = ray_prepare(o, d);
+	const RayPre r = ray_prepare(o, d, sc.eps_t);
 	Hit best{ tmax, 0.0f, 0.0f, INVALID };
 	int stack_node[STACK_SIZE];
 	float stack_t[STACK_SIZE];
@@ -70,8 +70,8 @@ __device__ __forceinline__ Hit traverse_closest(const DevScene& sc, V3 o, V3 d, 
 				}
 			}
 		}
-		h0 = h0 && c0 >= 0 && t0 <= best.t;
-		h1 = h1 && c1 >= 0 && t1 <= best.t;
+		h0 = h0 && c0 >= 0 && still_reachable(r, t0, best.t);
+		h1 = h1 && c1 >= 0 && still_reachable(r, t1, best.t);
 		if (h0 && h1) {
 			const bool near0 = t0 <= t1;
 			if (sp < STACK_SIZE) {
@@ -88,7 +88,7 @@ __device__ __forceinline__ Hit traverse_closest(const DevScene& sc, V3 o, V3 d, 
 			bool found = false;
 			while (sp > 0) {
 				--sp;
-				if (stack_t[sp] <= best.t) {
+				if (still_reachable(r, stack_t[sp], best.t)) {
 					cur	  = stack_node[sp];
 					found = true;
 					break;
@@ -106,7 +106,7 @@ template <bool COUNT>
 __device__ __forceinline__ bool traverse_any(const DevScene& sc, V3 o, V3 d, float tmin, float distance, uint32_t& cnt_nodes, uint32_t& cnt_tris)
 {
 	const float tmax = distance - 0.001f;
-	const RayPre r	 = ray_prepare(o, d);
+	const RayPre r	 = ray_prepare(o, d, sc.eps_t);
 	int stack_node[STACK_SIZE];
 	int sp	= 0;
 	int cur = 0;

@@ -534,6 +534,20 @@ int build_tables(const prgpu_scene_desc* d, HostTables& t, std::string& err)
 	wavelength_table(d, t, n_lights);
 	camera_cache(d, t);
 	filter_taps(d, t);
+	{ // largest |coordinate| of the world-space scene and the camera origin -> slack of the slab test
+		float scale = std::max(std::fabs(t.cam.o[0]), std::max(std::fabs(t.cam.o[1]), std::fabs(t.cam.o[2])));
+		for (uint32_t tri = 0; tri < d->n_triangles; ++tri) {
+			const float* m = t.entities[t.tri_entity[tri]].m;
+			for (int k = 0; k < 3; ++k) {
+				const float* p = d->positions + 3 * d->indices[3 * tri + k];
+				for (int r = 0; r < 3; ++r) {
+					const float w = ((m[4 * r] * p[0] + m[4 * r + 1] * p[1]) + m[4 * r + 2] * p[2]) + m[4 * r + 3];
+					scale		  = std::max(scale, std::fabs(w));
+				}
+			}
+		}
+		t.eps_t = 8e-6f * scale;
+	}
 	// Russian roulette: min(1, 0.9^(L - soft)) with the 1e-4 cut, indexed by path length
 	const prgpu_settings& c = d->settings;
 	t.rr_prob.resize(size_t(c.max_ray_depth) + 2);

@@ -27,6 +27,7 @@ struct HostTables {
 	uint32_t spp = 0, mj_x = 1, mj_y = 1, mj_seed = 0;
 	uint32_t single_tap = 0;
 	float centre_weight = 1.0f;
+	float eps_t = 0.0f; // slab-test slack (pr_device.h box_hit)
 };
 
 // returns PRGPU_OK or an error code with `err` set

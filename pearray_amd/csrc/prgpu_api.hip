@@ -201,6 +201,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.mj_seed		 = t.mj_seed;
 	sc.single_tap	 = t.single_tap;
 	sc.centre_weight = t.centre_weight;
+	sc.eps_t		 = t.eps_t;
 	sc.n_tris		 = d->n_triangles;
 
 	// device LBVH

@@ -1,0 +1,37 @@
+"""The only collective of the path: summing the per-rank float framebuffers onto rank 0.
+
+Ranks own disjoint image tiles (pearray_amd.tiling), so no data-path exchange happens while rendering; the
+reference's equivalent is the offline `pr_imagemerge.py` sum of per-tile EXRs (tools/pr_imagemerge.py) and the
+mutex-protected FrameOutputDevice::mergeLocal inside one process.  On MI355X nodes the reduce runs over
+RCCL/xGMI (torch.distributed backend "nccl"); CPU tests use gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def reduce_framebuffer(xyz, samples, dst=0):
+    """In-place sum onto rank `dst`: xyz float32 [H,W,3], samples int32 [H,W]."""
+    if world()[1] == 1:
+        return
+    dist.reduce(xyz, dst=dst, op=dist.ReduceOp.SUM)
+    dist.reduce(samples, dst=dst, op=dist.ReduceOp.SUM)
+
+
+def _scalar(value, op, device=None):
+    if world()[1] == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=op)
+    return float(t.item())
+
+
+def sum_scalar(value, device=None):
+    return _scalar(value, dist.ReduceOp.SUM, device)
+
+
+def max_scalar(value, device=None):
+    return _scalar(value, dist.ReduceOp.MAX, device)

@@ -1,0 +1,114 @@
+"""The C-ABI library loads on a CPU-only machine, exports every symbol include/prgpu.h declares and reports
+errors through codes + prgpu_last_error (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pearray_amd import _cabi as abi
+from pearray_amd import scene, tiling
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = abi.load()
+    header = open(os.path.join(ROOT, "include", "prgpu.h")).read()
+    declared = set(re.findall(r"\b(prgpu_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof/offsetof of every ABI struct as seen by a C compiler equal the ctypes mirror."""
+    import subprocess
+    structs = {"prgpu_spectrum": abi.Spectrum, "prgpu_material": abi.Material, "prgpu_emission": abi.Emission,
+               "prgpu_entity": abi.Entity, "prgpu_camera": abi.Camera, "prgpu_settings": abi.Settings,
+               "prgpu_scene_desc": abi.SceneDesc, "prgpu_tile": abi.Tile, "prgpu_trace_counters": abi.TraceCounters}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "prgpu.h"', "int main(void){"]
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for f, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, f)]) == getattr(cls, f).offset, (cname, f)
+
+
+def test_default_settings_are_the_reference_defaults():
+    lib = abi.load()
+    s = abi.Settings()
+    lib.prgpu_settings_default(C.byref(s))
+    d = abi.default_settings(1920, 1080)
+    for f, _ in abi.Settings._fields_:
+        assert getattr(s, f) == getattr(d, f), f
+    assert (s.seed, s.aa_sampler, s.aa_samples, s.filter, s.filter_radius) == (42, abi.SAMPLER_SOBOL, 128, abi.FILTER_MITCHELL, 1)
+    assert (s.max_ray_depth, s.soft_max_ray_depth, s.mis, s.nee) == (64, 4, abi.MIS_BALANCE, 1)
+
+
+def test_error_reporting_without_a_gpu():
+    lib = abi.load()
+    h = C.c_void_p()
+    assert lib.prgpu_scene_create(None, 0, C.byref(h)) == -1
+    assert b"null" in lib.prgpu_last_error()
+    sc = scene.cornell_box(8, 8, spp=1)
+    sc.desc.api_version = 7
+    assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"api_version" in lib.prgpu_last_error()
+    sc = scene.cornell_box(8, 8, spp=1)
+    sc.indices[5] = 99999
+    assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"index" in lib.prgpu_last_error()
+    sc = scene.cornell_box(8, 8, spp=1)
+    sc.desc.settings.filter_radius = 9
+    assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -4  # PRGPU_EUNSUPPORTED
+    sc = scene.cornell_box(8, 8, spp=1)
+    sc.materials[0].kind = 5
+    assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -4
+    assert lib.prgpu_rgb_to_coeffs(None, None) == -1
+    bad = (C.c_float * 3)(float("nan"), 0, 0)
+    assert lib.prgpu_rgb_to_coeffs(bad, (C.c_float * 3)()) == -1
+    assert lib.prgpu_render(None, 0, 1) == -1
+
+
+def test_scene_create_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = abi.load()
+    h = C.c_void_p()
+    rc = lib.prgpu_scene_create(C.byref(scene.cornell_box(8, 8, spp=1).desc), 0, C.byref(h))
+    assert rc == -2 and not h.value and b"no CPU fallback" in lib.prgpu_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pearray_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".inl")) and "build" not in dirpath:
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle/" not in src.replace("the CPU oracle", "") or f == "pr_tables.inl", os.path.join(dirpath, f)
+                assert "libpr_oracle" not in src and "pr_oracle.h" not in src
+
+
+def test_tiling_partitions_the_film():
+    W, H = 1920, 1080
+    seen = np.zeros((H, W), dtype=np.int32)
+    counts = []
+    for r in range(8):
+        t = tiling.tiles_for_rank(W, H, r, 8)
+        counts.append(tiling.owned_pixel_count(t))
+        for x0, y0, x1, y1 in t:
+            seen[y0:y1, x0:x1] += 1
+    assert (seen == 1).all() and sum(counts) == W * H
+    assert max(counts) - min(counts) <= 3 * 64 * 64
+    assert tiling.tiles_for_rank(7, 5, 0, 1, tile=4) == [(0, 0, 4, 4), (4, 0, 7, 4), (0, 4, 4, 5), (4, 4, 7, 5)]
+    with pytest.raises(ValueError):
+        tiling.tiles_for_rank(8, 8, 2, 2)
