@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: Msamples/s of the spectral path tracer on the
+1M-triangle Cornell scene (config C4: 1920x1080, sobol/1024-spp schedule, `direct` integrator), tile-sharded
+over N GPUs with one RCCL reduce of the float framebuffer, plus the traversal kernel's algorithmic
+bandwidth against the HBM roofline and the CPU checker timed on the host cores beside it.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one iteration = one camera sample (one full path) for every pixel of the frame.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, SPP, NTRI = 1920, 1080, 1024, 1_000_000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the achievable copy rate
+
+
+def cpu_baseline(scene_desc, iters=1):
+    """CPU checker ("port") on the host cores: `iters` full-frame iterations of the SAME workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleScene
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    o = OracleScene(scene_desc)
+    t_build = time.time() - t0
+    t0 = time.time()
+    o.render(iters, threads=cores)
+    dt = time.time() - t0
+    st = o.statistics()
+    return {"value": round(st["pixel_samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d iteration(s) of the full %dx%d frame of the same 1M-triangle scene (%d samples, %.1f s render, %.1f s SAH BVH build excluded); "
+                      "CPU restatement, not Embree" % (iters, W, H, st["pixel_samples"], dt, t_build)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--width", type=int, default=W)
+    ap.add_argument("--height", type=int, default=H)
+    ap.add_argument("--triangles", type=int, default=NTRI)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-only", action="store_true", help="skip roofline/cpu passes (for rocprofv3 runs)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from pearray_amd import backend, distributed, scene, tiling
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if args.steps + args.warmup > SPP:
+        raise SystemExit("steps + warmup exceed the %d-spp schedule" % SPP)
+
+    width, height = args.width, args.height
+    sc = scene.cornell_soup(width, height, spp=SPP, n_triangles=args.triangles)
+    t0 = time.time()
+    ctx = backend.RenderContext(sc, device=local)
+    t_create = time.time() - t0
+    tiles = tiling.tiles_for_rank(width, height, rank, world) if world > 1 else []
+    ctx.setTiles(tiles)
+    xyz = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
+    smp = torch.zeros((height, width), dtype=torch.int32, device=dev)
+    ctx.bindFramebuffer(xyz.data_ptr(), smp.data_ptr())
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.render(args.warmup)
+    ctx.waitForFinish()
+    before = ctx.statistics()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.render(args.steps)                      # K iterations of the hot path
+    ctx.waitForFinish()
+    distributed.reduce_framebuffer(xyz, smp)    # the path's one collective: RCCL sum onto rank 0 (no-op at N=1)
+    barrier()
+    dt = time.perf_counter() - t0
+    after = ctx.statistics()
+    dt = distributed.max_scalar(dt, device=dev)
+    samples = distributed.sum_scalar(after["pixel_samples"] - before["pixel_samples"], device=dev)
+    rays = distributed.sum_scalar(sum(after[k] - before[k] for k in ("primary_rays", "bounce_rays", "shadow_rays")), device=dev)
+    depth = distributed.sum_scalar(after["camera_depth"] - before["camera_depth"], device=dev)
+
+    out = {
+        "metric": "Msamples/s", "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C4: Cornell box + %d-triangle soup (%d triangles), %dx%d, `direct` integrator (NEE+MIS+RR, depth 64), "
+                               "sobol %d-spp schedule, hero wavelengths (spd CMIS), %d iterations timed"
+                               % (args.triangles - 32, args.triangles, width, height, SPP, args.steps),
+                   "samples_per_step": int(samples / args.steps), "parallelism": "tiles%d" % world,
+                   "mrays_per_s": round(rays / dt / 1e6, 2), "mean_path_depth": round(depth / max(samples, 1), 3),
+                   "scene_create_s": round(t_create, 3)},
+    }
+
+    if not args.profile_only:
+        # ---- roofline of the dominant kernel (closest-hit traversal), measured live on this rank ---------------
+        # pass 1: HIP events on the launch stream around every launch; pass 2: node/triangle counters
+        ctx.setTiming(True)
+        ctx.render(4)
+        ctx.waitForFinish()
+        ms_c, n_c = ctx.kernelTime("trace_closest")
+        ms_a, n_a = ctx.kernelTime("trace_any")
+        ms_s, n_s = ctx.kernelTime("shade")
+        ctx.setTiming(False)
+        tc0 = ctx.traceCounters()
+        ctx.setInstrumentation(True)
+        ctx.render(1)
+        ctx.waitForFinish()
+        ctx.setInstrumentation(False)
+        tc1 = ctx.traceCounters()
+        rays_counted = tc1["rays_closest"] - tc0["rays_closest"]
+        nodes_per_ray = tc1["nodes_closest"] / max(rays_counted, 1)
+        tris_per_ray = tc1["tris_closest"] / max(rays_counted, 1)
+        bytes_per_ray = tc1["ray_bytes"] + tc1["hit_bytes"] + tc1["node_bytes"] * nodes_per_ray + tc1["tri_bytes"] * tris_per_ray
+        rays_per_launch = rays_counted * 4 / max(n_c, 1)  # same pixels, statistically identical iterations
+        avg_ms = ms_c / max(n_c, 1)
+        achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
+        if rank == 0:
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "kernel": "k_trace_closest", "avg_launch_ms": round(avg_ms, 4), "launches": n_c,
+                               "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
+                               "tris_per_ray": round(tris_per_ray, 2), "rays_per_launch": round(rays_per_launch),
+                               "family_ms_per_iter": {"trace_closest": round(ms_c / 4, 3), "trace_any": round(ms_a / 4, 3), "shade": round(ms_s / 4, 3)}}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
