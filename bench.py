@@ -133,8 +133,8 @@ def main():
         tc1 = ctx.traceCounters()
         rays_counted = tc1["rays_closest"] - tc0["rays_closest"]
         nodes_per_ray = tc1["nodes_closest"] / max(rays_counted, 1)
-        tris_per_ray = tc1["tris_closest"] / max(rays_counted, 1)
-        bytes_per_ray = tc1["ray_bytes"] + tc1["hit_bytes"] + tc1["node_bytes"] * nodes_per_ray + tc1["tri_bytes"] * tris_per_ray
+        leaves_per_ray = tc1["leaves_closest"] / max(rays_counted, 1)
+        bytes_per_ray = tc1["ray_bytes"] + tc1["hit_bytes"] + tc1["node_bytes"] * nodes_per_ray + tc1["leaf_bytes"] * leaves_per_ray
         rays_per_launch = rays_counted * 4 / max(n_c, 1)  # same pixels, statistically identical iterations
         avg_ms = ms_c / max(n_c, 1)
         achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
@@ -143,7 +143,7 @@ def main():
                                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                                "kernel": "k_trace_closest", "avg_launch_ms": round(avg_ms, 4), "launches": n_c,
                                "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
-                               "tris_per_ray": round(tris_per_ray, 2), "rays_per_launch": round(rays_per_launch),
+                               "leaves_per_ray": round(leaves_per_ray, 2), "rays_per_launch": round(rays_per_launch),
                                "family_ms_per_iter": {"trace_closest": round(ms_c / 4, 3), "trace_any": round(ms_a / 4, 3), "shade": round(ms_s / 4, 3)}}
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc)

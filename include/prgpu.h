@@ -176,9 +176,9 @@ enum { PRGPU_STAT_CAMERA_RAYS = 0, PRGPU_STAT_LIGHT_RAYS, PRGPU_STAT_PRIMARY_RAY
 /* Traversal counters of the device kernels (not a reference concept; feeds the roofline). */
 typedef struct prgpu_trace_counters {
 	uint64_t rays_closest, rays_any;        /* rays traced by each kernel */
-	uint64_t nodes_closest, tris_closest;   /* BVH nodes popped / triangles tested (instrumented runs only) */
-	uint64_t nodes_any, tris_any;
-	uint32_t node_bytes, tri_bytes;         /* record sizes of the device BVH */
+	uint64_t nodes_closest, leaves_closest; /* inner / leaf BVH records fetched (instrumented runs only) */
+	uint64_t nodes_any, leaves_any;
+	uint32_t node_bytes, leaf_bytes;        /* record sizes of the device BVH (4-wide inner node, <=3-triangle leaf) */
 	uint32_t ray_bytes, hit_bytes;          /* queue record sizes */
 } prgpu_trace_counters;
 

@@ -14,9 +14,8 @@ struct BvhBuildInput {
 	const DevEntity* entities;	// device
 };
 struct BvhBuildOutput {
-	BvhNode* nodes = nullptr; // device, n_nodes
-	TriRecord* tris = nullptr; // device, n_tris, Morton order
-	uint32_t n_nodes = 0;
+	Rec128* recs = nullptr; // device: n_inner inner records followed by n_leaf leaf records; record 0 is the root
+	uint32_t n_inner = 0, n_leaf = 0;
 };
 bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err);
 } // namespace prd

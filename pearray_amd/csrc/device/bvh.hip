@@ -7,8 +7,8 @@
 // own bounds, so one sort + one radix-tree pass yields the same two-level structure: the top of the
 // tree separates entities, each entity's subtree is an LBVH over its own triangles.
 //
-// Layout produced (see pr_device.h): 64-byte BVH2 nodes holding both child boxes, 48-byte triangle
-// records in Morton order, leaves of 1..4 triangles (radix-tree subtrees of <= 4 leaves collapsed).
+// Layout produced (see pr_device.h): uniform 128-byte records -- 4-wide inner nodes (radix tree collapsed by
+// pulling grandchildren up) and leaves of 1..3 triangles in Morton order.
 #include "bvh.h"
 
 #include <hipcub/hipcub.hpp>
@@ -195,90 +195,176 @@ __device__ __forceinline__ void pad_box(float* lo, float* hi)
 	}
 }
 
-// 6. traversal nodes: both child boxes inline; subtrees of <= 4 triangles become leaves
-__global__ void k_emit_nodes(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
-							 const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ range_first,
-							 const int* __restrict__ range_last, const float* __restrict__ boxes, BvhNode* __restrict__ nodes)
+// 6. collapse the radix tree into the 4-wide traversal structure.
+// Records are uniform 128-byte blocks (one L2 line): inner nodes hold up to four child boxes, leaves hold up
+// to three triangles.  Rules (all decidable per node, no top-down pass):
+//   * a subtree with <= 3 triangles whose parent has > 3 is a LEAF record (these partition the triangles);
+//   * an internal node at EVEN depth with > 3 triangles is an INNER record; its children are its radix-tree
+//     children, each replaced by its own two children when it is an (odd-depth) internal node with > 3 triangles.
+__global__ void k_depth_and_flags(int n, const int* __restrict__ parent, const int* __restrict__ range_first, const int* __restrict__ range_last,
+								  uint32_t* __restrict__ inner_flag /* n-1 */, uint32_t* __restrict__ leaf_flag /* n */, uint32_t* __restrict__ leaf_count /* n */)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n - 1)
+	if (i < n - 1) {
+		int depth = 0;
+		for (int p = parent[i]; p >= 0; p = parent[p])
+			++depth;
+		const int cnt = range_last[i] - range_first[i] + 1;
+		inner_flag[i] = ((depth & 1) == 0 && cnt > 3) ? 1u : 0u;
+		if (cnt <= 3) {
+			const int p	   = parent[i];
+			const int pcnt = range_last[p] - range_first[p] + 1; // i != root here because cnt(root) = n > 3
+			if (pcnt > 3) {
+				leaf_flag[range_first[i]]  = 1u;
+				leaf_count[range_first[i]] = (uint32_t)cnt;
+			}
+		}
+	}
+	if (i < n) { // single triangles hanging directly below a big node
+		const int p	   = parent[(n - 1) + i];
+		const int pcnt = range_last[p] - range_first[p] + 1;
+		if (pcnt > 3) {
+			leaf_flag[i]  = 1u;
+			leaf_count[i] = 1u;
+		}
+	}
+}
+
+struct ChildRef {
+	float lo[3], hi[3];
+	uint32_t ref;
+};
+// reference to the subtree `c` (radix-tree child code: >= 0 internal, < 0 single triangle ~pos) as a child of an inner record
+__device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
+											   const int* __restrict__ range_first, const int* __restrict__ range_last, const float* __restrict__ boxes,
+											   const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx, uint32_t n_inner)
+{
+	ChildRef r;
+	expandable = false;
+	if (c < 0) {
+		tri_box(wv, sorted_tri[~c], r.lo, r.hi);
+		r.ref = REC_LEAF_BIT | (n_inner + leaf_idx[~c]);
+	} else {
+		for (int a = 0; a < 3; ++a) {
+			r.lo[a] = boxes[6 * c + a];
+			r.hi[a] = boxes[6 * c + 3 + a];
+		}
+		const int cnt = range_last[c] - range_first[c] + 1;
+		if (cnt <= 3) {
+			r.ref = REC_LEAF_BIT | (n_inner + leaf_idx[range_first[c]]);
+		} else {
+			r.ref	   = inner_idx[c]; // valid only when c is at even depth; odd-depth nodes get expanded by the caller
+			expandable = true;
+		}
+	}
+	pad_box(r.lo, r.hi);
+	return r;
+}
+
+__global__ void k_emit_inner(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+							 const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
+							 const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
+							 const uint32_t* __restrict__ leaf_idx, uint32_t n_inner, Rec128* __restrict__ recs)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n - 1 || !inner_flag[i])
 		return;
-	BvhNode out;
-	out.pad0 = out.pad1 = 0;
+	ChildRef ch[4];
+	int nc = 0;
 	for (int side = 0; side < 2; ++side) {
 		const int c = side == 0 ? left[i] : right[i];
-		float lo[3], hi[3];
-		int code;
-		if (c < 0) {
-			tri_box(wv, sorted_tri[~c], lo, hi);
-			code = ~((~c << 2) | 0);
-		} else {
-			for (int a = 0; a < 3; ++a) {
-				lo[a] = boxes[6 * c + a];
-				hi[a] = boxes[6 * c + 3 + a];
-			}
-			const int cnt = range_last[c] - range_first[c] + 1;
-			code		  = cnt <= 4 ? ~((range_first[c] << 2) | (cnt - 1)) : c;
+		bool expandable;
+		const ChildRef direct = make_child(c, expandable, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, n_inner);
+		if (!expandable) {
+			ch[nc++] = direct;
+		} else { // odd-depth internal node with > 3 triangles: pull its two children up
+			bool e2;
+			ch[nc++] = make_child(left[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, n_inner);
+			ch[nc++] = make_child(right[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, n_inner);
 		}
-		pad_box(lo, hi);
-		for (int a = 0; a < 3; ++a) {
-			if (side == 0) {
-				out.lo0[a] = lo[a];
-				out.hi0[a] = hi[a];
-			} else {
-				out.lo1[a] = lo[a];
-				out.hi1[a] = hi[a];
-			}
-		}
-		if (side == 0)
-			out.child0 = code;
-		else
-			out.child1 = code;
 	}
-	nodes[i] = out;
+	float f[32];
+	for (int k = 0; k < 4; ++k) {
+		const bool used = k < nc;
+		for (int a = 0; a < 3; ++a) {
+			f[4 * a + k]	  = used ? ch[k].lo[a] : INFINITY;	// q0..q2: lo x,y,z of the four children
+			f[12 + 4 * a + k] = used ? ch[k].hi[a] : -INFINITY; // q3..q5: hi x,y,z
+		}
+		f[24 + k] = __uint_as_float(used ? ch[k].ref : REC_EMPTY);
+		f[28 + k] = 0.0f;
+	}
+	float4* dst = reinterpret_cast<float4*>(recs + inner_idx[i]);
+	for (int q = 0; q < 8; ++q)
+		dst[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
 }
 
-// 7. triangle records in Morton order
-__global__ void k_emit_tris(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, TriRecord* __restrict__ out)
+// leaf record: triangle k occupies floats [10k, 10k+10): v0, v1, v2, original triangle index; float 30 = count
+__global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const uint32_t* __restrict__ leaf_flag,
+							  const uint32_t* __restrict__ leaf_count, const uint32_t* __restrict__ leaf_idx, uint32_t n_inner, Rec128* __restrict__ recs)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n)
+	const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pos >= n || !leaf_flag[pos])
 		return;
-	const uint32_t t = sorted_tri[i];
-	TriRecord r;
-	r.v0   = wv[3 * t];
-	r.v1   = wv[3 * t + 1];
-	r.v2   = wv[3 * t + 2];
-	r.v0.w = __uint_as_float(t);
-	out[i] = r;
+	const uint32_t cnt = leaf_count[pos];
+	float f[32];
+	for (int k = 0; k < 32; ++k)
+		f[k] = 0.0f;
+	for (uint32_t k = 0; k < cnt; ++k) {
+		const uint32_t t = sorted_tri[pos + k];
+		for (int v = 0; v < 3; ++v) {
+			const float4 p		 = wv[3 * t + v];
+			f[10 * k + 3 * v]	 = p.x;
+			f[10 * k + 3 * v + 1] = p.y;
+			f[10 * k + 3 * v + 2] = p.z;
+		}
+		f[10 * k + 9] = __uint_as_float(t);
+	}
+	f[30]		= __uint_as_float(cnt);
+	float4* dst = reinterpret_cast<float4*>(recs + n_inner + leaf_idx[pos]);
+	for (int q = 0; q < 8; ++q)
+		dst[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
 }
 
-// tiny scenes (n <= 4): one node, child0 = leaf with everything, child1 = empty box
-__global__ void k_single_node(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, BvhNode* __restrict__ nodes)
+// tiny scenes (n <= 3): one inner record whose only child is the single leaf
+__global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, Rec128* __restrict__ recs)
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0)
 		return;
 	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	float leaf[32], node[32];
+	for (int k = 0; k < 32; ++k)
+		leaf[k] = node[k] = 0.0f;
 	for (uint32_t i = 0; i < n; ++i) {
 		float a[3], b[3];
-		tri_box(wv, sorted_tri[i], a, b);
+		const uint32_t t = sorted_tri[i];
+		tri_box(wv, t, a, b);
 		for (int k = 0; k < 3; ++k) {
 			lo[k] = fminf(lo[k], a[k]);
 			hi[k] = fmaxf(hi[k], b[k]);
 		}
+		for (int v = 0; v < 3; ++v) {
+			const float4 p		  = wv[3 * t + v];
+			leaf[10 * i + 3 * v]	  = p.x;
+			leaf[10 * i + 3 * v + 1] = p.y;
+			leaf[10 * i + 3 * v + 2] = p.z;
+		}
+		leaf[10 * i + 9] = __uint_as_float(t);
 	}
+	leaf[30] = __uint_as_float(n);
 	pad_box(lo, hi);
-	BvhNode out;
-	for (int a = 0; a < 3; ++a) {
-		out.lo0[a] = lo[a];
-		out.hi0[a] = hi[a];
-		out.lo1[a] = INFINITY;
-		out.hi1[a] = -INFINITY;
+	for (int k = 0; k < 4; ++k) {
+		for (int a = 0; a < 3; ++a) {
+			node[4 * a + k]		 = k == 0 ? lo[a] : INFINITY;
+			node[12 + 4 * a + k] = k == 0 ? hi[a] : -INFINITY;
+		}
+		node[24 + k] = __uint_as_float(k == 0 ? (REC_LEAF_BIT | 1u) : REC_EMPTY);
 	}
-	out.child0 = ~((0 << 2) | int(n - 1));
-	out.child1 = ~0;
-	out.pad0 = out.pad1 = 0;
-	nodes[0]			= out;
+	float4* d0 = reinterpret_cast<float4*>(recs);
+	float4* d1 = reinterpret_cast<float4*>(recs + 1);
+	for (int q = 0; q < 8; ++q) {
+		d0[q] = make_float4(node[4 * q], node[4 * q + 1], node[4 * q + 2], node[4 * q + 3]);
+		d1[q] = make_float4(leaf[4 * q], leaf[4 * q + 1], leaf[4 * q + 2], leaf[4 * q + 3]);
+	}
 }
 
 #define HIPC(x)                                  \
@@ -299,15 +385,14 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 	const uint32_t G = (n + B - 1) / B;
 	float4* wv = nullptr;
 	uint32_t *ebounds = nullptr, *vals = nullptr, *vals_sorted = nullptr, *arrive = nullptr;
+	uint32_t *inner_flag = nullptr, *inner_idx = nullptr, *leaf_flag = nullptr, *leaf_cnt = nullptr, *leaf_idx = nullptr;
 	uint64_t *keys = nullptr, *keys_sorted = nullptr;
 	int *left = nullptr, *right = nullptr, *rf = nullptr, *rl = nullptr, *parent = nullptr;
 	float* boxes = nullptr;
-	void* temp	 = nullptr;
-	size_t temp_bytes = 0;
+	void *temp = nullptr, *temp2 = nullptr;
+	size_t temp_bytes = 0, temp2_bytes = 0, t2a = 0, t2b = 0;
 	bool ok = false;
-	out.nodes = nullptr;
-	out.tris  = nullptr;
-	const uint32_t n_nodes = n > 1 ? n - 1 : 1;
+	out.recs = nullptr;
 	{
 		HIPC(hipMalloc(&wv, sizeof(float4) * 3 * size_t(n)));
 		HIPC(hipMalloc(&ebounds, sizeof(uint32_t) * 6 * in.n_entities));
@@ -315,8 +400,6 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 		HIPC(hipMalloc(&keys_sorted, sizeof(uint64_t) * n));
 		HIPC(hipMalloc(&vals, sizeof(uint32_t) * n));
 		HIPC(hipMalloc(&vals_sorted, sizeof(uint32_t) * n));
-		HIPC(hipMalloc(&out.nodes, sizeof(BvhNode) * size_t(n_nodes)));
-		HIPC(hipMalloc(&out.tris, sizeof(TriRecord) * size_t(n)));
 		{
 			std::vector<uint32_t> init(6 * size_t(in.n_entities));
 			for (uint32_t e = 0; e < in.n_entities; ++e)
@@ -333,8 +416,11 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 		HIPC(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
 		HIPC(hipMalloc(&temp, temp_bytes));
 		HIPC(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
-		if (n <= 4) {
-			hipLaunchKernelGGL(k_single_node, dim3(1), dim3(64), 0, stream, n, wv, vals_sorted, out.nodes);
+		if (n <= 3) {
+			HIPC(hipMalloc(&out.recs, sizeof(Rec128) * 2));
+			hipLaunchKernelGGL(k_tiny_scene, dim3(1), dim3(64), 0, stream, n, wv, vals_sorted, out.recs);
+			out.n_inner = 1;
+			out.n_leaf	= 1;
 		} else {
 			HIPC(hipMalloc(&left, sizeof(int) * (n - 1)));
 			HIPC(hipMalloc(&right, sizeof(int) * (n - 1)));
@@ -343,25 +429,50 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipMalloc(&parent, sizeof(int) * (2 * size_t(n) - 1)));
 			HIPC(hipMalloc(&boxes, sizeof(float) * 6 * (n - 1)));
 			HIPC(hipMalloc(&arrive, sizeof(uint32_t) * (n - 1)));
+			HIPC(hipMalloc(&inner_flag, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&inner_idx, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&leaf_flag, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&leaf_cnt, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&leaf_idx, sizeof(uint32_t) * n));
 			HIPC(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * (n - 1), stream));
+			HIPC(hipMemsetAsync(inner_flag, 0, sizeof(uint32_t) * n, stream));
+			HIPC(hipMemsetAsync(leaf_flag, 0, sizeof(uint32_t) * n, stream));
+			HIPC(hipMemsetAsync(leaf_cnt, 0, sizeof(uint32_t) * n, stream));
 			hipLaunchKernelGGL(k_radix_tree, dim3(G), dim3(B), 0, stream, (int)n, keys_sorted, left, right, rf, rl, parent);
 			hipLaunchKernelGGL(k_fit_bounds, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, parent, boxes, arrive);
-			hipLaunchKernelGGL(k_emit_nodes, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, out.nodes);
+			hipLaunchKernelGGL(k_depth_and_flags, dim3(G), dim3(B), 0, stream, (int)n, parent, rf, rl, inner_flag, leaf_flag, leaf_cnt);
+			HIPC(hipGetLastError());
+			HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, t2a, inner_flag, inner_idx, (int)n, stream));
+			HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, t2b, leaf_flag, leaf_idx, (int)n, stream));
+			temp2_bytes = std::max(t2a, t2b);
+			HIPC(hipMalloc(&temp2, temp2_bytes));
+			HIPC(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, inner_flag, inner_idx, (int)n, stream));
+			HIPC(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, leaf_flag, leaf_idx, (int)n, stream));
+			uint32_t last[4] = { 0, 0, 0, 0 }; // inner_idx[n-1], inner_flag[n-1], leaf_idx[n-1], leaf_flag[n-1]
+			HIPC(hipMemcpyAsync(&last[0], inner_idx + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+			HIPC(hipMemcpyAsync(&last[1], inner_flag + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+			HIPC(hipMemcpyAsync(&last[2], leaf_idx + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+			HIPC(hipMemcpyAsync(&last[3], leaf_flag + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+			HIPC(hipStreamSynchronize(stream));
+			out.n_inner = last[0] + last[1];
+			out.n_leaf	= last[2] + last[3];
+			HIPC(hipMalloc(&out.recs, sizeof(Rec128) * (size_t(out.n_inner) + out.n_leaf)));
+			hipLaunchKernelGGL(k_emit_inner, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx,
+							   out.n_inner, out.recs);
+			hipLaunchKernelGGL(k_emit_leaves, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, leaf_flag, leaf_cnt, leaf_idx, out.n_inner, out.recs);
 		}
-		hipLaunchKernelGGL(k_emit_tris, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, out.tris);
 		HIPC(hipGetLastError());
 		HIPC(hipStreamSynchronize(stream));
-		out.n_nodes = n_nodes;
-		ok			= true;
+		ok = true;
 	}
 done:
 	(void)hipFree(wv); (void)hipFree(ebounds); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted);
-	(void)hipFree(left); (void)hipFree(right); (void)hipFree(rf); (void)hipFree(rl); (void)hipFree(parent); (void)hipFree(boxes); (void)hipFree(arrive); (void)hipFree(temp);
+	(void)hipFree(left); (void)hipFree(right); (void)hipFree(rf); (void)hipFree(rl); (void)hipFree(parent); (void)hipFree(boxes); (void)hipFree(arrive);
+	(void)hipFree(inner_flag); (void)hipFree(inner_idx); (void)hipFree(leaf_flag); (void)hipFree(leaf_cnt); (void)hipFree(leaf_idx);
+	(void)hipFree(temp); (void)hipFree(temp2);
 	if (!ok) {
-		(void)hipFree(out.nodes);
-		(void)hipFree(out.tris);
-		out.nodes = nullptr;
-		out.tris  = nullptr;
+		(void)hipFree(out.recs);
+		out.recs = nullptr;
 	}
 	return ok;
 }

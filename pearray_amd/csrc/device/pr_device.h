@@ -31,21 +31,17 @@ constexpr float CIE_DELTA	   = CIE_RANGE / (CIE_SAMPLES - 1);
 constexpr float CIE_Y_NORM	   = CIE_Y_NORM_SUM * CIE_DELTA;
 
 // ---- device BVH ---------------------------------------------------------------------------------
-// 64-byte BVH2 node holding BOTH child boxes (one 64 B fetch decides both children).
-// child >= 0: inner node index.  child < 0: leaf, ~child = (first_triangle << 2) | (count - 1), count 1..4.
-struct __attribute__((aligned(64))) BvhNode {
-	float lo0[3], hi0[3];
-	float lo1[3], hi1[3];
-	int child0, child1;
-	int pad0, pad1;
+// Uniform 128-byte records (= one L2 line), record 0 is the root inner node:
+//   inner: q0..q2 = lo.x/lo.y/lo.z of the four children, q3..q5 = hi.x/hi.y/hi.z, q6 = four child refs
+//   leaf : triangle k (k < 3) in floats [10k, 10k+10) = v0, v1, v2 (world space), original triangle index;
+//          float 30 = triangle count
+// child ref: record index | REC_LEAF_BIT for leaves, REC_EMPTY for an unused slot.
+struct __attribute__((aligned(128))) Rec128 {
+	float4 q[8];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
-
-// 48-byte triangle record in BVH (Morton) order: world-space vertices, w of v0 = original triangle index.
-struct __attribute__((aligned(16))) TriRecord {
-	float4 v0, v1, v2;
-};
-static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
+static_assert(sizeof(Rec128) == 128, "Rec128 must be 128 bytes");
+constexpr uint32_t REC_LEAF_BIT = 0x80000000u;
+constexpr uint32_t REC_EMPTY	= 0xFFFFFFFFu;
 
 struct DevEntity {
 	float m[12];  // rows 0..2 of the entity transform
@@ -63,9 +59,8 @@ struct DevCamera {
 
 // Everything the kernels read; passed by value.
 struct DevScene {
-	const BvhNode* nodes;
-	const TriRecord* tris;
-	uint32_t n_tris, n_nodes, root_is_leaf;
+	const Rec128* recs;
+	uint32_t n_tris, n_inner, n_leaf;
 	const float* positions;
 	const float* normals;
 	const uint32_t* indices;

@@ -7,8 +7,10 @@
 // replaces; the scalar arithmetic lives in pr_device.h.
 //
 // No MFMA: no stage is a dense contraction.  The kernels are latency/bandwidth bound on BVH-node and
-// triangle fetches (64 B + 48 B records, see DESIGN.md for the bytes-per-ray model).
+// triangle fetches (uniform 128-byte records, see DESIGN.md for the bytes-per-ray model).
 #include "render.h"
+
+#include <algorithm>
 
 namespace prd {
 
@@ -17,147 +19,217 @@ struct Hit {
 	uint32_t tri; // original triangle index, INVALID on miss
 };
 
-constexpr int STACK_SIZE = 64;
+// indices into the extra device counters after the 11 statistics
+enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY };
 
-// ---- traversal ------------------------------------------------------------------------------------------
-// Closest hit, tmin < t <= tmax, equal t -> lower original triangle index wins (tie rule shared with the
-// CPU checker).  Replaces rtcIntersect1 / rtcIntersect16 behind Scene::traceRays / traceSingleRay
-// (src/core/scene/Scene.cpp:138-242).
-template <bool COUNT>
-__device__ __forceinline__ Hit traverse_closest(const DevScene& sc, V3 o, V3 d, float tmin, float tmax, uint32_t& cnt_nodes, uint32_t& cnt_tris)
+// ---- traversal ------------------------------------------------------------------------------------------------
+// Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one 128-byte
+// record per step and refill idle lanes when too few are active, so a few long rays do not hold 63 idle lanes.
+// The traversal stack lives in LDS (STACK_LDS entries per lane, bank-conflict free layout [entry][lane]); the
+// rare deeper stacks spill their oldest entries to a per-thread slab in HBM.
+constexpr int TRAV_BLOCK	= 256;
+constexpr int STACK_LDS		= 16;
+constexpr int STACK_SPILL	= 64;  // additional entries per thread in global memory
+constexpr int REFILL_BELOW	= 44;  // refill the wave when fewer lanes than this are active
+
+struct Stack {
+	uint2* lds;		 // this lane's column: entry e at lds[e * TRAV_BLOCK]
+	uint2* spill;	 // this thread's column: entry e at spill[e * spill_stride]
+	uint32_t spill_stride;
+	int sp, base;	 // logical size, lowest logical index still held in LDS
+	__device__ __forceinline__ void reset() { sp = base = 0; }
+	__device__ __forceinline__ void push(uint32_t ref, float t)
+	{
+		if (sp - base == STACK_LDS) {
+			if (base < STACK_SPILL)
+				spill[(uint32_t)base * spill_stride] = lds[(base % STACK_LDS) * TRAV_BLOCK];
+			++base;
+		}
+		lds[(sp % STACK_LDS) * TRAV_BLOCK] = make_uint2(ref, __float_as_uint(t));
+		++sp;
+	}
+	__device__ __forceinline__ uint2 pop()
+	{
+		--sp;
+		if (sp < base) {
+			base = sp;
+			return sp < STACK_SPILL ? spill[(uint32_t)sp * spill_stride] : make_uint2(REC_EMPTY, 0x7F800000u);
+		}
+		return lds[(sp % STACK_LDS) * TRAV_BLOCK];
+	}
+};
+
+struct Trav {
+	RayPre r;
+	float tmin;
+	Hit best;	  // closest: running best (t starts at tmax); any: t = tmax, tri != INVALID once occluded
+	uint32_t cur; // current record ref, REC_EMPTY when the ray is finished
+};
+
+__device__ __forceinline__ void trav_begin(Trav& s, Stack& st, V3 o, V3 d, float tmin, float tmax, float eps_t)
 {
-	const RayPre r = ray_prepare(o, d, sc.eps_t);
-	Hit best{ tmax, 0.0f, 0.0f, INVALID };
-	int stack_node[STACK_SIZE];
-	float stack_t[STACK_SIZE];
-	int sp	= 0;
-	int cur = 0;
-	const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
-	for (;;) {
-		const float4 q0 = nodes4[4 * cur + 0], q1 = nodes4[4 * cur + 1], q2 = nodes4[4 * cur + 2], q3 = nodes4[4 * cur + 3];
+	s.r	   = ray_prepare(o, d, eps_t);
+	s.tmin = tmin;
+	s.best = Hit{ tmax, 0.0f, 0.0f, INVALID };
+	s.cur  = 0u; // root
+	st.reset();
+}
+
+// slab test of child k of an inner record (same arithmetic as box_hit)
+__device__ __forceinline__ bool child_hit(const RayPre& r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmin, float limit, float& tentry)
+{
+	const float lo[3] = { lox, loy, loz }, hi[3] = { hix, hiy, hiz };
+	return box_hit(r, lo, hi, tmin, limit, tentry);
+}
+
+// One step: fetch the current record (one 128-byte line) and process it.  ANY: stop at the first hit in (tmin, tmax].
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void trav_step(const DevScene& sc, Trav& s, Stack& st, uint32_t& cnt_inner, uint32_t& cnt_leaf)
+{
+	const uint32_t ref = s.cur;
+	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (ref & ~REC_LEAF_BIT));
+	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+	if (ref & REC_LEAF_BIT) {
 		if (COUNT)
-			++cnt_nodes;
-		const float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
-		const float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
-		const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-		float t0, t1;
-		bool h0 = box_hit(r, lo0, hi0, tmin, best.t, t0);
-		bool h1 = box_hit(r, lo1, hi1, tmin, best.t, t1);
+			++cnt_leaf;
+		const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+							  q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w };
+		const uint32_t count = __float_as_uint(f[30]);
 #pragma unroll
-		for (int side = 0; side < 2; ++side) {
-			const int c	 = side == 0 ? c0 : c1;
-			const bool h = side == 0 ? h0 : h1;
-			if (h && c < 0) {
-				const uint32_t code	 = uint32_t(~c);
-				const uint32_t first = code >> 2, count = (code & 3u) + 1u;
-				for (uint32_t i = 0; i < count; ++i) {
-					const float4* __restrict__ tp = reinterpret_cast<const float4*>(sc.tris + first + i);
-					const float4 a = tp[0], b = tp[1], c4 = tp[2];
-					if (COUNT)
-						++cnt_tris;
-					float t, u, v;
-					if (!woop(r, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c4.x, c4.y, c4.z), t, u, v))
-						continue;
-					if (!(t > tmin))
-						continue;
-					const uint32_t tri = __float_as_uint(a.w);
-					if (t < best.t || (t == best.t && tri < best.tri)) {
-						best.t	 = t;
-						best.u	 = u;
-						best.v	 = v;
-						best.tri = tri;
+		for (int k = 0; k < 3; ++k) {
+			if ((uint32_t)k < count) {
+				float t, u, v;
+				if (woop(s.r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]),
+						 v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), t, u, v)
+					&& t > s.tmin) {
+					const uint32_t tri = __float_as_uint(f[10 * k + 9]);
+					if (ANY) {
+						if (t <= s.best.t)
+							s.best.tri = tri;
+					} else if (t < s.best.t || (t == s.best.t && tri < s.best.tri)) {
+						s.best = Hit{ t, u, v, tri };
 					}
 				}
 			}
 		}
-		h0 = h0 && c0 >= 0 && still_reachable(r, t0, best.t);
-		h1 = h1 && c1 >= 0 && still_reachable(r, t1, best.t);
-		if (h0 && h1) {
-			const bool near0 = t0 <= t1;
-			if (sp < STACK_SIZE) {
-				stack_node[sp] = near0 ? c1 : c0;
-				stack_t[sp]	   = near0 ? t1 : t0;
-				++sp;
+		s.cur = REC_EMPTY;
+	} else {
+		if (COUNT)
+			++cnt_inner;
+		float t[4];
+		uint32_t c[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
+		bool h[4];
+		h[0] = c[0] != REC_EMPTY && child_hit(s.r, q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, s.tmin, s.best.t, t[0]);
+		h[1] = c[1] != REC_EMPTY && child_hit(s.r, q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, s.tmin, s.best.t, t[1]);
+		h[2] = c[2] != REC_EMPTY && child_hit(s.r, q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, s.tmin, s.best.t, t[2]);
+		h[3] = c[3] != REC_EMPTY && child_hit(s.r, q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, s.tmin, s.best.t, t[3]);
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			if (!h[k]) {
+				t[k] = INFINITY;
+				c[k] = REC_EMPTY;
 			}
-			cur = near0 ? c0 : c1;
-		} else if (h0) {
-			cur = c0;
-		} else if (h1) {
-			cur = c1;
+		if (!ANY) {
+			// sort the four (t, ref) pairs ascending: 5-comparator network
+#define PR_CSWAP(a, b)                                   \
+	if (t[b] < t[a]) {                                   \
+		const float tt = t[a]; t[a] = t[b]; t[b] = tt;    \
+		const uint32_t cc = c[a]; c[a] = c[b]; c[b] = cc; \
+	}
+			PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+#undef PR_CSWAP
+			if (c[3] != REC_EMPTY) st.push(c[3], t[3]);
+			if (c[2] != REC_EMPTY) st.push(c[2], t[2]);
+			if (c[1] != REC_EMPTY) st.push(c[1], t[1]);
+			s.cur = c[0];
 		} else {
-			bool found = false;
-			while (sp > 0) {
-				--sp;
-				if (still_reachable(r, stack_t[sp], best.t)) {
-					cur	  = stack_node[sp];
-					found = true;
-					break;
+			uint32_t first = REC_EMPTY;
+#pragma unroll
+			for (int k = 3; k >= 0; --k)
+				if (c[k] != REC_EMPTY) {
+					if (first != REC_EMPTY)
+						st.push(first, 0.0f);
+					first = c[k];
 				}
-			}
-			if (!found)
-				break;
+			s.cur = first;
 		}
 	}
-	return best;
+	if (ANY && s.best.tri != INVALID) { // occluded: done
+		s.cur = REC_EMPTY;
+		st.reset();
+		return;
+	}
+	// next record: the near child, or the closest stack entry that can still matter
+	while (s.cur == REC_EMPTY && st.sp > 0) {
+		const uint2 e = st.pop();
+		if (ANY || still_reachable(s.r, __uint_as_float(e.y), s.best.t))
+			s.cur = e.x;
+	}
 }
 
-// Any hit in (tmin, distance - 0.001]: Scene::traceShadowRay (Scene.cpp:266-280, rtcOccluded1).
-template <bool COUNT>
-__device__ __forceinline__ bool traverse_any(const DevScene& sc, V3 o, V3 d, float tmin, float distance, uint32_t& cnt_nodes, uint32_t& cnt_tris)
+// Persistent traversal loop shared by the four tracing kernels.  `load(i, o, d, tmin, tmax)` reads ray i,
+// `store(i, best)` writes its result.
+template <bool ANY, bool COUNT, typename LoadF, typename StoreF>
+__device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_rays, uint32_t* queue_head, uint2* spill, LoadF load, StoreF store,
+												 unsigned long long* gstats)
 {
-	const float tmax = distance - 0.001f;
-	const RayPre r	 = ray_prepare(o, d, sc.eps_t);
-	int stack_node[STACK_SIZE];
-	int sp	= 0;
-	int cur = 0;
-	const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes);
+	__shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
+	Stack st;
+	st.lds			= lds_stack + threadIdx.x;
+	st.spill_stride = gridDim.x * TRAV_BLOCK;
+	st.spill		= spill + (blockIdx.x * TRAV_BLOCK + threadIdx.x);
+	st.reset();
+	Trav s;
+	s.cur			   = REC_EMPTY;
+	uint32_t my_ray	   = 0;
+	bool has_ray	   = false;
+	bool exhausted	   = false; // wave-uniform: the queue has no more rays
+	uint32_t cn = 0, cl = 0;
+	const uint32_t lane = threadIdx.x & 63u;
 	for (;;) {
-		const float4 q0 = nodes4[4 * cur + 0], q1 = nodes4[4 * cur + 1], q2 = nodes4[4 * cur + 2], q3 = nodes4[4 * cur + 3];
-		if (COUNT)
-			++cnt_nodes;
-		const float lo0[3] = { q0.x, q0.y, q0.z }, hi0[3] = { q0.w, q1.x, q1.y };
-		const float lo1[3] = { q1.z, q1.w, q2.x }, hi1[3] = { q2.y, q2.z, q2.w };
-		const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-		float t0, t1;
-		bool h0 = box_hit(r, lo0, hi0, tmin, tmax, t0);
-		bool h1 = box_hit(r, lo1, hi1, tmin, tmax, t1);
-#pragma unroll
-		for (int side = 0; side < 2; ++side) {
-			const int c	 = side == 0 ? c0 : c1;
-			const bool h = side == 0 ? h0 : h1;
-			if (h && c < 0) {
-				const uint32_t code	 = uint32_t(~c);
-				const uint32_t first = code >> 2, count = (code & 3u) + 1u;
-				for (uint32_t i = 0; i < count; ++i) {
-					const float4* __restrict__ tp = reinterpret_cast<const float4*>(sc.tris + first + i);
-					const float4 a = tp[0], b = tp[1], c4 = tp[2];
-					if (COUNT)
-						++cnt_tris;
-					float t, u, v;
-					if (!woop(r, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c4.x, c4.y, c4.z), t, u, v))
-						continue;
-					if (t > tmin && t <= tmax)
-						return true;
+		if (!exhausted) {
+			const unsigned long long idle = __ballot(!has_ray);
+			if (idle) {
+				uint32_t base = 0;
+				const int leader = __ffsll((long long)idle) - 1;
+				if ((int)lane == leader)
+					base = atomicAdd(queue_head, (uint32_t)__popcll(idle));
+				base = __shfl(base, leader, 64);
+				if (!has_ray) {
+					const uint32_t i = base + __popcll(idle & ((1ull << lane) - 1ull));
+					if (i < n_rays) {
+						V3 o, d;
+						float tmin, tmax;
+						load(i, o, d, tmin, tmax);
+						trav_begin(s, st, o, d, tmin, tmax, sc.eps_t);
+						my_ray	= i;
+						has_ray = true;
+					}
 				}
+				exhausted = base + (uint32_t)__popcll(idle) >= n_rays;
 			}
 		}
-		h0 = h0 && c0 >= 0;
-		h1 = h1 && c1 >= 0;
-		if (h0 && h1) {
-			if (sp < STACK_SIZE)
-				stack_node[sp++] = c1;
-			cur = c0;
-		} else if (h0) {
-			cur = c0;
-		} else if (h1) {
-			cur = c1;
-		} else {
-			if (sp == 0)
+		if (!__any(has_ray))
+			break;
+		for (;;) {
+			if (has_ray) {
+				trav_step<ANY, COUNT>(sc, s, st, cn, cl);
+				if (s.cur == REC_EMPTY) {
+					store(my_ray, s.best);
+					has_ray = false;
+				}
+			}
+			const int active = __popcll(__ballot(has_ray));
+			if (active == 0 || (!exhausted && active < REFILL_BELOW))
 				break;
-			cur = stack_node[--sp];
 		}
 	}
-	return false;
+	if (COUNT) {
+		if (cn)
+			atomicAdd(&gstats[ANY ? CNT_NODES_ANY : CNT_NODES_CLOSEST], (unsigned long long)cn);
+		if (cl)
+			atomicAdd(&gstats[ANY ? CNT_TRIS_ANY : CNT_TRIS_CLOSEST], (unsigned long long)cl);
+	}
 }
 
 // ---- shading helpers --------------------------------------------------------------------------------------
@@ -293,8 +365,6 @@ __device__ __forceinline__ void stats_flush(BlockStats& s, unsigned long long* g
 	if (threadIdx.x < PRGPU_STAT_COUNT + 4 && s.v[threadIdx.x])
 		atomicAdd(&g[threadIdx.x], (unsigned long long)s.v[threadIdx.x]);
 }
-// indices into the extra device counters after the 11 statistics
-enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY };
 
 // wave-level stream compaction: ballot + prefix popcount, one atomic per wave
 __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter)
@@ -410,25 +480,24 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PathState ps, uint3
 	stats_flush(bs, gstats);
 }
 
-// Scene::traceRays / traceSingleRay for the active paths
+// Scene::traceRays / traceSingleRay for the active paths (persistent waves, see trace_persistent)
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_closest(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t n_active,
-													  unsigned long long* gstats)
+__global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t n_active,
+															 uint32_t* queue_head, uint2* spill, unsigned long long* gstats)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	uint32_t cn = 0, ct = 0;
-	if (i < n_active) {
+	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
 		const uint32_t slot = active ? active[i] : i;
-		const float4 o = ps.ray_o[slot], d = ps.ray_d[slot];
-		const Hit h	 = traverse_closest<COUNT>(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w, cn, ct);
-		ps.hit[slot] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
-	}
-	if (COUNT) {
-		if (cn)
-			atomicAdd(&gstats[CNT_NODES_CLOSEST], (unsigned long long)cn);
-		if (ct)
-			atomicAdd(&gstats[CNT_TRIS_CLOSEST], (unsigned long long)ct);
-	}
+		const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+		o	 = v3(ro.x, ro.y, ro.z);
+		d	 = v3(rd.x, rd.y, rd.z);
+		tmin = ro.w;
+		tmax = rd.w;
+	};
+	auto store = [&](uint32_t i, const Hit& h) {
+		const uint32_t slot = active ? active[i] : i;
+		ps.hit[slot]		= make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+	};
+	trace_persistent<false, COUNT>(sc, n_active, queue_head, spill, load, store, gstats);
 }
 
 // handleCameraVertex / handleDirectHit / handleNEE / handleScattering (direct.cpp:73-412), Walker::traverse
@@ -686,18 +755,25 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 	stats_flush(bs, gstats);
 }
 
-// Scene::traceShadowRay for the NEE queue, then the pending fragment (direct.cpp:329-351)
+// Scene::traceShadowRay for the NEE queue (tfar = distance - 0.001, Scene.cpp:275), then the pending fragment
+// (direct.cpp:329-351).  The item count is read on the device (counters[1]).
 template <bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_shadow(DevScene sc, PathState ps, const uint32_t* __restrict__ counters, unsigned long long* gstats)
+__global__ void __launch_bounds__(TRAV_BLOCK) k_trace_shadow(DevScene sc, PathState ps, const uint32_t* __restrict__ counters, uint32_t* queue_head,
+															uint2* spill, unsigned long long* gstats)
 {
 	const uint32_t n = counters[1];
-	uint32_t cn = 0, ct = 0;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const float4 o = ps.sh_o[i], d = ps.sh_d[i], x = ps.sh_xyz[i];
-		const bool occluded	 = traverse_any<COUNT>(sc, v3(o.x, o.y, o.z), v3(d.x, d.y, d.z), o.w, d.w, cn, ct);
+	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
+		const float4 so = ps.sh_o[i], sd = ps.sh_d[i];
+		o	 = v3(so.x, so.y, so.z);
+		d	 = v3(sd.x, sd.y, sd.z);
+		tmin = so.w;
+		tmax = sd.w - 0.001f;
+	};
+	auto store = [&](uint32_t i, const Hit& h) {
+		const float4 x		 = ps.sh_xyz[i];
 		const uint32_t fbs	 = __float_as_uint(x.w);
 		const uint32_t pixel = ps.pixel[ps.sh_slot[i]];
-		if (occluded) {
+		if (h.tri != INVALID) { // occluded
 			const uint32_t fb = (fbs >> 8) & 0xFFu;
 			if (fb)
 				ps.feedback[pixel] |= fb;
@@ -705,13 +781,8 @@ __global__ void __launch_bounds__(256) k_trace_shadow(DevScene sc, PathState ps,
 			const float xyz[3] = { x.x, x.y, x.z };
 			apply_fragment(ps, pixel, fbs & 0xFFu, xyz);
 		}
-	}
-	if (COUNT) {
-		if (cn)
-			atomicAdd(&gstats[CNT_NODES_ANY], (unsigned long long)cn);
-		if (ct)
-			atomicAdd(&gstats[CNT_TRIS_ANY], (unsigned long long)ct);
-	}
+	};
+	trace_persistent<true, COUNT>(sc, n, queue_head, spill, load, store, gstats);
 }
 
 // LocalFrameOutputDevice filter taps (LocalFrameOutputDevice.cpp:144-160), mergeLocal clipping at the film
@@ -757,39 +828,40 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 // covers nothing else, the plane is zero-initialised once) -- kept for symmetry with mCopySpectral->clear.
 
 // ---- ray service kernels (IArchive surface) ------------------------------------------------------------
-__global__ void k_service_closest(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
-								  const float* __restrict__ tmin, const float* __restrict__ tmax, uint32_t* entity, uint32_t* prim, float* u,
-								  float* v, float* t, unsigned long long* gstats)
+__global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
+															   const float* __restrict__ tmin_a, const float* __restrict__ tmax_a, uint32_t* entity,
+															   uint32_t* prim, float* u, float* v, float* t, uint32_t* queue_head, uint2* spill,
+															   unsigned long long* gstats)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n)
-		return;
-	uint32_t cn = 0, ct = 0;
-	const Hit h	  = traverse_closest<true>(sc, v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), tmin[i],
-									   tmax[i], cn, ct);
-	const bool ok = h.tri != INVALID;
-	const uint32_t e = ok ? sc.tri_entity[h.tri] : INVALID;
-	entity[i]		 = e;
-	prim[i]			 = ok ? h.tri - sc.entities[e].first_tri : INVALID;
-	u[i]			 = ok ? h.u : 0.0f;
-	v[i]			 = ok ? h.v : 0.0f;
-	t[i]			 = ok ? h.t : tmax[i];
-	atomicAdd(&gstats[CNT_NODES_CLOSEST], (unsigned long long)cn);
-	atomicAdd(&gstats[CNT_TRIS_CLOSEST], (unsigned long long)ct);
+	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
+		o	 = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+		d	 = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+		tmin = tmin_a[i];
+		tmax = tmax_a[i];
+	};
+	auto store = [&](uint32_t i, const Hit& h) {
+		const bool ok	 = h.tri != INVALID;
+		const uint32_t e = ok ? sc.tri_entity[h.tri] : INVALID;
+		entity[i]		 = e;
+		prim[i]			 = ok ? h.tri - sc.entities[e].first_tri : INVALID;
+		u[i]			 = ok ? h.u : 0.0f;
+		v[i]			 = ok ? h.v : 0.0f;
+		t[i]			 = ok ? h.t : tmax_a[i];
+	};
+	trace_persistent<false, true>(sc, n, queue_head, spill, load, store, gstats);
 }
-__global__ void k_service_any(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir, const float* __restrict__ tmin,
-							  const float* __restrict__ distance, uint8_t* occluded, unsigned long long* gstats)
+__global__ void __launch_bounds__(TRAV_BLOCK) k_service_any(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
+														   const float* __restrict__ tmin_a, const float* __restrict__ distance, uint8_t* occluded,
+														   uint32_t* queue_head, uint2* spill, unsigned long long* gstats)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n)
-		return;
-	uint32_t cn = 0, ct = 0;
-	occluded[i] = traverse_any<true>(sc, v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), tmin[i],
-									 distance[i], cn, ct)
-					  ? 1
-					  : 0;
-	atomicAdd(&gstats[CNT_NODES_ANY], (unsigned long long)cn);
-	atomicAdd(&gstats[CNT_TRIS_ANY], (unsigned long long)ct);
+	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
+		o	 = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+		d	 = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+		tmin = tmin_a[i];
+		tmax = distance[i] - 0.001f;
+	};
+	auto store = [&](uint32_t i, const Hit& h) { occluded[i] = h.tri != INVALID ? 1 : 0; };
+	trace_persistent<true, true>(sc, n, queue_head, spill, load, store, gstats);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------
@@ -799,41 +871,53 @@ void launch_raygen(const DevScene& sc, const PathState& ps, uint32_t n_slots, ui
 {
 	hipLaunchKernelGGL(k_raygen, grid_for(n_slots), dim3(256), 0, st, sc, ps, n_slots, iter, gstats);
 }
-void launch_trace_closest(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n_active, bool count, unsigned long long* gstats,
-						  hipStream_t st)
+// persistent grids: enough blocks to fill the chip, never more than the work
+static inline dim3 trav_grid(const TraceWorkspace& ws, uint32_t n) { return dim3(std::max(1u, std::min(ws.max_blocks, (n + TRAV_BLOCK - 1) / TRAV_BLOCK))); }
+
+void launch_trace_closest(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n_active, bool count, const TraceWorkspace& ws,
+						  unsigned long long* gstats, hipStream_t st)
 {
+	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
 	if (count)
-		hipLaunchKernelGGL(k_trace_closest<true>, grid_for(n_active), dim3(256), 0, st, sc, ps, active, n_active, gstats);
+		hipLaunchKernelGGL(k_trace_closest<true>, trav_grid(ws, n_active), dim3(TRAV_BLOCK), 0, st, sc, ps, active, n_active, ws.queue_head, ws.spill, gstats);
 	else
-		hipLaunchKernelGGL(k_trace_closest<false>, grid_for(n_active), dim3(256), 0, st, sc, ps, active, n_active, gstats);
+		hipLaunchKernelGGL(k_trace_closest<false>, trav_grid(ws, n_active), dim3(TRAV_BLOCK), 0, st, sc, ps, active, n_active, ws.queue_head, ws.spill, gstats);
 }
 void launch_shade(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n_active, uint32_t* next_active, uint32_t* counters,
 				  unsigned long long* gstats, hipStream_t st)
 {
 	hipLaunchKernelGGL(k_shade, grid_for(n_active), dim3(256), 0, st, sc, ps, active, n_active, next_active, counters, gstats);
 }
-void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t max_items, const uint32_t* counters, bool count,
+void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t max_items, const uint32_t* counters, bool count, const TraceWorkspace& ws,
 						 unsigned long long* gstats, hipStream_t st)
 {
-	const dim3 g = grid_for(max_items);
+	(void)hipMemsetAsync(ws.queue_head + 1, 0, sizeof(uint32_t), st);
+	const dim3 g = trav_grid(ws, max_items);
 	if (count)
-		hipLaunchKernelGGL(k_trace_shadow<true>, g, dim3(256), 0, st, sc, ps, counters, gstats);
+		hipLaunchKernelGGL(k_trace_shadow<true>, g, dim3(TRAV_BLOCK), 0, st, sc, ps, counters, ws.queue_head + 1, ws.spill, gstats);
 	else
-		hipLaunchKernelGGL(k_trace_shadow<false>, g, dim3(256), 0, st, sc, ps, counters, gstats);
+		hipLaunchKernelGGL(k_trace_shadow<false>, g, dim3(TRAV_BLOCK), 0, st, sc, ps, counters, ws.queue_head + 1, ws.spill, gstats);
 }
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st)
 {
 	hipLaunchKernelGGL(k_resolve, grid_for(sc.cfg.width * sc.cfg.height), dim3(256), 0, st, sc, ps, iter);
 }
 void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
-							uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, unsigned long long* gstats, hipStream_t st)
+							uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, unsigned long long* gstats,
+							hipStream_t st)
 {
-	hipLaunchKernelGGL(k_service_closest, grid_for(n), dim3(256), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, gstats);
+	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
+	hipLaunchKernelGGL(k_service_closest, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
+					   ws.spill, gstats);
 }
 void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* distance,
-						uint8_t* occluded, unsigned long long* gstats, hipStream_t st)
+						uint8_t* occluded, const TraceWorkspace& ws, unsigned long long* gstats, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_service_any, grid_for(n), dim3(256), 0, st, sc, n, org, dir, tmin, distance, occluded, gstats);
+	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
+	hipLaunchKernelGGL(k_service_any, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, distance, occluded, ws.queue_head, ws.spill,
+					   gstats);
 }
+
+size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * TRAV_BLOCK * STACK_SPILL; }
 
 } // namespace prd

@@ -57,6 +57,7 @@ struct prgpu_scene {
 	uint32_t *active_a = nullptr, *active_b = nullptr, *counters = nullptr;
 	unsigned long long* gstats = nullptr;
 	uint32_t* h_counters = nullptr; // pinned
+	prd::TraceWorkspace ws;
 	bool instrument = false, timing = false;
 	std::vector<TimedLaunch> pending;
 	double family_ms[N_FAMILIES] = { 0 };
@@ -209,11 +210,10 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	prd::BvhBuildOutput bout;
 	if (!prd::build_lbvh(bin, bout, s->stream, err))
 		return fail(PRGPU_EDEVICE, "LBVH build failed: " + err);
-	s->allocations.push_back(bout.nodes);
-	s->allocations.push_back(bout.tris);
-	sc.nodes   = bout.nodes;
-	sc.tris	   = bout.tris;
-	sc.n_nodes = bout.n_nodes;
+	s->allocations.push_back(bout.recs);
+	sc.recs	   = bout.recs;
+	sc.n_inner = bout.n_inner;
+	sc.n_leaf  = bout.n_leaf;
 
 	// per-path state and frame planes
 	const uint32_t np = d->settings.width * d->settings.height;
@@ -256,6 +256,13 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(s->active_b, np, false);
 	AL(s->counters, 4, true);
 	AL(s->gstats, prd::N_DEVICE_COUNTERS, true);
+	{ // persistent traversal grid: 5 blocks of 256 threads per CU (32 KB of LDS stack each)
+		hipDeviceProp_t prop;
+		HIP_TRY(hipGetDeviceProperties(&prop, device));
+		s->ws.max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 5u;
+		AL(s->ws.queue_head, 2, true);
+		AL(s->ws.spill, prd::trace_workspace_spill_entries(s->ws.max_blocks), false);
+	}
 	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), 4 * sizeof(uint32_t), hipHostMallocDefault));
 	HIP_TRY(hipStreamSynchronize(s->stream)); // host tables go out of scope
 	return apply_tiles(s, nullptr, 0);
@@ -276,7 +283,7 @@ int render_iteration(prgpu_scene* s, uint32_t iter)
 	uint32_t n_active	   = s->n_slots;
 	for (uint32_t depth = 0; n_active > 0 && depth < s->cfg.max_ray_depth; ++depth) {
 		s->time_begin(1);
-		prd::launch_trace_closest(sc, ps, active, n_active, s->instrument, s->gstats, st);
+		prd::launch_trace_closest(sc, ps, active, n_active, s->instrument, s->ws, s->gstats, st);
 		s->time_end();
 		s->rays_closest += n_active;
 		HIP_TRY(hipMemsetAsync(s->counters, 0, 2 * sizeof(uint32_t), st));
@@ -286,7 +293,7 @@ int render_iteration(prgpu_scene* s, uint32_t iter)
 		HIP_TRY(hipMemcpyAsync(s->h_counters, s->counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 		// the shadow kernel reads its item count on the device; launch it before waiting for the counters
 		s->time_begin(3);
-		prd::launch_trace_shadow(sc, ps, n_active, s->counters, s->instrument, s->gstats, st);
+		prd::launch_trace_shadow(sc, ps, n_active, s->counters, s->instrument, s->ws, s->gstats, st);
 		s->time_end();
 		HIP_TRY(hipStreamSynchronize(st));
 		s->rays_any += s->h_counters[1];
@@ -481,11 +488,11 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 	out->rays_closest  = s->rays_closest;
 	out->rays_any	   = s->rays_any;
 	out->nodes_closest = host[PRGPU_STAT_COUNT + 0];
-	out->tris_closest  = host[PRGPU_STAT_COUNT + 1];
+	out->leaves_closest  = host[PRGPU_STAT_COUNT + 1];
 	out->nodes_any	   = host[PRGPU_STAT_COUNT + 2];
-	out->tris_any	   = host[PRGPU_STAT_COUNT + 3];
-	out->node_bytes	   = sizeof(prd::BvhNode);
-	out->tri_bytes	   = sizeof(prd::TriRecord);
+	out->leaves_any	   = host[PRGPU_STAT_COUNT + 3];
+	out->node_bytes	   = sizeof(prd::Rec128); // inner record
+	out->leaf_bytes	   = sizeof(prd::Rec128); // leaf record (<= 3 triangles)
 	out->ray_bytes	   = 32; // o,tmin + d,tmax
 	out->hit_bytes	   = 16; // t,u,v,tri
 	return PRGPU_OK;
@@ -565,7 +572,7 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmin, tmin, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmax, tmax, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	s->time_begin(1);
-	prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->gstats, s->stream);
+	prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->gstats, s->stream);
 	s->time_end();
 	s->rays_closest += n;
 	TRY_OR_CLEAN(hipGetLastError());
@@ -606,7 +613,7 @@ int prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* d
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmin, tmin, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	TRY_OR_CLEAN(hipMemcpyAsync(d_dist, distance, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	s->time_begin(3);
-	prd::launch_service_any(s->sc, n, d_org, d_dir, d_tmin, d_dist, d_occ, s->gstats, s->stream);
+	prd::launch_service_any(s->sc, n, d_org, d_dir, d_tmin, d_dist, d_occ, s->ws, s->gstats, s->stream);
 	s->time_end();
 	s->rays_any += n;
 	TRY_OR_CLEAN(hipGetLastError());

@@ -217,7 +217,7 @@ def test_instrumented_run_changes_nothing_and_counts_work():
     tc = b.traceCounters()
     st = b.statistics()
     assert tc["rays_closest"] == st["primary_rays"] + st["bounce_rays"] and tc["rays_any"] == st["shadow_rays"]
-    assert tc["nodes_closest"] >= tc["rays_closest"] and tc["tris_closest"] > 0 and tc["node_bytes"] == 64 and tc["tri_bytes"] == 48
+    assert tc["nodes_closest"] >= tc["rays_closest"] and tc["leaves_closest"] > 0 and tc["node_bytes"] == 128 and tc["leaf_bytes"] == 128
     ms, n = b.kernelTime("trace_closest")
     assert n > 0 and ms > 0
 
