@@ -20,7 +20,7 @@ struct Hit {
 };
 
 // indices into the extra device counters after the 11 statistics
-enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY };
+enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY };
 
 // ---- traversal ------------------------------------------------------------------------------------------------
 // Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one 128-byte
@@ -30,7 +30,7 @@ enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CN
 constexpr int TRAV_BLOCK	= 256;
 constexpr int STACK_LDS		= 16;
 constexpr int STACK_SPILL	= 64;  // additional entries per thread in global memory
-constexpr int REFILL_BELOW	= 44;  // refill the wave when fewer lanes than this are active
+constexpr bool ANY_SORTED	= false; // near-to-far order for occlusion rays measured slightly slower than unsorted (fewer ALU ops win)
 
 struct Stack {
 	uint2* lds;		 // this lane's column: entry e at lds[e * TRAV_BLOCK]
@@ -38,15 +38,20 @@ struct Stack {
 	uint32_t spill_stride;
 	int sp, base;	 // logical size, lowest logical index still held in LDS
 	__device__ __forceinline__ void reset() { sp = base = 0; }
-	__device__ __forceinline__ void push(uint32_t ref, float t)
+	// make room for k more entries in the LDS window (spills the oldest entries; rare)
+	__device__ __forceinline__ void reserve(int k)
 	{
-		if (sp - base == STACK_LDS) {
+		while (sp - base + k > STACK_LDS) {
 			if (base < STACK_SPILL)
-				spill[(uint32_t)base * spill_stride] = lds[(base % STACK_LDS) * TRAV_BLOCK];
+				spill[(uint32_t)base * spill_stride] = lds[(base & (STACK_LDS - 1)) * TRAV_BLOCK];
 			++base;
 		}
-		lds[(sp % STACK_LDS) * TRAV_BLOCK] = make_uint2(ref, __float_as_uint(t));
-		++sp;
+	}
+	// branch-free conditional push (requires reserve): the slot is written either way, the size only grows when valid
+	__device__ __forceinline__ void push_if(bool valid, uint32_t ref, float t)
+	{
+		lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK] = make_uint2(ref, __float_as_uint(t));
+		sp += valid ? 1 : 0;
 	}
 	__device__ __forceinline__ uint2 pop()
 	{
@@ -55,9 +60,10 @@ struct Stack {
 			base = sp;
 			return sp < STACK_SPILL ? spill[(uint32_t)sp * spill_stride] : make_uint2(REC_EMPTY, 0x7F800000u);
 		}
-		return lds[(sp % STACK_LDS) * TRAV_BLOCK];
+		return lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK];
 	}
 };
+static_assert((STACK_LDS & (STACK_LDS - 1)) == 0, "STACK_LDS must be a power of two");
 
 struct Trav {
 	RayPre r;
@@ -82,84 +88,10 @@ __device__ __forceinline__ bool child_hit(const RayPre& r, float lox, float loy,
 	return box_hit(r, lo, hi, tmin, limit, tentry);
 }
 
-// One step: fetch the current record (one 128-byte line) and process it.  ANY: stop at the first hit in (tmin, tmax].
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ void trav_step(const DevScene& sc, Trav& s, Stack& st, uint32_t& cnt_inner, uint32_t& cnt_leaf)
+// next record after the current one is used up: the closest stack entry that can still matter
+template <bool ANY>
+__device__ __forceinline__ void trav_pop(Trav& s, Stack& st)
 {
-	const uint32_t ref = s.cur;
-	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (ref & ~REC_LEAF_BIT));
-	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
-	if (ref & REC_LEAF_BIT) {
-		if (COUNT)
-			++cnt_leaf;
-		const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
-							  q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w };
-		const uint32_t count = __float_as_uint(f[30]);
-#pragma unroll
-		for (int k = 0; k < 3; ++k) {
-			if ((uint32_t)k < count) {
-				float t, u, v;
-				if (woop(s.r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]),
-						 v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), t, u, v)
-					&& t > s.tmin) {
-					const uint32_t tri = __float_as_uint(f[10 * k + 9]);
-					if (ANY) {
-						if (t <= s.best.t)
-							s.best.tri = tri;
-					} else if (t < s.best.t || (t == s.best.t && tri < s.best.tri)) {
-						s.best = Hit{ t, u, v, tri };
-					}
-				}
-			}
-		}
-		s.cur = REC_EMPTY;
-	} else {
-		if (COUNT)
-			++cnt_inner;
-		float t[4];
-		uint32_t c[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
-		bool h[4];
-		h[0] = c[0] != REC_EMPTY && child_hit(s.r, q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, s.tmin, s.best.t, t[0]);
-		h[1] = c[1] != REC_EMPTY && child_hit(s.r, q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, s.tmin, s.best.t, t[1]);
-		h[2] = c[2] != REC_EMPTY && child_hit(s.r, q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, s.tmin, s.best.t, t[2]);
-		h[3] = c[3] != REC_EMPTY && child_hit(s.r, q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, s.tmin, s.best.t, t[3]);
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-			if (!h[k]) {
-				t[k] = INFINITY;
-				c[k] = REC_EMPTY;
-			}
-		if (!ANY) {
-			// sort the four (t, ref) pairs ascending: 5-comparator network
-#define PR_CSWAP(a, b)                                   \
-	if (t[b] < t[a]) {                                   \
-		const float tt = t[a]; t[a] = t[b]; t[b] = tt;    \
-		const uint32_t cc = c[a]; c[a] = c[b]; c[b] = cc; \
-	}
-			PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
-#undef PR_CSWAP
-			if (c[3] != REC_EMPTY) st.push(c[3], t[3]);
-			if (c[2] != REC_EMPTY) st.push(c[2], t[2]);
-			if (c[1] != REC_EMPTY) st.push(c[1], t[1]);
-			s.cur = c[0];
-		} else {
-			uint32_t first = REC_EMPTY;
-#pragma unroll
-			for (int k = 3; k >= 0; --k)
-				if (c[k] != REC_EMPTY) {
-					if (first != REC_EMPTY)
-						st.push(first, 0.0f);
-					first = c[k];
-				}
-			s.cur = first;
-		}
-	}
-	if (ANY && s.best.tri != INVALID) { // occluded: done
-		s.cur = REC_EMPTY;
-		st.reset();
-		return;
-	}
-	// next record: the near child, or the closest stack entry that can still matter
 	while (s.cur == REC_EMPTY && st.sp > 0) {
 		const uint2 e = st.pop();
 		if (ANY || still_reachable(s.r, __uint_as_float(e.y), s.best.t))
@@ -167,11 +99,95 @@ __device__ __forceinline__ void trav_step(const DevScene& sc, Trav& s, Stack& st
 	}
 }
 
+// Inner step: fetch the 4-wide node (112 of its 128 bytes), test the four child boxes, continue with the nearest
+// hit child and push the others far-to-near.  ANY: order does not matter, children are pushed unsorted.
+template <bool ANY>
+__device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& st)
+{
+	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + s.cur);
+	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+	float t[4];
+	uint32_t c[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
+	bool h[4];
+	h[0] = child_hit(s.r, q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, s.tmin, s.best.t, t[0]) && c[0] != REC_EMPTY;
+	h[1] = child_hit(s.r, q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, s.tmin, s.best.t, t[1]) && c[1] != REC_EMPTY;
+	h[2] = child_hit(s.r, q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, s.tmin, s.best.t, t[2]) && c[2] != REC_EMPTY;
+	h[3] = child_hit(s.r, q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, s.tmin, s.best.t, t[3]) && c[3] != REC_EMPTY;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		t[k] = h[k] ? t[k] : INFINITY;
+		c[k] = h[k] ? c[k] : REC_EMPTY;
+	}
+	if (!ANY || ANY_SORTED) {
+		// sort the four (t, ref) pairs ascending: 5-comparator network (misses carry t = +inf and sort last)
+#define PR_CSWAP(a, b)                                          \
+	{                                                           \
+		const bool sw	  = t[b] < t[a];                        \
+		const float ta = t[a], tb = t[b];                       \
+		const uint32_t ca = c[a], cb = c[b];                    \
+		t[a] = sw ? tb : ta; t[b] = sw ? ta : tb;               \
+		c[a] = sw ? cb : ca; c[b] = sw ? ca : cb;               \
+	}
+		PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+#undef PR_CSWAP
+	} else {
+		// compact the hits to the front (order irrelevant for occlusion)
+#define PR_CMOVE(a, b)                                          \
+	{                                                           \
+		const bool mv = c[a] == REC_EMPTY;                      \
+		c[a] = mv ? c[b] : c[a];                                \
+		c[b] = mv ? REC_EMPTY : c[b];                           \
+	}
+		PR_CMOVE(0, 1) PR_CMOVE(2, 3) PR_CMOVE(1, 2) PR_CMOVE(0, 1) PR_CMOVE(2, 3) PR_CMOVE(1, 2)
+#undef PR_CMOVE
+	}
+	st.reserve(3);
+	st.push_if(c[3] != REC_EMPTY, c[3], t[3]);
+	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
+	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
+	s.cur = c[0];
+	trav_pop<ANY>(s, st);
+}
+
+// Leaf step: fetch the leaf record (<= 3 triangles) and run the watertight test on each.
+template <bool ANY>
+__device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& s, Stack& st)
+{
+	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
+	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+	const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+						  q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w };
+	const uint32_t count = __float_as_uint(f[30]);
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		if ((uint32_t)k < count) {
+			float t, u, v;
+			if (woop(s.r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]),
+					 v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), t, u, v)
+				&& t > s.tmin) {
+				const uint32_t tri = __float_as_uint(f[10 * k + 9]);
+				if (ANY) {
+					if (t <= s.best.t)
+						s.best.tri = tri;
+				} else if (t < s.best.t || (t == s.best.t && tri < s.best.tri)) {
+					s.best = Hit{ t, u, v, tri };
+				}
+			}
+		}
+	}
+	s.cur = REC_EMPTY;
+	if (ANY && s.best.tri != INVALID) { // occluded: done
+		st.reset();
+		return;
+	}
+	trav_pop<ANY>(s, st);
+}
+
 // Persistent traversal loop shared by the four tracing kernels.  `load(i, o, d, tmin, tmax)` reads ray i,
 // `store(i, best)` writes its result.
 template <bool ANY, bool COUNT, typename LoadF, typename StoreF>
-__device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_rays, uint32_t* queue_head, uint2* spill, LoadF load, StoreF store,
-												 unsigned long long* gstats)
+__device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_rays, uint32_t* queue_head, uint2* spill, int refill_below, LoadF load,
+												 StoreF store, unsigned long long* gstats)
 {
 	__shared__ uint2 lds_stack[STACK_LDS * TRAV_BLOCK];
 	Stack st;
@@ -184,7 +200,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_
 	uint32_t my_ray	   = 0;
 	bool has_ray	   = false;
 	bool exhausted	   = false; // wave-uniform: the queue has no more rays
-	uint32_t cn = 0, cl = 0;
+	uint32_t cn = 0, cl = 0, witers = 0;
 	const uint32_t lane = threadIdx.x & 63u;
 	for (;;) {
 		if (!exhausted) {
@@ -212,15 +228,31 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_
 		if (!__any(has_ray))
 			break;
 		for (;;) {
-			if (has_ray) {
-				trav_step<ANY, COUNT>(sc, s, st, cn, cl);
-				if (s.cur == REC_EMPTY) {
-					store(my_ray, s.best);
-					has_ray = false;
+			// One path per wave step: the lanes at inner nodes or the lanes at leaves, whichever are more.  The other
+			// lanes wait, so every instruction of the step runs for the majority instead of both paths for a few.
+			const bool at_leaf		= has_ray && (s.cur & REC_LEAF_BIT) != 0;
+			const bool at_inner		= has_ray && !at_leaf;
+			const int n_leaf		= __popcll(__ballot(at_leaf));
+			const int n_inner		= __popcll(__ballot(at_inner));
+			if (COUNT && lane == 0)
+				++witers;
+			if (n_inner >= n_leaf) {
+				if (at_inner) {
+					if (COUNT)
+						++cn;
+					trav_inner<ANY>(sc, s, st);
 				}
+			} else if (at_leaf) {
+				if (COUNT)
+					++cl;
+				trav_leaf<ANY>(sc, s, st);
+			}
+			if (has_ray && s.cur == REC_EMPTY) {
+				store(my_ray, s.best);
+				has_ray = false;
 			}
 			const int active = __popcll(__ballot(has_ray));
-			if (active == 0 || (!exhausted && active < REFILL_BELOW))
+			if (active == 0 || (!exhausted && active < refill_below))
 				break;
 		}
 	}
@@ -229,6 +261,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_
 			atomicAdd(&gstats[ANY ? CNT_NODES_ANY : CNT_NODES_CLOSEST], (unsigned long long)cn);
 		if (cl)
 			atomicAdd(&gstats[ANY ? CNT_TRIS_ANY : CNT_TRIS_CLOSEST], (unsigned long long)cl);
+		if (witers)
+			atomicAdd(&gstats[ANY ? CNT_WAVE_ITERS_ANY : CNT_WAVE_ITERS_CLOSEST], (unsigned long long)witers);
 	}
 }
 
@@ -384,12 +418,13 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter)
 
 // ---- kernels ------------------------------------------------------------------------------------------------
 // RenderTile::constructCameraRay (RenderTile.cpp:71-132) + StreamPipeline::fillWithCameraRays (:83-133)
-__global__ void __launch_bounds__(256) k_raygen(DevScene sc, PathState ps, uint32_t n_slots, uint32_t iter, unsigned long long* gstats)
+__global__ void __launch_bounds__(256) k_raygen(DevScene sc, PathState ps, uint32_t slot_base, uint32_t n_slots, uint32_t iter, unsigned long long* gstats)
 {
 	__shared__ BlockStats bs;
 	stats_init(bs);
-	const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-	if (slot < n_slots) {
+	const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t slot	 = slot_base + local;
+	if (local < n_slots) {
 		const prgpu_settings& cfg = sc.cfg;
 		const uint32_t pixel	  = ps.pixel[slot];
 		const uint32_t gx = pixel % cfg.width, gy = pixel / cfg.width;
@@ -482,11 +517,16 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PathState ps, uint3
 
 // Scene::traceRays / traceSingleRay for the active paths (persistent waves, see trace_persistent)
 template <bool COUNT>
-__global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t n_active,
-															 uint32_t* queue_head, uint2* spill, unsigned long long* gstats)
+__global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t slot_base,
+															 uint32_t n_active, uint32_t* queue_head, uint2* spill, int refill_below, uint32_t* shade_counters,
+															 unsigned long long* gstats)
 {
+	if (blockIdx.x == 0 && threadIdx.x == 0) { // the following shade launch appends into these (stream ordered)
+		shade_counters[0] = 0;
+		shade_counters[1] = 0;
+	}
 	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
-		const uint32_t slot = active ? active[i] : i;
+		const uint32_t slot = active ? active[i] : slot_base + i;
 		const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
 		o	 = v3(ro.x, ro.y, ro.z);
 		d	 = v3(rd.x, rd.y, rd.z);
@@ -494,27 +534,31 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 		tmax = rd.w;
 	};
 	auto store = [&](uint32_t i, const Hit& h) {
-		const uint32_t slot = active ? active[i] : i;
+		const uint32_t slot = active ? active[i] : slot_base + i;
 		ps.hit[slot]		= make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
 	};
-	trace_persistent<false, COUNT>(sc, n_active, queue_head, spill, load, store, gstats);
+	trace_persistent<false, COUNT>(sc, n_active, queue_head, spill, refill_below, load, store, gstats);
 }
 
 // handleCameraVertex / handleDirectHit / handleNEE / handleScattering (direct.cpp:73-412), Walker::traverse
 // (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53)
-__global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t n_active,
+__global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t slot_base, uint32_t n_active,
 											  uint32_t* __restrict__ next_active, uint32_t* __restrict__ counters /* [0]=next, [1]=shadow */,
-											  unsigned long long* gstats)
+											  uint32_t* queue_head_closest, uint32_t* queue_head_shadow, unsigned long long* gstats)
 {
 	__shared__ BlockStats bs;
 	stats_init(bs);
+	if (blockIdx.x == 0 && threadIdx.x == 0) { // no traversal launch of this group is in flight during shade
+		*queue_head_closest = 0;
+		*queue_head_shadow	= 0;
+	}
 	const uint32_t i		  = blockIdx.x * blockDim.x + threadIdx.x;
 	const prgpu_settings& cfg = sc.cfg;
 	bool alive = false, want_shadow = false;
 	uint32_t slot = 0;
 	float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
 	if (i < n_active) {
-		slot				 = active ? active[i] : i;
+		slot				 = active ? active[i] : slot_base + i;
 		const uint32_t pixel = ps.pixel[slot];
 		const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
 		const V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
@@ -756,12 +800,11 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 }
 
 // Scene::traceShadowRay for the NEE queue (tfar = distance - 0.001, Scene.cpp:275), then the pending fragment
-// (direct.cpp:329-351).  The item count is read on the device (counters[1]).
+// (direct.cpp:329-351).
 template <bool COUNT>
-__global__ void __launch_bounds__(TRAV_BLOCK) k_trace_shadow(DevScene sc, PathState ps, const uint32_t* __restrict__ counters, uint32_t* queue_head,
-															uint2* spill, unsigned long long* gstats)
+__global__ void __launch_bounds__(TRAV_BLOCK) k_trace_shadow(DevScene sc, PathState ps, uint32_t n, uint32_t* queue_head, uint2* spill,
+															int refill_below, unsigned long long* gstats)
 {
-	const uint32_t n = counters[1];
 	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
 		const float4 so = ps.sh_o[i], sd = ps.sh_d[i];
 		o	 = v3(so.x, so.y, so.z);
@@ -782,7 +825,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_shadow(DevScene sc, PathSt
 			apply_fragment(ps, pixel, fbs & 0xFFu, xyz);
 		}
 	};
-	trace_persistent<true, COUNT>(sc, n, queue_head, spill, load, store, gstats);
+	trace_persistent<true, COUNT>(sc, n, queue_head, spill, refill_below, load, store, gstats);
 }
 
 // LocalFrameOutputDevice filter taps (LocalFrameOutputDevice.cpp:144-160), mergeLocal clipping at the film
@@ -831,7 +874,7 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
 															   const float* __restrict__ tmin_a, const float* __restrict__ tmax_a, uint32_t* entity,
 															   uint32_t* prim, float* u, float* v, float* t, uint32_t* queue_head, uint2* spill,
-															   unsigned long long* gstats)
+															   int refill_below, unsigned long long* gstats)
 {
 	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
 		o	 = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
@@ -848,11 +891,11 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uin
 		v[i]			 = ok ? h.v : 0.0f;
 		t[i]			 = ok ? h.t : tmax_a[i];
 	};
-	trace_persistent<false, true>(sc, n, queue_head, spill, load, store, gstats);
+	trace_persistent<false, true>(sc, n, queue_head, spill, refill_below, load, store, gstats);
 }
 __global__ void __launch_bounds__(TRAV_BLOCK) k_service_any(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
 														   const float* __restrict__ tmin_a, const float* __restrict__ distance, uint8_t* occluded,
-														   uint32_t* queue_head, uint2* spill, unsigned long long* gstats)
+														   uint32_t* queue_head, uint2* spill, int refill_below, unsigned long long* gstats)
 {
 	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
 		o	 = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
@@ -861,42 +904,43 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_any(DevScene sc, uint32_
 		tmax = distance[i] - 0.001f;
 	};
 	auto store = [&](uint32_t i, const Hit& h) { occluded[i] = h.tri != INVALID ? 1 : 0; };
-	trace_persistent<true, true>(sc, n, queue_head, spill, load, store, gstats);
+	trace_persistent<true, true>(sc, n, queue_head, spill, refill_below, load, store, gstats);
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block - 1) / block); }
 
-void launch_raygen(const DevScene& sc, const PathState& ps, uint32_t n_slots, uint32_t iter, unsigned long long* gstats, hipStream_t st)
+void launch_raygen(const DevScene& sc, const PathState& ps, uint32_t slot_base, uint32_t n_slots, uint32_t iter, unsigned long long* gstats, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_raygen, grid_for(n_slots), dim3(256), 0, st, sc, ps, n_slots, iter, gstats);
+	hipLaunchKernelGGL(k_raygen, grid_for(n_slots), dim3(256), 0, st, sc, ps, slot_base, n_slots, iter, gstats);
 }
 // persistent grids: enough blocks to fill the chip, never more than the work
 static inline dim3 trav_grid(const TraceWorkspace& ws, uint32_t n) { return dim3(std::max(1u, std::min(ws.max_blocks, (n + TRAV_BLOCK - 1) / TRAV_BLOCK))); }
 
-void launch_trace_closest(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n_active, bool count, const TraceWorkspace& ws,
-						  unsigned long long* gstats, hipStream_t st)
+void launch_trace_closest(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t slot_base, uint32_t n_active, bool count,
+						  const TraceWorkspace& ws, uint32_t* shade_counters, unsigned long long* gstats, hipStream_t st)
 {
-	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
 	if (count)
-		hipLaunchKernelGGL(k_trace_closest<true>, trav_grid(ws, n_active), dim3(TRAV_BLOCK), 0, st, sc, ps, active, n_active, ws.queue_head, ws.spill, gstats);
+		hipLaunchKernelGGL(k_trace_closest<true>, trav_grid(ws, n_active), dim3(TRAV_BLOCK), 0, st, sc, ps, active, slot_base, n_active, ws.queue_head, ws.spill,
+						   ws.refill_below, shade_counters, gstats);
 	else
-		hipLaunchKernelGGL(k_trace_closest<false>, trav_grid(ws, n_active), dim3(TRAV_BLOCK), 0, st, sc, ps, active, n_active, ws.queue_head, ws.spill, gstats);
+		hipLaunchKernelGGL(k_trace_closest<false>, trav_grid(ws, n_active), dim3(TRAV_BLOCK), 0, st, sc, ps, active, slot_base, n_active, ws.queue_head, ws.spill,
+						   ws.refill_below, shade_counters, gstats);
 }
-void launch_shade(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n_active, uint32_t* next_active, uint32_t* counters,
-				  unsigned long long* gstats, hipStream_t st)
+void launch_shade(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t slot_base, uint32_t n_active, uint32_t* next_active,
+				  uint32_t* counters, uint32_t* queue_head_closest, uint32_t* queue_head_shadow, unsigned long long* gstats, hipStream_t st)
 {
-	hipLaunchKernelGGL(k_shade, grid_for(n_active), dim3(256), 0, st, sc, ps, active, n_active, next_active, counters, gstats);
+	hipLaunchKernelGGL(k_shade, grid_for(n_active), dim3(256), 0, st, sc, ps, active, slot_base, n_active, next_active, counters, queue_head_closest,
+					   queue_head_shadow, gstats);
 }
-void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t max_items, const uint32_t* counters, bool count, const TraceWorkspace& ws,
-						 unsigned long long* gstats, hipStream_t st)
+void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t n_items, bool count, const TraceWorkspace& ws, unsigned long long* gstats,
+						 hipStream_t st)
 {
-	(void)hipMemsetAsync(ws.queue_head + 1, 0, sizeof(uint32_t), st);
-	const dim3 g = trav_grid(ws, max_items);
+	const dim3 g = trav_grid(ws, n_items);
 	if (count)
-		hipLaunchKernelGGL(k_trace_shadow<true>, g, dim3(TRAV_BLOCK), 0, st, sc, ps, counters, ws.queue_head + 1, ws.spill, gstats);
+		hipLaunchKernelGGL(k_trace_shadow<true>, g, dim3(TRAV_BLOCK), 0, st, sc, ps, n_items, ws.queue_head, ws.spill, ws.refill_below, gstats);
 	else
-		hipLaunchKernelGGL(k_trace_shadow<false>, g, dim3(TRAV_BLOCK), 0, st, sc, ps, counters, ws.queue_head + 1, ws.spill, gstats);
+		hipLaunchKernelGGL(k_trace_shadow<false>, g, dim3(TRAV_BLOCK), 0, st, sc, ps, n_items, ws.queue_head, ws.spill, ws.refill_below, gstats);
 }
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st)
 {
@@ -908,14 +952,14 @@ void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, co
 {
 	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
 	hipLaunchKernelGGL(k_service_closest, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
-					   ws.spill, gstats);
+					   ws.spill, ws.refill_below, gstats);
 }
 void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* distance,
 						uint8_t* occluded, const TraceWorkspace& ws, unsigned long long* gstats, hipStream_t st)
 {
 	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
 	hipLaunchKernelGGL(k_service_any, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, distance, occluded, ws.queue_head, ws.spill,
-					   gstats);
+					   ws.refill_below, gstats);
 }
 
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * TRAV_BLOCK * STACK_SPILL; }

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -54,10 +55,27 @@ struct prgpu_scene {
 	// frame planes owned by the library (may be replaced by prgpu_bind_framebuffer)
 	float* own_xyz = nullptr;
 	uint32_t *own_samples = nullptr, *own_feedback = nullptr;
-	uint32_t *active_a = nullptr, *active_b = nullptr, *counters = nullptr;
+	uint32_t *active_a = nullptr, *active_b = nullptr;
 	unsigned long long* gstats = nullptr;
-	uint32_t* h_counters = nullptr; // pinned
-	prd::TraceWorkspace ws;
+	prd::TraceWorkspace ws; // workspace of the ray-service launches
+	// Pixel groups: contiguous ranges of the Morton-ordered slot list, each running its own wavefront pipeline on
+	// its own pair of HIP streams so that the latency tails of one group's kernels overlap the other groups' work.
+	struct Group {
+		hipStream_t s_main = nullptr, s_shadow = nullptr; // group 0's s_main is the scene stream
+		hipEvent_t ev_shade = nullptr, ev_shadow = nullptr;
+		uint32_t slot_begin = 0, n_slots = 0;
+		uint32_t *active_a = nullptr, *active_b = nullptr, *counters = nullptr, *h_counters = nullptr;
+		prd::TraceWorkspace ws_closest, ws_shadow;
+		prd::PathState ps; // shadow-queue pointers offset to this group's region
+		// per-iteration state
+		const uint32_t* active = nullptr;
+		uint32_t* next = nullptr;
+		uint32_t n_active = 0, depth = 0;
+		bool done = true, shadow_pending = false;
+	};
+	std::vector<Group> groups;
+	hipEvent_t ev_resolve = nullptr;
+	bool resolve_recorded = false;
 	bool instrument = false, timing = false;
 	std::vector<TimedLaunch> pending;
 	double family_ms[N_FAMILIES] = { 0 };
@@ -94,7 +112,7 @@ struct prgpu_scene {
 		return upload(ptr, v.data(), v.size());
 	}
 
-	void time_begin(int family)
+	void time_begin(int family, hipStream_t st)
 	{
 		if (!timing)
 			return;
@@ -102,14 +120,14 @@ struct prgpu_scene {
 		t.family = family;
 		(void)hipEventCreate(&t.start);
 		(void)hipEventCreate(&t.stop);
-		(void)hipEventRecord(t.start, stream);
+		(void)hipEventRecord(t.start, st);
 		pending.push_back(t);
 	}
-	void time_end()
+	void time_end(hipStream_t st)
 	{
 		if (!timing)
 			return;
-		(void)hipEventRecord(pending.back().stop, stream);
+		(void)hipEventRecord(pending.back().stop, st);
 	}
 	void collect_timing()
 	{
@@ -139,6 +157,21 @@ int apply_tiles(prgpu_scene* s, const prgpu_tile* tiles, uint32_t n_tiles)
 	if (!pixels.empty())
 		HIP_TRY(hipMemcpyAsync(s->ps.pixel, pixels.data(), pixels.size() * 4, hipMemcpyHostToDevice, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
+	// split the slot list into the pixel groups (multiples of 256 slots)
+	const uint32_t G	 = (uint32_t)s->groups.size();
+	const uint32_t chunk = ((s->n_slots + G - 1) / G + 255u) / 256u * 256u;
+	for (uint32_t g = 0; g < G; ++g) {
+		prgpu_scene::Group& gr = s->groups[g];
+		gr.slot_begin = std::min(s->n_slots, g * chunk);
+		gr.n_slots	  = std::min(s->n_slots, (g + 1) * chunk) - gr.slot_begin;
+		gr.active_a	  = s->active_a + gr.slot_begin;
+		gr.active_b	  = s->active_b + gr.slot_begin;
+		gr.ps		  = s->ps;
+		gr.ps.sh_o += gr.slot_begin;
+		gr.ps.sh_d += gr.slot_begin;
+		gr.ps.sh_xyz += gr.slot_begin;
+		gr.ps.sh_slot += gr.slot_begin;
+	}
 	return PRGPU_OK;
 }
 
@@ -254,56 +287,161 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	ps.feedback = s->own_feedback;
 	AL(s->active_a, np, false);
 	AL(s->active_b, np, false);
-	AL(s->counters, 4, true);
 	AL(s->gstats, prd::N_DEVICE_COUNTERS, true);
-	{ // persistent traversal grid: 5 blocks of 256 threads per CU (32 KB of LDS stack each)
+	{ // persistent traversal grid: a few blocks of 256 threads per CU (32 KB of LDS stack each)
 		hipDeviceProp_t prop;
 		HIP_TRY(hipGetDeviceProperties(&prop, device));
-		s->ws.max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * 5u;
-		AL(s->ws.queue_head, 2, true);
-		AL(s->ws.spill, prd::trace_workspace_spill_entries(s->ws.max_blocks), false);
+		uint32_t blocks_per_cu = 2; // measured best on MI355X: fewer, longer-lived waves waste less in the drain phase
+		if (const char* env = getenv("PRGPU_BLOCKS_PER_CU"))
+			blocks_per_cu = (uint32_t)std::min(8, std::max(1, atoi(env)));
+		int refill = 44;
+		if (const char* env = getenv("PRGPU_REFILL"))
+			refill = std::min(64, std::max(1, atoi(env)));
+		const uint32_t max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * blocks_per_cu;
+		auto make_ws = [&](prd::TraceWorkspace& w) -> int {
+			w.max_blocks   = max_blocks;
+			w.refill_below = refill;
+			AL(w.queue_head, 1, true);
+			AL(w.spill, prd::trace_workspace_spill_entries(max_blocks), false);
+			return PRGPU_OK;
+		};
+		rc = make_ws(s->ws);
+		if (rc != PRGPU_OK)
+			return rc;
+		uint32_t n_groups = 1; // pipelined pixel groups (measured: 1 is fastest on MI355X); PRGPU_GROUPS overrides (1..16)
+		if (const char* env = getenv("PRGPU_GROUPS"))
+			n_groups = (uint32_t)std::min(16, std::max(1, atoi(env)));
+		if (np < 64u * 1024u)
+			n_groups = 1; // tiny films: nothing to overlap
+		s->groups.resize(n_groups);
+		HIP_TRY(hipEventCreateWithFlags(&s->ev_resolve, hipEventDisableTiming));
+		for (uint32_t g = 0; g < n_groups; ++g) {
+			prgpu_scene::Group& gr = s->groups[g];
+			if (g == 0)
+				gr.s_main = s->stream;
+			else
+				HIP_TRY(hipStreamCreateWithFlags(&gr.s_main, hipStreamNonBlocking));
+			HIP_TRY(hipStreamCreateWithFlags(&gr.s_shadow, hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&gr.ev_shade, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&gr.ev_shadow, hipEventDisableTiming));
+			AL(gr.counters, 2, true);
+			HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&gr.h_counters), 2 * sizeof(uint32_t), hipHostMallocDefault));
+			rc = make_ws(gr.ws_closest);
+			if (rc != PRGPU_OK)
+				return rc;
+			rc = make_ws(gr.ws_shadow);
+			if (rc != PRGPU_OK)
+				return rc;
+		}
 	}
-	HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), 4 * sizeof(uint32_t), hipHostMallocDefault));
 	HIP_TRY(hipStreamSynchronize(s->stream)); // host tables go out of scope
 	return apply_tiles(s, nullptr, 0);
 }
 
+// Enqueue one path vertex (closest hit -> shade -> counter read-back) of a pixel group on its main stream.
+int enqueue_vertex(prgpu_scene* s, prgpu_scene::Group& g)
+{
+	hipStream_t st = g.s_main;
+	s->time_begin(1, st);
+	prd::launch_trace_closest(s->sc, g.ps, g.active, g.slot_begin, g.n_active, s->instrument, g.ws_closest, g.counters, s->gstats, st);
+	s->time_end(st);
+	s->rays_closest += g.n_active;
+	if (g.shadow_pending) { // shade overwrites the shadow queue and adds emission after the previous NEE fragments
+		HIP_TRY(hipStreamWaitEvent(st, g.ev_shadow, 0));
+		g.shadow_pending = false;
+	}
+	s->time_begin(2, st);
+	prd::launch_shade(s->sc, g.ps, g.active, g.slot_begin, g.n_active, g.next, g.counters, g.ws_closest.queue_head, g.ws_shadow.queue_head, s->gstats, st);
+	s->time_end(st);
+	HIP_TRY(hipMemcpyAsync(g.h_counters, g.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(g.ev_shade, st));
+	return PRGPU_OK;
+}
+
 int render_iteration(prgpu_scene* s, uint32_t iter)
 {
-	hipStream_t st			 = s->stream;
-	const prd::DevScene& sc = s->sc;
-	const prd::PathState& ps = s->ps;
-	if (s->n_slots) {
-		s->time_begin(0);
-		prd::launch_raygen(sc, ps, s->n_slots, iter, s->gstats, st);
-		s->time_end();
+	// start every group: camera rays + first vertex
+	uint32_t running = 0;
+	for (auto& g : s->groups) {
+		g.done = true;
+		if (!g.n_slots)
+			continue;
+		if (s->resolve_recorded && g.s_main != s->stream)
+			HIP_TRY(hipStreamWaitEvent(g.s_main, s->ev_resolve, 0)); // raygen clears what the last resolve read
+		s->time_begin(0, g.s_main);
+		prd::launch_raygen(s->sc, g.ps, g.slot_begin, g.n_slots, iter, s->gstats, g.s_main);
+		s->time_end(g.s_main);
+		g.active		 = nullptr; // identity list for the primary wave
+		g.next			 = g.active_a;
+		g.n_active		 = g.n_slots;
+		g.depth			 = 0;
+		g.done			 = false;
+		g.shadow_pending = false;
+		const int rc = enqueue_vertex(s, g);
+		if (rc != PRGPU_OK)
+			return rc;
+		++running;
 	}
-	const uint32_t* active = nullptr; // identity for the primary wave
-	uint32_t* next		   = s->active_a;
-	uint32_t n_active	   = s->n_slots;
-	for (uint32_t depth = 0; n_active > 0 && depth < s->cfg.max_ray_depth; ++depth) {
-		s->time_begin(1);
-		prd::launch_trace_closest(sc, ps, active, n_active, s->instrument, s->ws, s->gstats, st);
-		s->time_end();
-		s->rays_closest += n_active;
-		HIP_TRY(hipMemsetAsync(s->counters, 0, 2 * sizeof(uint32_t), st));
-		s->time_begin(2);
-		prd::launch_shade(sc, ps, active, n_active, next, s->counters, s->gstats, st);
-		s->time_end();
-		HIP_TRY(hipMemcpyAsync(s->h_counters, s->counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-		// the shadow kernel reads its item count on the device; launch it before waiting for the counters
-		s->time_begin(3);
-		prd::launch_trace_shadow(sc, ps, n_active, s->counters, s->instrument, s->ws, s->gstats, st);
-		s->time_end();
-		HIP_TRY(hipStreamSynchronize(st));
-		s->rays_any += s->h_counters[1];
-		n_active = s->h_counters[0];
-		active	 = next;
-		next	 = (next == s->active_a) ? s->active_b : s->active_a;
+	// advance whichever group has its counters back
+	while (running) {
+		bool progress = false;
+		for (auto& g : s->groups) {
+			if (g.done)
+				continue;
+			const hipError_t q = hipEventQuery(g.ev_shade);
+			if (q == hipErrorNotReady)
+				continue;
+			if (q != hipSuccess)
+				return fail(PRGPU_EDEVICE, std::string("hipEventQuery failed: ") + hipGetErrorString(q));
+			progress				= true;
+			const uint32_t n_next	= g.h_counters[0];
+			const uint32_t n_shadow = g.h_counters[1];
+			if (n_shadow) { // NEE visibility on the side stream, overlapping the next closest-hit launch
+				HIP_TRY(hipStreamWaitEvent(g.s_shadow, g.ev_shade, 0));
+				s->time_begin(3, g.s_shadow);
+				prd::launch_trace_shadow(s->sc, g.ps, n_shadow, s->instrument, g.ws_shadow, s->gstats, g.s_shadow);
+				s->time_end(g.s_shadow);
+				HIP_TRY(hipEventRecord(g.ev_shadow, g.s_shadow));
+				g.shadow_pending = true;
+				s->rays_any += n_shadow;
+			}
+			g.active = g.next;
+			g.next	 = (g.next == g.active_a) ? g.active_b : g.active_a;
+			g.n_active = n_next;
+			g.depth += 1;
+			if (g.n_active > 0 && g.depth < s->cfg.max_ray_depth) {
+				const int rc = enqueue_vertex(s, g);
+				if (rc != PRGPU_OK)
+					return rc;
+			} else {
+				g.done = true;
+				--running;
+			}
+		}
+		if (!progress) { // block on the first unfinished group instead of spinning
+			for (auto& g : s->groups)
+				if (!g.done) {
+					HIP_TRY(hipEventSynchronize(g.ev_shade));
+					break;
+				}
+		}
 	}
-	s->time_begin(4);
-	prd::launch_resolve(sc, ps, iter, st);
-	s->time_end();
+	// filter taps + running mean once every group's fragments are in
+	for (auto& g : s->groups) {
+		if (!g.n_slots)
+			continue;
+		if (g.shadow_pending) {
+			HIP_TRY(hipStreamWaitEvent(s->stream, g.ev_shadow, 0));
+			g.shadow_pending = false;
+		}
+		if (g.s_main != s->stream)
+			HIP_TRY(hipStreamWaitEvent(s->stream, g.ev_shade, 0));
+	}
+	s->time_begin(4, s->stream);
+	prd::launch_resolve(s->sc, s->ps, iter, s->stream);
+	s->time_end(s->stream);
+	HIP_TRY(hipEventRecord(s->ev_resolve, s->stream));
+	s->resolve_recorded = true;
 	HIP_TRY(hipGetLastError());
 	return PRGPU_OK;
 }
@@ -386,8 +524,20 @@ void prgpu_scene_destroy(prgpu_scene* s)
 	s->collect_timing();
 	for (void* p : s->allocations)
 		(void)hipFree(p);
-	if (s->h_counters)
-		(void)hipHostFree(s->h_counters);
+	for (auto& g : s->groups) {
+		if (g.h_counters)
+			(void)hipHostFree(g.h_counters);
+		if (g.ev_shade)
+			(void)hipEventDestroy(g.ev_shade);
+		if (g.ev_shadow)
+			(void)hipEventDestroy(g.ev_shadow);
+		if (g.s_shadow)
+			(void)hipStreamDestroy(g.s_shadow);
+		if (g.s_main && g.s_main != s->stream && g.s_main != s->own_stream)
+			(void)hipStreamDestroy(g.s_main);
+	}
+	if (s->ev_resolve)
+		(void)hipEventDestroy(s->ev_resolve);
 	if (s->own_stream)
 		(void)hipStreamDestroy(s->own_stream);
 	delete s;
@@ -408,6 +558,8 @@ int prgpu_set_stream(prgpu_scene* s, void* hip_stream)
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : s->own_stream;
+	if (!s->groups.empty())
+		s->groups[0].s_main = s->stream;
 	return PRGPU_OK;
 }
 
@@ -495,6 +647,8 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 	out->leaf_bytes	   = sizeof(prd::Rec128); // leaf record (<= 3 triangles)
 	out->ray_bytes	   = 32; // o,tmin + d,tmax
 	out->hit_bytes	   = 16; // t,u,v,tri
+	out->wave_steps_closest = host[PRGPU_STAT_COUNT + 4];
+	out->wave_steps_any		= host[PRGPU_STAT_COUNT + 5];
 	return PRGPU_OK;
 }
 
@@ -571,9 +725,9 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	TRY_OR_CLEAN(hipMemcpyAsync(d_dir, dir, size_t(n) * 12, hipMemcpyHostToDevice, s->stream));
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmin, tmin, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmax, tmax, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
-	s->time_begin(1);
+	s->time_begin(1, s->stream);
 	prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->gstats, s->stream);
-	s->time_end();
+	s->time_end(s->stream);
 	s->rays_closest += n;
 	TRY_OR_CLEAN(hipGetLastError());
 	TRY_OR_CLEAN(hipStreamSynchronize(s->stream));
@@ -612,9 +766,9 @@ int prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* d
 	TRY_OR_CLEAN(hipMemcpyAsync(d_dir, dir, size_t(n) * 12, hipMemcpyHostToDevice, s->stream));
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmin, tmin, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	TRY_OR_CLEAN(hipMemcpyAsync(d_dist, distance, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
-	s->time_begin(3);
+	s->time_begin(3, s->stream);
 	prd::launch_service_any(s->sc, n, d_org, d_dir, d_tmin, d_dist, d_occ, s->ws, s->gstats, s->stream);
-	s->time_end();
+	s->time_end(s->stream);
 	s->rays_any += n;
 	TRY_OR_CLEAN(hipGetLastError());
 	TRY_OR_CLEAN(hipStreamSynchronize(s->stream));

@@ -25,3 +25,8 @@ ctx.render(1); ctx.waitForFinish()
 print(ctx.traceCounters())
 xyz, smp, fb = ctx.output()
 print("mean xyz", xyz.reshape(-1, 3).mean(0), "feedback any", int((fb != 0).sum()))
+tc = ctx.traceCounters()
+print("closest: records/ray %.1f, lane utilisation %.3f ; any: records/ray %.1f, lane utilisation %.3f" % (
+    (tc["nodes_closest"] + tc["leaves_closest"]) / (st["primary_rays"] + st["bounce_rays"]) * iters * 1.0 / 1 if False else (tc["nodes_closest"] + tc["leaves_closest"]) / max(1, tc["wave_steps_closest"]) ,
+    (tc["nodes_closest"] + tc["leaves_closest"]) / max(1, 64 * tc["wave_steps_closest"]),
+    (tc["nodes_any"] + tc["leaves_any"]) / max(1, tc["wave_steps_any"]), (tc["nodes_any"] + tc["leaves_any"]) / max(1, 64 * tc["wave_steps_any"])))
