@@ -585,7 +585,9 @@ inline RayPre ray_prepare(V3 o, V3 d, float eps_t)
 	r.Sx = d[kx] / d[kz];
 	r.Sy = d[ky] / d[kz];
 	r.Sz = 1.0f / d[kz];
-	r.inv_d = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	// reciprocal direction, +-inf (axis-parallel rays) replaced by +-FLT_MAX so that the slab test never forms 0*inf
+	auto rcp = [](float x) { return std::min(std::max(1.0f / x, -FLT_MAX), FLT_MAX); };
+	r.inv_d	 = v3(rcp(d.x), rcp(d.y), rcp(d.z));
 	return r;
 }
 // returns true and t,u,v when the (infinite) ray line crosses the triangle with det != 0
@@ -630,7 +632,6 @@ inline bool box_hit(const RayPre& r, const Aabb& b, float tmin, float limit, flo
 		float tf = (b.hi[a] - o[a]) * id[a];
 		if (tn > tf)
 			std::swap(tn, tf);
-		// NaN (0*inf) compares false -> keeps the interval, i.e. stays conservative
 		if (tn > t0)
 			t0 = tn;
 		if (tf < t1)

@@ -101,6 +101,7 @@ struct PathState {
 	float4* path_pdf;
 	float4* prev_pdf;
 	uint32_t* flags; // depth | mono<<8 | last_delta<<9 | last_emissive<<10
+	uint32_t* iter;	 // sample index of the path currently living in the slot
 	float4* hit;	 // t,u,v, original tri index bits (INVALID on miss)
 	// shadow queue records
 	float4* sh_o;	   // o.xyz, tmin
@@ -398,7 +399,9 @@ __device__ __forceinline__ RayPre ray_prepare(V3 o, V3 d, float eps_t)
 	r.Sx	= comp(d, kx) / comp(d, kz);
 	r.Sy	= comp(d, ky) / comp(d, kz);
 	r.Sz	= 1.0f / comp(d, kz);
-	r.inv_d = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	// reciprocal direction, +-inf (axis-parallel rays) replaced by +-FLT_MAX so that the slab test never forms 0*inf
+	r.inv_d = v3(fminf(fmaxf(1.0f / d.x, -3.402823466e+38f), 3.402823466e+38f), fminf(fmaxf(1.0f / d.y, -3.402823466e+38f), 3.402823466e+38f),
+				 fminf(fmaxf(1.0f / d.z, -3.402823466e+38f), 3.402823466e+38f));
 	return r;
 }
 __device__ __forceinline__ bool woop(const RayPre& r, V3 p0, V3 p1, V3 p2, float& t, float& u, float& v)
@@ -432,26 +435,13 @@ __device__ __forceinline__ bool woop(const RayPre& r, V3 p0, V3 p1, V3 p2, float
 // slab test against a padded box; entry <= limit keeps equal-t ties reachable
 __device__ __forceinline__ bool box_hit(const RayPre& r, const float* lo, const float* hi, float tmin, float limit, float& tentry)
 {
-	float t0 = tmin, t1 = limit;
-	{
-		float tn = (lo[0] - r.o.x) * r.inv_d.x, tf = (hi[0] - r.o.x) * r.inv_d.x;
-		if (tn > tf) { const float s = tn; tn = tf; tf = s; }
-		if (tn > t0) t0 = tn;
-		if (tf < t1) t1 = tf;
-	}
-	{
-		float tn = (lo[1] - r.o.y) * r.inv_d.y, tf = (hi[1] - r.o.y) * r.inv_d.y;
-		if (tn > tf) { const float s = tn; tn = tf; tf = s; }
-		if (tn > t0) t0 = tn;
-		if (tf < t1) t1 = tf;
-	}
-	{
-		float tn = (lo[2] - r.o.z) * r.inv_d.z, tf = (hi[2] - r.o.z) * r.inv_d.z;
-		if (tn > tf) { const float s = tn; tn = tf; tf = s; }
-		if (tn > t0) t0 = tn;
-		if (tf < t1) t1 = tf;
-	}
-	tentry = t0;
+	const float ax = (lo[0] - r.o.x) * r.inv_d.x, bx = (hi[0] - r.o.x) * r.inv_d.x;
+	const float ay = (lo[1] - r.o.y) * r.inv_d.y, by = (hi[1] - r.o.y) * r.inv_d.y;
+	const float az = (lo[2] - r.o.z) * r.inv_d.z, bz = (hi[2] - r.o.z) * r.inv_d.z;
+	// no NaN can occur (inv_d is finite), so min/max equal the checker's compare-and-swap sequence
+	const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+	const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), limit));
+	tentry		   = t0;
 	// The slab test must never cull a triangle whose COMPUTED t passes the watertight test: the padded box
 	// absorbs the rounding of its own coordinates, the factor the relative error of the slab distances and
 	// eps_t (8e-6 * largest scene coordinate) the absolute error of the triangle test's t.

@@ -21,8 +21,13 @@ void launch_raygen(const DevScene& sc, const PathState& ps, uint32_t slot_base, 
 void launch_trace_closest(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t slot_base, uint32_t n_active, bool count,
 						  const TraceWorkspace& ws, uint32_t* shade_counters, unsigned long long* gstats, hipStream_t st);
 // shade also clears the two queue heads for the next traversal launches of the group
+// counters: [0] survivors appended to next_active, [1] shadow-queue items, [2] paths ended (appended to dead_list when it is non-null)
 void launch_shade(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t slot_base, uint32_t n_active, uint32_t* next_active,
-				  uint32_t* counters, uint32_t* queue_head_closest, uint32_t* queue_head_shadow, unsigned long long* gstats, hipStream_t st);
+				  uint32_t* counters, uint32_t* dead_list, uint32_t* queue_head_closest, uint32_t* queue_head_shadow, unsigned long long* gstats,
+				  hipStream_t st);
+// streaming mode: fold finished paths into the running mean and start the pixel's next sample (appends to next_active / counters[0])
+void launch_regen(const DevScene& sc, const PathState& ps, const uint32_t* dead, uint32_t n_dead, uint32_t iter_end, uint32_t* next_active,
+				  uint32_t* counters, unsigned long long* gstats, hipStream_t st);
 void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t n_items, bool count, const TraceWorkspace& ws, unsigned long long* gstats,
 						 hipStream_t st);
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st);

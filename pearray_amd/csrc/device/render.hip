@@ -417,101 +417,137 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter)
 }
 
 // ---- kernels ------------------------------------------------------------------------------------------------
-// RenderTile::constructCameraRay (RenderTile.cpp:71-132) + StreamPipeline::fillWithCameraRays (:83-133)
+// RenderTile::constructCameraRay (RenderTile.cpp:71-132) + StreamPipeline::fillWithCameraRays (:83-133): starts the camera
+// path of sample `iter` of the slot's pixel (draws AA / lens / time / wavelength samples from the pixel's generator).
+__device__ __forceinline__ void camera_path(const DevScene& sc, const PathState& ps, uint32_t slot, uint32_t iter, BlockStats& bs)
+{
+	const prgpu_settings& cfg = sc.cfg;
+	const uint32_t pixel	  = ps.pixel[slot];
+	const uint32_t gx = pixel % cfg.width, gy = pixel / cfg.width;
+	uint64_t rnd = ps.rng[pixel];
+	float ax, ay;
+	if (cfg.aa_sampler == PRGPU_SAMPLER_MJITT) { // MultiJitteredSampler.cpp:118-150
+		const uint32_t n  = max(1u, sc.spp);
+		const uint32_t id = mjitt_permute(iter, n, sc.mj_seed * 0x51633e2d);
+		const uint32_t sx = mjitt_permute(id % sc.mj_x, sc.mj_x, sc.mj_seed * 0x68bc21eb);
+		const uint32_t sy = mjitt_permute(id / sc.mj_x, sc.mj_y, sc.mj_seed * 0x02e5be93);
+		const float jx	  = rng_float(rnd);
+		const float jy	  = rng_float(rnd);
+		ax				  = (sx + (sy + jx) / sc.mj_y) / sc.mj_x;
+		ay				  = (id + jy) / n;
+	} else if (cfg.aa_sampler == PRGPU_SAMPLER_SOBOL && iter < sc.spp) { // SobolSampler.cpp:67-73
+		ax = sc.sobol2d[2 * iter];
+		ay = sc.sobol2d[2 * iter + 1];
+	} else { // RandomSampler.cpp:20-21
+		ax = rng_float(rnd);
+		ay = rng_float(rnd);
+	}
+	const float px = (float)gx + ax - 0.5f, py = (float)gy + ay - 0.5f;
+	const float l1 = rng_float(rnd), l2 = rng_float(rnd); // lens
+	(void)rng_float(rnd);								   // time
+	Blob wl, wl_pdf;
+	if (cfg.spectral_mono) {
+		wl	   = blob(cfg.spectral_start);
+		wl_pdf = blob(1.0f);
+	} else if (cfg.mapper == PRGPU_MAPPER_SPD_CMIS) { // spd.cpp:40-48
+		const float span = cfg.spectral_end - cfg.spectral_start;
+		for (int k = 0; k < 4; ++k) {
+			float pdf;
+			const float v = distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, rng_float(rnd), pdf);
+			wl.v[k]		  = v * span + cfg.spectral_start;
+			wl_pdf.v[k]	  = pdf;
+		}
+	} else if (cfg.mapper == PRGPU_MAPPER_SPD_HERO) { // spd.cpp:103-113
+		const float span = cfg.spectral_end - cfg.spectral_start;
+		float pdf;
+		const float v	  = distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, rng_float(rnd), pdf);
+		const float hero  = v * span + cfg.spectral_start;
+		const float delta = span / 4;
+		wl.v[0]			  = hero;
+		for (int k = 1; k < 4; ++k)
+			wl.v[k] = cfg.spectral_start + fmodf(hero - cfg.spectral_start + k * delta, span);
+		wl_pdf = blob(pdf);
+	} else { // random.cpp:22-36
+		const float u	  = rng_float(rnd);
+		const float span  = cfg.spectral_end - cfg.spectral_start;
+		const float delta = span / 4;
+		const float start = u * span;
+		wl.v[0]			  = start + cfg.spectral_start;
+		for (int k = 1; k < 4; ++k)
+			wl.v[k] = cfg.spectral_start + fmodf(start + k * delta, span);
+		wl_pdf = blob(1.0f);
+	}
+	// PerspectiveCamera::constructRay (perspective.cpp:45-82)
+	const float nx = 2 * (px / (float)cfg.width - 0.5f);
+	const float ny = -(2 * (py / (float)cfg.height - 0.5f));
+	const DevCamera& cam = sc.cam;
+	V3 o = v3(cam.o[0], cam.o[1], cam.o[2]);
+	V3 d = (v3(cam.right[0], cam.right[1], cam.right[2]) * nx + v3(cam.up[0], cam.up[1], cam.up[2]) * ny) + v3(cam.focal[0], cam.focal[1], cam.focal[2]);
+	if (cam.dof) {
+		float sn, cs;
+		pr_sincos_2pi(l1, sn, cs);
+		const V3 e = v3(cam.xap[0], cam.xap[1], cam.xap[2]) * (l2 * sn) + v3(cam.yap[0], cam.yap[1], cam.yap[2]) * (l2 * cs);
+		o		   = o + e;
+		d		   = d - e;
+	}
+	d = normalized(d);
+	const bool mono	   = cfg.spectral_mono || !cfg.spectral_hero; // RenderTile.cpp:123-124
+	ps.rng[pixel]	   = rnd;
+	ps.ray_o[slot]	   = make_float4(o.x, o.y, o.z, cam.near_t);
+	ps.ray_d[slot]	   = make_float4(d.x, d.y, d.z, cam.far_t);
+	ps.wl[slot]		   = to4(wl);
+	ps.wl_pdf[slot]	   = to4(wl_pdf);
+	ps.throughput[slot] = make_float4(1, 1, 1, 1);
+	ps.path_pdf[slot]  = make_float4(1, 1, 1, 1);
+	ps.prev_pdf[slot]  = make_float4(1, 1, 1, 1);
+	ps.flags[slot]	   = 0u | (mono ? FLAG_MONO : 0u) | FLAG_LAST_DELTA;
+	ps.iter_xyz[3 * pixel + 0] = 0.0f;
+	ps.iter_xyz[3 * pixel + 1] = 0.0f;
+	ps.iter_xyz[3 * pixel + 2] = 0.0f;
+	atomicAdd(&bs.v[PRGPU_STAT_PIXEL_SAMPLES], 1u);
+	atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
+	atomicAdd(&bs.v[PRGPU_STAT_PRIMARY_RAYS], 1u);
+}
+
 __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PathState ps, uint32_t slot_base, uint32_t n_slots, uint32_t iter, unsigned long long* gstats)
 {
 	__shared__ BlockStats bs;
 	stats_init(bs);
 	const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t slot	 = slot_base + local;
 	if (local < n_slots) {
-		const prgpu_settings& cfg = sc.cfg;
-		const uint32_t pixel	  = ps.pixel[slot];
-		const uint32_t gx = pixel % cfg.width, gy = pixel / cfg.width;
-		uint64_t rnd = ps.rng[pixel];
-		float ax, ay;
-		if (cfg.aa_sampler == PRGPU_SAMPLER_MJITT) { // MultiJitteredSampler.cpp:118-150
-			const uint32_t n  = max(1u, sc.spp);
-			const uint32_t id = mjitt_permute(iter, n, sc.mj_seed * 0x51633e2d);
-			const uint32_t sx = mjitt_permute(id % sc.mj_x, sc.mj_x, sc.mj_seed * 0x68bc21eb);
-			const uint32_t sy = mjitt_permute(id / sc.mj_x, sc.mj_y, sc.mj_seed * 0x02e5be93);
-			const float jx	  = rng_float(rnd);
-			const float jy	  = rng_float(rnd);
-			ax				  = (sx + (sy + jx) / sc.mj_y) / sc.mj_x;
-			ay				  = (id + jy) / n;
-		} else if (cfg.aa_sampler == PRGPU_SAMPLER_SOBOL && iter < sc.spp) { // SobolSampler.cpp:67-73
-			ax = sc.sobol2d[2 * iter];
-			ay = sc.sobol2d[2 * iter + 1];
-		} else { // RandomSampler.cpp:20-21
-			ax = rng_float(rnd);
-			ay = rng_float(rnd);
-		}
-		const float px = (float)gx + ax - 0.5f, py = (float)gy + ay - 0.5f;
-		const float l1 = rng_float(rnd), l2 = rng_float(rnd); // lens
-		(void)rng_float(rnd);								   // time
-		Blob wl, wl_pdf;
-		if (cfg.spectral_mono) {
-			wl	   = blob(cfg.spectral_start);
-			wl_pdf = blob(1.0f);
-		} else if (cfg.mapper == PRGPU_MAPPER_SPD_CMIS) { // spd.cpp:40-48
-			const float span = cfg.spectral_end - cfg.spectral_start;
-			for (int k = 0; k < 4; ++k) {
-				float pdf;
-				const float v = distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, rng_float(rnd), pdf);
-				wl.v[k]		  = v * span + cfg.spectral_start;
-				wl_pdf.v[k]	  = pdf;
-			}
-		} else if (cfg.mapper == PRGPU_MAPPER_SPD_HERO) { // spd.cpp:103-113
-			const float span = cfg.spectral_end - cfg.spectral_start;
-			float pdf;
-			const float v	  = distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, rng_float(rnd), pdf);
-			const float hero  = v * span + cfg.spectral_start;
-			const float delta = span / 4;
-			wl.v[0]			  = hero;
-			for (int k = 1; k < 4; ++k)
-				wl.v[k] = cfg.spectral_start + fmodf(hero - cfg.spectral_start + k * delta, span);
-			wl_pdf = blob(pdf);
-		} else { // random.cpp:22-36
-			const float u	  = rng_float(rnd);
-			const float span  = cfg.spectral_end - cfg.spectral_start;
-			const float delta = span / 4;
-			const float start = u * span;
-			wl.v[0]			  = start + cfg.spectral_start;
-			for (int k = 1; k < 4; ++k)
-				wl.v[k] = cfg.spectral_start + fmodf(start + k * delta, span);
-			wl_pdf = blob(1.0f);
-		}
-		// PerspectiveCamera::constructRay (perspective.cpp:45-82)
-		const float nx = 2 * (px / (float)cfg.width - 0.5f);
-		const float ny = -(2 * (py / (float)cfg.height - 0.5f));
-		const DevCamera& cam = sc.cam;
-		V3 o = v3(cam.o[0], cam.o[1], cam.o[2]);
-		V3 d = (v3(cam.right[0], cam.right[1], cam.right[2]) * nx + v3(cam.up[0], cam.up[1], cam.up[2]) * ny) + v3(cam.focal[0], cam.focal[1], cam.focal[2]);
-		if (cam.dof) {
-			float sn, cs;
-			pr_sincos_2pi(l1, sn, cs);
-			const V3 e = v3(cam.xap[0], cam.xap[1], cam.xap[2]) * (l2 * sn) + v3(cam.yap[0], cam.yap[1], cam.yap[2]) * (l2 * cs);
-			o		   = o + e;
-			d		   = d - e;
-		}
-		d = normalized(d);
-		const bool mono	   = cfg.spectral_mono || !cfg.spectral_hero; // RenderTile.cpp:123-124
-		ps.rng[pixel]	   = rnd;
-		ps.ray_o[slot]	   = make_float4(o.x, o.y, o.z, cam.near_t);
-		ps.ray_d[slot]	   = make_float4(d.x, d.y, d.z, cam.far_t);
-		ps.wl[slot]		   = to4(wl);
-		ps.wl_pdf[slot]	   = to4(wl_pdf);
-		ps.throughput[slot] = make_float4(1, 1, 1, 1);
-		ps.path_pdf[slot]  = make_float4(1, 1, 1, 1);
-		ps.prev_pdf[slot]  = make_float4(1, 1, 1, 1);
-		ps.flags[slot]	   = 0u | (mono ? FLAG_MONO : 0u) | FLAG_LAST_DELTA;
-		ps.iter_xyz[3 * pixel + 0] = 0.0f;
-		ps.iter_xyz[3 * pixel + 1] = 0.0f;
-		ps.iter_xyz[3 * pixel + 2] = 0.0f;
-		atomicAdd(&bs.v[PRGPU_STAT_PIXEL_SAMPLES], 1u);
-		atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
-		atomicAdd(&bs.v[PRGPU_STAT_PRIMARY_RAYS], 1u);
+		ps.iter[slot_base + local] = iter;
+		camera_path(sc, ps, slot_base + local, iter, bs);
 	}
+	stats_flush(bs, gstats);
+}
+
+// Streaming mode: a finished path folds its pixel's sum of this sample into the running mean
+// (FrameOutputDevice::onEndOfIteration, FrameOutputDevice.cpp:202-221, single-tap filters only) and, if the pixel
+// has samples left, starts the next camera path right away -- pixels advance through their samples independently.
+__global__ void __launch_bounds__(256) k_regen(DevScene sc, PathState ps, const uint32_t* __restrict__ dead, uint32_t n_dead, uint32_t iter_end,
+											  uint32_t* __restrict__ next_active, uint32_t* __restrict__ counters, unsigned long long* gstats)
+{
+	__shared__ BlockStats bs;
+	stats_init(bs);
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	bool alive	  = false;
+	uint32_t slot = 0;
+	if (i < n_dead) {
+		slot				 = dead[i];
+		const uint32_t pixel = ps.pixel[slot];
+		const uint32_t iter	 = ps.iter[slot];
+		const float it = (float)(iter + 1), itm1 = (float)iter;
+		for (int c = 0; c < 3; ++c)
+			ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + ps.iter_xyz[3 * pixel + c]) / it;
+		if (iter + 1 < iter_end) {
+			ps.iter[slot] = iter + 1;
+			camera_path(sc, ps, slot, iter + 1, bs);
+			alive = true;
+		}
+	}
+	const uint32_t pos = wave_append(alive, &counters[0]);
+	if (alive)
+		next_active[pos] = slot;
 	stats_flush(bs, gstats);
 }
 
@@ -524,6 +560,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 	if (blockIdx.x == 0 && threadIdx.x == 0) { // the following shade launch appends into these (stream ordered)
 		shade_counters[0] = 0;
 		shade_counters[1] = 0;
+		shade_counters[2] = 0;
 	}
 	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
 		const uint32_t slot = active ? active[i] : slot_base + i;
@@ -543,8 +580,9 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 // handleCameraVertex / handleDirectHit / handleNEE / handleScattering (direct.cpp:73-412), Walker::traverse
 // (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53)
 __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t slot_base, uint32_t n_active,
-											  uint32_t* __restrict__ next_active, uint32_t* __restrict__ counters /* [0]=next, [1]=shadow */,
-											  uint32_t* queue_head_closest, uint32_t* queue_head_shadow, unsigned long long* gstats)
+											  uint32_t* __restrict__ next_active, uint32_t* __restrict__ counters /* [0]=next, [1]=shadow, [2]=dead */,
+											  uint32_t* __restrict__ dead_list, uint32_t* queue_head_closest, uint32_t* queue_head_shadow,
+											  unsigned long long* gstats)
 {
 	__shared__ BlockStats bs;
 	stats_init(bs);
@@ -785,10 +823,16 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 			}
 		}
 	}
-	// ballot/prefix-scan compaction of survivors and of the shadow queue
+	// ballot/prefix-scan compaction of survivors, finished paths and of the shadow queue
 	const uint32_t pos_next = wave_append(alive, &counters[0]);
 	if (alive)
 		next_active[pos_next] = slot;
+	if (dead_list) { // streaming mode: remember which paths ended in this launch
+		const bool died			= i < n_active && !alive;
+		const uint32_t pos_dead = wave_append(died, &counters[2]);
+		if (died)
+			dead_list[pos_dead] = slot;
+	}
 	const uint32_t pos_sh = wave_append(want_shadow, &counters[1]);
 	if (want_shadow) {
 		ps.sh_o[pos_sh]	   = sh_o;
@@ -928,10 +972,17 @@ void launch_trace_closest(const DevScene& sc, const PathState& ps, const uint32_
 						   ws.refill_below, shade_counters, gstats);
 }
 void launch_shade(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t slot_base, uint32_t n_active, uint32_t* next_active,
-				  uint32_t* counters, uint32_t* queue_head_closest, uint32_t* queue_head_shadow, unsigned long long* gstats, hipStream_t st)
+				  uint32_t* counters, uint32_t* dead_list, uint32_t* queue_head_closest, uint32_t* queue_head_shadow, unsigned long long* gstats,
+				  hipStream_t st)
 {
-	hipLaunchKernelGGL(k_shade, grid_for(n_active), dim3(256), 0, st, sc, ps, active, slot_base, n_active, next_active, counters, queue_head_closest,
-					   queue_head_shadow, gstats);
+	hipLaunchKernelGGL(k_shade, grid_for(n_active), dim3(256), 0, st, sc, ps, active, slot_base, n_active, next_active, counters, dead_list,
+					   queue_head_closest, queue_head_shadow, gstats);
+}
+void launch_regen(const DevScene& sc, const PathState& ps, const uint32_t* dead, uint32_t n_dead, uint32_t iter_end, uint32_t* next_active,
+				  uint32_t* counters, unsigned long long* gstats, hipStream_t st)
+{
+	if (n_dead)
+		hipLaunchKernelGGL(k_regen, grid_for(n_dead), dim3(256), 0, st, sc, ps, dead, n_dead, iter_end, next_active, counters, gstats);
 }
 void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t n_items, bool count, const TraceWorkspace& ws, unsigned long long* gstats,
 						 hipStream_t st)

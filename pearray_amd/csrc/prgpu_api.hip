@@ -55,7 +55,8 @@ struct prgpu_scene {
 	// frame planes owned by the library (may be replaced by prgpu_bind_framebuffer)
 	float* own_xyz = nullptr;
 	uint32_t *own_samples = nullptr, *own_feedback = nullptr;
-	uint32_t *active_a = nullptr, *active_b = nullptr;
+	uint32_t *active_a = nullptr, *active_b = nullptr, *dead_a = nullptr, *dead_b = nullptr;
+	bool lockstep = false; // iteration-synchronous pipeline (needed for multi-tap pixel filters; PRGPU_LOCKSTEP=1 forces it)
 	unsigned long long* gstats = nullptr;
 	prd::TraceWorkspace ws; // workspace of the ray-service launches
 	// Pixel groups: contiguous ranges of the Morton-ordered slot list, each running its own wavefront pipeline on
@@ -65,6 +66,9 @@ struct prgpu_scene {
 		hipEvent_t ev_shade = nullptr, ev_shadow = nullptr;
 		uint32_t slot_begin = 0, n_slots = 0;
 		uint32_t *active_a = nullptr, *active_b = nullptr, *counters = nullptr, *h_counters = nullptr;
+		uint32_t *dead_a = nullptr, *dead_b = nullptr; // streaming mode: paths that ended in the current / previous round
+		uint32_t *dead_cur = nullptr, *dead_prev = nullptr;
+		uint32_t n_dead_prev = 0;
 		prd::TraceWorkspace ws_closest, ws_shadow;
 		prd::PathState ps; // shadow-queue pointers offset to this group's region
 		// per-iteration state
@@ -166,6 +170,8 @@ int apply_tiles(prgpu_scene* s, const prgpu_tile* tiles, uint32_t n_tiles)
 		gr.n_slots	  = std::min(s->n_slots, (g + 1) * chunk) - gr.slot_begin;
 		gr.active_a	  = s->active_a + gr.slot_begin;
 		gr.active_b	  = s->active_b + gr.slot_begin;
+		gr.dead_a	  = s->dead_a + gr.slot_begin;
+		gr.dead_b	  = s->dead_b + gr.slot_begin;
 		gr.ps		  = s->ps;
 		gr.ps.sh_o += gr.slot_begin;
 		gr.ps.sh_d += gr.slot_begin;
@@ -287,6 +293,13 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	ps.feedback = s->own_feedback;
 	AL(s->active_a, np, false);
 	AL(s->active_b, np, false);
+	AL(s->dead_a, np, false);
+	AL(s->dead_b, np, false);
+	AL(ps.iter, np, true);
+	// streaming (pixels advance through their samples independently) is bit-identical for single-tap filters but measured
+	// ~6% slower than the iteration-synchronous pipeline on MI355X (finished paths wait one round before their pixel's
+	// next sample starts); it stays available behind PRGPU_STREAMING=1
+	s->lockstep = !t.single_tap || !(getenv("PRGPU_STREAMING") && atoi(getenv("PRGPU_STREAMING")) != 0);
 	AL(s->gstats, prd::N_DEVICE_COUNTERS, true);
 	{ // persistent traversal grid: a few blocks of 256 threads per CU (32 KB of LDS stack each)
 		hipDeviceProp_t prop;
@@ -324,8 +337,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 			HIP_TRY(hipStreamCreateWithFlags(&gr.s_shadow, hipStreamNonBlocking));
 			HIP_TRY(hipEventCreateWithFlags(&gr.ev_shade, hipEventDisableTiming));
 			HIP_TRY(hipEventCreateWithFlags(&gr.ev_shadow, hipEventDisableTiming));
-			AL(gr.counters, 2, true);
-			HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&gr.h_counters), 2 * sizeof(uint32_t), hipHostMallocDefault));
+			AL(gr.counters, 4, true);
+			HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&gr.h_counters), 4 * sizeof(uint32_t), hipHostMallocDefault));
 			rc = make_ws(gr.ws_closest);
 			if (rc != PRGPU_OK)
 				return rc;
@@ -351,9 +364,10 @@ int enqueue_vertex(prgpu_scene* s, prgpu_scene::Group& g)
 		g.shadow_pending = false;
 	}
 	s->time_begin(2, st);
-	prd::launch_shade(s->sc, g.ps, g.active, g.slot_begin, g.n_active, g.next, g.counters, g.ws_closest.queue_head, g.ws_shadow.queue_head, s->gstats, st);
+	prd::launch_shade(s->sc, g.ps, g.active, g.slot_begin, g.n_active, g.next, g.counters, nullptr, g.ws_closest.queue_head, g.ws_shadow.queue_head,
+					  s->gstats, st);
 	s->time_end(st);
-	HIP_TRY(hipMemcpyAsync(g.h_counters, g.counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(g.h_counters, g.counters, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipEventRecord(g.ev_shade, st));
 	return PRGPU_OK;
 }
@@ -442,6 +456,125 @@ int render_iteration(prgpu_scene* s, uint32_t iter)
 	s->time_end(s->stream);
 	HIP_TRY(hipEventRecord(s->ev_resolve, s->stream));
 	s->resolve_recorded = true;
+	HIP_TRY(hipGetLastError());
+	return PRGPU_OK;
+}
+
+// ---- streaming mode ---------------------------------------------------------------------------------------------
+// Pixels advance through their samples independently: when a path ends, its pixel's sum is folded into the running
+// mean and the pixel's next camera path joins the wavefront in the following round (k_regen).  The wavefront therefore
+// stays full until the last samples drain, instead of shrinking to a few thousand rays at the end of every iteration.
+// Per pixel nothing changes: same RNG stream, same fragment order, same fold arithmetic -> identical results.
+// Valid when the pixel filter has a single live tap (the reference default); other filters use the lock-step pipeline.
+int enqueue_round(prgpu_scene* s, prgpu_scene::Group& g, uint32_t iter_end)
+{
+	hipStream_t st = g.s_main;
+	if (g.n_active) {
+		s->time_begin(1, st);
+		prd::launch_trace_closest(s->sc, g.ps, g.active, g.slot_begin, g.n_active, s->instrument, g.ws_closest, g.counters, s->gstats, st);
+		s->time_end(st);
+		s->rays_closest += g.n_active;
+	} else {
+		HIP_TRY(hipMemsetAsync(g.counters, 0, 3 * sizeof(uint32_t), st)); // normally cleared by the closest-hit launch
+	}
+	if (g.shadow_pending) { // NEE fragments of the previous round land before shade adds emission / regen folds the pixel
+		HIP_TRY(hipStreamWaitEvent(st, g.ev_shadow, 0));
+		g.shadow_pending = false;
+	}
+	if (g.n_active) {
+		s->time_begin(2, st);
+		prd::launch_shade(s->sc, g.ps, g.active, g.slot_begin, g.n_active, g.next, g.counters, g.dead_cur, g.ws_closest.queue_head,
+						  g.ws_shadow.queue_head, s->gstats, st);
+		s->time_end(st);
+	}
+	if (g.n_dead_prev) {
+		s->time_begin(0, st);
+		prd::launch_regen(s->sc, g.ps, g.dead_prev, g.n_dead_prev, iter_end, g.next, g.counters, s->gstats, st);
+		s->time_end(st);
+	}
+	HIP_TRY(hipMemcpyAsync(g.h_counters, g.counters, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipEventRecord(g.ev_shade, st));
+	return PRGPU_OK;
+}
+
+int render_streaming(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
+{
+	uint32_t running = 0;
+	for (auto& g : s->groups) {
+		g.done = true;
+		if (!g.n_slots)
+			continue;
+		s->time_begin(0, g.s_main);
+		prd::launch_raygen(s->sc, g.ps, g.slot_begin, g.n_slots, iter_begin, s->gstats, g.s_main);
+		s->time_end(g.s_main);
+		g.active		 = nullptr;
+		g.next			 = g.active_a;
+		g.n_active		 = g.n_slots;
+		g.dead_cur		 = g.dead_a;
+		g.dead_prev		 = g.dead_b;
+		g.n_dead_prev	 = 0;
+		g.done			 = false;
+		g.shadow_pending = false;
+		const int rc = enqueue_round(s, g, iter_end);
+		if (rc != PRGPU_OK)
+			return rc;
+		++running;
+	}
+	while (running) {
+		bool progress = false;
+		for (auto& g : s->groups) {
+			if (g.done)
+				continue;
+			const hipError_t q = hipEventQuery(g.ev_shade);
+			if (q == hipErrorNotReady)
+				continue;
+			if (q != hipSuccess)
+				return fail(PRGPU_EDEVICE, std::string("hipEventQuery failed: ") + hipGetErrorString(q));
+			progress				= true;
+			const uint32_t n_next	= g.h_counters[0]; // survivors + regenerated camera paths
+			const uint32_t n_shadow = g.h_counters[1];
+			const uint32_t n_dead	= g.n_active ? g.h_counters[2] : 0;
+			if (n_shadow && g.n_active) {
+				HIP_TRY(hipStreamWaitEvent(g.s_shadow, g.ev_shade, 0));
+				s->time_begin(3, g.s_shadow);
+				prd::launch_trace_shadow(s->sc, g.ps, n_shadow, s->instrument, g.ws_shadow, s->gstats, g.s_shadow);
+				s->time_end(g.s_shadow);
+				HIP_TRY(hipEventRecord(g.ev_shadow, g.s_shadow));
+				g.shadow_pending = true;
+				s->rays_any += n_shadow;
+			}
+			g.active	  = g.next;
+			g.next		  = (g.next == g.active_a) ? g.active_b : g.active_a;
+			g.n_active	  = n_next;
+			std::swap(g.dead_cur, g.dead_prev);
+			g.n_dead_prev = n_dead;
+			if (g.n_active > 0 || g.n_dead_prev > 0) {
+				const int rc = enqueue_round(s, g, iter_end);
+				if (rc != PRGPU_OK)
+					return rc;
+			} else {
+				g.done = true;
+				--running;
+			}
+		}
+		if (!progress) {
+			for (auto& g : s->groups)
+				if (!g.done) {
+					HIP_TRY(hipEventSynchronize(g.ev_shade));
+					break;
+				}
+		}
+	}
+	for (auto& g : s->groups) { // everything funnels back into the scene stream
+		if (!g.n_slots)
+			continue;
+		if (g.shadow_pending) {
+			HIP_TRY(hipStreamWaitEvent(s->stream, g.ev_shadow, 0));
+			g.shadow_pending = false;
+		}
+		if (g.s_main != s->stream)
+			HIP_TRY(hipStreamWaitEvent(s->stream, g.ev_shade, 0));
+	}
 	HIP_TRY(hipGetLastError());
 	return PRGPU_OK;
 }
@@ -582,6 +715,15 @@ int prgpu_render(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	if (iter_begin != s->next_iteration || iter_end < iter_begin)
 		return fail(PRGPU_EINVAL, "iterations must be rendered in order (pixel RNG streams are sequential)");
 	HIP_TRY(hipSetDevice(s->device));
+	if (iter_end == iter_begin)
+		return PRGPU_OK;
+	if (!s->lockstep) {
+		const int rc = render_streaming(s, iter_begin, iter_end);
+		if (rc != PRGPU_OK)
+			return rc;
+		s->next_iteration = iter_end;
+		return PRGPU_OK;
+	}
 	for (uint32_t it = iter_begin; it < iter_end; ++it) {
 		const int rc = render_iteration(s, it);
 		if (rc != PRGPU_OK)
