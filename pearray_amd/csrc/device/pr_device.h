@@ -97,6 +97,9 @@ struct PathState {
 	float4* ray_d;	 // d.xyz, tmax
 	float4* wl;
 	float4* wl_pdf;
+	float4* cie_x;	 // CIE XYZ responses of the four wavelengths of the path (CIE::eval, computed once per camera sample)
+	float4* cie_y;
+	float4* cie_z;
 	float4* throughput;
 	float4* path_pdf;
 	float4* prev_pdf;

@@ -326,8 +326,11 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 
 // RenderTileSession::pushSpectralFragment (RenderTileSession.cpp:133-142) + commitSpectrals2
 // (LocalFrameOutputDevice.cpp:88-164): returns the XYZ addend and the feedback bits of one fragment.
+struct PathCie {
+	float x[4], y[4], z[4]; // CIE::eval(wavelength k) of the path's four wavelengths
+};
 __device__ __forceinline__ uint32_t fragment_value(const DevScene& sc, const Blob& mis, const Blob& importance, const Blob& grp_importance,
-												  const Blob& radiance, bool mono, const Blob& grp_wl, float blend, float xyz[3])
+												  const Blob& radiance, bool mono, const PathCie& cie, float blend, float xyz[3])
 {
 	const Blob imp		  = grp_importance * importance;
 	const Blob heroFactor = mono ? hero_only() : blob(1);
@@ -348,12 +351,10 @@ __device__ __forceinline__ uint32_t fragment_value(const DevScene& sc, const Blo
 	if (sc.cfg.spectral_mono) {
 		triplet[0] = triplet[1] = triplet[2] = contrib.v[0];
 	} else {
-		for (int k = 0; k < 4; ++k) {
-			float c[3];
-			cie_eval(sc.cie, grp_wl.v[k], c);
-			triplet[0] += contrib.v[k] * c[0];
-			triplet[1] += contrib.v[k] * c[1];
-			triplet[2] += contrib.v[k] * c[2];
+		for (int k = 0; k < 4; ++k) { // CIE::eval(weight, wavelength), spectral/CIE.h:30-39
+			triplet[0] += contrib.v[k] * cie.x[k];
+			triplet[1] += contrib.v[k] * cie.y[k];
+			triplet[2] += contrib.v[k] * cie.z[k];
 		}
 	}
 	const float w = sc.single_tap ? sc.centre_weight * blend : blend;
@@ -361,6 +362,24 @@ __device__ __forceinline__ uint32_t fragment_value(const DevScene& sc, const Blo
 	xyz[1] = w * triplet[1];
 	xyz[2] = w * triplet[2];
 	return 0;
+}
+// feedback bits of a fragment whose radiance is exactly zero (occluded NEE sample): the product is 0 unless
+// mis * importance is already NaN/Inf, in which case it is NaN (0 * inf) -- no XYZ needs to be formed
+__device__ __forceinline__ uint32_t fragment_feedback_zero(const Blob& mis, const Blob& importance, const Blob& grp_importance, bool mono)
+{
+	const Blob imp		  = grp_importance * importance;
+	const Blob heroFactor = mono ? hero_only() : blob(1);
+	const Blob contrib	  = heroFactor * ((mis * imp) * blob(0));
+	uint32_t fb = 0;
+	for (int k = 0; k < 4; ++k) {
+		if (isnan(contrib.v[k]))
+			fb |= 0x1;
+		if (isinf(contrib.v[k]))
+			fb |= 0x2;
+		if (contrib.v[k] < -PR_EPS)
+			fb |= 0x4;
+	}
+	return fb;
 }
 __device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pixel, uint32_t fb, const float xyz[3])
 {
@@ -497,6 +516,16 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	ps.ray_d[slot]	   = make_float4(d.x, d.y, d.z, cam.far_t);
 	ps.wl[slot]		   = to4(wl);
 	ps.wl_pdf[slot]	   = to4(wl_pdf);
+	{ // the path's wavelengths are fixed: evaluate the CIE response once instead of once per fragment
+		float c0[3], c1[3], c2[3], c3[3];
+		cie_eval(sc.cie, wl.v[0], c0);
+		cie_eval(sc.cie, wl.v[1], c1);
+		cie_eval(sc.cie, wl.v[2], c2);
+		cie_eval(sc.cie, wl.v[3], c3);
+		ps.cie_x[slot] = make_float4(c0[0], c1[0], c2[0], c3[0]);
+		ps.cie_y[slot] = make_float4(c0[1], c1[1], c2[1], c3[1]);
+		ps.cie_z[slot] = make_float4(c0[2], c1[2], c2[2], c3[2]);
+	}
 	ps.throughput[slot] = make_float4(1, 1, 1, 1);
 	ps.path_pdf[slot]  = make_float4(1, 1, 1, 1);
 	ps.prev_pdf[slot]  = make_float4(1, 1, 1, 1);
@@ -607,6 +636,13 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 		const bool mono		 = (flags & FLAG_MONO) != 0;
 		const Blob wl		 = from4(ps.wl[slot]);
 		const Blob wvl_pdf	 = from4(ps.wl_pdf[slot]);
+		PathCie cie;
+		{
+			const float4 cx = ps.cie_x[slot], cy = ps.cie_y[slot], cz = ps.cie_z[slot];
+			cie.x[0] = cx.x; cie.x[1] = cx.y; cie.x[2] = cx.z; cie.x[3] = cx.w;
+			cie.y[0] = cy.x; cie.y[1] = cy.y; cie.y[2] = cy.z; cie.y[3] = cy.w;
+			cie.z[0] = cz.x; cie.z[1] = cz.y; cie.z[2] = cz.z; cie.z[3] = cz.w;
+		}
 		Blob throughput		 = from4(ps.throughput[slot]);
 		Blob path_pdf		 = from4(ps.path_pdf[slot]);
 		Blob prev_pdf		 = from4(ps.prev_pdf[slot]);
@@ -625,9 +661,9 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 			uint32_t fb;
 			if (depth == 0) {
 				atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
-				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, wl, blend, xyz);
+				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
 			} else {
-				fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, blob(0), mono, wl, blend, xyz);
+				fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, blob(0), mono, cie, blend, xyz);
 			}
 			apply_fragment(ps, pixel, fb, xyz);
 		} else {
@@ -654,7 +690,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 					float xyz[3];
 					uint32_t fb;
 					if (!cfg.nee || behind || (flags & FLAG_LAST_DELTA)) {
-						fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, radiance, mono, wl, blend, xyz);
+						fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, radiance, mono, cie, blend, xyz);
 					} else {
 						const uint32_t lid	 = sc.entities[gp.entity].light_id;
 						const float selProb	 = sc.light_cdf[lid + 1] - sc.light_cdf[lid];
@@ -665,7 +701,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 						const float denom	 = bsum(power_mis ? a * a : a) + bsum(power_mis ? path_pdf * path_pdf : path_pdf);
 						const float p0		 = power_mis ? path_pdf.v[0] * path_pdf.v[0] : path_pdf.v[0];
 						const Blob mis		 = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
-						fb					 = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, wl, blend, xyz);
+						fb					 = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
 					}
 					apply_fragment(ps, pixel, fb, xyz);
 				}
@@ -749,9 +785,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 						const float distance = sqrtf(sqrD);
 						const V3 oN			 = dot(L, N) < 0 ? -N : N;
 						const V3 so			 = safe_position(P, L, oN);
-						float xyz_vis[3], xyz_occ[3];
-						const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, wl, blend, xyz_vis);
-						const uint32_t fb_occ = fragment_value(sc, mis, throughput, grp_imp, blob(0), mono, wl, blend, xyz_occ);
+						float xyz_vis[3];
+						const float xyz_occ[3] = { 0.0f, 0.0f, 0.0f };
+						const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, cie, blend, xyz_vis);
+						const uint32_t fb_occ = fragment_feedback_zero(mis, throughput, grp_imp, mono);
 						atomicAdd(&bs.v[PRGPU_STAT_ENTITY_HITS], 1u);
 						if (worth) {
 							atomicAdd(&bs.v[PRGPU_STAT_SHADOW_RAYS], 1u);

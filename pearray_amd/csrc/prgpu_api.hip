@@ -271,6 +271,9 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(ps.ray_d, np, false);
 	AL(ps.wl, np, false);
 	AL(ps.wl_pdf, np, false);
+	AL(ps.cie_x, np, false);
+	AL(ps.cie_y, np, false);
+	AL(ps.cie_z, np, false);
 	AL(ps.throughput, np, false);
 	AL(ps.path_pdf, np, false);
 	AL(ps.prev_pdf, np, false);
