@@ -138,9 +138,21 @@ def main():
         rays_per_launch = rays_counted * 4 / max(n_c, 1)  # same pixels, statistically identical iterations
         avg_ms = ms_c / max(n_c, 1)
         achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
+        # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure comes
+        # from the committed rocprofv3 --pmc passes of this very command (tools/gpu_profile_r01.sh -> profiles/), with the
+        # gfx950 correction FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM); divided by the live launch duration like `achieved`
+        traffic = traffic_bytes = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_v3_pmc_summary.json")) as f:
+                k = json.load(f)["kernels"]["prd::k_trace_closest<false>"]
+            traffic_bytes = (2.0 * k["FETCH_SIZE_per_launch"] + k["WRITE_SIZE_per_launch"]) * 1024.0
+            traffic = round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1)
+        except Exception:
+            pass
         if rank == 0:
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "traffic_bytes_per_launch": traffic_bytes, "traffic_source": "profiles/r01_v3_pmc_summary.json",
                                "kernel": "k_trace_closest", "avg_launch_ms": round(avg_ms, 4), "launches": n_c,
                                "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
                                "leaves_per_ray": round(leaves_per_ray, 2), "rays_per_launch": round(rays_per_launch),

@@ -26,7 +26,8 @@ print(ctx.traceCounters())
 xyz, smp, fb = ctx.output()
 print("mean xyz", xyz.reshape(-1, 3).mean(0), "feedback any", int((fb != 0).sum()))
 tc = ctx.traceCounters()
-print("closest: records/ray %.1f, lane utilisation %.3f ; any: records/ray %.1f, lane utilisation %.3f" % (
-    (tc["nodes_closest"] + tc["leaves_closest"]) / (st["primary_rays"] + st["bounce_rays"]) * iters * 1.0 / 1 if False else (tc["nodes_closest"] + tc["leaves_closest"]) / max(1, tc["wave_steps_closest"]) ,
-    (tc["nodes_closest"] + tc["leaves_closest"]) / max(1, 64 * tc["wave_steps_closest"]),
-    (tc["nodes_any"] + tc["leaves_any"]) / max(1, tc["wave_steps_any"]), (tc["nodes_any"] + tc["leaves_any"]) / max(1, 64 * tc["wave_steps_any"])))
+rc = (tc["nodes_closest"] + tc["leaves_closest"]); ra = (tc["nodes_any"] + tc["leaves_any"])
+n_c = (st["primary_rays"] + st["bounce_rays"]) / (iters + 1); n_a = st["shadow_rays"] / (iters + 1)
+print("closest: %.1f inner + %.1f leaf records/ray, lane utilisation per step %.3f ; any: %.1f + %.1f records/ray, utilisation %.3f" % (
+    tc["nodes_closest"] / n_c, tc["leaves_closest"] / n_c, rc / max(1, 64 * tc["wave_steps_closest"]),
+    tc["nodes_any"] / n_a, tc["leaves_any"] / n_a, ra / max(1, 64 * tc["wave_steps_any"])))
