@@ -607,7 +607,248 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 }
 
 // handleCameraVertex / handleDirectHit / handleNEE / handleScattering (direct.cpp:73-412), Walker::traverse
-// (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53)
+// (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53).
+// Processes the path vertex of `slot` whose closest hit is in ps.hit[slot]: adds emission, prepares the NEE shadow ray
+// (returned in sh_*, want_shadow) and the next bounce ray (written to the slot, alive).
+__device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState& ps, uint32_t slot, BlockStats& bs, bool& alive, bool& want_shadow,
+											 float4& sh_o, float4& sh_d, float4& sh_xyz)
+{
+	const prgpu_settings& cfg = sc.cfg;
+	const uint32_t pixel = ps.pixel[slot];
+	const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+	const V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
+	const float4 hit4  = ps.hit[slot];
+	const uint32_t tri = __float_as_uint(hit4.w);
+	uint32_t flags	   = ps.flags[slot];
+	const uint32_t depth = flags & 0xFFu;
+	const bool mono		 = (flags & FLAG_MONO) != 0;
+	const Blob wl		 = from4(ps.wl[slot]);
+	const Blob wvl_pdf	 = from4(ps.wl_pdf[slot]);
+	PathCie cie;
+	{
+		const float4 cx = ps.cie_x[slot], cy = ps.cie_y[slot], cz = ps.cie_z[slot];
+		cie.x[0] = cx.x; cie.x[1] = cx.y; cie.x[2] = cx.z; cie.x[3] = cx.w;
+		cie.y[0] = cy.x; cie.y[1] = cy.y; cie.y[2] = cy.z; cie.y[3] = cy.w;
+		cie.z[0] = cz.x; cie.z[1] = cz.y; cie.z[2] = cz.z; cie.z[3] = cz.w;
+	}
+	Blob throughput		 = from4(ps.throughput[slot]);
+	Blob path_pdf		 = from4(ps.path_pdf[slot]);
+	Blob prev_pdf		 = from4(ps.prev_pdf[slot]);
+	const Blob grp_imp	 = mono ? hero_only() : blob(1.0f); // RenderTile.cpp:126-127
+	const float blend	 = 1.0f;
+	const bool power_mis = cfg.mis == PRGPU_MIS_POWER;
+	const Blob hf		 = mono ? hero_only() : blob(1.0f);
+
+	if (depth == 0) {
+		ps.prim_entity[pixel] = tri == INVALID ? INVALID : sc.tri_entity[tri];
+		ps.prim_prim[pixel]	  = tri == INVALID ? INVALID : tri - sc.entities[sc.tri_entity[tri]].first_tri;
+	}
+	if (tri == INVALID) {
+		atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
+		float xyz[3];
+		uint32_t fb;
+		if (depth == 0) {
+			atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
+			fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
+		} else {
+			fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, blob(0), mono, cie, blend, xyz);
+		}
+		apply_fragment(ps, pixel, fb, xyz);
+	} else {
+		const V3 P = ray_o + ray_d * hit4.x;
+		GeomPoint gp;
+		geometry_point(sc, tri, hit4.y, hit4.z, gp);
+		const V3 N		   = gp.N;
+		const float NdotV  = dot(ray_d, N);
+		const V3 dP		   = ray_o - P;
+		const float depth2 = dot(dP, dP);
+		const uint32_t pathLength = depth + 1;
+		atomicAdd(&bs.v[PRGPU_STAT_ENTITY_HITS], 1u);
+		atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
+		if (pathLength == 1)
+			ps.samples[pixel] += 1;
+		const bool hasEmission = gp.emission != INVALID;
+		bool go_on			   = true;
+		if (cfg.direct && hasEmission) {
+			// ---- handleDirectHit
+			const float cosC = -NdotV;
+			if (!(fabsf(cosC) <= PR_EPS)) {
+				const bool behind	= cosC < 0.0f;
+				const Blob radiance = behind ? blob(0) : spectrum_eval(sc, sc.emissions[gp.emission].radiance, wl);
+				float xyz[3];
+				uint32_t fb;
+				if (!cfg.nee || behind || (flags & FLAG_LAST_DELTA)) {
+					fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, radiance, mono, cie, blend, xyz);
+				} else {
+					const uint32_t lid	 = sc.entities[gp.entity].light_id;
+					const float selProb	 = sc.light_cdf[lid + 1] - sc.light_cdf[lid];
+					float posPDF		 = 1.0f / sc.entities[gp.entity].world_area;
+					posPDF				 = posPDF * depth2 / fabsf(cosC);
+					const float posPDF_S = posPDF * selProb;
+					const Blob a		 = prev_pdf * posPDF_S;
+					const float denom	 = bsum(power_mis ? a * a : a) + bsum(power_mis ? path_pdf * path_pdf : path_pdf);
+					const float p0		 = power_mis ? path_pdf.v[0] * path_pdf.v[0] : path_pdf.v[0];
+					const Blob mis		 = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
+					fb					 = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
+				}
+				apply_fragment(ps, pixel, fb, xyz);
+			}
+			if (!cfg.emissive_scatter)
+				go_on = false;
+		}
+		if (gp.material == INVALID)
+			go_on = false;
+		if (go_on) {
+			const prgpu_material mat = sc.materials[gp.material];
+			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
+			uint64_t rnd			 = ps.rng[pixel];
+			if (cfg.nee && !hasEmission && sc.n_lights) {
+				// ---- handleNEE
+				do {
+					float selPdf;
+					const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + 1, rng_float(rnd), selPdf, nullptr);
+					const uint32_t le  = sc.light_entity[lid];
+					const DevEntity& LE = sc.entities[le];
+					const float u0 = rng_float(rnd), u1 = rng_float(rnd);
+					float k0, k1;
+					const float f0		= modff(u0 * LE.n_tris, &k0);
+					const float f1		= modff(u1 * LE.n_tris, &k1);
+					const uint32_t face = min((uint32_t)k0, LE.n_tris - 1);
+					const uint32_t ltri = LE.first_tri + face;
+					const uint32_t i0 = sc.indices[3 * ltri], i1 = sc.indices[3 * ltri + 1], i2 = sc.indices[3 * ltri + 2];
+					const V3 p0 = load3(sc.positions, i0), p1 = load3(sc.positions, i1), p2 = load3(sc.positions, i2);
+					const V3 ee		  = cross(p1 - p0, p2 - p0);
+					const float area  = 0.5f * sqrtf(dot(ee, ee));
+					const float pdf_a = 1.0f / (LE.n_tris * area * LE.vol_scale);
+					float bu, bv;
+					if (f1 > f0) {
+						const float x = f0 / 2;
+						bu = x;
+						bv = f1 - x;
+					} else {
+						const float y = f1 / 2;
+						bu = f0 - y;
+						bv = y;
+					}
+					const V3 lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
+					GeomPoint lgp;
+					geometry_point(sc, ltri, bu, bv, lgp);
+					const V3 L			 = normalized(lp - P);
+					const float cosLight = fminf(1.0f, fmaxf(-1.0f, -dot(L, lgp.N)));
+					const Blob radiance	 = spectrum_eval(sc, sc.emissions[LE.emission].radiance, wl);
+					const V3 dLP		 = lp - P;
+					const float sqrD	 = dot(dLP, dLP);
+					const float cosC	 = fabsf(dot(L, N));
+					const float cosL	 = fabsf(cosLight);
+					if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
+						break;
+					const V3 Lt		  = to_tangent_space(N, gp.Nx, gp.Ny, L);
+					const bool same	  = signbit(Vt.z) == signbit(Lt.z);
+					const float dt	  = same ? (mat.two_sided ? fabsf(Lt.z) : fmaxf(0.0f, Lt.z)) : 0.0f;
+					const Blob weight = (spectrum_eval(sc, mat.albedo, wl) * dt) * PR_INV_PI_F;
+					const float bsdf_pdf   = dt * PR_INV_PI_F;
+					const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+					if (all_le(bsdfWvlPdfS, PDF_EPS))
+						break;
+					const Blob connectionW = radiance * weight;
+					const bool worth	   = !is_zero(connectionW, PR_EPS);
+					float lightPdfS		   = pdf_a * sqrD / cosL;
+					lightPdfS *= selPdf;
+					if (!is_normal(lightPdfS) || lightPdfS <= PDF_EPS)
+						break;
+					const Blob lightPdfS2 = (blob(1) * lightPdfS) * hf;
+					if (all_le(lightPdfS2, PDF_EPS))
+						break;
+					Blob mis;
+					if (cfg.direct && !(flags & FLAG_LAST_EMISSIVE)) {
+						const float rr		= rr_probability(sc, pathLength);
+						const Blob bsdfPdfS = bsdfWvlPdfS * rr;
+						const Blob a = path_pdf * lightPdfS2, b = path_pdf * bsdfPdfS;
+						const float denom = bsum(power_mis ? a * a : a) + bsum(power_mis ? b * b : b);
+						const float num	  = path_pdf.v[0] * lightPdfS2.v[0];
+						mis				  = blob(power_mis ? num * num : num) / ((hf * denom) * (power_mis ? wvl_pdf * wvl_pdf : wvl_pdf));
+					} else {
+						mis = hf / (wvl_pdf * bsum(hf));
+					}
+					const float distance = sqrtf(sqrD);
+					const V3 oN			 = dot(L, N) < 0 ? -N : N;
+					const V3 so			 = safe_position(P, L, oN);
+					float xyz_vis[3];
+					const float xyz_occ[3] = { 0.0f, 0.0f, 0.0f };
+					const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, cie, blend, xyz_vis);
+					const uint32_t fb_occ = fragment_feedback_zero(mis, throughput, grp_imp, mono);
+					atomicAdd(&bs.v[PRGPU_STAT_ENTITY_HITS], 1u);
+					if (worth) {
+						atomicAdd(&bs.v[PRGPU_STAT_SHADOW_RAYS], 1u);
+						want_shadow = true;
+						sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
+						sh_d		= make_float4(L.x, L.y, L.z, distance);
+						sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8)));
+					} else {
+						apply_fragment(ps, pixel, fb_occ, xyz_occ);
+					}
+				} while (false);
+			}
+			flags = hasEmission ? (flags | FLAG_LAST_EMISSIVE) : (flags & ~FLAG_LAST_EMISSIVE);
+
+			// ---- handleScattering
+			const float scatProb = rr_probability(sc, pathLength);
+			bool cont			 = !(scatProb <= PR_EPS);
+			if (cont && scatProb < 1.0f) {
+				const float rp = rng_float(rnd);
+				if (rp > scatProb)
+					cont = false;
+			}
+			if (cont) {
+				V3 Lt;
+				Blob integral_weight, pdf_s;
+				if (!mat.two_sided && Vt.z < 0.0f) {
+					Lt				= v3(0, 0, 0);
+					integral_weight = blob(0);
+					pdf_s			= blob(0);
+				} else {
+					const float s1 = rng_float(rnd), s2 = rng_float(rnd);
+					Lt				= cos_hemi(s1, s2);
+					integral_weight = spectrum_eval(sc, mat.albedo, wl);
+					pdf_s			= blob(Lt.z * PR_INV_PI_F);
+					if (signbit(Vt.z) != signbit(Lt.z))
+						Lt = -Lt;
+				}
+				const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt));
+				flags &= ~FLAG_LAST_DELTA;
+				prev_pdf = path_pdf;
+				path_pdf = path_pdf * (pdf_s * scatProb);
+				if (all_le(path_pdf, PDF_EPS))
+					cont = false;
+				if (cont) {
+					throughput = throughput * integral_weight;
+					if (is_zero(throughput, PR_EPS))
+						cont = false;
+				}
+				if (cont) {
+					const V3 oN		 = dot(L, N) < 0 ? -N : N;
+					const V3 no		 = safe_position(P, L, oN);
+					const uint32_t nd = depth + 1;
+					if (nd < cfg.max_ray_depth) {
+						alive				= true;
+						ps.ray_o[slot]		= make_float4(no.x, no.y, no.z, BOUNCE_RAY_MIN);
+						ps.ray_d[slot]		= make_float4(L.x, L.y, L.z, INFINITY);
+						ps.throughput[slot] = to4(throughput);
+						ps.path_pdf[slot]	= to4(path_pdf);
+						ps.prev_pdf[slot]	= to4(prev_pdf);
+						ps.flags[slot]		= (flags & ~0xFFu) | nd;
+						atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
+						atomicAdd(&bs.v[PRGPU_STAT_BOUNCE_RAYS], 1u);
+						if (mono)
+							atomicAdd(&bs.v[PRGPU_STAT_MONOCHROME_RAYS], 1u);
+					}
+				}
+			}
+			ps.rng[pixel] = rnd;
+		}
+	}
+}
+
 __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t slot_base, uint32_t n_active,
 											  uint32_t* __restrict__ next_active, uint32_t* __restrict__ counters /* [0]=next, [1]=shadow, [2]=dead */,
 											  uint32_t* __restrict__ dead_list, uint32_t* queue_head_closest, uint32_t* queue_head_shadow,
@@ -619,246 +860,13 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 		*queue_head_closest = 0;
 		*queue_head_shadow	= 0;
 	}
-	const uint32_t i		  = blockIdx.x * blockDim.x + threadIdx.x;
-	const prgpu_settings& cfg = sc.cfg;
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	bool alive = false, want_shadow = false;
 	uint32_t slot = 0;
 	float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
 	if (i < n_active) {
-		slot				 = active ? active[i] : slot_base + i;
-		const uint32_t pixel = ps.pixel[slot];
-		const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
-		const V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
-		const float4 hit4  = ps.hit[slot];
-		const uint32_t tri = __float_as_uint(hit4.w);
-		uint32_t flags	   = ps.flags[slot];
-		const uint32_t depth = flags & 0xFFu;
-		const bool mono		 = (flags & FLAG_MONO) != 0;
-		const Blob wl		 = from4(ps.wl[slot]);
-		const Blob wvl_pdf	 = from4(ps.wl_pdf[slot]);
-		PathCie cie;
-		{
-			const float4 cx = ps.cie_x[slot], cy = ps.cie_y[slot], cz = ps.cie_z[slot];
-			cie.x[0] = cx.x; cie.x[1] = cx.y; cie.x[2] = cx.z; cie.x[3] = cx.w;
-			cie.y[0] = cy.x; cie.y[1] = cy.y; cie.y[2] = cy.z; cie.y[3] = cy.w;
-			cie.z[0] = cz.x; cie.z[1] = cz.y; cie.z[2] = cz.z; cie.z[3] = cz.w;
-		}
-		Blob throughput		 = from4(ps.throughput[slot]);
-		Blob path_pdf		 = from4(ps.path_pdf[slot]);
-		Blob prev_pdf		 = from4(ps.prev_pdf[slot]);
-		const Blob grp_imp	 = mono ? hero_only() : blob(1.0f); // RenderTile.cpp:126-127
-		const float blend	 = 1.0f;
-		const bool power_mis = cfg.mis == PRGPU_MIS_POWER;
-		const Blob hf		 = mono ? hero_only() : blob(1.0f);
-
-		if (depth == 0) {
-			ps.prim_entity[pixel] = tri == INVALID ? INVALID : sc.tri_entity[tri];
-			ps.prim_prim[pixel]	  = tri == INVALID ? INVALID : tri - sc.entities[sc.tri_entity[tri]].first_tri;
-		}
-		if (tri == INVALID) {
-			atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
-			float xyz[3];
-			uint32_t fb;
-			if (depth == 0) {
-				atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
-				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
-			} else {
-				fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, blob(0), mono, cie, blend, xyz);
-			}
-			apply_fragment(ps, pixel, fb, xyz);
-		} else {
-			const V3 P = ray_o + ray_d * hit4.x;
-			GeomPoint gp;
-			geometry_point(sc, tri, hit4.y, hit4.z, gp);
-			const V3 N		   = gp.N;
-			const float NdotV  = dot(ray_d, N);
-			const V3 dP		   = ray_o - P;
-			const float depth2 = dot(dP, dP);
-			const uint32_t pathLength = depth + 1;
-			atomicAdd(&bs.v[PRGPU_STAT_ENTITY_HITS], 1u);
-			atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
-			if (pathLength == 1)
-				ps.samples[pixel] += 1;
-			const bool hasEmission = gp.emission != INVALID;
-			bool go_on			   = true;
-			if (cfg.direct && hasEmission) {
-				// ---- handleDirectHit
-				const float cosC = -NdotV;
-				if (!(fabsf(cosC) <= PR_EPS)) {
-					const bool behind	= cosC < 0.0f;
-					const Blob radiance = behind ? blob(0) : spectrum_eval(sc, sc.emissions[gp.emission].radiance, wl);
-					float xyz[3];
-					uint32_t fb;
-					if (!cfg.nee || behind || (flags & FLAG_LAST_DELTA)) {
-						fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, radiance, mono, cie, blend, xyz);
-					} else {
-						const uint32_t lid	 = sc.entities[gp.entity].light_id;
-						const float selProb	 = sc.light_cdf[lid + 1] - sc.light_cdf[lid];
-						float posPDF		 = 1.0f / sc.entities[gp.entity].world_area;
-						posPDF				 = posPDF * depth2 / fabsf(cosC);
-						const float posPDF_S = posPDF * selProb;
-						const Blob a		 = prev_pdf * posPDF_S;
-						const float denom	 = bsum(power_mis ? a * a : a) + bsum(power_mis ? path_pdf * path_pdf : path_pdf);
-						const float p0		 = power_mis ? path_pdf.v[0] * path_pdf.v[0] : path_pdf.v[0];
-						const Blob mis		 = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
-						fb					 = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
-					}
-					apply_fragment(ps, pixel, fb, xyz);
-				}
-				if (!cfg.emissive_scatter)
-					go_on = false;
-			}
-			if (gp.material == INVALID)
-				go_on = false;
-			if (go_on) {
-				const prgpu_material mat = sc.materials[gp.material];
-				const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
-				uint64_t rnd			 = ps.rng[pixel];
-				if (cfg.nee && !hasEmission && sc.n_lights) {
-					// ---- handleNEE
-					do {
-						float selPdf;
-						const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + 1, rng_float(rnd), selPdf, nullptr);
-						const uint32_t le  = sc.light_entity[lid];
-						const DevEntity& LE = sc.entities[le];
-						const float u0 = rng_float(rnd), u1 = rng_float(rnd);
-						float k0, k1;
-						const float f0		= modff(u0 * LE.n_tris, &k0);
-						const float f1		= modff(u1 * LE.n_tris, &k1);
-						const uint32_t face = min((uint32_t)k0, LE.n_tris - 1);
-						const uint32_t ltri = LE.first_tri + face;
-						const uint32_t i0 = sc.indices[3 * ltri], i1 = sc.indices[3 * ltri + 1], i2 = sc.indices[3 * ltri + 2];
-						const V3 p0 = load3(sc.positions, i0), p1 = load3(sc.positions, i1), p2 = load3(sc.positions, i2);
-						const V3 ee		  = cross(p1 - p0, p2 - p0);
-						const float area  = 0.5f * sqrtf(dot(ee, ee));
-						const float pdf_a = 1.0f / (LE.n_tris * area * LE.vol_scale);
-						float bu, bv;
-						if (f1 > f0) {
-							const float x = f0 / 2;
-							bu = x;
-							bv = f1 - x;
-						} else {
-							const float y = f1 / 2;
-							bu = f0 - y;
-							bv = y;
-						}
-						const V3 lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
-						GeomPoint lgp;
-						geometry_point(sc, ltri, bu, bv, lgp);
-						const V3 L			 = normalized(lp - P);
-						const float cosLight = fminf(1.0f, fmaxf(-1.0f, -dot(L, lgp.N)));
-						const Blob radiance	 = spectrum_eval(sc, sc.emissions[LE.emission].radiance, wl);
-						const V3 dLP		 = lp - P;
-						const float sqrD	 = dot(dLP, dLP);
-						const float cosC	 = fabsf(dot(L, N));
-						const float cosL	 = fabsf(cosLight);
-						if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
-							break;
-						const V3 Lt		  = to_tangent_space(N, gp.Nx, gp.Ny, L);
-						const bool same	  = signbit(Vt.z) == signbit(Lt.z);
-						const float dt	  = same ? (mat.two_sided ? fabsf(Lt.z) : fmaxf(0.0f, Lt.z)) : 0.0f;
-						const Blob weight = (spectrum_eval(sc, mat.albedo, wl) * dt) * PR_INV_PI_F;
-						const float bsdf_pdf   = dt * PR_INV_PI_F;
-						const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
-						if (all_le(bsdfWvlPdfS, PDF_EPS))
-							break;
-						const Blob connectionW = radiance * weight;
-						const bool worth	   = !is_zero(connectionW, PR_EPS);
-						float lightPdfS		   = pdf_a * sqrD / cosL;
-						lightPdfS *= selPdf;
-						if (!is_normal(lightPdfS) || lightPdfS <= PDF_EPS)
-							break;
-						const Blob lightPdfS2 = (blob(1) * lightPdfS) * hf;
-						if (all_le(lightPdfS2, PDF_EPS))
-							break;
-						Blob mis;
-						if (cfg.direct && !(flags & FLAG_LAST_EMISSIVE)) {
-							const float rr		= rr_probability(sc, pathLength);
-							const Blob bsdfPdfS = bsdfWvlPdfS * rr;
-							const Blob a = path_pdf * lightPdfS2, b = path_pdf * bsdfPdfS;
-							const float denom = bsum(power_mis ? a * a : a) + bsum(power_mis ? b * b : b);
-							const float num	  = path_pdf.v[0] * lightPdfS2.v[0];
-							mis				  = blob(power_mis ? num * num : num) / ((hf * denom) * (power_mis ? wvl_pdf * wvl_pdf : wvl_pdf));
-						} else {
-							mis = hf / (wvl_pdf * bsum(hf));
-						}
-						const float distance = sqrtf(sqrD);
-						const V3 oN			 = dot(L, N) < 0 ? -N : N;
-						const V3 so			 = safe_position(P, L, oN);
-						float xyz_vis[3];
-						const float xyz_occ[3] = { 0.0f, 0.0f, 0.0f };
-						const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, cie, blend, xyz_vis);
-						const uint32_t fb_occ = fragment_feedback_zero(mis, throughput, grp_imp, mono);
-						atomicAdd(&bs.v[PRGPU_STAT_ENTITY_HITS], 1u);
-						if (worth) {
-							atomicAdd(&bs.v[PRGPU_STAT_SHADOW_RAYS], 1u);
-							want_shadow = true;
-							sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
-							sh_d		= make_float4(L.x, L.y, L.z, distance);
-							sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8)));
-						} else {
-							apply_fragment(ps, pixel, fb_occ, xyz_occ);
-						}
-					} while (false);
-				}
-				flags = hasEmission ? (flags | FLAG_LAST_EMISSIVE) : (flags & ~FLAG_LAST_EMISSIVE);
-
-				// ---- handleScattering
-				const float scatProb = rr_probability(sc, pathLength);
-				bool cont			 = !(scatProb <= PR_EPS);
-				if (cont && scatProb < 1.0f) {
-					const float rp = rng_float(rnd);
-					if (rp > scatProb)
-						cont = false;
-				}
-				if (cont) {
-					V3 Lt;
-					Blob integral_weight, pdf_s;
-					if (!mat.two_sided && Vt.z < 0.0f) {
-						Lt				= v3(0, 0, 0);
-						integral_weight = blob(0);
-						pdf_s			= blob(0);
-					} else {
-						const float s1 = rng_float(rnd), s2 = rng_float(rnd);
-						Lt				= cos_hemi(s1, s2);
-						integral_weight = spectrum_eval(sc, mat.albedo, wl);
-						pdf_s			= blob(Lt.z * PR_INV_PI_F);
-						if (signbit(Vt.z) != signbit(Lt.z))
-							Lt = -Lt;
-					}
-					const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt));
-					flags &= ~FLAG_LAST_DELTA;
-					prev_pdf = path_pdf;
-					path_pdf = path_pdf * (pdf_s * scatProb);
-					if (all_le(path_pdf, PDF_EPS))
-						cont = false;
-					if (cont) {
-						throughput = throughput * integral_weight;
-						if (is_zero(throughput, PR_EPS))
-							cont = false;
-					}
-					if (cont) {
-						const V3 oN		 = dot(L, N) < 0 ? -N : N;
-						const V3 no		 = safe_position(P, L, oN);
-						const uint32_t nd = depth + 1;
-						if (nd < cfg.max_ray_depth) {
-							alive				= true;
-							ps.ray_o[slot]		= make_float4(no.x, no.y, no.z, BOUNCE_RAY_MIN);
-							ps.ray_d[slot]		= make_float4(L.x, L.y, L.z, INFINITY);
-							ps.throughput[slot] = to4(throughput);
-							ps.path_pdf[slot]	= to4(path_pdf);
-							ps.prev_pdf[slot]	= to4(prev_pdf);
-							ps.flags[slot]		= (flags & ~0xFFu) | nd;
-							atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
-							atomicAdd(&bs.v[PRGPU_STAT_BOUNCE_RAYS], 1u);
-							if (mono)
-								atomicAdd(&bs.v[PRGPU_STAT_MONOCHROME_RAYS], 1u);
-						}
-					}
-				}
-				ps.rng[pixel] = rnd;
-			}
-		}
+		slot = active ? active[i] : slot_base + i;
+		shade_vertex(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 	}
 	// ballot/prefix-scan compaction of survivors, finished paths and of the shadow queue
 	const uint32_t pos_next = wave_append(alive, &counters[0]);
