@@ -30,6 +30,15 @@ void launch_regen(const DevScene& sc, const PathState& ps, const uint32_t* dead,
 				  uint32_t* counters, unsigned long long* gstats, hipStream_t st);
 void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t n_items, bool count, const TraceWorkspace& ws, unsigned long long* gstats,
 						 hipStream_t st);
+// Persistent path kernel (single-tap filters): the whole render call [iter_begin, iter_end) of the `n_owned` pixels of `owned`
+// in one launch.  ps.pixel must be a per-slot scratch array (NOT the owned list) of n_blocks * slots_per_block entries.
+struct PersistentGeometry {
+	uint32_t n_blocks, slots_per_block;
+};
+PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks);
+uint32_t persistent_slot_padding(); // per-slot arrays need n_pixels + this many entries
+void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
+							bool count, const TraceWorkspace& ws, uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st);
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st);
 void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
 							uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, unsigned long long* gstats,

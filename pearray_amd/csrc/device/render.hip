@@ -70,7 +70,11 @@ struct Trav {
 	float tmin;
 	Hit best;	  // closest: running best (t starts at tmax); any: t = tmax, tri != INVALID once occluded
 	uint32_t cur; // current record ref, REC_EMPTY when the ray is finished
+	bool any;	  // MODE_MIXED only: this lane's ray is an occlusion ray
 };
+
+// traversal flavour: closest hit, occlusion (any hit), or a per-lane mix of both in one wave (persistent path kernel)
+enum { MODE_CLOSEST = 0, MODE_ANY = 1, MODE_MIXED = 2 };
 
 __device__ __forceinline__ void trav_begin(Trav& s, Stack& st, V3 o, V3 d, float tmin, float tmax, float eps_t)
 {
@@ -78,6 +82,7 @@ __device__ __forceinline__ void trav_begin(Trav& s, Stack& st, V3 o, V3 d, float
 	s.tmin = tmin;
 	s.best = Hit{ tmax, 0.0f, 0.0f, INVALID };
 	s.cur  = 0u; // root
+	s.any  = false;
 	st.reset();
 }
 
@@ -89,19 +94,20 @@ __device__ __forceinline__ bool child_hit(const RayPre& r, float lox, float loy,
 }
 
 // next record after the current one is used up: the closest stack entry that can still matter
-template <bool ANY>
+template <int M>
 __device__ __forceinline__ void trav_pop(Trav& s, Stack& st)
 {
 	while (s.cur == REC_EMPTY && st.sp > 0) {
 		const uint2 e = st.pop();
-		if (ANY || still_reachable(s.r, __uint_as_float(e.y), s.best.t))
+		if (M == MODE_ANY || still_reachable(s.r, __uint_as_float(e.y), s.best.t))
 			s.cur = e.x;
 	}
 }
 
 // Inner step: fetch the 4-wide node (112 of its 128 bytes), test the four child boxes, continue with the nearest
-// hit child and push the others far-to-near.  ANY: order does not matter, children are pushed unsorted.
-template <bool ANY>
+// hit child and push the others far-to-near.  MODE_ANY: order does not matter, children are pushed unsorted (in
+// MODE_MIXED occlusion lanes share the sorted code of the closest-hit lanes; occlusion is order independent).
+template <int M>
 __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& st)
 {
 	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + s.cur);
@@ -118,7 +124,7 @@ __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& s
 		t[k] = h[k] ? t[k] : INFINITY;
 		c[k] = h[k] ? c[k] : REC_EMPTY;
 	}
-	if (!ANY || ANY_SORTED) {
+	if (M != MODE_ANY || ANY_SORTED) {
 		// sort the four (t, ref) pairs ascending: 5-comparator network (misses carry t = +inf and sort last)
 #define PR_CSWAP(a, b)                                          \
 	{                                                           \
@@ -146,13 +152,14 @@ __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& s
 	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
 	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
 	s.cur = c[0];
-	trav_pop<ANY>(s, st);
+	trav_pop<M>(s, st);
 }
 
 // Leaf step: fetch the leaf record (<= 3 triangles) and run the watertight test on each.
-template <bool ANY>
+template <int M>
 __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& s, Stack& st)
 {
+	const bool ANY = M == MODE_ANY || (M == MODE_MIXED && s.any);
 	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
 	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
 	const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
@@ -180,7 +187,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& s, Stack& st
 		st.reset();
 		return;
 	}
-	trav_pop<ANY>(s, st);
+	trav_pop<M>(s, st);
 }
 
 // Persistent traversal loop shared by the four tracing kernels.  `load(i, o, d, tmin, tmax)` reads ray i,
@@ -959,6 +966,320 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 // clears the per-iteration plane of the pixels a path wrote (owned pixels are re-zeroed by raygen; this
 // covers nothing else, the plane is zero-initialised once) -- kept for symmetry with mCopySpectral->clear.
 
+// ---- persistent path kernel -----------------------------------------------------------------------------------
+// The whole render call as ONE launch (single-tap pixel filters).  Every block owns `slots_per_block` path slots and two
+// ring queues in LDS -- rays to trace (closest and occlusion rays mixed) and vertices to shade -- and its four waves
+// switch between the two jobs: refill idle lanes from the ray queue and walk the BVH; whenever 64 vertices are waiting
+// (or nothing else is left to do) pop a wave-full of them and shade.  A vertex's NEE shadow ray and its bounce ray are
+// traced concurrently; the per-slot `pending` word counts them down and the ray that finishes last queues the next
+// shade, so fragments land in the reference order (NEE of vertex k before the emission of vertex k+1).  A path that ends
+// folds its pixel's sample into the running mean (FrameOutputDevice.cpp:202-221) and starts the pixel's next sample; once
+// the pixel has all its samples the slot takes the next unrendered pixel from a global counter.  There is no grid-wide
+// barrier, no host round trip and no drain phase between path vertices; blocks never wait for each other, waves only
+// ever wait for waves of their own block (which are resident by construction).
+constexpr int PP_SLOTS_MAX		= 1024;
+constexpr uint32_t PP_EMPTY		= 0xFFFFFFFFu;
+constexpr uint32_t PP_ANY		= 0x80000000u; // ray entry: the slot's shadow ray (else its path ray)
+constexpr uint32_t PP_REGEN		= 0x80000000u; // shade entry: the slot's path has ended (else: shade the vertex at ps.hit)
+constexpr uint32_t PP_DEAD		= 0x100u;	   // pending word: no bounce ray follows the rays in flight
+constexpr uint32_t PP_SPIN_LIMIT = 1u << 24;   // safety net: an idle wave gives up (and flags an error) after this many polls
+
+struct PPShared {
+	uint2 stack[STACK_LDS * TRAV_BLOCK];
+	uint32_t q_ray[2 * PP_SLOTS_MAX]; // a slot has at most two rays queued or in flight
+	uint32_t q_shade[PP_SLOTS_MAX];
+	uint32_t pending[PP_SLOTS_MAX];
+	uint32_t ray_head, ray_tail, shade_head, shade_tail;
+	uint32_t live; // slots that still own, or may still acquire, a pixel
+	uint32_t error;
+	BlockStats bs;
+};
+
+__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t wave_bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// append the value of every lane with `pred` to a ring queue: one LDS atomic per wave; the entry becomes visible to the
+// poppers when it is written (release: the slot's state in global memory is visible before the entry is)
+__device__ __forceinline__ void ring_push(uint32_t* q, uint32_t cap_mask, uint32_t* tail, bool pred, uint32_t value)
+{
+	const unsigned long long mask = __ballot(pred);
+	if (mask == 0ull)
+		return;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t base		= 0;
+	const int leader	= __ffsll((long long)mask) - 1;
+	if ((int)lane == leader)
+		base = __hip_atomic_fetch_add(tail, (uint32_t)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	base = __shfl(base, leader, 64);
+	if (pred)
+		__hip_atomic_store(&q[(base + __popcll(mask & ((1ull << lane) - 1ull))) & cap_mask], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// claim up to `want` entries; returns how many (wave-uniform) and the ring position of the first one
+__device__ __forceinline__ uint32_t ring_claim(uint32_t* head, const uint32_t* tail, uint32_t want, uint32_t& first)
+{
+	uint32_t n = 0, h = 0;
+	if ((threadIdx.x & 63u) == 0) {
+		h				 = lds_load(head);
+		const uint32_t t = lds_load(tail);
+		n				 = min(want, t - h);
+		if (n) {
+			uint32_t expect = h;
+			if (!__hip_atomic_compare_exchange_strong(head, &expect, h + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+				n = 0; // another wave was faster; the caller comes back
+		}
+	}
+	first = wave_bcast0(h);
+	return wave_bcast0(n);
+}
+// read (and clear) a claimed entry; its pusher has reserved the position and writes it within a few cycles
+__device__ __forceinline__ uint32_t ring_take(uint32_t* q, uint32_t cap_mask, uint32_t pos)
+{
+	uint32_t* e = &q[pos & cap_mask];
+	uint32_t v;
+	while ((v = __hip_atomic_load(e, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == PP_EMPTY)
+		__builtin_amdgcn_s_sleep(1);
+	__hip_atomic_store(e, PP_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	return v;
+}
+
+struct PersistentArgs {
+	const uint32_t* owned; // Morton-ordered list of the pixels this device renders
+	uint32_t n_owned;
+	uint32_t* next_pixel; // hand-out counter into `owned` (zeroed before the launch)
+	uint32_t* error;	  // set when a wave gave up waiting (a lost queue entry: bug)
+	uint32_t slots_per_block;
+	uint32_t iter_begin, iter_end;
+	uint2* spill;
+	int refill_below;
+	unsigned long long* gstats;
+};
+
+template <bool COUNT>
+__global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, PathState ps, PersistentArgs a)
+{
+	__shared__ PPShared sh;
+	constexpr uint32_t RAY_MASK = 2 * PP_SLOTS_MAX - 1, SHADE_MASK = PP_SLOTS_MAX - 1;
+	const uint32_t lane	 = threadIdx.x & 63u;
+	const uint32_t slot0 = blockIdx.x * a.slots_per_block;
+	for (uint32_t i = threadIdx.x; i < 2 * PP_SLOTS_MAX; i += TRAV_BLOCK)
+		sh.q_ray[i] = PP_EMPTY;
+	for (uint32_t i = threadIdx.x; i < PP_SLOTS_MAX; i += TRAV_BLOCK) {
+		sh.q_shade[i] = i < a.slots_per_block ? (i | PP_REGEN) : PP_EMPTY; // every slot starts by acquiring a pixel
+		sh.pending[i] = 0;
+		if (i < a.slots_per_block)
+			ps.pixel[slot0 + i] = INVALID;
+	}
+	if (threadIdx.x == 0) {
+		sh.ray_head = sh.ray_tail = 0;
+		sh.shade_head			  = 0;
+		sh.shade_tail			  = a.slots_per_block;
+		sh.live					  = a.slots_per_block;
+		sh.error				  = 0;
+	}
+	stats_init(sh.bs);
+	__syncthreads();
+
+	Stack st;
+	st.lds			= sh.stack + threadIdx.x;
+	st.spill_stride = gridDim.x * TRAV_BLOCK;
+	st.spill		= a.spill + (blockIdx.x * TRAV_BLOCK + threadIdx.x);
+	st.reset();
+	Trav s;
+	s.cur			  = REC_EMPTY;
+	s.any			  = false;
+	bool has_ray	  = false;
+	uint32_t my_entry = 0;
+	uint32_t spins	  = 0;
+	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0;
+
+	for (;;) {
+		const int n_act	  = __popcll(__ballot(has_ray));
+		uint32_t n_shade  = wave_bcast0(lds_load(&sh.shade_tail) - lds_load(&sh.shade_head));
+		uint32_t n_queued = wave_bcast0(lds_load(&sh.ray_tail) - lds_load(&sh.ray_head));
+
+		// ---- shade: a full wave of waiting vertices, or whatever is there when this wave is short of rays anyway
+		if (n_shade >= 64u || (n_shade > 0u && n_queued == 0u && n_act < a.refill_below)) {
+			uint32_t first;
+			const uint32_t n = ring_claim(&sh.shade_head, &sh.shade_tail, 64u, first);
+			if (n) {
+				spins			  = 0;
+				const bool mine	  = lane < n;
+				uint32_t slot_l	  = 0;
+				bool regen		  = false;
+				if (mine) {
+					const uint32_t e = ring_take(sh.q_shade, SHADE_MASK, first + lane);
+					slot_l			 = e & ~PP_REGEN;
+					regen			 = (e & PP_REGEN) != 0;
+				}
+				const uint32_t slot = slot0 + slot_l;
+				bool alive = false, want_shadow = false;
+				float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
+				if (mine && !regen)
+					shade_vertex(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+				// the path ended: fold the sample, then the pixel's next sample or the next pixel
+				const bool ended = mine && (regen || (!alive && !want_shadow));
+				bool need_pixel	 = false;
+				uint32_t iter	 = 0;
+				if (ended) {
+					const uint32_t pixel = ps.pixel[slot];
+					need_pixel			 = true;
+					if (pixel != INVALID) {
+						iter		   = ps.iter[slot];
+						const float it = (float)(iter + 1), itm1 = (float)iter;
+						for (int c = 0; c < 3; ++c)
+							ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + ps.iter_xyz[3 * pixel + c]) / it;
+						if (iter + 1 < a.iter_end) {
+							need_pixel = false;
+							iter	   = iter + 1;
+						}
+					}
+				}
+				bool retired = false;
+				{
+					const uint32_t idx = wave_append(need_pixel, a.next_pixel); // 64 neighbouring pixels per wave-full
+					if (need_pixel) {
+						if (idx < a.n_owned) {
+							ps.pixel[slot] = a.owned[idx];
+							iter		   = a.iter_begin;
+						} else {
+							retired = true;
+						}
+					}
+				}
+				if (ended && !retired) {
+					ps.iter[slot] = iter;
+					camera_path(sc, ps, slot, iter, sh.bs);
+					alive = true;
+				}
+				const int n_retired = __popcll(__ballot(retired));
+				if (n_retired && lane == 0)
+					__hip_atomic_fetch_sub(&sh.live, (uint32_t)n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (mine && !retired) {
+					if (want_shadow) {
+						ps.sh_o[slot]	= sh_o;
+						ps.sh_d[slot]	= sh_d;
+						ps.sh_xyz[slot] = sh_xyz;
+					}
+					__hip_atomic_store(&sh.pending[slot_l], (alive ? 1u : 0u) + (want_shadow ? 1u : 0u) + (alive ? 0u : PP_DEAD), __ATOMIC_RELAXED,
+									   __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+				ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY);
+				ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, alive, slot_l);
+			}
+			continue;
+		}
+
+		// ---- trace: hand queued rays to the idle lanes
+		const unsigned long long idle = __ballot(!has_ray);
+		if (idle != 0ull && n_queued > 0u) {
+			uint32_t first;
+			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(idle), first);
+			const uint32_t r = __popcll(idle & ((1ull << lane) - 1ull));
+			if (!has_ray && r < n) {
+				my_entry			= ring_take(sh.q_ray, RAY_MASK, first + r);
+				const uint32_t slot = slot0 + (my_entry & ~PP_ANY);
+				const bool any		= (my_entry & PP_ANY) != 0;
+				const float4 ro = any ? ps.sh_o[slot] : ps.ray_o[slot], rd = any ? ps.sh_d[slot] : ps.ray_d[slot];
+				trav_begin(s, st, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, any ? rd.w - 0.001f : rd.w, sc.eps_t); // tfar rule: Scene.cpp:275
+				s.any	= any;
+				has_ray = true;
+			}
+		}
+		if (!__any(has_ray)) {
+			// nothing to trace and not enough to shade: other waves of the block hold the work, or the block is done
+			if (lds_load(&sh.live) == 0u || lds_load(&sh.error) != 0u)
+				break;
+			if (n_shade == 0u && n_queued == 0u) {
+				__builtin_amdgcn_s_sleep(8);
+				if (++spins > PP_SPIN_LIMIT) {
+					if (lane == 0) {
+						__hip_atomic_store(&sh.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						atomicExch(a.error, 1u);
+					}
+					break;
+				}
+			}
+			continue;
+		}
+		spins = 0;
+		for (;;) {
+			// one kind of record per wave step (see trace_persistent)
+			const bool at_leaf	= has_ray && (s.cur & REC_LEAF_BIT) != 0;
+			const bool at_inner = has_ray && !at_leaf;
+			const int n_leaf	= __popcll(__ballot(at_leaf));
+			const int n_inner	= __popcll(__ballot(at_inner));
+			if (COUNT && lane == 0)
+				++witers;
+			if (n_inner >= n_leaf) {
+				if (at_inner) {
+					if (COUNT) {
+						cn_c += s.any ? 0 : 1;
+						cn_a += s.any ? 1 : 0;
+					}
+					trav_inner<MODE_MIXED>(sc, s, st);
+				}
+			} else if (at_leaf) {
+				if (COUNT) {
+					cl_c += s.any ? 0 : 1;
+					cl_a += s.any ? 1 : 0;
+				}
+				trav_leaf<MODE_MIXED>(sc, s, st);
+			}
+			const bool fin = has_ray && s.cur == REC_EMPTY;
+			if (__any(fin)) {
+				bool last	   = false;
+				uint32_t entry = 0;
+				if (fin) {
+					const uint32_t slot_l = my_entry & ~PP_ANY;
+					const uint32_t slot	  = slot0 + slot_l;
+					if (s.any) { // the pending NEE fragment (direct.cpp:329-351)
+						const float4 x		 = ps.sh_xyz[slot];
+						const uint32_t fbs	 = __float_as_uint(x.w);
+						const uint32_t pixel = ps.pixel[slot];
+						if (s.best.tri != INVALID) {
+							const uint32_t fb = (fbs >> 8) & 0xFFu;
+							if (fb)
+								ps.feedback[pixel] |= fb;
+						} else {
+							const float xyz[3] = { x.x, x.y, x.z };
+							apply_fragment(ps, pixel, fbs & 0xFFu, xyz);
+						}
+					} else {
+						ps.hit[slot] = make_float4(s.best.t, s.best.u, s.best.v, __uint_as_float(s.best.tri));
+					}
+					// release: the hit / fragment is visible to the wave that shades the slot next
+					const uint32_t old = __hip_atomic_fetch_sub(&sh.pending[slot_l], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+					last			   = (old & 0xFFu) == 1u;
+					entry			   = slot_l | ((old & PP_DEAD) ? PP_REGEN : 0u);
+					has_ray			   = false;
+				}
+				ring_push(sh.q_shade, SHADE_MASK, &sh.shade_tail, last, entry);
+			}
+			const int active = __popcll(__ballot(has_ray));
+			if (active == 0)
+				break;
+			if (active < a.refill_below) { // under-occupied: leave if there is anything to refill from or to shade
+				const uint32_t work = wave_bcast0((lds_load(&sh.ray_tail) - lds_load(&sh.ray_head)) | (lds_load(&sh.shade_tail) - lds_load(&sh.shade_head)));
+				if (work)
+					break;
+			}
+		}
+	}
+	if (COUNT) {
+		if (cn_c)
+			atomicAdd(&a.gstats[CNT_NODES_CLOSEST], (unsigned long long)cn_c);
+		if (cl_c)
+			atomicAdd(&a.gstats[CNT_TRIS_CLOSEST], (unsigned long long)cl_c);
+		if (cn_a)
+			atomicAdd(&a.gstats[CNT_NODES_ANY], (unsigned long long)cn_a);
+		if (cl_a)
+			atomicAdd(&a.gstats[CNT_TRIS_ANY], (unsigned long long)cl_a);
+		if (witers)
+			atomicAdd(&a.gstats[CNT_WAVE_ITERS_CLOSEST], (unsigned long long)witers);
+	}
+	stats_flush(sh.bs, a.gstats);
+}
+
 // ---- ray service kernels (IArchive surface) ------------------------------------------------------------
 __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
 															   const float* __restrict__ tmin_a, const float* __restrict__ tmax_a, uint32_t* entity,
@@ -1056,6 +1377,38 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
 	hipLaunchKernelGGL(k_service_any, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, distance, occluded, ws.queue_head, ws.spill,
 					   ws.refill_below, gstats);
+}
+
+PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks)
+{
+	PersistentGeometry g;
+	const uint32_t per_block = (n_owned + max_blocks - 1) / std::max(1u, max_blocks);
+	g.slots_per_block		 = std::min((uint32_t)PP_SLOTS_MAX, std::max(256u, (per_block + 63u) / 64u * 64u));
+	g.n_blocks				 = std::max(1u, std::min(max_blocks, (n_owned + g.slots_per_block - 1) / g.slots_per_block));
+	return g;
+}
+uint32_t persistent_slot_padding() { return PP_SLOTS_MAX; }
+
+void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
+							bool count, const TraceWorkspace& ws, uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st)
+{
+	const PersistentGeometry g = persistent_geometry(n_owned, ws.max_blocks);
+	PersistentArgs a;
+	a.owned			  = owned;
+	a.n_owned		  = n_owned;
+	a.next_pixel	  = next_pixel;
+	a.error			  = error;
+	a.slots_per_block = g.slots_per_block;
+	a.iter_begin	  = iter_begin;
+	a.iter_end		  = iter_end;
+	a.spill			  = ws.spill;
+	a.refill_below	  = ws.refill_below;
+	a.gstats		  = gstats;
+	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
+	if (count)
+		hipLaunchKernelGGL(k_path_persistent<true>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
+	else
+		hipLaunchKernelGGL(k_path_persistent<false>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
 }
 
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * TRAV_BLOCK * STACK_SPILL; }

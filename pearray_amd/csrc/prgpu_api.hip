@@ -39,8 +39,8 @@ struct TimedLaunch {
 	hipEvent_t start, stop;
 	int family;
 };
-const char* const FAMILY_NAMES[] = { "raygen", "trace_closest", "shade", "trace_any", "resolve", "sort" };
-constexpr int N_FAMILIES		 = 6;
+const char* const FAMILY_NAMES[] = { "raygen", "trace_closest", "shade", "trace_any", "resolve", "sort", "path" };
+constexpr int N_FAMILIES		 = 7;
 
 } // namespace
 
@@ -56,7 +56,12 @@ struct prgpu_scene {
 	float* own_xyz = nullptr;
 	uint32_t *own_samples = nullptr, *own_feedback = nullptr;
 	uint32_t *active_a = nullptr, *active_b = nullptr, *dead_a = nullptr, *dead_b = nullptr;
-	bool lockstep = false; // iteration-synchronous pipeline (needed for multi-tap pixel filters; PRGPU_LOCKSTEP=1 forces it)
+	// LOCKSTEP: iteration-synchronous wavefront (any pixel filter).  STREAMING: wavefront whose pixels advance through their
+	// samples independently.  PERSISTENT: the whole render call as one launch of the persistent path kernel.  The last two need a
+	// single-tap pixel filter (the reference default); all three produce identical images.
+	enum Mode { LOCKSTEP, STREAMING, PERSISTENT };
+	Mode mode = LOCKSTEP;
+	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
 	prd::TraceWorkspace ws; // workspace of the ray-service launches
 	// Pixel groups: contiguous ranges of the Morton-ordered slot list, each running its own wavefront pipeline on
@@ -264,25 +269,26 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		if (rc != PRGPU_OK)                       \
 			return rc;                            \
 	} while (0)
+	const size_t ns = size_t(np) + prd::persistent_slot_padding(); // per-slot arrays: the persistent kernel rounds its slot count up
 	AL(ps.rng, np, false);
 	HIP_TRY(hipMemcpyAsync(ps.rng, t.rng.data(), size_t(np) * 8, hipMemcpyHostToDevice, s->stream));
 	AL(ps.pixel, np, false);
-	AL(ps.ray_o, np, false);
-	AL(ps.ray_d, np, false);
-	AL(ps.wl, np, false);
-	AL(ps.wl_pdf, np, false);
-	AL(ps.cie_x, np, false);
-	AL(ps.cie_y, np, false);
-	AL(ps.cie_z, np, false);
-	AL(ps.throughput, np, false);
-	AL(ps.path_pdf, np, false);
-	AL(ps.prev_pdf, np, false);
-	AL(ps.flags, np, false);
-	AL(ps.hit, np, false);
-	AL(ps.sh_o, np, false);
-	AL(ps.sh_d, np, false);
-	AL(ps.sh_xyz, np, false);
-	AL(ps.sh_slot, np, false);
+	AL(ps.ray_o, ns, false);
+	AL(ps.ray_d, ns, false);
+	AL(ps.wl, ns, false);
+	AL(ps.wl_pdf, ns, false);
+	AL(ps.cie_x, ns, false);
+	AL(ps.cie_y, ns, false);
+	AL(ps.cie_z, ns, false);
+	AL(ps.throughput, ns, false);
+	AL(ps.path_pdf, ns, false);
+	AL(ps.prev_pdf, ns, false);
+	AL(ps.flags, ns, false);
+	AL(ps.hit, ns, false);
+	AL(ps.sh_o, ns, false);
+	AL(ps.sh_d, ns, false);
+	AL(ps.sh_xyz, ns, false);
+	AL(ps.sh_slot, ns, false);
 	AL(ps.iter_xyz, size_t(np) * 3, true);
 	AL(s->own_xyz, size_t(np) * 3, true);
 	AL(s->own_samples, np, true);
@@ -298,11 +304,28 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(s->active_b, np, false);
 	AL(s->dead_a, np, false);
 	AL(s->dead_b, np, false);
-	AL(ps.iter, np, true);
+	AL(ps.iter, ns, true);
 	// streaming (pixels advance through their samples independently) is bit-identical for single-tap filters but measured
 	// ~6% slower than the iteration-synchronous pipeline on MI355X (finished paths wait one round before their pixel's
 	// next sample starts); it stays available behind PRGPU_STREAMING=1
-	s->lockstep = !t.single_tap || !(getenv("PRGPU_STREAMING") && atoi(getenv("PRGPU_STREAMING")) != 0);
+	s->mode = prgpu_scene::LOCKSTEP;
+	if (t.single_tap) {
+		if (getenv("PRGPU_STREAMING") && atoi(getenv("PRGPU_STREAMING")) != 0)
+			s->mode = prgpu_scene::STREAMING;
+		if (const char* env = getenv("PRGPU_MODE")) {
+			if (std::strcmp(env, "streaming") == 0)
+				s->mode = prgpu_scene::STREAMING;
+			else if (std::strcmp(env, "persistent") == 0)
+				s->mode = prgpu_scene::PERSISTENT;
+			else if (std::strcmp(env, "lockstep") == 0)
+				s->mode = prgpu_scene::LOCKSTEP;
+			else
+				return fail(PRGPU_EINVAL, "PRGPU_MODE must be lockstep, streaming or persistent");
+		}
+	}
+	AL(s->pp_pixel, ns, false);
+	AL(s->pp_next, 1, true);
+	AL(s->pp_error, 1, true);
 	AL(s->gstats, prd::N_DEVICE_COUNTERS, true);
 	{ // persistent traversal grid: a few blocks of 256 threads per CU (32 KB of LDS stack each)
 		hipDeviceProp_t prop;
@@ -582,6 +605,35 @@ int render_streaming(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	return PRGPU_OK;
 }
 
+// ---- persistent mode ------------------------------------------------------------------------------------------
+// One launch per render call: see k_path_persistent (device/render.hip).  Same per-pixel arithmetic and fragment order as
+// the other two modes, hence identical images.
+int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
+{
+	if (!s->n_slots)
+		return PRGPU_OK;
+	prd::PathState ps = s->ps;
+	ps.pixel		  = s->pp_pixel; // s->ps.pixel is the Morton-ordered list of owned pixels
+	s->time_begin(6, s->stream);
+	prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, iter_begin, iter_end, s->instrument, s->groups[0].ws_closest, s->pp_next, s->pp_error,
+								s->gstats, s->stream);
+	s->time_end(s->stream);
+	HIP_TRY(hipGetLastError());
+	return PRGPU_OK;
+}
+
+// after a stream sync: did a wave of the persistent kernel give up waiting for work that never came?
+int check_watchdog(prgpu_scene* s)
+{
+	if (s->mode != prgpu_scene::PERSISTENT)
+		return PRGPU_OK;
+	uint32_t flag = 0;
+	HIP_TRY(hipMemcpy(&flag, s->pp_error, sizeof(flag), hipMemcpyDeviceToHost));
+	if (flag)
+		return fail(PRGPU_EDEVICE, "persistent path kernel: a wave timed out waiting for queued work (internal error)");
+	return PRGPU_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -720,8 +772,8 @@ int prgpu_render(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	HIP_TRY(hipSetDevice(s->device));
 	if (iter_end == iter_begin)
 		return PRGPU_OK;
-	if (!s->lockstep) {
-		const int rc = render_streaming(s, iter_begin, iter_end);
+	if (s->mode != prgpu_scene::LOCKSTEP) {
+		const int rc = s->mode == prgpu_scene::PERSISTENT ? render_persistent(s, iter_begin, iter_end) : render_streaming(s, iter_begin, iter_end);
 		if (rc != PRGPU_OK)
 			return rc;
 		s->next_iteration = iter_end;
@@ -743,7 +795,7 @@ int prgpu_sync(prgpu_scene* s)
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->collect_timing();
-	return PRGPU_OK;
+	return check_watchdog(s);
 }
 
 int prgpu_download(prgpu_scene* s, float* xyz, uint32_t* samples, uint32_t* feedback)
@@ -784,6 +836,10 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 	HIP_TRY(hipMemcpy(host, s->gstats, sizeof(host), hipMemcpyDeviceToHost));
 	out->rays_closest  = s->rays_closest;
 	out->rays_any	   = s->rays_any;
+	if (s->mode == prgpu_scene::PERSISTENT) { // no per-launch host counts: every path ray is in the device statistics
+		out->rays_closest += host[PRGPU_STAT_PRIMARY_RAYS] + host[PRGPU_STAT_BOUNCE_RAYS];
+		out->rays_any += host[PRGPU_STAT_SHADOW_RAYS];
+	}
 	out->nodes_closest = host[PRGPU_STAT_COUNT + 0];
 	out->leaves_closest  = host[PRGPU_STAT_COUNT + 1];
 	out->nodes_any	   = host[PRGPU_STAT_COUNT + 2];
