@@ -181,6 +181,7 @@ typedef struct prgpu_trace_counters {
 	uint32_t node_bytes, leaf_bytes;        /* record sizes of the device BVH (4-wide inner node, <=3-triangle leaf) */
 	uint32_t ray_bytes, hit_bytes;          /* queue record sizes */
 	uint64_t wave_steps_closest, wave_steps_any; /* wave-level traversal steps: lane utilisation = records / (64 * steps) */
+	uint64_t shade_batches, shade_lanes;    /* persistent kernel: wave-level shading passes and the vertices they shaded */
 } prgpu_trace_counters;
 
 typedef struct prgpu_scene prgpu_scene;

@@ -3,8 +3,9 @@
 #include "pr_device.h"
 
 namespace prd {
-// gstats: PRGPU_STAT_COUNT statistics, then inner/leaf record counters of closest and any-hit traversal, then wave-iteration counters
-constexpr int N_DEVICE_COUNTERS = PRGPU_STAT_COUNT + 6;
+// gstats: PRGPU_STAT_COUNT statistics, then inner/leaf record counters of closest and any-hit traversal, then wave-iteration
+// counters, then the persistent kernel's shading passes / shaded vertices
+constexpr int N_DEVICE_COUNTERS = PRGPU_STAT_COUNT + 8;
 
 // Scratch of one persistent traversal launch: queue head (u32) and the per-thread stack spill slab.
 // Launches that may run concurrently need separate workspaces.
@@ -35,10 +36,11 @@ void launch_trace_shadow(const DevScene& sc, const PathState& ps, uint32_t n_ite
 struct PersistentGeometry {
 	uint32_t n_blocks, slots_per_block;
 };
-PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks);
+PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, uint32_t max_slots_per_block);
 uint32_t persistent_slot_padding(); // per-slot arrays need n_pixels + this many entries
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
-							bool count, const TraceWorkspace& ws, uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st);
+							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int occupancy,
+							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st);
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st);
 void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
 							uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, unsigned long long* gstats,

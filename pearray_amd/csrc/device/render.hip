@@ -20,7 +20,7 @@ struct Hit {
 };
 
 // indices into the extra device counters after the 11 statistics
-enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY };
+enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES };
 
 // ---- traversal ------------------------------------------------------------------------------------------------
 // Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one 128-byte
@@ -1051,11 +1051,14 @@ struct PersistentArgs {
 	uint32_t iter_begin, iter_end;
 	uint2* spill;
 	int refill_below;
+	uint32_t shade_min; // shade as soon as this many vertices wait (<= 64)
+	uint32_t shade_partial; // ... or this many when no rays are queued and the wave has fewer than partial_act rays in flight
+	int partial_act;
 	unsigned long long* gstats;
 };
 
 template <bool COUNT>
-__global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, PathState ps, PersistentArgs a)
+__device__ __forceinline__ void path_persistent(const DevScene& sc, const PathState& ps, const PersistentArgs& a)
 {
 	__shared__ PPShared sh;
 	constexpr uint32_t RAY_MASK = 2 * PP_SLOTS_MAX - 1, SHADE_MASK = PP_SLOTS_MAX - 1;
@@ -1090,7 +1093,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, Pat
 	bool has_ray	  = false;
 	uint32_t my_entry = 0;
 	uint32_t spins	  = 0;
-	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0;
+	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, sbatches = 0, slanes = 0;
 
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
@@ -1098,11 +1101,15 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, Pat
 		uint32_t n_queued = wave_bcast0(lds_load(&sh.ray_tail) - lds_load(&sh.ray_head));
 
 		// ---- shade: a full wave of waiting vertices, or whatever is there when this wave is short of rays anyway
-		if (n_shade >= 64u || (n_shade > 0u && n_queued == 0u && n_act < a.refill_below)) {
+		if (n_shade >= a.shade_min || (n_queued == 0u && ((n_shade >= a.shade_partial && n_act < a.partial_act) || (n_shade > 0u && n_act == 0)))) {
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.shade_head, &sh.shade_tail, 64u, first);
 			if (n) {
 				spins			  = 0;
+				if (COUNT && lane == 0) {
+					++sbatches;
+					slanes += n;
+				}
 				const bool mine	  = lane < n;
 				uint32_t slot_l	  = 0;
 				bool regen		  = false;
@@ -1165,6 +1172,15 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, Pat
 				}
 				ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY);
 				ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, alive, slot_l);
+				{ // rays in flight were parked during the pass: rebuild their traversal constants (same values) rather than
+				  // holding them in registers across the shading code
+					const uint32_t pslot = slot0 + (has_ray ? (my_entry & ~PP_ANY) : 0u);
+					const bool pany		 = has_ray && (my_entry & PP_ANY) != 0;
+					const float4 ro = pany ? ps.sh_o[pslot] : ps.ray_o[pslot], rd = pany ? ps.sh_d[pslot] : ps.ray_d[pslot];
+					s.r	   = ray_prepare(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), sc.eps_t);
+					s.tmin = ro.w;
+					s.any  = pany;
+				}
 			}
 			continue;
 		}
@@ -1259,8 +1275,8 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, Pat
 			if (active == 0)
 				break;
 			if (active < a.refill_below) { // under-occupied: leave if there is anything to refill from or to shade
-				const uint32_t work = wave_bcast0((lds_load(&sh.ray_tail) - lds_load(&sh.ray_head)) | (lds_load(&sh.shade_tail) - lds_load(&sh.shade_head)));
-				if (work)
+				const uint32_t nq = lds_load(&sh.ray_tail) - lds_load(&sh.ray_head), nsh = lds_load(&sh.shade_tail) - lds_load(&sh.shade_head);
+				if (wave_bcast0((nq > 0u || nsh >= a.shade_min || (nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
 					break;
 			}
 		}
@@ -1276,8 +1292,24 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, Pat
 			atomicAdd(&a.gstats[CNT_TRIS_ANY], (unsigned long long)cl_a);
 		if (witers)
 			atomicAdd(&a.gstats[CNT_WAVE_ITERS_CLOSEST], (unsigned long long)witers);
+		if (sbatches) {
+			atomicAdd(&a.gstats[CNT_SHADE_BATCHES], (unsigned long long)sbatches);
+			atomicAdd(&a.gstats[CNT_SHADE_LANES], (unsigned long long)slanes);
+		}
 	}
 	stats_flush(sh.bs, a.gstats);
+}
+// Two register budgets of the same kernel: 2 waves per SIMD (no spills) and 3 waves per SIMD (the compiler spills a few shading
+// temporaries to scratch); which one is faster is a latency-hiding question answered by measurement (PRGPU_PP_OCCUPANCY).
+template <bool COUNT>
+__global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, PathState ps, PersistentArgs a)
+{
+	path_persistent<COUNT>(sc, ps, a);
+}
+template <bool COUNT>
+__global__ void __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_path_persistent_occ3(DevScene sc, PathState ps, PersistentArgs a)
+{
+	path_persistent<COUNT>(sc, ps, a);
 }
 
 // ---- ray service kernels (IArchive surface) ------------------------------------------------------------
@@ -1379,20 +1411,22 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 					   ws.refill_below, gstats);
 }
 
-PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks)
+PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, uint32_t max_slots_per_block)
 {
 	PersistentGeometry g;
 	const uint32_t per_block = (n_owned + max_blocks - 1) / std::max(1u, max_blocks);
-	g.slots_per_block		 = std::min((uint32_t)PP_SLOTS_MAX, std::max(256u, (per_block + 63u) / 64u * 64u));
+	const uint32_t cap		 = std::min((uint32_t)PP_SLOTS_MAX, std::max(256u, max_slots_per_block / 64u * 64u));
+	g.slots_per_block		 = std::min(cap, std::max(256u, (per_block + 63u) / 64u * 64u));
 	g.n_blocks				 = std::max(1u, std::min(max_blocks, (n_owned + g.slots_per_block - 1) / g.slots_per_block));
 	return g;
 }
 uint32_t persistent_slot_padding() { return PP_SLOTS_MAX; }
 
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
-							bool count, const TraceWorkspace& ws, uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st)
+							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int occupancy,
+							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st)
 {
-	const PersistentGeometry g = persistent_geometry(n_owned, ws.max_blocks);
+	const PersistentGeometry g = persistent_geometry(n_owned, ws.max_blocks, max_slots_per_block);
 	PersistentArgs a;
 	a.owned			  = owned;
 	a.n_owned		  = n_owned;
@@ -1403,9 +1437,17 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.iter_end		  = iter_end;
 	a.spill			  = ws.spill;
 	a.refill_below	  = ws.refill_below;
+	a.shade_min		  = (uint32_t)std::min(64, std::max(1, shade_min));
+	a.shade_partial	  = (uint32_t)std::min(64, std::max(1, shade_partial));
+	a.partial_act	  = std::min(ws.refill_below, std::max(1, partial_act));
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
-	if (count)
+	if (occupancy >= 3) {
+		if (count)
+			hipLaunchKernelGGL(k_path_persistent_occ3<true>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
+		else
+			hipLaunchKernelGGL(k_path_persistent_occ3<false>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
+	} else if (count)
 		hipLaunchKernelGGL(k_path_persistent<true>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
 	else
 		hipLaunchKernelGGL(k_path_persistent<false>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);

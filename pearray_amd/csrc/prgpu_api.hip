@@ -61,9 +61,12 @@ struct prgpu_scene {
 	// single-tap pixel filter (the reference default); all three produce identical images.
 	enum Mode { LOCKSTEP, STREAMING, PERSISTENT };
 	Mode mode = LOCKSTEP;
+	uint32_t pp_slots = 512;
+	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_occupancy = 3;
 	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
-	prd::TraceWorkspace ws; // workspace of the ray-service launches
+	prd::TraceWorkspace ws;	   // workspace of the ray-service launches
+	prd::TraceWorkspace ws_pp; // grid geometry and stack spill slab of the persistent path kernel
 	// Pixel groups: contiguous ranges of the Morton-ordered slot list, each running its own wavefront pipeline on
 	// its own pair of HIP streams so that the latency tails of one group's kernels overlap the other groups' work.
 	struct Group {
@@ -308,7 +311,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	// streaming (pixels advance through their samples independently) is bit-identical for single-tap filters but measured
 	// ~6% slower than the iteration-synchronous pipeline on MI355X (finished paths wait one round before their pixel's
 	// next sample starts); it stays available behind PRGPU_STREAMING=1
-	s->mode = prgpu_scene::LOCKSTEP;
+	s->mode = t.single_tap ? prgpu_scene::PERSISTENT : prgpu_scene::LOCKSTEP;
 	if (t.single_tap) {
 		if (getenv("PRGPU_STREAMING") && atoi(getenv("PRGPU_STREAMING")) != 0)
 			s->mode = prgpu_scene::STREAMING;
@@ -323,6 +326,16 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 				return fail(PRGPU_EINVAL, "PRGPU_MODE must be lockstep, streaming or persistent");
 		}
 	}
+	if (const char* env = getenv("PRGPU_PP_SLOTS"))
+		s->pp_slots = (uint32_t)std::max(256, atoi(env));
+	if (const char* env = getenv("PRGPU_PP_OCCUPANCY"))
+		s->pp_occupancy = atoi(env);
+	if (const char* env = getenv("PRGPU_PP_SHADE_PARTIAL"))
+		s->pp_shade_partial = atoi(env);
+	if (const char* env = getenv("PRGPU_PP_PARTIAL_ACT"))
+		s->pp_partial_act = atoi(env);
+	if (const char* env = getenv("PRGPU_PP_SHADE_MIN"))
+		s->pp_shade_min = atoi(env);
 	AL(s->pp_pixel, ns, false);
 	AL(s->pp_next, 1, true);
 	AL(s->pp_error, 1, true);
@@ -345,6 +358,18 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 			return PRGPU_OK;
 		};
 		rc = make_ws(s->ws);
+		if (rc != PRGPU_OK)
+			return rc;
+		{ // persistent path kernel: its own grid (measured best: 3 blocks per CU at 3 waves per SIMD, refill below 48 lanes)
+			uint32_t pp_blocks_per_cu = 3;
+			if (const char* env = getenv("PRGPU_PP_BLOCKS_PER_CU"))
+				pp_blocks_per_cu = (uint32_t)std::min(8, std::max(1, atoi(env)));
+			s->ws_pp.max_blocks	  = (uint32_t)std::max(1, prop.multiProcessorCount) * pp_blocks_per_cu;
+			s->ws_pp.refill_below = 48;
+			if (const char* env = getenv("PRGPU_PP_REFILL"))
+				s->ws_pp.refill_below = std::min(64, std::max(1, atoi(env)));
+			AL(s->ws_pp.spill, prd::trace_workspace_spill_entries(s->ws_pp.max_blocks), false);
+		}
 		if (rc != PRGPU_OK)
 			return rc;
 		uint32_t n_groups = 1; // pipelined pixel groups (measured: 1 is fastest on MI355X); PRGPU_GROUPS overrides (1..16)
@@ -615,7 +640,10 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	prd::PathState ps = s->ps;
 	ps.pixel		  = s->pp_pixel; // s->ps.pixel is the Morton-ordered list of owned pixels
 	s->time_begin(6, s->stream);
-	prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, iter_begin, iter_end, s->instrument, s->groups[0].ws_closest, s->pp_next, s->pp_error,
+	prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, iter_begin, iter_end, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act,
+								s->pp_occupancy,
+								s->pp_next,
+								s->pp_error,
 								s->gstats, s->stream);
 	s->time_end(s->stream);
 	HIP_TRY(hipGetLastError());
@@ -850,6 +878,8 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 	out->hit_bytes	   = 16; // t,u,v,tri
 	out->wave_steps_closest = host[PRGPU_STAT_COUNT + 4];
 	out->wave_steps_any		= host[PRGPU_STAT_COUNT + 5];
+	out->shade_batches		= host[PRGPU_STAT_COUNT + 6];
+	out->shade_lanes		= host[PRGPU_STAT_COUNT + 7];
 	return PRGPU_OK;
 }
 

@@ -218,8 +218,68 @@ def test_instrumented_run_changes_nothing_and_counts_work():
     st = b.statistics()
     assert tc["rays_closest"] == st["primary_rays"] + st["bounce_rays"] and tc["rays_any"] == st["shadow_rays"]
     assert tc["nodes_closest"] >= tc["rays_closest"] and tc["leaves_closest"] > 0 and tc["node_bytes"] == 128 and tc["leaf_bytes"] == 128
-    ms, n = b.kernelTime("trace_closest")
-    assert n > 0 and ms > 0
+    ms, n = b.kernelTime("path")  # single-tap filter: the persistent path kernel, one launch per render call
+    assert n == 1 and ms > 0
+    assert tc["shade_batches"] > 0 and tc["shade_lanes"] >= tc["rays_closest"]  # every traced vertex is shaded (+ path ends, slot starts)
+
+
+MODES = ("lockstep", "streaming", "persistent")
+
+
+def _render_mode(monkeypatch, mode, sc, chunks, tiles=None):
+    monkeypatch.setenv("PRGPU_MODE", mode)
+    g = backend.RenderContext(sc)
+    if tiles is not None:
+        g.setTiles(tiles)
+    for n in chunks:
+        g.render(n)
+    g.waitForFinish()
+    return g.output(), g.primaryHits(), g.statistics()
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_every_pipeline_matches_the_oracle(monkeypatch, mode):
+    """The three host pipelines (iteration-synchronous wavefront, streaming wavefront, persistent path kernel) run the same
+    per-pixel arithmetic in the same order: each is bit-identical to the CPU checker."""
+    monkeypatch.setenv("PRGPU_MODE", mode)
+    g, o = render_both(scene.cornell_box(96, 80, spp=6))
+    assert_parity(g, o, exact=True)
+    g, o = render_both(scene.cornell_soup(160, 90, spp=3, n_triangles=20_000))
+    assert_parity(g, o, exact=True)
+
+
+def test_pipelines_identical_with_tiles_and_resumed_calls(monkeypatch):
+    sc = scene.cornell_soup(200, 120, spp=8, n_triangles=5_000)
+    tiles = tiling.tiles_for_rank(200, 120, 1, 3, tile=32)
+    ref = _render_mode(monkeypatch, "lockstep", sc, [8], tiles)
+    for mode, chunks in (("streaming", [8]), ("persistent", [8]), ("persistent", [1, 4, 3]), ("streaming", [5, 3])):
+        out = _render_mode(monkeypatch, mode, sc, chunks, tiles)
+        for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+            assert np.array_equal(a, b), (mode, chunks)
+        assert ref[2] == out[2], (mode, chunks)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (8, 8), (17, 15), (300, 7)])
+def test_persistent_kernel_tiny_and_ragged_films(monkeypatch, w, h):
+    """Fewer pixels than one block has path slots, and pixel counts that are no multiple of 64."""
+    monkeypatch.setenv("PRGPU_MODE", "persistent")
+    g, o = render_both(scene.cornell_box(w, h, spp=5))
+    assert_parity(g, o, exact=True)
+
+
+def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypatch):
+    sc = scene.cornell_soup(192, 108, spp=4, n_triangles=20_000)
+    ref = _render_mode(monkeypatch, "lockstep", sc, [4])
+    for env in (dict(PRGPU_PP_SLOTS="256", PRGPU_PP_OCCUPANCY="2"), dict(PRGPU_PP_SLOTS="1024", PRGPU_PP_SHADE_PARTIAL="1"),
+                dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_PARTIAL_ACT="4")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = _render_mode(monkeypatch, "persistent", sc, [4])
+        for k in env:
+            monkeypatch.delenv(k)
+        for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+            assert np.array_equal(a, b), env
+        assert ref[2] == out[2], env
 
 
 def test_full_size_properties_1m_triangles():
