@@ -40,6 +40,76 @@ def cpu_baseline(scene_desc, iters=1):
                       "CPU restatement, not Embree" % (iters, W, H, st["pixel_samples"], dt, t_build)}
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per ITERATION of the dominant kernel from the newest committed rocprofv3 --pmc summary (PMC counters
+    cannot be read from inside this process): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the gfx950 correction of
+    MI355X_MICROARCH.md (HBM: FETCH_SIZE tallies 128-B requests at 64 B)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        try:
+            with open(path) as f:
+                summ = json.load(f)
+            for name, k in summ["kernels"].items():
+                if kernel_substr in name and "FETCH_SIZE_per_iteration" in k:
+                    return (2.0 * k["FETCH_SIZE_per_iteration"] + k["WRITE_SIZE_per_iteration"]) * 1024.0, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
+def roofline(ctx, rank, iters=8):
+    """Roofline of the dominant kernel, measured live on this rank: HIP events on the launch stream around every launch
+    (pass 1), node/triangle record counters of the instrumented kernel variant (pass 2; same pixels, statistically identical
+    iterations).  Algorithmic bytes = rays x (32 B ray + 16 B result) + 128 B x BVH records fetched."""
+    ctx.setTiming(True)
+    ctx.render(iters)
+    ctx.waitForFinish()
+    fam = {k: ctx.kernelTime(k) for k in ("path", "trace_closest", "trace_any", "shade")}
+    ctx.setTiming(False)
+    tc0 = ctx.traceCounters()
+    ctx.setInstrumentation(True)
+    ctx.render(iters)
+    ctx.waitForFinish()
+    ctx.setInstrumentation(False)
+    tc1 = ctx.traceCounters()
+    d = {k: tc1[k] - tc0[k] for k in ("rays_closest", "rays_any", "nodes_closest", "leaves_closest", "nodes_any", "leaves_any",
+                                      "wave_steps_closest", "wave_steps_any", "shade_batches", "shade_lanes")}
+    per_ray = tc1["ray_bytes"] + tc1["hit_bytes"]
+    bytes_closest = d["rays_closest"] * per_ray + tc1["node_bytes"] * d["nodes_closest"] + tc1["leaf_bytes"] * d["leaves_closest"]
+    bytes_any = d["rays_any"] * per_ray + tc1["node_bytes"] * d["nodes_any"] + tc1["leaf_bytes"] * d["leaves_any"]
+    persistent = fam["path"][1] > 0
+    if persistent:
+        # one launch = `iters` iterations of everything: closest-hit and occlusion traversal + shading, fused
+        kernel, substr = "k_path_persistent_occ3", "k_path_persistent"
+        ms, n = fam["path"]
+        alg_bytes = (bytes_closest + bytes_any) / n          # per launch
+        iters_per_launch = iters / n
+    else:
+        kernel, substr = "k_trace_closest", "k_trace_closest"
+        ms, n = fam["trace_closest"]
+        alg_bytes = bytes_closest / n
+        iters_per_launch = iters / n
+    avg_ms = ms / max(n, 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    t_iter, src = pmc_traffic(substr)
+    if t_iter is not None and not persistent:
+        t_iter = None  # lockstep summaries are per launch of one path depth; not comparable here
+    traffic_bytes = t_iter * iters_per_launch if t_iter is not None else None
+    records = d["nodes_closest"] + d["leaves_closest"] + d["nodes_any"] + d["leaves_any"]
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1) if traffic_bytes else None,
+            "traffic_bytes_per_launch": traffic_bytes, "traffic_source": src, "kernel": kernel, "avg_launch_ms": round(avg_ms, 4),
+            "launches": n, "iterations_per_launch": iters_per_launch, "algorithmic_bytes_per_launch": round(alg_bytes),
+            "algorithmic_bytes_per_closest_ray": round(bytes_closest / max(d["rays_closest"], 1), 1),
+            "algorithmic_bytes_per_occlusion_ray": round(bytes_any / max(d["rays_any"], 1), 1),
+            "nodes_per_closest_ray": round(d["nodes_closest"] / max(d["rays_closest"], 1), 2),
+            "leaves_per_closest_ray": round(d["leaves_closest"] / max(d["rays_closest"], 1), 2),
+            "rays_per_launch": round((d["rays_closest"] + d["rays_any"]) / n),
+            "lane_utilisation": round(records / max(64 * (d["wave_steps_closest"] + d["wave_steps_any"]), 1), 3),
+            "shade_pass_fill": round(d["shade_lanes"] / max(64 * d["shade_batches"], 1), 3) if d["shade_batches"] else None,
+            "family_ms_per_iter": {k: round(v[0] / iters, 3) for k, v in fam.items() if v[1]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,49 +186,11 @@ def main():
     }
 
     if not args.profile_only:
-        # ---- roofline of the dominant kernel (closest-hit traversal), measured live on this rank ---------------
-        # pass 1: HIP events on the launch stream around every launch; pass 2: node/triangle counters
-        ctx.setTiming(True)
-        ctx.render(4)
-        ctx.waitForFinish()
-        ms_c, n_c = ctx.kernelTime("trace_closest")
-        ms_a, n_a = ctx.kernelTime("trace_any")
-        ms_s, n_s = ctx.kernelTime("shade")
-        ctx.setTiming(False)
-        tc0 = ctx.traceCounters()
-        ctx.setInstrumentation(True)
-        ctx.render(1)
-        ctx.waitForFinish()
-        ctx.setInstrumentation(False)
-        tc1 = ctx.traceCounters()
-        rays_counted = tc1["rays_closest"] - tc0["rays_closest"]
-        nodes_per_ray = tc1["nodes_closest"] / max(rays_counted, 1)
-        leaves_per_ray = tc1["leaves_closest"] / max(rays_counted, 1)
-        bytes_per_ray = tc1["ray_bytes"] + tc1["hit_bytes"] + tc1["node_bytes"] * nodes_per_ray + tc1["leaf_bytes"] * leaves_per_ray
-        rays_per_launch = rays_counted * 4 / max(n_c, 1)  # same pixels, statistically identical iterations
-        avg_ms = ms_c / max(n_c, 1)
-        achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
-        # HBM-side traffic of the same kernel: PMC counters cannot be read from inside this process, so the figure comes
-        # from the committed rocprofv3 --pmc passes of this very command (tools/gpu_profile_r01.sh -> profiles/), with the
-        # gfx950 correction FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM); divided by the live launch duration like `achieved`
-        traffic = traffic_bytes = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_v3_pmc_summary.json")) as f:
-                k = json.load(f)["kernels"]["prd::k_trace_closest<false>"]
-            traffic_bytes = (2.0 * k["FETCH_SIZE_per_launch"] + k["WRITE_SIZE_per_launch"]) * 1024.0
-            traffic = round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1)
-        except Exception:
-            pass
-        if rank == 0:
-            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                               "traffic_bytes_per_launch": traffic_bytes, "traffic_source": "profiles/r01_v3_pmc_summary.json",
-                               "kernel": "k_trace_closest", "avg_launch_ms": round(avg_ms, 4), "launches": n_c,
-                               "algorithmic_bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 2),
-                               "leaves_per_ray": round(leaves_per_ray, 2), "rays_per_launch": round(rays_per_launch),
-                               "family_ms_per_iter": {"trace_closest": round(ms_c / 4, 3), "trace_any": round(ms_a / 4, 3), "shade": round(ms_s / 4, 3)}}
+        out["roofline"] = roofline(ctx, rank)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc)
+        if rank != 0:
+            out.pop("roofline", None)
 
     if world > 1:
         dist.barrier()
