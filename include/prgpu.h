@@ -182,6 +182,7 @@ typedef struct prgpu_trace_counters {
 	uint32_t ray_bytes, hit_bytes;          /* queue record sizes */
 	uint64_t wave_steps_closest, wave_steps_any; /* wave-level traversal steps: lane utilisation = records / (64 * steps) */
 	uint64_t shade_batches, shade_lanes;    /* persistent kernel: wave-level shading passes and the vertices they shaded */
+	uint64_t shade_ticks, idle_ticks, total_ticks; /* persistent kernel, summed over waves, 100 MHz ticks: in shading passes, waiting for work, alive */
 } prgpu_trace_counters;
 
 typedef struct prgpu_scene prgpu_scene;

@@ -81,7 +81,8 @@ class TraceCounters(C.Structure):
                 ("leaves_closest", C.c_uint64), ("nodes_any", C.c_uint64), ("leaves_any", C.c_uint64),
                 ("node_bytes", C.c_uint32), ("leaf_bytes", C.c_uint32), ("ray_bytes", C.c_uint32),
                 ("hit_bytes", C.c_uint32), ("wave_steps_closest", C.c_uint64), ("wave_steps_any", C.c_uint64),
-                ("shade_batches", C.c_uint64), ("shade_lanes", C.c_uint64)]
+                ("shade_batches", C.c_uint64), ("shade_lanes", C.c_uint64),
+                ("shade_ticks", C.c_uint64), ("idle_ticks", C.c_uint64), ("total_ticks", C.c_uint64)]
 
 
 def default_settings(width, height):

@@ -20,7 +20,7 @@ struct Hit {
 };
 
 // indices into the extra device counters after the 11 statistics
-enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES };
+enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES, CNT_SHADE_TICKS, CNT_IDLE_TICKS, CNT_TOTAL_TICKS };
 
 // ---- traversal ------------------------------------------------------------------------------------------------
 // Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one 128-byte
@@ -56,11 +56,16 @@ struct Stack {
 	__device__ __forceinline__ uint2 pop()
 	{
 		--sp;
-		if (sp < base) {
+		// always the LDS read; the rare refetch of a spilled entry overrides it (kept as two separate accesses so that the
+		// common case is a ds_read and not a flat load through a selected pointer)
+		uint2 e = lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK];
+		if (__builtin_expect(sp < base, 0)) {
 			base = sp;
-			return sp < STACK_SPILL ? spill[(uint32_t)sp * spill_stride] : make_uint2(REC_EMPTY, 0x7F800000u);
+			e	 = make_uint2(REC_EMPTY, 0x7F800000u);
+			if (sp < STACK_SPILL)
+				e = spill[(uint32_t)sp * spill_stride];
 		}
-		return lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK];
+		return e;
 	}
 };
 static_assert((STACK_LDS & (STACK_LDS - 1)) == 0, "STACK_LDS must be a power of two");
@@ -115,10 +120,25 @@ __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& s
 	float t[4];
 	uint32_t c[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
 	bool h[4];
-	h[0] = child_hit(s.r, q0.x, q1.x, q2.x, q3.x, q4.x, q5.x, s.tmin, s.best.t, t[0]) && c[0] != REC_EMPTY;
-	h[1] = child_hit(s.r, q0.y, q1.y, q2.y, q3.y, q4.y, q5.y, s.tmin, s.best.t, t[1]) && c[1] != REC_EMPTY;
-	h[2] = child_hit(s.r, q0.z, q1.z, q2.z, q3.z, q4.z, q5.z, s.tmin, s.best.t, t[2]) && c[2] != REC_EMPTY;
-	h[3] = child_hit(s.r, q0.w, q1.w, q2.w, q3.w, q4.w, q5.w, s.tmin, s.best.t, t[3]) && c[3] != REC_EMPTY;
+	{
+		// slab distances of the four child boxes, two children per instruction (v_pk_add_f32 / v_pk_mul_f32): the same
+		// subtract-then-multiply arithmetic as box_hit, so the results are identical to the scalar form
+		typedef float f2 __attribute__((ext_vector_type(2)));
+		const f2 ox = { s.r.o.x, s.r.o.x }, oy = { s.r.o.y, s.r.o.y }, oz = { s.r.o.z, s.r.o.z };
+		const f2 ix = { s.r.inv_d.x, s.r.inv_d.x }, iy = { s.r.inv_d.y, s.r.inv_d.y }, iz = { s.r.inv_d.z, s.r.inv_d.z };
+		const f2 ax[2] = { (f2{ q0.x, q0.y } - ox) * ix, (f2{ q0.z, q0.w } - ox) * ix }, bx[2] = { (f2{ q3.x, q3.y } - ox) * ix, (f2{ q3.z, q3.w } - ox) * ix };
+		const f2 ay[2] = { (f2{ q1.x, q1.y } - oy) * iy, (f2{ q1.z, q1.w } - oy) * iy }, by[2] = { (f2{ q4.x, q4.y } - oy) * iy, (f2{ q4.z, q4.w } - oy) * iy };
+		const f2 az[2] = { (f2{ q2.x, q2.y } - oz) * iz, (f2{ q2.z, q2.w } - oz) * iz }, bz[2] = { (f2{ q5.x, q5.y } - oz) * iz, (f2{ q5.z, q5.w } - oz) * iz };
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const float axk = ax[k >> 1][k & 1], bxk = bx[k >> 1][k & 1], ayk = ay[k >> 1][k & 1], byk = by[k >> 1][k & 1], azk = az[k >> 1][k & 1],
+						bzk = bz[k >> 1][k & 1];
+			const float t0 = fmaxf(fmaxf(fminf(axk, bxk), fminf(ayk, byk)), fmaxf(fminf(azk, bzk), s.tmin));
+			const float t1 = fminf(fminf(fmaxf(axk, bxk), fmaxf(ayk, byk)), fminf(fmaxf(azk, bzk), s.best.t));
+			t[k]		   = t0;
+			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY; // acceptance rule of box_hit
+		}
+	}
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
 		t[k] = h[k] ? t[k] : INFINITY;
@@ -1054,6 +1074,7 @@ struct PersistentArgs {
 	uint32_t shade_min; // shade as soon as this many vertices wait (<= 64)
 	uint32_t shade_partial; // ... or this many when no rays are queued and the wave has fewer than partial_act rays in flight
 	int partial_act;
+	uint32_t refill_min; // waves other than the block's first one refill only when at least this many rays are queued
 	unsigned long long* gstats;
 };
 
@@ -1094,6 +1115,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	uint32_t my_entry = 0;
 	uint32_t spins	  = 0;
 	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, sbatches = 0, slanes = 0;
+	unsigned long long t_shade = 0, t_idle = 0;
+	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
 
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
@@ -1106,6 +1129,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			const uint32_t n = ring_claim(&sh.shade_head, &sh.shade_tail, 64u, first);
 			if (n) {
 				spins			  = 0;
+				const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
 				if (COUNT && lane == 0) {
 					++sbatches;
 					slanes += n;
@@ -1181,13 +1205,18 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					s.tmin = ro.w;
 					s.any  = pany;
 				}
+				if (COUNT)
+					t_shade += wall_clock64() - t0;
 			}
 			continue;
 		}
 
 		// ---- trace: hand queued rays to the idle lanes
+		// Hand queued rays to the idle lanes.  When few rays are queued only the block's first wave takes them: the other waves
+		// wait for at least `refill_min`, so that a thin supply of rays fills a few waves instead of keeping every wave stepping
+		// with a handful of lanes (a wave step costs the same with 3 lanes as with 64).
 		const unsigned long long idle = __ballot(!has_ray);
-		if (idle != 0ull && n_queued > 0u) {
+		if (idle != 0ull && n_queued > 0u && (n_queued >= a.refill_min || threadIdx.x < 64u)) {
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(idle), first);
 			const uint32_t r = __popcll(idle & ((1ull << lane) - 1ull));
@@ -1205,8 +1234,11 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			// nothing to trace and not enough to shade: other waves of the block hold the work, or the block is done
 			if (lds_load(&sh.live) == 0u || lds_load(&sh.error) != 0u)
 				break;
+			const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
+			__builtin_amdgcn_s_sleep(8);
+			if (COUNT)
+				t_idle += wall_clock64() - t0;
 			if (n_shade == 0u && n_queued == 0u) {
-				__builtin_amdgcn_s_sleep(8);
 				if (++spins > PP_SPIN_LIMIT) {
 					if (lane == 0) {
 						__hip_atomic_store(&sh.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1276,7 +1308,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				break;
 			if (active < a.refill_below) { // under-occupied: leave if there is anything to refill from or to shade
 				const uint32_t nq = lds_load(&sh.ray_tail) - lds_load(&sh.ray_head), nsh = lds_load(&sh.shade_tail) - lds_load(&sh.shade_head);
-				if (wave_bcast0((nq > 0u || nsh >= a.shade_min || (nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
+				if (wave_bcast0(((nq > 0u && (nq >= a.refill_min || threadIdx.x < 64u)) || nsh >= a.shade_min || (nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
 					break;
 			}
 		}
@@ -1295,6 +1327,11 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		if (sbatches) {
 			atomicAdd(&a.gstats[CNT_SHADE_BATCHES], (unsigned long long)sbatches);
 			atomicAdd(&a.gstats[CNT_SHADE_LANES], (unsigned long long)slanes);
+		}
+		if (lane == 0) {
+			atomicAdd(&a.gstats[CNT_SHADE_TICKS], t_shade);
+			atomicAdd(&a.gstats[CNT_IDLE_TICKS], t_idle);
+			atomicAdd(&a.gstats[CNT_TOTAL_TICKS], wall_clock64() - t_start);
 		}
 	}
 	stats_flush(sh.bs, a.gstats);
@@ -1423,7 +1460,7 @@ PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, ui
 uint32_t persistent_slot_padding() { return PP_SLOTS_MAX; }
 
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
-							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int occupancy,
+							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int refill_min, int occupancy,
 							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st)
 {
 	const PersistentGeometry g = persistent_geometry(n_owned, ws.max_blocks, max_slots_per_block);
@@ -1440,6 +1477,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.shade_min		  = (uint32_t)std::min(64, std::max(1, shade_min));
 	a.shade_partial	  = (uint32_t)std::min(64, std::max(1, shade_partial));
 	a.partial_act	  = std::min(ws.refill_below, std::max(1, partial_act));
+	a.refill_min	  = (uint32_t)std::min(64, std::max(1, refill_min));
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	if (occupancy >= 3) {

@@ -21,11 +21,15 @@ def run(env, world, instrument=False):
         tc = ctx.traceCounters()
         recs = tc["nodes_closest"] + tc["leaves_closest"] + tc["nodes_any"] + tc["leaves_any"]
         steps = tc["wave_steps_closest"] + tc["wave_steps_any"]
-        extra = " lane-util %.3f shade-util %.3f (batches %d)" % (recs / max(64 * steps, 1), tc["shade_lanes"] / max(64 * tc["shade_batches"], 1), tc["shade_batches"])
+        extra = " lane-util %.3f shade-util %.3f (batches %d, %.1f us/pass) time: shade %.2f idle %.2f trace %.2f; %.2f us/step" % (
+            recs / max(64 * steps, 1), tc["shade_lanes"] / max(64 * tc["shade_batches"], 1), tc["shade_batches"],
+            tc["shade_ticks"] / max(tc["shade_batches"], 1) / 100.0, tc["shade_ticks"] / max(tc["total_ticks"], 1), tc["idle_ticks"] / max(tc["total_ticks"], 1),
+            1 - (tc["shade_ticks"] + tc["idle_ticks"]) / max(tc["total_ticks"], 1),
+            (tc["total_ticks"] - tc["shade_ticks"] - tc["idle_ticks"]) / max(steps, 1) / 100.0)
     ctx.close()
     return dt / iters * 1e3, extra
 
-base = {"PRGPU_MODE": "persistent", "PRGPU_PP_BLOCKS_PER_CU": 3, "PRGPU_PP_REFILL": 48, "PRGPU_PP_SLOTS": 512, "PRGPU_PP_SHADE_MIN": 64, "PRGPU_PP_SHADE_PARTIAL": 16, "PRGPU_PP_PARTIAL_ACT": 64, "PRGPU_PP_OCCUPANCY": 3}
+base = {"PRGPU_MODE": "persistent", "PRGPU_PP_BLOCKS_PER_CU": 3, "PRGPU_PP_REFILL": 48, "PRGPU_PP_SLOTS": 512, "PRGPU_PP_SHADE_MIN": 64, "PRGPU_PP_SHADE_PARTIAL": 16, "PRGPU_PP_PARTIAL_ACT": 64, "PRGPU_PP_REFILL_MIN": 1, "PRGPU_PP_OCCUPANCY": 3}
 configs = [dict(base)]
 for name in sys.argv[1:]:
     c = dict(base)
