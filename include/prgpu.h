@@ -254,6 +254,28 @@ int  prgpu_download_primary_hits(prgpu_scene* s, uint32_t* entity, uint32_t* pri
 int  prgpu_set_timing(prgpu_scene* s, int enabled);
 int  prgpu_kernel_time_ms(prgpu_scene* s, const char* family, double* total_ms, uint64_t* launches);
 
+/* -- .prc scene files ---------------------------------------------------------------------
+ * Replaces SceneLoader::loadFromFile / loadFromString (src/loader/SceneLoader.cpp:44-72) for the part of the scene language the
+ * `direct` hot path evaluates: (scene :render_width :render_height :camera :spectral_domain :spectral_hero), (sampler), (filter),
+ * (spectral_mapper), (integrator :type 'direct'), (camera :type 'standard'), (material :type 'diffuse'), (emission :type 'standard'),
+ * spectral expressions number / (refl r g b) / (illum r g b) / (illuminant "D65") / (spectrum :start :end v...) / (smul a b),
+ * inline (mesh (attribute :type 'p'|'n' ...) (faces ...) (materials ...)), (entity :type 'mesh' ...), (include "file").
+ * Constructs this backend cannot render fail with PRGPU_EUNSUPPORTED and a message naming the block; output blocks are skipped
+ * with a warning.  The returned object owns every array the description points to. */
+typedef struct prgpu_prc prgpu_prc;
+typedef struct prgpu_prc_options {
+	uint32_t width, height; /* 0: keep :render_width / :render_height */
+	uint32_t aa_samples;    /* 0: keep the aa sampler's :sample_count */
+	uint32_t force_direct;  /* 1: accept any (integrator :type ...) and render it with `direct` at default parameters */
+	uint64_t seed;          /* 0: RenderSettings default (42) */
+} prgpu_prc_options;
+int prgpu_prc_load_file(const char* path, const prgpu_prc_options* options, prgpu_prc** out);
+int prgpu_prc_load_string(const char* source, const char* include_dir, const prgpu_prc_options* options, prgpu_prc** out);
+const prgpu_scene_desc* prgpu_prc_desc(const prgpu_prc* scene);
+const char* prgpu_prc_warnings(const prgpu_prc* scene); /* newline separated */
+const char* prgpu_prc_last_error(void);                 /* message of the last failed prgpu_prc_load_* on this thread */
+void prgpu_prc_free(prgpu_prc* scene);
+
 #ifdef __cplusplus
 }
 #endif

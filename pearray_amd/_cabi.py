@@ -85,6 +85,11 @@ class TraceCounters(C.Structure):
                 ("shade_ticks", C.c_uint64), ("idle_ticks", C.c_uint64), ("total_ticks", C.c_uint64)]
 
 
+class PrcOptions(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("aa_samples", C.c_uint32), ("force_direct", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
 def default_settings(width, height):
     """Reference defaults (RenderSettings.cpp:11-31, direct.cpp:34-39, Sampler/FilterManager defaults)."""
     s = Settings()
@@ -121,6 +126,12 @@ SYMBOLS = {
     "prgpu_download_primary_hits": (C.c_int, [_VP, _U32P, _U32P]),
     "prgpu_set_timing": (C.c_int, [_VP, C.c_int]),
     "prgpu_kernel_time_ms": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_double), _U64P]),
+    "prgpu_prc_load_file": (C.c_int, [C.c_char_p, C.POINTER(PrcOptions), C.POINTER(_VP)]),
+    "prgpu_prc_load_string": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(PrcOptions), C.POINTER(_VP)]),
+    "prgpu_prc_desc": (C.POINTER(SceneDesc), [_VP]),
+    "prgpu_prc_warnings": (C.c_char_p, [_VP]),
+    "prgpu_prc_last_error": (C.c_char_p, []),
+    "prgpu_prc_free": (None, [_VP]),
 }
 
 _lib = None

@@ -1,0 +1,780 @@
+// prc_loader.cpp -- ".prc" scene files -> prgpu_scene_desc (include/prgpu.h: prgpu_prc_*).
+//
+// Replaces, for the part of PearRay the `direct` hot path evaluates, what SceneLoader does between the parsed DataLisp tree and
+// the Scene/RenderContext (reference file:line cited at each block):
+//   top level `(scene ...)`                                        SceneLoader.cpp:73-160
+//   dispatch of inner blocks                                       SceneLoader.cpp:162-198
+//   sampler / filter / spectral_mapper / integrator blocks         SceneLoader.cpp:192-384 + the plugins' getNames()/parameters
+//   :transform / :position :rotation :scale                        SceneLoader.cpp:386-444, parser/MathParser.cpp
+//   camera (perspective)                                           plugins/main/cameras/perspective.cpp:141-165
+//   material (diffuse/lambert), emission (diffuse)                 materials/lambert.cpp:90-117, emissions/diffuse.cpp:55-80
+//   spectral expressions                                           SceneLoader.cpp:999-1040, node/SpectralValueNode.cpp:12-59,
+//                                                                  IlluminantNode.cpp:86-130, SpectralConstNode.cpp:12-40, SpectralMathNode.cpp:265-280
+//   inline meshes                                                  parser/MeshParser.cpp:11-255
+//   entities of type 'mesh'                                        plugins/main/entities/mesh.cpp:205-330
+//   (include "file")                                               SceneLoader.cpp:848-886
+// Anything else the reference would accept but this backend cannot render (other entity, material, light, camera, sampler
+// types ...) is an error (PRGPU_EUNSUPPORTED) naming the block -- never silently dropped; blocks that do not influence the
+// radiance (outputs) are skipped with a warning.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../../include/prgpu.h"
+#include "../tables/pr_tables.inl"
+#include "datalisp.h"
+#include "setup.h"
+
+using prgpu_host::dl::Group;
+using prgpu_host::dl::Value;
+
+struct prgpu_prc {
+	std::vector<float> positions, normals, tables;
+	std::vector<uint32_t> indices, tri_material;
+	std::vector<prgpu_entity> entities;
+	std::vector<prgpu_material> materials;
+	std::vector<prgpu_emission> emissions;
+	std::vector<prgpu_spectrum> spectra;
+	prgpu_scene_desc desc;
+	std::string warnings;
+};
+
+namespace {
+
+thread_local std::string g_prc_error;
+
+struct LoadError {
+	int code;
+	std::string msg;
+};
+[[noreturn]] void fail(int code, const std::string& msg) { throw LoadError{ code, msg }; }
+std::string where(const Group& g) { return "(" + g.id + " ...) at line " + std::to_string(g.line); }
+std::string lower(std::string s)
+{
+	std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+	return s;
+}
+
+struct Mesh {
+	std::vector<float> p, n;
+	std::vector<std::vector<uint32_t>> faces;
+	std::vector<uint32_t> slots; // per face material slot (empty: slot 0)
+};
+
+struct Loader {
+	prgpu_prc& out;
+	prgpu_prc_options opt;
+	prgpu_settings settings;
+	std::map<std::string, uint32_t> material_ids, emission_ids;
+	std::map<std::string, Mesh> meshes;
+	std::map<std::string, prgpu_camera> cameras;
+	std::string first_camera, selected_camera;
+	bool any_normals = false, have_integrator = false, have_filter = false;
+	int include_depth = 0;
+
+	Loader(prgpu_prc& o, const prgpu_prc_options* op) : out(o)
+	{
+		std::memset(&opt, 0, sizeof(opt));
+		if (op)
+			opt = *op;
+		prgpu_settings_default(&settings);
+	}
+	void warn(const std::string& m) { out.warnings += m + "\n"; }
+
+	// ---- small accessors -----------------------------------------------------------------------------------
+	static std::string get_string(const Group& g, const char* key, const std::string& def)
+	{
+		const Value* v = g.get(key);
+		return v && v->type == Value::STRING ? v->s : def;
+	}
+	static double get_number(const Group& g, const char* key, double def)
+	{
+		const Value* v = g.get(key);
+		return v && v->is_number() ? v->number() : def;
+	}
+	static bool get_bool(const Group& g, const char* key, bool def)
+	{
+		const Value* v = g.get(key);
+		return v && v->type == Value::BOOL ? v->b : def;
+	}
+	static bool get_vec3(const Group& g, const char* key, float dst[3]) // MathParser::getVector: 2 or 3 numbers
+	{
+		const Value* v = g.get(key);
+		if (!v || v->type != Value::GROUP || !v->g->all_numbers())
+			return false;
+		const size_t n = v->g->anonymous_count();
+		if (n != 2 && n != 3)
+			return false;
+		for (size_t i = 0; i < 3; ++i)
+			dst[i] = i < n ? (float)v->g->at(i).number() : 0.0f;
+		return true;
+	}
+
+	// ---- transforms (SceneLoader.cpp:386-444) -----------------------------------------------------------------
+	static void identity(float m[16])
+	{
+		for (int i = 0; i < 16; ++i)
+			m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+	}
+	void transform_of(const Group& g, float m[16])
+	{
+		identity(m);
+		const Value* t = g.get("transform");
+		if (t && t->type == Value::GROUP) {
+			const Group& a = *t->g;
+			if (a.all_numbers() && a.anonymous_count() == 16) {
+				for (int i = 0; i < 16; ++i)
+					m[i] = (float)a.at(i).number();
+			} else if (a.all_numbers() && a.anonymous_count() == 9) {
+				for (int i = 0; i < 3; ++i)
+					for (int j = 0; j < 3; ++j)
+						m[4 * i + j] = (float)a.at(3 * i + j).number();
+			} else {
+				fail(PRGPU_EINVAL, ":transform of " + where(g) + " must have 16 or 9 numbers");
+			}
+			// Transformf::makeAffine: last row becomes 0 0 0 1
+			m[12] = m[13] = m[14] = 0.0f;
+			m[15]				  = 1.0f;
+			return;
+		}
+		float pos[3] = { 0, 0, 0 }, sca[3] = { 1, 1, 1 };
+		float q[4] = { 1, 0, 0, 0 }; // w x y z
+		if (g.get("position") && !get_vec3(g, "position", pos))
+			fail(PRGPU_EINVAL, ":position of " + where(g) + " is not a vector");
+		if (const Value* r = g.get("rotation")) {
+			bool ok = false;
+			if (r->type == Value::GROUP) {
+				const Group& a = *r->g;
+				if (a.is_array && a.anonymous_count() == 4 && a.all_numbers()) {
+					for (int i = 0; i < 4; ++i)
+						q[i] = (float)a.at(i).number();
+					ok = true;
+				} else if (a.id == "euler" && a.anonymous_count() == 3 && a.all_numbers()) { // degrees, applied z*y*x
+					const double x = a.at(0).number() * M_PI / 180 / 2, y = a.at(1).number() * M_PI / 180 / 2, z = a.at(2).number() * M_PI / 180 / 2;
+					const double qx[4] = { std::cos(x), std::sin(x), 0, 0 }, qy[4] = { std::cos(y), 0, std::sin(y), 0 }, qz[4] = { std::cos(z), 0, 0, std::sin(z) };
+					auto mul = [](const double a[4], const double b[4], double r[4]) {
+						r[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+						r[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+						r[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+						r[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+					};
+					double zy[4], zyx[4];
+					mul(qz, qy, zy);
+					mul(zy, qx, zyx);
+					for (int i = 0; i < 4; ++i)
+						q[i] = (float)zyx[i];
+					ok = true;
+				}
+			}
+			if (!ok)
+				fail(PRGPU_EINVAL, ":rotation of " + where(g) + " must be a quaternion [w,x,y,z] or (euler x y z)");
+		}
+		if (const Value* s = g.get("scale")) {
+			if (s->is_number())
+				sca[0] = sca[1] = sca[2] = (float)s->number();
+			else if (!get_vec3(g, "scale", sca))
+				fail(PRGPU_EINVAL, ":scale of " + where(g) + " is not a number or vector");
+		}
+		const float qn = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+		if (!(qn > 0))
+			fail(PRGPU_EINVAL, ":rotation of " + where(g) + " has zero length");
+		const float w = q[0] / qn, x = q[1] / qn, y = q[2] / qn, z = q[3] / qn;
+		const float R[9] = { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+							 2 * (y * z - x * w),	  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y) };
+		for (int i = 0; i < 3; ++i) {
+			for (int j = 0; j < 3; ++j)
+				m[4 * i + j] = R[3 * i + j] * sca[j]; // T * R * S
+			m[4 * i + 3] = pos[i];
+		}
+	}
+
+	// ---- spectral expressions ----------------------------------------------------------------------------------
+	uint32_t add_spectrum(const prgpu_spectrum& s)
+	{
+		out.spectra.push_back(s);
+		return (uint32_t)out.spectra.size() - 1;
+	}
+	static prgpu_spectrum blank(uint32_t kind)
+	{
+		prgpu_spectrum s;
+		std::memset(&s, 0, sizeof(s));
+		s.kind = kind;
+		return s;
+	}
+	uint32_t spectrum_const(float v)
+	{
+		prgpu_spectrum s = blank(PRGPU_SPEC_CONST);
+		s.p[0]			 = v;
+		return add_spectrum(s);
+	}
+	uint32_t spectrum_table(float start, float end, const float* values, size_t n)
+	{
+		prgpu_spectrum s = blank(PRGPU_SPEC_TABLE);
+		s.table_offset	 = (uint32_t)out.tables.size();
+		s.table_count	 = (uint32_t)n;
+		s.wl_start		 = start;
+		s.wl_end		 = end;
+		for (size_t i = 0; i < n; ++i)
+			out.tables.push_back(std::max(0.0f, values[i]));
+		return add_spectrum(s);
+	}
+	// a value in a spectral slot: number | (refl r g b) | (illum r g b) | (illuminant "D65") | (spectrum ...) | (smul a b)
+	uint32_t spectral_node(const Value& v, const Group& owner, const char* key)
+	{
+		if (v.is_number())
+			return spectrum_const((float)v.number());
+		if (v.type != Value::GROUP || v.g->is_array)
+			fail(PRGPU_EINVAL, std::string(":") + key + " of " + where(owner) + " is not a spectral expression");
+		const Group& e		 = *v.g;
+		const std::string id = lower(e.id);
+		if (id == "refl" || id == "reflection" || id == "illum" || id == "illumination") {
+			float rgb[3];
+			for (int k = 0; k < 3; ++k) {
+				rgb[k] = e.at(k).is_number() ? (float)e.at(k).number() : 0.0f;
+				if (!(rgb[k] >= 0.0f) || !std::isfinite(rgb[k]))
+					fail(PRGPU_EINVAL, where(e) + ": colour components must be finite and non-negative");
+			}
+			prgpu_spectrum s;
+			if (id[0] == 'r') { // SpectralValueNode.cpp:16-30
+				s = blank(PRGPU_SPEC_PARAMETRIC);
+				prgpu_host::rgb_to_coeffs(rgb, s.p);
+			} else { // :31-47: scaled so that the fitted colour has maximum 0.5
+				s				= blank(PRGPU_SPEC_PARAMETRIC_SCALED);
+				const float mx	= std::max(rgb[0], std::max(rgb[1], rgb[2]));
+				float power		= 1.0f;
+				float scaled[3] = { rgb[0], rgb[1], rgb[2] };
+				if (mx > 0.0f) {
+					const float scale = 2 * mx;
+					for (int k = 0; k < 3; ++k)
+						scaled[k] = rgb[k] / scale;
+					power = scale;
+				}
+				prgpu_host::rgb_to_coeffs(scaled, s.p);
+				s.p[3] = power;
+			}
+			return add_spectrum(s);
+		}
+		if (id == "illuminant") { // IlluminantNode.cpp:89-130
+			std::string name = get_string(e, "spectrum", "");
+			if (name.empty())
+				name = e.at(0).type == Value::STRING ? e.at(0).s : "D65";
+			name = lower(name);
+			if (name == "d65")
+				return spectrum_table(300.0f, 830.0f, PR_D65, 107);
+			if (name == "e")
+				return spectrum_const(1.0f);
+			fail(PRGPU_EUNSUPPORTED, where(e) + ": illuminant '" + name + "' is not available (D65 and E are)");
+		}
+		if (id == "spectrum") { // SpectralConstNode.cpp:12-33
+			const float start = (float)get_number(e, "start", 0.0), end = (float)get_number(e, "end", 0.0);
+			if (!(start < end))
+				fail(PRGPU_EINVAL, where(e) + ": invalid :start/:end wavelengths");
+			std::vector<float> vals;
+			for (size_t i = 0; i < e.anonymous_count(); ++i)
+				vals.push_back(e.at(i).is_number() ? (float)e.at(i).number() : 0.0f);
+			if (vals.size() < 2)
+				fail(PRGPU_EINVAL, where(e) + ": a spectrum needs at least two values");
+			return spectrum_table(start, end, vals.data(), vals.size());
+		}
+		if (id == "smul") { // SpectralMathNode.cpp:275: product of two spectral nodes
+			if (e.anonymous_count() != 2)
+				fail(PRGPU_EINVAL, where(e) + ": smul takes two operands");
+			prgpu_spectrum s = blank(PRGPU_SPEC_MUL);
+			s.lhs			 = spectral_node(e.at(0), e, "lhs");
+			s.rhs			 = spectral_node(e.at(1), e, "rhs");
+			if (out.spectra[s.lhs].kind == PRGPU_SPEC_MUL || out.spectra[s.rhs].kind == PRGPU_SPEC_MUL)
+				fail(PRGPU_EUNSUPPORTED, where(e) + ": nested smul is not supported (operands must be leaves)");
+			return add_spectrum(s);
+		}
+		fail(PRGPU_EUNSUPPORTED, "spectral expression " + where(e) + " is not supported (number, refl, illum, illuminant, spectrum, smul are)");
+	}
+	uint32_t spectral_param(const Group& g, std::initializer_list<const char*> keys, float def)
+	{
+		for (const char* k : keys)
+			if (const Value* v = g.get(k))
+				return spectral_node(*v, g, k);
+		return spectrum_const(def);
+	}
+
+	// ---- blocks -------------------------------------------------------------------------------------------------
+	void add_sampler(const Group& g) // SceneLoader.cpp:192-258
+	{
+		const std::string type = lower(get_string(g, "type", ""));
+		const std::string slot = lower(get_string(g, "slot", "aa"));
+		if (type.empty())
+			fail(PRGPU_EINVAL, where(g) + ": no valid type given");
+		uint32_t kind;
+		static const char* mj[] = { "multijittered", "multi_jittered", "jittered", "multijitter", "multi_jitter", "jitter", "mjitt", "jitt" };
+		if (type == "random")
+			kind = PRGPU_SAMPLER_RANDOM;
+		else if (type == "sobol")
+			kind = PRGPU_SAMPLER_SOBOL;
+		else if (std::find_if(std::begin(mj), std::end(mj), [&](const char* n) { return type == n; }) != std::end(mj))
+			kind = PRGPU_SAMPLER_MJITT;
+		else
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": sampler type '" + type + "' is not supported (random, mjitt, sobol are)");
+		const uint32_t count = (uint32_t)std::max(1.0, get_number(g, "sample_count", 128)); // DEF_SAMPLE_COUNT
+		if (slot == "aa" || slot == "pixel" || slot == "antialiasing") {
+			settings.aa_sampler = kind;
+			settings.aa_samples = count;
+		} else if (slot == "lens") {
+			settings.lens_samples = count;
+		} else if (slot == "time" || slot == "t") {
+			settings.time_samples = count;
+		} else if (slot == "spectral" || slot == "spectrum" || slot == "s") {
+			settings.spectral_samples = count;
+			if (const Value* r = g.get("range"))
+				if (r->type == Value::GROUP && r->g->anonymous_count() == 2 && r->g->all_numbers()) {
+					settings.spectral_start = (float)std::min(r->g->at(0).number(), r->g->at(1).number());
+					settings.spectral_end	= (float)std::max(r->g->at(0).number(), r->g->at(1).number());
+				}
+		} else {
+			fail(PRGPU_EINVAL, where(g) + ": unknown sampler slot '" + slot + "'");
+		}
+	}
+	void add_filter(const Group& g) // SceneLoader.cpp:260-306; plugin default radius 3
+	{
+		const std::string type = lower(get_string(g, "type", ""));
+		if (lower(get_string(g, "slot", "pixel")) != "pixel")
+			fail(PRGPU_EINVAL, where(g) + ": unknown filter slot");
+		if (type == "block" || type == "blur")
+			settings.filter = PRGPU_FILTER_BLOCK;
+		else if (type == "tri" || type == "triangle")
+			settings.filter = PRGPU_FILTER_TRIANGLE;
+		else if (type == "gaussian" || type == "gauss")
+			settings.filter = PRGPU_FILTER_GAUSSIAN;
+		else if (type == "mitchell" || type == "default")
+			settings.filter = PRGPU_FILTER_MITCHELL;
+		else
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": filter type '" + type + "' is not supported (block, triangle, gaussian, mitchell are)");
+		settings.filter_radius = (uint32_t)std::max(0.0, get_number(g, "radius", 3));
+		have_filter			   = true;
+	}
+	void add_mapper(const Group& g) // SceneLoader.cpp:308-352, spd.cpp:360-383, random.cpp
+	{
+		const std::string type = lower(get_string(g, "type", ""));
+		if (lower(get_string(g, "purpose", "pixel")) != "pixel") {
+			warn(where(g) + ": spectral mapper for a purpose other than 'pixel' ignored (only camera paths are traced)");
+			return;
+		}
+		if (type == "random") {
+			settings.mapper = PRGPU_MAPPER_RANDOM;
+		} else if (type == "spd" || type == "default") {
+			settings.mapper = get_bool(g, "cmis", true) ? PRGPU_MAPPER_SPD_CMIS : PRGPU_MAPPER_SPD_HERO;
+			if (g.get("bins") || g.get("weighting") || g.get("complete") || g.get("normalized") || g.get("smooth_iterations"))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": only the default spd histogram (bins, weighting, smoothing) is implemented");
+		} else {
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": spectral mapper '" + type + "' is not supported (spd, random are)");
+		}
+	}
+	void add_integrator(const Group& g) // SceneLoader.cpp:354-384, direct.cpp:498-512,545-563
+	{
+		const std::string type = lower(get_string(g, "type", ""));
+		const bool direct	   = type == "direct" || type == "standard" || type == "default";
+		if (!direct && !opt.force_direct)
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": integrator '" + type + "' is not supported (only direct/standard/default; set force_direct to render with it anyway)");
+		if (!direct) {
+			warn(where(g) + ": integrator '" + type + "' replaced by 'direct' with default parameters (force_direct)");
+			have_integrator = true;
+			return;
+		}
+		settings.max_ray_depth		= (uint32_t)get_number(g, "max_ray_depth", settings.max_ray_depth);
+		settings.soft_max_ray_depth = std::min(settings.max_ray_depth, (uint32_t)get_number(g, "soft_max_ray_depth", settings.soft_max_ray_depth));
+		const std::string mis		= lower(get_string(g, "mis", "balance"));
+		settings.mis				= mis == "power" ? PRGPU_MIS_POWER : PRGPU_MIS_BALANCE;
+		settings.emissive_scatter	= get_bool(g, "emissive_scatter", true) ? 1 : 0;
+		have_integrator				= true;
+	}
+	void add_camera(const Group& g) // perspective.cpp:141-165
+	{
+		const std::string type = lower(get_string(g, "type", "standard"));
+		if (type != "standard_camera" && type != "standard" && type != "default" && type != "perspective")
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": camera type '" + type + "' is not supported (perspective only)");
+		prgpu_camera c;
+		std::memset(&c, 0, sizeof(c));
+		transform_of(g, c.transform);
+		c.width			  = (float)get_number(g, "width", 1);
+		c.height		  = (float)get_number(g, "height", 1);
+		c.near_t		  = (float)get_number(g, "near", 0.000001); // NEAR_DEFAULT / FAR_DEFAULT, perspective.cpp:14-15
+		c.far_t			  = (float)get_number(g, "far", INFINITY);
+		c.fstop			  = (float)get_number(g, "fstop", 0);
+		c.aperture_radius = (float)get_number(g, "aperture_radius", 0.05);
+		const float dd[3] = { 0, 1, 0 }, dr[3] = { 1, 0, 0 }, du[3] = { 0, 0, 1 }; // ICamera::DefaultDirection/Right/Up, core/camera/ICamera.cpp:5-7
+		if (!get_vec3(g, "local_direction", c.local_direction))
+			std::memcpy(c.local_direction, dd, sizeof(dd));
+		if (!get_vec3(g, "local_right", c.local_right))
+			std::memcpy(c.local_right, dr, sizeof(dr));
+		if (!get_vec3(g, "local_up", c.local_up))
+			std::memcpy(c.local_up, du, sizeof(du));
+		const std::string name = get_string(g, "name", "__unnamed__");
+		cameras[name]		   = c;
+		if (first_camera.empty())
+			first_camera = name;
+	}
+	void add_material(const Group& g) // lambert.cpp:90-117
+	{
+		const std::string type = lower(get_string(g, "type", ""));
+		const std::string name = get_string(g, "name", "");
+		if (name.empty())
+			fail(PRGPU_EINVAL, where(g) + ": material without a name");
+		if (type != "diffuse" && type != "lambert")
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert only)");
+		prgpu_material m;
+		std::memset(&m, 0, sizeof(m));
+		m.kind		= PRGPU_MAT_LAMBERT;
+		m.albedo	= spectral_param(g, { "albedo", "base", "diffuse" }, 1.0f);
+		m.two_sided = get_bool(g, "two_sided", true) ? 1 : 0;
+		material_ids[name] = (uint32_t)out.materials.size();
+		out.materials.push_back(m);
+	}
+	void add_emission(const Group& g) // diffuse.cpp:55-80
+	{
+		const std::string type = lower(get_string(g, "type", ""));
+		const std::string name = get_string(g, "name", "");
+		if (name.empty())
+			fail(PRGPU_EINVAL, where(g) + ": emission without a name");
+		if (type != "diffuse" && type != "standard" && type != "default")
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": emission type '" + type + "' is not supported (diffuse only)");
+		prgpu_emission e;
+		e.kind	   = PRGPU_EMS_DIFFUSE;
+		e.radiance = spectral_param(g, { "radiance" }, 1.0f);
+		emission_ids[name] = (uint32_t)out.emissions.size();
+		out.emissions.push_back(e);
+	}
+	void add_mesh(const Group& g) // MeshParser.cpp:134-255
+	{
+		const std::string name = get_string(g, "name", "");
+		if (name.empty())
+			fail(PRGPU_EINVAL, where(g) + ": mesh without a name");
+		Mesh m;
+		auto load_attr = [&](const Group& a, std::vector<float>& dst) {
+			for (size_t j = 0; j < a.anonymous_count(); ++j) {
+				const Value& v = a.at(j);
+				const size_t n = v.type == Value::GROUP ? v.g->anonymous_count() : 0;
+				if (v.type != Value::GROUP || !v.g->all_numbers() || (n != 2 && n != 3))
+					fail(PRGPU_EINVAL, where(a) + " of mesh '" + name + "': attribute entry " + std::to_string(j) + " is not a vector");
+				for (size_t k = 0; k < 3; ++k)
+					dst.push_back(k < n ? (float)v.g->at(k).number() : 0.0f);
+			}
+		};
+		for (const auto& e : g.entries) {
+			if (!e.key.empty())
+				continue;
+			if (e.value.type != Value::GROUP)
+				fail(PRGPU_EINVAL, where(g) + ": invalid entry in mesh description");
+			const Group& b = *e.value.g;
+			if (b.id == "attribute") {
+				const std::string t = get_string(b, "type", "");
+				if (t == "p")
+					load_attr(b, m.p);
+				else if (t == "n")
+					load_attr(b, m.n);
+				else if (t == "t" || t == "uv" || t == "w" || t == "dp" || t == "u")
+					; // texture coordinates, weights, velocities, user attributes: not evaluated by Lambert / diffuse emission
+				else
+					fail(PRGPU_EINVAL, where(b) + ": unknown mesh attribute '" + t + "'");
+			} else if (b.id == "faces") {
+				for (size_t j = 0; j < b.anonymous_count(); ++j) {
+					const Value& v = b.at(j);
+					if (v.type != Value::GROUP || !v.g->is_array)
+						fail(PRGPU_EINVAL, where(b) + " of mesh '" + name + "': face " + std::to_string(j) + " is not an index array");
+					const size_t n = v.g->anonymous_count();
+					if (n != 3 && n != 4)
+						fail(PRGPU_EINVAL, where(b) + " of mesh '" + name + "': only triangle or quad faces are supported");
+					std::vector<uint32_t> f;
+					for (size_t k = 0; k < n; ++k) {
+						if (v.g->at(k).type != Value::INT || v.g->at(k).i < 0)
+							fail(PRGPU_EINVAL, where(b) + " of mesh '" + name + "': face index is not a non-negative integer");
+						f.push_back((uint32_t)v.g->at(k).i);
+					}
+					m.faces.push_back(f);
+				}
+			} else if (b.id == "materials") {
+				for (size_t j = 0; j < b.anonymous_count(); ++j) {
+					if (b.at(j).type != Value::INT || b.at(j).i < 0)
+						fail(PRGPU_EINVAL, where(b) + " of mesh '" + name + "': material slot is not a non-negative integer");
+					m.slots.push_back((uint32_t)b.at(j).i);
+				}
+			} else if (b.id == "normal_faces" || b.id == "texture_faces" || b.id == "weight_faces" || b.id == "velocity_faces") {
+				if (b.id == "normal_faces")
+					fail(PRGPU_EUNSUPPORTED, where(b) + " of mesh '" + name + "': separate normal indices are not supported");
+			}
+		}
+		const size_t nv = m.p.size() / 3;
+		if (nv == 0 || m.faces.empty())
+			fail(PRGPU_EINVAL, "mesh '" + name + "' has no vertices or faces");
+		if (!m.n.empty() && m.n.size() != m.p.size())
+			fail(PRGPU_EINVAL, "mesh '" + name + "': normal count differs from vertex count");
+		if (!m.slots.empty() && m.slots.size() != m.faces.size())
+			fail(PRGPU_EINVAL, "mesh '" + name + "': material slot count differs from face count");
+		for (const auto& f : m.faces)
+			for (uint32_t i : f)
+				if (i >= nv)
+					fail(PRGPU_EINVAL, "mesh '" + name + "': face index out of range");
+		meshes[name] = std::move(m);
+	}
+	void add_entity(const Group& g) // SceneLoader.cpp:446-520, mesh.cpp:260-300
+	{
+		const std::string type = lower(get_string(g, "type", ""));
+		const std::string name = get_string(g, "name", "__unnamed__");
+		if (type != "mesh")
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": entity type '" + type + "' is not supported (mesh only; tessellate other primitives)");
+		for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
+			if (!get_bool(g, flag, true))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
+		const auto mit = meshes.find(get_string(g, "mesh", ""));
+		if (mit == meshes.end())
+			fail(PRGPU_EINVAL, where(g) + ": entity '" + name + "' refers to unknown mesh '" + get_string(g, "mesh", "") + "'");
+		const Mesh& m = mit->second;
+		std::vector<uint32_t> mats; // SceneLoadContext::lookupMaterialIDArray
+		const Value* mv = g.get("materials") ? g.get("materials") : g.get("material");
+		auto lookup = [&](const std::string& n) {
+			const auto it = material_ids.find(n);
+			return it == material_ids.end() ? PRGPU_INVALID_ID : it->second; // unknown names give PR_INVALID_ID like the reference
+		};
+		if (mv && mv->type == Value::STRING)
+			mats.push_back(lookup(mv->s));
+		else if (mv && mv->type == Value::GROUP && mv->g->is_array)
+			for (size_t i = 0; i < mv->g->anonymous_count(); ++i)
+				mats.push_back(mv->g->at(i).type == Value::STRING ? lookup(mv->g->at(i).s) : PRGPU_INVALID_ID);
+		prgpu_entity e;
+		std::memset(&e, 0, sizeof(e));
+		e.first_tri	  = (uint32_t)(out.indices.size() / 3);
+		e.emission	  = PRGPU_INVALID_ID;
+		if (const Value* ev = g.get("emission")) {
+			const auto it = ev->type == Value::STRING ? emission_ids.find(ev->s) : emission_ids.end();
+			if (it == emission_ids.end())
+				fail(PRGPU_EINVAL, where(g) + ": entity '" + name + "' refers to an unknown emission");
+			e.emission = it->second;
+		}
+		e.has_normals = (!m.n.empty() && !get_bool(g, "ignore_normals", false)) ? 1 : 0;
+		transform_of(g, e.transform);
+		const uint32_t base = (uint32_t)(out.positions.size() / 3);
+		out.positions.insert(out.positions.end(), m.p.begin(), m.p.end());
+		if (e.has_normals) {
+			out.normals.resize(size_t(base) * 3, 0.0f);
+			out.normals.insert(out.normals.end(), m.n.begin(), m.n.end());
+			any_normals = true;
+		}
+		for (size_t fi = 0; fi < m.faces.size(); ++fi) {
+			const auto& f		= m.faces[fi];
+			const uint32_t slot = m.slots.empty() ? 0u : m.slots[fi];
+			const uint32_t mat	= slot < mats.size() ? mats[slot] : PRGPU_INVALID_ID; // mesh.cpp:227
+			auto tri = [&](uint32_t a, uint32_t b, uint32_t c) {
+				out.indices.push_back(base + a);
+				out.indices.push_back(base + b);
+				out.indices.push_back(base + c);
+				out.tri_material.push_back(mat);
+			};
+			if (f.size() == 3) {
+				tri(f[0], f[1], f[2]);
+			} else { // quads are handed to Embree as RTC_GEOMETRY_TYPE_QUAD: triangles (v0,v1,v3) and (v2,v3,v1)
+				tri(f[0], f[1], f[3]);
+				tri(f[2], f[3], f[1]);
+			}
+		}
+		e.n_tris = (uint32_t)(out.indices.size() / 3) - e.first_tri;
+		out.entities.push_back(e);
+	}
+
+	void add_include(const Group& g, const std::string& dir) // SceneLoader.cpp:848-886
+	{
+		if (g.anonymous_count() != 1 || g.at(0).type != Value::STRING)
+			fail(PRGPU_EINVAL, where(g) + ": include needs one file name");
+		if (++include_depth > 16)
+			fail(PRGPU_EINVAL, where(g) + ": includes nested too deeply");
+		std::string path = g.at(0).s;
+		if (!path.empty() && path[0] != '/' && !dir.empty())
+			path = dir + "/" + path;
+		std::ifstream f(path);
+		if (!f)
+			fail(PRGPU_EINVAL, where(g) + ": cannot open include file '" + path + "'");
+		std::stringstream ss;
+		ss << f.rdbuf();
+		std::vector<std::shared_ptr<Group>> top;
+		std::string err;
+		if (!prgpu_host::dl::parse(ss.str(), top, err))
+			fail(PRGPU_EINVAL, path + ": " + err);
+		const size_t slash = path.find_last_of('/');
+		const std::string sub = slash == std::string::npos ? std::string() : path.substr(0, slash);
+		for (const auto& t : top)
+			dispatch(*t, sub);
+		--include_depth;
+	}
+	void dispatch(const Group& b, const std::string& dir) // SceneLoader.cpp:162-198
+	{
+		const std::string& id = b.id;
+		if (id == "include")
+			add_include(b, dir);
+		else if (id == "sampler")
+			add_sampler(b);
+		else if (id == "filter")
+			add_filter(b);
+		else if (id == "integrator")
+			add_integrator(b);
+		else if (id == "spectral_mapper")
+			add_mapper(b);
+		else if (id == "mesh")
+			add_mesh(b);
+		else if (id == "material")
+			add_material(b);
+		else if (id == "emission")
+			add_emission(b);
+		else if (id == "entity")
+			add_entity(b);
+		else if (id == "camera")
+			add_camera(b);
+		else if (id == "output")
+			warn(where(b) + ": output specification ignored (the backend produces the XYZ frame, sample count and feedback planes)");
+		else if (id == "light" || id == "texture" || id == "node" || id == "graph" || id == "embed")
+			fail(PRGPU_EUNSUPPORTED, where(b) + ": block is not supported by this backend yet");
+		else if (id == "scene")
+			fail(PRGPU_EINVAL, where(b) + ": invalid inner scene entry");
+		else
+			warn(where(b) + ": unknown block ignored"); // the reference's setupEnvironment ignores unknown ids too
+	}
+
+	void run(const std::string& source, const std::string& dir)
+	{
+		std::vector<std::shared_ptr<Group>> top;
+		std::string err;
+		if (!prgpu_host::dl::parse(source, top, err))
+			fail(PRGPU_EINVAL, err);
+		if (top.empty() || top.front()->id != "scene")
+			fail(PRGPU_EINVAL, "the file does not contain a top-level (scene ...) entry"); // SceneLoader.cpp:76-84
+		const Group& scene = *top.front();
+		// top-level keys, SceneLoader.cpp:86-140
+		if (const Value* v = scene.get("render_width"))
+			if (v->type == Value::INT)
+				settings.width = (uint32_t)v->i;
+		if (const Value* v = scene.get("render_height"))
+			if (v->type == Value::INT)
+				settings.height = (uint32_t)v->i;
+		if (scene.get("crop"))
+			fail(PRGPU_EUNSUPPORTED, ":crop is not supported (use tiles)");
+		if (const Value* v = scene.get("spectral_domain")) {
+			if (v->is_number()) {
+				settings.spectral_start = settings.spectral_end = (float)v->number();
+				settings.spectral_mono							= 1;
+			} else if (v->type == Value::GROUP && v->g->anonymous_count() == 2 && v->g->all_numbers()) {
+				settings.spectral_start = (float)std::min(v->g->at(0).number(), v->g->at(1).number());
+				settings.spectral_end	= (float)std::max(v->g->at(0).number(), v->g->at(1).number());
+				settings.spectral_mono	= settings.spectral_start == settings.spectral_end ? 1 : 0;
+			}
+		}
+		if (const Value* v = scene.get("spectral_hero"))
+			if (v->type == Value::BOOL)
+				settings.spectral_hero = v->b ? 1 : 0;
+		selected_camera = get_string(scene, "camera", "");
+		for (const auto& e : scene.entries)
+			if (e.key.empty() && e.value.type == Value::GROUP)
+				dispatch(*e.value.g, dir);
+
+		// ---- assemble the description ---------------------------------------------------------------------------
+		if (opt.width)
+			settings.width = opt.width;
+		if (opt.height)
+			settings.height = opt.height;
+		if (opt.aa_samples)
+			settings.aa_samples = opt.aa_samples;
+		if (opt.seed)
+			settings.seed = opt.seed;
+		if (cameras.empty())
+			fail(PRGPU_EINVAL, "the scene has no camera");
+		const std::string cam = selected_camera.empty() ? first_camera : selected_camera;
+		if (!cameras.count(cam))
+			fail(PRGPU_EINVAL, "the scene's :camera '" + cam + "' does not exist");
+		if (out.entities.empty())
+			fail(PRGPU_EINVAL, "the scene has no entities");
+		if (any_normals)
+			out.normals.resize(out.positions.size(), 0.0f);
+		if (out.tables.empty())
+			out.tables.push_back(0.0f);
+		prgpu_scene_desc& d = out.desc;
+		std::memset(&d, 0, sizeof(d));
+		d.api_version			  = PRGPU_API_VERSION;
+		d.n_vertices			  = (uint32_t)(out.positions.size() / 3);
+		d.positions				  = out.positions.data();
+		d.normals				  = any_normals ? out.normals.data() : nullptr;
+		d.n_triangles			  = (uint32_t)(out.indices.size() / 3);
+		d.indices				  = out.indices.data();
+		d.tri_material			  = out.tri_material.data();
+		d.n_entities			  = (uint32_t)out.entities.size();
+		d.entities				  = out.entities.data();
+		d.n_materials			  = (uint32_t)out.materials.size();
+		d.materials				  = out.materials.data();
+		d.n_emissions			  = (uint32_t)out.emissions.size();
+		d.emissions				  = out.emissions.data();
+		d.n_spectra				  = (uint32_t)out.spectra.size();
+		d.spectra				  = out.spectra.data();
+		d.n_spectral_table_values = (uint32_t)out.tables.size();
+		d.spectral_tables		  = out.tables.data();
+		d.camera				  = cameras[cam];
+		d.settings				  = settings;
+	}
+};
+
+int load(const std::string& source, const std::string& dir, const prgpu_prc_options* opt, prgpu_prc** out)
+{
+	if (!out)
+		return PRGPU_EINVAL;
+	*out	= nullptr;
+	auto* p = new prgpu_prc();
+	try {
+		Loader l(*p, opt);
+		l.run(source, dir);
+	} catch (const LoadError& e) {
+		g_prc_error = e.msg;
+		delete p;
+		return e.code;
+	} catch (const std::exception& e) {
+		g_prc_error = e.what();
+		delete p;
+		return PRGPU_EINVAL;
+	}
+	*out = p;
+	return PRGPU_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int prgpu_prc_load_string(const char* source, const char* include_dir, const prgpu_prc_options* opt, prgpu_prc** out)
+{
+	if (!source) {
+		g_prc_error = "null source";
+		return PRGPU_EINVAL;
+	}
+	return load(source, include_dir ? include_dir : "", opt, out);
+}
+
+int prgpu_prc_load_file(const char* path, const prgpu_prc_options* opt, prgpu_prc** out)
+{
+	if (!path) {
+		g_prc_error = "null path";
+		return PRGPU_EINVAL;
+	}
+	std::ifstream f(path);
+	if (!f) {
+		g_prc_error = std::string("cannot open '") + path + "'";
+		return PRGPU_EINVAL;
+	}
+	std::stringstream ss;
+	ss << f.rdbuf();
+	const std::string p(path);
+	const size_t slash = p.find_last_of('/');
+	return load(ss.str(), slash == std::string::npos ? std::string() : p.substr(0, slash), opt, out);
+}
+
+const prgpu_scene_desc* prgpu_prc_desc(const prgpu_prc* p) { return p ? &p->desc : nullptr; }
+const char* prgpu_prc_warnings(const prgpu_prc* p) { return p ? p->warnings.c_str() : ""; }
+const char* prgpu_prc_last_error(void) { return g_prc_error.c_str(); }
+void prgpu_prc_free(prgpu_prc* p) { delete p; }
+
+} // extern "C"

@@ -203,6 +203,40 @@ class SceneData:
         return s.aa_samples * s.lens_samples * s.time_samples * s.spectral_samples
 
 
+class PrcScene:
+    """A scene parsed from PearRay's .prc language by the backend library (prgpu_prc_*, csrc/host/prc_loader.cpp).
+    Quacks like SceneData: .desc, .settings, .width, .height, .spp."""
+
+    def __init__(self, path=None, source=None, include_dir=None, width=0, height=0, spp=0, force_direct=False, seed=0):
+        lib = abi.load()
+        opt = abi.PrcOptions(width, height, spp, 1 if force_direct else 0, seed)
+        h = C.c_void_p()
+        if path is not None:
+            rc = lib.prgpu_prc_load_file(os.fsencode(path), C.byref(opt), C.byref(h))
+        else:
+            rc = lib.prgpu_prc_load_string(source.encode(), os.fsencode(include_dir) if include_dir else None, C.byref(opt), C.byref(h))
+        if rc != 0:
+            raise abi.PrgpuError("prgpu error %d: %s" % (rc, lib.prgpu_prc_last_error().decode()), rc)
+        self._lib, self._h = lib, h
+        self.desc = lib.prgpu_prc_desc(h).contents
+        self.warnings = [w for w in lib.prgpu_prc_warnings(h).decode().split("\n") if w]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.prgpu_prc_free(self._h)
+            self._h = None
+
+    settings = SceneData.settings
+    width = SceneData.width
+    height = SceneData.height
+    spp = SceneData.spp
+
+
+def load_prc(path, **overrides):
+    """SceneLoader::loadFromFile for the supported part of the scene language."""
+    return PrcScene(path=path, **overrides)
+
+
 # ---- stock scenes (BASELINE.json configs) -----------------------------------------------------------------
 
 def _cornell_into(b, data=None):
@@ -213,9 +247,10 @@ def _cornell_into(b, data=None):
     b.set_camera(np.asarray(cam["transform"], dtype=np.float32).reshape(4, 4), width=cam["width"][0], height=cam["height"][0],
                  near=cam["near"][0], far=cam["far"][0], local_direction=cam["local_direction"],
                  local_right=cam["local_right"], local_up=cam["local_up"])
-    mats = {name: b.lambert(b.refl(*m["refl"])) for name, m in data["materials"].items()}
+    # block order of examples/cornellbox.prc (emission before the materials), so that ids equal those of the .prc loader
     radiance = b.smul(b.illuminant_d65(), b.illum(*data["emission"]["illum"]))  # (smul (illuminant "D65") (illum 17 12 4))
     ems = b.diffuse_emission(radiance)
+    mats = {name: b.lambert(b.refl(*m["refl"])) for name, m in data["materials"].items()}
     for e in data["entities"]:
         b.add_mesh(e["p"], e["faces"], mats[e["material"]], normals=e["n"], emission=ems if e["emission"] else None,
                    transform=np.asarray(e["transform"], dtype=np.float32).reshape(4, 4))

@@ -302,3 +302,15 @@ def test_full_size_properties_1m_triangles():
     assert smp.max() == 2
     o.render(2, threads=8)
     assert np.array_equal(xyz, o.output()[0])
+
+
+def test_prc_scene_renders_like_the_oracle():
+    """A scene that went through the C++ .prc loader (prgpu_prc_*): same image as the CPU checker given the same description."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "two_quads.prc")
+    g, o = render_both(scene.PrcScene(path=path))            # triangle filter r=1: multi-tap, lockstep pipeline
+    assert_parity(g, o, exact=False)
+    src = open(path).read().replace("(filter :type 'triangle' :radius 1)", "")
+    g, o = render_both(scene.PrcScene(source=src, include_dir=os.path.dirname(path), width=96, height=64, spp=6))   # default filter: persistent kernel
+    assert_parity(g, o, exact=True)
+    assert g.statistics()["pixel_samples"] == 96 * 64 * 6

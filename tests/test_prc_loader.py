@@ -1,0 +1,181 @@
+"""Host-side .prc loader (csrc/host/datalisp.cpp, prc_loader.cpp; C ABI prgpu_prc_*): syntax, semantic mapping onto
+prgpu_scene_desc, error behaviour.  The checker is pearray_amd.scene.SceneBuilder (the Python scene assembly the parity tests
+use) -- the loader must produce the same description, byte for byte, for the same scene."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from pearray_amd import _cabi as abi
+from pearray_amd import scene
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SCENES = os.path.join(HERE, "golden", "scenes")
+REF_EXAMPLES = "/root/reference/examples"
+
+
+def arr(ptr, n, dtype):
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).copy() if n else np.zeros(0, dtype)
+
+
+def struct_bytes(x):
+    return bytes(memoryview(x).cast("B")) if not isinstance(x, C.Structure) else C.string_at(C.addressof(x), C.sizeof(x))
+
+
+def assert_same_desc(a, b, check_settings=True):
+    """Both prgpu_scene_desc describe the same scene (pointers followed, padding-free structs compared bytewise)."""
+    for f in ("n_vertices", "n_triangles", "n_entities", "n_materials", "n_emissions", "n_spectra", "n_spectral_table_values"):
+        assert getattr(a, f) == getattr(b, f), f
+    assert np.array_equal(arr(a.positions, 3 * a.n_vertices, np.float32), arr(b.positions, 3 * b.n_vertices, np.float32))
+    assert bool(a.normals) == bool(b.normals)
+    if a.normals:
+        assert np.array_equal(arr(a.normals, 3 * a.n_vertices, np.float32), arr(b.normals, 3 * b.n_vertices, np.float32))
+    assert np.array_equal(arr(a.indices, 3 * a.n_triangles, np.uint32), arr(b.indices, 3 * b.n_triangles, np.uint32))
+    assert np.array_equal(arr(a.tri_material, a.n_triangles, np.uint32), arr(b.tri_material, b.n_triangles, np.uint32))
+    assert np.array_equal(arr(a.spectral_tables, a.n_spectral_table_values, np.float32), arr(b.spectral_tables, b.n_spectral_table_values, np.float32))
+    for name, n in (("entities", a.n_entities), ("materials", a.n_materials), ("emissions", a.n_emissions), ("spectra", a.n_spectra)):
+        for i in range(n):
+            assert struct_bytes(getattr(a, name)[i]) == struct_bytes(getattr(b, name)[i]), (name, i)
+    assert struct_bytes(a.camera) == struct_bytes(b.camera)
+    if check_settings:
+        assert struct_bytes(a.settings) == struct_bytes(b.settings)
+
+
+def two_quads_by_hand():
+    """The scene of golden/scenes/two_quads.prc assembled through SceneBuilder."""
+    b = scene.SceneBuilder(48, 32)
+    s = b.settings
+    s.spectral_start, s.spectral_end = 400.0, 700.0
+    s.max_ray_depth, s.soft_max_ray_depth, s.mis = 8, 3, abi.MIS_POWER
+    s.aa_sampler, s.aa_samples = abi.SAMPLER_SOBOL, 4
+    s.filter, s.filter_radius = abi.FILTER_TRIANGLE, 1
+    s.mapper = abi.MAPPER_SPD_HERO
+    cam_t = np.eye(4, dtype=np.float32); cam_t[:3, 3] = [0, 0.5, 3]
+    b.set_camera(cam_t, width=0.8, height=0.6, near=0.01, far=50, local_direction=(0, 0, -1), local_up=(0, 1, 0), local_right=(1, 0, 0))
+    lamp = b.diffuse_emission(b.smul(b.illuminant_d65(), b.illum(4, 4, 3)))
+    white = b.lambert(b.refl(0.7, 0.7, 0.7))
+    red = b.lambert(b.refl(0.6, 0.1, 0.1), two_sided=False)
+    grey = b.lambert(b.spectrum_const(0.5))
+    tab = b.lambert(b.spectrum_table(400.0, 700.0, [0.1, 0.5, 0.9, 0.2]))
+    fp = [[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1], [0, 0, 0]]
+    b.add_mesh(fp, [[0, 3, 4], [3, 2, 4], [4, 2, 1], [0, 4, 1]], white, normals=[[0, 1, 0]] * 5, face_materials=[white, white, red, red],
+               transform=np.diag([2, 1, 2, 1]).astype(np.float32))
+    qp = [[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]]
+    t = np.eye(4, dtype=np.float32)            # T * R(euler 180 about x) * S(0.5)
+    c, sn = np.float32(np.cos(np.pi)), np.float32(np.sin(np.pi))
+    return b, lamp, grey, tab, qp
+
+
+def test_syntax_errors_are_reported_with_line_numbers():
+    lib = abi.load()
+    for src, needle in (("(scene :render_width 4", "missing ')'"), ("(scene ]", "mismatched"), ("scene", "expected '('"),
+                        ("(scene :k 'abc)", "unterminated string"), ("(scene\n\n  (camera :name #))", "line 3"), ("( :a 1)", "identifier")):
+        h = C.c_void_p()
+        assert lib.prgpu_prc_load_string(src.encode(), None, None, C.byref(h)) == -1
+        assert needle in lib.prgpu_prc_last_error().decode(), (src, lib.prgpu_prc_last_error())
+
+
+MINIMAL = """(scene :render_width 8 :render_height 8
+  (camera :name 'c' :type 'standard')
+  (material :name 'm' :type 'diffuse')
+  (mesh :name 'q' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,2]))
+  %s
+  (entity :name 'e' :type 'mesh' :mesh 'q' :materials 'm')
+)"""
+
+
+def test_defaults_follow_the_reference():
+    s = scene.PrcScene(source=MINIMAL % "")
+    d, st = s.desc, s.desc.settings
+    ref = abi.default_settings(8, 8)
+    assert struct_bytes(st) == struct_bytes(ref)  # RenderSettings.cpp / manager defaults: sobol 128, mitchell r=1, spd cmis, depth 64/4
+    cam = d.camera
+    assert list(cam.local_direction) == [0, 1, 0] and list(cam.local_up) == [0, 0, 1] and list(cam.local_right) == [1, 0, 0]  # ICamera.cpp:5-7
+    assert cam.width == 1 and cam.height == 1 and cam.near_t == np.float32(1e-6) and np.isinf(cam.far_t) and cam.fstop == 0
+    assert d.materials[0].two_sided == 1 and d.spectra[d.materials[0].albedo].kind == abi.SPEC_CONST and d.spectra[d.materials[0].albedo].p[0] == 1.0
+    assert d.entities[0].emission == abi.INVALID_ID and d.entities[0].has_normals == 0 and d.n_triangles == 1
+    assert s.spp == 128
+
+
+@pytest.mark.parametrize("block,code,needle", [
+    ("(entity :name 's' :type 'sphere' :radius 1)", -4, "entity type 'sphere'"),
+    ("(material :name 'g' :type 'glass')", -4, "material type 'glass'"),
+    ("(light :name 'sky' :type 'sky')", -4, "(light"),
+    ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
+    ("(sampler :type 'halton')", -4, "sampler type 'halton'"),
+    ("(filter :type 'lanczos')", -4, "filter type 'lanczos'"),
+    ("(spectral_mapper :type 'cie')", -4, "spectral mapper 'cie'"),
+    ("(emission :name 'x' :type 'standard' :radiance (illuminant 'A'))", -4, "illuminant 'a'"),
+    ("(material :name 'x' :type 'diffuse' :albedo (checkerboard 1 2))", -4, "checkerboard"),
+    ("(entity :name 'e2' :type 'mesh' :mesh 'nope' :materials 'm')", -1, "unknown mesh 'nope'"),
+    ("(mesh :name 'bad' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,5]))", -1, "out of range"),
+    ("(mesh :name 'bad' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,2,0,1]))", -1, "triangle or quad"),
+    ("(include 'does_not_exist.inc')", -1, "cannot open"),
+])
+def test_unsupported_and_invalid_blocks_fail_loudly(block, code, needle):
+    with pytest.raises(abi.PrgpuError) as e:
+        scene.PrcScene(source=MINIMAL % block)
+    assert e.value.args[1] == code and needle in e.value.args[0], e.value.args
+
+
+def test_force_direct_and_overrides():
+    s = scene.PrcScene(source=MINIMAL % "(integrator :type 'vcm' :max_ray_depth 6)", force_direct=True, width=20, height=10, spp=3, seed=7)
+    st = s.desc.settings
+    assert (st.width, st.height, st.aa_samples, st.seed, st.max_ray_depth) == (20, 10, 3, 7, 64)
+    assert any("replaced by 'direct'" in w for w in s.warnings)
+
+
+def test_two_quads_scene_matches_hand_assembly():
+    s = scene.PrcScene(path=os.path.join(SCENES, "two_quads.prc"))
+    d = s.desc
+    assert any("output specification ignored" in w for w in s.warnings)
+    b, lamp, grey, tab, qp = two_quads_by_hand()
+    # lamp: T(0,1.5,0) * Rx(180 deg) * S(0.5);   card: T * R(quaternion 45 deg about y) * S(0.3,1,0.3)
+    got_lamp = np.array(list(d.entities[1].transform), dtype=np.float32).reshape(4, 4)
+    want_lamp = np.array([[0.5, 0, 0, 0], [0, -0.5, 0, 1.5], [0, 0, -0.5, 0], [0, 0, 0, 1]], dtype=np.float32)
+    assert np.allclose(got_lamp, want_lamp, atol=1e-6)
+    got_card = np.array(list(d.entities[2].transform), dtype=np.float32).reshape(4, 4)
+    r = np.sqrt(0.5)
+    want_card = np.array([[r * 0.3, 0, r * 0.3, 0.5], [0, 1, 0, 0.3], [-r * 0.3, 0, r * 0.3, 0.2], [0, 0, 0, 1]], dtype=np.float32)
+    assert np.allclose(got_card, want_card, atol=1e-6)
+    b.add_mesh(qp, [[0, 1, 2, 3]], grey, emission=lamp, transform=got_lamp)   # rotation arithmetic checked above; reuse the exact matrices
+    b.add_mesh(qp, [[0, 1, 2, 3]], tab, transform=got_card)
+    want = b.build()  # keep the owner of the arrays alive while comparing
+    assert_same_desc(d, want.desc)
+    # quads split like Embree quads: (v0,v1,v3), (v2,v3,v1)
+    idx = arr(d.indices, 3 * d.n_triangles, np.uint32).reshape(-1, 3)
+    assert idx[4].tolist() == [5, 6, 8] and idx[5].tolist() == [7, 8, 6]
+    assert arr(d.tri_material, d.n_triangles, np.uint32).tolist() == [0, 0, 1, 1, 2, 2, 3, 3]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_EXAMPLES, "cornellbox.prc")), reason="reference checkout not present (GPU box)")
+def test_reference_cornellbox_prc_equals_the_committed_fixture_scene():
+    """examples/cornellbox.prc (+ its include) parsed by the C++ loader == the scene assembled from pearray_amd/data/cornell_box.json
+    (numbers extracted from the same file by tools/extract_fixtures.py).  The file asks for 'vcm': config C1 renders it with `direct`."""
+    s = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "cornellbox.prc"), force_direct=True, width=256, height=256, spp=16)
+    want = scene.cornell_box(256, 256, spp=16)
+    assert_same_desc(s.desc, want.desc, check_settings=False)
+    st = s.desc.settings
+    assert (st.width, st.height, st.aa_sampler, st.aa_samples) == (256, 256, abi.SAMPLER_MJITT, 16)
+    assert struct_bytes(st) == struct_bytes(want.desc.settings)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference checkout not present (GPU box)")
+def test_every_reference_example_either_loads_or_names_what_is_missing():
+    lib = abi.load()
+    loaded, refused = [], []
+    for name in sorted(os.listdir(REF_EXAMPLES)):
+        if not name.endswith(".prc"):
+            continue
+        h = C.c_void_p()
+        opt = abi.PrcOptions(0, 0, 0, 1, 0)
+        rc = lib.prgpu_prc_load_file(os.path.join(REF_EXAMPLES, name).encode(), C.byref(opt), C.byref(h))
+        if rc == 0:
+            loaded.append(name)
+            lib.prgpu_prc_free(h)
+        else:
+            assert rc == -4, (name, rc, lib.prgpu_prc_last_error())   # valid DataLisp, unsupported feature -- never a syntax error
+            assert "not supported" in lib.prgpu_prc_last_error().decode() or "not available" in lib.prgpu_prc_last_error().decode(), name
+            refused.append(name)
+    assert "cornellbox.prc" in loaded
