@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PRGPU_API_VERSION 1
+#define PRGPU_API_VERSION 2
 #define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
 
 enum {
@@ -64,9 +64,13 @@ enum {
  *   PARAMETRIC_SCALED  ParametricScaledSpectralNode      src/loader/shader/ConstNode.cpp:78-88
  *   TABLE              EquidistantSpectrum(View)Node     src/loader/shader/EquidistantSpectrumNode.h:19-28
  *   MUL                MulSpectralMath (`smul`)          src/plugins/main/node/SpectralMathNode.cpp:73,97
+ *   SELLMEIER          SellmeierIndexNode (`lookup_index`, `sellmeier_index`): n = sqrt(1 + sum_i B_i l^2 / (l^2 - C_i)), l in um
+ *                                                         src/plugins/main/node/ReflectiveNode.cpp:105-150,224-232, base/math/Scattering.h:219-242;
+ *                      table_count = 2N (N <= 4) values at table_offset: B_0..B_{N-1}, C_0..C_{N-1}.  The only node kind that is
+ *                      NodeFlag::SpectralVarying (a delta material whose index uses it collapses the hero wavelengths).
  * MUL operands must have a smaller index than the node itself (topological order). */
 enum { PRGPU_SPEC_CONST = 0, PRGPU_SPEC_PARAMETRIC = 1, PRGPU_SPEC_PARAMETRIC_SCALED = 2,
-       PRGPU_SPEC_TABLE = 3, PRGPU_SPEC_MUL = 4 };
+       PRGPU_SPEC_TABLE = 3, PRGPU_SPEC_MUL = 4, PRGPU_SPEC_SELLMEIER = 5 };
 
 typedef struct prgpu_spectrum {
 	uint32_t kind;
@@ -78,12 +82,18 @@ typedef struct prgpu_spectrum {
 	uint32_t lhs, rhs;      /* MUL: operand node indices */
 } prgpu_spectrum;
 
-enum { PRGPU_MAT_LAMBERT = 0 }; /* src/plugins/main/materials/lambert.cpp */
+/* LAMBERT     src/plugins/main/materials/lambert.cpp
+ * DIELECTRIC  src/plugins/main/materials/dielectric.cpp (smooth glass: delta reflection/refraction chosen by the Fresnel term;
+ *             against air n = 1.0002926; a wavelength dependent index (SELLMEIER) collapses the path to its hero wavelength) */
+enum { PRGPU_MAT_LAMBERT = 0, PRGPU_MAT_DIELECTRIC = 1 };
 typedef struct prgpu_material {
 	uint32_t kind;
-	uint32_t albedo;     /* spectrum index */
-	uint32_t two_sided;  /* lambert `two_sided`, default true (lambert.cpp:108) */
-	uint32_t reserved;
+	uint32_t albedo;       /* spectrum index.  LAMBERT: `albedo`; DIELECTRIC: `specularity` (reflection tint, default 1) */
+	uint32_t two_sided;    /* LAMBERT `two_sided`, default true (lambert.cpp:108) */
+	uint32_t ior;          /* DIELECTRIC: `index`/`eta`/`ior` spectrum (default 1.55) */
+	uint32_t transmission; /* DIELECTRIC: `transmission` tint spectrum, or PRGPU_INVALID_ID = same as specularity (dielectric.cpp:92-96) */
+	uint32_t thin;         /* DIELECTRIC: `thin` sheet approximation (dielectric.cpp:69-72,98-101) */
+	uint32_t reserved[2];
 } prgpu_material;
 
 enum { PRGPU_EMS_DIFFUSE = 0 }; /* src/plugins/main/emissions/diffuse.cpp */

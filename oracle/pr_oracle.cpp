@@ -727,9 +727,75 @@ Blob spectrum_eval(const Scene& s, uint32_t id, const Blob& wl)
 		return b;
 	}
 	case PRGPU_SPEC_MUL: return spectrum_eval(s, n.lhs, wl) * spectrum_eval(s, n.rhs, wl);
+	case PRGPU_SPEC_SELLMEIER: { // Scattering::sellmeier (base/math/Scattering.h:219-242), SellmeierIndexNode::eval (ReflectiveNode.cpp:113-125)
+		const uint32_t nc = n.table_count / 2;
+		const float* B	  = &s.tables[n.table_offset];
+		const float* C	  = B + nc;
+		Blob b;
+		for (int k = 0; k < 4; ++k) {
+			const float lq	= wl[k] / 1000;
+			const float lq2 = lq * lq;
+			float value		= 1.0f;
+			for (uint32_t i = 0; i < nc; ++i)
+				value += B[i] * lq2 / (lq2 - C[i]);
+			b[k] = std::sqrt(value);
+		}
+		return b;
+	}
 	}
 	return blob(0);
 }
+inline bool spectrum_is_varying(const Scene& s, uint32_t id) { return s.spectra[id].kind == PRGPU_SPEC_SELLMEIER; } // NodeFlag::SpectralVarying, INode.h:12
+
+// ---- delta dielectric helpers -----------------------------------------------------------------------
+// diffProd / sumProd (base/config/MathGlue.inl:6-25): explicit fused multiply-adds
+inline float diff_prod(float a, float b, float c, float d)
+{
+	const float cd	= c * d;
+	const float err = std::fma(-c, d, cd);
+	const float dop = std::fma(a, b, -cd);
+	return dop + err;
+}
+inline float sum_prod(float a, float b, float c, float d) { return std::fma(a, b, c * d); }
+// Scattering::refraction_angle (base/math/Scattering.h:51-62)
+inline float refraction_angle(float cosI, float eta)
+{
+	if (std::signbit(cosI)) {
+		cosI = -cosI;
+		eta	 = 1 / eta;
+	}
+	const float k = 1 - (eta * eta) * (1 - cosI * cosI);
+	return k < 0 ? -1.0f : std::sqrt(k);
+}
+// Fresnel::dielectric (base/math/Fresnel.h:9-31)
+inline float fresnel_dielectric(float cosI, float n_in, float n_out)
+{
+	if (std::signbit(cosI)) { // negative hemisphere: swap the media
+		cosI			= -cosI;
+		const float tmp = n_in;
+		n_in			= n_out;
+		n_out			= tmp;
+	}
+	const float cosT = refraction_angle(cosI, n_in / n_out);
+	if (cosT < 0)
+		return 1;
+	const float perp = diff_prod(n_in, cosI, n_out, cosT) / sum_prod(n_in, cosI, n_out, cosT);
+	const float para = diff_prod(n_out, cosI, n_in, cosT) / sum_prod(n_out, cosI, n_in, cosT);
+	return std::min(std::max(sum_prod(para, para, perp, perp) / 2.0f, 0.0f), 1.0f);
+}
+// Scattering::refract in shading space (base/math/Scattering.h:94-105); total reflection returns reflect(wIn)
+inline V3 refract_shading(float eta, V3 w)
+{
+	const bool neg = std::signbit(w.z);
+	if (neg) {
+		eta = 1 / eta;
+		w	= -w;
+	}
+	const float cosT = refraction_angle(w.z, eta);
+	V3 r			 = cosT < 0.0f ? v3(-w.x, -w.y, w.z) : normalized(v3(-w.x * eta, -w.y * eta, -cosT));
+	return neg ? -r : r;
+}
+constexpr float DIELECTRIC_AIR = 1.0002926f; // dielectric.cpp:17
 // spectral/SpectralRange.h + INode::spectralRange (core/shader/INode.h:48): unbounded = (-1,-1)
 struct Range {
 	float start = -1, end = -1;
@@ -1337,8 +1403,10 @@ inline void push_fragment(const Scene& s, TileOut& out, int lx, int ly, const Bl
 }
 
 // RussianRoulette::probability (vcm/RussianRoulette.h:22-35), table built in scene_create
-inline float rr_probability(const Scene& s, uint32_t path_length)
+inline float rr_probability(const Scene& s, uint32_t path_length, bool delta = false)
 {
+	if (delta) // mIgnoreDelta (default true): delta materials are never terminated by roulette
+		return 1.0f;
 	return path_length < s.rr_prob.size() ? s.rr_prob[path_length] : s.rr_prob.back();
 }
 
@@ -1492,7 +1560,9 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		// tangent-space view vector: MaterialSampleContext::fromIP (MaterialContext.h:27-44)
 		const V3 Vt = to_tangent_space(N, gp.Nx, gp.Ny, -ray.d);
 
-		if (cfg.nee && !hasEmission && !s.light_entity.empty()) {
+		const bool deltaMat = mat.kind == PRGPU_MAT_DIELECTRIC; // IMaterial::hasOnlyDeltaDistribution
+
+		if (cfg.nee && !deltaMat && !hasEmission && !s.light_entity.empty()) { // direct.cpp:100-101
 			// ---- handleNEE (direct.cpp:233-352)
 			do {
 				float selPdf;
@@ -1588,7 +1658,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		// ---- handleScattering (direct.cpp:170-230)
 		cur.last_pos = P;
 		cur.last_n	 = N;
-		const float scatProb = rr_probability(s, pathLength); // RussianRoulette::check :37-48
+		const float scatProb = rr_probability(s, pathLength, deltaMat); // RussianRoulette::check :37-48
 		if (scatProb <= PR_EPS)
 			break;
 		if (scatProb < 1.0f) {
@@ -1596,10 +1666,32 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 			if (rp > scatProb)
 				break;
 		}
-		// LambertMaterial::sample (lambert.cpp:53-73)
 		V3 Lt;
 		Blob integral_weight, pdf_s;
-		if (!mat.two_sided && Vt.z < 0.0f) {
+		bool heroCollapsing = false;
+		if (deltaMat) {
+			// DielectricMaterial::sample (dielectric.cpp:60-114), camera rays (no eta^2 factor)
+			pdf_s		   = blob(1);
+			const Blob n2  = spectrum_eval(s, mat.ior, ray.wl);
+			float F		   = fresnel_dielectric(Vt.z, DIELECTRIC_AIR, n2[0]);
+			if (mat.thin && F < 1.0f)
+				F += (1 - F) * F / (F + 1);
+			const Blob rWeight = spectrum_eval(s, mat.albedo, ray.wl);
+			if (rng_float(rnd) <= F) {
+				Lt				= v3(-Vt.x, -Vt.y, Vt.z); // Scattering::reflect
+				integral_weight = rWeight;
+			} else {
+				const Blob tWeight = mat.transmission != INVALID ? spectrum_eval(s, mat.transmission, ray.wl) : rWeight;
+				if (mat.thin) {
+					Lt				= -Vt;
+					integral_weight = tWeight;
+				} else {
+					Lt = refract_shading(DIELECTRIC_AIR / n2[0], Vt);
+					integral_weight = (std::signbit(Lt.z) == std::signbit(Vt.z)) ? rWeight : tWeight; // sameHemisphere: total reflection
+				}
+			}
+			heroCollapsing = spectrum_is_varying(s, mat.ior); // isDelta && isSpectralVarying (MaterialData.h:22)
+		} else if (!mat.two_sided && Vt.z < 0.0f) { // LambertMaterial::sample (lambert.cpp:53-73)
 			Lt = v3(0, 0, 0);
 			integral_weight = blob(0);
 			pdf_s = blob(0);
@@ -1612,14 +1704,20 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				Lt = -Lt;
 		}
 		const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt)); // MaterialSampleOutput::globalL
-		cur.last_delta	  = false;
+		cur.last_delta	  = deltaMat;
 		cur.prev_path_pdf = cur.path_pdf;
 		cur.path_pdf	  = cur.path_pdf * (pdf_s * scatProb);
 		if (all_le(cur.path_pdf, PDF_EPS))
 			break;
 		cur.throughput = cur.throughput * integral_weight;
+		if (heroCollapsing) { // direct.cpp:212-215
+			cur.throughput = cur.throughput * hero_only();
+			cur.path_pdf   = cur.path_pdf * hero_only();
+		}
 		if (is_zero(cur.throughput, PR_EPS))
 			break;
+		if (heroCollapsing)
+			ray.mono = true; // RayFlag::Monochrome is OR-ed into the next ray (direct.cpp:220-223, Ray.h:113)
 		// next ray (Ray::next, ray/Ray.h:102-122); Walker loop bound (vcm/Walker.h:26)
 		const V3 oN = dot(L, N) < 0 ? -N : N;
 		ray.o		= safe_position(P, L, oN);
@@ -1789,16 +1887,21 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("material index out of range");
 	for (uint32_t i = 0; i < d->n_spectra; ++i) {
 		const prgpu_spectrum& n = s.spectra[i];
-		if (n.kind > PRGPU_SPEC_MUL)
+		if (n.kind > PRGPU_SPEC_SELLMEIER)
 			return fail("unknown spectrum kind");
+		if (n.kind == PRGPU_SPEC_SELLMEIER && (n.table_count < 2 || n.table_count > 8 || (n.table_count & 1) || n.table_offset + n.table_count > d->n_spectral_table_values))
+			return fail("sellmeier coefficients out of range");
 		if (n.kind == PRGPU_SPEC_MUL && (n.lhs >= i || n.rhs >= i))
 			return fail("MUL operands must precede the node");
 		if (n.kind == PRGPU_SPEC_TABLE && (n.table_count < 2 || n.table_offset + n.table_count > d->n_spectral_table_values))
 			return fail("spectrum table out of range");
 	}
-	for (const auto& m : s.materials)
-		if (m.kind != PRGPU_MAT_LAMBERT || m.albedo >= d->n_spectra)
+	for (const auto& m : s.materials) {
+		if (m.kind > PRGPU_MAT_DIELECTRIC || m.albedo >= d->n_spectra)
 			return fail("bad material");
+		if (m.kind == PRGPU_MAT_DIELECTRIC && (m.ior >= d->n_spectra || (m.transmission != INVALID && m.transmission >= d->n_spectra)))
+			return fail("bad dielectric material");
+	}
 	for (const auto& e : s.emissions)
 		if (e.kind != PRGPU_EMS_DIFFUSE || e.radiance >= d->n_spectra)
 			return fail("bad emission");
@@ -2140,6 +2243,15 @@ void orc_safe_position(const float p[3], const float d[3], const float n[3], flo
 	out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 float orc_rr_probability(orc_scene* h, uint32_t L) { return rr_probability(h->s, L); }
+float orc_fresnel_dielectric(float cosI, float n_in, float n_out) { return fresnel_dielectric(cosI, n_in, n_out); }
+void orc_refract(float eta, const float w[3], float out[3])
+{
+	const V3 r = refract_shading(eta, v3(w[0], w[1], w[2]));
+	out[0] = r.x;
+	out[1] = r.y;
+	out[2] = r.z;
+}
+
 void orc_camera_ray(orc_scene* h, float px, float py, float r1, float r2, float org[3], float dir[3])
 {
 	V3 o, d;

@@ -9,11 +9,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libprgpu.so")
 
-PRGPU_API_VERSION = 1
+PRGPU_API_VERSION = 2
 INVALID_ID = 0xFFFFFFFF
 
-SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL = range(5)
-MAT_LAMBERT = 0
+SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER = range(6)
+MAT_LAMBERT, MAT_DIELECTRIC = 0, 1
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL = range(3)
 MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO = range(3)
@@ -32,7 +32,8 @@ class Spectrum(C.Structure):
 
 
 class Material(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("albedo", C.c_uint32), ("two_sided", C.c_uint32), ("reserved", C.c_uint32)]
+    _fields_ = [("kind", C.c_uint32), ("albedo", C.c_uint32), ("two_sided", C.c_uint32), ("ior", C.c_uint32),
+                ("transmission", C.c_uint32), ("thin", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class Emission(C.Structure):

@@ -123,6 +123,7 @@ struct PathState {
 constexpr uint32_t FLAG_MONO		  = 1u << 8;
 constexpr uint32_t FLAG_LAST_DELTA	  = 1u << 9;
 constexpr uint32_t FLAG_LAST_EMISSIVE = 1u << 10;
+constexpr uint32_t FLAG_GROUP_MONO	  = 1u << 11; // the camera ray started monochrome (ray-group importance, RenderTile.cpp:126-127)
 
 // ---- vector helpers -------------------------------------------------------------------------------
 struct V3 {
@@ -450,6 +451,56 @@ __device__ __forceinline__ bool box_hit(const RayPre& r, const float* lo, const 
 	// eps_t (8e-6 * largest scene coordinate) the absolute error of the triangle test's t.
 	return t0 <= t1 * 1.000001f + r.eps_t;
 }
+// ---- delta dielectric helpers (same operations as the checker) ---------------------------------------------------
+// diffProd / sumProd (base/config/MathGlue.inl:6-25): explicit fused multiply-adds
+__device__ __forceinline__ float diff_prod(float a, float b, float c, float d)
+{
+	const float cd	= c * d;
+	const float err = __fmaf_rn(-c, d, cd);
+	const float dop = __fmaf_rn(a, b, -cd);
+	return dop + err;
+}
+__device__ __forceinline__ float sum_prod(float a, float b, float c, float d) { return __fmaf_rn(a, b, c * d); }
+// Scattering::refraction_angle (base/math/Scattering.h:51-62)
+__device__ __forceinline__ float refraction_angle(float cosI, float eta)
+{
+	if (signbit(cosI)) {
+		cosI = -cosI;
+		eta	 = 1 / eta;
+	}
+	const float k = 1 - (eta * eta) * (1 - cosI * cosI);
+	return k < 0 ? -1.0f : sqrtf(k);
+}
+// Fresnel::dielectric (base/math/Fresnel.h:9-31)
+__device__ __forceinline__ float fresnel_dielectric(float cosI, float n_in, float n_out)
+{
+	if (signbit(cosI)) {
+		cosI			= -cosI;
+		const float tmp = n_in;
+		n_in			= n_out;
+		n_out			= tmp;
+	}
+	const float cosT = refraction_angle(cosI, n_in / n_out);
+	if (cosT < 0)
+		return 1;
+	const float perp = diff_prod(n_in, cosI, n_out, cosT) / sum_prod(n_in, cosI, n_out, cosT);
+	const float para = diff_prod(n_out, cosI, n_in, cosT) / sum_prod(n_out, cosI, n_in, cosT);
+	return fminf(fmaxf(sum_prod(para, para, perp, perp) / 2.0f, 0.0f), 1.0f);
+}
+// Scattering::refract in shading space (base/math/Scattering.h:94-105)
+__device__ __forceinline__ V3 refract_shading(float eta, V3 w)
+{
+	const bool neg = signbit(w.z);
+	if (neg) {
+		eta = 1 / eta;
+		w	= -w;
+	}
+	const float cosT = refraction_angle(w.z, eta);
+	V3 r			 = cosT < 0.0f ? v3(-w.x, -w.y, w.z) : normalized(v3(-w.x * eta, -w.y * eta, -cosT));
+	return neg ? -r : r;
+}
+constexpr float DIELECTRIC_AIR = 1.0002926f; // dielectric.cpp:17
+
 // same acceptance rule for a box entry distance that was computed earlier (stack entries, re-checks)
 __device__ __forceinline__ bool still_reachable(const RayPre& r, float tentry, float limit)
 {

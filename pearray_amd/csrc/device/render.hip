@@ -309,6 +309,21 @@ __device__ __forceinline__ Blob spectrum_leaf(const DevScene& sc, const prgpu_sp
 			b.v[k] = equidistant_lookup(data, (int)n.table_count, n.wl_start, delta, wl.v[k]);
 		return b;
 	}
+	case PRGPU_SPEC_SELLMEIER: { // Scattering::sellmeier (base/math/Scattering.h:219-242)
+		const uint32_t nc = n.table_count / 2;
+		const float* B	  = sc.tables + n.table_offset;
+		const float* C	  = B + nc;
+		Blob b;
+		for (int k = 0; k < 4; ++k) {
+			const float lq	= wl.v[k] / 1000;
+			const float lq2 = lq * lq;
+			float value		= 1.0f;
+			for (uint32_t i = 0; i < nc; ++i)
+				value += B[i] * lq2 / (lq2 - C[i]);
+			b.v[k] = sqrtf(value);
+		}
+		return b;
+	}
 	default: return blob(0);
 	}
 }
@@ -556,7 +571,7 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	ps.throughput[slot] = make_float4(1, 1, 1, 1);
 	ps.path_pdf[slot]  = make_float4(1, 1, 1, 1);
 	ps.prev_pdf[slot]  = make_float4(1, 1, 1, 1);
-	ps.flags[slot]	   = 0u | (mono ? FLAG_MONO : 0u) | FLAG_LAST_DELTA;
+	ps.flags[slot]	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA;
 	ps.iter_xyz[3 * pixel + 0] = 0.0f;
 	ps.iter_xyz[3 * pixel + 1] = 0.0f;
 	ps.iter_xyz[3 * pixel + 2] = 0.0f;
@@ -661,7 +676,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	Blob throughput		 = from4(ps.throughput[slot]);
 	Blob path_pdf		 = from4(ps.path_pdf[slot]);
 	Blob prev_pdf		 = from4(ps.prev_pdf[slot]);
-	const Blob grp_imp	 = mono ? hero_only() : blob(1.0f); // RenderTile.cpp:126-127
+	const Blob grp_imp	 = (flags & FLAG_GROUP_MONO) ? hero_only() : blob(1.0f); // RenderTile.cpp:126-127 (importance of the ray group)
 	const float blend	 = 1.0f;
 	const bool power_mis = cfg.mis == PRGPU_MIS_POWER;
 	const Blob hf		 = mono ? hero_only() : blob(1.0f);
@@ -729,7 +744,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			const prgpu_material mat = sc.materials[gp.material];
 			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
 			uint64_t rnd			 = ps.rng[pixel];
-			if (cfg.nee && !hasEmission && sc.n_lights) {
+			const bool deltaMat		 = mat.kind == PRGPU_MAT_DIELECTRIC; // IMaterial::hasOnlyDeltaDistribution
+			if (cfg.nee && !deltaMat && !hasEmission && sc.n_lights) { // direct.cpp:100-101
 				// ---- handleNEE
 				do {
 					float selPdf;
@@ -819,7 +835,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			flags = hasEmission ? (flags | FLAG_LAST_EMISSIVE) : (flags & ~FLAG_LAST_EMISSIVE);
 
 			// ---- handleScattering
-			const float scatProb = rr_probability(sc, pathLength);
+			const float scatProb = deltaMat ? 1.0f : rr_probability(sc, pathLength); // RussianRoulette: delta materials are never terminated
 			bool cont			 = !(scatProb <= PR_EPS);
 			if (cont && scatProb < 1.0f) {
 				const float rp = rng_float(rnd);
@@ -829,7 +845,30 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			if (cont) {
 				V3 Lt;
 				Blob integral_weight, pdf_s;
-				if (!mat.two_sided && Vt.z < 0.0f) {
+				bool heroCollapsing = false;
+				if (deltaMat) {
+					// DielectricMaterial::sample (dielectric.cpp:60-114), camera rays
+					pdf_s		  = blob(1);
+					const Blob n2 = spectrum_eval(sc, mat.ior, wl);
+					float F		  = fresnel_dielectric(Vt.z, DIELECTRIC_AIR, n2.v[0]);
+					if (mat.thin && F < 1.0f)
+						F += (1 - F) * F / (F + 1);
+					const Blob rWeight = spectrum_eval(sc, mat.albedo, wl);
+					if (rng_float(rnd) <= F) {
+						Lt				= v3(-Vt.x, -Vt.y, Vt.z);
+						integral_weight = rWeight;
+					} else {
+						const Blob tWeight = mat.transmission != INVALID ? spectrum_eval(sc, mat.transmission, wl) : rWeight;
+						if (mat.thin) {
+							Lt				= -Vt;
+							integral_weight = tWeight;
+						} else {
+							Lt				= refract_shading(DIELECTRIC_AIR / n2.v[0], Vt);
+							integral_weight = (signbit(Lt.z) == signbit(Vt.z)) ? rWeight : tWeight;
+						}
+					}
+					heroCollapsing = sc.spectra[mat.ior].kind == PRGPU_SPEC_SELLMEIER; // isDelta && isSpectralVarying (MaterialData.h:22)
+				} else if (!mat.two_sided && Vt.z < 0.0f) {
 					Lt				= v3(0, 0, 0);
 					integral_weight = blob(0);
 					pdf_s			= blob(0);
@@ -842,15 +881,21 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						Lt = -Lt;
 				}
 				const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt));
-				flags &= ~FLAG_LAST_DELTA;
+				flags	 = deltaMat ? (flags | FLAG_LAST_DELTA) : (flags & ~FLAG_LAST_DELTA);
 				prev_pdf = path_pdf;
 				path_pdf = path_pdf * (pdf_s * scatProb);
 				if (all_le(path_pdf, PDF_EPS))
 					cont = false;
 				if (cont) {
 					throughput = throughput * integral_weight;
+					if (heroCollapsing) { // direct.cpp:212-215,220-223: the path continues on its hero wavelength only
+						throughput = throughput * hero_only();
+						path_pdf   = path_pdf * hero_only();
+					}
 					if (is_zero(throughput, PR_EPS))
 						cont = false;
+					if (heroCollapsing)
+						flags |= FLAG_MONO;
 				}
 				if (cont) {
 					const V3 oN		 = dot(L, N) < 0 ? -N : N;
@@ -866,7 +911,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						ps.flags[slot]		= (flags & ~0xFFu) | nd;
 						atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
 						atomicAdd(&bs.v[PRGPU_STAT_BOUNCE_RAYS], 1u);
-						if (mono)
+						if (flags & FLAG_MONO)
 							atomicAdd(&bs.v[PRGPU_STAT_MONOCHROME_RAYS], 1u);
 					}
 				}

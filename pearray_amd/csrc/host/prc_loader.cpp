@@ -223,6 +223,15 @@ struct Loader {
 			out.tables.push_back(std::max(0.0f, values[i]));
 		return add_spectrum(s);
 	}
+	uint32_t spectrum_sellmeier(const float* b, const float* c, int n)
+	{
+		prgpu_spectrum s = blank(PRGPU_SPEC_SELLMEIER);
+		s.table_offset	 = (uint32_t)out.tables.size();
+		s.table_count	 = (uint32_t)(2 * n);
+		out.tables.insert(out.tables.end(), b, b + n);
+		out.tables.insert(out.tables.end(), c, c + n);
+		return add_spectrum(s);
+	}
 	// a value in a spectral slot: number | (refl r g b) | (illum r g b) | (illuminant "D65") | (spectrum ...) | (smul a b)
 	uint32_t spectral_node(const Value& v, const Group& owner, const char* key)
 	{
@@ -291,7 +300,40 @@ struct Loader {
 				fail(PRGPU_EUNSUPPORTED, where(e) + ": nested smul is not supported (operands must be leaves)");
 			return add_spectrum(s);
 		}
-		fail(PRGPU_EUNSUPPORTED, "spectral expression " + where(e) + " is not supported (number, refl, illum, illuminant, spectrum, smul are)");
+		if (id == "lookup_index") { // ReflectiveNode.cpp:224-246,387-396: tabulated Sellmeier coefficients (refractiveindex.info)
+			std::string name = lower(e.at(0).type == Value::STRING ? e.at(0).s : get_string(e, "name", "bk7"));
+			static const struct {
+				const char* name;
+				int n;
+				float b[4], c[4];
+			} table[] = {
+				{ "bk7", 3, { 1.03961212f, 0.231792344f, 1.01046945f }, { 0.00600069867f, 0.0200179144f, 103.560653f } },
+				{ "glass", 3, { 1.03961212f, 0.231792344f, 1.01046945f }, { 0.00600069867f, 0.0200179144f, 103.560653f } },
+				{ "h2o", 4, { 5.684027565e-1f, 1.726177391e-1f, 2.086189578e-2f, 1.130748688e-1f }, { 5.101829712e-3f, 1.821153936e-2f, 2.620722293e-2f, 1.069792721e1f } },
+				{ "water", 4, { 5.684027565e-1f, 1.726177391e-1f, 2.086189578e-2f, 1.130748688e-1f }, { 5.101829712e-3f, 1.821153936e-2f, 2.620722293e-2f, 1.069792721e1f } },
+				{ "diamond", 2, { 0.3306f, 4.3356f }, { 0.030625f, 0.011236f } },
+			};
+			if (name == "vacuum" || name == "none")
+				return spectrum_const(1.0f);
+			if (name == "air")
+				return spectrum_const(1.000277f);
+			for (const auto& t : table)
+				if (name == t.name)
+					return spectrum_sellmeier(t.b, t.c, t.n);
+			fail(PRGPU_EINVAL, where(e) + ": unknown lookup_index '" + name + "'");
+		}
+		if (id == "sellmeier_index") { // (sellmeier_index b1 c1 b2 c2 ...), ReflectiveNode.cpp:330-360 (constant coefficients only)
+			const size_t n = e.anonymous_count();
+			if (n < 2 || n > 8 || (n & 1) || !e.all_numbers())
+				fail(PRGPU_EUNSUPPORTED, where(e) + ": sellmeier_index takes 1..4 constant (B, C) pairs");
+			float b[4], c[4];
+			for (size_t i = 0; i < n / 2; ++i) {
+				b[i] = (float)e.at(2 * i).number();
+				c[i] = (float)e.at(2 * i + 1).number();
+			}
+			return spectrum_sellmeier(b, c, (int)(n / 2));
+		}
+		fail(PRGPU_EUNSUPPORTED, "spectral expression " + where(e) + " is not supported (number, refl, illum, illuminant, spectrum, smul, lookup_index are)");
 	}
 	uint32_t spectral_param(const Group& g, std::initializer_list<const char*> keys, float def)
 	{
@@ -422,13 +464,23 @@ struct Loader {
 		const std::string name = get_string(g, "name", "");
 		if (name.empty())
 			fail(PRGPU_EINVAL, where(g) + ": material without a name");
-		if (type != "diffuse" && type != "lambert")
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert only)");
 		prgpu_material m;
 		std::memset(&m, 0, sizeof(m));
-		m.kind		= PRGPU_MAT_LAMBERT;
-		m.albedo	= spectral_param(g, { "albedo", "base", "diffuse" }, 1.0f);
-		m.two_sided = get_bool(g, "two_sided", true) ? 1 : 0;
+		if (type == "glass" || type == "dielectric") { // dielectric.cpp:150-197
+			if (g.get("roughness") || g.get("roughness_x") || g.get("roughness_y"))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": rough dielectrics are not supported (smooth glass only)");
+			m.kind		   = PRGPU_MAT_DIELECTRIC;
+			m.ior		   = spectral_param(g, { "index", "eta", "ior" }, 1.55f);
+			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);
+			m.transmission = g.get("transmission") ? spectral_node(*g.get("transmission"), g, "transmission") : PRGPU_INVALID_ID;
+			m.thin		   = get_bool(g, "thin", false) ? 1 : 0;
+		} else if (type == "diffuse" || type == "lambert") {
+			m.kind		= PRGPU_MAT_LAMBERT;
+			m.albedo	= spectral_param(g, { "albedo", "base", "diffuse" }, 1.0f);
+			m.two_sided = get_bool(g, "two_sided", true) ? 1 : 0;
+		} else {
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert and smooth glass/dielectric are)");
+		}
 		material_ids[name] = (uint32_t)out.materials.size();
 		out.materials.push_back(m);
 	}

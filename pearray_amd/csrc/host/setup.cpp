@@ -496,8 +496,10 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 			return bad("material index out of range");
 	for (uint32_t i = 0; i < d->n_spectra; ++i) {
 		const prgpu_spectrum& n = d->spectra[i];
-		if (n.kind > PRGPU_SPEC_MUL)
+		if (n.kind > PRGPU_SPEC_SELLMEIER)
 			return bad("unknown spectrum kind");
+		if (n.kind == PRGPU_SPEC_SELLMEIER && (n.table_count < 2 || n.table_count > 8 || (n.table_count & 1u) || uint64_t(n.table_offset) + n.table_count > d->n_spectral_table_values))
+			return bad("sellmeier coefficients out of range (1..4 B/C pairs in the table array)");
 		if (n.kind == PRGPU_SPEC_TABLE && (n.table_count < 2 || uint64_t(n.table_offset) + n.table_count > d->n_spectral_table_values || !(n.wl_end > n.wl_start)))
 			return bad("spectrum table out of range");
 		if (n.kind == PRGPU_SPEC_MUL) {
@@ -508,16 +510,25 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		}
 	}
 	for (uint32_t i = 0; i < d->n_materials; ++i) {
-		if (d->materials[i].kind != PRGPU_MAT_LAMBERT)
-			return bad("only lambert materials are implemented", PRGPU_EUNSUPPORTED);
-		if (d->materials[i].albedo >= d->n_spectra)
+		const prgpu_material& m = d->materials[i];
+		if (m.kind != PRGPU_MAT_LAMBERT && m.kind != PRGPU_MAT_DIELECTRIC)
+			return bad("only lambert and (smooth) dielectric materials are implemented", PRGPU_EUNSUPPORTED);
+		if (m.albedo >= d->n_spectra)
 			return bad("material albedo index out of range");
+		if (m.kind == PRGPU_MAT_DIELECTRIC && (m.ior >= d->n_spectra || (m.transmission != PRGPU_INVALID_ID && m.transmission >= d->n_spectra)))
+			return bad("dielectric index / transmission spectrum out of range");
 	}
 	for (uint32_t i = 0; i < d->n_emissions; ++i) {
 		if (d->emissions[i].kind != PRGPU_EMS_DIFFUSE)
 			return bad("only diffuse emissions are implemented", PRGPU_EUNSUPPORTED);
 		if (d->emissions[i].radiance >= d->n_spectra)
 			return bad("emission radiance index out of range");
+		{
+			const prgpu_spectrum& r = d->spectra[d->emissions[i].radiance];
+			if (r.kind == PRGPU_SPEC_SELLMEIER
+				|| (r.kind == PRGPU_SPEC_MUL && (d->spectra[r.lhs].kind == PRGPU_SPEC_SELLMEIER || d->spectra[r.rhs].kind == PRGPU_SPEC_SELLMEIER)))
+				return bad("a refractive-index node cannot be used as radiance", PRGPU_EUNSUPPORTED);
+		}
 	}
 	return PRGPU_OK;
 }

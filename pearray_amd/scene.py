@@ -90,7 +90,34 @@ class SceneBuilder:
 
     # ---- materials / emissions ---------------------------------------------------------------------
     def lambert(self, albedo, two_sided=True):
-        m = abi.Material(abi.MAT_LAMBERT, albedo, 1 if two_sided else 0, 0)
+        m = abi.Material(abi.MAT_LAMBERT, albedo, 1 if two_sided else 0, 0, 0, 0)
+        self.materials.append(m)
+        return len(self.materials) - 1
+
+    SELLMEIER = {  # (lookup_index name): B and C coefficients, ReflectiveNode.cpp:224-232 (refractiveindex.info data)
+        "bk7": ([1.03961212, 0.231792344, 1.01046945], [0.00600069867, 0.0200179144, 103.560653]),
+        "h2o": ([5.684027565e-1, 1.726177391e-1, 2.086189578e-2, 1.130748688e-1], [5.101829712e-3, 1.821153936e-2, 2.620722293e-2, 1.069792721e1]),
+        "diamond": ([0.3306, 4.3356], [0.030625, 0.011236]),
+    }
+
+    def sellmeier(self, bs, cs):
+        """(sellmeier_index ...) / (lookup_index name): n = sqrt(1 + sum B l^2 / (l^2 - C)), ReflectiveNode.cpp:105-150"""
+        off = len(self.tables)
+        self.tables.extend(float(v) for v in list(bs) + list(cs))
+        return self._add_spec(kind=abi.SPEC_SELLMEIER, table_offset=off, table_count=2 * len(bs))
+
+    def lookup_index(self, name):
+        name = {"glass": "bk7", "water": "h2o"}.get(name.lower(), name.lower())
+        if name in ("vacuum", "none"):
+            return self.spectrum_const(1.0)
+        if name == "air":
+            return self.spectrum_const(1.000277)
+        return self.sellmeier(*self.SELLMEIER[name])
+
+    def dielectric(self, ior, specularity=None, transmission=None, thin=False):
+        """(material :type 'glass'), dielectric.cpp:150-197 (index default 1.55, tints default 1)"""
+        spec = self.spectrum_const(1.0) if specularity is None else specularity
+        m = abi.Material(abi.MAT_DIELECTRIC, spec, 0, ior, abi.INVALID_ID if transmission is None else transmission, 1 if thin else 0)
         self.materials.append(m)
         return len(self.materials) - 1
 
@@ -239,7 +266,7 @@ def load_prc(path, **overrides):
 
 # ---- stock scenes (BASELINE.json configs) -----------------------------------------------------------------
 
-def _cornell_into(b, data=None):
+def _cornell_into(b, data=None, material_override=None):
     if data is None:
         with open(os.path.join(_DATA, "cornell_box.json")) as f:
             data = json.load(f)
@@ -250,7 +277,8 @@ def _cornell_into(b, data=None):
     # block order of examples/cornellbox.prc (emission before the materials), so that ids equal those of the .prc loader
     radiance = b.smul(b.illuminant_d65(), b.illum(*data["emission"]["illum"]))  # (smul (illuminant "D65") (illum 17 12 4))
     ems = b.diffuse_emission(radiance)
-    mats = {name: b.lambert(b.refl(*m["refl"])) for name, m in data["materials"].items()}
+    mats = {name: (material_override[name](b) if material_override and name in material_override else b.lambert(b.refl(*m["refl"])))
+            for name, m in data["materials"].items()}
     for e in data["entities"]:
         b.add_mesh(e["p"], e["faces"], mats[e["material"]], normals=e["n"], emission=ems if e["emission"] else None,
                    transform=np.asarray(e["transform"], dtype=np.float32).reshape(4, 4))
@@ -264,6 +292,24 @@ def cornell_box(width=256, height=256, spp=16, sampler=abi.SAMPLER_MJITT, **sett
     for k, v in settings.items():
         setattr(b.settings, k, v)
     _cornell_into(b)
+    return b.build()
+
+
+def cornell_glassy(width=256, height=256, spp=16, ior="bk7", thin=False, tinted=False, sampler=abi.SAMPLER_MJITT, **settings):
+    """The Cornell box with glass boxes (examples/cornellbox_glassy.prc's tallBox material on both boxes): smooth dielectric with a
+    tabulated Sellmeier index (hero-wavelength collapse) or a constant index (`ior` a number)."""
+    b = SceneBuilder(width, height)
+    b.settings.aa_sampler, b.settings.aa_samples = sampler, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+
+    def glass(bb):
+        n = bb.lookup_index(ior) if isinstance(ior, str) else bb.spectrum_const(float(ior))
+        if tinted:
+            return bb.dielectric(n, specularity=bb.refl(0.9, 0.9, 0.9), transmission=bb.refl(0.4, 0.8, 0.5), thin=thin)
+        return bb.dielectric(n, thin=thin)
+
+    _cornell_into(b, material_override={"shortBox": glass, "tallBox": glass})
     return b.build()
 
 

@@ -78,6 +78,12 @@ def load():
     lib.orc_safe_position.argtypes = [_F32P] * 4
     lib.orc_rr_probability.restype = C.c_float
     lib.orc_rr_probability.argtypes = [C.c_void_p, C.c_uint32]
+    lib.orc_fresnel_dielectric.restype = C.c_float
+    lib.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.orc_refract.restype = None
+    lib.orc_refract.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.orc_spectrum_eval.restype = None
+    lib.orc_spectrum_eval.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.orc_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, _F32P, _F32P]
     lib.orc_wavelength_cdf.argtypes = [C.c_void_p, _U32P, C.POINTER(_F32P)]
     lib.orc_light_selector.argtypes = [C.c_void_p, _U32P, C.POINTER(_F32P), C.POINTER(_F32P)]

@@ -314,3 +314,43 @@ def test_prc_scene_renders_like_the_oracle():
     g, o = render_both(scene.PrcScene(source=src, include_dir=os.path.dirname(path), width=96, height=64, spp=6))   # default filter: persistent kernel
     assert_parity(g, o, exact=True)
     assert g.statistics()["pixel_samples"] == 96 * 64 * 6
+
+
+@pytest.mark.parametrize("kw", [dict(ior="bk7"), dict(ior=1.5), dict(ior=1.33, thin=True), dict(ior="diamond", tinted=True)])
+def test_glass_boxes_bit_exact(kw):
+    """Smooth dielectric (delta reflection / refraction by the Fresnel term, no NEE at the vertex, no roulette, hero-wavelength
+    collapse for a Sellmeier index incl. the reference's NaN-feedback quirk on monochrome NEE fragments): identical to the checker."""
+    g, o = render_both(scene.cornell_glassy(128, 128, spp=8, **kw))
+    assert_parity(g, o, exact=True)
+    assert (g.statistics()["monochrome_rays"] > 0) == isinstance(kw["ior"], str)
+
+
+def test_glass_in_every_pipeline(monkeypatch):
+    sc = scene.cornell_glassy(96, 96, spp=5, ior="bk7")
+    ref = _render_mode(monkeypatch, "lockstep", sc, [5])
+    for mode in ("streaming", "persistent"):
+        out = _render_mode(monkeypatch, mode, sc, [5])
+        for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+            assert np.array_equal(a, b), mode
+        assert ref[2] == out[2], mode
+
+
+def test_glass_scene_through_the_prc_loader():
+    src = """(scene :render_width 64 :render_height 64 :camera 'c'
+      (sampler :slot 'aa' :type 'mjitt' :sample_count 6)
+      (camera :name 'c' :type 'standard' :width 0.9 :height 0.9 :local_direction [0,0,-1] :local_up [0,1,0] :local_right [1,0,0] :position [0,0.6,3.2])
+      (emission :name 'lamp' :type 'standard' :radiance (smul (illuminant "D65") (illum 6 6 5)))
+      (material :name 'white' :type 'diffuse' :albedo (refl 0.7 0.7 0.7))
+      (material :name 'lampmat' :type 'diffuse' :albedo 0.5)
+      (material :name 'glass' :type 'glass' :index (lookup_index "bk7") :specularity 0.95 :transmission (refl 0.8 0.9 0.8))
+      (material :name 'water' :type 'dielectric' :index (lookup_index 'water') :thin true)
+      (mesh :name 'quad' (attribute :type 'p' [-1,0,-1],[1,0,-1],[1,0,1],[-1,0,1]) (faces [0,1,2,3]))
+      (entity :name 'floor' :type 'mesh' :mesh 'quad' :materials 'white' :scale 3)
+      (entity :name 'back' :type 'mesh' :mesh 'quad' :materials 'white' :rotation (euler 90 0 0) :position [0,1,-1.5] :scale 3)
+      (entity :name 'pane' :type 'mesh' :mesh 'quad' :materials 'glass' :rotation (euler 90 0 0) :position [0,0.6,0.5] :scale 0.5)
+      (entity :name 'film' :type 'mesh' :mesh 'quad' :materials 'water' :position [0.3,0.3,0.2] :scale 0.4)
+      (entity :name 'lamp' :type 'mesh' :mesh 'quad' :materials 'lampmat' :emission 'lamp' :rotation (euler 180 0 0) :position [0,2,0.5] :scale 0.4)
+    )"""
+    g, o = render_both(scene.PrcScene(source=src))
+    assert_parity(g, o, exact=True)
+    assert g.statistics()["monochrome_rays"] > 0
