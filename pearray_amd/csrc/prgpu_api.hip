@@ -62,7 +62,7 @@ struct prgpu_scene {
 	enum Mode { LOCKSTEP, STREAMING, PERSISTENT };
 	Mode mode = LOCKSTEP;
 	uint32_t pp_slots = 512;
-	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_occupancy = 3;
+	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 24, pp_occupancy = 3;
 	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
 	prd::TraceWorkspace ws;	   // workspace of the ray-service launches
@@ -332,6 +332,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		s->pp_occupancy = atoi(env);
 	if (const char* env = getenv("PRGPU_PP_SHADE_PARTIAL"))
 		s->pp_shade_partial = atoi(env);
+	if (const char* env = getenv("PRGPU_PP_BOTH"))
+		s->pp_both_below = atoi(env);
 	if (const char* env = getenv("PRGPU_PP_REFILL_MIN"))
 		s->pp_refill_min = atoi(env);
 	if (const char* env = getenv("PRGPU_PP_PARTIAL_ACT"))
@@ -642,7 +644,7 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	prd::PathState ps = s->ps;
 	ps.pixel		  = s->pp_pixel; // s->ps.pixel is the Morton-ordered list of owned pixels
 	s->time_begin(6, s->stream);
-	prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, iter_begin, iter_end, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act, s->pp_refill_min,
+	prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, iter_begin, iter_end, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act, s->pp_refill_min, s->pp_both_below,
 								s->pp_occupancy,
 								s->pp_next,
 								s->pp_error,

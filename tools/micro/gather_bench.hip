@@ -89,10 +89,12 @@ __global__ void __launch_bounds__(256) k_gather_dma(const Rec* __restrict__ recs
 	out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
-int main()
+int main(int argc, char** argv)
 {
 	const uint32_t n_recs = 600000; // ~77 MB like the 1M-triangle BVH
-	const int steps = 200, blocks = 256 * 5;
+	const int per_cu = argc > 1 ? atoi(argv[1]) : 5; // resident blocks of 256 threads per CU
+	const int steps = 200, blocks = 256 * per_cu;
+	printf("%d blocks per CU (%d waves per CU)\n", per_cu, 4 * per_cu);
 	Rec* recs; float* out;
 	hipMalloc(&recs, sizeof(Rec) * n_recs);
 	hipMalloc(&out, sizeof(float) * blocks * 256);
