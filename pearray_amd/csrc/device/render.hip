@@ -70,56 +70,6 @@ struct Stack {
 };
 static_assert((STACK_LDS & (STACK_LDS - 1)) == 0, "STACK_LDS must be a power of two");
 
-// The same stack with 4-byte entries: the record reference in the low `rb` bits (index + leaf flag; rb is chosen per scene) and
-// the entry distance in the remaining high bits as a truncated float (t >= 0, so the sign bit is dropped; truncation rounds
-// DOWN, which keeps the pop-time cull conservative -- it is an optimisation, the child boxes are tested exactly when the node is
-// visited).  Halves the LDS footprint of the stack; used by the persistent path kernel, whose LDS also holds the record
-// staging buffer of the cooperative fetch.
-struct PackedStack {
-	uint32_t* lds;
-	uint32_t* spill;
-	uint32_t spill_stride;
-	uint32_t rb; // bits of the reference code
-	int sp, base;
-	__device__ __forceinline__ void reset() { sp = base = 0; }
-	__device__ __forceinline__ uint32_t encode(uint32_t ref, float t) const
-	{
-		const uint32_t code = (ref & ((1u << (rb - 1)) - 1u)) | ((ref >> 31) << (rb - 1));
-		return (((__float_as_uint(t) << 1) >> rb) << rb) | code;
-	}
-	__device__ __forceinline__ uint2 decode(uint32_t e) const
-	{
-		const uint32_t code = e & ((1u << rb) - 1u);
-		const uint32_t ref	= (code & ((1u << (rb - 1)) - 1u)) | ((code >> (rb - 1)) << 31);
-		return make_uint2(ref, ((e >> rb) << rb) >> 1);
-	}
-	__device__ __forceinline__ void reserve(int k)
-	{
-		while (sp - base + k > STACK_LDS) {
-			if (base < STACK_SPILL)
-				spill[(uint32_t)base * spill_stride] = lds[(base & (STACK_LDS - 1)) * TRAV_BLOCK];
-			++base;
-		}
-	}
-	__device__ __forceinline__ void push_if(bool valid, uint32_t ref, float t)
-	{
-		lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK] = encode(ref, t);
-		sp += valid ? 1 : 0;
-	}
-	__device__ __forceinline__ uint2 pop()
-	{
-		--sp;
-		uint32_t e = lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK];
-		if (__builtin_expect(sp < base, 0)) {
-			base = sp;
-			if (sp >= STACK_SPILL)
-				return make_uint2(REC_EMPTY, 0x7F800000u);
-			e = spill[(uint32_t)sp * spill_stride];
-		}
-		return decode(e);
-	}
-};
-
 struct Trav {
 	RayPre r;
 	float tmin;
@@ -1105,17 +1055,15 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 // the pixel has all its samples the slot takes the next unrendered pixel from a global counter.  There is no grid-wide
 // barrier, no host round trip and no drain phase between path vertices; blocks never wait for each other, waves only
 // ever wait for waves of their own block (which are resident by construction).
-constexpr int PP_SLOTS_MAX		= 512;
+constexpr int PP_SLOTS_MAX		= 1024;
 constexpr uint32_t PP_EMPTY		= 0xFFFFFFFFu;
 constexpr uint32_t PP_ANY		= 0x80000000u; // ray entry: the slot's shadow ray (else its path ray)
 constexpr uint32_t PP_REGEN		= 0x80000000u; // shade entry: the slot's path has ended (else: shade the vertex at ps.hit)
 constexpr uint32_t PP_DEAD		= 0x100u;	   // pending word: no bounce ray follows the rays in flight
 constexpr uint32_t PP_SPIN_LIMIT = 1u << 24;   // safety net: an idle wave gives up (and flags an error) after this many polls
 
-constexpr int PP_STAGE_CHUNKS = 7; // 16-byte chunks of a record staged through LDS by the cooperative fetch (an inner node's 112 bytes)
 struct PPShared {
-	uint32_t stack[STACK_LDS * TRAV_BLOCK];					// PackedStack entries, [entry][lane]
-	float4 stage[(TRAV_BLOCK / 64) * 64 * PP_STAGE_CHUNKS]; // per wave: 64 records x 7 chunks
+	uint2 stack[STACK_LDS * TRAV_BLOCK];
 	uint32_t q_ray[2 * PP_SLOTS_MAX]; // a slot has at most two rays queued or in flight
 	uint32_t q_shade[PP_SLOTS_MAX];
 	uint32_t pending[PP_SLOTS_MAX];
@@ -1184,7 +1132,6 @@ struct PersistentArgs {
 	uint32_t shade_min; // shade as soon as this many vertices wait (<= 64)
 	uint32_t shade_partial; // ... or this many when no rays are queued and the wave has fewer than partial_act rays in flight
 	int partial_act;
-	uint32_t ref_bits;	 // PackedStack: bits of the record reference code (index bits + leaf flag)
 	int both_below;		 // a wave with fewer rays in flight than this steps inner nodes AND leaves in one step
 	uint32_t refill_min; // waves other than the block's first one refill only when at least this many rays are queued
 	unsigned long long* gstats;
@@ -1215,13 +1162,11 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	stats_init(sh.bs);
 	__syncthreads();
 
-	PackedStack st;
+	Stack st;
 	st.lds			= sh.stack + threadIdx.x;
 	st.spill_stride = gridDim.x * TRAV_BLOCK;
-	st.spill		= reinterpret_cast<uint32_t*>(a.spill) + (blockIdx.x * TRAV_BLOCK + threadIdx.x);
-	st.rb			= a.ref_bits;
+	st.spill		= a.spill + (blockIdx.x * TRAV_BLOCK + threadIdx.x);
 	st.reset();
-	float4* const stage = sh.stage + (threadIdx.x >> 6) * (64 * PP_STAGE_CHUNKS); // this wave's staging buffer
 	Trav s;
 	s.cur			  = REC_EMPTY;
 	s.any			  = false;
@@ -1379,56 +1324,12 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			const bool both		= n_inner + n_leaf < a.both_below;
 			const bool do_inner = both ? n_inner > 0 : n_inner >= n_leaf;
 			const bool go_inner = do_inner && at_inner, go_leaf = (both || !do_inner) && at_leaf;
-			// Cooperative record fetch.  A lane reading its own 128-byte record costs the texture path one cycle per lane and
-			// load instruction (64 different lines); instead eight neighbouring lanes read the eight 16-byte chunks of ONE record
-			// per instruction -- eight full lines per wave instruction -- and the records are handed to their owners through the
-			// wave's LDS staging buffer.  Measured on MI355X (tools/micro/gather_bench.hip): 72 G records/s per-lane vs 140 G
-			// records/s cooperative.  Chunk 7 (leaves only) is read by the owner itself.
-			const unsigned long long want = __ballot(go_inner || go_leaf);
-			float4 q7 = make_float4(0, 0, 0, 0);
-			if (want != 0ull) {
-				const uint32_t my_idx = s.cur & ~REC_LEAF_BIT;
-				const uint32_t g = lane >> 3, j = lane & 7u;
-				if (go_leaf)
-					q7 = reinterpret_cast<const float4*>(sc.recs + my_idx)[7];
-				// All eight loads must be in flight together (one memory round trip per step).  Left to itself the compiler, short of
-				// registers under the 3-waves-per-SIMD budget, issues them one at a time through a single register quad; hence
-				// the asm block.  Lanes whose record nobody wants read record 0 (one shared line); what they stage is never read.
-				typedef float v4f __attribute__((ext_vector_type(4)));
-				const float4* ad[8];
-				const uint32_t pub_idx	 = (go_inner || go_leaf) ? my_idx : 0u; // what the other lanes see
-				const float4* const base = reinterpret_cast<const float4*>(sc.recs) + j;
-#pragma unroll
-				for (uint32_t i = 0; i < 8; ++i)
-					ad[i] = base + 8u * __shfl(pub_idx, 8u * i + g, 64); // record of lane 8 i + g, chunk j
-				v4f v0, v1, v2, v3, v4, v5, v6, v7;
-				asm volatile("global_load_dwordx4 %0, %8, off\n\t"
-							 "global_load_dwordx4 %1, %9, off\n\t"
-							 "global_load_dwordx4 %2, %10, off\n\t"
-							 "global_load_dwordx4 %3, %11, off\n\t"
-							 "global_load_dwordx4 %4, %12, off\n\t"
-							 "global_load_dwordx4 %5, %13, off\n\t"
-							 "global_load_dwordx4 %6, %14, off\n\t"
-							 "global_load_dwordx4 %7, %15, off\n\t"
-							 "s_waitcnt vmcnt(0)"
-							 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
-							 : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
-							 : "memory");
-				if (j < (uint32_t)PP_STAGE_CHUNKS) {
-					v4f* dst = reinterpret_cast<v4f*>(stage) + g * PP_STAGE_CHUNKS + j; // record 8 i + g, chunk j
-					dst[0 * 8 * PP_STAGE_CHUNKS] = v0;
-					dst[1 * 8 * PP_STAGE_CHUNKS] = v1;
-					dst[2 * 8 * PP_STAGE_CHUNKS] = v2;
-					dst[3 * 8 * PP_STAGE_CHUNKS] = v3;
-					dst[4 * 8 * PP_STAGE_CHUNKS] = v4;
-					dst[5 * 8 * PP_STAGE_CHUNKS] = v5;
-					dst[6 * 8 * PP_STAGE_CHUNKS] = v6;
-					dst[7 * 8 * PP_STAGE_CHUNKS] = v7;
-				}
-			}
+			// (Measured and dropped, see DESIGN.md: a cooperative fetch -- eight lanes reading one record's eight chunks, handed over
+			// through an LDS staging buffer: 2x the raw gather rate in tools/micro/gather_bench.hip but 11 % slower here; 4-byte
+			// packed stack entries to make room for a 4th wave per SIMD: +5 % time, and the 4th wave bought nothing.)
 			if (go_inner || go_leaf) {
-				const float4* own = stage + lane * PP_STAGE_CHUNKS;
-				const float4 q0 = own[0], q1 = own[1], q2 = own[2], q3 = own[3], q4 = own[4], q5 = own[5], q6 = own[6];
+				const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
+				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
 				if (go_inner) {
 					if (COUNT) {
 						cn_c += s.any ? 0 : 1;
@@ -1436,6 +1337,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					}
 					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, q3, q4, q5, q6);
 				} else {
+					const float4 q7 = rec[7];
 					if (COUNT) {
 						cl_c += s.any ? 0 : 1;
 						cl_a += s.any ? 1 : 0;
@@ -1649,12 +1551,6 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.partial_act	  = std::min(ws.refill_below, std::max(1, partial_act));
 	a.refill_min	  = (uint32_t)std::min(64, std::max(1, refill_min));
 	a.both_below	  = std::min(65, std::max(0, both_below));
-	{
-		uint32_t bits = 1;
-		while ((1ull << bits) < (unsigned long long)sc.n_inner + sc.n_leaf)
-			++bits;
-		a.ref_bits = bits + 1; // + leaf flag; at most 30 for 2^29 records, leaving >= 2 bits of entry distance
-	}
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	if (occupancy >= 3) {

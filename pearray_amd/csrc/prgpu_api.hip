@@ -62,7 +62,7 @@ struct prgpu_scene {
 	enum Mode { LOCKSTEP, STREAMING, PERSISTENT };
 	Mode mode = LOCKSTEP;
 	uint32_t pp_slots = 512;
-	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 24, pp_occupancy = 3;
+	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 0, pp_occupancy = 3;
 	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
 	prd::TraceWorkspace ws;	   // workspace of the ray-service launches

@@ -271,7 +271,8 @@ def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypat
     sc = scene.cornell_soup(192, 108, spp=4, n_triangles=20_000)
     ref = _render_mode(monkeypatch, "lockstep", sc, [4])
     for env in (dict(PRGPU_PP_SLOTS="256", PRGPU_PP_OCCUPANCY="2"), dict(PRGPU_PP_SLOTS="1024", PRGPU_PP_SHADE_PARTIAL="1"),
-                dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_PARTIAL_ACT="4")):
+                dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_PARTIAL_ACT="4"),
+                dict(PRGPU_PP_BOTH="65", PRGPU_PP_REFILL_MIN="16"), dict(PRGPU_PP_BOTH="20")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         out = _render_mode(monkeypatch, "persistent", sc, [4])
