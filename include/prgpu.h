@@ -84,16 +84,19 @@ typedef struct prgpu_spectrum {
 
 /* LAMBERT     src/plugins/main/materials/lambert.cpp
  * DIELECTRIC  src/plugins/main/materials/dielectric.cpp (smooth glass: delta reflection/refraction chosen by the Fresnel term;
- *             against air n = 1.0002926; a wavelength dependent index (SELLMEIER) collapses the path to its hero wavelength) */
-enum { PRGPU_MAT_LAMBERT = 0, PRGPU_MAT_DIELECTRIC = 1 };
+ *             against air n = 1.0002926; a wavelength dependent index (SELLMEIER) collapses the path to its hero wavelength)
+ * CONDUCTOR   src/plugins/main/materials/conductor.cpp (smooth metal: delta mirror weighted per wavelength by Fresnel::conductor)
+ */
+enum { PRGPU_MAT_LAMBERT = 0, PRGPU_MAT_DIELECTRIC = 1, PRGPU_MAT_CONDUCTOR = 2 };
 typedef struct prgpu_material {
 	uint32_t kind;
-	uint32_t albedo;       /* spectrum index.  LAMBERT: `albedo`; DIELECTRIC: `specularity` (reflection tint, default 1) */
+	uint32_t albedo;       /* spectrum index.  LAMBERT: `albedo`; DIELECTRIC, CONDUCTOR: `specularity` (reflection tint, default 1) */
 	uint32_t two_sided;    /* LAMBERT `two_sided`, default true (lambert.cpp:108) */
-	uint32_t ior;          /* DIELECTRIC: `index`/`eta`/`ior` spectrum (default 1.55) */
+	uint32_t ior;          /* DIELECTRIC: `index`/`eta`/`ior` spectrum (default 1.55); CONDUCTOR: `eta` (default 1.2) */
 	uint32_t transmission; /* DIELECTRIC: `transmission` tint spectrum, or PRGPU_INVALID_ID = same as specularity (dielectric.cpp:92-96) */
 	uint32_t thin;         /* DIELECTRIC: `thin` sheet approximation (dielectric.cpp:69-72,98-101) */
-	uint32_t reserved[2];
+	uint32_t k;            /* CONDUCTOR: `k`/`kappa` absorption index spectrum (default 2.605) */
+	uint32_t reserved;
 } prgpu_material;
 
 enum { PRGPU_EMS_DIFFUSE = 0 }; /* src/plugins/main/emissions/diffuse.cpp */

@@ -796,6 +796,29 @@ inline V3 refract_shading(float eta, V3 w)
 	return neg ? -r : r;
 }
 constexpr float DIELECTRIC_AIR = 1.0002926f; // dielectric.cpp:17
+// Fresnel::conductor (base/math/Fresnel.h:33-59)
+inline float fresnel_conductor(float cosI, float n_in, float n_out, float k)
+{
+	if (cosI < 0)
+		cosI = -cosI;
+	const float eta	   = n_out / n_in;
+	const float kappa  = k / n_in;
+	const float cosI2  = cosI * cosI;
+	const float sinI2  = 1 - cosI2;
+	const float eta2   = eta * eta;
+	const float kappa2 = kappa * kappa;
+	const float t0	   = eta2 - kappa2 - sinI2;
+	const float ap	   = std::sqrt(sum_prod(t0, t0, 4 * eta2, kappa2));
+	const float t1	   = ap + cosI2;
+	const float a	   = std::sqrt((ap + t0) / 2);
+	const float t2	   = 2 * cosI * a;
+	const float perp2  = (t1 - t2) / (t1 + t2);
+	const float t3	   = sum_prod(cosI2, ap, sinI2, sinI2);
+	const float t4	   = t2 * sinI2;
+	const float para2  = perp2 * (t3 - t4) / (t3 + t4);
+	const float R	   = (para2 + perp2) / 2;
+	return std::min(std::max(R, 0.0f), 1.0f);
+}
 // spectral/SpectralRange.h + INode::spectralRange (core/shader/INode.h:48): unbounded = (-1,-1)
 struct Range {
 	float start = -1, end = -1;
@@ -1560,7 +1583,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		// tangent-space view vector: MaterialSampleContext::fromIP (MaterialContext.h:27-44)
 		const V3 Vt = to_tangent_space(N, gp.Nx, gp.Ny, -ray.d);
 
-		const bool deltaMat = mat.kind == PRGPU_MAT_DIELECTRIC; // IMaterial::hasOnlyDeltaDistribution
+		const bool deltaMat = mat.kind != PRGPU_MAT_LAMBERT; // IMaterial::hasOnlyDeltaDistribution (dielectric, conductor)
 
 		if (cfg.nee && !deltaMat && !hasEmission && !s.light_entity.empty()) { // direct.cpp:100-101
 			// ---- handleNEE (direct.cpp:233-352)
@@ -1669,7 +1692,17 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		V3 Lt;
 		Blob integral_weight, pdf_s;
 		bool heroCollapsing = false;
-		if (deltaMat) {
+		if (mat.kind == PRGPU_MAT_CONDUCTOR) {
+			// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
+			pdf_s		   = blob(1);
+			const Blob eta = spectrum_eval(s, mat.ior, ray.wl), kk = spectrum_eval(s, mat.k, ray.wl);
+			Blob fresnel;
+			for (int i = 0; i < 4; ++i)
+				fresnel[i] = fresnel_conductor(std::fabs(Vt.z), 1.0f, eta[i], kk[i]);
+			integral_weight = fresnel * spectrum_eval(s, mat.albedo, ray.wl);
+			Lt				= v3(-Vt.x, -Vt.y, Vt.z);
+			heroCollapsing	= spectrum_is_varying(s, mat.ior) || spectrum_is_varying(s, mat.k);
+		} else if (deltaMat) {
 			// DielectricMaterial::sample (dielectric.cpp:60-114), camera rays (no eta^2 factor)
 			pdf_s		   = blob(1);
 			const Blob n2  = spectrum_eval(s, mat.ior, ray.wl);
@@ -1897,8 +1930,10 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("spectrum table out of range");
 	}
 	for (const auto& m : s.materials) {
-		if (m.kind > PRGPU_MAT_DIELECTRIC || m.albedo >= d->n_spectra)
+		if (m.kind > PRGPU_MAT_CONDUCTOR || m.albedo >= d->n_spectra)
 			return fail("bad material");
+		if (m.kind == PRGPU_MAT_CONDUCTOR && (m.ior >= d->n_spectra || m.k >= d->n_spectra))
+			return fail("bad conductor material");
 		if (m.kind == PRGPU_MAT_DIELECTRIC && (m.ior >= d->n_spectra || (m.transmission != INVALID && m.transmission >= d->n_spectra)))
 			return fail("bad dielectric material");
 	}
@@ -2244,6 +2279,7 @@ void orc_safe_position(const float p[3], const float d[3], const float n[3], flo
 }
 float orc_rr_probability(orc_scene* h, uint32_t L) { return rr_probability(h->s, L); }
 float orc_fresnel_dielectric(float cosI, float n_in, float n_out) { return fresnel_dielectric(cosI, n_in, n_out); }
+float orc_fresnel_conductor(float cosI, float n_in, float n_out, float k) { return fresnel_conductor(cosI, n_in, n_out, k); }
 void orc_refract(float eta, const float w[3], float out[3])
 {
 	const V3 r = refract_shading(eta, v3(w[0], w[1], w[2]));

@@ -13,7 +13,7 @@ PRGPU_API_VERSION = 2
 INVALID_ID = 0xFFFFFFFF
 
 SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER = range(6)
-MAT_LAMBERT, MAT_DIELECTRIC = 0, 1
+MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR = 0, 1, 2
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL = range(3)
 MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO = range(3)
@@ -33,7 +33,7 @@ class Spectrum(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("albedo", C.c_uint32), ("two_sided", C.c_uint32), ("ior", C.c_uint32),
-                ("transmission", C.c_uint32), ("thin", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+                ("transmission", C.c_uint32), ("thin", C.c_uint32), ("k", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Emission(C.Structure):

@@ -500,6 +500,29 @@ __device__ __forceinline__ V3 refract_shading(float eta, V3 w)
 	return neg ? -r : r;
 }
 constexpr float DIELECTRIC_AIR = 1.0002926f; // dielectric.cpp:17
+// Fresnel::conductor (base/math/Fresnel.h:33-59)
+__device__ __forceinline__ float fresnel_conductor(float cosI, float n_in, float n_out, float k)
+{
+	if (cosI < 0)
+		cosI = -cosI;
+	const float eta	   = n_out / n_in;
+	const float kappa  = k / n_in;
+	const float cosI2  = cosI * cosI;
+	const float sinI2  = 1 - cosI2;
+	const float eta2   = eta * eta;
+	const float kappa2 = kappa * kappa;
+	const float t0	   = eta2 - kappa2 - sinI2;
+	const float ap	   = sqrtf(sum_prod(t0, t0, 4 * eta2, kappa2));
+	const float t1	   = ap + cosI2;
+	const float a	   = sqrtf((ap + t0) / 2);
+	const float t2	   = 2 * cosI * a;
+	const float perp2  = (t1 - t2) / (t1 + t2);
+	const float t3	   = sum_prod(cosI2, ap, sinI2, sinI2);
+	const float t4	   = t2 * sinI2;
+	const float para2  = perp2 * (t3 - t4) / (t3 + t4);
+	const float R	   = (para2 + perp2) / 2;
+	return fminf(fmaxf(R, 0.0f), 1.0f);
+}
 
 // same acceptance rule for a box entry distance that was computed earlier (stack entries, re-checks)
 __device__ __forceinline__ bool still_reachable(const RayPre& r, float tentry, float limit)

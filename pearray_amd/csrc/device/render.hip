@@ -757,7 +757,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			const prgpu_material mat = sc.materials[gp.material];
 			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
 			uint64_t rnd			 = ps.rng[pixel];
-			const bool deltaMat		 = mat.kind == PRGPU_MAT_DIELECTRIC; // IMaterial::hasOnlyDeltaDistribution
+			const bool deltaMat		 = mat.kind != PRGPU_MAT_LAMBERT; // IMaterial::hasOnlyDeltaDistribution (dielectric, conductor)
 			if (cfg.nee && !deltaMat && !hasEmission && sc.n_lights) { // direct.cpp:100-101
 				// ---- handleNEE
 				do {
@@ -859,7 +859,17 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				V3 Lt;
 				Blob integral_weight, pdf_s;
 				bool heroCollapsing = false;
-				if (deltaMat) {
+				if (mat.kind == PRGPU_MAT_CONDUCTOR) {
+					// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
+					pdf_s		   = blob(1);
+					const Blob eta = spectrum_eval(sc, mat.ior, wl), kk = spectrum_eval(sc, mat.k, wl);
+					Blob fresnel;
+					for (int i = 0; i < 4; ++i)
+						fresnel.v[i] = fresnel_conductor(fabsf(Vt.z), 1.0f, eta.v[i], kk.v[i]);
+					integral_weight = fresnel * spectrum_eval(sc, mat.albedo, wl);
+					Lt				= v3(-Vt.x, -Vt.y, Vt.z);
+					heroCollapsing	= sc.spectra[mat.ior].kind == PRGPU_SPEC_SELLMEIER || sc.spectra[mat.k].kind == PRGPU_SPEC_SELLMEIER;
+				} else if (deltaMat) {
 					// DielectricMaterial::sample (dielectric.cpp:60-114), camera rays
 					pdf_s		  = blob(1);
 					const Blob n2 = spectrum_eval(sc, mat.ior, wl);

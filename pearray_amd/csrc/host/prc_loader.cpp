@@ -474,12 +474,20 @@ struct Loader {
 			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);
 			m.transmission = g.get("transmission") ? spectral_node(*g.get("transmission"), g, "transmission") : PRGPU_INVALID_ID;
 			m.thin		   = get_bool(g, "thin", false) ? 1 : 0;
+		} else if (type == "conductor" || type == "metal") { // conductor.cpp:95-125
+			if (g.get("roughness") || g.get("roughness_x") || g.get("roughness_y"))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": rough conductors are not supported (smooth metal only)");
+			m.kind		   = PRGPU_MAT_CONDUCTOR;
+			m.ior		   = spectral_param(g, { "eta", "index", "ior" }, 1.2f);
+			m.k			   = spectral_param(g, { "k", "kappa" }, 2.605f);
+			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);
+			m.transmission = PRGPU_INVALID_ID;
 		} else if (type == "diffuse" || type == "lambert") {
 			m.kind		= PRGPU_MAT_LAMBERT;
 			m.albedo	= spectral_param(g, { "albedo", "base", "diffuse" }, 1.0f);
 			m.two_sided = get_bool(g, "two_sided", true) ? 1 : 0;
 		} else {
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert and smooth glass/dielectric are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert, smooth glass/dielectric and smooth conductor/metal are)");
 		}
 		material_ids[name] = (uint32_t)out.materials.size();
 		out.materials.push_back(m);

@@ -511,8 +511,10 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 	}
 	for (uint32_t i = 0; i < d->n_materials; ++i) {
 		const prgpu_material& m = d->materials[i];
-		if (m.kind != PRGPU_MAT_LAMBERT && m.kind != PRGPU_MAT_DIELECTRIC)
-			return bad("only lambert and (smooth) dielectric materials are implemented", PRGPU_EUNSUPPORTED);
+		if (m.kind != PRGPU_MAT_LAMBERT && m.kind != PRGPU_MAT_DIELECTRIC && m.kind != PRGPU_MAT_CONDUCTOR)
+			return bad("only lambert, smooth dielectric and smooth conductor materials are implemented", PRGPU_EUNSUPPORTED);
+		if (m.kind == PRGPU_MAT_CONDUCTOR && (m.ior >= d->n_spectra || m.k >= d->n_spectra))
+			return bad("conductor eta / k spectrum out of range");
 		if (m.albedo >= d->n_spectra)
 			return bad("material albedo index out of range");
 		if (m.kind == PRGPU_MAT_DIELECTRIC && (m.ior >= d->n_spectra || (m.transmission != PRGPU_INVALID_ID && m.transmission >= d->n_spectra)))

@@ -90,7 +90,7 @@ class SceneBuilder:
 
     # ---- materials / emissions ---------------------------------------------------------------------
     def lambert(self, albedo, two_sided=True):
-        m = abi.Material(abi.MAT_LAMBERT, albedo, 1 if two_sided else 0, 0, 0, 0)
+        m = abi.Material(abi.MAT_LAMBERT, albedo, 1 if two_sided else 0, 0, 0, 0, 0)
         self.materials.append(m)
         return len(self.materials) - 1
 
@@ -117,8 +117,16 @@ class SceneBuilder:
     def dielectric(self, ior, specularity=None, transmission=None, thin=False):
         """(material :type 'glass'), dielectric.cpp:150-197 (index default 1.55, tints default 1)"""
         spec = self.spectrum_const(1.0) if specularity is None else specularity
-        m = abi.Material(abi.MAT_DIELECTRIC, spec, 0, ior, abi.INVALID_ID if transmission is None else transmission, 1 if thin else 0)
+        m = abi.Material(abi.MAT_DIELECTRIC, spec, 0, ior, abi.INVALID_ID if transmission is None else transmission, 1 if thin else 0, 0)
         self.materials.append(m)
+        return len(self.materials) - 1
+
+    def conductor(self, eta=None, k=None, specularity=None):
+        """(material :type 'conductor'|'metal'), conductor.cpp:95-125 (eta 1.2, k 2.605, tint 1 by default)"""
+        eta = self.spectrum_const(1.2) if eta is None else eta
+        k = self.spectrum_const(2.605) if k is None else k
+        spec = self.spectrum_const(1.0) if specularity is None else specularity
+        self.materials.append(abi.Material(abi.MAT_CONDUCTOR, spec, 0, eta, abi.INVALID_ID, 0, k))
         return len(self.materials) - 1
 
     def diffuse_emission(self, radiance):
@@ -310,6 +318,18 @@ def cornell_glassy(width=256, height=256, spp=16, ior="bk7", thin=False, tinted=
         return bb.dielectric(n, thin=thin)
 
     _cornell_into(b, material_override={"shortBox": glass, "tallBox": glass})
+    return b.build()
+
+
+def cornell_metal(width=256, height=256, spp=16, sampler=abi.SAMPLER_MJITT, **settings):
+    """The Cornell box with a default conductor on the tall box and a tinted, measured-like (tabulated eta/k) one on the short box."""
+    b = SceneBuilder(width, height)
+    b.settings.aa_sampler, b.settings.aa_samples = sampler, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+    gold = lambda bb: bb.conductor(eta=bb.spectrum_table(400.0, 700.0, [1.47, 1.38, 0.95, 0.35, 0.21, 0.16, 0.14]),
+                                   k=bb.spectrum_table(400.0, 700.0, [1.95, 1.91, 1.85, 2.37, 2.88, 3.30, 3.70]), specularity=bb.refl(0.95, 0.95, 0.95))
+    _cornell_into(b, material_override={"tallBox": lambda bb: bb.conductor(), "shortBox": gold})
     return b.build()
 
 

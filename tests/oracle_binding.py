@@ -80,6 +80,8 @@ def load():
     lib.orc_rr_probability.argtypes = [C.c_void_p, C.c_uint32]
     lib.orc_fresnel_dielectric.restype = C.c_float
     lib.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.orc_fresnel_conductor.restype = C.c_float
+    lib.orc_fresnel_conductor.argtypes = [C.c_float] * 4
     lib.orc_refract.restype = None
     lib.orc_refract.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.orc_spectrum_eval.restype = None

@@ -355,3 +355,21 @@ def test_glass_scene_through_the_prc_loader():
     g, o = render_both(scene.PrcScene(source=src))
     assert_parity(g, o, exact=True)
     assert g.statistics()["monochrome_rays"] > 0
+
+
+def test_metal_boxes_bit_exact():
+    g, o = render_both(scene.cornell_metal(128, 128, spp=8))
+    assert_parity(g, o, exact=True)
+    src = """(scene :render_width 40 :render_height 40
+      (sampler :slot 'aa' :type 'random' :sample_count 5)
+      (camera :name 'c' :type 'standard' :local_direction [0,0,-1] :local_up [0,1,0] :local_right [1,0,0] :position [0,0.8,3])
+      (emission :name 'lamp' :type 'standard' :radiance (illum 5 5 5))
+      (material :name 'white' :type 'diffuse' :albedo 0.6)
+      (material :name 'alu' :type 'metal' :eta 1.1 :k 6.8 :specularity (refl 0.9 0.9 0.95))
+      (mesh :name 'quad' (attribute :type 'p' [-1,0,-1],[1,0,-1],[1,0,1],[-1,0,1]) (faces [0,1,2,3]))
+      (entity :name 'floor' :type 'mesh' :mesh 'quad' :materials 'alu' :scale 2)
+      (entity :name 'back' :type 'mesh' :mesh 'quad' :materials 'white' :rotation (euler 90 0 0) :position [0,1,-1.2] :scale 2)
+      (entity :name 'lamp' :type 'mesh' :mesh 'quad' :materials 'white' :emission 'lamp' :rotation (euler 180 0 0) :position [0,2,0] :scale 0.3)
+    )"""
+    g, o = render_both(scene.PrcScene(source=src))
+    assert_parity(g, o, exact=True)

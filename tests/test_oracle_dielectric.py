@@ -101,3 +101,24 @@ def test_api_rejects_bad_dielectrics_without_a_gpu():
     h = C.c_void_p()
     rc = lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h))
     assert rc in (-1, -2)   # invalid description (or no device before validation) -- never accepted
+
+
+def test_reference_conductor_kats(lib):
+    # src/tests/fresnel.cpp, testcase Conductor: "Zero Dot" -> 1, "One Dot" -> 0.2, "Kappa 0" -> 0  (PR_CHECK_NEARLY_EQ)
+    assert abs(lib.orc_fresnel_conductor(0.0, 1.0, 1.0, 1.0) - 1.0) < 1e-5
+    assert abs(lib.orc_fresnel_conductor(1.0, 1.0, 1.0, 1.0) - 0.2) < 1e-5
+    assert abs(lib.orc_fresnel_conductor(0.45, 1.0, 1.0, 0.0)) < 1e-5
+    # k = 0 degenerates to the dielectric term
+    for c in (0.2, 0.7, 1.0):
+        assert abs(lib.orc_fresnel_conductor(c, 1.0, 1.5, 0.0) - lib.orc_fresnel_dielectric(c, 1.0, 1.5)) < 1e-5
+    assert lib.orc_fresnel_conductor(-0.3, 1.0, 0.2, 3.0) == lib.orc_fresnel_conductor(0.3, 1.0, 0.2, 3.0)
+
+
+def test_metal_boxes_render_sane():
+    sc = scene.cornell_metal(48, 48, spp=6)
+    a = ob.OracleScene(sc); a.render(6, threads=4)
+    xa, sa, fa = a.output()
+    assert np.isfinite(xa).all() and (xa >= 0).all() and (fa == 0).all()
+    assert a.statistics()["monochrome_rays"] == 0   # tabulated eta/k are not NodeFlag::SpectralVarying: no hero collapse
+    lam = ob.OracleScene(scene.cornell_box(48, 48, spp=6)); lam.render(6, threads=4)
+    assert 0.5 < xa.sum() / lam.output()[0].sum() < 1.5

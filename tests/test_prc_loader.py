@@ -102,6 +102,7 @@ def test_defaults_follow_the_reference():
     ("(entity :name 's' :type 'sphere' :radius 1)", -4, "entity type 'sphere'"),
     ("(material :name 'g' :type 'glass' :roughness 0.1)", -4, "rough dielectrics"),
     ("(material :name 'g' :type 'principled')", -4, "material type 'principled'"),
+    ("(material :name 'g' :type 'metal' :roughness_x 0.1)", -4, "rough conductors"),
     ("(light :name 'sky' :type 'sky')", -4, "(light"),
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
     ("(sampler :type 'halton')", -4, "sampler type 'halton'"),
