@@ -642,6 +642,109 @@ struct Loader {
 		out.entities.push_back(e);
 	}
 
+	// (embed :loader 'obj' :file 'x.obj' :name 'n' [:flipNormal bool]) -- SceneLoader.cpp:775-812 + archives/WavefrontLoader.cpp:24-170.
+	// The reference reads the file with tinyobjloader (un-vendored submodule external/tinyobjloader, PearCoding fork, branch master,
+	// no pinned revision; LoadObj(..., triangulate = true)).  Restated here from the OBJ format and tinyobj's documented behaviour:
+	// `v`/`vn` records, `f` corners "v", "v/vt", "v//vn", "v/vt/vn" with 1-based or negative (relative) indices, polygons
+	// triangulated as a fan around their first corner, all shapes merged into one mesh, materials ignored.  When the normal indices
+	// differ from the vertex indices the reference keeps a second index buffer (WavefrontLoader.cpp:55-64,118-128); this backend's
+	// meshes have one index per corner, so such a mesh is expanded to one vertex per face corner (same geometry, same normals).
+	void add_embed(const Group& g, const std::string& dir)
+	{
+		const std::string loader = lower(get_string(g, "loader", "obj"));
+		if (loader != "obj")
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": embed loader '" + loader + "' is not supported (obj only)");
+		std::string path = get_string(g, "file", "");
+		if (path.empty())
+			fail(PRGPU_EINVAL, where(g) + ": embed without a :file");
+		if (path[0] != '/' && !dir.empty())
+			path = dir + "/" + path;
+		std::ifstream f(path);
+		if (!f)
+			fail(PRGPU_EINVAL, where(g) + ": cannot open '" + path + "'");
+		const bool flip = get_bool(g, "flipNormal", false);
+		std::vector<float> v, vn;
+		struct Corner {
+			int v, n;
+		};
+		std::vector<std::vector<Corner>> faces;
+		std::string name = get_string(g, "name", ""), first_shape, line;
+		int line_no = 0;
+		while (std::getline(f, line)) {
+			++line_no;
+			std::istringstream ls(line);
+			std::string tag;
+			if (!(ls >> tag) || tag[0] == '#')
+				continue;
+			if (tag == "v" || tag == "vn") {
+				float x[3];
+				if (!(ls >> x[0] >> x[1] >> x[2]))
+					fail(PRGPU_EINVAL, path + ":" + std::to_string(line_no) + ": malformed '" + tag + "' record");
+				std::vector<float>& dst = tag == "v" ? v : vn;
+				for (float c : x)
+					dst.push_back(tag == "vn" && flip ? -c : c);
+			} else if (tag == "f") {
+				std::vector<Corner> face;
+				std::string tok;
+				while (ls >> tok) {
+					Corner c{ 0, 0 };
+					const size_t s1 = tok.find('/');
+					c.v				= std::atoi(tok.substr(0, s1).c_str());
+					if (s1 != std::string::npos) {
+						const size_t s2 = tok.find('/', s1 + 1);
+						if (s2 != std::string::npos && s2 + 1 < tok.size())
+							c.n = std::atoi(tok.substr(s2 + 1).c_str());
+					}
+					const int nv = (int)(v.size() / 3), nn = (int)(vn.size() / 3);
+					c.v = c.v < 0 ? nv + c.v : c.v - 1; // negative indices are relative to the records read so far
+					c.n = c.n < 0 ? nn + c.n : c.n - 1; // -1: no normal given
+					if (c.v < 0 || c.v >= nv || c.n >= nn)
+						fail(PRGPU_EINVAL, path + ":" + std::to_string(line_no) + ": face index out of range");
+					face.push_back(c);
+				}
+				if (face.size() < 3)
+					fail(PRGPU_EINVAL, path + ":" + std::to_string(line_no) + ": face with fewer than three corners");
+				faces.push_back(face);
+			} else if ((tag == "o" || tag == "g") && first_shape.empty()) {
+				ls >> first_shape;
+			}
+		}
+		if (v.empty() || faces.empty())
+			fail(PRGPU_EINVAL, path + ": no vertices or faces");
+		if (name.empty())
+			name = first_shape; // WavefrontLoader.cpp:150-153
+		if (name.empty())
+			fail(PRGPU_EINVAL, where(g) + ": embedded mesh has no name");
+		bool use_normals = !vn.empty(), same_index = true;
+		for (const auto& face : faces)
+			for (const Corner& c : face) {
+				if (c.n < 0)
+					use_normals = false;
+				if (c.n != c.v)
+					same_index = false;
+			}
+		Mesh m;
+		if (!use_normals || (same_index && vn.size() == v.size())) {
+			m.p = v;
+			if (use_normals)
+				m.n = vn;
+			for (const auto& face : faces)
+				for (size_t k = 1; k + 1 < face.size(); ++k)
+					m.faces.push_back({ (uint32_t)face[0].v, (uint32_t)face[k].v, (uint32_t)face[k + 1].v });
+		} else { // one vertex per face corner
+			for (const auto& face : faces) {
+				const uint32_t base = (uint32_t)(m.p.size() / 3);
+				for (const Corner& c : face) {
+					m.p.insert(m.p.end(), v.begin() + 3 * c.v, v.begin() + 3 * c.v + 3);
+					m.n.insert(m.n.end(), vn.begin() + 3 * c.n, vn.begin() + 3 * c.n + 3);
+				}
+				for (uint32_t k = 1; k + 1 < face.size(); ++k)
+					m.faces.push_back({ base, base + k, base + k + 1 });
+			}
+		}
+		meshes[name] = std::move(m);
+	}
+
 	void add_include(const Group& g, const std::string& dir) // SceneLoader.cpp:848-886
 	{
 		if (g.anonymous_count() != 1 || g.at(0).type != Value::STRING)
@@ -691,7 +794,9 @@ struct Loader {
 			add_camera(b);
 		else if (id == "output")
 			warn(where(b) + ": output specification ignored (the backend produces the XYZ frame, sample count and feedback planes)");
-		else if (id == "light" || id == "texture" || id == "node" || id == "graph" || id == "embed")
+		else if (id == "embed" || id == "graph")
+			add_embed(b, dir);
+		else if (id == "light" || id == "texture" || id == "node")
 			fail(PRGPU_EUNSUPPORTED, where(b) + ": block is not supported by this backend yet");
 		else if (id == "scene")
 			fail(PRGPU_EINVAL, where(b) + ": invalid inner scene entry");

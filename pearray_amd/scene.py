@@ -435,7 +435,7 @@ def cbox_eval(width=256, height=256, spp=128, **settings):
         T = np.eye(4, dtype=np.float32)
         if ent["position"]:
             T[:3, 3] = ent["position"]
-        b.add_mesh(ent["p"], ent["faces"], mats[ent["material"]], emission=ems if ent["emission"] else None, transform=T)
+        b.add_mesh(ent["p"], ent["faces"], mats[ent["material"]], normals=ent.get("n"), emission=ems if ent["emission"] else None, transform=T)
     cam = data["camera"]
     T = np.eye(4, dtype=np.float32)
     T[:3, 3] = cam["position"]

@@ -181,3 +181,45 @@ def test_every_reference_example_either_loads_or_names_what_is_missing():
             assert "not supported" in lib.prgpu_prc_last_error().decode() or "not available" in lib.prgpu_prc_last_error().decode(), name
             refused.append(name)
     assert "cornellbox.prc" in loaded
+
+
+def test_obj_embed_semantics(tmp_path):
+    """v / vn / f with the four corner forms, negative indices, polygons fanned, per-corner expansion when normal indices differ."""
+    (tmp_path / "m.obj").write_text("""# test mesh
+o tetra
+v 0 0 0
+v 1 0 0
+v 0 1 0
+v 0 0 1
+vn 0 0 -1
+vn 0 -1 0
+f 1//1 3//1 2//1
+f 1//2 2//2 4//2
+f -4/7/1 -1/8/1 -2/9/1
+""")
+    (tmp_path / "quad.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nv 0 1 0\nf 1 2 3 4 5\n")
+    src = MINIMAL % ("(embed :loader 'obj' :file 'm.obj') (embed :loader 'obj' :file 'quad.obj' :name 'pent')"
+                     "(entity :name 't' :type 'mesh' :mesh 'tetra' :materials 'm') (entity :name 'p' :type 'mesh' :mesh 'pent' :materials 'm')")
+    s = scene.PrcScene(source=src, include_dir=str(tmp_path))
+    d = s.desc
+    assert d.n_entities == 3 and d.entities[0].n_tris == 3 and d.entities[0].has_normals == 1 and d.entities[1].n_tris == 3 and d.entities[1].has_normals == 0
+    pos = arr(d.positions, 3 * d.n_vertices, np.float32).reshape(-1, 3)
+    nrm = arr(d.normals, 3 * d.n_vertices, np.float32).reshape(-1, 3)
+    idx = arr(d.indices, 3 * d.n_triangles, np.uint32).reshape(-1, 3)
+    # tetra: 9 expanded corners (normal index != vertex index); third face uses negative indices: v1, v4, v3 with normal 1
+    assert idx[:3].tolist() == [[0, 1, 2], [3, 4, 5], [6, 7, 8]]
+    assert pos[6:9].tolist() == [[0, 0, 0], [0, 0, 1], [0, 1, 0]] and nrm[6:9].tolist() == [[0, 0, -1]] * 3 and nrm[3:6].tolist() == [[0, -1, 0]] * 3
+    # pentagon: indexed, fanned around its first corner
+    assert (idx[3:6] - 9).tolist() == [[0, 1, 2], [0, 2, 3], [0, 3, 4]]
+    with pytest.raises(abi.PrgpuError) as e:
+        scene.PrcScene(source=MINIMAL % "(embed :loader 'ply' :file 'm.ply')", include_dir=str(tmp_path))
+    assert e.value.args[1] == -4
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_EXAMPLES, "evaluation", "scene.prc")), reason="reference checkout not present (GPU box)")
+def test_reference_evaluation_scene_equals_the_committed_fixture_scene():
+    """examples/evaluation/scene.prc (+ its eight OBJ meshes) through the C++ loader == pearray_amd/data/cbox_eval.json through SceneBuilder."""
+    s = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "evaluation", "scene.prc"))
+    want = scene.cbox_eval()
+    assert_same_desc(s.desc, want.desc)
+    assert any("output specification ignored" in w for w in s.warnings)
