@@ -29,7 +29,7 @@ def run(env, world, instrument=False):
     ctx.close()
     return dt / iters * 1e3, extra
 
-base = {"PRGPU_MODE": "persistent", "PRGPU_PP_BLOCKS_PER_CU": 3, "PRGPU_PP_REFILL": 48, "PRGPU_PP_SLOTS": 512, "PRGPU_PP_SHADE_MIN": 64, "PRGPU_PP_SHADE_PARTIAL": 16, "PRGPU_PP_PARTIAL_ACT": 64, "PRGPU_PP_REFILL_MIN": 1, "PRGPU_PP_BOTH": 24, "PRGPU_PP_OCCUPANCY": 3}
+base = {"PRGPU_MODE": "persistent", "PRGPU_PP_BLOCKS_PER_CU": 3, "PRGPU_PP_REFILL": 48, "PRGPU_PP_SLOTS": 512, "PRGPU_PP_SHADE_MIN": 64, "PRGPU_PP_SHADE_PARTIAL": 16, "PRGPU_PP_PARTIAL_ACT": 64, "PRGPU_PP_REFILL_MIN": 1, "PRGPU_PP_BOTH": 0, "PRGPU_PP_OCCUPANCY": 3}
 configs = [dict(base)]
 for name in sys.argv[1:]:
     c = dict(base)
