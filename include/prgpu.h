@@ -127,7 +127,8 @@ typedef struct prgpu_camera {
 	float fstop, aperture_radius; /* DOF active iff both > FLT_EPSILON (perspective.cpp:158) */
 } prgpu_camera;
 
-enum { PRGPU_SAMPLER_RANDOM = 0, PRGPU_SAMPLER_MJITT = 1, PRGPU_SAMPLER_SOBOL = 2 };
+/* RandomSampler.cpp, MultiJitteredSampler.cpp, SobolSampler.cpp, HaltonSampler.cpp (halton + hammersley) of src/plugins/main/sampler */
+enum { PRGPU_SAMPLER_RANDOM = 0, PRGPU_SAMPLER_MJITT = 1, PRGPU_SAMPLER_SOBOL = 2, PRGPU_SAMPLER_HALTON = 3, PRGPU_SAMPLER_HAMMERSLEY = 4 };
 enum { PRGPU_MAPPER_SPD_CMIS = 0, PRGPU_MAPPER_RANDOM = 1, PRGPU_MAPPER_SPD_HERO = 2 };
 enum { PRGPU_FILTER_BLOCK = 0, PRGPU_FILTER_TRIANGLE = 1, PRGPU_FILTER_GAUSSIAN = 2,
        PRGPU_FILTER_MITCHELL = 3 };
@@ -152,6 +153,9 @@ typedef struct prgpu_settings {
 	float    spectral_start, spectral_end;  /* 390, 830 */
 	uint32_t spectral_hero;          /* true */
 	uint32_t spectral_mono;          /* false; true => all four lanes at spectral_start */
+	uint32_t aa_base_x, aa_base_y;   /* HALTON / HAMMERSLEY radical-inverse bases; 0 = plugin defaults 13 / 47 (HaltonSampler.cpp:10-11) */
+	uint32_t aa_burnin;              /* index shift; 0 = plugin default: max(base_x, base_y) for halton, base_x for hammersley (:173,:191) */
+	uint32_t reserved;
 } prgpu_settings;
 
 typedef struct prgpu_scene_desc {

@@ -1141,6 +1141,24 @@ void geometry_point(const Scene& s, uint32_t tri, float u, float v, GeomPoint& g
 
 // ------------------------------------------------------------------------------------------------
 // samplers (RenderTile.cpp:33-44 slots; SamplerManager defaults)
+// HaltonSampler.cpp:12-22 (float arithmetic as written there, including the float division of the index)
+inline float halton(uint32_t index, uint32_t base)
+{
+	float result = 0;
+	float f		 = 1;
+	for (uint32_t i = index; i > 0;) {
+		f = f / base;
+		result += f * (i % base);
+		i = static_cast<uint32_t>(std::floor(i / static_cast<float>(base)));
+	}
+	return result;
+}
+inline void halton_params(const prgpu_settings& c, uint32_t& bx, uint32_t& by, uint32_t& burnin)
+{
+	bx	   = c.aa_base_x ? c.aa_base_x : 13;
+	by	   = c.aa_base_y ? c.aa_base_y : 47;
+	burnin = c.aa_burnin ? c.aa_burnin : (c.aa_sampler == PRGPU_SAMPLER_HALTON ? std::max(bx, by) : bx);
+}
 void setup_samplers(Scene& s)
 {
 	const prgpu_settings& c = s.cfg;
@@ -1153,6 +1171,16 @@ void setup_samplers(Scene& s)
 		s.mj_x				= (uint32_t)std::sqrt((float)bins);
 		s.mj_y				= (bins + s.mj_x - 1) / s.mj_x;
 		s.mj_seed			= 14512081u ^ rng_u32(aa);
+	} else if (c.aa_sampler == PRGPU_SAMPLER_HALTON || c.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) {
+		// HaltonSampler.cpp:30-42 / 77-89: tabulated at construction, no shuffle, no random draws
+		uint32_t bx, by, burnin;
+		halton_params(c, bx, by, burnin);
+		const uint32_t n = s.spp;
+		s.sobol2d.resize(2 * size_t(n));
+		for (uint32_t i = 0; i < n; ++i) {
+			s.sobol2d[2 * i]	 = halton(i + burnin, bx);
+			s.sobol2d[2 * i + 1] = c.aa_sampler == PRGPU_SAMPLER_HALTON ? halton(i + burnin, by) : (0.5f + i) / n;
+		}
 	} else if (c.aa_sampler == PRGPU_SAMPLER_SOBOL) {
 		// SobolSampler.cpp:27-55.  Direction numbers: dimension 0 = van der Corput (2^63 >> k),
 		// dimension 1 = v_k = v_{k-1} ^ (v_{k-1} >> 1) (SobolSamplerData.inl rows 0 and 1).
@@ -1199,6 +1227,19 @@ void setup_samplers(Scene& s)
 inline void aa_sample(const Scene& s, Rng& rnd, uint32_t index, float& x, float& y)
 {
 	switch (s.cfg.aa_sampler) {
+	case PRGPU_SAMPLER_HALTON:
+	case PRGPU_SAMPLER_HAMMERSLEY: { // HaltonSampler.cpp:44-53 / 91-100: table below the promised count, plain halton above
+		if (index < s.spp) {
+			x = s.sobol2d[2 * index];
+			y = s.sobol2d[2 * index + 1];
+		} else {
+			uint32_t bx, by, burnin;
+			halton_params(s.cfg, bx, by, burnin);
+			x = halton(index + burnin, bx);
+			y = halton(index + burnin, s.cfg.aa_sampler == PRGPU_SAMPLER_HALTON ? by : 47u);
+		}
+		break;
+	}
 	case PRGPU_SAMPLER_MJITT: { // MultiJitteredSampler.cpp:118-150 (PR_MJS_USE_RANDOM, PR_MJS_CLIP)
 		const uint32_t n  = std::max(1u, s.spp);
 		const uint32_t id = mjitt_permute(index, n, s.mj_seed * 0x51633e2d);
@@ -2278,6 +2319,7 @@ void orc_safe_position(const float p[3], const float d[3], const float n[3], flo
 	out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 float orc_rr_probability(orc_scene* h, uint32_t L) { return rr_probability(h->s, L); }
+float orc_halton(uint32_t index, uint32_t base) { return halton(index, base); }
 float orc_fresnel_dielectric(float cosI, float n_in, float n_out) { return fresnel_dielectric(cosI, n_in, n_out); }
 float orc_fresnel_conductor(float cosI, float n_in, float n_out, float k) { return fresnel_conductor(cosI, n_in, n_out, k); }
 void orc_refract(float eta, const float w[3], float out[3])

@@ -78,6 +78,7 @@ void     orc_filter_table(uint32_t kind, uint32_t radius, float* table /* (2r+1)
 void     orc_triangle_sample(const float u[2], float out[2]);
 void     orc_safe_position(const float p[3], const float d[3], const float n[3], float out[3]);
 float    orc_rr_probability(orc_scene* s, uint32_t path_length);
+float    orc_halton(uint32_t index, uint32_t base);                     /* HaltonSampler.cpp:12-22 */
 float    orc_fresnel_dielectric(float cosI, float n_in, float n_out);   /* Fresnel::dielectric, base/math/Fresnel.h:19-31 */
 float    orc_fresnel_conductor(float cosI, float n_in, float n_out, float k); /* Fresnel::conductor, base/math/Fresnel.h:33-59 */
 void     orc_refract(float eta, const float w[3], float out[3]);         /* Scattering::refract, base/math/Scattering.h:94-105 */

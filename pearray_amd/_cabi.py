@@ -15,7 +15,7 @@ INVALID_ID = 0xFFFFFFFF
 SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER = range(6)
 MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR = 0, 1, 2
 EMS_DIFFUSE = 0
-SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL = range(3)
+SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_HAMMERSLEY = range(5)
 MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO = range(3)
 FILTER_BLOCK, FILTER_TRIANGLE, FILTER_GAUSSIAN, FILTER_MITCHELL = range(4)
 MIS_BALANCE, MIS_POWER = range(2)
@@ -59,7 +59,8 @@ class Settings(C.Structure):
                 ("filter", C.c_uint32), ("filter_radius", C.c_uint32), ("max_ray_depth", C.c_uint32),
                 ("soft_max_ray_depth", C.c_uint32), ("mis", C.c_uint32), ("nee", C.c_uint32),
                 ("direct", C.c_uint32), ("emissive_scatter", C.c_uint32), ("spectral_start", C.c_float),
-                ("spectral_end", C.c_float), ("spectral_hero", C.c_uint32), ("spectral_mono", C.c_uint32)]
+                ("spectral_end", C.c_float), ("spectral_hero", C.c_uint32), ("spectral_mono", C.c_uint32),
+                ("aa_base_x", C.c_uint32), ("aa_base_y", C.c_uint32), ("aa_burnin", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SceneDesc(C.Structure):

@@ -84,6 +84,7 @@ struct DevScene {
 	DevCamera cam;
 	prgpu_settings cfg;
 	uint32_t spp, mj_x, mj_y, mj_seed;
+	uint32_t halton_bx, halton_by, halton_burnin; // radical-inverse bases / index shift beyond the tabulated samples
 	uint32_t single_tap; // filter has exactly one weight > eps (the centre): splat is per-pixel
 	float centre_weight;
 	float eps_t; // slab-test slack: 8e-6 * max |coordinate| over world vertices and the camera origin

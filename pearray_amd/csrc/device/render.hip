@@ -493,6 +493,18 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter)
 // ---- kernels ------------------------------------------------------------------------------------------------
 // RenderTile::constructCameraRay (RenderTile.cpp:71-132) + StreamPipeline::fillWithCameraRays (:83-133): starts the camera
 // path of sample `iter` of the slot's pixel (draws AA / lens / time / wavelength samples from the pixel's generator).
+// HaltonSampler.cpp:12-22 (float arithmetic as written there, including the float division of the index)
+__device__ __forceinline__ float halton(uint32_t index, uint32_t base)
+{
+	float result = 0;
+	float f		 = 1;
+	for (uint32_t i = index; i > 0;) {
+		f = f / base;
+		result += f * (i % base);
+		i = (uint32_t)floorf(i / (float)base);
+	}
+	return result;
+}
 __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState& ps, uint32_t slot, uint32_t iter, BlockStats& bs)
 {
 	const prgpu_settings& cfg = sc.cfg;
@@ -509,9 +521,12 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 		const float jy	  = rng_float(rnd);
 		ax				  = (sx + (sy + jx) / sc.mj_y) / sc.mj_x;
 		ay				  = (id + jy) / n;
-	} else if (cfg.aa_sampler == PRGPU_SAMPLER_SOBOL && iter < sc.spp) { // SobolSampler.cpp:67-73
+	} else if (cfg.aa_sampler >= PRGPU_SAMPLER_SOBOL && iter < sc.spp) { // SobolSampler.cpp:67-73, HaltonSampler.cpp:44-48,91-95: tabulated
 		ax = sc.sobol2d[2 * iter];
 		ay = sc.sobol2d[2 * iter + 1];
+	} else if (cfg.aa_sampler >= PRGPU_SAMPLER_HALTON) { // beyond the promised sample count: plain halton (HaltonSampler.cpp:49-52,96-100)
+		ax = halton(iter + sc.halton_burnin, sc.halton_bx);
+		ay = halton(iter + sc.halton_burnin, sc.halton_by);
 	} else { // RandomSampler.cpp:20-21
 		ax = rng_float(rnd);
 		ay = rng_float(rnd);

@@ -358,12 +358,24 @@ struct Loader {
 			kind = PRGPU_SAMPLER_SOBOL;
 		else if (std::find_if(std::begin(mj), std::end(mj), [&](const char* n) { return type == n; }) != std::end(mj))
 			kind = PRGPU_SAMPLER_MJITT;
+		else if (type == "halton")
+			kind = PRGPU_SAMPLER_HALTON;
+		else if (type == "hammersley")
+			kind = PRGPU_SAMPLER_HAMMERSLEY;
 		else
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": sampler type '" + type + "' is not supported (random, mjitt, sobol are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": sampler type '" + type + "' is not supported (random, mjitt, sobol, halton, hammersley are)");
 		const uint32_t count = (uint32_t)std::max(1.0, get_number(g, "sample_count", 128)); // DEF_SAMPLE_COUNT
 		if (slot == "aa" || slot == "pixel" || slot == "antialiasing") {
 			settings.aa_sampler = kind;
 			settings.aa_samples = count;
+			settings.aa_base_x = settings.aa_base_y = settings.aa_burnin = 0;
+			if (kind == PRGPU_SAMPLER_HALTON || kind == PRGPU_SAMPLER_HAMMERSLEY) { // HaltonSampler.cpp:169-192
+				settings.aa_base_x = (uint32_t)get_number(g, "base_x", 13);
+				settings.aa_base_y = (uint32_t)get_number(g, "base_y", 47);
+				settings.aa_burnin = (uint32_t)get_number(g, "burnin", kind == PRGPU_SAMPLER_HALTON ? std::max(settings.aa_base_x, settings.aa_base_y) : settings.aa_base_x);
+				if (settings.aa_base_x < 2 || settings.aa_base_y < 2)
+					fail(PRGPU_EINVAL, where(g) + ": halton bases must be >= 2");
+			}
 		} else if (slot == "lens") {
 			settings.lens_samples = count;
 		} else if (slot == "time" || slot == "t") {

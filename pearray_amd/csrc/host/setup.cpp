@@ -240,6 +240,29 @@ void sampler_tables(const prgpu_scene_desc* d, HostTables& t)
 		t.mj_x				= (uint32_t)std::sqrt((float)bins);
 		t.mj_y				= (bins + t.mj_x - 1) / t.mj_x;
 		t.mj_seed			= 14512081u ^ aa.next();
+	} else if (c.aa_sampler == PRGPU_SAMPLER_HALTON || c.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) {
+		// HaltonSampler.cpp:30-42 / 77-89: tabulated at construction, no shuffle, no random draws; the table shares the device
+		// array of the sobol samples (one AA sampler per scene)
+		const uint32_t bx = c.aa_base_x ? c.aa_base_x : 13, by = c.aa_base_y ? c.aa_base_y : 47;
+		const uint32_t burnin = c.aa_burnin ? c.aa_burnin : (c.aa_sampler == PRGPU_SAMPLER_HALTON ? std::max(bx, by) : bx);
+		auto halton = [](uint32_t index, uint32_t base) { // HaltonSampler.cpp:12-22, float arithmetic as written there
+			float result = 0, f = 1;
+			for (uint32_t i = index; i > 0;) {
+				f = f / base;
+				result += f * (i % base);
+				i = static_cast<uint32_t>(std::floor(i / static_cast<float>(base)));
+			}
+			return result;
+		};
+		const uint32_t n = t.spp;
+		t.sobol2d.resize(2 * size_t(n));
+		for (uint32_t i = 0; i < n; ++i) {
+			t.sobol2d[2 * i]	 = halton(i + burnin, bx);
+			t.sobol2d[2 * i + 1] = c.aa_sampler == PRGPU_SAMPLER_HALTON ? halton(i + burnin, by) : (0.5f + i) / n;
+		}
+		t.halton_bx		= bx;
+		t.halton_by		= c.aa_sampler == PRGPU_SAMPLER_HALTON ? by : 47u; // HAMMERSLEY_EVASIVE_BASE_Y beyond the promised count
+		t.halton_burnin = burnin;
 	} else if (c.aa_sampler == PRGPU_SAMPLER_SOBOL) {
 		const uint32_t n = t.spp;
 		auto to_unit	 = [](uint64_t v) {
@@ -461,7 +484,7 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		return bad("film too large");
 	if (c.filter_radius > 3)
 		return bad("filter radius > 3 is not supported", PRGPU_EUNSUPPORTED);
-	if (c.aa_sampler > PRGPU_SAMPLER_SOBOL || c.mapper > PRGPU_MAPPER_SPD_HERO || c.filter > PRGPU_FILTER_MITCHELL || c.mis > PRGPU_MIS_POWER)
+	if (c.aa_sampler > PRGPU_SAMPLER_HAMMERSLEY || (c.aa_base_x == 1) || (c.aa_base_y == 1) || c.mapper > PRGPU_MAPPER_SPD_HERO || c.filter > PRGPU_FILTER_MITCHELL || c.mis > PRGPU_MIS_POWER)
 		return bad("unknown sampler / mapper / filter / mis selector");
 	if (!c.aa_samples || !c.lens_samples || !c.time_samples || !c.spectral_samples)
 		return bad("sample counts must be positive");

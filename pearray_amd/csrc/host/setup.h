@@ -18,7 +18,8 @@ struct HostTables {
 	std::vector<uint32_t> light_entity;
 	std::vector<float> light_cdf, light_intensity;
 	std::vector<float> wl_cdf;
-	std::vector<float> sobol2d;
+	std::vector<float> sobol2d; // tabulated AA samples (sobol, halton or hammersley)
+	uint32_t halton_bx = 13, halton_by = 47, halton_burnin = 47;
 	std::vector<float> rr_prob;
 	std::vector<float> filter;
 	std::vector<float> cie; // X,Y,Z planes

@@ -247,6 +247,9 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.mj_x			 = t.mj_x;
 	sc.mj_y			 = t.mj_y;
 	sc.mj_seed		 = t.mj_seed;
+	sc.halton_bx	 = t.halton_bx;
+	sc.halton_by	 = t.halton_by;
+	sc.halton_burnin = t.halton_burnin;
 	sc.single_tap	 = t.single_tap;
 	sc.centre_weight = t.centre_weight;
 	sc.eps_t		 = t.eps_t;

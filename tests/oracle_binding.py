@@ -78,6 +78,8 @@ def load():
     lib.orc_safe_position.argtypes = [_F32P] * 4
     lib.orc_rr_probability.restype = C.c_float
     lib.orc_rr_probability.argtypes = [C.c_void_p, C.c_uint32]
+    lib.orc_halton.restype = C.c_float
+    lib.orc_halton.argtypes = [C.c_uint32, C.c_uint32]
     lib.orc_fresnel_dielectric.restype = C.c_float
     lib.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_float]
     lib.orc_fresnel_conductor.restype = C.c_float

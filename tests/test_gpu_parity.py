@@ -60,7 +60,7 @@ def test_cornell_c1_bit_exact():
     assert g.statistics()["pixel_samples"] == 256 * 256 * 16
 
 
-@pytest.mark.parametrize("sampler", [abi.SAMPLER_RANDOM, abi.SAMPLER_MJITT, abi.SAMPLER_SOBOL])
+@pytest.mark.parametrize("sampler", [abi.SAMPLER_RANDOM, abi.SAMPLER_MJITT, abi.SAMPLER_SOBOL, abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY])
 @pytest.mark.parametrize("mapper", [abi.MAPPER_SPD_CMIS, abi.MAPPER_RANDOM, abi.MAPPER_SPD_HERO])
 def test_samplers_and_mappers(sampler, mapper):
     g, o = render_both(scene.cornell_box(48, 40, spp=6, sampler=sampler, mapper=mapper))
@@ -372,4 +372,13 @@ def test_metal_boxes_bit_exact():
       (entity :name 'lamp' :type 'mesh' :mesh 'quad' :materials 'white' :emission 'lamp' :rotation (euler 180 0 0) :position [0,2,0] :scale 0.3)
     )"""
     g, o = render_both(scene.PrcScene(source=src))
+    assert_parity(g, o, exact=True)
+
+
+@pytest.mark.parametrize("sampler", [abi.SAMPLER_SOBOL, abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY])
+def test_tabulated_samplers_beyond_their_promised_count(sampler):
+    """Rendering more iterations than :sample_count: sobol falls back to random draws, halton/hammersley to the plain
+    sequence (HaltonSampler.cpp:49-52,96-100) -- custom bases and burn-in included."""
+    sc = scene.cornell_box(40, 40, spp=3, sampler=sampler, aa_base_x=3, aa_base_y=5, aa_burnin=7)
+    g, o = render_both(sc, iters=7)
     assert_parity(g, o, exact=True)

@@ -163,3 +163,31 @@ def test_oracle_rejects_malformed_scenes():
     sc = scene.cornell_box(8, 8, spp=1)
     sc.indices[0] = 10_000
     assert ob.load().orc_scene_create(C.byref(sc.desc)) is None
+
+
+def test_halton_radical_inverse_known_values():
+    lib = ob.load()
+    # https://en.wikipedia.org/wiki/Halton_sequence (cited by HaltonSampler.cpp:25-27): base 2 and base 3 prefixes
+    assert [lib.orc_halton(i, 2) for i in range(1, 9)] == [0.5, 0.25, 0.75, 0.125, 0.625, 0.375, 0.875, 0.0625]
+    want3 = [1 / 3, 2 / 3, 1 / 9, 4 / 9, 7 / 9, 2 / 9, 5 / 9, 8 / 9, 1 / 27]
+    assert np.allclose([lib.orc_halton(i, 3) for i in range(1, 10)], want3, atol=1e-7)
+    assert lib.orc_halton(0, 13) == 0.0
+
+
+@pytest.mark.parametrize("kind", [abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY])
+def test_halton_and_hammersley_tables(kind):
+    sc = scene.cornell_box(8, 8, spp=32, sampler=kind)
+    o = ob.OracleScene(sc)
+    n, ptr = C.c_uint32(), C.POINTER(C.c_float)()
+    o.lib.orc_sobol_table(o.h, C.byref(n), C.byref(ptr))
+    t = np.ctypeslib.as_array(ptr, shape=(2 * n.value,)).reshape(-1, 2).copy()
+    lib = ob.load()
+    burnin = 47 if kind == abi.SAMPLER_HALTON else 13     # defaults: max(13, 47) resp. base_x (HaltonSampler.cpp:173,191)
+    assert np.array_equal(t[:, 0], np.array([lib.orc_halton(i + burnin, 13) for i in range(32)], dtype=np.float32))
+    if kind == abi.SAMPLER_HALTON:
+        assert np.array_equal(t[:, 1], np.array([lib.orc_halton(i + burnin, 47) for i in range(32)], dtype=np.float32))
+    else:
+        assert np.array_equal(t[:, 1], ((np.float32(0.5) + np.arange(32, dtype=np.float32)) / np.float32(32)))
+    assert (t >= 0).all() and (t < 1).all()
+    o.render(3, threads=2)
+    assert np.isfinite(o.output()[0]).all()

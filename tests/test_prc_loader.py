@@ -105,7 +105,7 @@ def test_defaults_follow_the_reference():
     ("(material :name 'g' :type 'metal' :roughness_x 0.1)", -4, "rough conductors"),
     ("(light :name 'sky' :type 'sky')", -4, "(light"),
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
-    ("(sampler :type 'halton')", -4, "sampler type 'halton'"),
+    ("(sampler :type 'stratified')", -4, "sampler type 'stratified'"),
     ("(filter :type 'lanczos')", -4, "filter type 'lanczos'"),
     ("(spectral_mapper :type 'cie')", -4, "spectral mapper 'cie'"),
     ("(emission :name 'x' :type 'standard' :radiance (illuminant 'A'))", -4, "illuminant 'a'"),
