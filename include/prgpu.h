@@ -128,10 +128,12 @@ typedef struct prgpu_camera {
 } prgpu_camera;
 
 /* RandomSampler.cpp, MultiJitteredSampler.cpp, SobolSampler.cpp, HaltonSampler.cpp (halton + hammersley) of src/plugins/main/sampler */
-enum { PRGPU_SAMPLER_RANDOM = 0, PRGPU_SAMPLER_MJITT = 1, PRGPU_SAMPLER_SOBOL = 2, PRGPU_SAMPLER_HALTON = 3, PRGPU_SAMPLER_HAMMERSLEY = 4 };
+enum { PRGPU_SAMPLER_RANDOM = 0, PRGPU_SAMPLER_MJITT = 1, PRGPU_SAMPLER_SOBOL = 2, PRGPU_SAMPLER_HALTON = 3, PRGPU_SAMPLER_HAMMERSLEY = 4,
+       PRGPU_SAMPLER_UNIFORM = 5,     /* UniformSampler.cpp: always (0.5, 0.5) */
+       PRGPU_SAMPLER_STRATIFIED = 6 }; /* StratifiedSampler.cpp: jitter inside a sqrt(bins) x sqrt(bins) grid; bins in aa_base_x (0 = aa_samples) */
 enum { PRGPU_MAPPER_SPD_CMIS = 0, PRGPU_MAPPER_RANDOM = 1, PRGPU_MAPPER_SPD_HERO = 2 };
 enum { PRGPU_FILTER_BLOCK = 0, PRGPU_FILTER_TRIANGLE = 1, PRGPU_FILTER_GAUSSIAN = 2,
-       PRGPU_FILTER_MITCHELL = 3 };
+       PRGPU_FILTER_MITCHELL = 3, PRGPU_FILTER_LANCZOS = 4 }; /* src/plugins/main/filter/*.cpp */
 enum { PRGPU_MIS_BALANCE = 0, PRGPU_MIS_POWER = 1 };
 
 /* RenderSettings (src/core/renderer/RenderSettings.cpp:11-31) + `direct` parameters

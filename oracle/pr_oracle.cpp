@@ -496,6 +496,9 @@ void filter_table(uint32_t kind, uint32_t radius, std::vector<float>& table)
 				const float dev2 = 0.2f, alpha = 1 / (2 * dev2);
 				const float q = rr / (float)r;
 				val			  = q <= 1.0f ? std::exp(-alpha * q * q) : 0.0f;
+			} else if (kind == PRGPU_FILTER_LANCZOS) { // LanczosFilter.cpp:38-47
+				auto sinc = [](float x) { return PR_INV_PI_F * std::sin(PR_PI_F * x) / x; };
+				val = rr <= PR_EPS ? 1.0f : (rr <= r ? sinc(rr) * sinc(rr / r) : 0.0f);
 			} else { // MitchellFilter.cpp:32-52, B = C = 1/3
 				const float B = 1 / 3.0f, C = 1 / 3.0f;
 				float xx = std::fabs(2 * rr / r);
@@ -1257,7 +1260,21 @@ inline void aa_sample(const Scene& s, Rng& rnd, uint32_t index, float& x, float&
 			y = s.sobol2d[2 * index + 1];
 			break;
 		}
-		[[fallthrough]]; // beyond the table -> rnd.get2D()
+		x = rng_float(rnd); // beyond the table -> rnd.get2D()
+		y = rng_float(rnd);
+		break;
+	case PRGPU_SAMPLER_UNIFORM: // UniformSampler.cpp:18-26
+		x = y = 0.5f;
+		break;
+	case PRGPU_SAMPLER_STRATIFIED: { // StratifiedSampler.cpp:32-37, Projection::stratified (base/math/Projection.h:14-18)
+		const uint32_t groups = s.cfg.aa_base_x ? s.cfg.aa_base_x : std::max(1u, s.cfg.aa_samples);
+		const uint32_t gx	  = static_cast<uint32_t>(std::sqrt(groups));
+		const float range	  = (1.0f - 0.0f) / (int)gx;
+		const float ux = rng_float(rnd), uy = rng_float(rnd);
+		x = 0.0f + ux * range + (int)(index % gx) * range;
+		y = 0.0f + uy * range + (int)(index / gx) * range;
+		break;
+	}
 	default: // RandomSampler.cpp:20-21 (left-to-right draw order fixed by the oracle)
 		x = rng_float(rnd);
 		y = rng_float(rnd);

@@ -521,10 +521,17 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 		const float jy	  = rng_float(rnd);
 		ax				  = (sx + (sy + jx) / sc.mj_y) / sc.mj_x;
 		ay				  = (id + jy) / n;
-	} else if (cfg.aa_sampler >= PRGPU_SAMPLER_SOBOL && iter < sc.spp) { // SobolSampler.cpp:67-73, HaltonSampler.cpp:44-48,91-95: tabulated
+	} else if (cfg.aa_sampler == PRGPU_SAMPLER_UNIFORM) { // UniformSampler.cpp:18-26
+		ax = ay = 0.5f;
+	} else if (cfg.aa_sampler == PRGPU_SAMPLER_STRATIFIED) { // StratifiedSampler.cpp:32-37 (mj_x holds floor(sqrt(bins)))
+		const float range = (1.0f - 0.0f) / (int)sc.mj_x;
+		const float ux = rng_float(rnd), uy = rng_float(rnd);
+		ax = 0.0f + ux * range + (int)(iter % sc.mj_x) * range;
+		ay = 0.0f + uy * range + (int)(iter / sc.mj_x) * range;
+	} else if (cfg.aa_sampler >= PRGPU_SAMPLER_SOBOL && cfg.aa_sampler <= PRGPU_SAMPLER_HAMMERSLEY && iter < sc.spp) { // SobolSampler.cpp:67-73, HaltonSampler.cpp:44-48,91-95: tabulated
 		ax = sc.sobol2d[2 * iter];
 		ay = sc.sobol2d[2 * iter + 1];
-	} else if (cfg.aa_sampler >= PRGPU_SAMPLER_HALTON) { // beyond the promised sample count: plain halton (HaltonSampler.cpp:49-52,96-100)
+	} else if (cfg.aa_sampler == PRGPU_SAMPLER_HALTON || cfg.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) { // beyond the promised sample count: plain halton (HaltonSampler.cpp:49-52,96-100)
 		ax = halton(iter + sc.halton_burnin, sc.halton_bx);
 		ay = halton(iter + sc.halton_burnin, sc.halton_by);
 	} else { // RandomSampler.cpp:20-21

@@ -358,12 +358,16 @@ struct Loader {
 			kind = PRGPU_SAMPLER_SOBOL;
 		else if (std::find_if(std::begin(mj), std::end(mj), [&](const char* n) { return type == n; }) != std::end(mj))
 			kind = PRGPU_SAMPLER_MJITT;
+		else if (type == "uniform")
+			kind = PRGPU_SAMPLER_UNIFORM;
+		else if (type == "stratified")
+			kind = PRGPU_SAMPLER_STRATIFIED;
 		else if (type == "halton")
 			kind = PRGPU_SAMPLER_HALTON;
 		else if (type == "hammersley")
 			kind = PRGPU_SAMPLER_HAMMERSLEY;
 		else
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": sampler type '" + type + "' is not supported (random, mjitt, sobol, halton, hammersley are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": sampler type '" + type + "' is not supported (random, uniform, stratified, mjitt, sobol, halton, hammersley are)");
 		const uint32_t count = (uint32_t)std::max(1.0, get_number(g, "sample_count", 128)); // DEF_SAMPLE_COUNT
 		if (slot == "aa" || slot == "pixel" || slot == "antialiasing") {
 			settings.aa_sampler = kind;
@@ -375,6 +379,8 @@ struct Loader {
 				settings.aa_burnin = (uint32_t)get_number(g, "burnin", kind == PRGPU_SAMPLER_HALTON ? std::max(settings.aa_base_x, settings.aa_base_y) : settings.aa_base_x);
 				if (settings.aa_base_x < 2 || settings.aa_base_y < 2)
 					fail(PRGPU_EINVAL, where(g) + ": halton bases must be >= 2");
+			} else if (kind == PRGPU_SAMPLER_STRATIFIED) {
+				settings.aa_base_x = (uint32_t)get_number(g, "bins", std::max(1u, count)); // StratifiedSampler.cpp:55
 			}
 		} else if (slot == "lens") {
 			settings.lens_samples = count;
@@ -404,8 +410,10 @@ struct Loader {
 			settings.filter = PRGPU_FILTER_GAUSSIAN;
 		else if (type == "mitchell" || type == "default")
 			settings.filter = PRGPU_FILTER_MITCHELL;
+		else if (type == "lanczos" || type == "sinc" || type == "lancz")
+			settings.filter = PRGPU_FILTER_LANCZOS;
 		else
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": filter type '" + type + "' is not supported (block, triangle, gaussian, mitchell are)");
+			fail(PRGPU_EINVAL, where(g) + ": unknown filter type '" + type + "'");
 		settings.filter_radius = (uint32_t)std::max(0.0, get_number(g, "radius", 3));
 		have_filter			   = true;
 	}

@@ -240,6 +240,10 @@ void sampler_tables(const prgpu_scene_desc* d, HostTables& t)
 		t.mj_x				= (uint32_t)std::sqrt((float)bins);
 		t.mj_y				= (bins + t.mj_x - 1) / t.mj_x;
 		t.mj_seed			= 14512081u ^ aa.next();
+	} else if (c.aa_sampler == PRGPU_SAMPLER_STRATIFIED) { // StratifiedSampler.cpp:17-21: m2D_X = sqrt(groups), groups = bins
+		const uint32_t groups = c.aa_base_x ? c.aa_base_x : std::max(1u, c.aa_samples);
+		t.mj_x				  = static_cast<uint32_t>(std::sqrt(groups));
+		t.mj_y				  = t.mj_x;
 	} else if (c.aa_sampler == PRGPU_SAMPLER_HALTON || c.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) {
 		// HaltonSampler.cpp:30-42 / 77-89: tabulated at construction, no shuffle, no random draws; the table shares the device
 		// array of the sobol samples (one AA sampler per scene)
@@ -432,6 +436,9 @@ void filter_taps(const prgpu_scene_desc* d, HostTables& t)
 				} else if (kind == PRGPU_FILTER_GAUSSIAN) {
 					const float dev2 = 0.2f, alpha = 1 / (2 * dev2), q = dist / (float)r;
 					val = q <= 1.0f ? std::exp(-alpha * q * q) : 0.0f;
+				} else if (kind == PRGPU_FILTER_LANCZOS) { // LanczosFilter.cpp:38-47
+					auto sinc = [](float x) { return 0.318309886183790671538f * std::sin(3.14159265358979323846f * x) / x; };
+					val		  = dist <= EPS_F ? 1.0f : (dist <= r ? sinc(dist) * sinc(dist / r) : 0.0f);
 				} else {
 					const float B = 1 / 3.0f, C = 1 / 3.0f;
 					const float xx = std::fabs(2 * dist / r);
@@ -484,7 +491,7 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		return bad("film too large");
 	if (c.filter_radius > 3)
 		return bad("filter radius > 3 is not supported", PRGPU_EUNSUPPORTED);
-	if (c.aa_sampler > PRGPU_SAMPLER_HAMMERSLEY || (c.aa_base_x == 1) || (c.aa_base_y == 1) || c.mapper > PRGPU_MAPPER_SPD_HERO || c.filter > PRGPU_FILTER_MITCHELL || c.mis > PRGPU_MIS_POWER)
+	if (c.aa_sampler > PRGPU_SAMPLER_STRATIFIED || ((c.aa_sampler == PRGPU_SAMPLER_HALTON || c.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) && (c.aa_base_x == 1 || c.aa_base_y == 1)) || c.mapper > PRGPU_MAPPER_SPD_HERO || c.filter > PRGPU_FILTER_LANCZOS || c.mis > PRGPU_MIS_POWER)
 		return bad("unknown sampler / mapper / filter / mis selector");
 	if (!c.aa_samples || !c.lens_samples || !c.time_samples || !c.spectral_samples)
 		return bad("sample counts must be positive");

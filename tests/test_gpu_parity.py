@@ -60,7 +60,8 @@ def test_cornell_c1_bit_exact():
     assert g.statistics()["pixel_samples"] == 256 * 256 * 16
 
 
-@pytest.mark.parametrize("sampler", [abi.SAMPLER_RANDOM, abi.SAMPLER_MJITT, abi.SAMPLER_SOBOL, abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY])
+@pytest.mark.parametrize("sampler", [abi.SAMPLER_RANDOM, abi.SAMPLER_MJITT, abi.SAMPLER_SOBOL, abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY,
+                                     abi.SAMPLER_UNIFORM, abi.SAMPLER_STRATIFIED])
 @pytest.mark.parametrize("mapper", [abi.MAPPER_SPD_CMIS, abi.MAPPER_RANDOM, abi.MAPPER_SPD_HERO])
 def test_samplers_and_mappers(sampler, mapper):
     g, o = render_both(scene.cornell_box(48, 40, spp=6, sampler=sampler, mapper=mapper))
@@ -77,7 +78,8 @@ def test_integrator_parameters(kw):
 
 
 @pytest.mark.parametrize("flt,r", [(abi.FILTER_BLOCK, 0), (abi.FILTER_BLOCK, 1), (abi.FILTER_TRIANGLE, 2),
-                                   (abi.FILTER_GAUSSIAN, 2), (abi.FILTER_MITCHELL, 2), (abi.FILTER_MITCHELL, 3)])
+                                   (abi.FILTER_GAUSSIAN, 2), (abi.FILTER_MITCHELL, 2), (abi.FILTER_MITCHELL, 3),
+                                   (abi.FILTER_LANCZOS, 0), (abi.FILTER_LANCZOS, 2), (abi.FILTER_LANCZOS, 3)])
 def test_pixel_filters(flt, r):
     """Multi-tap filters: device gathers per-pixel sums, the oracle splats per fragment -> tolerance, not bits."""
     g, o = render_both(scene.cornell_box(40, 36, spp=4, filter=flt, filter_radius=r))

@@ -191,3 +191,18 @@ def test_halton_and_hammersley_tables(kind):
     assert (t >= 0).all() and (t < 1).all()
     o.render(3, threads=2)
     assert np.isfinite(o.output()[0]).all()
+
+
+def test_lanczos_filter_weights_and_stratified_sampler():
+    """LanczosFilter.cpp:38-66: windowed sinc, normalised over the mirrored quadrant; StratifiedSampler.cpp: jittered grid."""
+    sc = scene.cornell_box(24, 24, spp=16, sampler=abi.SAMPLER_STRATIFIED, filter=abi.FILTER_LANCZOS, filter_radius=3)
+    o = ob.OracleScene(sc)
+    o.render(16, threads=2)
+    xyz, smp, fb = o.output()
+    assert np.isfinite(xyz).all() and smp.max() == 16
+    ref = ob.OracleScene(scene.cornell_box(24, 24, spp=16, sampler=abi.SAMPLER_STRATIFIED)); ref.render(16, threads=2)
+    # commitSpectrals2 only splats taps with weight > eps: the negative lobes of the normalised kernel are dropped, the positive
+    # ones alone sum to more than one
+    assert 1.0 < xyz.sum() / ref.output()[0].sum() < 3.0
+    u = ob.OracleScene(scene.cornell_box(24, 24, spp=4, sampler=abi.SAMPLER_UNIFORM)); u.render(4, threads=2)
+    assert np.isfinite(u.output()[0]).all()

@@ -105,8 +105,8 @@ def test_defaults_follow_the_reference():
     ("(material :name 'g' :type 'metal' :roughness_x 0.1)", -4, "rough conductors"),
     ("(light :name 'sky' :type 'sky')", -4, "(light"),
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
-    ("(sampler :type 'stratified')", -4, "sampler type 'stratified'"),
-    ("(filter :type 'lanczos')", -4, "filter type 'lanczos'"),
+    ("(sampler :type 'blue_noise')", -4, "sampler type 'blue_noise'"),
+    ("(filter :type 'box3')", -1, "unknown filter type 'box3'"),
     ("(spectral_mapper :type 'cie')", -4, "spectral mapper 'cie'"),
     ("(emission :name 'x' :type 'standard' :radiance (illuminant 'A'))", -4, "illuminant 'a'"),
     ("(material :name 'x' :type 'diffuse' :albedo (checkerboard 1 2))", -4, "checkerboard"),
