@@ -110,11 +110,18 @@ typedef struct prgpu_emission {
  * (src/loader/parser/MathParser.cpp:18-26).  Triangles [first_tri, first_tri+n_tris) of the
  * scene index buffer belong to this entity; primitive id reported for a hit is the index
  * relative to first_tri (Embree primID, Scene.cpp:184-192). */
+/* PLANE (src/plugins/main/entities/plane.cpp): a parallelogram p, p + y, p + y + x, p + x handed to Embree as ONE quad
+ * (plane.cpp:70-92), i.e. exactly two triangles over four local vertices v0..v3 indexed (0,1,3), (2,3,1); both report
+ * primitive id 0; the shading frame is N = nm * normalize(x X y), Nx = M x, Ny = M y (normalised; plane.cpp:206-217,225-238) with
+ * x = v3 - v0, y = v1 - v0.  Emissive planes are not supported yet (spherical-rectangle sampling, plane.cpp:94-196). */
+enum { PRGPU_ENTITY_MESH = 0, PRGPU_ENTITY_PLANE = 1 };
 typedef struct prgpu_entity {
 	uint32_t first_tri;
 	uint32_t n_tris;
 	uint32_t emission;     /* emission index or PRGPU_INVALID_ID */
-	uint32_t has_normals;  /* 1: interpolate vertex normals (MeshEntity<*,true>), 0: geometric */
+	uint32_t has_normals;  /* MESH: 1: interpolate vertex normals (MeshEntity<*,true>), 0: geometric */
+	uint32_t kind;         /* PRGPU_ENTITY_* */
+	uint32_t reserved[3];
 	float    transform[16];
 } prgpu_entity;
 

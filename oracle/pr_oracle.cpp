@@ -1117,12 +1117,31 @@ struct GeomPoint {
 };
 inline V3 tri_interp(V3 a0, V3 a1, V3 a2, float u, float v) { return (a1 * u + a2 * v) + a0 * (1 - u - v); }
 inline V3 load3(const std::vector<float>& a, uint32_t i) { return v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+// Embree primID: triangle index inside a mesh, 0 for the single quad of a plane
+inline uint32_t prim_id(const Scene& s, uint32_t tri)
+{
+	const prgpu_entity& E = s.entities[s.tri_entity[tri]];
+	return E.kind == PRGPU_ENTITY_PLANE ? 0u : tri - E.first_tri;
+}
 void geometry_point(const Scene& s, uint32_t tri, float u, float v, GeomPoint& g)
 {
 	const uint32_t e	 = s.tri_entity[tri];
 	const prgpu_entity& E = s.entities[e];
 	const uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
 	V3 N, Nx, Ny;
+	if (E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
+		const uint32_t t0 = E.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0
+		const V3 v0 = load3(s.positions, s.indices[3 * t0]), v1 = load3(s.positions, s.indices[3 * t0 + 1]), v3p = load3(s.positions, s.indices[3 * t0 + 2]);
+		const V3 x = v3p - v0, y = v1 - v0;
+		g.N		   = normalized(mat3_mul(s.nmat[e].data(), normalized(cross(x, y))));
+		g.Nx	   = normalized(linear_mul(E.transform, x));
+		g.Ny	   = normalized(linear_mul(E.transform, y));
+		g.entity   = e;
+		g.prim	   = 0; // one Embree quad
+		g.material = s.tri_material[tri];
+		g.emission = E.emission;
+		return;
+	}
 	if (E.has_normals && s.has_normals_array) {
 		N = tri_interp(load3(s.normals, i0), load3(s.normals, i1), load3(s.normals, i2), u, v);
 		frame_duff(N, Nx, Ny); // Tangent::unnormalized_frame on the interpolated (unnormalised) normal
@@ -1580,7 +1599,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		}
 		if (ray.depth == 0) {
 			s.prim_entity[pixel] = hit.tri == INVALID ? INVALID : s.tri_entity[hit.tri];
-			s.prim_prim[pixel]	 = hit.tri == INVALID ? INVALID : hit.tri - s.entities[s.tri_entity[hit.tri]].first_tri;
+			s.prim_prim[pixel]	 = hit.tri == INVALID ? INVALID : prim_id(s, hit.tri);
 		}
 		if (hit.tri == INVALID) {
 			// depth 0: IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53);
@@ -1968,6 +1987,8 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("emission index out of range");
 		if (E.has_normals && !s.has_normals_array)
 			return fail("entity wants normals but none given");
+		if (E.kind > PRGPU_ENTITY_PLANE || (E.kind == PRGPU_ENTITY_PLANE && (E.n_tris != 2 || E.emission != INVALID)))
+			return fail("bad plane entity");
 		for (uint32_t t = 0; t < E.n_tris; ++t)
 			s.tri_entity[E.first_tri + t] = e;
 	}
@@ -2141,7 +2162,7 @@ int orc_trace_closest(orc_scene* h, uint32_t n, const float* org, const float* d
 		if (entity)
 			entity[i] = ok ? s.tri_entity[hit.tri] : INVALID;
 		if (prim)
-			prim[i] = ok ? hit.tri - s.entities[s.tri_entity[hit.tri]].first_tri : INVALID;
+			prim[i] = ok ? prim_id(s, hit.tri) : INVALID;
 		if (u)
 			u[i] = ok ? hit.u : 0;
 		if (v)

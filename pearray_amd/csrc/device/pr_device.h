@@ -48,7 +48,7 @@ struct DevEntity {
 	float nm[9];  // normal matrix (M^-1)^T
 	uint32_t first_tri, n_tris, emission, has_normals;
 	float vol_scale, world_area;
-	uint32_t light_id, pad;
+	uint32_t light_id, kind; // kind: PRGPU_ENTITY_*
 };
 
 struct DevCamera {
@@ -365,6 +365,10 @@ __device__ __forceinline__ uint32_t mjitt_permute(uint32_t i, uint32_t l, uint32
 __device__ __forceinline__ V3 mat3_mul(const float* m, V3 v)
 {
 	return v3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[3] * v.x + m[4] * v.y) + m[5] * v.z, (m[6] * v.x + m[7] * v.y) + m[8] * v.z);
+}
+__device__ __forceinline__ V3 linear_mul(const float* m, V3 v) // linear part of m = 3 rows of 4
+{
+	return v3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z, (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
 }
 __device__ __forceinline__ V3 affine_mul(const float* m, V3 v) // m = 3 rows of 4
 {

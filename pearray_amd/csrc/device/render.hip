@@ -355,6 +355,12 @@ struct GeomPoint {
 };
 __device__ __forceinline__ V3 load3(const float* a, uint32_t i) { return v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
 __device__ __forceinline__ V3 tri_interp(V3 a0, V3 a1, V3 a2, float u, float v) { return (a1 * u + a2 * v) + a0 * (1 - u - v); }
+// Embree primID: triangle index inside a mesh, 0 for the single quad of a plane
+__device__ __forceinline__ uint32_t prim_id(const DevScene& sc, uint32_t tri)
+{
+	const DevEntity& E = sc.entities[sc.tri_entity[tri]];
+	return E.kind == PRGPU_ENTITY_PLANE ? 0u : tri - E.first_tri;
+}
 // MeshEntity::provideGeometryPoint (entities/mesh.cpp:205-250)
 __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri, float u, float v, GeomPoint& g)
 {
@@ -362,6 +368,19 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 	const DevEntity& E = sc.entities[e];
 	const uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
 	V3 N, Nx, Ny;
+	if (E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
+		const uint32_t t0 = E.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0
+		const V3 v0 = load3(sc.positions, sc.indices[3 * t0]), v1 = load3(sc.positions, sc.indices[3 * t0 + 1]), v3p = load3(sc.positions, sc.indices[3 * t0 + 2]);
+		const V3 x = v3p - v0, y = v1 - v0;
+		g.N		   = normalized(mat3_mul(E.nm, normalized(cross(x, y))));
+		g.Nx	   = normalized(linear_mul(E.m, x));
+		g.Ny	   = normalized(linear_mul(E.m, y));
+		g.entity   = e;
+		g.prim	   = 0; // one Embree quad
+		g.material = sc.tri_material[tri];
+		g.emission = E.emission;
+		return;
+	}
 	if (E.has_normals) {
 		N = tri_interp(load3(sc.normals, i0), load3(sc.normals, i1), load3(sc.normals, i2), u, v);
 		frame_duff(N, Nx, Ny);
@@ -718,7 +737,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 
 	if (depth == 0) {
 		ps.prim_entity[pixel] = tri == INVALID ? INVALID : sc.tri_entity[tri];
-		ps.prim_prim[pixel]	  = tri == INVALID ? INVALID : tri - sc.entities[sc.tri_entity[tri]].first_tri;
+		ps.prim_prim[pixel]	  = tri == INVALID ? INVALID : prim_id(sc, tri);
 	}
 	if (tri == INVALID) {
 		atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
@@ -1469,7 +1488,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uin
 		const bool ok	 = h.tri != INVALID;
 		const uint32_t e = ok ? sc.tri_entity[h.tri] : INVALID;
 		entity[i]		 = e;
-		prim[i]			 = ok ? h.tri - sc.entities[e].first_tri : INVALID;
+		prim[i]			 = ok ? prim_id(sc, h.tri) : INVALID;
 		u[i]			 = ok ? h.u : 0.0f;
 		v[i]			 = ok ? h.v : 0.0f;
 		t[i]			 = ok ? h.t : tmax_a[i];

@@ -598,12 +598,65 @@ struct Loader {
 					fail(PRGPU_EINVAL, "mesh '" + name + "': face index out of range");
 		meshes[name] = std::move(m);
 	}
+	void add_plane(const Group& g, const std::string& name) // plane.cpp:241-258
+	{
+		for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
+			if (!get_bool(g, flag, true))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
+		if (g.get("emission"))
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": emissive plane entities are not supported yet (use a quad mesh)");
+		float xa[3] = { 1, 0, 0 }, ya[3] = { 0, 1, 0 };
+		if (!get_vec3(g, "x_axis", xa))
+			get_vec3(g, "axis_x", xa);
+		if (!get_vec3(g, "y_axis", ya))
+			get_vec3(g, "axis_y", ya);
+		const float w = (float)get_number(g, "width", 1), h = (float)get_number(g, "height", 1);
+		float x[3], y[3], p[3];
+		for (int k = 0; k < 3; ++k) {
+			x[k] = w * xa[k];
+			y[k] = h * ya[k];
+		}
+		const bool centering = get_bool(g, "centering", false);
+		for (int k = 0; k < 3; ++k)
+			p[k] = centering ? -0.5f * x[k] - 0.5f * y[k] : 0.0f; // PlaneEntity::centerOn
+		const Value* mv = g.get("material");
+		uint32_t mat	= PRGPU_INVALID_ID;
+		if (mv && mv->type == Value::STRING) {
+			const auto it = material_ids.find(mv->s);
+			mat			  = it == material_ids.end() ? PRGPU_INVALID_ID : it->second;
+		}
+		prgpu_entity e;
+		std::memset(&e, 0, sizeof(e));
+		e.first_tri = (uint32_t)(out.indices.size() / 3);
+		e.n_tris	= 2;
+		e.emission	= PRGPU_INVALID_ID;
+		e.kind		= PRGPU_ENTITY_PLANE;
+		transform_of(g, e.transform);
+		const uint32_t base = (uint32_t)(out.positions.size() / 3);
+		const float v[4][3] = { { p[0], p[1], p[2] },
+								{ p[0] + y[0], p[1] + y[1], p[2] + y[2] },
+								{ (p[0] + y[0]) + x[0], (p[1] + y[1]) + x[1], (p[2] + y[2]) + x[2] },
+								{ p[0] + x[0], p[1] + x[1], p[2] + x[2] } }; // plane.cpp:81-84
+		for (const auto& q : v)
+			out.positions.insert(out.positions.end(), q, q + 3);
+		const uint32_t idx[6] = { 0, 1, 3, 2, 3, 1 }; // Embree quad
+		for (uint32_t i : idx)
+			out.indices.push_back(base + i);
+		out.tri_material.push_back(mat);
+		out.tri_material.push_back(mat);
+		out.entities.push_back(e);
+		(void)name;
+	}
 	void add_entity(const Group& g) // SceneLoader.cpp:446-520, mesh.cpp:260-300
 	{
 		const std::string type = lower(get_string(g, "type", ""));
 		const std::string name = get_string(g, "name", "__unnamed__");
+		if (type == "plane") {
+			add_plane(g, name);
+			return;
+		}
 		if (type != "mesh")
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": entity type '" + type + "' is not supported (mesh only; tessellate other primitives)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": entity type '" + type + "' is not supported (mesh and plane are; tessellate other primitives)");
 		for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
 			if (!get_bool(g, flag, true))
 				fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
@@ -878,8 +931,9 @@ struct Loader {
 			fail(PRGPU_EINVAL, "the scene has no entities");
 		if (any_normals)
 			out.normals.resize(out.positions.size(), 0.0f);
+		const uint32_t n_table_values = (uint32_t)out.tables.size();
 		if (out.tables.empty())
-			out.tables.push_back(0.0f);
+			out.tables.push_back(0.0f); // keep the pointer valid
 		prgpu_scene_desc& d = out.desc;
 		std::memset(&d, 0, sizeof(d));
 		d.api_version			  = PRGPU_API_VERSION;
@@ -897,7 +951,7 @@ struct Loader {
 		d.emissions				  = out.emissions.data();
 		d.n_spectra				  = (uint32_t)out.spectra.size();
 		d.spectra				  = out.spectra.data();
-		d.n_spectral_table_values = (uint32_t)out.tables.size();
+		d.n_spectral_table_values = n_table_values;
 		d.spectral_tables		  = out.tables.data();
 		d.camera				  = cameras[cam];
 		d.settings				  = settings;

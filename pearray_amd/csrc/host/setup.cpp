@@ -215,7 +215,7 @@ void entity_tables(const prgpu_scene_desc* d, HostTables& t)
 		E.emission	  = src.emission;
 		E.has_normals = (src.has_normals && d->normals) ? 1u : 0u;
 		E.light_id	  = PRGPU_INVALID_ID;
-		E.pad		  = 0;
+		E.kind		  = src.kind;
 		float area	  = 0;
 		for (uint32_t tri = src.first_tri; tri < src.first_tri + src.n_tris; ++tri) {
 			t.tri_entity[tri] = e;
@@ -524,6 +524,15 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 	for (uint32_t t = 0; t < d->n_triangles; ++t)
 		if (d->tri_material[t] != PRGPU_INVALID_ID && d->tri_material[t] >= d->n_materials)
 			return bad("material index out of range");
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& E = d->entities[e];
+		if (E.kind > PRGPU_ENTITY_PLANE)
+			return bad("unknown entity kind");
+		if (E.kind == PRGPU_ENTITY_PLANE && E.n_tris != 2)
+			return bad("a plane entity is exactly two triangles (v0,v1,v3), (v2,v3,v1)");
+		if (E.kind == PRGPU_ENTITY_PLANE && E.emission != PRGPU_INVALID_ID)
+			return bad("emissive plane entities are not supported yet (spherical-rectangle light sampling)", PRGPU_EUNSUPPORTED);
+	}
 	for (uint32_t i = 0; i < d->n_spectra; ++i) {
 		const prgpu_spectrum& n = d->spectra[i];
 		if (n.kind > PRGPU_SPEC_SELLMEIER)

@@ -168,6 +168,15 @@ class SceneBuilder:
         self._n_vertices += len(positions)
         return len(self.entities) - 1
 
+    def add_plane(self, material, x_axis=(1, 0, 0), y_axis=(0, 1, 0), width=1.0, height=1.0, centering=False, transform=IDENTITY):
+        """(entity :type 'plane'), plane.cpp:241-258: parallelogram spanned by width * x_axis and height * y_axis"""
+        x = np.float32(width) * np.asarray(x_axis, dtype=np.float32)
+        y = np.float32(height) * np.asarray(y_axis, dtype=np.float32)
+        p = (np.float32(-0.5) * x - np.float32(0.5) * y) if centering else np.zeros(3, dtype=np.float32)   # PlaneEntity::centerOn
+        e = self.add_mesh([p, p + y, (p + y) + x, p + x], [[0, 1, 3], [2, 3, 1]], material, transform=transform)   # plane.cpp:81-84
+        self.entities[e].kind = abi.ENTITY_PLANE
+        return e
+
     def set_camera(self, transform, width=1.0, height=1.0, near=1e-6, far=float("inf"), local_direction=(0, 0, 1),
                    local_right=(1, 0, 0), local_up=(0, 1, 0), fstop=0.0, aperture_radius=0.05):
         c = self.camera

@@ -384,3 +384,32 @@ def test_tabulated_samplers_beyond_their_promised_count(sampler):
     sc = scene.cornell_box(40, 40, spp=3, sampler=sampler, aa_base_x=3, aa_base_y=5, aa_burnin=7)
     g, o = render_both(sc, iters=7)
     assert_parity(g, o, exact=True)
+
+
+def test_plane_entities_bit_exact_and_report_primitive_zero():
+    """plane.cpp: one Embree quad -> both triangles are primitive 0; shading frame from the plane axes, not from triangle edges."""
+    b = scene.SceneBuilder(72, 56)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, 6
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = [0, 0.4, 3.0]
+    b.set_camera(T, width=0.9, height=0.7, near=0.01, far=100.0, local_direction=(0, 0, -1), local_up=(0, 1, 0), local_right=(1, 0, 0))
+    white = b.lambert(b.refl(0.7, 0.7, 0.7))
+    red = b.lambert(b.refl(0.6, 0.1, 0.1), two_sided=False)
+    lamp = b.diffuse_emission(b.illum(6, 6, 5))
+    S = np.diag([2, 1, 0.5, 1]).astype(np.float32); S[:3, 3] = [0, -0.5, 0]     # non-uniform scale: nm * n differs from M * n
+    b.add_plane(white, x_axis=(1, 0, 0), y_axis=(0, 0, -1), width=3, height=6, centering=True, transform=S)
+    Rz = np.array([[0.8, -0.6, 0, -1.2], [0.6, 0.8, 0, 0.2], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    b.add_plane(red, x_axis=(0, 0, 1), y_axis=(0, 1, 0), width=1.5, height=1.0, transform=Rz)
+    b.add_mesh([[-0.4, 1.6, -0.4], [0.4, 1.6, -0.4], [0.4, 1.6, 0.4], [-0.4, 1.6, 0.4]], [[0, 1, 2, 3]], white, emission=lamp)
+    sc = b.build()
+    g, o = render_both(sc)
+    assert_parity(g, o, exact=True)
+    ent, prim = g.primaryHits()
+    assert set(np.unique(prim[ent == 0])) == {0} and set(np.unique(prim[ent == 1])) <= {0} and (ent == 0).sum() > 500
+    # the ray service reports the same ids
+    rng = np.random.default_rng(3)
+    org = np.tile(np.array([[0, 1.0, 0.2]], dtype=np.float32), (256, 1))
+    d = rng.normal(size=(256, 3)); d[:, 1] = -np.abs(d[:, 1]); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    a, bb = g.traceRays(org, d, 1e-4, np.inf), o.trace_closest(org, d, 1e-4, np.inf)
+    for x, y in zip(a, bb):
+        assert np.array_equal(x, y)
+    assert set(np.unique(a[1][a[0] == 0])) == {0}

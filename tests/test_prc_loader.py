@@ -223,3 +223,26 @@ def test_reference_evaluation_scene_equals_the_committed_fixture_scene():
     want = scene.cbox_eval()
     assert_same_desc(s.desc, want.desc)
     assert any("output specification ignored" in w for w in s.warnings)
+
+
+def test_plane_entity_matches_scene_builder():
+    src = MINIMAL % ("(entity :name 'floor' :type 'plane' :material 'm' :x_axis [1,0,0] :y_axis [0,0,-1] :width 4 :height 3 :centering true :position [0,-1,0])"
+                     "(entity :name 'wall' :type 'plane' :material 'm' :axis_x [0,2,0] :rotation (euler 0 90 0))")
+    s = scene.PrcScene(source=src)
+    b = scene.SceneBuilder(8, 8)
+    b.set_camera(scene.IDENTITY, near=1e-6, local_direction=(0, 1, 0), local_up=(0, 0, 1), local_right=(1, 0, 0))
+    m = b.lambert(b.spectrum_const(1.0))
+    T = np.eye(4, dtype=np.float32); T[1, 3] = -1
+    b.add_plane(m, x_axis=(1, 0, 0), y_axis=(0, 0, -1), width=4, height=3, centering=True, transform=T)
+    b.add_plane(m, x_axis=(0, 2, 0), transform=np.array(list(s.desc.entities[1].transform), dtype=np.float32).reshape(4, 4))
+    b.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]], m)
+    want = b.build()
+    assert_same_desc(s.desc, want.desc)
+    d = s.desc
+    assert d.entities[0].kind == abi.ENTITY_PLANE and d.entities[0].n_tris == 2 and d.entities[2].kind == abi.ENTITY_MESH
+    pos = arr(d.positions, 12, np.float32).reshape(4, 3)
+    assert pos.tolist() == [[-2, 0, 1.5], [-2, 0, -1.5], [2, 0, -1.5], [2, 0, 1.5]]          # p, p+y, p+y+x, p+x  (plane.cpp:81-84)
+    assert arr(d.indices, 6, np.uint32).tolist() == [0, 1, 3, 2, 3, 1]
+    with pytest.raises(abi.PrgpuError) as e:
+        scene.PrcScene(source=MINIMAL % "(emission :name 'l' :type 'standard') (entity :name 'p' :type 'plane' :material 'm' :emission 'l')")
+    assert e.value.args[1] == -4 and "emissive plane" in e.value.args[0]
