@@ -23,7 +23,7 @@ W, H, SPP, NTRI = 1920, 1080, 1024, 1_000_000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the achievable copy rate
 
 
-def cpu_baseline(scene_desc, iters=1):
+def cpu_baseline(scene_desc, iters=4):
     """CPU checker ("port") on the host cores: `iters` full-frame iterations of the SAME workload."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_binding import OracleScene
