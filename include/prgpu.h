@@ -125,6 +125,25 @@ typedef struct prgpu_entity {
 	float    transform[16];
 } prgpu_entity;
 
+/* Infinite lights (src/plugins/main/infinitelights):
+ *   ENVIRONMENT  environment.cpp, untextured: `radiance` from every direction; sampled for NEE as a cosine hemisphere around the
+ *                light's local z axis (environment.cpp:84-100), pdf |z| / pi (:71); camera rays that leave the scene see
+ *                `background` (:56-63), bounce rays see `radiance` weighted by MIS (direct.cpp:415-456).
+ *   DISTANT      distant.cpp: delta light arriving from `direction` (transformed by the light's normal matrix) with `radiance` =
+ *                irradiance; only reachable through NEE (direct.cpp:321, Light.cpp:118-150).
+ * They follow the area lights in the light-selection distribution with intensity 2 pi R mean(power) (LightSampler.cpp:20,62-71),
+ * R = radius of the origin-centred bounding sphere of the scene (Scene.cpp:107-118). */
+enum { PRGPU_LIGHT_ENVIRONMENT = 0, PRGPU_LIGHT_DISTANT = 1 };
+typedef struct prgpu_light {
+	uint32_t kind;
+	uint32_t radiance;     /* spectrum index: ENVIRONMENT `radiance`, DISTANT `irradiance` */
+	uint32_t background;   /* ENVIRONMENT: `background` spectrum index, or PRGPU_INVALID_ID = radiance */
+	uint32_t reserved;
+	float    direction[3]; /* DISTANT: `direction` (default 0 0 1) */
+	float    reserved2;
+	float    transform[16];
+} prgpu_light;
+
 /* PerspectiveCamera, src/plugins/main/cameras/perspective.cpp:16-113 */
 typedef struct prgpu_camera {
 	float transform[16];      /* row-major 4x4 */
@@ -189,6 +208,8 @@ typedef struct prgpu_scene_desc {
 	const float* spectral_tables;
 	prgpu_camera   camera;
 	prgpu_settings settings;
+	uint32_t n_lights;               /* infinite lights (may be 0) */
+	const prgpu_light* lights;
 } prgpu_scene_desc;
 
 /* Half-open pixel rectangle [x0,x1) x [y0,y1): one RenderTile (src/core/renderer/RenderTile.h). */

@@ -692,6 +692,14 @@ struct Scene {
 	std::vector<uint32_t> light_entity;	 // light id -> entity
 	std::vector<uint32_t> entity_light;	 // entity -> light id or INVALID
 	std::vector<float> light_cdf, light_intensity;
+	// infinite lights follow the area lights in the selection distribution (LightSampler.cpp:62-71,104-108)
+	struct InfLight {
+		prgpu_light l;
+		float nm[9], inv_nm[9]; // ITransformable::normalMatrix / invNormalMatrix
+		V3 outgoing;			// DISTANT: (normalMatrix * direction).normalized(), distant.cpp:24
+	};
+	std::vector<InfLight> inf_lights;
+	float scene_radius = 0; // Scene::boundingSphere().radius(), Scene.cpp:107-118
 	// wavelength distribution (spd mapper)
 	std::vector<float> wl_cdf;
 	// integrator
@@ -851,6 +859,19 @@ Blob node_average(const Scene& s, uint32_t id, const Blob& wl)
 		for (int k = 0; k < 4; ++k)
 			sum[k] += v[k];
 	return sum / 1024.0f;
+}
+
+// inverse of a 3x3 (cofactors / determinant), used for ITransformable::invNormalMatrix
+inline void mat3_inverse(const float m[9], float out[9])
+{
+	const float a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+	const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+	const float c10 = c * h - b * i, c11 = a * i - c * g, c12 = b * g - a * h;
+	const float c20 = b * f - c * e, c21 = c * d - a * f, c22 = a * e - b * d;
+	const float det = (a * c00 + b * c01) + c * c02;
+	out[0] = c00 / det; out[1] = c10 / det; out[2] = c20 / det;
+	out[3] = c01 / det; out[4] = c11 / det; out[5] = c21 / det;
+	out[6] = c02 / det; out[7] = c12 / det; out[8] = c22 / det;
 }
 
 // ---- BVH build: binned SAH BVH2 over world-space triangles -------------------------------------
@@ -1325,7 +1346,19 @@ int setup_lights(Scene& s)
 		s.light_entity.push_back(e);
 		s.light_intensity.push_back(intensity);
 	}
-	const uint32_t nl = (uint32_t)s.light_entity.size();
+	// infinite lights (approximate intensities), LightSampler.cpp:20,62-71
+	const float scene_area = 2 * PR_PI_F * s.scene_radius;
+	for (const auto& il : s.inf_lights) {
+		const Range node = spectrum_range(s, il.l.radiance);
+		const float rs = node.start < 0 ? s.cfg.spectral_start : node.start;
+		const float re = node.end < 0 ? s.cfg.spectral_end : node.end;
+		Blob wl;
+		for (int k = 0; k < 4; ++k)
+			wl[k] = rs + (re - rs) * test_wvl_distr[k];
+		const Blob pw = node_average(s, il.l.radiance, wl);
+		s.light_intensity.push_back(scene_area * (bsum(pw) / 4.0f));
+	}
+	const uint32_t nl = (uint32_t)s.light_intensity.size();
 	if (nl) {
 		s.light_cdf.resize(nl + 1);
 		float full;
@@ -1346,8 +1379,9 @@ void setup_wavelengths(Scene& s)
 	const float start = s.cfg.spectral_start, span = s.cfg.spectral_end - s.cfg.spectral_start;
 	auto bin2wvl = [&](uint32_t bin) { return start + (bin / float(bins - 1)) * span; };
 	std::vector<float> full(bins, 0.0f), lp(bins, 0.0f);
-	for (uint32_t l = 0; l < s.light_entity.size(); ++l) {
-		const uint32_t node = s.emissions[s.entities[s.light_entity[l]].emission].radiance;
+	const uint32_t n_area = (uint32_t)s.light_entity.size();
+	for (uint32_t l = 0; l < n_area + s.inf_lights.size(); ++l) { // Light::averagePower (Light.cpp:42-51): emission or infinite light power
+		const uint32_t node = l < n_area ? s.emissions[s.entities[s.light_entity[l]].emission].radiance : s.inf_lights[l - n_area].l.radiance;
 		for (uint32_t i = 0; i < bins; i += 4) {
 			const uint32_t k = std::min<uint32_t>(bins - i, 4);
 			Blob wl = blob(0);
@@ -1603,12 +1637,50 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		}
 		if (hit.tri == INVALID) {
 			// depth 0: IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53);
-			// depth>0: handleZero (direct.cpp:459-464).  No infinite lights in this restatement.
+			// depth>0: handleInfLights (direct.cpp:415-456) when the scene has infinite lights, else handleZero (:459-464)
 			st[PRGPU_STAT_BACKGROUND_HITS]++;
+			// EnvironmentLight::eval (environment.cpp:53-73): depth 0 sees the background, deeper rays the radiance
+			auto env_radiance = [&](const Scene::InfLight& il) {
+				const uint32_t node = (ray.depth == 0 && il.l.background != INVALID) ? il.l.background : il.l.radiance;
+				return spectrum_eval(s, node, ray.wl);
+			};
 			if (ray.depth == 0) {
 				st[PRGPU_STAT_CAMERA_DEPTH]++;
-				const Blob one = blob(1);
-				push_fragment(s, out, lx, ly, one, one, grp_importance, blob(0), ray.mono, wl, blend, path_sum);
+				const Blob one	 = blob(1);
+				bool illuminated = false;
+				for (const auto& il : s.inf_lights) { // one fragment per non-delta infinite light
+					if (il.l.kind != PRGPU_LIGHT_ENVIRONMENT)
+						continue;
+					illuminated = true;
+					push_fragment(s, out, lx, ly, one, one, grp_importance, env_radiance(il), ray.mono, wl, blend, path_sum);
+				}
+				if (!illuminated)
+					push_fragment(s, out, lx, ly, one, one, grp_importance, blob(0), ray.mono, wl, blend, path_sum);
+			} else if (!s.inf_lights.empty() && cfg.direct) {
+				// ---- handleInfLights (direct.cpp:415-456)
+				const Blob hf	= hero_factor(ray.mono);
+				float denom_mis = 0;
+				Blob radiance	= blob(0);
+				const uint32_t n_area = (uint32_t)s.light_entity.size();
+				for (uint32_t k = 0; k < s.inf_lights.size(); ++k) {
+					const auto& il = s.inf_lights[k];
+					if (il.l.kind != PRGPU_LIGHT_ENVIRONMENT)
+						continue;
+					const V3 ld			= mat3_mul(il.inv_nm, ray.d);
+					const float dir_pdf = std::fabs(ld.z) * PR_INV_PI_F; // cos_hemi_pdf(|z|)
+					const float selProb = s.light_cdf[n_area + k + 1] - s.light_cdf[n_area + k]; // pdfLightSelection
+					const float pdf_S	= dir_pdf * selProb;
+					const Blob er = env_radiance(il);
+					for (int c = 0; c < 4; ++c)
+						radiance[c] += er[c];
+					denom_mis += bsum(mis_b(cur.prev_path_pdf * pdf_S));
+				}
+				if (!cfg.nee || cur.last_delta) {
+					push(hf / (cur.wvl_pdf * bsum(hf)), radiance, ray.mono);
+				} else {
+					const float denom = bsum(mis_b(cur.path_pdf)) + denom_mis;
+					push((hf * mis_f(cur.path_pdf[0])) / (mis_b(cur.wvl_pdf) * denom), radiance, ray.mono);
+				}
 			} else {
 				const Blob hf = hero_factor(ray.mono);
 				push(hf / (cur.wvl_pdf * bsum(hf)), blob(0), ray.mono);
@@ -1662,11 +1734,84 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 
 		const bool deltaMat = mat.kind != PRGPU_MAT_LAMBERT; // IMaterial::hasOnlyDeltaDistribution (dielectric, conductor)
 
-		if (cfg.nee && !deltaMat && !hasEmission && !s.light_entity.empty()) { // direct.cpp:100-101
+		if (cfg.nee && !deltaMat && !hasEmission && !s.light_intensity.empty()) { // direct.cpp:100-101
 			// ---- handleNEE (direct.cpp:233-352)
 			do {
 				float selPdf;
 				const uint32_t lid = distribution_sample_discrete(s.light_cdf.data(), (uint32_t)s.light_cdf.size(), rng_float(rnd), selPdf, nullptr);
+				if (lid >= s.light_entity.size()) {
+					// ---- infinite light: Light::sample (Light.cpp:112-150) + the isInfinite branches of handleNEE
+					const auto& il = s.inf_lights[lid - s.light_entity.size()];
+					const float d0 = rng_float(rnd), d1 = rng_float(rnd); // DirectionRND
+					(void)rng_float(rnd);								   // PositionRND (unused with a shading point)
+					(void)rng_float(rnd);
+					V3 L;
+					float dirPdf;
+					Blob radiance;
+					const bool delta = il.l.kind == PRGPU_LIGHT_DISTANT;
+					if (delta) { // distant.cpp:58-77
+						L		 = il.outgoing;
+						dirPdf	 = 1.0f;
+						radiance = spectrum_eval(s, il.l.radiance, ray.wl);
+					} else { // environment.cpp:75-116 (no distribution)
+						const V3 lo = cos_hemi(d0, d1);
+						dirPdf		= lo.z * PR_INV_PI_F;
+						L			= mat3_mul(il.nm, lo);
+						radiance	= spectrum_eval(s, il.l.radiance, ray.wl);
+					}
+					const V3 lpos	 = P + L * s.scene_radius; // LightPosition
+					const V3 dLP	 = lpos - P;
+					const float sqrD = dot(dLP, dLP);
+					const float cosC = std::fabs(dot(L, N));
+					const float cosL = 1.0f; // out.CosLight = 1
+					if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
+						break;
+					// material evaluation (Lambert)
+					const V3 Lt		= to_tangent_space(N, gp.Nx, gp.Ny, L);
+					const bool same = std::signbit(Vt.z) == std::signbit(Lt.z);
+					const float dt	= same ? (mat.two_sided ? std::fabs(Lt.z) : std::max(0.0f, Lt.z)) : 0.0f;
+					const Blob weight	   = (spectrum_eval(s, mat.albedo, ray.wl) * dt) * PR_INV_PI_F;
+					const float bsdf_pdf   = dt * PR_INV_PI_F;
+					const Blob rayHero	   = ray.mono ? hero_only() : blob(1);
+					const Blob hf		   = ray.mono ? hero_only() : blob(1);
+					const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+					if (all_le(bsdfWvlPdfS, PDF_EPS))
+						break;
+					const Blob connectionW = radiance * weight;
+					const bool worth	   = !is_zero(connectionW, PR_EPS);
+					float lightPdfS;
+					if (delta) {
+						lightPdfS = 1;
+					} else {
+						lightPdfS = dirPdf;
+						lightPdfS *= selPdf;
+						if (!std::isnormal(lightPdfS) || lightPdfS <= PDF_EPS)
+							break;
+					}
+					const Blob lightPdfS2 = (blob(1) * lightPdfS) * rayHero;
+					if (all_le(lightPdfS2, PDF_EPS))
+						break;
+					Blob mis;
+					if (cfg.direct && !cur.last_emissive) {
+						const float rr		= rr_probability(s, pathLength);
+						const Blob bsdfPdfS = bsdfWvlPdfS * rr;
+						const float denom	= bsum(mis_b(cur.path_pdf * lightPdfS2)) + bsum(mis_b(cur.path_pdf * bsdfPdfS));
+						mis = delta ? hf / bsum(hf) : blob(mis_f(cur.path_pdf[0] * lightPdfS2[0])) / ((hf * denom) * mis_b(cur.wvl_pdf));
+					} else {
+						mis = hf / (cur.wvl_pdf * bsum(hf));
+					}
+					const V3 oN	 = dot(L, N) < 0 ? -N : N;
+					const V3 so	 = safe_position(P, L, oN);
+					bool visible = false;
+					if (worth) {
+						st[PRGPU_STAT_SHADOW_RAYS]++;
+						visible = !trace_any(s, so, L, SHADOW_RAY_MIN, PR_INF_F, false); // distance = PR_INF (direct.cpp:329)
+					}
+					const Blob contrib = visible ? connectionW / lightPdfS2[0] : blob(0);
+					st[PRGPU_STAT_BACKGROUND_HITS]++;
+					push(mis, contrib, ray.mono);
+					break;
+				}
 				const uint32_t le  = s.light_entity[lid];
 				const prgpu_entity& LE = s.entities[le];
 				// MeshEntity::sampleParameterPoint (mesh.cpp:187-203) with SplitSample2D (SplitSample.h:6-55)
@@ -2040,6 +2185,32 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 		}
 		s.world_area[e] = s.vol_scale[e] * area;
 	}
+	{ // origin-centred bounding sphere of the world-space bounding box (Scene.cpp:107-118, Sphere::combine)
+		V3 lo = v3(PR_INF_F, PR_INF_F, PR_INF_F), hi = v3(-PR_INF_F, -PR_INF_F, -PR_INF_F);
+		for (const V3& p : s.wv) {
+			lo = v3(std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z));
+			hi = v3(std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z));
+		}
+		float r2 = 0;
+		const float fu = dot(hi, hi), fl = dot(lo, lo);
+		if (fu > r2)
+			r2 = fu;
+		float radius = std::sqrt(r2);
+		if (fl > radius * radius)
+			radius = std::sqrt(fl);
+		s.scene_radius = radius;
+	}
+	for (uint32_t i = 0; i < d->n_lights; ++i) {
+		Scene::InfLight il;
+		il.l = d->lights[i];
+		if (il.l.kind > PRGPU_LIGHT_DISTANT || il.l.radiance >= d->n_spectra || (il.l.background != INVALID && il.l.background >= d->n_spectra))
+			return fail("bad infinite light");
+		float det;
+		normal_matrix(il.l.transform, il.nm, det);
+		mat3_inverse(il.nm, il.inv_nm);
+		il.outgoing = normalized(mat3_mul(il.nm, v3(il.l.direction[0], il.l.direction[1], il.l.direction[2])));
+		s.inf_lights.push_back(il);
+	}
 	setup_camera(s);
 	{
 		float scale = std::max(std::fabs(s.cam_o.x), std::max(std::fabs(s.cam_o.y), std::fabs(s.cam_o.z)));
@@ -2382,7 +2553,7 @@ void orc_wavelength_cdf(orc_scene* h, uint32_t* size, const float** cdf)
 }
 void orc_light_selector(orc_scene* h, uint32_t* n, const float** cdf, const float** intens)
 {
-	*n		= (uint32_t)h->s.light_entity.size();
+	*n		= (uint32_t)h->s.light_intensity.size(); // area lights, then infinite lights
 	*cdf	= h->s.light_cdf.data();
 	*intens = h->s.light_intensity.data();
 }

@@ -15,6 +15,7 @@ INVALID_ID = 0xFFFFFFFF
 SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER = range(6)
 MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR = 0, 1, 2
 ENTITY_MESH, ENTITY_PLANE = 0, 1
+LIGHT_ENVIRONMENT, LIGHT_DISTANT = 0, 1
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_HAMMERSLEY, SAMPLER_UNIFORM, SAMPLER_STRATIFIED = range(7)
 MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO = range(3)
@@ -46,6 +47,11 @@ class Entity(C.Structure):
                 ("has_normals", C.c_uint32), ("kind", C.c_uint32), ("reserved", C.c_uint32 * 3), ("transform", C.c_float * 16)]
 
 
+class Light(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("radiance", C.c_uint32), ("background", C.c_uint32), ("reserved", C.c_uint32),
+                ("direction", C.c_float * 3), ("reserved2", C.c_float), ("transform", C.c_float * 16)]
+
+
 class Camera(C.Structure):
     _fields_ = [("transform", C.c_float * 16), ("width", C.c_float), ("height", C.c_float),
                 ("near_t", C.c_float), ("far_t", C.c_float), ("local_direction", C.c_float * 3),
@@ -72,7 +78,7 @@ class SceneDesc(C.Structure):
                 ("materials", C.POINTER(Material)), ("n_emissions", C.c_uint32),
                 ("emissions", C.POINTER(Emission)), ("n_spectra", C.c_uint32), ("spectra", C.POINTER(Spectrum)),
                 ("n_spectral_table_values", C.c_uint32), ("spectral_tables", C.POINTER(C.c_float)),
-                ("camera", Camera), ("settings", Settings)]
+                ("camera", Camera), ("settings", Settings), ("n_lights", C.c_uint32), ("lights", C.POINTER(Light))]
 
 
 class Tile(C.Structure):

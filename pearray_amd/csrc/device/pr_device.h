@@ -51,6 +51,13 @@ struct DevEntity {
 	uint32_t light_id, kind; // kind: PRGPU_ENTITY_*
 };
 
+// Infinite light (include/prgpu.h prgpu_light) with the matrices the kernels need
+struct DevInfLight {
+	uint32_t kind, radiance, background, pad;
+	float nm[9], inv_nm[9]; // ITransformable::normalMatrix / invNormalMatrix of the light's transform
+	float outgoing[3];		// DISTANT: normalized(nm * direction)
+};
+
 struct DevCamera {
 	float o[3], right[3], up[3], focal[3], xap[3], yap[3];
 	float near_t, far_t;
@@ -73,7 +80,10 @@ struct DevScene {
 	const float* tables;
 	const uint32_t* light_entity;
 	const float* light_cdf;
-	uint32_t n_lights;
+	uint32_t n_lights; // area lights; the infinite lights follow them in light_cdf
+	const DevInfLight* inf_lights;
+	uint32_t n_inf_lights;
+	float scene_radius; // origin-centred bounding sphere (Scene.cpp:107-118)
 	const float* wl_cdf;
 	uint32_t wl_cdf_size;
 	const float* sobol2d;

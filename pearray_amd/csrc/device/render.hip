@@ -743,13 +743,53 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
 		float xyz[3];
 		uint32_t fb;
-		if (depth == 0) {
+		if (depth == 0) { // IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53): one fragment per non-delta infinite light
 			atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
-			fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
+			bool illuminated = false;
+			for (uint32_t k = 0; k < sc.n_inf_lights; ++k) {
+				const DevInfLight& il = sc.inf_lights[k];
+				if (il.kind != PRGPU_LIGHT_ENVIRONMENT)
+					continue;
+				illuminated = true;
+				const Blob radiance = spectrum_eval(sc, il.background != INVALID ? il.background : il.radiance, wl); // environment.cpp:56-63
+				fb = fragment_value(sc, blob(1), blob(1), grp_imp, radiance, mono, cie, blend, xyz);
+				apply_fragment(ps, pixel, fb, xyz);
+			}
+			if (!illuminated) {
+				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
+				apply_fragment(ps, pixel, fb, xyz);
+			}
+		} else if (sc.n_inf_lights && cfg.direct) {
+			// ---- handleInfLights (direct.cpp:415-456)
+			float denom_mis = 0;
+			Blob radiance	= blob(0);
+			for (uint32_t k = 0; k < sc.n_inf_lights; ++k) {
+				const DevInfLight& il = sc.inf_lights[k];
+				if (il.kind != PRGPU_LIGHT_ENVIRONMENT)
+					continue;
+				const V3 ld			= mat3_mul(il.inv_nm, ray_d);
+				const float dir_pdf = fabsf(ld.z) * PR_INV_PI_F;
+				const float selProb = sc.light_cdf[sc.n_lights + k + 1] - sc.light_cdf[sc.n_lights + k];
+				const float pdf_S	= dir_pdf * selProb;
+				const Blob er		= spectrum_eval(sc, il.radiance, wl);
+				for (int c = 0; c < 4; ++c)
+					radiance.v[c] += er.v[c];
+				const Blob a = prev_pdf * pdf_S;
+				denom_mis += bsum(power_mis ? a * a : a);
+			}
+			if (!cfg.nee || (flags & FLAG_LAST_DELTA)) {
+				fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, radiance, mono, cie, blend, xyz);
+			} else {
+				const float denom = bsum(power_mis ? path_pdf * path_pdf : path_pdf) + denom_mis;
+				const float p0	  = power_mis ? path_pdf.v[0] * path_pdf.v[0] : path_pdf.v[0];
+				const Blob mis	  = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
+				fb				  = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
+			}
+			apply_fragment(ps, pixel, fb, xyz);
 		} else {
 			fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, blob(0), mono, cie, blend, xyz);
+			apply_fragment(ps, pixel, fb, xyz);
 		}
-		apply_fragment(ps, pixel, fb, xyz);
 	} else {
 		const V3 P = ray_o + ray_d * hit4.x;
 		GeomPoint gp;
@@ -799,11 +839,87 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
 			uint64_t rnd			 = ps.rng[pixel];
 			const bool deltaMat		 = mat.kind != PRGPU_MAT_LAMBERT; // IMaterial::hasOnlyDeltaDistribution (dielectric, conductor)
-			if (cfg.nee && !deltaMat && !hasEmission && sc.n_lights) { // direct.cpp:100-101
+			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + sc.n_inf_lights)) { // direct.cpp:100-101
 				// ---- handleNEE
 				do {
 					float selPdf;
-					const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + 1, rng_float(rnd), selPdf, nullptr);
+					const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + sc.n_inf_lights + 1, rng_float(rnd), selPdf, nullptr);
+					if (lid >= sc.n_lights) {
+						// ---- infinite light: Light::sample (Light.cpp:112-150) + the isInfinite branches of handleNEE
+						const DevInfLight& il = sc.inf_lights[lid - sc.n_lights];
+						const float d0 = rng_float(rnd), d1 = rng_float(rnd); // DirectionRND
+						(void)rng_float(rnd);								   // PositionRND (unused with a shading point)
+						(void)rng_float(rnd);
+						V3 L;
+						float dirPdf;
+						const bool delta	= il.kind == PRGPU_LIGHT_DISTANT;
+						const Blob radiance = spectrum_eval(sc, il.radiance, wl);
+						if (delta) { // distant.cpp:58-77
+							L	   = v3(il.outgoing[0], il.outgoing[1], il.outgoing[2]);
+							dirPdf = 1.0f;
+						} else { // environment.cpp:75-116 (no distribution)
+							const V3 lo = cos_hemi(d0, d1);
+							dirPdf		= lo.z * PR_INV_PI_F;
+							L			= mat3_mul(il.nm, lo);
+						}
+						const V3 lpos	 = P + L * sc.scene_radius;
+						const V3 dLP	 = lpos - P;
+						const float sqrD = dot(dLP, dLP);
+						const float cosC = fabsf(dot(L, N));
+						const float cosL = 1.0f;
+						if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
+							break;
+						const V3 Lt		  = to_tangent_space(N, gp.Nx, gp.Ny, L);
+						const bool same	  = signbit(Vt.z) == signbit(Lt.z);
+						const float dt	  = same ? (mat.two_sided ? fabsf(Lt.z) : fmaxf(0.0f, Lt.z)) : 0.0f;
+						const Blob weight = (spectrum_eval(sc, mat.albedo, wl) * dt) * PR_INV_PI_F;
+						const float bsdf_pdf   = dt * PR_INV_PI_F;
+						const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+						if (all_le(bsdfWvlPdfS, PDF_EPS))
+							break;
+						const Blob connectionW = radiance * weight;
+						const bool worth	   = !is_zero(connectionW, PR_EPS);
+						float lightPdfS;
+						if (delta) {
+							lightPdfS = 1;
+						} else {
+							lightPdfS = dirPdf;
+							lightPdfS *= selPdf;
+							if (!is_normal(lightPdfS) || lightPdfS <= PDF_EPS)
+								break;
+						}
+						const Blob lightPdfS2 = (blob(1) * lightPdfS) * hf;
+						if (all_le(lightPdfS2, PDF_EPS))
+							break;
+						Blob mis;
+						if (cfg.direct && !(flags & FLAG_LAST_EMISSIVE)) {
+							const float rr		= rr_probability(sc, pathLength);
+							const Blob bsdfPdfS = bsdfWvlPdfS * rr;
+							const Blob a = path_pdf * lightPdfS2, b = path_pdf * bsdfPdfS;
+							const float denom = bsum(power_mis ? a * a : a) + bsum(power_mis ? b * b : b);
+							const float num	  = path_pdf.v[0] * lightPdfS2.v[0];
+							mis = delta ? hf / bsum(hf) : blob(power_mis ? num * num : num) / ((hf * denom) * (power_mis ? wvl_pdf * wvl_pdf : wvl_pdf));
+						} else {
+							mis = hf / (wvl_pdf * bsum(hf));
+						}
+						const V3 oN = dot(L, N) < 0 ? -N : N;
+						const V3 so = safe_position(P, L, oN);
+						float xyz_vis[3];
+						const float xyz_occ[3] = { 0.0f, 0.0f, 0.0f };
+						const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, cie, blend, xyz_vis);
+						const uint32_t fb_occ = fragment_feedback_zero(mis, throughput, grp_imp, mono);
+						atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
+						if (worth) {
+							atomicAdd(&bs.v[PRGPU_STAT_SHADOW_RAYS], 1u);
+							want_shadow = true;
+							sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
+							sh_d		= make_float4(L.x, L.y, L.z, INFINITY); // distance = PR_INF (direct.cpp:329)
+							sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8)));
+						} else {
+							apply_fragment(ps, pixel, fb_occ, xyz_occ);
+						}
+						break;
+					}
 					const uint32_t le  = sc.light_entity[lid];
 					const DevEntity& LE = sc.entities[le];
 					const float u0 = rng_float(rnd), u1 = rng_float(rnd);

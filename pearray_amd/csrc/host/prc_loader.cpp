@@ -40,6 +40,7 @@ struct prgpu_prc {
 	std::vector<prgpu_material> materials;
 	std::vector<prgpu_emission> emissions;
 	std::vector<prgpu_spectrum> spectra;
+	std::vector<prgpu_light> lights;
 	prgpu_scene_desc desc;
 	std::string warnings;
 };
@@ -237,6 +238,8 @@ struct Loader {
 	{
 		if (v.is_number())
 			return spectrum_const((float)v.number());
+		if (v.type == Value::STRING) // SceneLoadContext::lookupSpectralNode: a string names a (node ...)/(texture ...) block
+			fail(PRGPU_EUNSUPPORTED, std::string(":") + key + " of " + where(owner) + " refers to the named node '" + v.s + "': named nodes are not supported");
 		if (v.type != Value::GROUP || v.g->is_array)
 			fail(PRGPU_EINVAL, std::string(":") + key + " of " + where(owner) + " is not a spectral expression");
 		const Group& e		 = *v.g;
@@ -451,6 +454,40 @@ struct Loader {
 		settings.mis				= mis == "power" ? PRGPU_MIS_POWER : PRGPU_MIS_BALANCE;
 		settings.emissive_scatter	= get_bool(g, "emissive_scatter", true) ? 1 : 0;
 		have_integrator				= true;
+	}
+	void add_light(const Group& g) // SceneLoader.cpp:558-600, environment.cpp:152-205, distant.cpp:112-121
+	{
+		const std::string type = lower(get_string(g, "type", ""));
+		prgpu_light l;
+		std::memset(&l, 0, sizeof(l));
+		transform_of(g, l.transform);
+		l.background   = PRGPU_INVALID_ID;
+		l.direction[2] = 1.0f;
+		if (type == "env" || type == "environment" || type == "background") {
+			l.kind					 = PRGPU_LIGHT_ENVIRONMENT;
+			const Value *rad = g.get("radiance"), *bg = g.get("background");
+			if (rad && bg) {
+				l.radiance	 = spectral_node(*rad, g, "radiance");
+				l.background = spectral_node(*bg, g, "background");
+			} else if (rad) {
+				l.radiance = spectral_node(*rad, g, "radiance");
+			} else if (bg) {
+				l.radiance = spectral_node(*bg, g, "background");
+			} else {
+				l.radiance = spectrum_const(1.0f);
+			}
+		} else if (type == "distant" || type == "direction") {
+			l.kind	   = PRGPU_LIGHT_DISTANT;
+			l.radiance = spectral_param(g, { "irradiance" }, 1.0f);
+			float d[3];
+			if (get_vec3(g, "direction", d))
+				std::memcpy(l.direction, d, sizeof(d));
+			if (l.direction[0] == 0 && l.direction[1] == 0 && l.direction[2] == 0)
+				fail(PRGPU_EINVAL, where(g) + ": distant light with a zero :direction");
+		} else {
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": light type '" + type + "' is not supported (env/environment/background and distant/direction are)");
+		}
+		out.lights.push_back(l);
 	}
 	void add_camera(const Group& g) // perspective.cpp:141-165
 	{
@@ -869,7 +906,9 @@ struct Loader {
 			warn(where(b) + ": output specification ignored (the backend produces the XYZ frame, sample count and feedback planes)");
 		else if (id == "embed" || id == "graph")
 			add_embed(b, dir);
-		else if (id == "light" || id == "texture" || id == "node")
+		else if (id == "light")
+			add_light(b);
+		else if (id == "texture" || id == "node")
 			fail(PRGPU_EUNSUPPORTED, where(b) + ": block is not supported by this backend yet");
 		else if (id == "scene")
 			fail(PRGPU_EINVAL, where(b) + ": invalid inner scene entry");
@@ -955,6 +994,8 @@ struct Loader {
 		d.spectral_tables		  = out.tables.data();
 		d.camera				  = cameras[cam];
 		d.settings				  = settings;
+		d.n_lights				  = (uint32_t)out.lights.size();
+		d.lights				  = out.lights.empty() ? nullptr : out.lights.data();
 	}
 };
 

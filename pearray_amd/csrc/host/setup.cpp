@@ -327,7 +327,23 @@ void light_tables(const prgpu_scene_desc* d, HostTables& t)
 		t.light_entity.push_back(e);
 		t.light_intensity.push_back(t.entities[e].world_area * mean);
 	}
-	if (!t.light_entity.empty()) {
+	// infinite lights follow with intensity 2 pi R mean(power) (LightSampler.cpp:20,62-71)
+	const float scene_area = 2 * 3.14159265358979323846f * t.scene_radius;
+	for (uint32_t i = 0; i < d->n_lights; ++i) {
+		float rs, re;
+		spectral_range(d, d->lights[i].radiance, rs, re);
+		if (rs < 0)
+			rs = d->settings.spectral_start;
+		if (re < 0)
+			re = d->settings.spectral_end;
+		V4 wl;
+		for (int k = 0; k < 4; ++k)
+			wl.v[k] = rs + (re - rs) * probe[k];
+		const V4 pw		 = average_power(d, d->lights[i].radiance, wl);
+		const float mean = (((pw.v[0] + pw.v[1]) + pw.v[2]) + pw.v[3]) / 4.0f;
+		t.light_intensity.push_back(scene_area * mean);
+	}
+	if (!t.light_intensity.empty()) {
 		float total;
 		make_cdf(t.light_intensity, t.light_cdf, &total);
 		if (total > EPS_F)
@@ -335,7 +351,64 @@ void light_tables(const prgpu_scene_desc* d, HostTables& t)
 				f *= 1 / total;
 	} else {
 		t.light_cdf.assign(2, 0.0f);
+	}
+	if (t.light_entity.empty())
 		t.light_entity.assign(1, 0);
+}
+
+// world-space bounding box -> origin-centred bounding sphere radius (Scene.cpp:107-118, Sphere::combine); infinite light matrices
+void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
+{
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (uint32_t tri = 0; tri < d->n_triangles; ++tri) {
+		const float* m = t.entities[t.tri_entity[tri]].m;
+		for (int k = 0; k < 3; ++k) {
+			const float* p = d->positions + 3 * d->indices[3 * tri + k];
+			for (int r = 0; r < 3; ++r) {
+				const float w = ((m[4 * r] * p[0] + m[4 * r + 1] * p[1]) + m[4 * r + 2] * p[2]) + m[4 * r + 3];
+				lo[r]		  = std::min(lo[r], w);
+				hi[r]		  = std::max(hi[r], w);
+			}
+		}
+	}
+	const float fu = (hi[0] * hi[0] + hi[1] * hi[1]) + hi[2] * hi[2], fl = (lo[0] * lo[0] + lo[1] * lo[1]) + lo[2] * lo[2];
+	float radius = fu > 0 ? std::sqrt(fu) : 0.0f;
+	if (fl > radius * radius)
+		radius = std::sqrt(fl);
+	t.scene_radius = radius;
+	t.inf_lights.resize(d->n_lights);
+	for (uint32_t i = 0; i < d->n_lights; ++i) {
+		const prgpu_light& src = d->lights[i];
+		prd::DevInfLight& L	   = t.inf_lights[i];
+		L.kind				   = src.kind;
+		L.radiance			   = src.radiance;
+		L.background		   = src.background;
+		L.pad				   = 0;
+		{ // (M^-1)^T = cofactor / det, same expression as entity_tables
+			const float* m = src.transform;
+			const float a = m[0], b = m[1], c = m[2], dd = m[4], ee = m[5], f = m[6], g = m[8], h = m[9], i2 = m[10];
+			const float cof[9] = { ee * i2 - f * h, f * g - dd * i2, dd * h - ee * g, c * h - b * i2, a * i2 - c * g, b * g - a * h, b * f - c * ee, c * dd - a * f, a * ee - b * dd };
+			const float det	   = (a * cof[0] + b * cof[1]) + c * cof[2];
+			for (int k = 0; k < 9; ++k)
+				L.nm[k] = cof[k] / det;
+		}
+		{ // inverse of the normal matrix: transposed cofactors / det
+			const float* m = L.nm;
+			const float a = m[0], b = m[1], c = m[2], dd = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i2 = m[8];
+			const float c00 = e * i2 - f * h, c01 = f * g - dd * i2, c02 = dd * h - e * g;
+			const float c10 = c * h - b * i2, c11 = a * i2 - c * g, c12 = b * g - a * h;
+			const float c20 = b * f - c * e, c21 = c * dd - a * f, c22 = a * e - b * dd;
+			const float det = (a * c00 + b * c01) + c * c02;
+			const float inv[9] = { c00 / det, c10 / det, c20 / det, c01 / det, c11 / det, c21 / det, c02 / det, c12 / det, c22 / det };
+			std::memcpy(L.inv_nm, inv, sizeof(inv));
+		}
+		const float* dv = src.direction;
+		float o[3];
+		for (int r = 0; r < 3; ++r)
+			o[r] = (L.nm[3 * r] * dv[0] + L.nm[3 * r + 1] * dv[1]) + L.nm[3 * r + 2] * dv[2];
+		const float len = std::sqrt((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]);
+		for (int r = 0; r < 3; ++r)
+			L.outgoing[r] = o[r] / len;
 	}
 }
 
@@ -345,8 +418,8 @@ void wavelength_table(const prgpu_scene_desc* d, HostTables& t, size_t n_lights)
 	const float start = d->settings.spectral_start, span = d->settings.spectral_end - d->settings.spectral_start;
 	auto wavelength_of = [&](uint32_t bin) { return start + (bin / float(bins - 1)) * span; };
 	std::vector<float> total(bins, 0.0f), one(bins, 0.0f);
-	for (size_t l = 0; l < n_lights; ++l) {
-		const uint32_t node = d->emissions[d->entities[t.light_entity[l]].emission].radiance;
+	for (size_t l = 0; l < n_lights + d->n_lights; ++l) { // area lights, then infinite lights (Light::averagePower)
+		const uint32_t node = l < n_lights ? d->emissions[d->entities[t.light_entity[l]].emission].radiance : d->lights[l - n_lights].radiance;
 		for (uint32_t i = 0; i < bins; i += 4) {
 			const uint32_t k = std::min<uint32_t>(bins - i, 4);
 			V4 wl{ { 0, 0, 0, 0 } };
@@ -559,6 +632,17 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		if (m.kind == PRGPU_MAT_DIELECTRIC && (m.ior >= d->n_spectra || (m.transmission != PRGPU_INVALID_ID && m.transmission >= d->n_spectra)))
 			return bad("dielectric index / transmission spectrum out of range");
 	}
+	if (d->n_lights && !d->lights)
+		return bad("n_lights without a lights array");
+	for (uint32_t i = 0; i < d->n_lights; ++i) {
+		const prgpu_light& l = d->lights[i];
+		if (l.kind > PRGPU_LIGHT_DISTANT)
+			return bad("unknown infinite light kind");
+		if (l.radiance >= d->n_spectra || (l.background != PRGPU_INVALID_ID && l.background >= d->n_spectra))
+			return bad("infinite light spectrum index out of range");
+		if (l.kind == PRGPU_LIGHT_DISTANT && !((l.direction[0] != 0) || (l.direction[1] != 0) || (l.direction[2] != 0)))
+			return bad("distant light with a zero direction");
+	}
 	for (uint32_t i = 0; i < d->n_emissions; ++i) {
 		if (d->emissions[i].kind != PRGPU_EMS_DIFFUSE)
 			return bad("only diffuse emissions are implemented", PRGPU_EUNSUPPORTED);
@@ -579,6 +663,7 @@ int build_tables(const prgpu_scene_desc* d, HostTables& t, std::string& err)
 	(void)err;
 	entity_tables(d, t);
 	sampler_tables(d, t);
+	infinite_light_tables(d, t);
 	light_tables(d, t);
 	size_t n_lights = 0;
 	for (uint32_t e = 0; e < d->n_entities; ++e)

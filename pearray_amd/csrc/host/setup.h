@@ -17,6 +17,8 @@ struct HostTables {
 	std::vector<uint32_t> tri_entity;
 	std::vector<uint32_t> light_entity;
 	std::vector<float> light_cdf, light_intensity;
+	std::vector<prd::DevInfLight> inf_lights;
+	float scene_radius = 0.0f;
 	std::vector<float> wl_cdf;
 	std::vector<float> sobol2d; // tabulated AA samples (sobol, halton or hammersley)
 	uint32_t halton_bx = 13, halton_by = 47, halton_burnin = 47;

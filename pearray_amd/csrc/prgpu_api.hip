@@ -231,6 +231,12 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	UP(sc.tables, d->spectral_tables, d->n_spectral_table_values);
 	UP(sc.light_entity, t.light_entity);
 	UP(sc.light_cdf, t.light_cdf);
+	{
+		std::vector<prd::DevInfLight> il = t.inf_lights;
+		if (il.empty())
+			il.resize(1); // never read
+		UP(sc.inf_lights, il);
+	}
 	UP(sc.wl_cdf, t.wl_cdf);
 	UP(sc.sobol2d, t.sobol2d);
 	UP(sc.rr_prob, t.rr_prob);
@@ -239,6 +245,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.n_lights = 0;
 	for (uint32_t e = 0; e < d->n_entities; ++e)
 		sc.n_lights += d->entities[e].emission != PRGPU_INVALID_ID;
+	sc.n_inf_lights	 = d->n_lights;
+	sc.scene_radius	 = t.scene_radius;
 	sc.wl_cdf_size	 = (uint32_t)t.wl_cdf.size();
 	sc.rr_size		 = (uint32_t)t.rr_prob.size();
 	sc.cam			 = t.cam;

@@ -36,7 +36,7 @@ class SceneBuilder:
         self.settings = abi.default_settings(width, height)
         self.camera = abi.Camera()
         self.spectra, self.tables = [], []
-        self.materials, self.emissions, self.entities = [], [], []
+        self.materials, self.emissions, self.entities, self.lights = [], [], [], []
         self._pos, self._nrm, self._idx, self._trimat = [], [], [], []
         self._n_vertices = 0
         self._any_normals = False
@@ -168,6 +168,24 @@ class SceneBuilder:
         self._n_vertices += len(positions)
         return len(self.entities) - 1
 
+    def _light(self, kind, radiance, background, direction, transform):
+        l = abi.Light(kind, radiance, abi.INVALID_ID if background is None else background, 0)
+        for i in range(3):
+            l.direction[i] = float(direction[i])
+        t = np.asarray(transform, dtype=np.float32).reshape(16)
+        for i in range(16):
+            l.transform[i] = float(t[i])
+        self.lights.append(l)
+        return len(self.lights) - 1
+
+    def environment_light(self, radiance, background=None, transform=IDENTITY):
+        """(light :type 'env' :radiance r [:background b]), environment.cpp:152-205 (untextured)"""
+        return self._light(abi.LIGHT_ENVIRONMENT, radiance, background, (0, 0, 1), transform)
+
+    def distant_light(self, irradiance, direction=(0, 0, 1), transform=IDENTITY):
+        """(light :type 'distant' :direction d :irradiance e), distant.cpp:112-121"""
+        return self._light(abi.LIGHT_DISTANT, irradiance, None, direction, transform)
+
     def add_plane(self, material, x_axis=(1, 0, 0), y_axis=(0, 1, 0), width=1.0, height=1.0, centering=False, transform=IDENTITY):
         """(entity :type 'plane'), plane.cpp:241-258: parallelogram spanned by width * x_axis and height * y_axis"""
         x = np.float32(width) * np.asarray(x_axis, dtype=np.float32)
@@ -227,6 +245,9 @@ class SceneData:
         d.spectral_tables = self.tables.ctypes.data_as(C.POINTER(C.c_float))
         d.camera = b.camera
         d.settings = b.settings
+        self.lights = (abi.Light * max(1, len(b.lights)))(*b.lights)
+        d.n_lights = len(b.lights)
+        d.lights = self.lights
         self.desc = d
 
     @property

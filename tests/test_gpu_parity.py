@@ -413,3 +413,70 @@ def test_plane_entities_bit_exact_and_report_primitive_zero():
     for x, y in zip(a, bb):
         assert np.array_equal(x, y)
     assert set(np.unique(a[1][a[0] == 0])) == {0}
+
+
+def _open_scene(lights, spp=6, glass=False, **settings):
+    """Floor + two boxes under infinite lights (no walls, so camera and bounce rays reach the background)."""
+    b = scene.SceneBuilder(96, 72)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+    T = np.array([[1, 0, 0, 0], [0, 0.8, 0.6, 2.2], [0, -0.6, 0.8, 3.0], [0, 0, 0, 1]], dtype=np.float32)
+    b.set_camera(T, width=0.9, height=0.675, near=0.01, far=100.0, local_direction=(0, 0, -1), local_up=(0, 1, 0), local_right=(1, 0, 0))
+    white = b.lambert(b.refl(0.7, 0.7, 0.7))
+    box_m = b.dielectric(b.lookup_index("bk7")) if glass else b.lambert(b.refl(0.2, 0.5, 0.7))
+    b.add_plane(white, x_axis=(1, 0, 0), y_axis=(0, 0, -1), width=8, height=8, centering=True)
+    cube_p = [[x, y, z] for x in (-0.5, 0.5) for y in (0, 1) for z in (-0.5, 0.5)]
+    cube_f = [[0, 1, 3, 2], [4, 6, 7, 5], [0, 4, 5, 1], [2, 3, 7, 6], [0, 2, 6, 4], [1, 5, 7, 3]]
+    b.add_mesh(cube_p, cube_f, box_m, transform=np.array([[0.8, 0, 0.6, -0.7], [0, 1.2, 0, 0], [-0.6, 0, 0.8, 0], [0, 0, 0, 1]], dtype=np.float32))
+    b.add_mesh(cube_p, cube_f, white, transform=np.array([[0.6, 0, 0, 0.9], [0, 0.6, 0, 0], [0, 0, 0.6, 0.6], [0, 0, 0, 1]], dtype=np.float32))
+    for l in lights:
+        if l == "env":
+            b.environment_light(b.illuminant_d65())
+        elif l == "env_split_rot":
+            R = np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], dtype=np.float32)     # light z axis -> world +y
+            b.environment_light(b.smul(b.illuminant_d65(), b.illum(1.0, 0.9, 0.8)), background=b.refl(0.1, 0.2, 0.6), transform=R)
+        elif l == "sun":
+            b.distant_light(b.illum(4, 4, 3.5), direction=(0.3, 0.9, 0.2))
+        elif l == "lamp":
+            b.add_mesh([[-0.4, 2.5, -0.4], [0.4, 2.5, -0.4], [0.4, 2.5, 0.4], [-0.4, 2.5, 0.4]], [[0, 3, 2, 1]], white, emission=b.diffuse_emission(b.illum(9, 9, 8)))
+    return b.build()
+
+
+@pytest.mark.parametrize("lights,kw", [(("env",), {}), (("env_split_rot",), {}), (("sun",), {}), (("env_split_rot", "sun", "lamp"), {}),
+                                       (("env", "sun"), dict(mis=abi.MIS_POWER)), (("env",), dict(nee=0)), (("env", "lamp"), dict(direct=0)),
+                                       (("env_split_rot", "sun"), dict(spectral_hero=0))])
+def test_infinite_lights_bit_exact(lights, kw):
+    """environment (untextured, optional split background, rotated frame) and distant lights: NEE sampling, background hits of camera
+    and bounce rays with MIS (direct.cpp:415-456), selection together with an area light -- identical to the checker."""
+    g, o = render_both(_open_scene(lights, **kw))
+    assert_parity(g, o, exact=True)
+    assert g.statistics()["background_hits"] > 0
+
+
+def test_infinite_lights_with_glass_and_in_every_pipeline(monkeypatch):
+    sc = _open_scene(("env_split_rot", "sun"), glass=True)
+    g, o = render_both(sc)
+    assert_parity(g, o, exact=True)
+    ref = _render_mode(monkeypatch, "lockstep", sc, [6])
+    for mode in ("streaming", "persistent"):
+        out = _render_mode(monkeypatch, mode, sc, [6])
+        for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+            assert np.array_equal(a, b), mode
+        assert ref[2] == out[2], mode
+
+
+def test_infinite_lights_through_the_prc_loader():
+    src = """(scene :render_width 48 :render_height 36
+      (sampler :slot 'aa' :type 'hammersley' :sample_count 5)
+      (camera :name 'c' :type 'standard' :local_direction [0,0,-1] :local_up [0,1,0] :local_right [1,0,0] :position [0,1.2,3.5])
+      (light :name 'sky' :type 'env' :radiance (smul (illuminant "D65") (illum 0.8 0.9 1.0)) :background 0.3 :rotation (euler -90 0 0))
+      (light :name 'sun' :type 'distant' :direction [0.2, 1, 0.3] :irradiance (illum 3 3 2.5))
+      (material :name 'white' :type 'diffuse' :albedo (refl 0.7 0.7 0.7))
+      (material :name 'metal' :type 'conductor')
+      (entity :name 'floor' :type 'plane' :material 'white' :x_axis [1,0,0] :y_axis [0,0,-1] :width 6 :height 6 :centering true)
+      (mesh :name 'quad' (attribute :type 'p' [-1,0,-1],[1,0,-1],[1,0,1],[-1,0,1]) (faces [0,1,2,3]))
+      (entity :name 'mirror' :type 'mesh' :mesh 'quad' :materials 'metal' :rotation (euler 60 20 0) :position [0,1,-1] :scale 0.8)
+    )"""
+    g, o = render_both(scene.PrcScene(source=src))
+    assert_parity(g, o, exact=True)

@@ -34,7 +34,8 @@ def assert_same_desc(a, b, check_settings=True):
     assert np.array_equal(arr(a.indices, 3 * a.n_triangles, np.uint32), arr(b.indices, 3 * b.n_triangles, np.uint32))
     assert np.array_equal(arr(a.tri_material, a.n_triangles, np.uint32), arr(b.tri_material, b.n_triangles, np.uint32))
     assert np.array_equal(arr(a.spectral_tables, a.n_spectral_table_values, np.float32), arr(b.spectral_tables, b.n_spectral_table_values, np.float32))
-    for name, n in (("entities", a.n_entities), ("materials", a.n_materials), ("emissions", a.n_emissions), ("spectra", a.n_spectra)):
+    assert a.n_lights == b.n_lights
+    for name, n in (("entities", a.n_entities), ("materials", a.n_materials), ("emissions", a.n_emissions), ("spectra", a.n_spectra), ("lights", a.n_lights)):
         for i in range(n):
             assert struct_bytes(getattr(a, name)[i]) == struct_bytes(getattr(b, name)[i]), (name, i)
     assert struct_bytes(a.camera) == struct_bytes(b.camera)
@@ -103,7 +104,7 @@ def test_defaults_follow_the_reference():
     ("(material :name 'g' :type 'glass' :roughness 0.1)", -4, "rough dielectrics"),
     ("(material :name 'g' :type 'principled')", -4, "material type 'principled'"),
     ("(material :name 'g' :type 'metal' :roughness_x 0.1)", -4, "rough conductors"),
-    ("(light :name 'sky' :type 'sky')", -4, "(light"),
+    ("(light :name 'sky' :type 'sky')", -4, "light type 'sky'"),
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
     ("(sampler :type 'blue_noise')", -4, "sampler type 'blue_noise'"),
     ("(filter :type 'box3')", -1, "unknown filter type 'box3'"),
@@ -246,3 +247,22 @@ def test_plane_entity_matches_scene_builder():
     with pytest.raises(abi.PrgpuError) as e:
         scene.PrcScene(source=MINIMAL % "(emission :name 'l' :type 'standard') (entity :name 'p' :type 'plane' :material 'm' :emission 'l')")
     assert e.value.args[1] == -4 and "emissive plane" in e.value.args[0]
+
+
+def test_infinite_lights_match_scene_builder():
+    src = MINIMAL % ("(light :name 'sky' :type 'env' :radiance (illuminant 'D65') :background 0.25 :rotation (euler 90 0 0))"
+                     "(light :name 'sun' :type 'distant' :direction [0.2, -1, 0.1] :irradiance (illum 3 3 2))"
+                     "(light :type 'background')")
+    s = scene.PrcScene(source=src)
+    b = scene.SceneBuilder(8, 8)
+    b.set_camera(scene.IDENTITY, near=1e-6, local_direction=(0, 1, 0), local_up=(0, 0, 1), local_right=(1, 0, 0))
+    m = b.lambert(b.spectrum_const(1.0))
+    b.environment_light(b.illuminant_d65(), background=b.spectrum_const(0.25), transform=np.array(list(s.desc.lights[0].transform), dtype=np.float32).reshape(4, 4))
+    b.distant_light(b.illum(3, 3, 2), direction=(0.2, -1, 0.1))
+    b.environment_light(b.spectrum_const(1.0))
+    b.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]], m)
+    want = b.build()
+    # the loader creates nodes in block order: material, then the lights; the builder above created the material first too
+    assert_same_desc(s.desc, want.desc)
+    rot = np.array(list(s.desc.lights[0].transform), dtype=np.float32).reshape(4, 4)
+    assert np.allclose(rot[:3, :3], [[1, 0, 0], [0, 0, -1], [0, 1, 0]], atol=1e-6)
