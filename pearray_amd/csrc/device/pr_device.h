@@ -51,6 +51,8 @@ struct DevEntity {
 	uint32_t light_id, kind; // kind: PRGPU_ENTITY_*
 };
 
+constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u;
+
 // Infinite light (include/prgpu.h prgpu_light) with the matrices the kernels need
 struct DevInfLight {
 	uint32_t kind, radiance, background, pad;
@@ -84,6 +86,7 @@ struct DevScene {
 	const DevInfLight* inf_lights;
 	uint32_t n_inf_lights;
 	float scene_radius; // origin-centred bounding sphere (Scene.cpp:107-118)
+	uint32_t features;	// FEAT_* bits the scene needs beyond Lambert + meshes + area lights (selects the kernel variant)
 	const float* wl_cdf;
 	uint32_t wl_cdf_size;
 	const float* sobol2d;

@@ -362,13 +362,14 @@ __device__ __forceinline__ uint32_t prim_id(const DevScene& sc, uint32_t tri)
 	return E.kind == PRGPU_ENTITY_PLANE ? 0u : tri - E.first_tri;
 }
 // MeshEntity::provideGeometryPoint (entities/mesh.cpp:205-250)
+template <bool FULL>
 __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri, float u, float v, GeomPoint& g)
 {
 	const uint32_t e   = sc.tri_entity[tri];
 	const DevEntity& E = sc.entities[e];
 	const uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
 	V3 N, Nx, Ny;
-	if (E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
+	if (FULL && E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
 		const uint32_t t0 = E.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0
 		const V3 v0 = load3(sc.positions, sc.indices[3 * t0]), v1 = load3(sc.positions, sc.indices[3 * t0 + 1]), v3p = load3(sc.positions, sc.indices[3 * t0 + 2]);
 		const V3 x = v3p - v0, y = v1 - v0;
@@ -706,6 +707,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 // (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53).
 // Processes the path vertex of `slot` whose closest hit is in ps.hit[slot]: adds emission, prepares the NEE shadow ray
 // (returned in sh_*, want_shadow) and the next bounce ray (written to the slot, alive).
+// FULL = false is the lean variant for scenes with Lambert materials, mesh entities and area lights only (DevScene::features == 0,
+// e.g. the C4 benchmark scene): delta materials, infinite lights and plane entities are compiled out, which keeps their registers
+// and spills out of the hot kernel.
+template <bool FULL>
 __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState& ps, uint32_t slot, BlockStats& bs, bool& alive, bool& want_shadow,
 											 float4& sh_o, float4& sh_d, float4& sh_xyz)
 {
@@ -746,7 +751,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		if (depth == 0) { // IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53): one fragment per non-delta infinite light
 			atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
 			bool illuminated = false;
-			for (uint32_t k = 0; k < sc.n_inf_lights; ++k) {
+			for (uint32_t k = 0; FULL && k < sc.n_inf_lights; ++k) {
 				const DevInfLight& il = sc.inf_lights[k];
 				if (il.kind != PRGPU_LIGHT_ENVIRONMENT)
 					continue;
@@ -759,7 +764,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
 				apply_fragment(ps, pixel, fb, xyz);
 			}
-		} else if (sc.n_inf_lights && cfg.direct) {
+		} else if (FULL && sc.n_inf_lights && cfg.direct) {
 			// ---- handleInfLights (direct.cpp:415-456)
 			float denom_mis = 0;
 			Blob radiance	= blob(0);
@@ -793,7 +798,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	} else {
 		const V3 P = ray_o + ray_d * hit4.x;
 		GeomPoint gp;
-		geometry_point(sc, tri, hit4.y, hit4.z, gp);
+		geometry_point<FULL>(sc, tri, hit4.y, hit4.z, gp);
 		const V3 N		   = gp.N;
 		const float NdotV  = dot(ray_d, N);
 		const V3 dP		   = ray_o - P;
@@ -838,13 +843,13 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			const prgpu_material mat = sc.materials[gp.material];
 			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
 			uint64_t rnd			 = ps.rng[pixel];
-			const bool deltaMat		 = mat.kind != PRGPU_MAT_LAMBERT; // IMaterial::hasOnlyDeltaDistribution (dielectric, conductor)
-			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + sc.n_inf_lights)) { // direct.cpp:100-101
+			const bool deltaMat		 = FULL && mat.kind != PRGPU_MAT_LAMBERT; // IMaterial::hasOnlyDeltaDistribution (dielectric, conductor)
+			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + (FULL ? sc.n_inf_lights : 0u))) { // direct.cpp:100-101
 				// ---- handleNEE
 				do {
 					float selPdf;
-					const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + sc.n_inf_lights + 1, rng_float(rnd), selPdf, nullptr);
-					if (lid >= sc.n_lights) {
+					const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + (FULL ? sc.n_inf_lights : 0u) + 1, rng_float(rnd), selPdf, nullptr);
+					if (FULL && lid >= sc.n_lights) {
 						// ---- infinite light: Light::sample (Light.cpp:112-150) + the isInfinite branches of handleNEE
 						const DevInfLight& il = sc.inf_lights[lid - sc.n_lights];
 						const float d0 = rng_float(rnd), d1 = rng_float(rnd); // DirectionRND
@@ -945,7 +950,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					}
 					const V3 lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
 					GeomPoint lgp;
-					geometry_point(sc, ltri, bu, bv, lgp);
+					geometry_point<FULL>(sc, ltri, bu, bv, lgp);
 					const V3 L			 = normalized(lp - P);
 					const float cosLight = fminf(1.0f, fmaxf(-1.0f, -dot(L, lgp.N)));
 					const Blob radiance	 = spectrum_eval(sc, sc.emissions[LE.emission].radiance, wl);
@@ -1016,7 +1021,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				V3 Lt;
 				Blob integral_weight, pdf_s;
 				bool heroCollapsing = false;
-				if (mat.kind == PRGPU_MAT_CONDUCTOR) {
+				if (FULL && mat.kind == PRGPU_MAT_CONDUCTOR) {
 					// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
 					pdf_s		   = blob(1);
 					const Blob eta = spectrum_eval(sc, mat.ior, wl), kk = spectrum_eval(sc, mat.k, wl);
@@ -1118,7 +1123,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 	float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
 	if (i < n_active) {
 		slot = active ? active[i] : slot_base + i;
-		shade_vertex(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+		if (sc.features)
+			shade_vertex<true>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+		else
+			shade_vertex<false>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 	}
 	// ballot/prefix-scan compaction of survivors, finished paths and of the shadow queue
 	const uint32_t pos_next = wave_append(alive, &counters[0]);
@@ -1304,7 +1312,7 @@ struct PersistentArgs {
 	unsigned long long* gstats;
 };
 
-template <bool COUNT>
+template <bool COUNT, bool FULL>
 __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathState& ps, const PersistentArgs& a)
 {
 	__shared__ PPShared sh;
@@ -1372,7 +1380,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				bool alive = false, want_shadow = false;
 				float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
 				if (mine && !regen)
-					shade_vertex(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+					shade_vertex<FULL>(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 				// the path ended: fold the sample, then the pixel's next sample or the next pixel
 				const bool ended = mine && (regen || (!alive && !want_shadow));
 				bool need_pixel	 = false;
@@ -1577,15 +1585,15 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 }
 // Two register budgets of the same kernel: 2 waves per SIMD (no spills) and 3 waves per SIMD (the compiler spills a few shading
 // temporaries to scratch); which one is faster is a latency-hiding question answered by measurement (PRGPU_PP_OCCUPANCY).
-template <bool COUNT>
+template <bool COUNT, bool FULL>
 __global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, PathState ps, PersistentArgs a)
 {
-	path_persistent<COUNT>(sc, ps, a);
+	path_persistent<COUNT, FULL>(sc, ps, a);
 }
-template <bool COUNT>
+template <bool COUNT, bool FULL>
 __global__ void __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_path_persistent_occ3(DevScene sc, PathState ps, PersistentArgs a)
 {
-	path_persistent<COUNT>(sc, ps, a);
+	path_persistent<COUNT, FULL>(sc, ps, a);
 }
 
 // ---- ray service kernels (IArchive surface) ------------------------------------------------------------
@@ -1720,15 +1728,24 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.both_below	  = std::min(65, std::max(0, both_below));
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
-	if (occupancy >= 3) {
-		if (count)
-			hipLaunchKernelGGL(k_path_persistent_occ3<true>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
-		else
-			hipLaunchKernelGGL(k_path_persistent_occ3<false>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
-	} else if (count)
-		hipLaunchKernelGGL(k_path_persistent<true>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
+	const dim3 grid(g.n_blocks), block(TRAV_BLOCK);
+	const bool full = sc.features != 0; // lean variant for Lambert / mesh / area-light scenes
+#define PR_LAUNCH_PP(KERNEL)                                                                         \
+	do {                                                                                             \
+		if (count && full)                                                                           \
+			hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, st, sc, ps, a);                 \
+		else if (count)                                                                              \
+			hipLaunchKernelGGL((KERNEL<true, false>), grid, block, 0, st, sc, ps, a);                \
+		else if (full)                                                                               \
+			hipLaunchKernelGGL((KERNEL<false, true>), grid, block, 0, st, sc, ps, a);                \
+		else                                                                                         \
+			hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, st, sc, ps, a);               \
+	} while (0)
+	if (occupancy >= 3)
+		PR_LAUNCH_PP(k_path_persistent_occ3);
 	else
-		hipLaunchKernelGGL(k_path_persistent<false>, dim3(g.n_blocks), dim3(TRAV_BLOCK), 0, st, sc, ps, a);
+		PR_LAUNCH_PP(k_path_persistent);
+#undef PR_LAUNCH_PP
 }
 
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * TRAV_BLOCK * STACK_SPILL; }

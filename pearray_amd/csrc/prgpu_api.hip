@@ -246,6 +246,13 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	for (uint32_t e = 0; e < d->n_entities; ++e)
 		sc.n_lights += d->entities[e].emission != PRGPU_INVALID_ID;
 	sc.n_inf_lights	 = d->n_lights;
+	sc.features		 = d->n_lights ? prd::FEAT_INFINITE_LIGHTS : 0u;
+	for (uint32_t i = 0; i < d->n_materials; ++i)
+		if (d->materials[i].kind != PRGPU_MAT_LAMBERT)
+			sc.features |= prd::FEAT_DELTA_MATERIALS;
+	for (uint32_t e = 0; e < d->n_entities; ++e)
+		if (d->entities[e].kind == PRGPU_ENTITY_PLANE)
+			sc.features |= prd::FEAT_PLANES;
 	sc.scene_radius	 = t.scene_radius;
 	sc.wl_cdf_size	 = (uint32_t)t.wl_cdf.size();
 	sc.rr_size		 = (uint32_t)t.rr_prob.size();
