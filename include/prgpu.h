@@ -113,15 +113,20 @@ typedef struct prgpu_emission {
 /* PLANE (src/plugins/main/entities/plane.cpp): a parallelogram p, p + y, p + y + x, p + x handed to Embree as ONE quad
  * (plane.cpp:70-92), i.e. exactly two triangles over four local vertices v0..v3 indexed (0,1,3), (2,3,1); both report
  * primitive id 0; the shading frame is N = nm * normalize(x X y), Nx = M x, Ny = M y (normalised; plane.cpp:206-217,225-238) with
- * x = v3 - v0, y = v1 - v0.  Emissive planes are not supported yet (spherical-rectangle sampling, plane.cpp:94-196). */
-enum { PRGPU_ENTITY_MESH = 0, PRGPU_ENTITY_PLANE = 1 };
+ * x = v3 - v0, y = v1 - v0.  Emissive planes are not supported yet (spherical-rectangle sampling, plane.cpp:94-196).
+ * SPHERE (src/plugins/main/entities/sphere.cpp): an Embree RTC_GEOMETRY_TYPE_SPHERE_POINT at M * (0,0,0) with radius
+ * `radius` * mean column norm of the linear part (sphere.cpp:77-92).  Described as ONE placeholder triangle (its three indices are
+ * ignored) so that the per-triangle arrays stay uniform; primitive id 0; N = normalize(P - centre), Tangent::frame (sphere.cpp:118-129).
+ * Emissive spheres are not supported yet. */
+enum { PRGPU_ENTITY_MESH = 0, PRGPU_ENTITY_PLANE = 1, PRGPU_ENTITY_SPHERE = 2 };
 typedef struct prgpu_entity {
 	uint32_t first_tri;
 	uint32_t n_tris;
 	uint32_t emission;     /* emission index or PRGPU_INVALID_ID */
 	uint32_t has_normals;  /* MESH: 1: interpolate vertex normals (MeshEntity<*,true>), 0: geometric */
 	uint32_t kind;         /* PRGPU_ENTITY_* */
-	uint32_t reserved[3];
+	float    radius;       /* SPHERE: local radius (`:radius`, default 1) */
+	uint32_t reserved[2];
 	float    transform[16];
 } prgpu_entity;
 

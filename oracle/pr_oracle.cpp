@@ -677,6 +677,8 @@ struct Scene {
 	std::vector<std::array<float, 9>> nmat; // per entity normal matrix
 	std::vector<float> vol_scale;		   // |det linear|
 	std::vector<float> world_area;		   // IEntity::worldSurfaceArea
+	std::vector<V3> sphere_c;			   // SPHERE entities: world centre (transform * 0) ...
+	std::vector<float> sphere_r;		   // ... and world radius (sphere.cpp:77-92)
 	float eps_t = 0;					   // slab-test slack, 8e-6 * max |coordinate| (world vertices, camera origin)
 	// BVH
 	std::vector<BvhNode> nodes;
@@ -1029,11 +1031,42 @@ void bvh_build(Scene& s)
 	bvh_build_rec(c, 0, 0, n);
 }
 
+// Ray / sphere, the formulation of Embree 3's sphere intersector (un-vendored dependency; kernels/geometry/sphere_intersector.h):
+// project the centre onto the ray, compare the perpendicular distance with the radius, front root first, then the back root.
+// Reports the nearest root in (tmin, limit]; u = v = 0 like Embree's point primitives.
+inline bool sphere_hit(const RayPre& r, V3 c, float radius, float tmin, float limit, float& t)
+{
+	const float rd2	   = 1.0f / dot(r.d, r.d);
+	const V3 c0		   = c - r.o;
+	const float projC0 = dot(c0, r.d) * rd2;
+	const V3 perp	   = c0 - r.d * projC0;
+	const float l2	   = dot(perp, perp);
+	const float r2	   = radius * radius;
+	if (!(l2 <= r2))
+		return false;
+	const float td		= std::sqrt((r2 - l2) * rd2);
+	const float t_front = projC0 - td, t_back = projC0 + td;
+	if (t_front > tmin && t_front <= limit) {
+		t = t_front;
+		return true;
+	}
+	if (t_back > tmin && t_back <= limit) {
+		t = t_back;
+		return true;
+	}
+	return false;
+}
+inline bool prim_is_sphere(const Scene& s, uint32_t tri) { return s.entities[s.tri_entity[tri]].kind == PRGPU_ENTITY_SPHERE; }
 // closest hit: tmin < t <= tmax; equal t -> lower global triangle index wins (documented tie rule)
 inline void test_tri_closest(const Scene& s, const RayPre& r, uint32_t tri, float tmin, Hit& best)
 {
 	float t, u, v;
-	if (!woop(r, s.wv[3 * tri], s.wv[3 * tri + 1], s.wv[3 * tri + 2], t, u, v))
+	if (prim_is_sphere(s, tri)) {
+		const uint32_t e = s.tri_entity[tri];
+		if (!sphere_hit(r, s.sphere_c[e], s.sphere_r[e], tmin, best.t, t))
+			return;
+		u = v = 0.0f;
+	} else if (!woop(r, s.wv[3 * tri], s.wv[3 * tri + 1], s.wv[3 * tri + 2], t, u, v))
 		return;
 	if (!(t > tmin))
 		return;
@@ -1099,6 +1132,10 @@ bool trace_any(Scene& s, V3 o, V3 d, float tmin, float distance, bool brute)
 	const RayPre r	 = ray_prepare(o, d, s.eps_t);
 	auto test = [&](uint32_t tri) {
 		float t, u, v;
+		if (prim_is_sphere(s, tri)) {
+			const uint32_t e = s.tri_entity[tri];
+			return sphere_hit(r, s.sphere_c[e], s.sphere_r[e], tmin, tmax, t);
+		}
 		if (!woop(r, s.wv[3 * tri], s.wv[3 * tri + 1], s.wv[3 * tri + 2], t, u, v))
 			return false;
 		return t > tmin && t <= tmax;
@@ -1142,14 +1179,25 @@ inline V3 load3(const std::vector<float>& a, uint32_t i) { return v3(a[3 * i], a
 inline uint32_t prim_id(const Scene& s, uint32_t tri)
 {
 	const prgpu_entity& E = s.entities[s.tri_entity[tri]];
-	return E.kind == PRGPU_ENTITY_PLANE ? 0u : tri - E.first_tri;
+	return E.kind != PRGPU_ENTITY_MESH ? 0u : tri - E.first_tri;
 }
-void geometry_point(const Scene& s, uint32_t tri, float u, float v, GeomPoint& g)
+void geometry_point(const Scene& s, uint32_t tri, float u, float v, V3 P, GeomPoint& g)
 {
 	const uint32_t e	 = s.tri_entity[tri];
 	const prgpu_entity& E = s.entities[e];
 	const uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
 	V3 N, Nx, Ny;
+	if (E.kind == PRGPU_ENTITY_SPHERE) { // SphereEntity::provideGeometryPoint (sphere.cpp:118-129): normal from the queried position
+		g.N = normalized(P - s.sphere_c[e]);
+		frame_duff(g.N, g.Nx, g.Ny); // Tangent::frame = unnormalized_frame + normalize
+		g.Nx	   = normalized(g.Nx);
+		g.Ny	   = normalized(g.Ny);
+		g.entity   = e;
+		g.prim	   = 0;
+		g.material = s.tri_material[tri];
+		g.emission = E.emission;
+		return;
+	}
 	if (E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
 		const uint32_t t0 = E.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0
 		const V3 v0 = load3(s.positions, s.indices[3 * t0]), v1 = load3(s.positions, s.indices[3 * t0 + 1]), v3p = load3(s.positions, s.indices[3 * t0 + 2]);
@@ -1690,7 +1738,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		// IntersectionPoint::setForSurface (trace/IntersectionPoint.h:61-75)
 		const V3 P = ray.o + ray.d * hit.t; // Ray::t
 		GeomPoint gp;
-		geometry_point(s, hit.tri, hit.u, hit.v, gp);
+		geometry_point(s, hit.tri, hit.u, hit.v, P, gp);
 		const V3 N		  = gp.N;
 		const float NdotV = dot(ray.d, N);
 		const V3 dP		  = ray.o - P;
@@ -1839,7 +1887,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				}
 				const V3 lp = affine_mul(LE.transform, tri_interp(p0, p1, p2, bu, bv));
 				GeomPoint lgp;
-				geometry_point(s, tri, bu, bv, lgp);
+				geometry_point(s, tri, bu, bv, lp, lgp);
 				// Light::sample area branch (light/Light.cpp:159-225)
 				const V3 L			 = normalized(lp - P);
 				const float cosLight = std::min(1.0f, std::max(-1.0f, -dot(L, lgp.N)));
@@ -2132,8 +2180,10 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("emission index out of range");
 		if (E.has_normals && !s.has_normals_array)
 			return fail("entity wants normals but none given");
-		if (E.kind > PRGPU_ENTITY_PLANE || (E.kind == PRGPU_ENTITY_PLANE && (E.n_tris != 2 || E.emission != INVALID)))
+		if (E.kind > PRGPU_ENTITY_SPHERE || (E.kind == PRGPU_ENTITY_PLANE && (E.n_tris != 2 || E.emission != INVALID)))
 			return fail("bad plane entity");
+		if (E.kind == PRGPU_ENTITY_SPHERE && (E.n_tris != 1 || E.emission != INVALID || !(E.radius > 0)))
+			return fail("bad sphere entity");
 		for (uint32_t t = 0; t < E.n_tris; ++t)
 			s.tri_entity[E.first_tri + t] = e;
 	}
@@ -2184,6 +2234,22 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			area += 0.5f * std::sqrt(dot(ee, ee)); // MeshBase::surfaceArea (identity transform)
 		}
 		s.world_area[e] = s.vol_scale[e] * area;
+	}
+	s.sphere_c.assign(d->n_entities, v3(0, 0, 0));
+	s.sphere_r.assign(d->n_entities, 0.0f);
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& E = s.entities[e];
+		if (E.kind != PRGPU_ENTITY_SPHERE)
+			continue;
+		const float* m = E.transform;
+		auto col_norm  = [&](int j) { return std::sqrt((m[j] * m[j] + m[4 + j] * m[4 + j]) + m[8 + j] * m[8 + j]); };
+		s.sphere_c[e]  = v3(m[3], m[7], m[11]); // transform() * (0,0,0)
+		s.sphere_r[e]  = E.radius * (((col_norm(0) + col_norm(1)) + col_norm(2)) / 3.0f);
+		// the placeholder triangle carries the primitive's (slightly inflated) bounding box for the BVH builders
+		const float rr = s.sphere_r[e] * 1.000002f + 1e-7f;
+		s.wv[3 * E.first_tri]	  = s.sphere_c[e] - v3(rr, rr, rr);
+		s.wv[3 * E.first_tri + 1] = s.sphere_c[e] + v3(rr, rr, rr);
+		s.wv[3 * E.first_tri + 2] = s.sphere_c[e];
 	}
 	{ // origin-centred bounding sphere of the world-space bounding box (Scene.cpp:107-118, Sphere::combine)
 		V3 lo = v3(PR_INF_F, PR_INF_F, PR_INF_F), hi = v3(-PR_INF_F, -PR_INF_F, -PR_INF_F);

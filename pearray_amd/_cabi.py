@@ -14,7 +14,7 @@ INVALID_ID = 0xFFFFFFFF
 
 SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER = range(6)
 MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR = 0, 1, 2
-ENTITY_MESH, ENTITY_PLANE = 0, 1
+ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE = 0, 1, 2
 LIGHT_ENVIRONMENT, LIGHT_DISTANT = 0, 1
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_HAMMERSLEY, SAMPLER_UNIFORM, SAMPLER_STRATIFIED = range(7)
@@ -44,7 +44,7 @@ class Emission(C.Structure):
 
 class Entity(C.Structure):
     _fields_ = [("first_tri", C.c_uint32), ("n_tris", C.c_uint32), ("emission", C.c_uint32),
-                ("has_normals", C.c_uint32), ("kind", C.c_uint32), ("reserved", C.c_uint32 * 3), ("transform", C.c_float * 16)]
+                ("has_normals", C.c_uint32), ("kind", C.c_uint32), ("radius", C.c_float), ("reserved", C.c_uint32 * 2), ("transform", C.c_float * 16)]
 
 
 class Light(C.Structure):

@@ -39,8 +39,15 @@ __global__ void k_world_tris(uint32_t n, const float* __restrict__ positions, co
 	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (int k = 0; k < 3; ++k) {
 		const uint32_t i = indices[3 * t + k];
-		const V3 p		 = affine_mul(E.m, v3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]));
-		wv[3 * t + k]	 = make_float4(p.x, p.y, p.z, 0.0f);
+		V3 p			 = affine_mul(E.m, v3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]));
+		float w			 = 0.0f;
+		if (E.kind == PRGPU_ENTITY_SPHERE) { // placeholder triangle of an analytic sphere: (c - r', c + r', c) spans its inflated box;
+			const V3 c	   = v3(E.m[3], E.m[7], E.m[11]); // w of the first vertex flags the primitive, w of the third carries the radius
+			const float rr = E.sphere_r * 1.000002f + 1e-7f;
+			p			   = k == 0 ? c - v3(rr, rr, rr) : (k == 1 ? c + v3(rr, rr, rr) : c);
+			w			   = k == 0 ? 1.0f : (k == 2 ? E.sphere_r : 0.0f);
+		}
+		wv[3 * t + k] = make_float4(p.x, p.y, p.z, w);
 		lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
 		hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
 	}
@@ -311,6 +318,15 @@ __global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const u
 		f[k] = 0.0f;
 	for (uint32_t k = 0; k < cnt; ++k) {
 		const uint32_t t = sorted_tri[pos + k];
+		if (wv[3 * t].w != 0.0f) { // analytic sphere: centre, radius
+			const float4 c = wv[3 * t + 2];
+			f[10 * k]	   = c.x;
+			f[10 * k + 1]  = c.y;
+			f[10 * k + 2]  = c.z;
+			f[10 * k + 3]  = c.w;
+			f[10 * k + 9]  = __uint_as_float(t | PRIM_SPHERE_BIT);
+			continue;
+		}
 		for (int v = 0; v < 3; ++v) {
 			const float4 p		 = wv[3 * t + v];
 			f[10 * k + 3 * v]	 = p.x;
@@ -341,6 +357,15 @@ __global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const ui
 		for (int k = 0; k < 3; ++k) {
 			lo[k] = fminf(lo[k], a[k]);
 			hi[k] = fmaxf(hi[k], b[k]);
+		}
+		if (wv[3 * t].w != 0.0f) { // analytic sphere: centre, radius
+			const float4 c	 = wv[3 * t + 2];
+			leaf[10 * i]	 = c.x;
+			leaf[10 * i + 1] = c.y;
+			leaf[10 * i + 2] = c.z;
+			leaf[10 * i + 3] = c.w;
+			leaf[10 * i + 9] = __uint_as_float(t | PRIM_SPHERE_BIT);
+			continue;
 		}
 		for (int v = 0; v < 3; ++v) {
 			const float4 p		  = wv[3 * t + v];

@@ -49,9 +49,12 @@ struct DevEntity {
 	uint32_t first_tri, n_tris, emission, has_normals;
 	float vol_scale, world_area;
 	uint32_t light_id, kind; // kind: PRGPU_ENTITY_*
+	float sphere_r;			 // SPHERE: world radius (sphere.cpp:77-92); the centre is the translation (m[3], m[7], m[11])
+	uint32_t pad;
 };
 
-constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u;
+constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u;
+constexpr uint32_t PRIM_SPHERE_BIT = 0x40000000u; // leaf records: the primitive in this slot is an analytic sphere (centre, radius), not a triangle
 
 // Infinite light (include/prgpu.h prgpu_light) with the matrices the kernels need
 struct DevInfLight {
@@ -391,7 +394,7 @@ __device__ __forceinline__ V3 affine_mul(const float* m, V3 v) // m = 3 rows of 
 
 // ---- watertight ray/triangle test (Woop, Benthin, Wald 2013) --------------------------------------
 struct RayPre {
-	V3 o;
+	V3 o, d;
 	int kx, ky, kz;
 	float Sx, Sy, Sz;
 	V3 inv_d;
@@ -402,6 +405,7 @@ __device__ __forceinline__ RayPre ray_prepare(V3 o, V3 d, float eps_t)
 	RayPre r;
 	r.eps_t		   = eps_t;
 	r.o			   = o;
+	r.d			   = d;
 	const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
 	int kz = 0;
 	if (ay > ax)
@@ -453,6 +457,29 @@ __device__ __forceinline__ bool woop(const RayPre& r, V3 p0, V3 p1, V3 p2, float
 	u				= V * rcp;
 	v				= W * rcp;
 	return true;
+}
+// Ray / sphere in the formulation of Embree 3's sphere intersector (see the checker): nearest root in (tmin, limit]
+__device__ __forceinline__ bool sphere_hit(const RayPre& r, V3 c, float radius, float tmin, float limit, float& t)
+{
+	const float rd2	   = 1.0f / dot(r.d, r.d);
+	const V3 c0		   = c - r.o;
+	const float projC0 = dot(c0, r.d) * rd2;
+	const V3 perp	   = c0 - r.d * projC0;
+	const float l2	   = dot(perp, perp);
+	const float r2	   = radius * radius;
+	if (!(l2 <= r2))
+		return false;
+	const float td		= sqrtf((r2 - l2) * rd2);
+	const float t_front = projC0 - td, t_back = projC0 + td;
+	if (t_front > tmin && t_front <= limit) {
+		t = t_front;
+		return true;
+	}
+	if (t_back > tmin && t_back <= limit) {
+		t = t_back;
+		return true;
+	}
+	return false;
 }
 // slab test against a padded box; entry <= limit keeps equal-t ties reachable
 __device__ __forceinline__ bool box_hit(const RayPre& r, const float* lo, const float* hi, float tmin, float limit, float& tentry)

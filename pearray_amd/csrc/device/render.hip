@@ -183,7 +183,8 @@ __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& s
 }
 
 // Leaf step: fetch the leaf record (<= 3 triangles) and run the watertight test on each.
-template <int M, typename STK>
+// SPH: the leaf may hold analytic spheres (scenes with sphere entities); compiled out of the lean persistent kernel
+template <int M, bool SPH, typename STK>
 __device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
 											  const float4& q5, const float4& q6, const float4& q7)
 {
@@ -195,10 +196,18 @@ __device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0
 	for (int k = 0; k < 3; ++k) {
 		if ((uint32_t)k < count) {
 			float t, u, v;
-			if (woop(s.r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]),
-					 v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), t, u, v)
-				&& t > s.tmin) {
-				const uint32_t tri = __float_as_uint(f[10 * k + 9]);
+			const uint32_t prim = __float_as_uint(f[10 * k + 9]);
+			bool hit;
+			if (SPH && (prim & PRIM_SPHERE_BIT)) { // analytic sphere: centre in floats 0..2, radius in float 3 of the slot
+				u = v = 0.0f;
+				hit	  = sphere_hit(s.r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), f[10 * k + 3], s.tmin, s.best.t, t);
+			} else {
+				hit = woop(s.r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]),
+						   v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), t, u, v)
+					  && t > s.tmin;
+			}
+			if (hit) {
+				const uint32_t tri = prim & ~PRIM_SPHERE_BIT;
 				if (ANY) {
 					if (t <= s.best.t)
 						s.best.tri = tri;
@@ -220,7 +229,7 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& s, Stack& st
 {
 	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
 	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
-	trav_leaf_rec<M>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
+	trav_leaf_rec<M, true>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
 }
 
 // Persistent traversal loop shared by the four tracing kernels.  `load(i, o, d, tmin, tmax)` reads ray i,
@@ -359,16 +368,27 @@ __device__ __forceinline__ V3 tri_interp(V3 a0, V3 a1, V3 a2, float u, float v) 
 __device__ __forceinline__ uint32_t prim_id(const DevScene& sc, uint32_t tri)
 {
 	const DevEntity& E = sc.entities[sc.tri_entity[tri]];
-	return E.kind == PRGPU_ENTITY_PLANE ? 0u : tri - E.first_tri;
+	return E.kind != PRGPU_ENTITY_MESH ? 0u : tri - E.first_tri;
 }
 // MeshEntity::provideGeometryPoint (entities/mesh.cpp:205-250)
 template <bool FULL>
-__device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri, float u, float v, GeomPoint& g)
+__device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri, float u, float v, V3 P, GeomPoint& g)
 {
 	const uint32_t e   = sc.tri_entity[tri];
 	const DevEntity& E = sc.entities[e];
 	const uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
 	V3 N, Nx, Ny;
+	if (FULL && E.kind == PRGPU_ENTITY_SPHERE) { // SphereEntity::provideGeometryPoint (sphere.cpp:118-129)
+		g.N = normalized(P - v3(E.m[3], E.m[7], E.m[11]));
+		frame_duff(g.N, g.Nx, g.Ny);
+		g.Nx	   = normalized(g.Nx);
+		g.Ny	   = normalized(g.Ny);
+		g.entity   = e;
+		g.prim	   = 0;
+		g.material = sc.tri_material[tri];
+		g.emission = E.emission;
+		return;
+	}
 	if (FULL && E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
 		const uint32_t t0 = E.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0
 		const V3 v0 = load3(sc.positions, sc.indices[3 * t0]), v1 = load3(sc.positions, sc.indices[3 * t0 + 1]), v3p = load3(sc.positions, sc.indices[3 * t0 + 2]);
@@ -798,7 +818,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	} else {
 		const V3 P = ray_o + ray_d * hit4.x;
 		GeomPoint gp;
-		geometry_point<FULL>(sc, tri, hit4.y, hit4.z, gp);
+		geometry_point<FULL>(sc, tri, hit4.y, hit4.z, P, gp);
 		const V3 N		   = gp.N;
 		const float NdotV  = dot(ray_d, N);
 		const V3 dP		   = ray_o - P;
@@ -950,7 +970,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					}
 					const V3 lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
 					GeomPoint lgp;
-					geometry_point<FULL>(sc, ltri, bu, bv, lgp);
+					geometry_point<FULL>(sc, ltri, bu, bv, lp, lgp);
 					const V3 L			 = normalized(lp - P);
 					const float cosLight = fminf(1.0f, fmaxf(-1.0f, -dot(L, lgp.N)));
 					const Blob radiance	 = spectrum_eval(sc, sc.emissions[LE.emission].radiance, wl);
@@ -1517,7 +1537,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						cl_c += s.any ? 0 : 1;
 						cl_a += s.any ? 1 : 0;
 					}
-					trav_leaf_rec<MODE_MIXED>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
+					trav_leaf_rec<MODE_MIXED, FULL>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
 				}
 			}
 			const bool fin = has_ray && s.cur == REC_EMPTY;

@@ -692,8 +692,38 @@ struct Loader {
 			add_plane(g, name);
 			return;
 		}
+		if (type == "sphere") { // sphere.cpp:157-168
+			for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
+				if (!get_bool(g, flag, true))
+					fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
+			if (g.get("emission"))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": emissive sphere entities are not supported yet");
+			prgpu_entity e;
+			std::memset(&e, 0, sizeof(e));
+			e.first_tri = (uint32_t)(out.indices.size() / 3);
+			e.n_tris	= 1;
+			e.emission	= PRGPU_INVALID_ID;
+			e.kind		= PRGPU_ENTITY_SPHERE;
+			e.radius	= (float)get_number(g, "radius", 1.0);
+			if (!(e.radius > 0))
+				fail(PRGPU_EINVAL, where(g) + ": sphere :radius must be positive");
+			transform_of(g, e.transform);
+			const Value* mv = g.get("material");
+			uint32_t mat	= PRGPU_INVALID_ID;
+			if (mv && mv->type == Value::STRING) {
+				const auto it = material_ids.find(mv->s);
+				mat			  = it == material_ids.end() ? PRGPU_INVALID_ID : it->second;
+			}
+			const uint32_t base = (uint32_t)(out.positions.size() / 3);
+			out.positions.insert(out.positions.end(), 9, 0.0f); // placeholder triangle
+			for (uint32_t i = 0; i < 3; ++i)
+				out.indices.push_back(base + i);
+			out.tri_material.push_back(mat);
+			out.entities.push_back(e);
+			return;
+		}
 		if (type != "mesh")
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": entity type '" + type + "' is not supported (mesh and plane are; tessellate other primitives)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": entity type '" + type + "' is not supported (mesh, plane and sphere are; tessellate other primitives)");
 		for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
 			if (!get_bool(g, flag, true))
 				fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");

@@ -216,6 +216,12 @@ void entity_tables(const prgpu_scene_desc* d, HostTables& t)
 		E.has_normals = (src.has_normals && d->normals) ? 1u : 0u;
 		E.light_id	  = PRGPU_INVALID_ID;
 		E.kind		  = src.kind;
+		E.pad		  = 0;
+		E.sphere_r	  = 0.0f;
+		if (src.kind == PRGPU_ENTITY_SPHERE) { // sphere.cpp:77-92: radius * mean column norm of the linear part
+			auto col_norm = [&](int j) { return std::sqrt((m[j] * m[j] + m[4 + j] * m[4 + j]) + m[8 + j] * m[8 + j]); };
+			E.sphere_r	  = src.radius * (((col_norm(0) + col_norm(1)) + col_norm(2)) / 3.0f);
+		}
 		float area	  = 0;
 		for (uint32_t tri = src.first_tri; tri < src.first_tri + src.n_tris; ++tri) {
 			t.tri_entity[tri] = e;
@@ -356,18 +362,35 @@ void light_tables(const prgpu_scene_desc* d, HostTables& t)
 		t.light_entity.assign(1, 0);
 }
 
+// world-space vertex k of a triangle as the BVH builders see it: transformed mesh vertex, or for the placeholder triangle of an
+// analytic sphere the corners / centre of its (inflated) bounding box -- same values as k_world_tris and the checker
+void world_vertex(const prgpu_scene_desc* d, const HostTables& t, uint32_t tri, int k, float w[3])
+{
+	const prd::DevEntity& E = t.entities[t.tri_entity[tri]];
+	const float* m			= E.m;
+	if (E.kind == PRGPU_ENTITY_SPHERE) {
+		const float rr = E.sphere_r * 1.000002f + 1e-7f;
+		const float c[3] = { m[3], m[7], m[11] };
+		for (int r = 0; r < 3; ++r)
+			w[r] = k == 0 ? c[r] - rr : (k == 1 ? c[r] + rr : c[r]);
+		return;
+	}
+	const float* p = d->positions + 3 * d->indices[3 * tri + k];
+	for (int r = 0; r < 3; ++r)
+		w[r] = ((m[4 * r] * p[0] + m[4 * r + 1] * p[1]) + m[4 * r + 2] * p[2]) + m[4 * r + 3];
+}
+
 // world-space bounding box -> origin-centred bounding sphere radius (Scene.cpp:107-118, Sphere::combine); infinite light matrices
 void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 {
 	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (uint32_t tri = 0; tri < d->n_triangles; ++tri) {
-		const float* m = t.entities[t.tri_entity[tri]].m;
 		for (int k = 0; k < 3; ++k) {
-			const float* p = d->positions + 3 * d->indices[3 * tri + k];
+			float w[3];
+			world_vertex(d, t, tri, k, w);
 			for (int r = 0; r < 3; ++r) {
-				const float w = ((m[4 * r] * p[0] + m[4 * r + 1] * p[1]) + m[4 * r + 2] * p[2]) + m[4 * r + 3];
-				lo[r]		  = std::min(lo[r], w);
-				hi[r]		  = std::max(hi[r], w);
+				lo[r] = std::min(lo[r], w[r]);
+				hi[r] = std::max(hi[r], w[r]);
 			}
 		}
 	}
@@ -599,8 +622,12 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 			return bad("material index out of range");
 	for (uint32_t e = 0; e < d->n_entities; ++e) {
 		const prgpu_entity& E = d->entities[e];
-		if (E.kind > PRGPU_ENTITY_PLANE)
+		if (E.kind > PRGPU_ENTITY_SPHERE)
 			return bad("unknown entity kind");
+		if (E.kind == PRGPU_ENTITY_SPHERE && (E.n_tris != 1 || !(E.radius > 0)))
+			return bad("a sphere entity is one placeholder triangle and a positive radius");
+		if (E.kind == PRGPU_ENTITY_SPHERE && E.emission != PRGPU_INVALID_ID)
+			return bad("emissive sphere entities are not supported yet", PRGPU_EUNSUPPORTED);
 		if (E.kind == PRGPU_ENTITY_PLANE && E.n_tris != 2)
 			return bad("a plane entity is exactly two triangles (v0,v1,v3), (v2,v3,v1)");
 		if (E.kind == PRGPU_ENTITY_PLANE && E.emission != PRGPU_INVALID_ID)
@@ -674,13 +701,11 @@ int build_tables(const prgpu_scene_desc* d, HostTables& t, std::string& err)
 	{ // largest |coordinate| of the world-space scene and the camera origin -> slack of the slab test
 		float scale = std::max(std::fabs(t.cam.o[0]), std::max(std::fabs(t.cam.o[1]), std::fabs(t.cam.o[2])));
 		for (uint32_t tri = 0; tri < d->n_triangles; ++tri) {
-			const float* m = t.entities[t.tri_entity[tri]].m;
 			for (int k = 0; k < 3; ++k) {
-				const float* p = d->positions + 3 * d->indices[3 * tri + k];
-				for (int r = 0; r < 3; ++r) {
-					const float w = ((m[4 * r] * p[0] + m[4 * r + 1] * p[1]) + m[4 * r + 2] * p[2]) + m[4 * r + 3];
-					scale		  = std::max(scale, std::fabs(w));
-				}
+				float w[3];
+				world_vertex(d, t, tri, k, w);
+				for (int r = 0; r < 3; ++r)
+					scale = std::max(scale, std::fabs(w[r]));
 			}
 		}
 		t.eps_t = 8e-6f * scale;

@@ -253,6 +253,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	for (uint32_t e = 0; e < d->n_entities; ++e)
 		if (d->entities[e].kind == PRGPU_ENTITY_PLANE)
 			sc.features |= prd::FEAT_PLANES;
+		else if (d->entities[e].kind == PRGPU_ENTITY_SPHERE)
+			sc.features |= prd::FEAT_SPHERES;
 	sc.scene_radius	 = t.scene_radius;
 	sc.wl_cdf_size	 = (uint32_t)t.wl_cdf.size();
 	sc.rr_size		 = (uint32_t)t.rr_prob.size();

@@ -195,6 +195,13 @@ class SceneBuilder:
         self.entities[e].kind = abi.ENTITY_PLANE
         return e
 
+    def add_sphere(self, material, radius=1.0, transform=IDENTITY):
+        """(entity :type 'sphere' :radius r), sphere.cpp:157-168: one placeholder triangle stands for the analytic primitive"""
+        e = self.add_mesh([[0, 0, 0], [0, 0, 0], [0, 0, 0]], [[0, 1, 2]], material, transform=transform)
+        self.entities[e].kind = abi.ENTITY_SPHERE
+        self.entities[e].radius = float(radius)
+        return e
+
     def set_camera(self, transform, width=1.0, height=1.0, near=1e-6, far=float("inf"), local_direction=(0, 0, 1),
                    local_right=(1, 0, 0), local_up=(0, 1, 0), fstop=0.0, aperture_radius=0.05):
         c = self.camera

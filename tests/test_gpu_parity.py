@@ -480,3 +480,46 @@ def test_infinite_lights_through_the_prc_loader():
     )"""
     g, o = render_both(scene.PrcScene(source=src))
     assert_parity(g, o, exact=True)
+
+
+def test_sphere_entities_bit_exact():
+    """Analytic spheres (sphere.cpp) as BVH primitives next to triangles: hit ids, shading frames and images equal the checker;
+    glass and mirror spheres exercise refraction through the analytic normals."""
+    b = scene.SceneBuilder(96, 72)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, 8
+    T = np.array([[1, 0, 0, 0], [0, 0.8, 0.6, 2.0], [0, -0.6, 0.8, 3.2], [0, 0, 0, 1]], dtype=np.float32)
+    b.set_camera(T, width=0.9, height=0.675, near=0.01, far=100.0, local_direction=(0, 0, -1), local_up=(0, 1, 0), local_right=(1, 0, 0))
+    white = b.lambert(b.refl(0.7, 0.7, 0.7))
+    glass = b.dielectric(b.lookup_index("bk7"))
+    metal = b.conductor()
+    b.add_plane(white, x_axis=(1, 0, 0), y_axis=(0, 0, -1), width=8, height=8, centering=True)
+    for k, (m, r, pos, sx) in enumerate([(white, 0.5, (-1.2, 0.5, 0.0), 1.0), (glass, 0.25, (0.0, 0.6, 0.4), 2.4), (metal, 0.6, (1.3, 0.6, -0.2), 1.0)]):
+        M = np.diag([sx, sx, sx, 1]).astype(np.float32); M[:3, 3] = pos
+        b.add_sphere(m, radius=r, transform=M)
+    b.add_mesh([[-0.5, 3, -0.5], [0.5, 3, -0.5], [0.5, 3, 0.5], [-0.5, 3, 0.5]], [[0, 3, 2, 1]], white, emission=b.diffuse_emission(b.illum(12, 12, 11)))
+    b.environment_light(b.smul(b.illuminant_d65(), b.illum(0.3, 0.35, 0.45)))
+    sc = b.build()
+    g, o = render_both(sc)
+    assert_parity(g, o, exact=True)
+    ent, prim = g.primaryHits()
+    for e in (1, 2, 3):
+        assert (ent == e).sum() > 50 and set(np.unique(prim[ent == e])) == {0}
+    rng = np.random.default_rng(11)
+    org = (rng.random((4096, 3)) * [4, 2, 4] + [-2, 0.2, -2]).astype(np.float32)
+    d = rng.normal(size=(4096, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    for x, y in zip(g.traceRays(org, d, 1e-4, np.inf), o.trace_closest(org, d, 1e-4, np.inf)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(g.traceShadowRays(org, d, 1e-4, 3.0), o.trace_any(org, d, 1e-4, 3.0))
+
+
+def test_sphere_scene_through_the_prc_loader_and_alone():
+    src = """(scene :render_width 40 :render_height 40
+      (sampler :slot 'aa' :type 'mjitt' :sample_count 4)
+      (camera :name 'c' :type 'standard' :local_direction [0,0,-1] :local_up [0,1,0] :local_right [1,0,0] :position [0,0,4])
+      (light :type 'env' :radiance (illuminant 'D65'))
+      (material :name 'm' :type 'diffuse' :albedo (refl 0.8 0.4 0.3))
+      (entity :name 'ball' :type 'sphere' :radius 1.2 :material 'm' :position [0.1, -0.2, 0] :scale [1, 1.5, 0.5])
+    )"""
+    g, o = render_both(scene.PrcScene(source=src))        # a single primitive: the tiny-scene BVH path
+    assert_parity(g, o, exact=True)
+    assert (g.primaryHits()[0] == 0).sum() > 100

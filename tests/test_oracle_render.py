@@ -206,3 +206,37 @@ def test_lanczos_filter_weights_and_stratified_sampler():
     assert 1.0 < xyz.sum() / ref.output()[0].sum() < 3.0
     u = ob.OracleScene(scene.cornell_box(24, 24, spp=4, sampler=abi.SAMPLER_UNIFORM)); u.render(4, threads=2)
     assert np.isfinite(u.output()[0]).all()
+
+
+def test_analytic_sphere_hits_match_the_closed_form():
+    """sphere.cpp: centre = M * 0, radius = r * mean column norm; hits from the Embree-style projection formula."""
+    b = scene.SceneBuilder(8, 8)
+    b.set_camera(scene.IDENTITY)
+    m = b.lambert(b.spectrum_const(0.5))
+    T = np.array([[2, 0, 0, 1.0], [0, 2, 0, -0.5], [0, 0, 2, 3.0], [0, 0, 0, 1]], dtype=np.float32)
+    b.add_sphere(m, radius=0.75, transform=T)                         # world radius 1.5 at (1, -0.5, 3)
+    b.add_mesh([[-9, -9, 9], [9, -9, 9], [9, 9, 9], [-9, 9, 9]], [[0, 1, 2, 3]], m)
+    sc = b.build()
+    o = ob.OracleScene(sc)
+    rng = np.random.default_rng(5)
+    n = 4000
+    org = (rng.random((n, 3)) * 8 - 4).astype(np.float32)
+    org = org[np.linalg.norm(org - [1, -0.5, 3], axis=1) > 1.6]      # outside the sphere
+    d = rng.normal(size=(len(org), 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ent, prim, u, v, t = o.trace_closest(org, d, 1e-4, np.inf)
+    eb, pb, ub, vb, tb = o.trace_closest(org, d, 1e-4, np.inf, brute=True)
+    assert np.array_equal(ent, eb) and np.array_equal(t, tb)          # BVH == brute force
+    c = np.array([1, -0.5, 3], dtype=np.float64)
+    oc = org.astype(np.float64) - c
+    bq = (oc * d).sum(1); cq = (oc * oc).sum(1) - 1.5 ** 2
+    disc = bq * bq - cq
+    t_ref = np.where(disc >= 0, -bq - np.sqrt(np.maximum(disc, 0)), np.inf)
+    hits = (ent == 0)
+    assert hits.sum() > 100 and (prim[hits] == 0).all() and (u[hits] == 0).all()
+    assert np.allclose(t[hits], t_ref[hits], rtol=2e-5, atol=2e-5)
+    front = (disc > 1e-4) & (t_ref > 1e-3)
+    assert (ent[front & (t_ref < tb + 1e-3)] == 0).all()
+    # from inside: the back root
+    inside = np.tile(np.array([[1, -0.5, 3]], dtype=np.float32), (64, 1))
+    e2, p2, _, _, t2 = o.trace_closest(inside, d[:64], 1e-4, np.inf)
+    assert (e2 == 0).all() and np.allclose(t2, 1.5, atol=1e-5)

@@ -100,7 +100,8 @@ def test_defaults_follow_the_reference():
 
 
 @pytest.mark.parametrize("block,code,needle", [
-    ("(entity :name 's' :type 'sphere' :radius 1)", -4, "entity type 'sphere'"),
+    ("(entity :name 's' :type 'cone' :radius 1)", -4, "entity type 'cone'"),
+    ("(emission :name 'l' :type 'standard') (entity :name 's' :type 'sphere' :emission 'l')", -4, "emissive sphere"),
     ("(material :name 'g' :type 'glass' :roughness 0.1)", -4, "rough dielectrics"),
     ("(material :name 'g' :type 'principled')", -4, "material type 'principled'"),
     ("(material :name 'g' :type 'metal' :roughness_x 0.1)", -4, "rough conductors"),
