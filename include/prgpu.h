@@ -149,13 +149,15 @@ typedef struct prgpu_light {
 	float    transform[16];
 } prgpu_light;
 
-/* PerspectiveCamera, src/plugins/main/cameras/perspective.cpp:16-113 */
+/* PerspectiveCamera, src/plugins/main/cameras/perspective.cpp:16-113; OrthoCamera, ortho.cpp:14-75 */
+enum { PRGPU_CAMERA_PERSPECTIVE = 0, PRGPU_CAMERA_ORTHO = 1 };
 typedef struct prgpu_camera {
 	float transform[16];      /* row-major 4x4 */
 	float width, height;      /* sensor size */
 	float near_t, far_t;      /* ray interval; far_t may be +inf */
 	float local_direction[3], local_right[3], local_up[3];
-	float fstop, aperture_radius; /* DOF active iff both > FLT_EPSILON (perspective.cpp:158) */
+	float fstop, aperture_radius; /* PERSPECTIVE: DOF active iff both > FLT_EPSILON (perspective.cpp:158) */
+	uint32_t kind;            /* PRGPU_CAMERA_*: perspective.cpp, or ortho.cpp (parallel rays from the sensor rectangle, ortho.cpp:29-33,61-66) */
 } prgpu_camera;
 
 /* RandomSampler.cpp, MultiJitteredSampler.cpp, SobolSampler.cpp, HaltonSampler.cpp (halton + hammersley) of src/plugins/main/sampler */

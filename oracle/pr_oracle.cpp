@@ -685,7 +685,7 @@ struct Scene {
 	std::vector<uint32_t> tri_order;
 	// camera cache (perspective.cpp:84-113)
 	V3 cam_o, cam_right, cam_up, cam_focal, cam_xap, cam_yap;
-	bool cam_dof = false;
+	bool cam_dof = false, cam_ortho = false;
 	// samplers
 	uint32_t spp = 0;
 	uint32_t mj_x = 1, mj_y = 1, mj_seed = 0;
@@ -1475,8 +1475,14 @@ void setup_camera(Scene& s)
 	V3 right	   = linear_mul(c.transform, v3(c.local_right[0], c.local_right[1], c.local_right[2]));
 	V3 up		   = linear_mul(c.transform, v3(c.local_up[0], c.local_up[1], c.local_up[2]));
 	s.cam_o		   = v3(c.transform[3], c.transform[7], c.transform[11]);
-	s.cam_dof	   = c.aperture_radius > PR_EPS && c.fstop > PR_EPS; // perspective.cpp:158
-	if (!s.cam_dof) {
+	s.cam_dof	   = c.kind == PRGPU_CAMERA_PERSPECTIVE && c.aperture_radius > PR_EPS && c.fstop > PR_EPS; // perspective.cpp:158
+	s.cam_ortho	   = c.kind == PRGPU_CAMERA_ORTHO;
+	if (s.cam_ortho) { // ortho.cpp:29-31
+		s.cam_focal = normalized(dir);
+		s.cam_xap = s.cam_yap = v3(0, 0, 0);
+		s.cam_right = (right * 0.5f) * c.width;
+		s.cam_up	= (up * 0.5f) * c.height;
+	} else if (!s.cam_dof) {
 		s.cam_focal = dir;
 		s.cam_xap = s.cam_yap = v3(0, 0, 0);
 		s.cam_right = right * (0.5f * c.width);
@@ -1494,6 +1500,11 @@ inline void camera_ray(const Scene& s, float px, float py, float r1, float r2, V
 {
 	const float nx = 2 * (px / (float)s.cfg.width - 0.5f);
 	const float ny = -(2 * (py / (float)s.cfg.height - 0.5f));
+	if (s.cam_ortho) { // ortho.cpp:61-66
+		o = (s.cam_o + s.cam_right * nx) + s.cam_up * ny;
+		d = s.cam_focal;
+		return;
+	}
 	o			   = s.cam_o;
 	d			   = (s.cam_right * nx + s.cam_up * ny) + s.cam_focal;
 	if (s.cam_dof) {

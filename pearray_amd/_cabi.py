@@ -16,6 +16,7 @@ SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_
 MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR = 0, 1, 2
 ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE = 0, 1, 2
 LIGHT_ENVIRONMENT, LIGHT_DISTANT = 0, 1
+CAMERA_PERSPECTIVE, CAMERA_ORTHO = 0, 1
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_HAMMERSLEY, SAMPLER_UNIFORM, SAMPLER_STRATIFIED = range(7)
 MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO = range(3)
@@ -56,7 +57,7 @@ class Camera(C.Structure):
     _fields_ = [("transform", C.c_float * 16), ("width", C.c_float), ("height", C.c_float),
                 ("near_t", C.c_float), ("far_t", C.c_float), ("local_direction", C.c_float * 3),
                 ("local_right", C.c_float * 3), ("local_up", C.c_float * 3), ("fstop", C.c_float),
-                ("aperture_radius", C.c_float)]
+                ("aperture_radius", C.c_float), ("kind", C.c_uint32)]
 
 
 class Settings(C.Structure):

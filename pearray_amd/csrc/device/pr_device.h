@@ -66,7 +66,7 @@ struct DevInfLight {
 struct DevCamera {
 	float o[3], right[3], up[3], focal[3], xap[3], yap[3];
 	float near_t, far_t;
-	uint32_t dof;
+	uint32_t dof, ortho; // ortho: parallel rays, `focal` is the normalised view direction
 };
 
 // Everything the kernels read; passed by value.

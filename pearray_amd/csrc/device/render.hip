@@ -619,14 +619,19 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	const DevCamera& cam = sc.cam;
 	V3 o = v3(cam.o[0], cam.o[1], cam.o[2]);
 	V3 d = (v3(cam.right[0], cam.right[1], cam.right[2]) * nx + v3(cam.up[0], cam.up[1], cam.up[2]) * ny) + v3(cam.focal[0], cam.focal[1], cam.focal[2]);
-	if (cam.dof) {
-		float sn, cs;
-		pr_sincos_2pi(l1, sn, cs);
-		const V3 e = v3(cam.xap[0], cam.xap[1], cam.xap[2]) * (l2 * sn) + v3(cam.yap[0], cam.yap[1], cam.yap[2]) * (l2 * cs);
-		o		   = o + e;
-		d		   = d - e;
+	if (cam.ortho) { // OrthoCamera::constructRay (ortho.cpp:61-66)
+		o = (o + v3(cam.right[0], cam.right[1], cam.right[2]) * nx) + v3(cam.up[0], cam.up[1], cam.up[2]) * ny;
+		d = v3(cam.focal[0], cam.focal[1], cam.focal[2]);
+	} else {
+		if (cam.dof) {
+			float sn, cs;
+			pr_sincos_2pi(l1, sn, cs);
+			const V3 e = v3(cam.xap[0], cam.xap[1], cam.xap[2]) * (l2 * sn) + v3(cam.yap[0], cam.yap[1], cam.yap[2]) * (l2 * cs);
+			o		   = o + e;
+			d		   = d - e;
+		}
+		d = normalized(d);
 	}
-	d = normalized(d);
 	const bool mono	   = cfg.spectral_mono || !cfg.spectral_hero; // RenderTile.cpp:123-124
 	ps.rng[pixel]	   = rnd;
 	ps.ray_o[slot]	   = make_float4(o.x, o.y, o.z, cam.near_t);

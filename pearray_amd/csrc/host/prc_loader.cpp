@@ -492,10 +492,12 @@ struct Loader {
 	void add_camera(const Group& g) // perspective.cpp:141-165
 	{
 		const std::string type = lower(get_string(g, "type", "standard"));
-		if (type != "standard_camera" && type != "standard" && type != "default" && type != "perspective")
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": camera type '" + type + "' is not supported (perspective only)");
+		const bool ortho = type == "ortho" || type == "orthographic"; // ortho.cpp:78-92
+		if (!ortho && type != "standard_camera" && type != "standard" && type != "default" && type != "perspective")
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": camera type '" + type + "' is not supported (perspective and orthographic are)");
 		prgpu_camera c;
 		std::memset(&c, 0, sizeof(c));
+		c.kind = ortho ? PRGPU_CAMERA_ORTHO : PRGPU_CAMERA_PERSPECTIVE;
 		transform_of(g, c.transform);
 		c.width			  = (float)get_number(g, "width", 1);
 		c.height		  = (float)get_number(g, "height", 1);

@@ -493,9 +493,20 @@ void camera_cache(const prgpu_scene_desc* d, HostTables& t)
 	o.o[0] = c.transform[3];
 	o.o[1] = c.transform[7];
 	o.o[2] = c.transform[11];
-	o.dof	 = (c.aperture_radius > EPS_F && c.fstop > EPS_F) ? 1u : 0u;
+	o.ortho	 = c.kind == PRGPU_CAMERA_ORTHO ? 1u : 0u;
+	o.dof	 = (!o.ortho && c.aperture_radius > EPS_F && c.fstop > EPS_F) ? 1u : 0u;
 	o.near_t = c.near_t;
 	o.far_t	 = c.far_t;
+	if (o.ortho) { // ortho.cpp:29-31: normalised direction, half-extent axes
+		const float len = std::sqrt((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
+		for (int k = 0; k < 3; ++k) {
+			o.focal[k] = dir[k] / len;
+			o.xap[k] = o.yap[k] = 0.0f;
+			o.right[k] = (right[k] * 0.5f) * c.width;
+			o.up[k]	   = (up[k] * 0.5f) * c.height;
+		}
+		return;
+	}
 	for (int k = 0; k < 3; ++k) {
 		if (!o.dof) {
 			o.focal[k] = dir[k];
@@ -659,6 +670,8 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		if (m.kind == PRGPU_MAT_DIELECTRIC && (m.ior >= d->n_spectra || (m.transmission != PRGPU_INVALID_ID && m.transmission >= d->n_spectra)))
 			return bad("dielectric index / transmission spectrum out of range");
 	}
+	if (d->camera.kind > PRGPU_CAMERA_ORTHO)
+		return bad("unknown camera kind");
 	if (d->n_lights && !d->lights)
 		return bad("n_lights without a lights array");
 	for (uint32_t i = 0; i < d->n_lights; ++i) {

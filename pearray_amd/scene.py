@@ -203,7 +203,7 @@ class SceneBuilder:
         return e
 
     def set_camera(self, transform, width=1.0, height=1.0, near=1e-6, far=float("inf"), local_direction=(0, 0, 1),
-                   local_right=(1, 0, 0), local_up=(0, 1, 0), fstop=0.0, aperture_radius=0.05):
+                   local_right=(1, 0, 0), local_up=(0, 1, 0), fstop=0.0, aperture_radius=0.05, ortho=False):
         c = self.camera
         t = np.asarray(transform, dtype=np.float32).reshape(16)
         for i in range(16):
@@ -214,6 +214,7 @@ class SceneBuilder:
             c.local_right[i] = local_right[i]
             c.local_up[i] = local_up[i]
         c.fstop, c.aperture_radius = fstop, aperture_radius
+        c.kind = abi.CAMERA_ORTHO if ortho else abi.CAMERA_PERSPECTIVE
 
     def build(self):
         return SceneData(self)

@@ -523,3 +523,28 @@ def test_sphere_scene_through_the_prc_loader_and_alone():
     g, o = render_both(scene.PrcScene(source=src))        # a single primitive: the tiny-scene BVH path
     assert_parity(g, o, exact=True)
     assert (g.primaryHits()[0] == 0).sum() > 100
+
+
+def test_orthographic_camera_bit_exact():
+    """ortho.cpp: parallel rays from the sensor rectangle; hits must land where the closed form says and match the checker."""
+    b = scene.SceneBuilder(64, 48)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_MJITT, 6
+    T = np.array([[1, 0, 0, 0.3], [0, 0.8, 0.6, 2.0], [0, -0.6, 0.8, 3.0], [0, 0, 0, 1]], dtype=np.float32)
+    b.set_camera(T, width=4.0, height=3.0, near=0.01, far=100.0, local_direction=(0, 0, -2), local_up=(0, 1, 0), local_right=(1, 0, 0), ortho=True)
+    white = b.lambert(b.refl(0.7, 0.7, 0.7))
+    b.add_plane(white, x_axis=(1, 0, 0), y_axis=(0, 0, -1), width=8, height=8, centering=True)
+    b.add_sphere(b.lambert(b.refl(0.2, 0.6, 0.3)), radius=0.6, transform=np.array([[1, 0, 0, 0], [0, 1, 0, 0.6], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32))
+    b.environment_light(b.illuminant_d65())
+    g, o = render_both(b.build())
+    assert_parity(g, o, exact=True)
+    ent, _ = g.primaryHits()
+    # parallel projection: the sphere's silhouette is a circle of radius 0.6 / (4 / 64) = 9.6 pixels
+    area = (ent == 1).sum()
+    assert abs(area - np.pi * 9.6 ** 2) < 0.08 * np.pi * 9.6 ** 2
+    src = """(scene :render_width 32 :render_height 32
+      (camera :name 'c' :type 'orthographic' :width 3 :height 3 :local_direction [0,0,-1] :local_up [0,1,0] :local_right [1,0,0] :position [0,0.5,5])
+      (light :type 'env')
+      (material :name 'm' :type 'diffuse' :albedo 0.5)
+      (entity :name 'ball' :type 'sphere' :radius 1 :material 'm'))"""
+    g, o = render_both(scene.PrcScene(source=src, spp=4))
+    assert_parity(g, o, exact=True)
