@@ -238,8 +238,13 @@ struct Loader {
 	{
 		if (v.is_number())
 			return spectrum_const((float)v.number());
-		if (v.type == Value::STRING) // SceneLoadContext::lookupSpectralNode: a string names a (node ...)/(texture ...) block
-			fail(PRGPU_EUNSUPPORTED, std::string(":") + key + " of " + where(owner) + " refers to the named node '" + v.s + "': named nodes are not supported");
+		if (v.type == Value::STRING) {
+			// SceneLoadContext::lookupSpectralNode (SceneLoadContext.cpp:222-232): a string names a (node ...)/(texture ...) block; an
+			// unknown name silently yields the parameter's default.  Named blocks are rejected when they are declared (dispatch), so
+			// every name is unknown here.
+			warn(std::string(":") + key + " of " + where(owner) + " names the unknown node '" + v.s + "': default value used (as the reference does)");
+			return spectrum_const(string_default);
+		}
 		if (v.type != Value::GROUP || v.g->is_array)
 			fail(PRGPU_EINVAL, std::string(":") + key + " of " + where(owner) + " is not a spectral expression");
 		const Group& e		 = *v.g;
@@ -338,8 +343,10 @@ struct Loader {
 		}
 		fail(PRGPU_EUNSUPPORTED, "spectral expression " + where(e) + " is not supported (number, refl, illum, illuminant, spectrum, smul, lookup_index are)");
 	}
+	float string_default = 1.0f; // default of the parameter being parsed (for strings naming unknown nodes)
 	uint32_t spectral_param(const Group& g, std::initializer_list<const char*> keys, float def)
 	{
+		string_default = def;
 		for (const char* k : keys)
 			if (const Value* v = g.get(k))
 				return spectral_node(*v, g, k);
@@ -463,6 +470,7 @@ struct Loader {
 		transform_of(g, l.transform);
 		l.background   = PRGPU_INVALID_ID;
 		l.direction[2] = 1.0f;
+		string_default = 1.0f; // defaults of :radiance / :background / :irradiance
 		if (type == "env" || type == "environment" || type == "background") {
 			l.kind					 = PRGPU_LIGHT_ENVIRONMENT;
 			const Value *rad = g.get("radiance"), *bg = g.get("background");
