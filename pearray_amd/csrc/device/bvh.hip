@@ -51,6 +51,18 @@ __global__ void k_world_tris(uint32_t n, const float* __restrict__ positions, co
 		lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
 		hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
 	}
+	// entity bounds: when the whole wave works on one entity (the common case: a million-triangle mesh) reduce inside the wave
+	// first -- 64 lanes hammering the same six words cost 68 ms on the C4 scene
+	const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+	if (__all(e == e0) && __popcll(__ballot(true)) == 64) {
+		for (int a = 0; a < 3; ++a)
+			for (int off = 32; off > 0; off >>= 1) {
+				lo[a] = fminf(lo[a], __shfl_xor(lo[a], off, 64));
+				hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off, 64));
+			}
+		if ((threadIdx.x & 63u) != 0)
+			return;
+	}
 	for (int a = 0; a < 3; ++a) {
 		atomicMin(&ebounds[6 * e + a], float_to_ordered(lo[a]));
 		atomicMax(&ebounds[6 * e + 3 + a], float_to_ordered(hi[a]));
