@@ -308,6 +308,23 @@ int  prgpu_download_primary_hits(prgpu_scene* s, uint32_t* entity, uint32_t* pri
 int  prgpu_set_timing(prgpu_scene* s, int enabled);
 int  prgpu_kernel_time_ms(prgpu_scene* s, const char* family, double* total_ms, uint64_t* launches);
 
+/* -- shading-point AOVs and image files ------------------------------------------------------
+ * LocalFrameOutputDevice::commitShadingPoints (src/loader/output/LocalFrameOutputDevice.cpp:252-283): every camera sample whose
+ * primary ray hits a surface ADDS the hit's attributes to the pixel (plain sums, no filter; divide by the sample-count plane for
+ * a mean -- the ids are summed as floats exactly like the reference).  Enable before the first iteration; planes are W*H*channels
+ * floats, interleaved per pixel. */
+enum { PRGPU_AOV_POSITION = 0, PRGPU_AOV_NORMAL, PRGPU_AOV_NORMAL_G, PRGPU_AOV_TANGENT, PRGPU_AOV_BITANGENT, PRGPU_AOV_VIEW, /* 3 channels (AOV3D) */
+       PRGPU_AOV_ENTITY_ID, PRGPU_AOV_MATERIAL_ID, PRGPU_AOV_EMISSION_ID, PRGPU_AOV_DEPTH,                                       /* 1 channel (AOV1D)  */
+       PRGPU_AOV_COUNT };
+int      prgpu_enable_aovs(prgpu_scene* s, uint32_t mask);           /* bit k enables PRGPU_AOV_k */
+uint32_t prgpu_aov_channels(uint32_t aov);                           /* 3 or 1; 0 for an unknown id */
+int      prgpu_download_aov(prgpu_scene* s, uint32_t aov, float* out);
+/* Minimal OpenEXR 2 writer (scanline, uncompressed, 32-bit float channels; replaces the OIIO path of src/loader/output/io for
+ * plain frames).  `planes[c]` points to width*height floats of channel `names[c]`, read with a stride of `strides[c]` floats
+ * (1 = planar, 3 = one component of an interleaved XYZ frame).  Channels are stored in the alphabetical order EXR requires. */
+int prgpu_write_exr(const char* path, uint32_t width, uint32_t height, uint32_t n_channels, const char* const* names,
+                    const float* const* planes, const uint32_t* strides);
+
 /* -- .prc scene files ---------------------------------------------------------------------
  * Replaces SceneLoader::loadFromFile / loadFromString (src/loader/SceneLoader.cpp:44-72) for the part of the scene language the
  * `direct` hot path evaluates: (scene :render_width :render_height :camera :spectral_domain :spectral_hero), (sampler), (filter),

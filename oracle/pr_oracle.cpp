@@ -714,6 +714,7 @@ struct Scene {
 	std::vector<float> iter_xyz; // per-iteration copy buffer (mCopySpectral)
 	std::vector<float> last_xyz; // unfiltered per-path sums of the last iteration
 	std::vector<uint32_t> samples, feedback, prim_entity, prim_prim;
+	std::vector<float> aov[PRGPU_AOV_COUNT]; // shading-point AOV sums (enabled planes are non-empty)
 	std::atomic<uint64_t> stats[PRGPU_STAT_COUNT];
 	std::atomic<uint64_t> cnt_nodes{ 0 }, cnt_tris{ 0 };
 	// debugging aid: rays of one pixel (kind, iter, o[3], d[3], tmin, tmax|distance, result)
@@ -1759,8 +1760,31 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		const uint32_t pathLength = ray.depth + 1;
 		st[PRGPU_STAT_ENTITY_HITS]++;
 		st[PRGPU_STAT_CAMERA_DEPTH]++;
-		if (pathLength == 1)
+		if (pathLength == 1) {
 			out.samples[size_t(ly + out.r) * out.w + (lx + out.r)] += 1; // pushSPFragment -> AOV_SampleCount
+			// LocalFrameOutputDevice::commitShadingPoints (LocalFrameOutputDevice.cpp:252-283): plain per-pixel sums
+			auto add3 = [&](int k, V3 v) {
+				if (!s.aov[k].empty()) {
+					s.aov[k][3 * size_t(pixel)] += v.x;
+					s.aov[k][3 * size_t(pixel) + 1] += v.y;
+					s.aov[k][3 * size_t(pixel) + 2] += v.z;
+				}
+			};
+			auto add1 = [&](int k, float v) {
+				if (!s.aov[k].empty())
+					s.aov[k][pixel] += v;
+			};
+			add3(PRGPU_AOV_POSITION, P);
+			add3(PRGPU_AOV_NORMAL, N);
+			add3(PRGPU_AOV_NORMAL_G, N);
+			add3(PRGPU_AOV_TANGENT, gp.Nx);
+			add3(PRGPU_AOV_BITANGENT, gp.Ny);
+			add3(PRGPU_AOV_VIEW, ray.d);
+			add1(PRGPU_AOV_ENTITY_ID, (float)gp.entity);
+			add1(PRGPU_AOV_MATERIAL_ID, (float)gp.material);
+			add1(PRGPU_AOV_EMISSION_ID, (float)gp.emission);
+			add1(PRGPU_AOV_DEPTH, std::sqrt(depth2));
+		}
 		const bool hasEmission = gp.emission != INVALID;
 		if (cfg.direct && hasEmission) {
 			// ---- handleDirectHit (direct.cpp:355-412)
@@ -2386,6 +2410,21 @@ int orc_stats(orc_scene* h, uint64_t out[PRGPU_STAT_COUNT])
 	for (int k = 0; k < PRGPU_STAT_COUNT; ++k)
 		out[k] = h->s.stats[k];
 	return PRGPU_OK;
+}
+int orc_enable_aovs(orc_scene* h, uint32_t mask)
+{
+	const size_t np = size_t(h->s.cfg.width) * h->s.cfg.height;
+	for (uint32_t k = 0; k < PRGPU_AOV_COUNT; ++k)
+		if ((mask >> k) & 1u)
+			h->s.aov[k].assign(np * (k < PRGPU_AOV_ENTITY_ID ? 3 : 1), 0.0f);
+	return 0;
+}
+int orc_download_aov(orc_scene* h, uint32_t aov, float* out)
+{
+	if (aov >= PRGPU_AOV_COUNT || h->s.aov[aov].empty())
+		return -1;
+	std::memcpy(out, h->s.aov[aov].data(), h->s.aov[aov].size() * sizeof(float));
+	return 0;
 }
 int orc_download_primary_hits(orc_scene* h, uint32_t* entity, uint32_t* prim)
 {

@@ -17,6 +17,7 @@ MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR = 0, 1, 2
 ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE = 0, 1, 2
 LIGHT_ENVIRONMENT, LIGHT_DISTANT = 0, 1
 CAMERA_PERSPECTIVE, CAMERA_ORTHO = 0, 1
+AOV_NAMES = ("position", "normal", "normal_g", "tangent", "bitangent", "view", "entity_id", "material_id", "emission_id", "depth")
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_HAMMERSLEY, SAMPLER_UNIFORM, SAMPLER_STRATIFIED = range(7)
 MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO = range(3)
@@ -136,6 +137,10 @@ SYMBOLS = {
     "prgpu_download_primary_hits": (C.c_int, [_VP, _U32P, _U32P]),
     "prgpu_set_timing": (C.c_int, [_VP, C.c_int]),
     "prgpu_kernel_time_ms": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_double), _U64P]),
+    "prgpu_enable_aovs": (C.c_int, [_VP, C.c_uint32]),
+    "prgpu_aov_channels": (C.c_uint32, [C.c_uint32]),
+    "prgpu_download_aov": (C.c_int, [_VP, C.c_uint32, _F32P]),
+    "prgpu_write_exr": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(_F32P), _U32P]),
     "prgpu_prc_load_file": (C.c_int, [C.c_char_p, C.POINTER(PrcOptions), C.POINTER(_VP)]),
     "prgpu_prc_load_string": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(PrcOptions), C.POINTER(_VP)]),
     "prgpu_prc_desc": (C.POINTER(SceneDesc), [_VP]),

@@ -7,6 +7,7 @@ create -> start -> wait -> save) and the `direct` integrator contract (IIntegrat
 All compute goes through ``libprgpu.so``; there is no CPU path here.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -101,6 +102,20 @@ class RenderContext:
         abi.check(self.lib.prgpu_download(self._h, _f32p(xyz), _u32p(smp), _u32p(fb)))
         return xyz.reshape(self.height, self.width, 3), smp.reshape(self.height, self.width), fb.reshape(self.height, self.width)
 
+    def enableAOVs(self, names):
+        """Shading-point AOVs (LocalFrameOutputDevice::commitShadingPoints): enable before the first iteration."""
+        mask = 0
+        for n in names:
+            mask |= 1 << abi.AOV_NAMES.index(n)
+        abi.check(self.lib.prgpu_enable_aovs(self._h, mask))
+
+    def aov(self, name):
+        k = abi.AOV_NAMES.index(name)
+        ch = self.lib.prgpu_aov_channels(k)
+        out = np.empty(self.width * self.height * ch, dtype=np.float32)
+        abi.check(self.lib.prgpu_download_aov(self._h, k, _f32p(out)))
+        return out.reshape(self.height, self.width, ch) if ch > 1 else out.reshape(self.height, self.width)
+
     def primaryHits(self):
         n = self.width * self.height
         e = np.empty(n, dtype=np.uint32)
@@ -131,6 +146,18 @@ class RenderContext:
         abi.check(self.lib.prgpu_trace_any(self._h, n, _f32p(org), _f32p(direction), _f32p(tmin), _f32p(distance),
                                            occ.ctypes.data_as(C.POINTER(C.c_uint8))))
         return occ.astype(bool)
+
+
+def write_exr(path, channels):
+    """channels: dict name -> float32 array [H, W]; written by the library's EXR writer (uncompressed scanline, float)."""
+    lib = abi.load()
+    names = sorted(channels)
+    arrs = [np.ascontiguousarray(channels[n], dtype=np.float32) for n in names]
+    h, w = arrs[0].shape
+    c_names = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    c_planes = (C.POINTER(C.c_float) * len(names))(*[_f32p(a) for a in arrs])
+    strides = (C.c_uint32 * len(names))(*([1] * len(names)))
+    abi.check(lib.prgpu_write_exr(os.fsencode(path), w, h, len(names), c_names, c_planes, strides))
 
 
 def xyz_to_srgb_linear(xyz):

@@ -53,7 +53,7 @@ struct DevEntity {
 	uint32_t pad;
 };
 
-constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u;
+constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u;
 constexpr uint32_t PRIM_SPHERE_BIT = 0x40000000u; // leaf records: the primitive in this slot is an analytic sphere (centre, radius), not a triangle
 
 // Infinite light (include/prgpu.h prgpu_light) with the matrices the kernels need
@@ -135,6 +135,9 @@ struct PathState {
 	uint32_t* feedback; // feedback bit plane
 	uint32_t* prim_entity;
 	uint32_t* prim_prim;
+	// shading-point AOV sums (LocalFrameOutputDevice::commitShadingPoints), null when disabled; index = PRGPU_AOV_*
+	float* aov[PRGPU_AOV_COUNT];
+	uint32_t aov_mask;
 };
 
 constexpr uint32_t FLAG_MONO		  = 1u << 8;

@@ -831,8 +831,32 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		const uint32_t pathLength = depth + 1;
 		atomicAdd(&bs.v[PRGPU_STAT_ENTITY_HITS], 1u);
 		atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
-		if (pathLength == 1)
+		if (pathLength == 1) {
 			ps.samples[pixel] += 1;
+			if (FULL && ps.aov_mask) { // LocalFrameOutputDevice::commitShadingPoints (LocalFrameOutputDevice.cpp:252-283): plain per-pixel sums
+				auto add3 = [&](int k, V3 v) {
+					if (ps.aov[k]) {
+						ps.aov[k][3 * pixel] += v.x;
+						ps.aov[k][3 * pixel + 1] += v.y;
+						ps.aov[k][3 * pixel + 2] += v.z;
+					}
+				};
+				auto add1 = [&](int k, float v) {
+					if (ps.aov[k])
+						ps.aov[k][pixel] += v;
+				};
+				add3(PRGPU_AOV_POSITION, P);
+				add3(PRGPU_AOV_NORMAL, N);
+				add3(PRGPU_AOV_NORMAL_G, N); // IntersectionPoint::setForSurface: Surface.N = Geometry.N (IntersectionPoint.h:61-75)
+				add3(PRGPU_AOV_TANGENT, gp.Nx);
+				add3(PRGPU_AOV_BITANGENT, gp.Ny);
+				add3(PRGPU_AOV_VIEW, ray_d);
+				add1(PRGPU_AOV_ENTITY_ID, (float)gp.entity);
+				add1(PRGPU_AOV_MATERIAL_ID, (float)gp.material);
+				add1(PRGPU_AOV_EMISSION_ID, (float)gp.emission);
+				add1(PRGPU_AOV_DEPTH, sqrtf(depth2));
+			}
+		}
 		const bool hasEmission = gp.emission != INVALID;
 		bool go_on			   = true;
 		if (cfg.direct && hasEmission) {

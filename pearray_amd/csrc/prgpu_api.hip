@@ -1035,6 +1035,47 @@ int prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* d
 	return PRGPU_OK;
 }
 
+uint32_t prgpu_aov_channels(uint32_t aov) { return aov < PRGPU_AOV_ENTITY_ID ? 3u : (aov < PRGPU_AOV_COUNT ? 1u : 0u); }
+
+int prgpu_enable_aovs(prgpu_scene* s, uint32_t mask)
+{
+	if (!s)
+		return fail(PRGPU_EINVAL, "null scene");
+	if (s->next_iteration != 0)
+		return fail(PRGPU_EINVAL, "AOVs must be enabled before the first iteration");
+	if (mask >> PRGPU_AOV_COUNT)
+		return fail(PRGPU_EINVAL, "unknown AOV bit");
+	HIP_TRY(hipSetDevice(s->device));
+	for (uint32_t k = 0; k < PRGPU_AOV_COUNT; ++k) {
+		if (!((mask >> k) & 1u) || s->ps.aov[k])
+			continue;
+		const int rc = s->alloc(s->ps.aov[k], size_t(s->n_pixels) * prgpu_aov_channels(k), true);
+		if (rc != PRGPU_OK)
+			return rc;
+	}
+	s->ps.aov_mask |= mask;
+	if (s->ps.aov_mask)
+		s->sc.features |= prd::FEAT_AOVS; // selects the full kernel variant
+	for (auto& g : s->groups) { // the pixel groups carry copies of the path state
+		std::memcpy(g.ps.aov, s->ps.aov, sizeof(s->ps.aov));
+		g.ps.aov_mask = s->ps.aov_mask;
+	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return PRGPU_OK;
+}
+
+int prgpu_download_aov(prgpu_scene* s, uint32_t aov, float* out)
+{
+	if (!s || !out)
+		return fail(PRGPU_EINVAL, "null argument");
+	if (aov >= PRGPU_AOV_COUNT || !s->ps.aov[aov])
+		return fail(PRGPU_EINVAL, "AOV not enabled");
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	HIP_TRY(hipMemcpy(out, s->ps.aov[aov], size_t(s->n_pixels) * prgpu_aov_channels(aov) * sizeof(float), hipMemcpyDeviceToHost));
+	return PRGPU_OK;
+}
+
 int prgpu_download_primary_hits(prgpu_scene* s, uint32_t* entity, uint32_t* prim)
 {
 	if (!s || !entity || !prim)

@@ -150,6 +150,21 @@ class OracleScene:
         self.lib.orc_stats(self.h, out)
         return {n: int(out[i]) for i, n in enumerate(abi.STAT_NAMES)}
 
+    def enable_aovs(self, names):
+        mask = 0
+        for n in names:
+            mask |= 1 << abi.AOV_NAMES.index(n)
+        self.lib.orc_enable_aovs.argtypes = [C.c_void_p, C.c_uint32]
+        self.lib.orc_enable_aovs(self.h, mask)
+
+    def aov(self, name):
+        k = abi.AOV_NAMES.index(name)
+        ch = 3 if k < 6 else 1
+        out = np.empty(self.width * self.height * ch, dtype=np.float32)
+        self.lib.orc_download_aov.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+        assert self.lib.orc_download_aov(self.h, k, out.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        return out.reshape(self.height, self.width, ch) if ch > 1 else out.reshape(self.height, self.width)
+
     def primary_hits(self):
         n = self.width * self.height
         e, p = np.empty(n, np.uint32), np.empty(n, np.uint32)
