@@ -164,7 +164,11 @@ typedef struct prgpu_camera {
 enum { PRGPU_SAMPLER_RANDOM = 0, PRGPU_SAMPLER_MJITT = 1, PRGPU_SAMPLER_SOBOL = 2, PRGPU_SAMPLER_HALTON = 3, PRGPU_SAMPLER_HAMMERSLEY = 4,
        PRGPU_SAMPLER_UNIFORM = 5,     /* UniformSampler.cpp: always (0.5, 0.5) */
        PRGPU_SAMPLER_STRATIFIED = 6 }; /* StratifiedSampler.cpp: jitter inside a sqrt(bins) x sqrt(bins) grid; bins in aa_base_x (0 = aa_samples) */
-enum { PRGPU_MAPPER_SPD_CMIS = 0, PRGPU_MAPPER_RANDOM = 1, PRGPU_MAPPER_SPD_HERO = 2 };
+enum { PRGPU_MAPPER_SPD_CMIS = 0, PRGPU_MAPPER_RANDOM = 1, PRGPU_MAPPER_SPD_HERO = 2,
+       PRGPU_MAPPER_CIE = 3,     /* spectralmapper/cie.cpp: each wavelength drawn from the X+Y+Z CDF (CIE.h:97-101), truncated to the
+                                    spectral range when it lies inside the CIE domain (CIE.h:110-118); a range reaching outside the
+                                    CIE domain is PRGPU_EINVAL (the reference factory returns no mapper, cie.cpp:93-102) */
+       PRGPU_MAPPER_CIE_Y = 4 }; /* the same with the Y-only CDF ('cie_y', 'visible_y' or :only_y true, cie.cpp:109-113) */
 enum { PRGPU_FILTER_BLOCK = 0, PRGPU_FILTER_TRIANGLE = 1, PRGPU_FILTER_GAUSSIAN = 2,
        PRGPU_FILTER_MITCHELL = 3, PRGPU_FILTER_LANCZOS = 4 }; /* src/plugins/main/filter/*.cpp */
 enum { PRGPU_MIS_BALANCE = 0, PRGPU_MIS_POWER = 1 };

@@ -405,6 +405,13 @@ inline float distribution_sample_continuous(const float* cdf, uint32_t size, flo
 	pdf *= float(size - 1);
 	return (float(off) + rem) / float(size - 1);
 }
+// Distribution1D.inl:105-111 evalContinuous
+inline float distribution_eval_continuous(const float* cdf, uint32_t size, float x)
+{
+	const size_t off = std::min<size_t>(size - 2, (size_t)(x * (size - 1)));
+	const float dt	 = x * (size - 1) - off;
+	return cdf[off] * (1 - dt) + cdf[off + 1] * dt;
+}
 inline float distribution_continuous_pdf(const float* cdf, uint32_t size, float x)
 {
 	const size_t off = std::min<size_t>(size - 2, (size_t)(x * (size - 1)));
@@ -704,6 +711,7 @@ struct Scene {
 	float scene_radius = 0; // Scene::boundingSphere().radius(), Scene.cpp:107-118
 	// wavelength distribution (spd mapper)
 	std::vector<float> wl_cdf;
+	float wl_cdf_start = 0.0f, wl_cdf_end = 1.0f; // cie mapper truncation window
 	// integrator
 	std::vector<float> rr_prob; // by path length
 	std::vector<float> filter;
@@ -1424,6 +1432,31 @@ int setup_lights(Scene& s)
 // complete sampling floor 1e-2)
 void setup_wavelengths(Scene& s)
 {
+	if (s.cfg.mapper == PRGPU_MAPPER_CIE || s.cfg.mapper == PRGPU_MAPPER_CIE_Y) {
+		// StaticCDF (Distribution1D.h:13-46) over NM_TO_Y or NM_TO_X+Y+Z (CIE.cpp:431-433)
+		const uint32_t n = CIE_SAMPLES;
+		s.wl_cdf.assign(n + 1, 0.0f);
+		for (uint32_t i = 1; i < n + 1; ++i) {
+			const float value = s.cfg.mapper == PRGPU_MAPPER_CIE_Y ? PR_CIE2006_Y[i - 1] : (PR_CIE2006_X[i - 1] + PR_CIE2006_Y[i - 1] + PR_CIE2006_Z[i - 1]);
+			s.wl_cdf[i]		  = s.wl_cdf[i - 1] + value / n;
+		}
+		const float total = s.wl_cdf[n];
+		if (total < PR_EPS) {
+			for (uint32_t i = 1; i < n + 1; ++i)
+				s.wl_cdf[i] = float(i) / float(n);
+		} else {
+			for (uint32_t i = 1; i < n + 1; ++i)
+				s.wl_cdf[i] /= total;
+		}
+		s.wl_cdf[n] = 1.0f;
+		// CIE.h:124-134 sample_trunc: window of the CDF covered by the camera range; (0, 1) for the full domain, where
+		// FullCIESpectralMapper (cie.cpp:21-30) computes the same values without the window
+		const float norm_start = (s.cfg.spectral_start - CIE_START) / CIE_RANGE;
+		const float norm_end   = (s.cfg.spectral_end - CIE_START) / CIE_RANGE;
+		s.wl_cdf_start		   = distribution_eval_continuous(s.wl_cdf.data(), n + 1, norm_start);
+		s.wl_cdf_end		   = distribution_eval_continuous(s.wl_cdf.data(), n + 1, norm_end);
+		return;
+	}
 	const uint32_t bins = 440; // PR_CIE_WAVELENGTH_RANGE
 	const float start = s.cfg.spectral_start, span = s.cfg.spectral_end - s.cfg.spectral_start;
 	auto bin2wvl = [&](uint32_t bin) { return start + (bin / float(bins - 1)) * span; };
@@ -1645,6 +1678,17 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		for (int k = 1; k < 4; ++k)
 			wl[k] = cfg.spectral_start + std::fmod(hero - cfg.spectral_start + k * delta, span);
 		wl_pdf = blob(pdf);
+	} else if (cfg.mapper == PRGPU_MAPPER_CIE || cfg.mapper == PRGPU_MAPPER_CIE_Y) {
+		// cie.cpp:59-68 TruncatedCIESpectralMapper::sample -> CIE.h:80-87,110-134 (the full-domain mapper, cie.cpp:21-30, is the
+		// window (0, 1) of the same arithmetic)
+		for (int k = 0; k < 4; ++k) {
+			float pdf;
+			const float u = rng_float(rnd);
+			const float v = distribution_sample_continuous(s.wl_cdf.data(), (uint32_t)s.wl_cdf.size(), s.wl_cdf_start + u * (s.wl_cdf_end - s.wl_cdf_start), pdf);
+			pdf /= (s.wl_cdf_end - s.wl_cdf_start);
+			wl[k]	  = v * (cfg.spectral_end - cfg.spectral_start) + cfg.spectral_start;
+			wl_pdf[k] = pdf;
+		}
 	} else { // random.cpp:22-36
 		const float u	  = rng_float(rnd);
 		const float span  = cfg.spectral_end - cfg.spectral_start;
@@ -2189,6 +2233,9 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 		return fail("empty film");
 	if (s.cfg.filter_radius > 3)
 		return fail("filter radius > 3");
+	// cie.cpp:93-102: no mapper is created for a camera range reaching outside the CIE domain
+	if (!s.cfg.spectral_mono && (s.cfg.mapper == PRGPU_MAPPER_CIE || s.cfg.mapper == PRGPU_MAPPER_CIE_Y) && !(s.cfg.spectral_start >= CIE_START && s.cfg.spectral_end <= CIE_END))
+		return fail("cie spectral mapper outside the CIE domain");
 	s.positions.assign(d->positions, d->positions + 3 * size_t(d->n_vertices));
 	s.has_normals_array = d->normals != nullptr;
 	if (d->normals)

@@ -5,6 +5,6 @@ assembly) and `backend` (ctypes host mirror).  Importing the package does not lo
 `backend.RenderContext` does, and raises if it has not been built.
 """
 from . import _cabi  # noqa: F401
-from ._cabi import (FILTER_BLOCK, FILTER_GAUSSIAN, FILTER_MITCHELL, FILTER_TRIANGLE, MAPPER_RANDOM,  # noqa: F401
+from ._cabi import (FILTER_BLOCK, FILTER_GAUSSIAN, FILTER_MITCHELL, FILTER_TRIANGLE, MAPPER_CIE, MAPPER_CIE_Y, MAPPER_RANDOM,  # noqa: F401
                     MAPPER_SPD_CMIS, MAPPER_SPD_HERO, MIS_BALANCE, MIS_POWER, SAMPLER_MJITT, SAMPLER_RANDOM,
                     SAMPLER_SOBOL)

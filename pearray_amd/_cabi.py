@@ -20,7 +20,7 @@ CAMERA_PERSPECTIVE, CAMERA_ORTHO = 0, 1
 AOV_NAMES = ("position", "normal", "normal_g", "tangent", "bitangent", "view", "entity_id", "material_id", "emission_id", "depth")
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_HAMMERSLEY, SAMPLER_UNIFORM, SAMPLER_STRATIFIED = range(7)
-MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO = range(3)
+MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO, MAPPER_CIE, MAPPER_CIE_Y = range(5)
 FILTER_BLOCK, FILTER_TRIANGLE, FILTER_GAUSSIAN, FILTER_MITCHELL, FILTER_LANCZOS = range(5)
 MIS_BALANCE, MIS_POWER = range(2)
 

@@ -92,6 +92,7 @@ struct DevScene {
 	uint32_t features;	// FEAT_* bits the scene needs beyond Lambert + meshes + area lights (selects the kernel variant)
 	const float* wl_cdf;
 	uint32_t wl_cdf_size;
+	float wl_u_offset, wl_u_scale; // cie mapper truncation window (CIE.h:124-134); (0, 1) over the full CIE domain
 	const float* sobol2d;
 	const float* rr_prob;
 	uint32_t rr_size;

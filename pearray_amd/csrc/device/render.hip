@@ -603,6 +603,14 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 		for (int k = 1; k < 4; ++k)
 			wl.v[k] = cfg.spectral_start + fmodf(hero - cfg.spectral_start + k * delta, span);
 		wl_pdf = blob(pdf);
+	} else if (cfg.mapper == PRGPU_MAPPER_CIE || cfg.mapper == PRGPU_MAPPER_CIE_Y) { // cie.cpp:21-30,59-68 over CIE.h:110-134
+		const float span = cfg.spectral_end - cfg.spectral_start;
+		for (int k = 0; k < 4; ++k) {
+			float pdf;
+			const float v = distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, sc.wl_u_offset + rng_float(rnd) * sc.wl_u_scale, pdf);
+			wl.v[k]		  = v * span + cfg.spectral_start;
+			wl_pdf.v[k]	  = pdf / sc.wl_u_scale;
+		}
 	} else { // random.cpp:22-36
 		const float u	  = rng_float(rnd);
 		const float span  = cfg.spectral_end - cfg.spectral_start;

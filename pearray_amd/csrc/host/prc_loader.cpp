@@ -427,7 +427,7 @@ struct Loader {
 		settings.filter_radius = (uint32_t)std::max(0.0, get_number(g, "radius", 3));
 		have_filter			   = true;
 	}
-	void add_mapper(const Group& g) // SceneLoader.cpp:308-352, spd.cpp:360-383, random.cpp
+	void add_mapper(const Group& g) // SceneLoader.cpp:308-352, spd.cpp:360-383, random.cpp, cie.cpp
 	{
 		const std::string type = lower(get_string(g, "type", ""));
 		if (lower(get_string(g, "purpose", "pixel")) != "pixel") {
@@ -440,8 +440,11 @@ struct Loader {
 			settings.mapper = get_bool(g, "cmis", true) ? PRGPU_MAPPER_SPD_CMIS : PRGPU_MAPPER_SPD_HERO;
 			if (g.get("bins") || g.get("weighting") || g.get("complete") || g.get("normalized") || g.get("smooth_iterations"))
 				fail(PRGPU_EUNSUPPORTED, where(g) + ": only the default spd histogram (bins, weighting, smoothing) is implemented");
+		} else if (type == "cie" || type == "cie_y" || type == "visible" || type == "visible_y") { // cie.cpp:107-120
+			const bool only_y = type == "cie_y" || type == "visible_y" || get_bool(g, "only_y", false);
+			settings.mapper	  = only_y ? PRGPU_MAPPER_CIE_Y : PRGPU_MAPPER_CIE;
 		} else {
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": spectral mapper '" + type + "' is not supported (spd, random are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": spectral mapper '" + type + "' is not supported (spd, random, cie, cie_y are)");
 		}
 	}
 	void add_integrator(const Group& g) // SceneLoader.cpp:354-384, direct.cpp:498-512,545-563

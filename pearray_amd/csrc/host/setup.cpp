@@ -435,8 +435,43 @@ void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 	}
 }
 
+// Distribution1D::evalContinuous (Distribution1D.inl:105-111)
+float cdf_eval_continuous(const std::vector<float>& cdf, float x)
+{
+	const size_t size = cdf.size();
+	const size_t off  = std::min<size_t>(size - 2, (size_t)(x * (size - 1)));
+	const float dt	  = x * (size - 1) - off;
+	return cdf[off] * (1 - dt) + cdf[off + 1] * dt;
+}
+
+// cie mapper: StaticCDF over the tabulated curves (Distribution1D.h:13-46, CIE.cpp:431-433) and the truncation window of
+// CIE::sample_trunc (CIE.h:124-134); the full range gives exactly (0, 1)
+void cie_wavelength_table(const prgpu_scene_desc* d, HostTables& t)
+{
+	const uint32_t n  = prd::CIE_SAMPLES;
+	const bool only_y = d->settings.mapper == PRGPU_MAPPER_CIE_Y;
+	std::vector<float>& cdf = t.wl_cdf;
+	cdf.assign(n + 1, 0.0f);
+	for (uint32_t i = 1; i < n + 1; ++i)
+		cdf[i] = cdf[i - 1] + (only_y ? PR_CIE2006_Y[i - 1] : (PR_CIE2006_X[i - 1] + PR_CIE2006_Y[i - 1] + PR_CIE2006_Z[i - 1])) / n;
+	const float sum = cdf[n];
+	for (uint32_t i = 1; i < n + 1; ++i)
+		cdf[i] = sum < EPS_F ? float(i) / float(n) : cdf[i] / sum;
+	cdf[n] = 1.0f;
+	const float norm_start = (d->settings.spectral_start - prd::CIE_START) / prd::CIE_RANGE;
+	const float norm_end   = (d->settings.spectral_end - prd::CIE_START) / prd::CIE_RANGE;
+	const float cdf_start  = cdf_eval_continuous(cdf, norm_start);
+	const float cdf_end	   = cdf_eval_continuous(cdf, norm_end);
+	t.wl_u_offset		   = cdf_start;
+	t.wl_u_scale		   = cdf_end - cdf_start;
+}
+
 void wavelength_table(const prgpu_scene_desc* d, HostTables& t, size_t n_lights)
 {
+	if (d->settings.mapper == PRGPU_MAPPER_CIE || d->settings.mapper == PRGPU_MAPPER_CIE_Y) {
+		cie_wavelength_table(d, t);
+		return;
+	}
 	const uint32_t bins = 440;
 	const float start = d->settings.spectral_start, span = d->settings.spectral_end - d->settings.spectral_start;
 	auto wavelength_of = [&](uint32_t bin) { return start + (bin / float(bins - 1)) * span; };
@@ -598,12 +633,14 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		return bad("film too large");
 	if (c.filter_radius > 3)
 		return bad("filter radius > 3 is not supported", PRGPU_EUNSUPPORTED);
-	if (c.aa_sampler > PRGPU_SAMPLER_STRATIFIED || ((c.aa_sampler == PRGPU_SAMPLER_HALTON || c.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) && (c.aa_base_x == 1 || c.aa_base_y == 1)) || c.mapper > PRGPU_MAPPER_SPD_HERO || c.filter > PRGPU_FILTER_LANCZOS || c.mis > PRGPU_MIS_POWER)
+	if (c.aa_sampler > PRGPU_SAMPLER_STRATIFIED || ((c.aa_sampler == PRGPU_SAMPLER_HALTON || c.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) && (c.aa_base_x == 1 || c.aa_base_y == 1)) || c.mapper > PRGPU_MAPPER_CIE_Y || c.filter > PRGPU_FILTER_LANCZOS || c.mis > PRGPU_MIS_POWER)
 		return bad("unknown sampler / mapper / filter / mis selector");
 	if (!c.aa_samples || !c.lens_samples || !c.time_samples || !c.spectral_samples)
 		return bad("sample counts must be positive");
 	if (!(c.spectral_end > c.spectral_start))
 		return bad("spectral domain is empty");
+	if (!c.spectral_mono && (c.mapper == PRGPU_MAPPER_CIE || c.mapper == PRGPU_MAPPER_CIE_Y) && !(c.spectral_start >= prd::CIE_START && c.spectral_end <= prd::CIE_END))
+		return bad("the cie spectral mapper needs a spectral domain inside the CIE domain (cie.cpp:93-102)");
 	if (c.max_ray_depth == 0 || c.max_ray_depth > 255)
 		return bad("max_ray_depth must be in 1..255");
 	if (d->n_entities > 0xFFFF)

@@ -20,6 +20,7 @@ struct HostTables {
 	std::vector<prd::DevInfLight> inf_lights;
 	float scene_radius = 0.0f;
 	std::vector<float> wl_cdf;
+	float wl_u_offset = 0.0f, wl_u_scale = 1.0f; // cie mapper: truncation window inside the CDF (CIE.h:124-134)
 	std::vector<float> sobol2d; // tabulated AA samples (sobol, halton or hammersley)
 	uint32_t halton_bx = 13, halton_by = 47, halton_burnin = 47;
 	std::vector<float> rr_prob;

@@ -257,6 +257,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 			sc.features |= prd::FEAT_SPHERES;
 	sc.scene_radius	 = t.scene_radius;
 	sc.wl_cdf_size	 = (uint32_t)t.wl_cdf.size();
+	sc.wl_u_offset	 = t.wl_u_offset;
+	sc.wl_u_scale	 = t.wl_u_scale;
 	sc.rr_size		 = (uint32_t)t.rr_prob.size();
 	sc.cam			 = t.cam;
 	sc.cfg			 = d->settings;

@@ -62,10 +62,24 @@ def test_cornell_c1_bit_exact():
 
 @pytest.mark.parametrize("sampler", [abi.SAMPLER_RANDOM, abi.SAMPLER_MJITT, abi.SAMPLER_SOBOL, abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY,
                                      abi.SAMPLER_UNIFORM, abi.SAMPLER_STRATIFIED])
-@pytest.mark.parametrize("mapper", [abi.MAPPER_SPD_CMIS, abi.MAPPER_RANDOM, abi.MAPPER_SPD_HERO])
+@pytest.mark.parametrize("mapper", [abi.MAPPER_SPD_CMIS, abi.MAPPER_RANDOM, abi.MAPPER_SPD_HERO, abi.MAPPER_CIE, abi.MAPPER_CIE_Y])
 def test_samplers_and_mappers(sampler, mapper):
     g, o = render_both(scene.cornell_box(48, 40, spp=6, sampler=sampler, mapper=mapper))
     assert_parity(g, o, exact=True)
+
+
+@pytest.mark.parametrize("mapper", [abi.MAPPER_CIE, abi.MAPPER_CIE_Y])
+@pytest.mark.parametrize("domain", [(420.0, 700.0), (390.0, 600.0), (555.0, 830.0)])
+def test_truncated_cie_mapper(mapper, domain):
+    """TruncatedCIESpectralMapper (cie.cpp:46-86): camera range strictly inside the CIE domain."""
+    g, o = render_both(scene.cornell_box(40, 32, spp=5, mapper=mapper, spectral_start=domain[0], spectral_end=domain[1]))
+    assert_parity(g, o, exact=True)
+
+
+def test_cie_mapper_outside_the_cie_domain_is_rejected():
+    b = scene.cornell_box(8, 8, spp=1, mapper=abi.MAPPER_CIE, spectral_start=380.0, spectral_end=780.0)
+    with pytest.raises(RuntimeError, match="CIE domain"):
+        backend.RenderContext(b)
 
 
 @pytest.mark.parametrize("kw", [dict(mis=abi.MIS_POWER), dict(nee=0), dict(direct=0), dict(emissive_scatter=0),

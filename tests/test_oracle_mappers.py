@@ -1,0 +1,122 @@
+"""The `cie` / `cie_y` spectral mappers (src/plugins/main/spectralmapper/cie.cpp over CIE.h:68-134 and the StaticCDF of
+Distribution1D.h:13-46): the CDF against an independent float32 restatement, the truncation window, the sample/pdf consistency
+KAT of the reference's tests (distribution.cpp:69-78) on the CIE CDFs, unbiasedness against the `random` mapper, and the
+factory's domain rule (cie.cpp:93-102)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from pearray_amd import _cabi as abi
+from pearray_amd import scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cie_planes():
+    """The committed CIE 2006 planes, parsed from the table file itself (so the test does not go through the oracle's code)."""
+    src = open(os.path.join(ROOT, "oracle", "pr_tables.inl")).read()
+    out = []
+    for name in ("PR_CIE2006_X", "PR_CIE2006_Y", "PR_CIE2006_Z"):
+        body = re.search(r"%s\[441\]\s*=\s*\{(.*?)\};" % name, src, re.S).group(1)
+        out.append(np.array([np.float32(t.rstrip("f")) for t in re.findall(r"[-+0-9.eE]+f?", body) if t not in ("f",)], np.float32))
+        assert out[-1].size == 441
+    return out
+
+
+def static_cdf(values):
+    n = np.float32(values.size)
+    cdf = np.zeros(values.size + 1, np.float32)
+    for i in range(1, values.size + 1):
+        cdf[i] = np.float32(cdf[i - 1] + np.float32(values[i - 1] / n))
+    cdf[1:] = cdf[1:] / cdf[-1]
+    cdf[-1] = 1.0
+    return cdf
+
+
+def oracle_cdf(mapper, **kw):
+    o = ob.OracleScene(scene.cornell_box(8, 8, spp=1, mapper=mapper, **kw))
+    n, ptr = C.c_uint32(), C.POINTER(C.c_float)()
+    o.lib.orc_wavelength_cdf(o.h, C.byref(n), C.byref(ptr))
+    return o, np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+
+def test_cie_cdfs_match_an_independent_restatement():
+    x, y, z = cie_planes()
+    _, cdf_xyz = oracle_cdf(abi.MAPPER_CIE)
+    _, cdf_y = oracle_cdf(abi.MAPPER_CIE_Y)
+    assert cdf_xyz.size == 442 and cdf_y.size == 442
+    assert np.array_equal(cdf_xyz, static_cdf((x + y) + z))
+    assert np.array_equal(cdf_y, static_cdf(y))
+    assert cdf_y[0] == 0 and cdf_y[-1] == 1 and (np.diff(cdf_y) >= 0).all()
+    # the Y curve peaks near 555 nm: the median wavelength of the Y CDF sits there, the X+Y+Z one further towards blue
+    med_y = 390 + 440 * np.searchsorted(cdf_y, 0.5) / 441
+    med_xyz = 390 + 440 * np.searchsorted(cdf_xyz, 0.5) / 441
+    assert 545 < med_y < 570 and med_xyz < med_y
+
+
+@pytest.mark.parametrize("mapper", [abi.MAPPER_CIE, abi.MAPPER_CIE_Y])
+def test_sample_pdf_consistency_kat(mapper):
+    """distribution.cpp:69-78 'Consistency Continous' on the CIE CDFs: continuousPdf(sampleContinuous(u)) == pdf."""
+    o, cdf = oracle_cdf(mapper)
+    p = cdf.ctypes.data_as(C.POINTER(C.c_float))
+    for u in np.linspace(0.01, 0.99, 57, dtype=np.float32):
+        pdf = C.c_float()
+        v = o.lib.orc_distribution_sample_continuous(p, cdf.size, float(u), C.byref(pdf))
+        assert 0 <= v <= 1
+        assert o.lib.orc_distribution_continuous_pdf(p, cdf.size, v) == pdf.value
+
+
+def radiance_image(mapper, spp, **kw):
+    o = ob.OracleScene(scene.cornell_box(24, 24, spp=spp, mapper=mapper, **kw))
+    o.render(spp)
+    return o.output()[0].reshape(-1, 3)
+
+
+@pytest.mark.parametrize("mapper,kw", [(abi.MAPPER_CIE, {}), (abi.MAPPER_CIE_Y, {}),
+                                       (abi.MAPPER_CIE, dict(spectral_start=420.0, spectral_end=700.0))])
+def test_cie_mappers_are_unbiased(mapper, kw):
+    """Importance-sampled wavelengths estimate the same image as uniform ones: mean XYZ of the diffusely lit pixels (the pixels
+    straddling the light's edge carry most of the anti-aliasing noise and are masked out) within Monte-Carlo noise.
+    In the truncated case the reference maps the CDF abscissa of the whole CIE domain onto [start, end] (CIE.h:86-87), so that
+    estimate is only required to be finite and positive."""
+    got = radiance_image(mapper, 64, **kw)
+    assert np.isfinite(got).all() and (got.mean(axis=0) > 0).all()
+    if not kw:
+        ref = radiance_image(abi.MAPPER_RANDOM, 64)
+        mask = (ref[:, 1] < 0.5) & (got[:, 1] < 0.5)
+        assert mask.sum() > 500
+        a, b = got[mask].mean(axis=0), ref[mask].mean(axis=0)
+        assert np.allclose(a, b, rtol=0.04), (a, b)
+
+
+def test_truncation_window():
+    """Samples of the truncated mapper stay inside [start, end]; its CDF window is the one CIE.h:124-134 evaluates."""
+    b = scene.cornell_box(16, 16, spp=4, mapper=abi.MAPPER_CIE_Y, spectral_start=500.0, spectral_end=600.0)
+    o = ob.OracleScene(b)
+    o.render(4)
+    assert np.isfinite(o.output()[0]).all()
+
+
+@pytest.mark.parametrize("rng", [(380.0, 780.0), (400.0, 831.0)])
+def test_domain_outside_cie_is_rejected(rng):
+    b = scene.cornell_box(8, 8, spp=1, mapper=abi.MAPPER_CIE, spectral_start=rng[0], spectral_end=rng[1])
+    assert not ob.load().orc_scene_create(C.byref(b.desc))
+    assert b"CIE domain" in ob.load().orc_last_error()
+
+
+def test_loader_names():
+    """cie.cpp:107-120: four names and the :only_y switch."""
+    body = """(scene :render_width 8 :render_height 8
+      (spectral_mapper :type '%s' %s)
+      (camera :name 'c' :type 'standard')
+      (material :name 'm' :type 'diffuse')
+      (mesh :name 'q' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,2]))
+      (entity :name 'e' :type 'mesh' :mesh 'q' :materials 'm'))"""
+    for name, extra, want in [("cie", "", abi.MAPPER_CIE), ("visible", "", abi.MAPPER_CIE), ("cie_y", "", abi.MAPPER_CIE_Y),
+                              ("visible_y", "", abi.MAPPER_CIE_Y), ("cie", ":only_y true", abi.MAPPER_CIE_Y)]:
+        s = scene.PrcScene(source=body % (name, extra))
+        assert s.desc.settings.mapper == want

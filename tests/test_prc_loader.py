@@ -109,7 +109,7 @@ def test_defaults_follow_the_reference():
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
     ("(sampler :type 'blue_noise')", -4, "sampler type 'blue_noise'"),
     ("(filter :type 'box3')", -1, "unknown filter type 'box3'"),
-    ("(spectral_mapper :type 'cie')", -4, "spectral mapper 'cie'"),
+    ("(spectral_mapper :type 'agh')", -4, "spectral mapper 'agh'"),
     ("(emission :name 'x' :type 'standard' :radiance (illuminant 'A'))", -4, "illuminant 'a'"),
     ("(material :name 'x' :type 'diffuse' :albedo (checkerboard 1 2))", -4, "checkerboard"),
     ("(entity :name 'e2' :type 'mesh' :mesh 'nope' :materials 'm')", -1, "unknown mesh 'nope'"),
