@@ -1366,6 +1366,8 @@ struct PersistentArgs {
 	int partial_act;
 	int both_below;		 // a wave with fewer rays in flight than this steps inner nodes AND leaves in one step
 	uint32_t refill_min; // waves other than the block's first one refill only when at least this many rays are queued
+	uint32_t shader_wave; // 1: the block's last wave only shades (any batch size, never holds rays); the others trace and help
+	uint32_t shade_help;  // ... with full batches once this many vertices wait
 	unsigned long long* gstats;
 };
 
@@ -1409,13 +1411,22 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	unsigned long long t_shade = 0, t_idle = 0;
 	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
 
+	const bool shader = a.shader_wave != 0u && (threadIdx.x >> 6) == TRAV_BLOCK / 64 - 1;
+	const uint32_t shade_full = a.shader_wave != 0u ? a.shade_help : a.shade_min;
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
 		uint32_t n_shade  = wave_bcast0(lds_load(&sh.shade_tail) - lds_load(&sh.shade_head));
 		uint32_t n_queued = wave_bcast0(lds_load(&sh.ray_tail) - lds_load(&sh.ray_head));
 
 		// ---- shade: a full wave of waiting vertices, or whatever is there when this wave is short of rays anyway
-		if (n_shade >= a.shade_min || (n_queued == 0u && ((n_shade >= a.shade_partial && n_act < a.partial_act) || (n_shade > 0u && n_act == 0)))) {
+		bool shade_now;
+		if (shader)
+			shade_now = n_shade > 0u;
+		else if (a.shader_wave != 0u)
+			shade_now = n_shade >= shade_full || (n_queued == 0u && n_shade > 0u && n_act == 0);
+		else
+			shade_now = n_shade >= a.shade_min || (n_queued == 0u && ((n_shade >= a.shade_partial && n_act < a.partial_act) || (n_shade > 0u && n_act == 0)));
+		if (shade_now) {
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.shade_head, &sh.shade_tail, 64u, first);
 			if (n) {
@@ -1507,7 +1518,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		// wait for at least `refill_min`, so that a thin supply of rays fills a few waves instead of keeping every wave stepping
 		// with a handful of lanes (a wave step costs the same with 3 lanes as with 64).
 		const unsigned long long idle = __ballot(!has_ray);
-		if (idle != 0ull && n_queued > 0u && (n_queued >= a.refill_min || threadIdx.x < 64u)) {
+		if (!shader && idle != 0ull && n_queued > 0u && (n_queued >= a.refill_min || threadIdx.x < 64u)) {
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(idle), first);
 			const uint32_t r = __popcll(idle & ((1ull << lane) - 1ull));
@@ -1612,7 +1623,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				break;
 			if (active < a.refill_below) { // under-occupied: leave if there is anything to refill from or to shade
 				const uint32_t nq = lds_load(&sh.ray_tail) - lds_load(&sh.ray_head), nsh = lds_load(&sh.shade_tail) - lds_load(&sh.shade_head);
-				if (wave_bcast0(((nq > 0u && (nq >= a.refill_min || threadIdx.x < 64u)) || nsh >= a.shade_min || (nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
+				if (wave_bcast0(((nq > 0u && (nq >= a.refill_min || threadIdx.x < 64u)) || nsh >= shade_full || (a.shader_wave == 0u && nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
 					break;
 			}
 		}
@@ -1764,7 +1775,7 @@ PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, ui
 uint32_t persistent_slot_padding() { return PP_SLOTS_MAX; }
 
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
-							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int refill_min, int both_below, int occupancy,
+							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int refill_min, int both_below, int occupancy, int shader_wave, int shade_help,
 							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st)
 {
 	const PersistentGeometry g = persistent_geometry(n_owned, ws.max_blocks, max_slots_per_block);
@@ -1783,6 +1794,8 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.partial_act	  = std::min(ws.refill_below, std::max(1, partial_act));
 	a.refill_min	  = (uint32_t)std::min(64, std::max(1, refill_min));
 	a.both_below	  = std::min(65, std::max(0, both_below));
+	a.shader_wave	  = shader_wave ? 1u : 0u;
+	a.shade_help	  = (uint32_t)std::max(64, shade_help);
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks), block(TRAV_BLOCK);

@@ -62,7 +62,7 @@ struct prgpu_scene {
 	enum Mode { LOCKSTEP, STREAMING, PERSISTENT };
 	Mode mode = LOCKSTEP;
 	uint32_t pp_slots = 512;
-	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 0, pp_occupancy = 3;
+	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 0, pp_occupancy = 3, pp_shader_wave = 0, pp_shade_help = 128;
 	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
 	prd::TraceWorkspace ws;	   // workspace of the ray-service launches
@@ -166,6 +166,29 @@ int apply_tiles(prgpu_scene* s, const prgpu_tile* tiles, uint32_t n_tiles)
 	std::vector<uint32_t> pixels;
 	prgpu_host::owned_pixels_morton(s->cfg.width, s->cfg.height, tiles, n_tiles, pixels);
 	s->n_slots = (uint32_t)pixels.size();
+	// Persistent mode with every owned pixel in flight at once (a small tile share: pixels <= path slots): no slot ever takes a
+	// second pixel, so a block that was handed only cheap pixels (camera rays that miss the scene) runs dry while one with only
+	// expensive ones is crowded.  Handing out the Morton order in a strided order of 2x2-pixel quads gives every block the same mix
+	// (1/8 of the C4 frame: 2.96 -> 2.75 ms per iteration).  With more pixels than slots the plain Morton order is faster (primary
+	// ray coherence; full frame 14.7 vs 15.4 ms), and slots pick up new pixels as they finish anyway.
+	{
+		uint32_t g = s->mode == prgpu_scene::PERSISTENT && uint64_t(s->n_slots) <= uint64_t(s->ws_pp.max_blocks) * s->pp_slots ? 4u : 0u;
+		if (const char* env = getenv("PRGPU_PIXEL_INTERLEAVE"))
+			g = (uint32_t)std::max(0, atoi(env));
+		const uint32_t n_groups = g ? s->n_slots / g : 0u;
+		if (n_groups > 2) {
+			uint32_t stride = (uint32_t)(n_groups * 0.6180339887) | 1u;
+			auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+			while (gcd(stride, n_groups) != 1)
+				stride += 2;
+			std::vector<uint32_t> out(pixels);
+			for (uint32_t i = 0; i < n_groups; ++i) {
+				const uint32_t src = (uint32_t)((uint64_t(i) * stride) % n_groups);
+				std::copy(pixels.begin() + size_t(src) * g, pixels.begin() + size_t(src + 1) * g, out.begin() + size_t(i) * g);
+			}
+			pixels.swap(out);
+		}
+	}
 	if (!pixels.empty())
 		HIP_TRY(hipMemcpyAsync(s->ps.pixel, pixels.data(), pixels.size() * 4, hipMemcpyHostToDevice, s->stream));
 	HIP_TRY(hipStreamSynchronize(s->stream));
@@ -354,6 +377,10 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		s->pp_occupancy = atoi(env);
 	if (const char* env = getenv("PRGPU_PP_SHADE_PARTIAL"))
 		s->pp_shade_partial = atoi(env);
+	if (const char* env = getenv("PRGPU_PP_SHADER"))
+		s->pp_shader_wave = atoi(env);
+	if (const char* env = getenv("PRGPU_PP_SHADE_HELP"))
+		s->pp_shade_help = atoi(env);
 	if (const char* env = getenv("PRGPU_PP_BOTH"))
 		s->pp_both_below = atoi(env);
 	if (const char* env = getenv("PRGPU_PP_REFILL_MIN"))
@@ -667,7 +694,7 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	ps.pixel		  = s->pp_pixel; // s->ps.pixel is the Morton-ordered list of owned pixels
 	s->time_begin(6, s->stream);
 	prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, iter_begin, iter_end, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act, s->pp_refill_min, s->pp_both_below,
-								s->pp_occupancy,
+								s->pp_occupancy, s->pp_shader_wave, s->pp_shade_help,
 								s->pp_next,
 								s->pp_error,
 								s->gstats, s->stream);

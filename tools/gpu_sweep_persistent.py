@@ -39,5 +39,6 @@ for name in sys.argv[1:]:
     configs.append(c)
 for c in configs:
     r1, e1 = (run(c, 1, True) if not os.environ.get("SWEEP_SKIP_FULL") else (0.0, ""))
-    r8, e8 = run(c, 8, True)
-    print({k[6:]: v for k, v in c.items() if k != "PRGPU_MODE"}, "full %.2f ms/iter%s | 1/8 share %.2f ms/iter%s -> %.2fx" % (r1, e1, r8, e8, r1 / r8), flush=True)
+    world = int(os.environ.get("SWEEP_WORLD", "8"))
+    r8, e8 = run(c, world, True)
+    print({k[6:]: v for k, v in c.items() if k != "PRGPU_MODE"}, "full %.2f ms/iter%s | 1/%d share %.2f ms/iter%s -> %.2fx" % (r1, e1, world, r8, e8, r1 / r8), flush=True)
