@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PRGPU_API_VERSION 2
+#define PRGPU_API_VERSION 3
 #define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
 
 enum {
@@ -87,16 +87,24 @@ typedef struct prgpu_spectrum {
  *             against air n = 1.0002926; a wavelength dependent index (SELLMEIER) collapses the path to its hero wavelength)
  * CONDUCTOR   src/plugins/main/materials/conductor.cpp (smooth metal: delta mirror weighted per wavelength by Fresnel::conductor)
  */
-enum { PRGPU_MAT_LAMBERT = 0, PRGPU_MAT_DIELECTRIC = 1, PRGPU_MAT_CONDUCTOR = 2 };
+enum { PRGPU_MAT_LAMBERT = 0, PRGPU_MAT_DIELECTRIC = 1, PRGPU_MAT_CONDUCTOR = 2,
+       PRGPU_MAT_ROUGH_CONDUCTOR = 3,    /* roughconductor.cpp: GGX microfacet reflection (base/math/MicrofacetReflection.h, RoughDistribution.h,
+                                            Microfacet.h) with the conductor Fresnel term; also `conductor` with a roughness (conductor.cpp:102-106) */
+       PRGPU_MAT_ROUGH_DIELECTRIC = 4 }; /* roughdielectric.cpp: GGX reflection + refraction (MicrofacetTransmission.h), branch chosen by the hero
+                                            wavelength's Fresnel term; also `glass` with a roughness (dielectric.cpp:172-176) */
+enum { PRGPU_MATF_ANISOTROPIC = 1u, /* roughness_y given as its own parameter (the reference compares the NODES, not the values) */
+       PRGPU_MATF_NO_VNDF = 2u };   /* `:vndf false`: sample the plain GGX normal distribution (isotropic only; the anisotropic variant needs atan/tan) */
 typedef struct prgpu_material {
 	uint32_t kind;
-	uint32_t albedo;       /* spectrum index.  LAMBERT: `albedo`; DIELECTRIC, CONDUCTOR: `specularity` (reflection tint, default 1) */
+	uint32_t albedo;       /* spectrum index.  LAMBERT: `albedo`; every other kind: `specularity` (reflection tint, default 1) */
 	uint32_t two_sided;    /* LAMBERT `two_sided`, default true (lambert.cpp:108) */
-	uint32_t ior;          /* DIELECTRIC: `index`/`eta`/`ior` spectrum (default 1.55); CONDUCTOR: `eta` (default 1.2) */
-	uint32_t transmission; /* DIELECTRIC: `transmission` tint spectrum, or PRGPU_INVALID_ID = same as specularity (dielectric.cpp:92-96) */
+	uint32_t ior;          /* (ROUGH_)DIELECTRIC: `index`/`eta`/`ior` spectrum (default 1.55); (ROUGH_)CONDUCTOR: `eta` (default 1.2) */
+	uint32_t transmission; /* (ROUGH_)DIELECTRIC: `transmission` tint spectrum, or PRGPU_INVALID_ID = same as specularity (dielectric.cpp:92-96) */
 	uint32_t thin;         /* DIELECTRIC: `thin` sheet approximation (dielectric.cpp:69-72,98-101) */
-	uint32_t k;            /* CONDUCTOR: `k`/`kappa` absorption index spectrum (default 2.605) */
-	uint32_t reserved;
+	uint32_t k;            /* (ROUGH_)CONDUCTOR: `k`/`kappa` absorption index spectrum (default 2.605) */
+	uint32_t flags;        /* PRGPU_MATF_* (rough kinds) */
+	float roughness_x;     /* rough kinds: `roughness_x` or `roughness` (constant scalar; textures are out of scope) */
+	float roughness_y;     /* rough kinds: `roughness_y`; ignored (= roughness_x) unless PRGPU_MATF_ANISOTROPIC */
 } prgpu_material;
 
 enum { PRGPU_EMS_DIFFUSE = 0 }; /* src/plugins/main/emissions/diffuse.cpp */

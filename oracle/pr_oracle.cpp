@@ -96,6 +96,7 @@ inline Blob operator*(Blob a, Blob b) { return blob4(a[0] * b[0], a[1] * b[1], a
 inline Blob operator*(Blob a, float s) { return blob4(a[0] * s, a[1] * s, a[2] * s, a[3] * s); }
 inline Blob operator/(Blob a, Blob b) { return blob4(a[0] / b[0], a[1] / b[1], a[2] / b[2], a[3] / b[3]); }
 inline Blob operator/(Blob a, float s) { return blob4(a[0] / s, a[1] / s, a[2] / s, a[3] / s); }
+inline Blob operator-(Blob a, Blob b) { return blob4(a[0] - b[0], a[1] - b[1], a[2] - b[2], a[3] - b[3]); }
 inline float bsum(Blob a) { return ((a[0] + a[1]) + a[2]) + a[3]; }
 inline bool all_le(Blob a, float e) { return a[0] <= e && a[1] <= e && a[2] <= e && a[3] <= e; }
 inline bool is_zero(Blob a, float e) // Eigen DenseBase::isZero(prec): all |x| <= prec
@@ -840,6 +841,264 @@ inline float fresnel_conductor(float cosI, float n_in, float n_out, float k)
 	const float para2  = perp2 * (t3 - t4) / (t3 + t4);
 	const float R	   = (para2 + perp2) / 2;
 	return std::min(std::max(R, 0.0f), 1.0f);
+}
+
+// ---- rough (GGX microfacet) materials ----------------------------------------------------------------
+// Eigen's normalized(): the zero vector stays zero ("No need to check if zero. Eigen3 will handle it", Scattering.h:151)
+inline V3 normalized_or_zero(V3 a)
+{
+	const float z = dot(a, a);
+	if (z > 0.0f) {
+		const float n = std::sqrt(z);
+		return v3(a.x / n, a.y / n, a.z / n);
+	}
+	return a;
+}
+// ShadingVector.h:41-73,87-100
+inline float sv_cos2_theta(V3 v) { return v.z * v.z; }
+inline float sv_sin2_theta(V3 v) { return std::max(0.0f, 1 - v.z * v.z); }
+inline float sv_tan2_theta(V3 v) { return std::fabs(v.z) <= PR_EPS ? 0.0f : sv_sin2_theta(v) / sv_cos2_theta(v); }
+inline float sv_cos2_phi(V3 v)
+{
+	const float q = sv_sin2_theta(v);
+	return q <= PR_EPS ? 0.0f : std::min(1.0f, v.x * v.x / q);
+}
+inline float sv_sin2_phi(V3 v)
+{
+	const float q = sv_sin2_theta(v);
+	return q <= PR_EPS ? 0.0f : std::min(1.0f, v.y * v.y / q);
+}
+inline bool sv_same_hemisphere(V3 a, V3 b) { return std::signbit(a.z) == std::signbit(b.z); }
+inline V3 sv_positive(V3 v) { return std::signbit(v.z) ? -v : v; }
+// Microfacet.h:121-160 ndf_ggx (the anisotropic form pairs sin2Phi with roughnessX like the reference)
+inline float ndf_ggx(V3 H, float rx, float ry, bool aniso)
+{
+	const float sin2 = sv_sin2_theta(H), cos2 = sv_cos2_theta(H);
+	if (cos2 <= PR_EPS)
+		return 0.0f;
+	const float tan2 = sin2 / cos2;
+	const float cos4 = cos2 * cos2;
+	if (!aniso) {
+		const float alpha2 = rx * rx;
+		if (alpha2 <= PR_EPS)
+			return 0.0f;
+		const float e	  = tan2 / alpha2;
+		const float denom = alpha2 * cos4 * (1 + e) * (1 + e);
+		return denom <= PR_EPS ? 0.0f : PR_INV_PI_F / denom;
+	}
+	const float ax2 = rx * rx, ay2 = ry * ry;
+	if (ax2 <= PR_EPS || ay2 <= PR_EPS)
+		return 0.0f;
+	const float t	  = sv_sin2_phi(H) / ax2 + sv_cos2_phi(H) / ay2;
+	const float e	  = tan2 * t;
+	const float denom = rx * ry * cos4 * (1 + e) * (1 + e);
+	return denom <= PR_EPS ? 0.0f : PR_INV_PI_F / denom;
+}
+// Microfacet.h:69-89 g_1_smith, :91-106 g_1_smith_lambda
+inline float g1_smith(V3 K, float rx, float ry, bool aniso)
+{
+	const float a	  = aniso ? sv_cos2_phi(K) * rx * rx + sv_sin2_phi(K) * ry * ry : rx * rx;
+	const float b	  = sv_tan2_theta(K);
+	const float denom = 1 + std::sqrt(1 + a * b);
+	return denom <= PR_EPS ? 0.0f : 2.0f / denom;
+}
+inline float g1_smith_lambda(V3 K, float rx, float ry, bool aniso)
+{
+	const float a = aniso ? sv_cos2_phi(K) * rx * rx + sv_sin2_phi(K) * ry * ry : rx * rx;
+	const float b = sv_tan2_theta(K);
+	return (std::sqrt(1 + a * b) - 1) / 2;
+}
+// Microfacet.h:225-228 pdf_ggx, :266-271 pdf_ggx_vndf (always the two-roughness forms)
+inline float pdf_ggx(V3 H, float rx, float ry, bool aniso) { return ndf_ggx(H, rx, ry, aniso) * std::fabs(H.z); }
+inline float pdf_ggx_vndf(V3 V, V3 H, float rx, float ry)
+{
+	return std::fabs(V.z) <= PR_EPS ? 0.0f : g1_smith(V, rx, ry, true) * std::fabs(dot(V, H)) * ndf_ggx(H, rx, ry, true) / std::fabs(V.z);
+}
+// Microfacet.h:235-249 sample_ndf_ggx (isotropic)
+inline V3 sample_ndf_ggx(float u0, float u1, float roughness)
+{
+	const float alpha2	 = roughness * roughness;
+	const float t2		 = alpha2 * u1 / (1 - u1);
+	const float cosTheta = alpha2 <= PR_EPS ? 1.0f : std::max(0.001f, 1.0f / std::sqrt(1 + t2));
+	const float sinTheta = std::sqrt(1 - cosTheta * cosTheta);
+	float sinPhi, cosPhi;
+	sincos_2pi(u0, sinPhi, cosPhi);
+	return v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
+// Microfacet.h:274-331 sample_vndf_ggx (Heitz 2018, the "#if 1" branch)
+inline V3 sample_vndf_ggx(float u0, float u1, V3 nV, float rx, float ry)
+{
+	const V3 Vh		  = normalized_or_zero(v3(rx * nV.x, ry * nV.y, nV.z));
+	const float lensq = sum_prod(Vh.x, Vh.x, Vh.y, Vh.y);
+	V3 T1			  = v3(1, 0, 0);
+	if (lensq > PR_EPS) {
+		const float l = std::sqrt(lensq);
+		T1			  = v3(-Vh.y / l, Vh.x / l, 0.0f / l);
+	}
+	const V3 T2	  = cross(Vh, T1);
+	const float r = std::sqrt(u0);
+	float sphi, cphi;
+	sincos_2pi(u1, sphi, cphi);
+	const float t1 = r * cphi;
+	float t2	   = r * sphi;
+	const float q  = 0.5f * (1.0f + Vh.z);
+	t2			   = (1.0f - q) * std::sqrt(1.0f - t1 * t1) + q * t2;
+	const float c  = std::sqrt(std::max(0.0f, 1.0f + diff_prod(-t1, t1, t2, t2)));
+	const V3 Nh	   = (T1 * t1 + T2 * t2) + Vh * c;
+	return normalized_or_zero(v3(rx * Nh.x, ry * Nh.y, std::max(0.0f, Nh.z)));
+}
+// RoughDistribution.h: GGX distribution with or without visible-normal sampling
+struct RoughDistribution {
+	float m1, m2;
+	bool aniso, vndf;
+	bool is_delta() const { return m1 <= 1e-3f || m2 <= 1e-3f; } // :22-26
+	float G(V3 H, V3 V, V3 L) const								  // :28-52
+	{
+		const bool chi_v = V.z * dot(H, V) > PR_EPS;
+		const bool chi_l = L.z * dot(H, L) > PR_EPS;
+		if (!chi_v || !chi_l)
+			return 0.0f;
+		if (!vndf)
+			return g1_smith(V, m1, m2, aniso) * g1_smith(L, m1, m2, aniso);
+		const float denom = 1 + g1_smith_lambda(V, m1, m2, aniso) + g1_smith_lambda(L, m1, m2, aniso);
+		return denom <= PR_EPS ? 0.0f : 1 / denom;
+	}
+	float D(V3 H) const { return ndf_ggx(H, m1, m2, aniso); } // :54-60
+	float norm(V3 H, V3 V, V3 L) const						   // :64-72
+	{
+		const float denom = std::fabs(V.z);
+		if (denom <= PR_EPS)
+			return 0.0f;
+		return std::fabs(dot(H, L)) / denom;
+	}
+	float dg_norm(V3 H, V3 V, V3 L) const { return D(H) * G(H, V, L) * norm(H, V, L); } // :79-82
+	float pdf(V3 H, V3 V) const															 // :89-103
+	{
+		if (is_delta())
+			return 1.0f;
+		if (vndf)
+			return pdf_ggx_vndf(sv_positive(V), sv_positive(H), m1, m2);
+		return pdf_ggx(H, m1, m2, aniso);
+	}
+	V3 sample(float u0, float u1, V3 V) const // :105-120 (the anisotropic non-VNDF sampler is not built: validate rejects it)
+	{
+		if (is_delta())
+			return v3(0, 0, 1);
+		if (vndf)
+			return sample_vndf_ggx(u0, u1, sv_positive(V), m1, m2);
+		return sample_ndf_ggx(u0, u1, m1);
+	}
+};
+inline bool v3_is_zero(V3 v, float prec) { return std::fabs(v.x) <= prec && std::fabs(v.y) <= prec && std::fabs(v.z) <= prec; } // Eigen isZero(prec)
+// Scattering.h:82-85,116-130,170-183
+inline V3 reflect_about(V3 V, V3 N) { return N * (2 * dot(N, V)) - V; }
+inline V3 refract_about(float eta, V3 wIn, V3 N, bool& total)
+{
+	const float cosI = dot(wIn, N);
+	if (std::signbit(cosI))
+		return -refract_about(1 / eta, -wIn, N, total);
+	const float cosT = refraction_angle(cosI, eta);
+	total			 = cosT < 0.0f;
+	if (total)
+		return reflect_about(wIn, N);
+	return normalized_or_zero(-wIn * eta + N * (eta * cosI - cosT));
+}
+inline float reflective_jacobian(float cosO)
+{
+	const float denom = 4 * std::fabs(cosO);
+	return denom <= PR_EPS ? 0.0f : 1 / denom;
+}
+inline float refractive_jacobian(float eta, float cosI, float cosO)
+{
+	const float denom  = eta * cosI + cosO;
+	const float denom2 = denom * denom;
+	return denom2 <= PR_EPS ? 0.0f : std::fabs(cosO) / denom2;
+}
+// MicrofacetReflection.h
+inline float mf_reflection_eval(const RoughDistribution& d, V3 wIn, V3 wOut, bool conductor, float n_in_or_ior, float n_out_or_kappa) // :31-74
+{
+	if (!sv_same_hemisphere(wIn, wOut))
+		return 0.0f;
+	V3 H = normalized_or_zero(wIn + wOut);
+	if (std::signbit(H.z))
+		H = -H;
+	const float cosI = dot(H, wIn);
+	const float F	 = conductor ? fresnel_conductor(cosI, 1, n_in_or_ior, n_out_or_kappa) : fresnel_dielectric(cosI, n_in_or_ior, n_out_or_kappa);
+	if (d.is_delta())
+		return F;
+	const float jacobian = reflective_jacobian(cosI);
+	return F * d.dg_norm(H, wIn, wOut) * jacobian;
+}
+inline float mf_reflection_pdf(const RoughDistribution& d, V3 wIn, V3 wOut) // :92-105 (H is not flipped here)
+{
+	if (!sv_same_hemisphere(wIn, wOut))
+		return 0.0f;
+	const V3 H = normalized_or_zero(wIn + wOut);
+	if (d.is_delta())
+		return 1.0f;
+	const float cosI	 = dot(H, wIn);
+	const float jacobian = reflective_jacobian(cosI);
+	return jacobian * d.pdf(H, wIn);
+}
+inline V3 mf_reflection_sample(const RoughDistribution& d, float u0, float u1, V3 wIn) // :107-120
+{
+	const V3 H = d.sample(u0, u1, wIn);
+	if (v3_is_zero(H, PR_EPS))
+		return v3(0, 0, 0);
+	const V3 wOut = reflect_about(wIn, H);
+	return sv_same_hemisphere(wIn, wOut) ? wOut : v3(0, 0, 0);
+}
+// MicrofacetTransmission.h (inner = the first index given, outer = the second; the closure passes AIR, IOR)
+inline bool mf_transmission_halfway(V3 wIn, V3 wOut, float inner, float outer, V3& H, float& cosI, float& cosO, float& eta)
+{
+	if (sv_same_hemisphere(wIn, wOut))
+		return false;
+	const bool pos		= !std::signbit(wIn.z);
+	const float in_ior	= pos ? inner : outer;
+	const float out_ior = pos ? outer : inner;
+	H					= -normalized_or_zero(wIn * in_ior + wOut * out_ior);
+	if (std::signbit(H.z))
+		H = -H;
+	cosI = dot(H, wIn);
+	cosO = dot(H, wOut);
+	if (cosI * cosO >= -PR_EPS)
+		return false;
+	eta = in_ior / out_ior;
+	return true;
+}
+inline float mf_transmission_eval(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :34-63, camera paths (spread = 1)
+{
+	V3 H;
+	float cosI, cosO, eta;
+	if (!mf_transmission_halfway(wIn, wOut, inner, outer, H, cosI, cosO, eta))
+		return 0.0f;
+	const float F = fresnel_dielectric(cosI, inner, outer);
+	if (d.is_delta())
+		return 1 - F;
+	const float jacobian = refractive_jacobian(eta, cosI, cosO);
+	const float spread	 = 1.0f;
+	return (1 - F) * d.dg_norm(H, wIn, wOut) * jacobian * spread;
+}
+inline float mf_transmission_pdf(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :93-118
+{
+	V3 H;
+	float cosI, cosO, eta;
+	if (!mf_transmission_halfway(wIn, wOut, inner, outer, H, cosI, cosO, eta))
+		return 0.0f;
+	if (d.is_delta())
+		return 1.0f;
+	const float jacobian = refractive_jacobian(eta, cosI, cosO);
+	return d.pdf(H, wIn) * jacobian;
+}
+inline V3 mf_transmission_sample(const RoughDistribution& d, float u0, float u1, V3 wIn, float inner, float outer) // :120-139
+{
+	const V3 H = d.sample(u0, u1, wIn);
+	if (v3_is_zero(H, PR_EPS))
+		return v3(0, 0, 0);
+	const float eta = inner / outer;
+	bool total;
+	const V3 L = refract_about(eta, wIn, H, total);
+	return total == sv_same_hemisphere(wIn, L) ? L : v3(0, 0, 0);
 }
 // spectral/SpectralRange.h + INode::spectralRange (core/shader/INode.h:48): unbounded = (-1,-1)
 struct Range {
@@ -1637,6 +1896,120 @@ inline float rr_probability(const Scene& s, uint32_t path_length, bool delta = f
 	return path_length < s.rr_prob.size() ? s.rr_prob[path_length] : s.rr_prob.back();
 }
 
+// ---- material evaluation for next event estimation: IMaterial::eval in tangent space ---------------------
+inline RoughDistribution rough_distribution(const prgpu_material& m)
+{
+	const bool aniso = (m.flags & PRGPU_MATF_ANISOTROPIC) != 0; // the reference decides by node identity (roughconductor.cpp:174-177)
+	return RoughDistribution{ m.roughness_x, aniso ? m.roughness_y : m.roughness_x, aniso, (m.flags & PRGPU_MATF_NO_VNDF) == 0 };
+}
+// RoughDielectricClosure::eval / ::pdf (roughdielectric.cpp:73-122); inner = AIR, outer = the material's index
+inline Blob rough_dielectric_eval(const RoughDistribution& d, V3 V, V3 L, const Blob& spec, const Blob& trans, const Blob& ior)
+{
+	Blob w;
+	if (sv_same_hemisphere(V, L)) {
+		for (int i = 0; i < 4; ++i)
+			w[i] = mf_reflection_eval(d, V, L, false, DIELECTRIC_AIR, ior[i]);
+		return w * spec;
+	}
+	for (int i = 0; i < 4; ++i)
+		w[i] = mf_transmission_eval(d, V, L, DIELECTRIC_AIR, ior[i]);
+	return w * trans;
+}
+inline Blob rough_dielectric_pdf(const RoughDistribution& d, V3 V, V3 L, const Blob& ior)
+{
+	Blob F, p;
+	for (int i = 0; i < 4; ++i)
+		F[i] = fresnel_dielectric(V.z, DIELECTRIC_AIR, ior[i]);
+	if (sv_same_hemisphere(V, L)) {
+		for (int i = 0; i < 4; ++i)
+			p[i] = mf_reflection_pdf(d, L, V);
+		return F * p;
+	}
+	for (int i = 0; i < 4; ++i)
+		p[i] = mf_transmission_pdf(d, V, L, DIELECTRIC_AIR, ior[i]);
+	return (blob(1) - F) * p;
+}
+// LambertMaterial::eval (lambert.cpp:33-42), RoughConductorMaterial::eval (roughconductor.cpp:41-65),
+// RoughDielectricMaterial::eval (roughdielectric.cpp:184-205).  `delta`: MaterialSampleFlag::DeltaDistribution
+inline void material_eval(const Scene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
+{
+	delta = false;
+	if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC) {
+		const RoughDistribution d = rough_distribution(mat);
+		if (d.is_delta()) {
+			delta  = true;
+			weight = blob(0);
+			pdf	   = blob(0);
+			return;
+		}
+		if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR) {
+			const Blob eta = spectrum_eval(s, mat.ior, wl), kk = spectrum_eval(s, mat.k, wl);
+			Blob factor;
+			for (int i = 0; i < 4; ++i)
+				factor[i] = mf_reflection_eval(d, Lt, Vt, true, eta[i], kk[i]);
+			weight = spectrum_eval(s, mat.albedo, wl) * factor;
+			pdf	   = blob(mf_reflection_pdf(d, Lt, Vt));
+		} else {
+			const Blob spec	 = spectrum_eval(s, mat.albedo, wl);
+			const Blob trans = mat.transmission != INVALID ? spectrum_eval(s, mat.transmission, wl) : spec;
+			const Blob ior	 = spectrum_eval(s, mat.ior, wl);
+			weight			 = rough_dielectric_eval(d, Vt, Lt, spec, trans, ior);
+			pdf				 = rough_dielectric_pdf(d, Vt, Lt, ior);
+		}
+		return;
+	}
+	const bool same = std::signbit(Vt.z) == std::signbit(Lt.z);
+	const float dt	= same ? (mat.two_sided ? std::fabs(Lt.z) : std::max(0.0f, Lt.z)) : 0.0f;
+	weight			= (spectrum_eval(s, mat.albedo, wl) * dt) * PR_INV_PI_F;
+	pdf				= blob(dt * PR_INV_PI_F);
+}
+// RoughConductorMaterial::sample (roughconductor.cpp:83-117), RoughDielectricMaterial::sample (roughdielectric.cpp:222-254)
+inline void rough_sample(const Scene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, Rng& rnd, V3& Lt, Blob& integral_weight, Blob& pdf_s, bool& delta,
+						 bool& hero_collapsing)
+{
+	const RoughDistribution d = rough_distribution(mat);
+	delta					  = d.is_delta();
+	if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR) {
+		const float u0 = rng_float(rnd), u1 = rng_float(rnd);
+		Lt				= mf_reflection_sample(d, u0, u1, Vt);
+		hero_collapsing = delta && (spectrum_is_varying(s, mat.ior) || spectrum_is_varying(s, mat.k));
+		if (!sv_same_hemisphere(Vt, Lt)) { // MaterialSampleOutput::Reject
+			Lt				= v3(0, 0, 0);
+			integral_weight = blob(0);
+			pdf_s			= blob(0);
+			return;
+		}
+		const Blob eta = spectrum_eval(s, mat.ior, wl), kk = spectrum_eval(s, mat.k, wl);
+		Blob factor;
+		for (int i = 0; i < 4; ++i)
+			factor[i] = mf_reflection_eval(d, Lt, Vt, true, eta[i], kk[i]);
+		integral_weight = spectrum_eval(s, mat.albedo, wl) * factor;
+		pdf_s			= blob(mf_reflection_pdf(d, Lt, Vt));
+	} else {
+		const Blob spec	 = spectrum_eval(s, mat.albedo, wl);
+		const Blob trans = mat.transmission != INVALID ? spectrum_eval(s, mat.transmission, wl) : spec;
+		const Blob ior	 = spectrum_eval(s, mat.ior, wl);
+		hero_collapsing	 = delta && spectrum_is_varying(s, mat.ior);
+		// RoughDielectricClosure::sample (roughdielectric.cpp:124-137): branch on the hero wavelength's Fresnel term
+		const float F  = fresnel_dielectric(Vt.z, DIELECTRIC_AIR, ior[0]);
+		const float ub = rng_float(rnd);
+		const float u0 = rng_float(rnd), u1 = rng_float(rnd);
+		Lt = ub <= F ? mf_reflection_sample(d, u0, u1, Vt) : mf_transmission_sample(d, u0, u1, Vt, DIELECTRIC_AIR, ior[0]);
+		if (v3_is_zero(Lt, 1e-5f)) { // Eigen isZero() with the default precision
+			Lt				= v3(0, 0, 0);
+			integral_weight = blob(0);
+			pdf_s			= blob(0);
+			return;
+		}
+		integral_weight = rough_dielectric_eval(d, Vt, Lt, spec, trans, ior);
+		pdf_s			= rough_dielectric_pdf(d, Vt, Lt, ior);
+	}
+	if (pdf_s[0] > PR_EPS)
+		integral_weight = integral_weight / pdf_s[0];
+	if (delta)
+		pdf_s = blob(1);
+}
+
 // one camera sample: RenderTile::constructCameraRay (RenderTile.cpp:71-132) then the path
 // (direct.cpp:73-464, vcm/Walker.h:23-54)
 void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
@@ -1859,7 +2232,8 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		// tangent-space view vector: MaterialSampleContext::fromIP (MaterialContext.h:27-44)
 		const V3 Vt = to_tangent_space(N, gp.Nx, gp.Ny, -ray.d);
 
-		const bool deltaMat = mat.kind != PRGPU_MAT_LAMBERT; // IMaterial::hasOnlyDeltaDistribution (dielectric, conductor)
+		const bool deltaMat = mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR; // IMaterial::hasOnlyDeltaDistribution
+		const bool roughMat = mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC;
 
 		if (cfg.nee && !deltaMat && !hasEmission && !s.light_intensity.empty()) { // direct.cpp:100-101
 			// ---- handleNEE (direct.cpp:233-352)
@@ -1893,15 +2267,16 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 					const float cosL = 1.0f; // out.CosLight = 1
 					if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
 						break;
-					// material evaluation (Lambert)
-					const V3 Lt		= to_tangent_space(N, gp.Nx, gp.Ny, L);
-					const bool same = std::signbit(Vt.z) == std::signbit(Lt.z);
-					const float dt	= same ? (mat.two_sided ? std::fabs(Lt.z) : std::max(0.0f, Lt.z)) : 0.0f;
-					const Blob weight	   = (spectrum_eval(s, mat.albedo, ray.wl) * dt) * PR_INV_PI_F;
-					const float bsdf_pdf   = dt * PR_INV_PI_F;
+					// material evaluation (direct.cpp:262-270); a delta closure ends the connection
+					const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
+					Blob weight, bsdf_pdf;
+					bool evalDelta;
+					material_eval(s, mat, ray.wl, Vt, Lt, weight, bsdf_pdf, evalDelta);
+					if (evalDelta)
+						break;
 					const Blob rayHero	   = ray.mono ? hero_only() : blob(1);
 					const Blob hf		   = ray.mono ? hero_only() : blob(1);
-					const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+					const Blob bsdfWvlPdfS = bsdf_pdf * hf;
 					if (all_le(bsdfWvlPdfS, PDF_EPS))
 						break;
 					const Blob connectionW = radiance * weight;
@@ -1977,16 +2352,17 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				const float cosL	 = std::fabs(cosLight);
 				if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
 					break;
-				// LambertMaterial::eval (lambert.cpp:33-42)
-				const V3 Lt		= to_tangent_space(N, gp.Nx, gp.Ny, L);
-				const bool same = std::signbit(Vt.z) == std::signbit(Lt.z);
-				const float dt	= same ? (mat.two_sided ? std::fabs(Lt.z) : std::max(0.0f, Lt.z)) : 0.0f;
-				const Blob weight = (spectrum_eval(s, mat.albedo, ray.wl) * dt) * PR_INV_PI_F;
-				const float bsdf_pdf = dt * PR_INV_PI_F;
+				// IMaterial::eval (direct.cpp:262-270); a delta closure ends the connection
+				const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
+				Blob weight, bsdf_pdf;
+				bool evalDelta;
+				material_eval(s, mat, ray.wl, Vt, Lt, weight, bsdf_pdf, evalDelta);
+				if (evalDelta)
+					break;
 				const bool rayMono	 = ray.mono;
 				const Blob rayHero	 = rayMono ? hero_only() : blob(1);
 				const Blob hf		 = rayMono ? hero_only() : blob(1);
-				const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+				const Blob bsdfWvlPdfS = bsdf_pdf * hf;
 				if (all_le(bsdfWvlPdfS, PDF_EPS))
 					break;
 				const Blob connectionW = radiance * weight;
@@ -2041,7 +2417,10 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		V3 Lt;
 		Blob integral_weight, pdf_s;
 		bool heroCollapsing = false;
-		if (mat.kind == PRGPU_MAT_CONDUCTOR) {
+		bool sampleDelta	= deltaMat;
+		if (roughMat) {
+			rough_sample(s, mat, ray.wl, Vt, rnd, Lt, integral_weight, pdf_s, sampleDelta, heroCollapsing);
+		} else if (mat.kind == PRGPU_MAT_CONDUCTOR) {
 			// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
 			pdf_s		   = blob(1);
 			const Blob eta = spectrum_eval(s, mat.ior, ray.wl), kk = spectrum_eval(s, mat.k, ray.wl);
@@ -2086,7 +2465,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				Lt = -Lt;
 		}
 		const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt)); // MaterialSampleOutput::globalL
-		cur.last_delta	  = deltaMat;
+		cur.last_delta	  = sampleDelta;
 		cur.prev_path_pdf = cur.path_pdf;
 		cur.path_pdf	  = cur.path_pdf * (pdf_s * scatProb);
 		if (all_le(cur.path_pdf, PDF_EPS))
@@ -2286,12 +2665,18 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("spectrum table out of range");
 	}
 	for (const auto& m : s.materials) {
-		if (m.kind > PRGPU_MAT_CONDUCTOR || m.albedo >= d->n_spectra)
+		if (m.kind > PRGPU_MAT_ROUGH_DIELECTRIC || m.albedo >= d->n_spectra)
 			return fail("bad material");
-		if (m.kind == PRGPU_MAT_CONDUCTOR && (m.ior >= d->n_spectra || m.k >= d->n_spectra))
+		if ((m.kind == PRGPU_MAT_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_CONDUCTOR) && (m.ior >= d->n_spectra || m.k >= d->n_spectra))
 			return fail("bad conductor material");
-		if (m.kind == PRGPU_MAT_DIELECTRIC && (m.ior >= d->n_spectra || (m.transmission != INVALID && m.transmission >= d->n_spectra)))
+		if ((m.kind == PRGPU_MAT_DIELECTRIC || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC) && (m.ior >= d->n_spectra || (m.transmission != INVALID && m.transmission >= d->n_spectra)))
 			return fail("bad dielectric material");
+		if (m.kind == PRGPU_MAT_ROUGH_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC) {
+			if (!(m.roughness_x >= 0.0f) || !((m.flags & PRGPU_MATF_ANISOTROPIC) == 0 || m.roughness_y >= 0.0f) || !std::isfinite(m.roughness_x) || !std::isfinite(m.roughness_y))
+				return fail("bad roughness");
+			if ((m.flags & PRGPU_MATF_ANISOTROPIC) && (m.flags & PRGPU_MATF_NO_VNDF))
+				return fail("anisotropic roughness without vndf sampling is not supported");
+		}
 	}
 	for (const auto& e : s.emissions)
 		if (e.kind != PRGPU_EMS_DIFFUSE || e.radiance >= d->n_spectra)
@@ -2753,6 +3138,62 @@ void orc_lambert_sample(orc_scene* h, uint32_t material, const float wvl[4], con
 	if (std::signbit(v[2]) != std::signbit(L.z))
 		L = -L;
 	l[0] = L.x; l[1] = L.y; l[2] = L.z;
+}
+
+// ---- rough material KAT exports (tests/microfacets.cpp, tests/materials.cpp of the reference) --------------------------
+float orc_ndf_ggx(const float h[3], float rx, float ry, int aniso) { return ndf_ggx(v3(h[0], h[1], h[2]), rx, ry, aniso != 0); }
+float orc_pdf_ggx(const float h[3], float rx, float ry, int aniso) { return pdf_ggx(v3(h[0], h[1], h[2]), rx, ry, aniso != 0); }
+// MicrofacetReflection<aniso, vndf>(m1, m2): 0 = eval() without Fresnel (F = 1 through a perfect conductor is not available, so the
+// dielectric form with equal indices is NOT used; the plain eval is restated here), 1 = evalConductor, 2 = pdf
+float orc_mf_reflection(int what, float m1, float m2, int aniso, int vndf, const float a[3], const float b[3], float ior, float kappa)
+{
+	const RoughDistribution d{ m1, m2, aniso != 0, vndf != 0 };
+	const V3 wIn = v3(a[0], a[1], a[2]), wOut = v3(b[0], b[1], b[2]);
+	if (what == 1)
+		return mf_reflection_eval(d, wIn, wOut, true, ior, kappa);
+	if (what == 2)
+		return mf_reflection_pdf(d, wIn, wOut);
+	// MicrofacetReflection::eval (MicrofacetReflection.h:76-90)
+	if (!sv_same_hemisphere(wIn, wOut))
+		return 0.0f;
+	const V3 H = normalized_or_zero(wIn + wOut);
+	if (d.is_delta())
+		return 1.0f;
+	const float cosI = dot(H, wIn);
+	return d.dg_norm(H, wIn, wOut) * reflective_jacobian(cosI);
+}
+void orc_reflect(const float v[3], float out[3]) // Scattering::reflect(V) in shading space (Scattering.h:69-72)
+{
+	out[0] = -v[0]; out[1] = -v[1]; out[2] = v[2];
+}
+// IMaterial::eval / ::sample in tangent space for any material kind; `rng` is the pixel's generator state (in/out)
+void orc_material_eval(orc_scene* h, uint32_t material, const float wvl[4], const float v[3], const float l[3], float weight[4], float pdf[4], int* delta)
+{
+	Blob w, p;
+	bool dl;
+	material_eval(h->s, h->s.materials[material], blob4(wvl[0], wvl[1], wvl[2], wvl[3]), v3(v[0], v[1], v[2]), v3(l[0], l[1], l[2]), w, p, dl);
+	for (int k = 0; k < 4; ++k) {
+		weight[k] = w[k];
+		pdf[k]	  = p[k];
+	}
+	*delta = dl ? 1 : 0;
+}
+void orc_rough_sample(orc_scene* h, uint32_t material, const float wvl[4], const float v[3], uint64_t* rng, float l[3], float iw[4], float pdf[4], int* delta,
+					  int* hero_collapsing)
+{
+	Rng r{ *rng };
+	V3 L;
+	Blob w, p;
+	bool dl, hc;
+	rough_sample(h->s, h->s.materials[material], blob4(wvl[0], wvl[1], wvl[2], wvl[3]), v3(v[0], v[1], v[2]), r, L, w, p, dl, hc);
+	*rng = r.s;
+	l[0] = L.x; l[1] = L.y; l[2] = L.z;
+	for (int k = 0; k < 4; ++k) {
+		iw[k]  = w[k];
+		pdf[k] = p[k];
+	}
+	*delta			 = dl ? 1 : 0;
+	*hero_collapsing = hc ? 1 : 0;
 }
 
 } // extern "C"

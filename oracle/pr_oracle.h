@@ -94,6 +94,18 @@ void     orc_lambert_eval(orc_scene* s, uint32_t material, const float wvl[4], c
 void     orc_lambert_sample(orc_scene* s, uint32_t material, const float wvl[4], const float v[3], float u1, float u2,
                             float l[3], float integral_weight[4], float pdf[4]);
 
+/* GGX microfacet closures (base/math/Microfacet.h, RoughDistribution.h, MicrofacetReflection.h) and the rough materials built on
+ * them (roughconductor.cpp, roughdielectric.cpp); KATs of the reference's tests/microfacets.cpp and tests/materials.cpp. */
+float    orc_ndf_ggx(const float h[3], float rx, float ry, int aniso);
+float    orc_pdf_ggx(const float h[3], float rx, float ry, int aniso);
+float    orc_mf_reflection(int what /*0 eval, 1 evalConductor, 2 pdf*/, float m1, float m2, int aniso, int vndf, const float w_in[3],
+                           const float w_out[3], float ior, float kappa);
+void     orc_reflect(const float v[3], float out[3]);
+void     orc_material_eval(orc_scene* s, uint32_t material, const float wvl[4], const float v[3], const float l[3], float weight[4],
+                           float pdf[4], int* delta);
+void     orc_rough_sample(orc_scene* s, uint32_t material, const float wvl[4], const float v[3], uint64_t* rng, float l[3],
+                          float integral_weight[4], float pdf[4], int* delta, int* hero_collapsing);
+
 #ifdef __cplusplus
 }
 #endif

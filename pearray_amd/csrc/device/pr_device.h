@@ -175,6 +175,7 @@ __device__ __forceinline__ Blob operator*(Blob a, Blob b) { return blob4(a.v[0] 
 __device__ __forceinline__ Blob operator*(Blob a, float s) { return blob4(a.v[0] * s, a.v[1] * s, a.v[2] * s, a.v[3] * s); }
 __device__ __forceinline__ Blob operator/(Blob a, Blob b) { return blob4(a.v[0] / b.v[0], a.v[1] / b.v[1], a.v[2] / b.v[2], a.v[3] / b.v[3]); }
 __device__ __forceinline__ Blob operator/(Blob a, float s) { return blob4(a.v[0] / s, a.v[1] / s, a.v[2] / s, a.v[3] / s); }
+__device__ __forceinline__ Blob operator-(Blob a, Blob b) { return blob4(a.v[0] - b.v[0], a.v[1] - b.v[1], a.v[2] - b.v[2], a.v[3] - b.v[3]); }
 __device__ __forceinline__ float bsum(Blob a) { return ((a.v[0] + a.v[1]) + a.v[2]) + a.v[3]; }
 __device__ __forceinline__ bool all_le(Blob a, float e) { return a.v[0] <= e && a.v[1] <= e && a.v[2] <= e && a.v[3] <= e; }
 __device__ __forceinline__ bool is_zero(Blob a, float e)
@@ -571,6 +572,267 @@ __device__ __forceinline__ float fresnel_conductor(float cosI, float n_in, float
 	const float para2  = perp2 * (t3 - t4) / (t3 + t4);
 	const float R	   = (para2 + perp2) / 2;
 	return fminf(fmaxf(R, 0.0f), 1.0f);
+}
+
+// ---- rough (GGX microfacet) materials ----------------------------------------------------------------
+// Eigen's normalized(): the zero vector stays zero ("No need to check if zero. Eigen3 will handle it", Scattering.h:151)
+__device__ __forceinline__ V3 normalized_or_zero(V3 a)
+{
+	const float z = dot(a, a);
+	if (z > 0.0f) {
+		const float n = sqrtf(z);
+		return v3(a.x / n, a.y / n, a.z / n);
+	}
+	return a;
+}
+// ShadingVector.h:41-73,87-100
+__device__ __forceinline__ float sv_cos2_theta(V3 v) { return v.z * v.z; }
+__device__ __forceinline__ float sv_sin2_theta(V3 v) { return fmaxf(0.0f, 1 - v.z * v.z); }
+__device__ __forceinline__ float sv_tan2_theta(V3 v) { return fabsf(v.z) <= PR_EPS ? 0.0f : sv_sin2_theta(v) / sv_cos2_theta(v); }
+__device__ __forceinline__ float sv_cos2_phi(V3 v)
+{
+	const float q = sv_sin2_theta(v);
+	return q <= PR_EPS ? 0.0f : fminf(1.0f, v.x * v.x / q);
+}
+__device__ __forceinline__ float sv_sin2_phi(V3 v)
+{
+	const float q = sv_sin2_theta(v);
+	return q <= PR_EPS ? 0.0f : fminf(1.0f, v.y * v.y / q);
+}
+__device__ __forceinline__ bool sv_same_hemisphere(V3 a, V3 b) { return signbit(a.z) == signbit(b.z); }
+__device__ __forceinline__ V3 sv_positive(V3 v) { return signbit(v.z) ? -v : v; }
+// Microfacet.h:121-160 ndf_ggx (the anisotropic form pairs sin2Phi with roughnessX like the reference)
+__device__ __forceinline__ float ndf_ggx(V3 H, float rx, float ry, bool aniso)
+{
+	const float sin2 = sv_sin2_theta(H), cos2 = sv_cos2_theta(H);
+	if (cos2 <= PR_EPS)
+		return 0.0f;
+	const float tan2 = sin2 / cos2;
+	const float cos4 = cos2 * cos2;
+	if (!aniso) {
+		const float alpha2 = rx * rx;
+		if (alpha2 <= PR_EPS)
+			return 0.0f;
+		const float e	  = tan2 / alpha2;
+		const float denom = alpha2 * cos4 * (1 + e) * (1 + e);
+		return denom <= PR_EPS ? 0.0f : PR_INV_PI_F / denom;
+	}
+	const float ax2 = rx * rx, ay2 = ry * ry;
+	if (ax2 <= PR_EPS || ay2 <= PR_EPS)
+		return 0.0f;
+	const float t	  = sv_sin2_phi(H) / ax2 + sv_cos2_phi(H) / ay2;
+	const float e	  = tan2 * t;
+	const float denom = rx * ry * cos4 * (1 + e) * (1 + e);
+	return denom <= PR_EPS ? 0.0f : PR_INV_PI_F / denom;
+}
+// Microfacet.h:69-89 g_1_smith, :91-106 g_1_smith_lambda
+__device__ __forceinline__ float g1_smith(V3 K, float rx, float ry, bool aniso)
+{
+	const float a	  = aniso ? sv_cos2_phi(K) * rx * rx + sv_sin2_phi(K) * ry * ry : rx * rx;
+	const float b	  = sv_tan2_theta(K);
+	const float denom = 1 + sqrtf(1 + a * b);
+	return denom <= PR_EPS ? 0.0f : 2.0f / denom;
+}
+__device__ __forceinline__ float g1_smith_lambda(V3 K, float rx, float ry, bool aniso)
+{
+	const float a = aniso ? sv_cos2_phi(K) * rx * rx + sv_sin2_phi(K) * ry * ry : rx * rx;
+	const float b = sv_tan2_theta(K);
+	return (sqrtf(1 + a * b) - 1) / 2;
+}
+// Microfacet.h:225-228 pdf_ggx, :266-271 pdf_ggx_vndf (always the two-roughness forms)
+__device__ __forceinline__ float pdf_ggx(V3 H, float rx, float ry, bool aniso) { return ndf_ggx(H, rx, ry, aniso) * fabsf(H.z); }
+__device__ __forceinline__ float pdf_ggx_vndf(V3 V, V3 H, float rx, float ry)
+{
+	return fabsf(V.z) <= PR_EPS ? 0.0f : g1_smith(V, rx, ry, true) * fabsf(dot(V, H)) * ndf_ggx(H, rx, ry, true) / fabsf(V.z);
+}
+// Microfacet.h:235-249 sample_ndf_ggx (isotropic)
+__device__ __forceinline__ V3 sample_ndf_ggx(float u0, float u1, float roughness)
+{
+	const float alpha2	 = roughness * roughness;
+	const float t2		 = alpha2 * u1 / (1 - u1);
+	const float cosTheta = alpha2 <= PR_EPS ? 1.0f : fmaxf(0.001f, 1.0f / sqrtf(1 + t2));
+	const float sinTheta = sqrtf(1 - cosTheta * cosTheta);
+	float sinPhi, cosPhi;
+	pr_sincos_2pi(u0, sinPhi, cosPhi);
+	return v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
+// Microfacet.h:274-331 sample_vndf_ggx (Heitz 2018, the "#if 1" branch)
+__device__ __forceinline__ V3 sample_vndf_ggx(float u0, float u1, V3 nV, float rx, float ry)
+{
+	const V3 Vh		  = normalized_or_zero(v3(rx * nV.x, ry * nV.y, nV.z));
+	const float lensq = sum_prod(Vh.x, Vh.x, Vh.y, Vh.y);
+	V3 T1			  = v3(1, 0, 0);
+	if (lensq > PR_EPS) {
+		const float l = sqrtf(lensq);
+		T1			  = v3(-Vh.y / l, Vh.x / l, 0.0f / l);
+	}
+	const V3 T2	  = cross(Vh, T1);
+	const float r = sqrtf(u0);
+	float sphi, cphi;
+	pr_sincos_2pi(u1, sphi, cphi);
+	const float t1 = r * cphi;
+	float t2	   = r * sphi;
+	const float q  = 0.5f * (1.0f + Vh.z);
+	t2			   = (1.0f - q) * sqrtf(1.0f - t1 * t1) + q * t2;
+	const float c  = sqrtf(fmaxf(0.0f, 1.0f + diff_prod(-t1, t1, t2, t2)));
+	const V3 Nh	   = (T1 * t1 + T2 * t2) + Vh * c;
+	return normalized_or_zero(v3(rx * Nh.x, ry * Nh.y, fmaxf(0.0f, Nh.z)));
+}
+// RoughDistribution.h: GGX distribution with or without visible-normal sampling
+struct RoughDistribution {
+	float m1, m2;
+	bool aniso, vndf;
+	__device__ __forceinline__ bool is_delta() const { return m1 <= 1e-3f || m2 <= 1e-3f; } // :22-26
+	__device__ __forceinline__ float G(V3 H, V3 V, V3 L) const								  // :28-52
+	{
+		const bool chi_v = V.z * dot(H, V) > PR_EPS;
+		const bool chi_l = L.z * dot(H, L) > PR_EPS;
+		if (!chi_v || !chi_l)
+			return 0.0f;
+		if (!vndf)
+			return g1_smith(V, m1, m2, aniso) * g1_smith(L, m1, m2, aniso);
+		const float denom = 1 + g1_smith_lambda(V, m1, m2, aniso) + g1_smith_lambda(L, m1, m2, aniso);
+		return denom <= PR_EPS ? 0.0f : 1 / denom;
+	}
+	__device__ __forceinline__ float D(V3 H) const { return ndf_ggx(H, m1, m2, aniso); } // :54-60
+	__device__ __forceinline__ float norm(V3 H, V3 V, V3 L) const						   // :64-72
+	{
+		const float denom = fabsf(V.z);
+		if (denom <= PR_EPS)
+			return 0.0f;
+		return fabsf(dot(H, L)) / denom;
+	}
+	__device__ __forceinline__ float dg_norm(V3 H, V3 V, V3 L) const { return D(H) * G(H, V, L) * norm(H, V, L); } // :79-82
+	__device__ __forceinline__ float pdf(V3 H, V3 V) const															 // :89-103
+	{
+		if (is_delta())
+			return 1.0f;
+		if (vndf)
+			return pdf_ggx_vndf(sv_positive(V), sv_positive(H), m1, m2);
+		return pdf_ggx(H, m1, m2, aniso);
+	}
+	__device__ __forceinline__ V3 sample(float u0, float u1, V3 V) const // :105-120 (the anisotropic non-VNDF sampler is not built: validate rejects it)
+	{
+		if (is_delta())
+			return v3(0, 0, 1);
+		if (vndf)
+			return sample_vndf_ggx(u0, u1, sv_positive(V), m1, m2);
+		return sample_ndf_ggx(u0, u1, m1);
+	}
+};
+__device__ __forceinline__ bool v3_is_zero(V3 v, float prec) { return fabsf(v.x) <= prec && fabsf(v.y) <= prec && fabsf(v.z) <= prec; } // Eigen isZero(prec)
+// Scattering.h:82-85,116-130,170-183
+__device__ __forceinline__ V3 reflect_about(V3 V, V3 N) { return N * (2 * dot(N, V)) - V; }
+__device__ __forceinline__ V3 refract_about(float eta, V3 wIn, V3 N, bool& total)
+{
+	float cosI	   = dot(wIn, N);
+	const bool neg = signbit(cosI); // negative hemisphere: the mirrored problem, result negated (the reference recurses once)
+	if (neg) {
+		eta	 = 1 / eta;
+		wIn	 = -wIn;
+		cosI = dot(wIn, N);
+	}
+	const float cosT = refraction_angle(cosI, eta);
+	total			 = cosT < 0.0f;
+	const V3 r		 = total ? reflect_about(wIn, N) : normalized_or_zero(-wIn * eta + N * (eta * cosI - cosT));
+	return neg ? -r : r;
+}
+__device__ __forceinline__ float reflective_jacobian(float cosO)
+{
+	const float denom = 4 * fabsf(cosO);
+	return denom <= PR_EPS ? 0.0f : 1 / denom;
+}
+__device__ __forceinline__ float refractive_jacobian(float eta, float cosI, float cosO)
+{
+	const float denom  = eta * cosI + cosO;
+	const float denom2 = denom * denom;
+	return denom2 <= PR_EPS ? 0.0f : fabsf(cosO) / denom2;
+}
+// MicrofacetReflection.h
+__device__ __forceinline__ float mf_reflection_eval(const RoughDistribution& d, V3 wIn, V3 wOut, bool conductor, float n_in_or_ior, float n_out_or_kappa) // :31-74
+{
+	if (!sv_same_hemisphere(wIn, wOut))
+		return 0.0f;
+	V3 H = normalized_or_zero(wIn + wOut);
+	if (signbit(H.z))
+		H = -H;
+	const float cosI = dot(H, wIn);
+	const float F	 = conductor ? fresnel_conductor(cosI, 1, n_in_or_ior, n_out_or_kappa) : fresnel_dielectric(cosI, n_in_or_ior, n_out_or_kappa);
+	if (d.is_delta())
+		return F;
+	const float jacobian = reflective_jacobian(cosI);
+	return F * d.dg_norm(H, wIn, wOut) * jacobian;
+}
+__device__ __forceinline__ float mf_reflection_pdf(const RoughDistribution& d, V3 wIn, V3 wOut) // :92-105 (H is not flipped here)
+{
+	if (!sv_same_hemisphere(wIn, wOut))
+		return 0.0f;
+	const V3 H = normalized_or_zero(wIn + wOut);
+	if (d.is_delta())
+		return 1.0f;
+	const float cosI	 = dot(H, wIn);
+	const float jacobian = reflective_jacobian(cosI);
+	return jacobian * d.pdf(H, wIn);
+}
+__device__ __forceinline__ V3 mf_reflection_sample(const RoughDistribution& d, float u0, float u1, V3 wIn) // :107-120
+{
+	const V3 H = d.sample(u0, u1, wIn);
+	if (v3_is_zero(H, PR_EPS))
+		return v3(0, 0, 0);
+	const V3 wOut = reflect_about(wIn, H);
+	return sv_same_hemisphere(wIn, wOut) ? wOut : v3(0, 0, 0);
+}
+// MicrofacetTransmission.h (inner = the first index given, outer = the second; the closure passes AIR, IOR)
+__device__ __forceinline__ bool mf_transmission_halfway(V3 wIn, V3 wOut, float inner, float outer, V3& H, float& cosI, float& cosO, float& eta)
+{
+	if (sv_same_hemisphere(wIn, wOut))
+		return false;
+	const bool pos		= !signbit(wIn.z);
+	const float in_ior	= pos ? inner : outer;
+	const float out_ior = pos ? outer : inner;
+	H					= -normalized_or_zero(wIn * in_ior + wOut * out_ior);
+	if (signbit(H.z))
+		H = -H;
+	cosI = dot(H, wIn);
+	cosO = dot(H, wOut);
+	if (cosI * cosO >= -PR_EPS)
+		return false;
+	eta = in_ior / out_ior;
+	return true;
+}
+__device__ __forceinline__ float mf_transmission_eval(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :34-63, camera paths (spread = 1)
+{
+	V3 H;
+	float cosI, cosO, eta;
+	if (!mf_transmission_halfway(wIn, wOut, inner, outer, H, cosI, cosO, eta))
+		return 0.0f;
+	const float F = fresnel_dielectric(cosI, inner, outer);
+	if (d.is_delta())
+		return 1 - F;
+	const float jacobian = refractive_jacobian(eta, cosI, cosO);
+	const float spread	 = 1.0f;
+	return (1 - F) * d.dg_norm(H, wIn, wOut) * jacobian * spread;
+}
+__device__ __forceinline__ float mf_transmission_pdf(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :93-118
+{
+	V3 H;
+	float cosI, cosO, eta;
+	if (!mf_transmission_halfway(wIn, wOut, inner, outer, H, cosI, cosO, eta))
+		return 0.0f;
+	if (d.is_delta())
+		return 1.0f;
+	const float jacobian = refractive_jacobian(eta, cosI, cosO);
+	return d.pdf(H, wIn) * jacobian;
+}
+__device__ __forceinline__ V3 mf_transmission_sample(const RoughDistribution& d, float u0, float u1, V3 wIn, float inner, float outer) // :120-139
+{
+	const V3 H = d.sample(u0, u1, wIn);
+	if (v3_is_zero(H, PR_EPS))
+		return v3(0, 0, 0);
+	const float eta = inner / outer;
+	bool total;
+	const V3 L = refract_about(eta, wIn, H, total);
+	return total == sv_same_hemisphere(wIn, L) ? L : v3(0, 0, 0);
 }
 
 // same acceptance rule for a box entry distance that was computed earlier (stack entries, re-checks)

@@ -743,6 +743,126 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 // FULL = false is the lean variant for scenes with Lambert materials, mesh entities and area lights only (DevScene::features == 0,
 // e.g. the C4 benchmark scene): delta materials, infinite lights and plane entities are compiled out, which keeps their registers
 // and spills out of the hot kernel.
+// ---- material evaluation for next event estimation: IMaterial::eval in tangent space ---------------------
+__device__ __forceinline__ RoughDistribution rough_distribution(const prgpu_material& m)
+{
+	const bool aniso = (m.flags & PRGPU_MATF_ANISOTROPIC) != 0; // the reference decides by node identity (roughconductor.cpp:174-177)
+	return RoughDistribution{ m.roughness_x, aniso ? m.roughness_y : m.roughness_x, aniso, (m.flags & PRGPU_MATF_NO_VNDF) == 0 };
+}
+// RoughDielectricClosure::eval / ::pdf (roughdielectric.cpp:73-122); inner = AIR, outer = the material's index
+__device__ __forceinline__ Blob rough_dielectric_eval(const RoughDistribution& d, V3 V, V3 L, const Blob& spec, const Blob& trans, const Blob& ior)
+{
+	Blob w;
+	if (sv_same_hemisphere(V, L)) {
+		for (int i = 0; i < 4; ++i)
+			w.v[i] = mf_reflection_eval(d, V, L, false, DIELECTRIC_AIR, ior.v[i]);
+		return w * spec;
+	}
+	for (int i = 0; i < 4; ++i)
+		w.v[i] = mf_transmission_eval(d, V, L, DIELECTRIC_AIR, ior.v[i]);
+	return w * trans;
+}
+__device__ __forceinline__ Blob rough_dielectric_pdf(const RoughDistribution& d, V3 V, V3 L, const Blob& ior)
+{
+	Blob F, p;
+	for (int i = 0; i < 4; ++i)
+		F.v[i] = fresnel_dielectric(V.z, DIELECTRIC_AIR, ior.v[i]);
+	if (sv_same_hemisphere(V, L)) {
+		for (int i = 0; i < 4; ++i)
+			p.v[i] = mf_reflection_pdf(d, L, V);
+		return F * p;
+	}
+	for (int i = 0; i < 4; ++i)
+		p.v[i] = mf_transmission_pdf(d, V, L, DIELECTRIC_AIR, ior.v[i]);
+	return (blob(1) - F) * p;
+}
+// RoughConductorMaterial::eval (roughconductor.cpp:41-65), RoughDielectricMaterial::eval (roughdielectric.cpp:184-205).
+// `delta`: MaterialSampleFlag::DeltaDistribution.  Out of line: only scenes with rough materials pay for it.
+__device__ __noinline__ void rough_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
+{
+	const RoughDistribution d = rough_distribution(mat);
+	delta					  = d.is_delta();
+	if (delta) {
+		weight = blob(0);
+		pdf	   = blob(0);
+		return;
+	}
+	if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR) {
+		const Blob eta = spectrum_eval(s, mat.ior, wl), kk = spectrum_eval(s, mat.k, wl);
+		Blob factor;
+		for (int i = 0; i < 4; ++i)
+			factor.v[i] = mf_reflection_eval(d, Lt, Vt, true, eta.v[i], kk.v[i]);
+		weight = spectrum_eval(s, mat.albedo, wl) * factor;
+		pdf	   = blob(mf_reflection_pdf(d, Lt, Vt));
+	} else {
+		const Blob spec	 = spectrum_eval(s, mat.albedo, wl);
+		const Blob trans = mat.transmission != INVALID ? spectrum_eval(s, mat.transmission, wl) : spec;
+		const Blob ior	 = spectrum_eval(s, mat.ior, wl);
+		weight			 = rough_dielectric_eval(d, Vt, Lt, spec, trans, ior);
+		pdf				 = rough_dielectric_pdf(d, Vt, Lt, ior);
+	}
+}
+// IMaterial::eval for next event estimation: LambertMaterial::eval (lambert.cpp:33-42) inline, the rough closures out of line
+template <bool FULL>
+__device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
+{
+	if (FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC)) {
+		rough_eval(s, mat, wl, Vt, Lt, weight, pdf, delta);
+		return;
+	}
+	delta			= false;
+	const bool same = signbit(Vt.z) == signbit(Lt.z);
+	const float dt	= same ? (mat.two_sided ? fabsf(Lt.z) : fmaxf(0.0f, Lt.z)) : 0.0f;
+	weight			= (spectrum_eval(s, mat.albedo, wl) * dt) * PR_INV_PI_F;
+	pdf				= blob(dt * PR_INV_PI_F);
+}
+// RoughConductorMaterial::sample (roughconductor.cpp:83-117), RoughDielectricMaterial::sample (roughdielectric.cpp:222-254)
+__device__ __noinline__ void rough_sample(const DevScene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, uint64_t& rnd, V3& Lt, Blob& integral_weight, Blob& pdf_s, bool& delta,
+						 bool& hero_collapsing)
+{
+	const RoughDistribution d = rough_distribution(mat);
+	delta					  = d.is_delta();
+	if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR) {
+		const float u0 = rng_float(rnd), u1 = rng_float(rnd);
+		Lt				= mf_reflection_sample(d, u0, u1, Vt);
+		hero_collapsing = delta && ((s.spectra[mat.ior].kind == PRGPU_SPEC_SELLMEIER) || (s.spectra[mat.k].kind == PRGPU_SPEC_SELLMEIER));
+		if (!sv_same_hemisphere(Vt, Lt)) { // MaterialSampleOutput::Reject
+			Lt				= v3(0, 0, 0);
+			integral_weight = blob(0);
+			pdf_s			= blob(0);
+			return;
+		}
+		const Blob eta = spectrum_eval(s, mat.ior, wl), kk = spectrum_eval(s, mat.k, wl);
+		Blob factor;
+		for (int i = 0; i < 4; ++i)
+			factor.v[i] = mf_reflection_eval(d, Lt, Vt, true, eta.v[i], kk.v[i]);
+		integral_weight = spectrum_eval(s, mat.albedo, wl) * factor;
+		pdf_s			= blob(mf_reflection_pdf(d, Lt, Vt));
+	} else {
+		const Blob spec	 = spectrum_eval(s, mat.albedo, wl);
+		const Blob trans = mat.transmission != INVALID ? spectrum_eval(s, mat.transmission, wl) : spec;
+		const Blob ior	 = spectrum_eval(s, mat.ior, wl);
+		hero_collapsing	 = delta && (s.spectra[mat.ior].kind == PRGPU_SPEC_SELLMEIER);
+		// RoughDielectricClosure::sample (roughdielectric.cpp:124-137): branch on the hero wavelength's Fresnel term
+		const float F  = fresnel_dielectric(Vt.z, DIELECTRIC_AIR, ior.v[0]);
+		const float ub = rng_float(rnd);
+		const float u0 = rng_float(rnd), u1 = rng_float(rnd);
+		Lt = ub <= F ? mf_reflection_sample(d, u0, u1, Vt) : mf_transmission_sample(d, u0, u1, Vt, DIELECTRIC_AIR, ior.v[0]);
+		if (v3_is_zero(Lt, 1e-5f)) { // Eigen isZero() with the default precision
+			Lt				= v3(0, 0, 0);
+			integral_weight = blob(0);
+			pdf_s			= blob(0);
+			return;
+		}
+		integral_weight = rough_dielectric_eval(d, Vt, Lt, spec, trans, ior);
+		pdf_s			= rough_dielectric_pdf(d, Vt, Lt, ior);
+	}
+	if (pdf_s.v[0] > PR_EPS)
+		integral_weight = integral_weight / pdf_s.v[0];
+	if (delta)
+		pdf_s = blob(1);
+}
+
 template <bool FULL>
 __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState& ps, uint32_t slot, BlockStats& bs, bool& alive, bool& want_shadow,
 											 float4& sh_o, float4& sh_d, float4& sh_xyz)
@@ -900,7 +1020,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			const prgpu_material mat = sc.materials[gp.material];
 			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
 			uint64_t rnd			 = ps.rng[pixel];
-			const bool deltaMat		 = FULL && mat.kind != PRGPU_MAT_LAMBERT; // IMaterial::hasOnlyDeltaDistribution (dielectric, conductor)
+			const bool deltaMat		 = FULL && (mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR); // IMaterial::hasOnlyDeltaDistribution
+			const bool roughMat		 = FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC);
 			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + (FULL ? sc.n_inf_lights : 0u))) { // direct.cpp:100-101
 				// ---- handleNEE
 				do {
@@ -931,12 +1052,13 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						const float cosL = 1.0f;
 						if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
 							break;
-						const V3 Lt		  = to_tangent_space(N, gp.Nx, gp.Ny, L);
-						const bool same	  = signbit(Vt.z) == signbit(Lt.z);
-						const float dt	  = same ? (mat.two_sided ? fabsf(Lt.z) : fmaxf(0.0f, Lt.z)) : 0.0f;
-						const Blob weight = (spectrum_eval(sc, mat.albedo, wl) * dt) * PR_INV_PI_F;
-						const float bsdf_pdf   = dt * PR_INV_PI_F;
-						const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+						const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
+						Blob weight, bsdf_pdf;
+						bool evalDelta;
+						material_eval<FULL>(sc, mat, wl, Vt, Lt, weight, bsdf_pdf, evalDelta);
+						if (evalDelta) // direct.cpp:269-270
+							break;
+						const Blob bsdfWvlPdfS = bsdf_pdf * hf;
 						if (all_le(bsdfWvlPdfS, PDF_EPS))
 							break;
 						const Blob connectionW = radiance * weight;
@@ -1017,12 +1139,13 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const float cosL	 = fabsf(cosLight);
 					if (!(cosC * cosL > GEOMETRY_EPS && sqrD > DISTANCE_EPS))
 						break;
-					const V3 Lt		  = to_tangent_space(N, gp.Nx, gp.Ny, L);
-					const bool same	  = signbit(Vt.z) == signbit(Lt.z);
-					const float dt	  = same ? (mat.two_sided ? fabsf(Lt.z) : fmaxf(0.0f, Lt.z)) : 0.0f;
-					const Blob weight = (spectrum_eval(sc, mat.albedo, wl) * dt) * PR_INV_PI_F;
-					const float bsdf_pdf   = dt * PR_INV_PI_F;
-					const Blob bsdfWvlPdfS = blob(bsdf_pdf) * hf;
+					const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
+					Blob weight, bsdf_pdf;
+					bool evalDelta;
+					material_eval<FULL>(sc, mat, wl, Vt, Lt, weight, bsdf_pdf, evalDelta);
+					if (evalDelta) // direct.cpp:269-270
+						break;
+					const Blob bsdfWvlPdfS = bsdf_pdf * hf;
 					if (all_le(bsdfWvlPdfS, PDF_EPS))
 						break;
 					const Blob connectionW = radiance * weight;
@@ -1078,7 +1201,10 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				V3 Lt;
 				Blob integral_weight, pdf_s;
 				bool heroCollapsing = false;
-				if (FULL && mat.kind == PRGPU_MAT_CONDUCTOR) {
+				bool sampleDelta	= deltaMat;
+				if (roughMat) {
+					rough_sample(sc, mat, wl, Vt, rnd, Lt, integral_weight, pdf_s, sampleDelta, heroCollapsing);
+				} else if (FULL && mat.kind == PRGPU_MAT_CONDUCTOR) {
 					// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
 					pdf_s		   = blob(1);
 					const Blob eta = spectrum_eval(sc, mat.ior, wl), kk = spectrum_eval(sc, mat.k, wl);
@@ -1123,7 +1249,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						Lt = -Lt;
 				}
 				const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt));
-				flags	 = deltaMat ? (flags | FLAG_LAST_DELTA) : (flags & ~FLAG_LAST_DELTA);
+				flags	 = sampleDelta ? (flags | FLAG_LAST_DELTA) : (flags & ~FLAG_LAST_DELTA);
 				prev_pdf = path_pdf;
 				path_pdf = path_pdf * (pdf_s * scatProb);
 				if (all_le(path_pdf, PDF_EPS))

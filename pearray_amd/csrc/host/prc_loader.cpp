@@ -536,17 +536,50 @@ struct Loader {
 			fail(PRGPU_EINVAL, where(g) + ": material without a name");
 		prgpu_material m;
 		std::memset(&m, 0, sizeof(m));
-		if (type == "glass" || type == "dielectric") { // dielectric.cpp:150-197
-			if (g.get("roughness") || g.get("roughness_x") || g.get("roughness_y"))
-				fail(PRGPU_EUNSUPPORTED, where(g) + ": rough dielectrics are not supported (smooth glass only)");
+		const bool has_roughness = g.get("roughness") || g.get("roughness_x") || g.get("roughness_y");
+		auto roughness			 = [&](prgpu_material& mm) { // roughconductor.cpp:158-177 / roughdielectric.cpp:282-310 (scalar nodes: constants only)
+			auto scalar = [&](const char* key) -> float {
+				const Value* v = g.get(key);
+				if (!v)
+					return 0.0f; // lookupScalarNode(key, 0)
+				if (!v->is_number())
+					fail(PRGPU_EUNSUPPORTED, where(g) + ": :" + key + " must be a number (textured roughness is not supported)");
+				return (float)v->number();
+			};
+			mm.roughness_x = g.get("roughness_x") ? scalar("roughness_x") : scalar("roughness");
+			if (g.get("roughness_y")) { // its own node: the anisotropic closure, whatever the value
+				mm.roughness_y = scalar("roughness_y");
+				mm.flags |= PRGPU_MATF_ANISOTROPIC;
+			} else {
+				mm.roughness_y = mm.roughness_x;
+			}
+			if (!get_bool(g, "vndf", true))
+				mm.flags |= PRGPU_MATF_NO_VNDF;
+			if ((mm.flags & PRGPU_MATF_ANISOTROPIC) && (mm.flags & PRGPU_MATF_NO_VNDF))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": anisotropic roughness with :vndf false is not supported");
+		};
+		const bool rough_glass = type == "roughglass" || type == "roughdielectric" || type == "rough_glass" || type == "rough_dielectric";
+		const bool rough_metal = type == "roughconductor" || type == "roughmirror" || type == "roughmetal";
+		if (rough_glass || ((type == "glass" || type == "dielectric") && has_roughness)) { // roughdielectric.cpp:282-365, dielectric.cpp:172-176
+			m.kind		   = PRGPU_MAT_ROUGH_DIELECTRIC;
+			m.ior		   = spectral_param(g, { "eta", "index", "ior" }, 1.55f);
+			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);
+			m.transmission = g.get("transmission") ? spectral_node(*g.get("transmission"), g, "transmission") : PRGPU_INVALID_ID;
+			roughness(m);
+		} else if (rough_metal || ((type == "conductor" || type == "metal") && has_roughness)) { // roughconductor.cpp:158-216, conductor.cpp:102-106
+			m.kind		   = PRGPU_MAT_ROUGH_CONDUCTOR;
+			m.ior		   = spectral_param(g, { "eta", "index", "ior" }, 1.2f);
+			m.k			   = spectral_param(g, { "k", "kappa" }, 2.605f);
+			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);
+			m.transmission = PRGPU_INVALID_ID;
+			roughness(m);
+		} else if (type == "glass" || type == "dielectric") { // dielectric.cpp:150-197
 			m.kind		   = PRGPU_MAT_DIELECTRIC;
 			m.ior		   = spectral_param(g, { "index", "eta", "ior" }, 1.55f);
 			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);
 			m.transmission = g.get("transmission") ? spectral_node(*g.get("transmission"), g, "transmission") : PRGPU_INVALID_ID;
 			m.thin		   = get_bool(g, "thin", false) ? 1 : 0;
 		} else if (type == "conductor" || type == "metal") { // conductor.cpp:95-125
-			if (g.get("roughness") || g.get("roughness_x") || g.get("roughness_y"))
-				fail(PRGPU_EUNSUPPORTED, where(g) + ": rough conductors are not supported (smooth metal only)");
 			m.kind		   = PRGPU_MAT_CONDUCTOR;
 			m.ior		   = spectral_param(g, { "eta", "index", "ior" }, 1.2f);
 			m.k			   = spectral_param(g, { "k", "kappa" }, 2.605f);
@@ -557,7 +590,7 @@ struct Loader {
 			m.albedo	= spectral_param(g, { "albedo", "base", "diffuse" }, 1.0f);
 			m.two_sided = get_bool(g, "two_sided", true) ? 1 : 0;
 		} else {
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert, smooth glass/dielectric and smooth conductor/metal are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert, glass/dielectric, conductor/metal and their rough variants are)");
 		}
 		material_ids[name] = (uint32_t)out.materials.size();
 		out.materials.push_back(m);

@@ -698,14 +698,23 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 	}
 	for (uint32_t i = 0; i < d->n_materials; ++i) {
 		const prgpu_material& m = d->materials[i];
-		if (m.kind != PRGPU_MAT_LAMBERT && m.kind != PRGPU_MAT_DIELECTRIC && m.kind != PRGPU_MAT_CONDUCTOR)
-			return bad("only lambert, smooth dielectric and smooth conductor materials are implemented", PRGPU_EUNSUPPORTED);
-		if (m.kind == PRGPU_MAT_CONDUCTOR && (m.ior >= d->n_spectra || m.k >= d->n_spectra))
+		if (m.kind > PRGPU_MAT_ROUGH_DIELECTRIC)
+			return bad("unknown material kind", PRGPU_EUNSUPPORTED);
+		const bool conductor = m.kind == PRGPU_MAT_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_CONDUCTOR;
+		const bool glass	 = m.kind == PRGPU_MAT_DIELECTRIC || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC;
+		if (conductor && (m.ior >= d->n_spectra || m.k >= d->n_spectra))
 			return bad("conductor eta / k spectrum out of range");
 		if (m.albedo >= d->n_spectra)
 			return bad("material albedo index out of range");
-		if (m.kind == PRGPU_MAT_DIELECTRIC && (m.ior >= d->n_spectra || (m.transmission != PRGPU_INVALID_ID && m.transmission >= d->n_spectra)))
+		if (glass && (m.ior >= d->n_spectra || (m.transmission != PRGPU_INVALID_ID && m.transmission >= d->n_spectra)))
 			return bad("dielectric index / transmission spectrum out of range");
+		if (m.kind == PRGPU_MAT_ROUGH_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC) {
+			const bool aniso = (m.flags & PRGPU_MATF_ANISOTROPIC) != 0;
+			if (!(m.roughness_x >= 0.0f) || !std::isfinite(m.roughness_x) || !std::isfinite(m.roughness_y) || (aniso && !(m.roughness_y >= 0.0f)))
+				return bad("roughness must be finite and non-negative");
+			if (aniso && (m.flags & PRGPU_MATF_NO_VNDF))
+				return bad("anisotropic roughness without vndf sampling is not supported", PRGPU_EUNSUPPORTED);
+		}
 	}
 	if (d->camera.kind > PRGPU_CAMERA_ORTHO)
 		return bad("unknown camera kind");

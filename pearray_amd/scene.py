@@ -129,6 +129,29 @@ class SceneBuilder:
         self.materials.append(abi.Material(abi.MAT_CONDUCTOR, spec, 0, eta, abi.INVALID_ID, 0, k))
         return len(self.materials) - 1
 
+    def _rough(self, roughness, roughness_y, vndf):
+        rx = float(roughness)
+        ry, flags = (rx, 0) if roughness_y is None else (float(roughness_y), abi.MATF_ANISOTROPIC)
+        return rx, ry, flags | (0 if vndf else abi.MATF_NO_VNDF)
+
+    def rough_conductor(self, roughness, eta=None, k=None, specularity=None, roughness_y=None, vndf=True):
+        """(material :type 'roughconductor'|'roughmirror'|'roughmetal') or a conductor with a roughness, roughconductor.cpp:158-216"""
+        eta = self.spectrum_const(1.2) if eta is None else eta
+        k = self.spectrum_const(2.605) if k is None else k
+        spec = self.spectrum_const(1.0) if specularity is None else specularity
+        rx, ry, flags = self._rough(roughness, roughness_y, vndf)
+        self.materials.append(abi.Material(abi.MAT_ROUGH_CONDUCTOR, spec, 0, eta, abi.INVALID_ID, 0, k, flags, rx, ry))
+        return len(self.materials) - 1
+
+    def rough_dielectric(self, roughness, ior=None, specularity=None, transmission=None, roughness_y=None, vndf=True):
+        """(material :type 'roughglass'|'roughdielectric') or a glass with a roughness, roughdielectric.cpp:282-365"""
+        ior = self.spectrum_const(1.55) if ior is None else ior
+        spec = self.spectrum_const(1.0) if specularity is None else specularity
+        rx, ry, flags = self._rough(roughness, roughness_y, vndf)
+        self.materials.append(abi.Material(abi.MAT_ROUGH_DIELECTRIC, spec, 0, ior, abi.INVALID_ID if transmission is None else transmission, 0, 0,
+                                           flags, rx, ry))
+        return len(self.materials) - 1
+
     def diffuse_emission(self, radiance):
         self.emissions.append(abi.Emission(abi.EMS_DIFFUSE, radiance))
         return len(self.emissions) - 1
@@ -405,6 +428,21 @@ def triangle_soup(n, seed=42, size=0.01, lo=(-0.95, -0.95, 0.05), hi=(0.95, 0.95
     pos = np.stack([c, c + e1, c + e2], axis=1).reshape(-1, 3).astype(np.float32)
     faces = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
     return pos, faces
+
+
+def cornell_rough(width=256, height=256, spp=16, roughness=0.2, vndf=True, sampler=abi.SAMPLER_MJITT, **settings):
+    """The Cornell box with GGX materials: a rough gold-like conductor (short box), rough tinted BK7 glass (tall box) and an anisotropic
+    rough conductor (left wall) -- roughconductor.cpp / roughdielectric.cpp closures under NEE + MIS."""
+    b = SceneBuilder(width, height)
+    b.settings.aa_sampler, b.settings.aa_samples = sampler, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+    _cornell_into(b, material_override={
+        "shortBox": lambda bb: bb.rough_conductor(roughness, eta=bb.spectrum_const(0.2), k=bb.spectrum_const(3.9), vndf=vndf),
+        "tallBox": lambda bb: bb.rough_dielectric(0.75 * roughness, ior=bb.lookup_index("bk7"), transmission=bb.refl(0.6, 0.9, 0.7), vndf=vndf),
+        "leftWall": lambda bb: (bb.rough_conductor(1.5 * roughness, roughness_y=0.5 * roughness, specularity=bb.refl(0.9, 0.6, 0.3)) if vndf
+                                else bb.rough_conductor(1.5 * roughness, specularity=bb.refl(0.9, 0.6, 0.3), vndf=False))})
+    return b.build()
 
 
 def cornell_soup(width=1920, height=1080, spp=1024, n_triangles=1_000_000, sampler=abi.SAMPLER_SOBOL, **settings):

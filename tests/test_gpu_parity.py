@@ -562,3 +562,25 @@ def test_orthographic_camera_bit_exact():
       (entity :name 'ball' :type 'sphere' :radius 1 :material 'm'))"""
     g, o = render_both(scene.PrcScene(source=src, spp=4))
     assert_parity(g, o, exact=True)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(vndf=False), dict(roughness=0.05), dict(roughness=0.6), dict(mis=abi.MIS_POWER), dict(nee=0),
+                                dict(spectral_hero=0), dict(spectral_mono=1, spectral_start=520.0, spectral_end=830.0),
+                                dict(roughness=0.0008), dict(sampler=abi.SAMPLER_SOBOL, mapper=abi.MAPPER_CIE)])
+def test_rough_materials(kw):
+    """GGX conductor / dielectric closures (isotropic, anisotropic, VNDF and plain sampling; roughness 0.0008 is the delta closure with
+    hero collapse in the dispersive glass)."""
+    g, o = render_both(scene.cornell_rough(48, 48, spp=6, **kw))
+    assert_parity(g, o, exact=True)
+    assert g.statistics()["shadow_rays"] > 0 or kw.get("nee") == 0
+
+
+def test_rough_materials_under_infinite_lights():
+    b = scene.SceneBuilder(40, 40)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_MJITT, 6
+    scene._cornell_into(b, material_override={"shortBox": lambda bb: bb.rough_conductor(0.25), "tallBox": lambda bb: bb.rough_dielectric(0.1),
+                                               "ceiling": lambda bb: bb.rough_dielectric(0.3, roughness_y=0.1, ior=bb.lookup_index("bk7"))})
+    b.environment_light(b.illuminant_d65())
+    b.distant_light(b.spectrum_const(2.0), direction=(0.2, 0.3, -1.0))
+    g, o = render_both(b.build())
+    assert_parity(g, o, exact=True)
