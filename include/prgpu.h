@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PRGPU_API_VERSION 3
+#define PRGPU_API_VERSION 4
 #define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
 
 enum {
@@ -90,21 +90,31 @@ typedef struct prgpu_spectrum {
 enum { PRGPU_MAT_LAMBERT = 0, PRGPU_MAT_DIELECTRIC = 1, PRGPU_MAT_CONDUCTOR = 2,
        PRGPU_MAT_ROUGH_CONDUCTOR = 3,    /* roughconductor.cpp: GGX microfacet reflection (base/math/MicrofacetReflection.h, RoughDistribution.h,
                                             Microfacet.h) with the conductor Fresnel term; also `conductor` with a roughness (conductor.cpp:102-106) */
-       PRGPU_MAT_ROUGH_DIELECTRIC = 4 }; /* roughdielectric.cpp: GGX reflection + refraction (MicrofacetTransmission.h), branch chosen by the hero
+       PRGPU_MAT_ROUGH_DIELECTRIC = 4,   /* roughdielectric.cpp: GGX reflection + refraction (MicrofacetTransmission.h), branch chosen by the hero
                                             wavelength's Fresnel term; also `glass` with a roughness (dielectric.cpp:172-176) */
-enum { PRGPU_MATF_ANISOTROPIC = 1u, /* roughness_y given as its own parameter (the reference compares the NODES, not the values) */
-       PRGPU_MATF_NO_VNDF = 2u };   /* `:vndf false`: sample the plain GGX normal distribution (isotropic only; the anisotropic variant needs atan/tan) */
+       PRGPU_MAT_PRINCIPLED = 5 };       /* principled.cpp: Disney-style diffuse / retro / sheen / GGX specular / refraction / clearcoat lobes with a
+                                            four-way lobe selection (principled.cpp:111-139,418-435); constant scalar parameters only */
+enum { PRGPU_MATF_ANISOTROPIC = 1u,      /* roughness_y given as its own parameter (the reference compares the NODES, not the values) */
+       PRGPU_MATF_NO_VNDF = 2u,          /* `:vndf false`: sample the plain GGX normal distribution (isotropic only; the anisotropic variant needs
+                                            atan/tan, so PRINCIPLED, whose closure is always anisotropic, requires vndf) */
+       PRGPU_MATF_HAS_TRANSMISSION = 4u }; /* PRINCIPLED: a transmission parameter was given (principled.cpp:657-666 picks the template by presence) */
+/* PRINCIPLED scalar parameters (principled.cpp:634-655; defaults 0 except roughness 0.5 in roughness_x) */
+enum { PRGPU_PRINCIPLED_DIFFUSE_TRANSMISSION = 0, PRGPU_PRINCIPLED_SPECULAR_TRANSMISSION = 1, PRGPU_PRINCIPLED_SPECULAR_TINT = 2,
+       PRGPU_PRINCIPLED_ANISOTROPIC = 3, PRGPU_PRINCIPLED_FLATNESS = 4, PRGPU_PRINCIPLED_METALLIC = 5, PRGPU_PRINCIPLED_SHEEN = 6,
+       PRGPU_PRINCIPLED_SHEEN_TINT = 7, PRGPU_PRINCIPLED_CLEARCOAT = 8, PRGPU_PRINCIPLED_CLEARCOAT_GLOSS = 9, PRGPU_PRINCIPLED_COUNT = 10 };
 typedef struct prgpu_material {
 	uint32_t kind;
 	uint32_t albedo;       /* spectrum index.  LAMBERT: `albedo`; every other kind: `specularity` (reflection tint, default 1) */
 	uint32_t two_sided;    /* LAMBERT `two_sided`, default true (lambert.cpp:108) */
 	uint32_t ior;          /* (ROUGH_)DIELECTRIC: `index`/`eta`/`ior` spectrum (default 1.55); (ROUGH_)CONDUCTOR: `eta` (default 1.2) */
 	uint32_t transmission; /* (ROUGH_)DIELECTRIC: `transmission` tint spectrum, or PRGPU_INVALID_ID = same as specularity (dielectric.cpp:92-96) */
-	uint32_t thin;         /* DIELECTRIC: `thin` sheet approximation (dielectric.cpp:69-72,98-101) */
+	uint32_t thin;         /* DIELECTRIC: `thin` sheet approximation (dielectric.cpp:69-72,98-101); PRINCIPLED: `thin` */
 	uint32_t k;            /* (ROUGH_)CONDUCTOR: `k`/`kappa` absorption index spectrum (default 2.605) */
 	uint32_t flags;        /* PRGPU_MATF_* (rough kinds) */
 	float roughness_x;     /* rough kinds: `roughness_x` or `roughness` (constant scalar; textures are out of scope) */
 	float roughness_y;     /* rough kinds: `roughness_y`; ignored (= roughness_x) unless PRGPU_MATF_ANISOTROPIC */
+	float principled[PRGPU_PRINCIPLED_COUNT]; /* PRINCIPLED: albedo = `base`/`base_color` (default 0.8), ior (1.55), roughness_x = `roughness` (0.5),
+	                                             thin = `thin`, and these scalars */
 } prgpu_material;
 
 enum { PRGPU_EMS_DIFFUSE = 0 }; /* src/plugins/main/emissions/diffuse.cpp */

@@ -908,6 +908,21 @@ inline float g1_smith_lambda(V3 K, float rx, float ry, bool aniso)
 	const float b = sv_tan2_theta(K);
 	return (std::sqrt(1 + a * b) - 1) / 2;
 }
+// Microfacet.h:46-53 g_1_smith_opt (isotropic; 1/(4 NdotV NdotL) multiplied out)
+inline float g1_smith_opt(float NdotK, float roughness)
+{
+	const float a	  = roughness * roughness;
+	const float b	  = NdotK * NdotK;
+	const float denom = NdotK + std::sqrt(a + b - a * b);
+	return denom <= PR_EPS ? 0.0f : 1.0f / denom;
+}
+// Fresnel.h:61-71 schlick_term, schlick
+inline float schlick_term(float d)
+{
+	const float t = 1 - d;
+	return (t * t) * (t * t) * t;
+}
+inline float schlick(float d, float f0) { return f0 + (1 - f0) * schlick_term(d); }
 // Microfacet.h:225-228 pdf_ggx, :266-271 pdf_ggx_vndf (always the two-roughness forms)
 inline float pdf_ggx(V3 H, float rx, float ry, bool aniso) { return ndf_ggx(H, rx, ry, aniso) * std::fabs(H.z); }
 inline float pdf_ggx_vndf(V3 V, V3 H, float rx, float ry)
@@ -1028,6 +1043,17 @@ inline float mf_reflection_eval(const RoughDistribution& d, V3 wIn, V3 wOut, boo
 		return F;
 	const float jacobian = reflective_jacobian(cosI);
 	return F * d.dg_norm(H, wIn, wOut) * jacobian;
+}
+inline float mf_reflection_eval_plain(const RoughDistribution& d, V3 wIn, V3 wOut) // :76-90 eval() without a Fresnel term (H is not flipped)
+{
+	if (!sv_same_hemisphere(wIn, wOut))
+		return 0.0f;
+	const V3 H = normalized_or_zero(wIn + wOut);
+	if (d.is_delta())
+		return 1.0f;
+	const float cosI	 = dot(H, wIn);
+	const float jacobian = reflective_jacobian(cosI);
+	return d.dg_norm(H, wIn, wOut) * jacobian;
 }
 inline float mf_reflection_pdf(const RoughDistribution& d, V3 wIn, V3 wOut) // :92-105 (H is not flipped here)
 {
@@ -1929,11 +1955,270 @@ inline Blob rough_dielectric_pdf(const RoughDistribution& d, V3 V, V3 L, const B
 		p[i] = mf_transmission_pdf(d, V, L, DIELECTRIC_AIR, ior[i]);
 	return (blob(1) - F) * p;
 }
+// PrincipledClosure (principled.cpp:31-436), camera paths (no light-path eta^2 factor)
+struct Principled {
+	Blob base, ior, cie_y; // cie_y: CIE::eval_y of the path's wavelengths (tintColor, :171-179)
+	float diff_trans, roughness, anisotropic, spec_trans, spec_tint, flatness, metallic, sheen, sheen_tint, clearcoat, clearcoat_gloss;
+	bool thin, has_trans, vndf;
+
+	static float mix(float v0, float v1, float t) { return (1 - t) * v0 + t * v1; } // :38-42
+	static float schlick_r0(float eta)												  // :44-48
+	{
+		const float factor = (eta - 1.0f) / (eta + 1.0f);
+		return factor * factor;
+	}
+	float thin_transmission_roughness() const { return std::max(0.0f, std::min(1.0f, (0.65f * (bsum(ior) / 4) - 0.35f) * roughness)); } // :86-89
+	RoughDistribution roughness_closure(float r) const																					  // :91-97
+	{
+		const float aspect = std::sqrt(1 - anisotropic * 0.9f);
+		const float ax	   = std::max(0.001f, r * r / aspect);
+		const float ay	   = std::max(0.001f, r * r * aspect);
+		return RoughDistribution{ ax, ay, true, vndf };
+	}
+	bool is_delta() const { return roughness_closure(roughness).is_delta(); }
+	struct Lobes {
+		float diff_refl, diff_trans, spec_refl, spec_trans;
+	};
+	Lobes lobe_distribution(V3 V) const // :111-139
+	{
+		Lobes d;
+		d.diff_refl = roughness * roughness * (1.0f - metallic) * (1.0f - spec_trans);
+		d.spec_refl = 1;
+		if (has_trans) {
+			const float F = fresnel_dielectric(V.z, DIELECTRIC_AIR, ior[0]);
+			d.diff_trans  = diff_trans * d.diff_refl;
+			d.spec_trans  = (1.0f - F) * (1.0f - metallic) * spec_trans;
+			d.spec_refl *= F;
+		} else {
+			d.diff_trans = 0;
+			d.spec_trans = 0;
+		}
+		const float norm = d.diff_refl + d.spec_refl + d.diff_trans + d.spec_trans;
+		if (norm <= PR_EPS)
+			return Lobes{ 1.0f, 0.0f, 0.0f, 0.0f };
+		d.diff_refl /= norm;
+		d.spec_refl /= norm;
+		d.diff_trans /= norm;
+		d.spec_trans /= norm;
+		return d;
+	}
+	Blob tint_color() const // :171-179
+	{
+		float lum = 0;
+		for (int i = 0; i < 4; ++i)
+			lum = std::max(lum, base[i] * cie_y[i]);
+		return lum > PR_EPS ? base / lum : blob(1);
+	}
+	Blob disney_fresnel(float HdotV, float HdotL) const // :141-169
+	{
+		Blob res;
+		if (metallic <= 1e-4f) {
+			for (int i = 0; i < 4; ++i)
+				res[i] = fresnel_dielectric(HdotV, DIELECTRIC_AIR, ior[i]);
+			return res;
+		}
+		const Blob color = tint_color();
+		for (int i = 0; i < 4; ++i) {
+			const float eta = HdotV < 0 ? DIELECTRIC_AIR / ior[i] : ior[i] / DIELECTRIC_AIR;
+			const float r0	= mix(schlick_r0(eta) * mix(1.0f, color[i], spec_tint), base[i], metallic);
+			const float f1	= fresnel_dielectric(HdotV, DIELECTRIC_AIR, ior[i]);
+			const float f2	= schlick(std::fabs(HdotL), r0);
+			res[i]			= mix(f1, f2, metallic);
+		}
+		return res;
+	}
+	float retro_diffuse(V3 V, V3 L, float HdotL) const // :186-194
+	{
+		const float alpha2 = roughness * roughness;
+		const float fd90   = 0.5f + 2 * HdotL * HdotL * alpha2;
+		const float lk	   = schlick_term(std::fabs(L.z));
+		const float vk	   = schlick_term(std::fabs(V.z));
+		return PR_INV_PI_F * fd90 * (lk + vk + lk * vk * (fd90 - 1.0f));
+	}
+	float subsurface(V3 V, V3 L, float HdotL) const // :196-210
+	{
+		const float alpha2 = roughness * roughness;
+		const float fss90  = HdotL * HdotL * alpha2;
+		const float lk	   = schlick_term(std::fabs(L.z));
+		const float vk	   = schlick_term(std::fabs(V.z));
+		const float fss	   = mix(1.0f, fss90, lk) * mix(1.0f, fss90, vk);
+		const float f	   = std::fabs(L.z) + std::fabs(V.z);
+		if (std::fabs(f) < PR_EPS)
+			return 0.0f;
+		return 1.25f * (fss * (1.0f / f - 0.5f) + 0.5f);
+	}
+	float diffuse_term(V3 V, V3 L, float HdotL) const // :213-225
+	{
+		const float lk = schlick_term(std::fabs(L.z));
+		const float vk = schlick_term(std::fabs(V.z));
+		float diffuse  = 1;
+		if (thin)
+			diffuse = mix(1.0f, subsurface(V, L, HdotL), flatness);
+		return PR_INV_PI_F * diffuse * (1 - 0.5f * lk) * (1 - 0.5f * vk);
+	}
+	float clearcoat_term(V3 V, V3 L, V3 H) const // :250-263
+	{
+		const float F0 = 0.04f, R = 0.25f;
+		const float D  = ndf_ggx(H, mix(0.1f, 0.001f, clearcoat_gloss), 0.0f, false);
+		const float hk = schlick_term(std::fabs(dot(H, L)));
+		const float F  = mix(F0, 1.0f, hk);
+		const float G  = g1_smith_opt(std::fabs(L.z), R) * g1_smith_opt(std::fabs(V.z), R);
+		return R * D * F * G;
+	}
+	Blob eval(V3 V, V3 L) const // :274-344
+	{
+		if (std::fabs(V.z) <= PR_EPS || std::fabs(L.z) <= PR_EPS)
+			return blob(0);
+		const float diffuseWeight  = (1.0f - metallic) * (1.0f - spec_trans);
+		const bool isTransmission  = !sv_same_hemisphere(V, L);
+		const bool upperHemisphere = V.z >= 0.0f && !isTransmission;
+		if (!has_trans && isTransmission)
+			return blob(0);
+		const V3 rH		  = normalized_or_zero(V + L);
+		const float HdotL = dot(rH, L);
+		Blob value		  = blob(0);
+		const float absL  = std::fabs(L.z);
+		if (diffuseWeight > 1e-4f) {
+			if (!isTransmission) { // retro-reflection + sheen
+				const float retro = retro_diffuse(V, L, HdotL) * diffuseWeight;
+				Blob sh			  = blob(0);
+				if (!(sheen <= 1e-4f)) { // sheenTerm :265-272, sheenTintColor :181-184
+					const Blob tint = tint_color();
+					const float st	= schlick_term(std::fabs(HdotL));
+					for (int i = 0; i < 4; ++i)
+						sh[i] = sheen * mix(1.0f, tint[i], sheen_tint) * st;
+				}
+				sh = sh * diffuseWeight;
+				for (int i = 0; i < 4; ++i)
+					value[i] += (retro * base[i] + sh[i]) * absL;
+			}
+			if (!isTransmission) { // diffuse reflection
+				const float diff = diffuse_term(V, L, HdotL) * (thin ? 1 - diff_trans : diffuseWeight);
+				for (int i = 0; i < 4; ++i)
+					value[i] += base[i] * (diff * absL);
+			}
+			if (has_trans && thin && isTransmission) { // diffuse transmission
+				const float diff = diffuse_term(V, L, HdotL) * diff_trans;
+				for (int i = 0; i < 4; ++i)
+					value[i] += base[i] * (diff * absL);
+			}
+		}
+		{ // specular reflection :227-236
+			const RoughDistribution micro = roughness_closure(roughness);
+			const float HdotV			  = dot(V, rH);
+			const float HdotL2			  = dot(L, rH);
+			const Blob F				  = disney_fresnel(HdotV, HdotL2);
+			const float m				  = mf_reflection_eval_plain(micro, V, L);
+			for (int i = 0; i < 4; ++i)
+				value[i] += F[i] * m;
+		}
+		if (has_trans) { // specular refraction :238-248,322-336
+			const float transmissionWeight = (1.0f - metallic) * spec_trans;
+			if (transmissionWeight > 1e-4f) {
+				const float scaledR			  = thin ? thin_transmission_roughness() : roughness;
+				const RoughDistribution micro = roughness_closure(scaledR);
+				for (int i = 0; i < 4; ++i) {
+					const float R = mf_transmission_eval(micro, V, L, DIELECTRIC_AIR, ior[i]);
+					const float w = thin ? std::sqrt(base[i]) * R : base[i] * R;
+					value[i] += transmissionWeight * w;
+				}
+			}
+		}
+		if (upperHemisphere && clearcoat > 1e-4f) {
+			const float c = clearcoat_term(V, L, rH);
+			for (int i = 0; i < 4; ++i)
+				value[i] += c;
+		}
+		return value;
+	}
+	Blob pdf(V3 V, V3 L) const // :346-397
+	{
+		if (std::fabs(V.z) <= PR_EPS || std::fabs(L.z) <= PR_EPS)
+			return blob(0);
+		const Lobes distr		  = lobe_distribution(V);
+		const bool isTransmission = !sv_same_hemisphere(V, L);
+		const float diffPdf		  = std::fabs(L.z) * PR_INV_PI_F;
+		Blob pdfV				  = blob(0);
+		if (!isTransmission) {
+			for (int i = 0; i < 4; ++i)
+				pdfV[i] += distr.diff_refl * diffPdf;
+			if (distr.spec_refl > 1e-4f) {
+				const float r = mf_reflection_pdf(roughness_closure(roughness), V, L);
+				for (int i = 0; i < 4; ++i)
+					pdfV[i] += distr.spec_refl * r;
+			}
+		}
+		if (has_trans && isTransmission) {
+			for (int i = 0; i < 4; ++i)
+				pdfV[i] += distr.diff_trans * diffPdf;
+			if (distr.spec_trans > 1e-4f) {
+				const RoughDistribution micro = roughness_closure(roughness);
+				for (int i = 0; i < 4; ++i)
+					pdfV[i] += distr.spec_trans * mf_transmission_pdf(micro, V, L, DIELECTRIC_AIR, ior[i]);
+			}
+		}
+		return pdfV;
+	}
+	V3 sample(Rng& rnd, V3 V) const // :399-435
+	{
+		if (std::fabs(V.z) <= PR_EPS)
+			return v3(0, 0, 0);
+		const Lobes distr = lobe_distribution(V);
+		const float u0	  = rng_float(rnd);
+		const float a = rng_float(rnd), b = rng_float(rnd); // every branch draws two more numbers
+		if (u0 < distr.diff_refl || u0 < distr.diff_refl + distr.diff_trans) {
+			const V3 Ld = cos_hemi(a, b);
+			const V3 Lf = V.z < 0 ? -Ld : Ld; // sampleDiffuse :399-404
+			return u0 < distr.diff_refl ? Lf : -Lf;
+		}
+		if (u0 < distr.diff_refl + distr.diff_trans + distr.spec_trans)
+			return mf_transmission_sample(roughness_closure(roughness), a, b, V, DIELECTRIC_AIR, ior[0]);
+		return mf_reflection_sample(roughness_closure(roughness), a, b, V);
+	}
+};
+inline Principled principled_closure(const Scene& s, const prgpu_material& m, const Blob& wl) // createClosure :475-497, ctor :63-84
+{
+	Principled p;
+	p.base = spectrum_eval(s, m.albedo, wl);
+	p.ior  = spectrum_eval(s, m.ior, wl);
+	for (int i = 0; i < 4; ++i) {
+		float xyz[3];
+		cie_eval(wl[i], xyz);
+		p.cie_y[i] = xyz[1];
+	}
+	p.has_trans		  = (m.flags & PRGPU_MATF_HAS_TRANSMISSION) != 0;
+	p.thin			  = m.thin != 0;
+	p.vndf			  = (m.flags & PRGPU_MATF_NO_VNDF) == 0;
+	p.diff_trans	  = p.has_trans ? m.principled[PRGPU_PRINCIPLED_DIFFUSE_TRANSMISSION] : 0.0f;
+	p.spec_trans	  = p.has_trans ? m.principled[PRGPU_PRINCIPLED_SPECULAR_TRANSMISSION] : 0.0f;
+	p.roughness		  = m.roughness_x;
+	p.anisotropic	  = m.principled[PRGPU_PRINCIPLED_ANISOTROPIC];
+	p.spec_tint		  = m.principled[PRGPU_PRINCIPLED_SPECULAR_TINT];
+	p.flatness		  = m.principled[PRGPU_PRINCIPLED_FLATNESS];
+	p.metallic		  = m.principled[PRGPU_PRINCIPLED_METALLIC];
+	p.sheen			  = m.principled[PRGPU_PRINCIPLED_SHEEN];
+	p.sheen_tint	  = m.principled[PRGPU_PRINCIPLED_SHEEN_TINT];
+	p.clearcoat		  = m.principled[PRGPU_PRINCIPLED_CLEARCOAT];
+	p.clearcoat_gloss = m.principled[PRGPU_PRINCIPLED_CLEARCOAT_GLOSS];
+	return p;
+}
 // LambertMaterial::eval (lambert.cpp:33-42), RoughConductorMaterial::eval (roughconductor.cpp:41-65),
 // RoughDielectricMaterial::eval (roughdielectric.cpp:184-205).  `delta`: MaterialSampleFlag::DeltaDistribution
 inline void material_eval(const Scene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
 {
 	delta = false;
+	if (mat.kind == PRGPU_MAT_PRINCIPLED) { // PrincipledMaterial::eval (principled.cpp:499-528)
+		const Principled c = principled_closure(s, mat, wl);
+		if (c.is_delta()) {
+			delta  = true;
+			weight = blob(0);
+			pdf	   = blob(0);
+			return;
+		}
+		weight = c.eval(Vt, Lt);
+		pdf	   = c.pdf(Vt, Lt);
+		return;
+	}
 	if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC) {
 		const RoughDistribution d = rough_distribution(mat);
 		if (d.is_delta()) {
@@ -1967,6 +2252,25 @@ inline void material_eval(const Scene& s, const prgpu_material& mat, const Blob&
 inline void rough_sample(const Scene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, Rng& rnd, V3& Lt, Blob& integral_weight, Blob& pdf_s, bool& delta,
 						 bool& hero_collapsing)
 {
+	if (mat.kind == PRGPU_MAT_PRINCIPLED) { // PrincipledMaterial::sample (principled.cpp:548-590)
+		const Principled c = principled_closure(s, mat, wl);
+		Lt				   = c.sample(rnd, Vt);
+		delta			   = c.is_delta();
+		hero_collapsing	   = false; // the material sets no SpectralVarying flag
+		if (v3_is_zero(Lt, 1e-5f)) {
+			Lt				= v3(0, 0, 0);
+			integral_weight = blob(0);
+			pdf_s			= blob(0);
+			return;
+		}
+		integral_weight = c.eval(Vt, Lt);
+		pdf_s			= c.pdf(Vt, Lt);
+		if (pdf_s[0] > PR_EPS)
+			integral_weight = integral_weight / pdf_s[0];
+		if (delta)
+			pdf_s = blob(1);
+		return;
+	}
 	const RoughDistribution d = rough_distribution(mat);
 	delta					  = d.is_delta();
 	if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR) {
@@ -2233,7 +2537,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		const V3 Vt = to_tangent_space(N, gp.Nx, gp.Ny, -ray.d);
 
 		const bool deltaMat = mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR; // IMaterial::hasOnlyDeltaDistribution
-		const bool roughMat = mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC;
+		const bool roughMat = mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED;
 
 		if (cfg.nee && !deltaMat && !hasEmission && !s.light_intensity.empty()) { // direct.cpp:100-101
 			// ---- handleNEE (direct.cpp:233-352)
@@ -2665,12 +2969,23 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("spectrum table out of range");
 	}
 	for (const auto& m : s.materials) {
-		if (m.kind > PRGPU_MAT_ROUGH_DIELECTRIC || m.albedo >= d->n_spectra)
+		if (m.kind > PRGPU_MAT_PRINCIPLED || m.albedo >= d->n_spectra)
 			return fail("bad material");
 		if ((m.kind == PRGPU_MAT_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_CONDUCTOR) && (m.ior >= d->n_spectra || m.k >= d->n_spectra))
 			return fail("bad conductor material");
 		if ((m.kind == PRGPU_MAT_DIELECTRIC || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC) && (m.ior >= d->n_spectra || (m.transmission != INVALID && m.transmission >= d->n_spectra)))
 			return fail("bad dielectric material");
+		if (m.kind == PRGPU_MAT_PRINCIPLED) {
+			if (m.ior >= d->n_spectra)
+				return fail("bad principled material");
+			if (m.flags & PRGPU_MATF_NO_VNDF)
+				return fail("principled without vndf sampling is not supported");
+			for (int i = 0; i < PRGPU_PRINCIPLED_COUNT; ++i)
+				if (!std::isfinite(m.principled[i]))
+					return fail("bad principled parameter");
+			if (!std::isfinite(m.roughness_x) || !(m.principled[PRGPU_PRINCIPLED_ANISOTROPIC] * 0.9f < 1.0f))
+				return fail("bad principled roughness / anisotropy");
+		}
 		if (m.kind == PRGPU_MAT_ROUGH_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC) {
 			if (!(m.roughness_x >= 0.0f) || !((m.flags & PRGPU_MATF_ANISOTROPIC) == 0 || m.roughness_y >= 0.0f) || !std::isfinite(m.roughness_x) || !std::isfinite(m.roughness_y))
 				return fail("bad roughness");
@@ -3153,14 +3468,7 @@ float orc_mf_reflection(int what, float m1, float m2, int aniso, int vndf, const
 		return mf_reflection_eval(d, wIn, wOut, true, ior, kappa);
 	if (what == 2)
 		return mf_reflection_pdf(d, wIn, wOut);
-	// MicrofacetReflection::eval (MicrofacetReflection.h:76-90)
-	if (!sv_same_hemisphere(wIn, wOut))
-		return 0.0f;
-	const V3 H = normalized_or_zero(wIn + wOut);
-	if (d.is_delta())
-		return 1.0f;
-	const float cosI = dot(H, wIn);
-	return d.dg_norm(H, wIn, wOut) * reflective_jacobian(cosI);
+	return mf_reflection_eval_plain(d, wIn, wOut);
 }
 void orc_reflect(const float v[3], float out[3]) // Scattering::reflect(V) in shading space (Scattering.h:69-72)
 {

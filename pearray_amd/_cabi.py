@@ -9,12 +9,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libprgpu.so")
 
-PRGPU_API_VERSION = 3
+PRGPU_API_VERSION = 4
 INVALID_ID = 0xFFFFFFFF
 
 SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER = range(6)
-MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_ROUGH_CONDUCTOR, MAT_ROUGH_DIELECTRIC = 0, 1, 2, 3, 4
-MATF_ANISOTROPIC, MATF_NO_VNDF = 1, 2
+MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_ROUGH_CONDUCTOR, MAT_ROUGH_DIELECTRIC, MAT_PRINCIPLED = 0, 1, 2, 3, 4, 5
+MATF_ANISOTROPIC, MATF_NO_VNDF, MATF_HAS_TRANSMISSION = 1, 2, 4
+PRINCIPLED_PARAMS = ("diffuse_transmission", "specular_transmission", "specular_tint", "anisotropic", "flatness", "metallic", "sheen",
+                     "sheen_tint", "clearcoat", "clearcoat_gloss")
 ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE = 0, 1, 2
 LIGHT_ENVIRONMENT, LIGHT_DISTANT = 0, 1
 CAMERA_PERSPECTIVE, CAMERA_ORTHO = 0, 1
@@ -39,7 +41,7 @@ class Spectrum(C.Structure):
 class Material(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("albedo", C.c_uint32), ("two_sided", C.c_uint32), ("ior", C.c_uint32),
                 ("transmission", C.c_uint32), ("thin", C.c_uint32), ("k", C.c_uint32), ("flags", C.c_uint32),
-                ("roughness_x", C.c_float), ("roughness_y", C.c_float)]
+                ("roughness_x", C.c_float), ("roughness_y", C.c_float), ("principled", C.c_float * 10)]
 
 
 class Emission(C.Structure):

@@ -639,6 +639,21 @@ __device__ __forceinline__ float g1_smith_lambda(V3 K, float rx, float ry, bool 
 	const float b = sv_tan2_theta(K);
 	return (sqrtf(1 + a * b) - 1) / 2;
 }
+// Microfacet.h:46-53 g_1_smith_opt (isotropic; 1/(4 NdotV NdotL) multiplied out)
+__device__ __forceinline__ float g1_smith_opt(float NdotK, float roughness)
+{
+	const float a	  = roughness * roughness;
+	const float b	  = NdotK * NdotK;
+	const float denom = NdotK + sqrtf(a + b - a * b);
+	return denom <= PR_EPS ? 0.0f : 1.0f / denom;
+}
+// Fresnel.h:61-71 schlick_term, schlick
+__device__ __forceinline__ float schlick_term(float d)
+{
+	const float t = 1 - d;
+	return (t * t) * (t * t) * t;
+}
+__device__ __forceinline__ float schlick(float d, float f0) { return f0 + (1 - f0) * schlick_term(d); }
 // Microfacet.h:225-228 pdf_ggx, :266-271 pdf_ggx_vndf (always the two-roughness forms)
 __device__ __forceinline__ float pdf_ggx(V3 H, float rx, float ry, bool aniso) { return ndf_ggx(H, rx, ry, aniso) * fabsf(H.z); }
 __device__ __forceinline__ float pdf_ggx_vndf(V3 V, V3 H, float rx, float ry)
@@ -749,7 +764,7 @@ __device__ __forceinline__ float refractive_jacobian(float eta, float cosI, floa
 	return denom2 <= PR_EPS ? 0.0f : fabsf(cosO) / denom2;
 }
 // MicrofacetReflection.h
-__device__ __forceinline__ float mf_reflection_eval(const RoughDistribution& d, V3 wIn, V3 wOut, bool conductor, float n_in_or_ior, float n_out_or_kappa) // :31-74
+static __device__ __noinline__ float mf_reflection_eval(const RoughDistribution& d, V3 wIn, V3 wOut, bool conductor, float n_in_or_ior, float n_out_or_kappa) // :31-74
 {
 	if (!sv_same_hemisphere(wIn, wOut))
 		return 0.0f;
@@ -763,7 +778,18 @@ __device__ __forceinline__ float mf_reflection_eval(const RoughDistribution& d, 
 	const float jacobian = reflective_jacobian(cosI);
 	return F * d.dg_norm(H, wIn, wOut) * jacobian;
 }
-__device__ __forceinline__ float mf_reflection_pdf(const RoughDistribution& d, V3 wIn, V3 wOut) // :92-105 (H is not flipped here)
+static __device__ __noinline__ float mf_reflection_eval_plain(const RoughDistribution& d, V3 wIn, V3 wOut) // :76-90 eval() without a Fresnel term
+{
+	if (!sv_same_hemisphere(wIn, wOut))
+		return 0.0f;
+	const V3 H = normalized_or_zero(wIn + wOut);
+	if (d.is_delta())
+		return 1.0f;
+	const float cosI	 = dot(H, wIn);
+	const float jacobian = reflective_jacobian(cosI);
+	return d.dg_norm(H, wIn, wOut) * jacobian;
+}
+static __device__ __noinline__ float mf_reflection_pdf(const RoughDistribution& d, V3 wIn, V3 wOut) // :92-105 (H is not flipped here)
 {
 	if (!sv_same_hemisphere(wIn, wOut))
 		return 0.0f;
@@ -774,7 +800,7 @@ __device__ __forceinline__ float mf_reflection_pdf(const RoughDistribution& d, V
 	const float jacobian = reflective_jacobian(cosI);
 	return jacobian * d.pdf(H, wIn);
 }
-__device__ __forceinline__ V3 mf_reflection_sample(const RoughDistribution& d, float u0, float u1, V3 wIn) // :107-120
+static __device__ __noinline__ V3 mf_reflection_sample(const RoughDistribution& d, float u0, float u1, V3 wIn) // :107-120
 {
 	const V3 H = d.sample(u0, u1, wIn);
 	if (v3_is_zero(H, PR_EPS))
@@ -800,7 +826,7 @@ __device__ __forceinline__ bool mf_transmission_halfway(V3 wIn, V3 wOut, float i
 	eta = in_ior / out_ior;
 	return true;
 }
-__device__ __forceinline__ float mf_transmission_eval(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :34-63, camera paths (spread = 1)
+static __device__ __noinline__ float mf_transmission_eval(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :34-63, camera paths (spread = 1)
 {
 	V3 H;
 	float cosI, cosO, eta;
@@ -813,7 +839,7 @@ __device__ __forceinline__ float mf_transmission_eval(const RoughDistribution& d
 	const float spread	 = 1.0f;
 	return (1 - F) * d.dg_norm(H, wIn, wOut) * jacobian * spread;
 }
-__device__ __forceinline__ float mf_transmission_pdf(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :93-118
+static __device__ __noinline__ float mf_transmission_pdf(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :93-118
 {
 	V3 H;
 	float cosI, cosO, eta;
@@ -824,7 +850,7 @@ __device__ __forceinline__ float mf_transmission_pdf(const RoughDistribution& d,
 	const float jacobian = refractive_jacobian(eta, cosI, cosO);
 	return d.pdf(H, wIn) * jacobian;
 }
-__device__ __forceinline__ V3 mf_transmission_sample(const RoughDistribution& d, float u0, float u1, V3 wIn, float inner, float outer) // :120-139
+static __device__ __noinline__ V3 mf_transmission_sample(const RoughDistribution& d, float u0, float u1, V3 wIn, float inner, float outer) // :120-139
 {
 	const V3 H = d.sample(u0, u1, wIn);
 	if (v3_is_zero(H, PR_EPS))

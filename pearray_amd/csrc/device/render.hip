@@ -743,6 +743,8 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 // FULL = false is the lean variant for scenes with Lambert materials, mesh entities and area lights only (DevScene::features == 0,
 // e.g. the C4 benchmark scene): delta materials, infinite lights and plane entities are compiled out, which keeps their registers
 // and spills out of the hot kernel.
+// one shared out-of-line copy of the spectral node evaluation for the (cold, large) rough / principled closures
+static __device__ __noinline__ Blob spectrum_eval_cold(const DevScene& sc, uint32_t id, const Blob& wl) { return spectrum_eval(sc, id, wl); }
 // ---- material evaluation for next event estimation: IMaterial::eval in tangent space ---------------------
 __device__ __forceinline__ RoughDistribution rough_distribution(const prgpu_material& m)
 {
@@ -776,10 +778,271 @@ __device__ __forceinline__ Blob rough_dielectric_pdf(const RoughDistribution& d,
 		p.v[i] = mf_transmission_pdf(d, V, L, DIELECTRIC_AIR, ior.v[i]);
 	return (blob(1) - F) * p;
 }
+// PrincipledClosure (principled.cpp:31-436), camera paths (no light-path eta^2 factor)
+struct Principled {
+	Blob base, ior, cie_y; // cie_y: CIE::eval_y of the path's wavelengths (tintColor, :171-179)
+	float diff_trans, roughness, anisotropic, spec_trans, spec_tint, flatness, metallic, sheen, sheen_tint, clearcoat, clearcoat_gloss;
+	bool thin, has_trans, vndf;
+
+	__device__ __forceinline__ static float mix(float v0, float v1, float t) { return (1 - t) * v0 + t * v1; } // :38-42
+	__device__ __forceinline__ static float schlick_r0(float eta)												  // :44-48
+	{
+		const float factor = (eta - 1.0f) / (eta + 1.0f);
+		return factor * factor;
+	}
+	__device__ __forceinline__ float thin_transmission_roughness() const { return fmaxf(0.0f, fminf(1.0f, (0.65f * (bsum(ior) / 4) - 0.35f) * roughness)); } // :86-89
+	__device__ __forceinline__ RoughDistribution roughness_closure(float r) const																					  // :91-97
+	{
+		const float aspect = sqrtf(1 - anisotropic * 0.9f);
+		const float ax	   = fmaxf(0.001f, r * r / aspect);
+		const float ay	   = fmaxf(0.001f, r * r * aspect);
+		return RoughDistribution{ ax, ay, true, vndf };
+	}
+	__device__ __forceinline__ bool is_delta() const { return roughness_closure(roughness).is_delta(); }
+	struct Lobes {
+		float diff_refl, diff_trans, spec_refl, spec_trans;
+	};
+	__device__ __forceinline__ Lobes lobe_distribution(V3 V) const // :111-139
+	{
+		Lobes d;
+		d.diff_refl = roughness * roughness * (1.0f - metallic) * (1.0f - spec_trans);
+		d.spec_refl = 1;
+		if (has_trans) {
+			const float F = fresnel_dielectric(V.z, DIELECTRIC_AIR, ior.v[0]);
+			d.diff_trans  = diff_trans * d.diff_refl;
+			d.spec_trans  = (1.0f - F) * (1.0f - metallic) * spec_trans;
+			d.spec_refl *= F;
+		} else {
+			d.diff_trans = 0;
+			d.spec_trans = 0;
+		}
+		const float norm = d.diff_refl + d.spec_refl + d.diff_trans + d.spec_trans;
+		if (norm <= PR_EPS)
+			return Lobes{ 1.0f, 0.0f, 0.0f, 0.0f };
+		d.diff_refl /= norm;
+		d.spec_refl /= norm;
+		d.diff_trans /= norm;
+		d.spec_trans /= norm;
+		return d;
+	}
+	__device__ __forceinline__ Blob tint_color() const // :171-179
+	{
+		float lum = 0;
+		for (int i = 0; i < 4; ++i)
+			lum = fmaxf(lum, base.v[i] * cie_y.v[i]);
+		return lum > PR_EPS ? base / lum : blob(1);
+	}
+	__device__ __forceinline__ Blob disney_fresnel(float HdotV, float HdotL) const // :141-169
+	{
+		Blob res;
+		if (metallic <= 1e-4f) {
+			for (int i = 0; i < 4; ++i)
+				res.v[i] = fresnel_dielectric(HdotV, DIELECTRIC_AIR, ior.v[i]);
+			return res;
+		}
+		const Blob color = tint_color();
+		for (int i = 0; i < 4; ++i) {
+			const float eta = HdotV < 0 ? DIELECTRIC_AIR / ior.v[i] : ior.v[i] / DIELECTRIC_AIR;
+			const float r0	= mix(schlick_r0(eta) * mix(1.0f, color.v[i], spec_tint), base.v[i], metallic);
+			const float f1	= fresnel_dielectric(HdotV, DIELECTRIC_AIR, ior.v[i]);
+			const float f2	= schlick(fabsf(HdotL), r0);
+			res.v[i]			= mix(f1, f2, metallic);
+		}
+		return res;
+	}
+	__device__ __forceinline__ float retro_diffuse(V3 V, V3 L, float HdotL) const // :186-194
+	{
+		const float alpha2 = roughness * roughness;
+		const float fd90   = 0.5f + 2 * HdotL * HdotL * alpha2;
+		const float lk	   = schlick_term(fabsf(L.z));
+		const float vk	   = schlick_term(fabsf(V.z));
+		return PR_INV_PI_F * fd90 * (lk + vk + lk * vk * (fd90 - 1.0f));
+	}
+	__device__ __forceinline__ float subsurface(V3 V, V3 L, float HdotL) const // :196-210
+	{
+		const float alpha2 = roughness * roughness;
+		const float fss90  = HdotL * HdotL * alpha2;
+		const float lk	   = schlick_term(fabsf(L.z));
+		const float vk	   = schlick_term(fabsf(V.z));
+		const float fss	   = mix(1.0f, fss90, lk) * mix(1.0f, fss90, vk);
+		const float f	   = fabsf(L.z) + fabsf(V.z);
+		if (fabsf(f) < PR_EPS)
+			return 0.0f;
+		return 1.25f * (fss * (1.0f / f - 0.5f) + 0.5f);
+	}
+	__device__ __forceinline__ float diffuse_term(V3 V, V3 L, float HdotL) const // :213-225
+	{
+		const float lk = schlick_term(fabsf(L.z));
+		const float vk = schlick_term(fabsf(V.z));
+		float diffuse  = 1;
+		if (thin)
+			diffuse = mix(1.0f, subsurface(V, L, HdotL), flatness);
+		return PR_INV_PI_F * diffuse * (1 - 0.5f * lk) * (1 - 0.5f * vk);
+	}
+	__device__ __forceinline__ float clearcoat_term(V3 V, V3 L, V3 H) const // :250-263
+	{
+		const float F0 = 0.04f, R = 0.25f;
+		const float D  = ndf_ggx(H, mix(0.1f, 0.001f, clearcoat_gloss), 0.0f, false);
+		const float hk = schlick_term(fabsf(dot(H, L)));
+		const float F  = mix(F0, 1.0f, hk);
+		const float G  = g1_smith_opt(fabsf(L.z), R) * g1_smith_opt(fabsf(V.z), R);
+		return R * D * F * G;
+	}
+	__device__ __forceinline__ Blob eval(V3 V, V3 L) const // :274-344
+	{
+		if (fabsf(V.z) <= PR_EPS || fabsf(L.z) <= PR_EPS)
+			return blob(0);
+		const float diffuseWeight  = (1.0f - metallic) * (1.0f - spec_trans);
+		const bool isTransmission  = !sv_same_hemisphere(V, L);
+		const bool upperHemisphere = V.z >= 0.0f && !isTransmission;
+		if (!has_trans && isTransmission)
+			return blob(0);
+		const V3 rH		  = normalized_or_zero(V + L);
+		const float HdotL = dot(rH, L);
+		Blob value		  = blob(0);
+		const float absL  = fabsf(L.z);
+		if (diffuseWeight > 1e-4f) {
+			if (!isTransmission) { // retro-reflection + sheen
+				const float retro = retro_diffuse(V, L, HdotL) * diffuseWeight;
+				Blob sh			  = blob(0);
+				if (!(sheen <= 1e-4f)) { // sheenTerm :265-272, sheenTintColor :181-184
+					const Blob tint = tint_color();
+					const float st	= schlick_term(fabsf(HdotL));
+					for (int i = 0; i < 4; ++i)
+						sh.v[i] = sheen * mix(1.0f, tint.v[i], sheen_tint) * st;
+				}
+				sh = sh * diffuseWeight;
+				for (int i = 0; i < 4; ++i)
+					value.v[i] += (retro * base.v[i] + sh.v[i]) * absL;
+			}
+			if (!isTransmission) { // diffuse reflection
+				const float diff = diffuse_term(V, L, HdotL) * (thin ? 1 - diff_trans : diffuseWeight);
+				for (int i = 0; i < 4; ++i)
+					value.v[i] += base.v[i] * (diff * absL);
+			}
+			if (has_trans && thin && isTransmission) { // diffuse transmission
+				const float diff = diffuse_term(V, L, HdotL) * diff_trans;
+				for (int i = 0; i < 4; ++i)
+					value.v[i] += base.v[i] * (diff * absL);
+			}
+		}
+		{ // specular reflection :227-236
+			const RoughDistribution micro = roughness_closure(roughness);
+			const float HdotV			  = dot(V, rH);
+			const float HdotL2			  = dot(L, rH);
+			const Blob F				  = disney_fresnel(HdotV, HdotL2);
+			const float m				  = mf_reflection_eval_plain(micro, V, L);
+			for (int i = 0; i < 4; ++i)
+				value.v[i] += F.v[i] * m;
+		}
+		if (has_trans) { // specular refraction :238-248,322-336
+			const float transmissionWeight = (1.0f - metallic) * spec_trans;
+			if (transmissionWeight > 1e-4f) {
+				const float scaledR			  = thin ? thin_transmission_roughness() : roughness;
+				const RoughDistribution micro = roughness_closure(scaledR);
+				for (int i = 0; i < 4; ++i) {
+					const float R = mf_transmission_eval(micro, V, L, DIELECTRIC_AIR, ior.v[i]);
+					const float w = thin ? sqrtf(base.v[i]) * R : base.v[i] * R;
+					value.v[i] += transmissionWeight * w;
+				}
+			}
+		}
+		if (upperHemisphere && clearcoat > 1e-4f) {
+			const float c = clearcoat_term(V, L, rH);
+			for (int i = 0; i < 4; ++i)
+				value.v[i] += c;
+		}
+		return value;
+	}
+	__device__ __forceinline__ Blob pdf(V3 V, V3 L) const // :346-397
+	{
+		if (fabsf(V.z) <= PR_EPS || fabsf(L.z) <= PR_EPS)
+			return blob(0);
+		const Lobes distr		  = lobe_distribution(V);
+		const bool isTransmission = !sv_same_hemisphere(V, L);
+		const float diffPdf		  = fabsf(L.z) * PR_INV_PI_F;
+		Blob pdfV				  = blob(0);
+		if (!isTransmission) {
+			for (int i = 0; i < 4; ++i)
+				pdfV.v[i] += distr.diff_refl * diffPdf;
+			if (distr.spec_refl > 1e-4f) {
+				const float r = mf_reflection_pdf(roughness_closure(roughness), V, L);
+				for (int i = 0; i < 4; ++i)
+					pdfV.v[i] += distr.spec_refl * r;
+			}
+		}
+		if (has_trans && isTransmission) {
+			for (int i = 0; i < 4; ++i)
+				pdfV.v[i] += distr.diff_trans * diffPdf;
+			if (distr.spec_trans > 1e-4f) {
+				const RoughDistribution micro = roughness_closure(roughness);
+				for (int i = 0; i < 4; ++i)
+					pdfV.v[i] += distr.spec_trans * mf_transmission_pdf(micro, V, L, DIELECTRIC_AIR, ior.v[i]);
+			}
+		}
+		return pdfV;
+	}
+	__device__ __forceinline__ V3 sample(uint64_t& rnd, V3 V) const // :399-435
+	{
+		if (fabsf(V.z) <= PR_EPS)
+			return v3(0, 0, 0);
+		const Lobes distr = lobe_distribution(V);
+		const float u0	  = rng_float(rnd);
+		const float a = rng_float(rnd), b = rng_float(rnd); // every branch draws two more numbers
+		if (u0 < distr.diff_refl || u0 < distr.diff_refl + distr.diff_trans) {
+			const V3 Ld = cos_hemi(a, b);
+			const V3 Lf = V.z < 0 ? -Ld : Ld; // sampleDiffuse :399-404
+			return u0 < distr.diff_refl ? Lf : -Lf;
+		}
+		if (u0 < distr.diff_refl + distr.diff_trans + distr.spec_trans)
+			return mf_transmission_sample(roughness_closure(roughness), a, b, V, DIELECTRIC_AIR, ior.v[0]);
+		return mf_reflection_sample(roughness_closure(roughness), a, b, V);
+	}
+};
+// out-of-line entry points: the closure's lobes are large, and every caller shares one copy
+static __device__ __noinline__ void principled_eval_pdf(const Principled& c, V3 V, V3 L, Blob& weight, Blob& pdf)
+{
+	weight = c.eval(V, L);
+	pdf	   = c.pdf(V, L);
+}
+static __device__ __noinline__ V3 principled_sample(const Principled& c, uint64_t& rnd, V3 V) { return c.sample(rnd, V); }
+__device__ __forceinline__ Principled principled_closure(const DevScene& s, const prgpu_material& m, const Blob& wl, const Blob& cie_y) // createClosure :475-497, ctor :63-84
+{
+	Principled p;
+	p.base = spectrum_eval_cold(s, m.albedo, wl);
+	p.ior  = spectrum_eval_cold(s, m.ior, wl);
+	p.cie_y = cie_y;
+	p.has_trans		  = (m.flags & PRGPU_MATF_HAS_TRANSMISSION) != 0;
+	p.thin			  = m.thin != 0;
+	p.vndf			  = (m.flags & PRGPU_MATF_NO_VNDF) == 0;
+	p.diff_trans	  = p.has_trans ? m.principled[PRGPU_PRINCIPLED_DIFFUSE_TRANSMISSION] : 0.0f;
+	p.spec_trans	  = p.has_trans ? m.principled[PRGPU_PRINCIPLED_SPECULAR_TRANSMISSION] : 0.0f;
+	p.roughness		  = m.roughness_x;
+	p.anisotropic	  = m.principled[PRGPU_PRINCIPLED_ANISOTROPIC];
+	p.spec_tint		  = m.principled[PRGPU_PRINCIPLED_SPECULAR_TINT];
+	p.flatness		  = m.principled[PRGPU_PRINCIPLED_FLATNESS];
+	p.metallic		  = m.principled[PRGPU_PRINCIPLED_METALLIC];
+	p.sheen			  = m.principled[PRGPU_PRINCIPLED_SHEEN];
+	p.sheen_tint	  = m.principled[PRGPU_PRINCIPLED_SHEEN_TINT];
+	p.clearcoat		  = m.principled[PRGPU_PRINCIPLED_CLEARCOAT];
+	p.clearcoat_gloss = m.principled[PRGPU_PRINCIPLED_CLEARCOAT_GLOSS];
+	return p;
+}
 // RoughConductorMaterial::eval (roughconductor.cpp:41-65), RoughDielectricMaterial::eval (roughdielectric.cpp:184-205).
 // `delta`: MaterialSampleFlag::DeltaDistribution.  Out of line: only scenes with rough materials pay for it.
-__device__ __noinline__ void rough_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
+__device__ __noinline__ void rough_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
 {
+	if (mat.kind == PRGPU_MAT_PRINCIPLED) { // PrincipledMaterial::eval (principled.cpp:499-528)
+		const Principled c = principled_closure(s, mat, wl, cie_y);
+		delta			   = c.is_delta();
+		if (delta) {
+			weight = blob(0);
+			pdf	   = blob(0);
+			return;
+		}
+		principled_eval_pdf(c, Vt, Lt, weight, pdf);
+		return;
+	}
 	const RoughDistribution d = rough_distribution(mat);
 	delta					  = d.is_delta();
 	if (delta) {
@@ -788,26 +1051,26 @@ __device__ __noinline__ void rough_eval(const DevScene& s, const prgpu_material&
 		return;
 	}
 	if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR) {
-		const Blob eta = spectrum_eval(s, mat.ior, wl), kk = spectrum_eval(s, mat.k, wl);
+		const Blob eta = spectrum_eval_cold(s, mat.ior, wl), kk = spectrum_eval_cold(s, mat.k, wl);
 		Blob factor;
 		for (int i = 0; i < 4; ++i)
 			factor.v[i] = mf_reflection_eval(d, Lt, Vt, true, eta.v[i], kk.v[i]);
-		weight = spectrum_eval(s, mat.albedo, wl) * factor;
+		weight = spectrum_eval_cold(s, mat.albedo, wl) * factor;
 		pdf	   = blob(mf_reflection_pdf(d, Lt, Vt));
 	} else {
-		const Blob spec	 = spectrum_eval(s, mat.albedo, wl);
-		const Blob trans = mat.transmission != INVALID ? spectrum_eval(s, mat.transmission, wl) : spec;
-		const Blob ior	 = spectrum_eval(s, mat.ior, wl);
+		const Blob spec	 = spectrum_eval_cold(s, mat.albedo, wl);
+		const Blob trans = mat.transmission != INVALID ? spectrum_eval_cold(s, mat.transmission, wl) : spec;
+		const Blob ior	 = spectrum_eval_cold(s, mat.ior, wl);
 		weight			 = rough_dielectric_eval(d, Vt, Lt, spec, trans, ior);
 		pdf				 = rough_dielectric_pdf(d, Vt, Lt, ior);
 	}
 }
 // IMaterial::eval for next event estimation: LambertMaterial::eval (lambert.cpp:33-42) inline, the rough closures out of line
 template <bool FULL>
-__device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
+__device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
 {
-	if (FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC)) {
-		rough_eval(s, mat, wl, Vt, Lt, weight, pdf, delta);
+	if (FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED)) {
+		rough_eval(s, mat, wl, cie_y, Vt, Lt, weight, pdf, delta);
 		return;
 	}
 	delta			= false;
@@ -817,9 +1080,27 @@ __device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_mat
 	pdf				= blob(dt * PR_INV_PI_F);
 }
 // RoughConductorMaterial::sample (roughconductor.cpp:83-117), RoughDielectricMaterial::sample (roughdielectric.cpp:222-254)
-__device__ __noinline__ void rough_sample(const DevScene& s, const prgpu_material& mat, const Blob& wl, V3 Vt, uint64_t& rnd, V3& Lt, Blob& integral_weight, Blob& pdf_s, bool& delta,
-						 bool& hero_collapsing)
+__device__ __noinline__ void rough_sample(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, uint64_t& rnd, V3& Lt, Blob& integral_weight, Blob& pdf_s,
+										  bool& delta, bool& hero_collapsing)
 {
+	if (mat.kind == PRGPU_MAT_PRINCIPLED) { // PrincipledMaterial::sample (principled.cpp:548-590)
+		const Principled c = principled_closure(s, mat, wl, cie_y);
+		Lt				   = principled_sample(c, rnd, Vt);
+		delta			   = c.is_delta();
+		hero_collapsing	   = false; // the material sets no SpectralVarying flag
+		if (v3_is_zero(Lt, 1e-5f)) {
+			Lt				= v3(0, 0, 0);
+			integral_weight = blob(0);
+			pdf_s			= blob(0);
+			return;
+		}
+		principled_eval_pdf(c, Vt, Lt, integral_weight, pdf_s);
+		if (pdf_s.v[0] > PR_EPS)
+			integral_weight = integral_weight / pdf_s.v[0];
+		if (delta)
+			pdf_s = blob(1);
+		return;
+	}
 	const RoughDistribution d = rough_distribution(mat);
 	delta					  = d.is_delta();
 	if (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR) {
@@ -832,16 +1113,16 @@ __device__ __noinline__ void rough_sample(const DevScene& s, const prgpu_materia
 			pdf_s			= blob(0);
 			return;
 		}
-		const Blob eta = spectrum_eval(s, mat.ior, wl), kk = spectrum_eval(s, mat.k, wl);
+		const Blob eta = spectrum_eval_cold(s, mat.ior, wl), kk = spectrum_eval_cold(s, mat.k, wl);
 		Blob factor;
 		for (int i = 0; i < 4; ++i)
 			factor.v[i] = mf_reflection_eval(d, Lt, Vt, true, eta.v[i], kk.v[i]);
-		integral_weight = spectrum_eval(s, mat.albedo, wl) * factor;
+		integral_weight = spectrum_eval_cold(s, mat.albedo, wl) * factor;
 		pdf_s			= blob(mf_reflection_pdf(d, Lt, Vt));
 	} else {
-		const Blob spec	 = spectrum_eval(s, mat.albedo, wl);
-		const Blob trans = mat.transmission != INVALID ? spectrum_eval(s, mat.transmission, wl) : spec;
-		const Blob ior	 = spectrum_eval(s, mat.ior, wl);
+		const Blob spec	 = spectrum_eval_cold(s, mat.albedo, wl);
+		const Blob trans = mat.transmission != INVALID ? spectrum_eval_cold(s, mat.transmission, wl) : spec;
+		const Blob ior	 = spectrum_eval_cold(s, mat.ior, wl);
 		hero_collapsing	 = delta && (s.spectra[mat.ior].kind == PRGPU_SPEC_SELLMEIER);
 		// RoughDielectricClosure::sample (roughdielectric.cpp:124-137): branch on the hero wavelength's Fresnel term
 		const float F  = fresnel_dielectric(Vt.z, DIELECTRIC_AIR, ior.v[0]);
@@ -1021,7 +1302,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
 			uint64_t rnd			 = ps.rng[pixel];
 			const bool deltaMat		 = FULL && (mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR); // IMaterial::hasOnlyDeltaDistribution
-			const bool roughMat		 = FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC);
+			const bool roughMat		 = FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED);
+			const Blob cie_y_blob	 = blob4(cie.y[0], cie.y[1], cie.y[2], cie.y[3]);
 			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + (FULL ? sc.n_inf_lights : 0u))) { // direct.cpp:100-101
 				// ---- handleNEE
 				do {
@@ -1055,7 +1337,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
 						Blob weight, bsdf_pdf;
 						bool evalDelta;
-						material_eval<FULL>(sc, mat, wl, Vt, Lt, weight, bsdf_pdf, evalDelta);
+						material_eval<FULL>(sc, mat, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
 						if (evalDelta) // direct.cpp:269-270
 							break;
 						const Blob bsdfWvlPdfS = bsdf_pdf * hf;
@@ -1142,7 +1424,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
 					Blob weight, bsdf_pdf;
 					bool evalDelta;
-					material_eval<FULL>(sc, mat, wl, Vt, Lt, weight, bsdf_pdf, evalDelta);
+					material_eval<FULL>(sc, mat, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
 					if (evalDelta) // direct.cpp:269-270
 						break;
 					const Blob bsdfWvlPdfS = bsdf_pdf * hf;
@@ -1203,7 +1485,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				bool heroCollapsing = false;
 				bool sampleDelta	= deltaMat;
 				if (roughMat) {
-					rough_sample(sc, mat, wl, Vt, rnd, Lt, integral_weight, pdf_s, sampleDelta, heroCollapsing);
+					rough_sample(sc, mat, wl, cie_y_blob, Vt, rnd, Lt, integral_weight, pdf_s, sampleDelta, heroCollapsing);
 				} else if (FULL && mat.kind == PRGPU_MAT_CONDUCTOR) {
 					// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
 					pdf_s		   = blob(1);

@@ -585,12 +585,42 @@ struct Loader {
 			m.k			   = spectral_param(g, { "k", "kappa" }, 2.605f);
 			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);
 			m.transmission = PRGPU_INVALID_ID;
+		} else if (type == "principled") { // principled.cpp:634-687 (scalar nodes: constants only)
+			m.kind		   = PRGPU_MAT_PRINCIPLED;
+			m.albedo	   = spectral_param(g, { "base_color", "base" }, 0.8f);
+			m.ior		   = spectral_param(g, { "ior", "eta", "index" }, 1.55f);
+			m.transmission = PRGPU_INVALID_ID;
+			m.thin		   = get_bool(g, "thin", false) ? 1 : 0;
+			auto scalar	   = [&](std::initializer_list<const char*> keys, float def) -> float {
+				   for (const char* key : keys)
+					   if (const Value* v = g.get(key)) {
+						   if (!v->is_number())
+							   fail(PRGPU_EUNSUPPORTED, where(g) + ": :" + key + " must be a number (textured principled parameters are not supported)");
+						   return (float)v->number();
+					   }
+				   return def;
+			};
+			m.roughness_x = m.roughness_y						= scalar({ "roughness" }, 0.5f);
+			m.principled[PRGPU_PRINCIPLED_DIFFUSE_TRANSMISSION]	= scalar({ "diffuse_transmission", "diff_trans" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_SPECULAR_TRANSMISSION] = scalar({ "specular_transmission", "spec_trans" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_SPECULAR_TINT]		= scalar({ "specular_tint" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_ANISOTROPIC]			= scalar({ "anisotropic" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_FLATNESS]				= scalar({ "flatness", "subsurface" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_METALLIC]				= scalar({ "metallic" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_SHEEN]				= scalar({ "sheen" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_SHEEN_TINT]			= scalar({ "sheen_tint" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_CLEARCOAT]			= scalar({ "clearcoat" }, 0.0f);
+			m.principled[PRGPU_PRINCIPLED_CLEARCOAT_GLOSS]		= scalar({ "clearcoat_gloss" }, 0.0f);
+			if (g.get("specular_transmission") || g.get("spec_trans") || g.get("diffuse_transmission") || g.get("diff_trans")) // :657-666
+				m.flags |= PRGPU_MATF_HAS_TRANSMISSION;
+			if (!get_bool(g, "vndf", true))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": principled with :vndf false is not supported (anisotropic closure)");
 		} else if (type == "diffuse" || type == "lambert") {
 			m.kind		= PRGPU_MAT_LAMBERT;
 			m.albedo	= spectral_param(g, { "albedo", "base", "diffuse" }, 1.0f);
 			m.two_sided = get_bool(g, "two_sided", true) ? 1 : 0;
 		} else {
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert, glass/dielectric, conductor/metal and their rough variants are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": material type '" + type + "' is not supported (diffuse/lambert, glass/dielectric, conductor/metal, their rough variants and principled are)");
 		}
 		material_ids[name] = (uint32_t)out.materials.size();
 		out.materials.push_back(m);

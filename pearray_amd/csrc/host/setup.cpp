@@ -698,7 +698,7 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 	}
 	for (uint32_t i = 0; i < d->n_materials; ++i) {
 		const prgpu_material& m = d->materials[i];
-		if (m.kind > PRGPU_MAT_ROUGH_DIELECTRIC)
+		if (m.kind > PRGPU_MAT_PRINCIPLED)
 			return bad("unknown material kind", PRGPU_EUNSUPPORTED);
 		const bool conductor = m.kind == PRGPU_MAT_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_CONDUCTOR;
 		const bool glass	 = m.kind == PRGPU_MAT_DIELECTRIC || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC;
@@ -708,6 +708,17 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 			return bad("material albedo index out of range");
 		if (glass && (m.ior >= d->n_spectra || (m.transmission != PRGPU_INVALID_ID && m.transmission >= d->n_spectra)))
 			return bad("dielectric index / transmission spectrum out of range");
+		if (m.kind == PRGPU_MAT_PRINCIPLED) {
+			if (m.ior >= d->n_spectra)
+				return bad("principled index spectrum out of range");
+			if (m.flags & PRGPU_MATF_NO_VNDF)
+				return bad("the principled closure is anisotropic: sampling without vndf is not supported", PRGPU_EUNSUPPORTED);
+			for (int k = 0; k < PRGPU_PRINCIPLED_COUNT; ++k)
+				if (!std::isfinite(m.principled[k]))
+					return bad("principled parameters must be finite");
+			if (!std::isfinite(m.roughness_x) || !(m.principled[PRGPU_PRINCIPLED_ANISOTROPIC] * 0.9f < 1.0f))
+				return bad("principled roughness must be finite and anisotropic < 1/0.9");
+		}
 		if (m.kind == PRGPU_MAT_ROUGH_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC) {
 			const bool aniso = (m.flags & PRGPU_MATF_ANISOTROPIC) != 0;
 			if (!(m.roughness_x >= 0.0f) || !std::isfinite(m.roughness_x) || !std::isfinite(m.roughness_y) || (aniso && !(m.roughness_y >= 0.0f)))

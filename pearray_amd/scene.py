@@ -152,6 +152,21 @@ class SceneBuilder:
                                            flags, rx, ry))
         return len(self.materials) - 1
 
+    def principled(self, base=None, ior=None, roughness=0.5, thin=False, vndf=True, **params):
+        """(material :type 'principled'), principled.cpp:634-687; `params`: the scalars of _cabi.PRINCIPLED_PARAMS.  Giving either
+        transmission parameter (even 0) selects the HasTransmission closure, like the reference's hasParameter test."""
+        base = self.spectrum_const(0.8) if base is None else base
+        ior = self.spectrum_const(1.55) if ior is None else ior
+        unknown = set(params) - set(abi.PRINCIPLED_PARAMS)
+        if unknown:
+            raise TypeError("unknown principled parameters: %s" % sorted(unknown))
+        flags = (0 if vndf else abi.MATF_NO_VNDF) | (abi.MATF_HAS_TRANSMISSION if ("diffuse_transmission" in params or "specular_transmission" in params) else 0)
+        m = abi.Material(abi.MAT_PRINCIPLED, base, 0, ior, abi.INVALID_ID, 1 if thin else 0, 0, flags, float(roughness), float(roughness))
+        for i, name in enumerate(abi.PRINCIPLED_PARAMS):
+            m.principled[i] = float(params.get(name, 0.0))
+        self.materials.append(m)
+        return len(self.materials) - 1
+
     def diffuse_emission(self, radiance):
         self.emissions.append(abi.Emission(abi.EMS_DIFFUSE, radiance))
         return len(self.emissions) - 1

@@ -71,7 +71,7 @@ def test_error_reporting_without_a_gpu():
     sc.desc.settings.filter_radius = 9
     assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -4  # PRGPU_EUNSUPPORTED
     sc = scene.cornell_box(8, 8, spp=1)
-    sc.materials[0].kind = 5
+    sc.materials[0].kind = 9
     assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -4
     assert lib.prgpu_rgb_to_coeffs(None, None) == -1
     bad = (C.c_float * 3)(float("nan"), 0, 0)

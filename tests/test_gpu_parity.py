@@ -584,3 +584,25 @@ def test_rough_materials_under_infinite_lights():
     b.distant_light(b.spectrum_const(2.0), direction=(0.2, 0.3, -1.0))
     g, o = render_both(b.build())
     assert_parity(g, o, exact=True)
+
+
+def cornell_principled(w=48, h=48, spp=6, **settings):
+    b = scene.SceneBuilder(w, h)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_MJITT, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+    scene._cornell_into(b, material_override={
+        "shortBox": lambda bb: bb.principled(base=bb.refl(0.8, 0.3, 0.2), roughness=0.4, metallic=0.6, specular_tint=0.5, clearcoat=0.5, clearcoat_gloss=0.8),
+        "tallBox": lambda bb: bb.principled(roughness=0.25, specular_transmission=0.8, ior=bb.lookup_index("bk7")),
+        "leftWall": lambda bb: bb.principled(base=bb.refl(0.2, 0.4, 0.9), sheen=0.7, sheen_tint=0.4, anisotropic=0.7, roughness=0.6),
+        "rightWall": lambda bb: bb.principled(thin=True, diffuse_transmission=0.4, specular_transmission=0.3, flatness=0.6, roughness=0.5),
+        "floor": lambda bb: bb.principled()})
+    return b.build()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mis=abi.MIS_POWER), dict(spectral_hero=0), dict(nee=0), dict(spectral_mono=1, spectral_start=520.0, spectral_end=830.0)])
+def test_principled_material(kw):
+    """principled.cpp closures (metallic / clearcoat, transmissive with a dispersive index, sheen + anisotropy, thin with diffuse transmission,
+    plugin defaults) under NEE + MIS."""
+    g, o = render_both(cornell_principled(**kw))
+    assert_parity(g, o, exact=True)

@@ -197,3 +197,105 @@ def test_loader_material_names():
         assert m.roughness_x == np.float32(rx) and m.roughness_y == np.float32(ry)
     with pytest.raises(RuntimeError, match="vndf"):
         scene.PrcScene(source=body % ":type 'roughmetal' :roughness_x 0.1 :roughness_y 0.2 :vndf false")
+
+
+# ---- principled (principled.cpp) ----------------------------------------------------------------------------------------
+
+def principled_scene(**kw):
+    b = scene.SceneBuilder(8, 8)
+    if "base_rgb" in kw:
+        kw["base"] = b.refl(*kw.pop("base_rgb"))
+    if kw.pop("dispersive", False):
+        kw["ior"] = b.lookup_index("bk7")
+    mat = b.principled(**kw)
+    b.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]], mat)
+    sc = b.build()
+    return sc, ob.OracleScene(sc), mat
+
+
+PRINCIPLED_CASES = [dict(),  # the plugin defaults, as materials.cpp creates it
+                    dict(metallic=0.8, specular_tint=0.5, base_rgb=(0.8, 0.5, 0.2)),
+                    dict(sheen=0.7, sheen_tint=0.4, clearcoat=0.8, clearcoat_gloss=0.3, base_rgb=(0.2, 0.4, 0.9)),
+                    dict(specular_transmission=0.7, roughness=0.3, dispersive=True),
+                    dict(thin=True, diffuse_transmission=0.4, specular_transmission=0.3, flatness=0.6),
+                    dict(anisotropic=0.8, roughness=0.35, metallic=1.0)]
+
+
+@pytest.mark.parametrize("kw", PRINCIPLED_CASES)
+@pytest.mark.parametrize("backside", [False, True])
+def test_principled_sample_agrees_with_eval(kw, backside):
+    """materials.cpp:90-135 'Eval = Sample' for the principled plugin, front and back."""
+    sc, o, mat = principled_scene(**dict(kw))
+    V = norm(1, 0, 1) * (np.float32(-1) if backside else np.float32(1))
+    state = C.c_uint64(0)
+    o.lib.orc_pcg_seed(42, C.byref(state))
+    checked = 0
+    for _ in range(96):
+        L, iw, pdf = (C.c_float * 3)(), (C.c_float * 4)(), (C.c_float * 4)()
+        delta, hc = C.c_int(), C.c_int()
+        o.lib.orc_rough_sample(o.h, mat, f32(*WVL), f32(*V), C.byref(state), L, iw, pdf, C.byref(delta), C.byref(hc))
+        assert not delta.value and not hc.value
+        if list(L) == [0, 0, 0]:
+            assert list(iw) == [0, 0, 0, 0] and list(pdf) == [0, 0, 0, 0]
+            continue
+        w, p, d = (C.c_float * 4)(), (C.c_float * 4)(), C.c_int()
+        o.lib.orc_material_eval(o.h, mat, f32(*WVL), f32(*V), L, w, p, C.byref(d))
+        for k in range(4):
+            assert np.isfinite(w[k]) and w[k] >= 0 and p[k] >= 0
+            assert abs(pdf[k] - p[k]) <= NEARLY * max(1.0, abs(p[k]))
+            if pdf[0] > 1.2e-7:
+                assert abs(iw[k] * pdf[0] - w[k]) <= NEARLY * max(1.0, abs(w[k]))
+        checked += 1
+    assert checked > 40
+
+
+def test_principled_lobes():
+    """Closed forms: a non-metallic, non-transmissive surface seen and lit head-on is Lambert-like (base/pi times the Schlick
+    retro/diffuse factors, which are 1 at normal incidence ... plus the specular lobe); transmission needs the parameter to be given;
+    the sampler only produces the lower hemisphere for a transmissive closure."""
+    sc, o, mat = principled_scene(roughness=1.0)
+    V = L = norm(0, 0, 1)
+    w, p, d = (C.c_float * 4)(), (C.c_float * 4)(), C.c_int()
+    o.lib.orc_material_eval(o.h, mat, f32(*WVL), f32(*V), f32(*L), w, p, C.byref(d))
+    # diffuse: 0.8/pi; retro: 0.8/pi * fd90 * 0 (Schlick terms vanish at normal incidence); specular: F(1.55) * D*G/(4 cos) > 0
+    assert w[0] > 0.8 / np.pi and w[0] < 0.8 / np.pi + 0.05
+    below = norm(0.2, 0.1, -1)
+    o.lib.orc_material_eval(o.h, mat, f32(*WVL), f32(*V), f32(*below), w, p, C.byref(d))
+    assert list(w) == [0, 0, 0, 0] and list(p) == [0, 0, 0, 0]
+    sc, o, mat = principled_scene(specular_transmission=1.0, roughness=0.4)
+    o.lib.orc_material_eval(o.h, mat, f32(*WVL), f32(*V), f32(*below), w, p, C.byref(d))
+    assert w[0] > 0 and p[0] > 0
+    state, n_below = C.c_uint64(99), 0
+    for _ in range(200):
+        Ls, iw, pdf = (C.c_float * 3)(), (C.c_float * 4)(), (C.c_float * 4)()
+        delta, hc = C.c_int(), C.c_int()
+        o.lib.orc_rough_sample(o.h, mat, f32(*WVL), f32(*norm(0.3, 0, 1)), C.byref(state), Ls, iw, pdf, C.byref(delta), C.byref(hc))
+        n_below += Ls[2] < 0
+    assert n_below > 100  # (1 - F) * spec_trans dominates the lobe selection
+
+
+def test_principled_cornell_renders_and_loader():
+    b = scene.SceneBuilder(24, 24)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_MJITT, 8
+    scene._cornell_into(b, material_override={
+        "shortBox": lambda bb: bb.principled(base=bb.refl(0.8, 0.3, 0.2), roughness=0.4, metallic=0.6, clearcoat=0.5, clearcoat_gloss=0.8),
+        "tallBox": lambda bb: bb.principled(roughness=0.25, specular_transmission=0.8, ior=bb.lookup_index("bk7"))})
+    o = ob.OracleScene(b.build())
+    o.render(8)
+    xyz = o.output()[0]
+    assert np.isfinite(xyz).all() and xyz.mean() > 0.01
+    body = """(scene :render_width 8 :render_height 8
+      (camera :name 'c' :type 'standard')
+      (material :name 'm' :type 'principled' %s)
+      (mesh :name 'q' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,2]))
+      (entity :name 'e' :type 'mesh' :mesh 'q' :materials 'm'))"""
+    s = scene.PrcScene(source=body % "")
+    m = s.desc.materials[0]
+    assert m.kind == abi.MAT_PRINCIPLED and m.flags == 0 and m.roughness_x == 0.5 and list(m.principled) == [0.0] * 10
+    assert s.desc.spectra[m.albedo].p[0] == np.float32(0.8) and s.desc.spectra[m.ior].p[0] == np.float32(1.55)
+    s = scene.PrcScene(source=body % ":base (refl 0.5 0.2 0.1) :roughness 0.2 :spec_trans 0 :metallic 0.3 :subsurface 0.25 :clearcoat_gloss 1 :thin true")
+    m = s.desc.materials[0]
+    assert m.flags == abi.MATF_HAS_TRANSMISSION and m.thin == 1 and m.roughness_x == np.float32(0.2)
+    assert m.principled[5] == np.float32(0.3) and m.principled[4] == np.float32(0.25) and m.principled[9] == 1.0
+    with pytest.raises(RuntimeError, match="must be a number"):
+        scene.PrcScene(source=body % ":roughness 'tex'")

@@ -103,7 +103,7 @@ def test_defaults_follow_the_reference():
     ("(entity :name 's' :type 'cone' :radius 1)", -4, "entity type 'cone'"),
     ("(emission :name 'l' :type 'standard') (entity :name 's' :type 'sphere' :emission 'l')", -4, "emissive sphere"),
     ("(material :name 'g' :type 'glass' :roughness 'tex')", -4, "must be a number"),
-    ("(material :name 'g' :type 'principled')", -4, "material type 'principled'"),
+    ("(material :name 'g' :type 'ward')", -4, "material type 'ward'"),
     ("(material :name 'g' :type 'metal' :roughness_x 0.1 :roughness_y 0.2 :vndf false)", -4, "vndf"),
     ("(light :name 'sky' :type 'sky')", -4, "light type 'sky'"),
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
