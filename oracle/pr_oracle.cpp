@@ -283,6 +283,29 @@ inline void sincos_2pi(float u, float& s, float& c)
 	default: s = -cs; c = sn; break;
 	}
 }
+// sin/cos of an angle in radians through the same reduction (the argument is scaled by 1/(2 pi) in fp32; plane.cpp:152-153 calls
+// std::cos / std::sin, which differ from this by an ulp or so -- shared with the device so that both sides agree bit for bit)
+inline void sincos_rad(float x, float& s, float& c) { sincos_2pi(x * 0.15915494309189533577f, s, c); }
+// acos on [-1, 1] (Cephes asinf/acosf minimax polynomial, fp32 operations only); plane.cpp:109 safe_acos clamps the argument
+inline float asin_poly(float x) // |x| <= 0.5
+{
+	const float z = x * x;
+	float p		  = 4.2163199048e-2f;
+	p			  = p * z + 2.4181311049e-2f;
+	p			  = p * z + 4.5470025998e-2f;
+	p			  = p * z + 7.4953002686e-2f;
+	p			  = p * z + 1.6666752422e-1f;
+	return (p * z) * x + x;
+}
+inline float safe_acos(float a)
+{
+	const float x = std::max(-1.0f, std::min(1.0f, a));
+	if (x < -0.5f)
+		return 3.14159265358979323846f - 2.0f * asin_poly(std::sqrt((1.0f + x) * 0.5f));
+	if (x > 0.5f)
+		return 2.0f * asin_poly(std::sqrt((1.0f - x) * 0.5f));
+	return 1.57079632679489661923f - asin_poly(x);
+}
 
 // base/math/Sampling.h:38-57 cos_hemi
 inline V3 cos_hemi(float u1, float u2)
@@ -563,6 +586,18 @@ inline V3 linear_mul(const float m[16], V3 v)
 	return v3((m[0] * v.x + m[1] * v.y) + m[2] * v.z, (m[4] * v.x + m[5] * v.y) + m[6] * v.z, (m[8] * v.x + m[9] * v.y) + m[10] * v.z);
 }
 
+// Transformf::inverse() of an affine transform (ITransformable.cpp:11): linear^-1 = (normal matrix)^T, translation = -linear^-1 * t
+inline void affine_inverse(const float m[16], float out[12])
+{
+	float nm[9], det;
+	normal_matrix(m, nm, det);
+	for (int r = 0; r < 3; ++r) {
+		for (int c = 0; c < 3; ++c)
+			out[4 * r + c] = nm[3 * c + r];
+		out[4 * r + 3] = -((out[4 * r] * m[3] + out[4 * r + 1] * m[7]) + out[4 * r + 2] * m[11]);
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // Watertight ray/triangle test (Woop, Benthin, Wald 2013).  Stands in for Embree's robust
 // triangle intersector behind rtcIntersect1/rtcOccluded1 (Scene.cpp:220-280); Embree is an
@@ -685,6 +720,13 @@ struct Scene {
 	std::vector<std::array<float, 9>> nmat; // per entity normal matrix
 	std::vector<float> vol_scale;		   // |det linear|
 	std::vector<float> world_area;		   // IEntity::worldSurfaceArea
+	struct ShapeLight { // area-light data of analytic entities: PlaneEntity::cache (plane.cpp:227-243), SphereEntity (sphere.cpp:23-31)
+		V3 S, Ex, Ey, Ez, nrm; // plane: world corner, unit axes, unit normal, normalMatrix * plane.normal() (NOT normalised, plane.cpp:177)
+		float width = 0, height = 0;
+		float inv[12];		   // sphere: invTransform (rows of the affine inverse)
+		float pdf_cache = 0;   // sphere: 1 / worldSurfaceArea
+	};
+	std::vector<ShapeLight> shape_light; // per entity
 	std::vector<V3> sphere_c;			   // SPHERE entities: world centre (transform * 0) ...
 	std::vector<float> sphere_r;		   // ... and world radius (sphere.cpp:77-92)
 	float eps_t = 0;					   // slab-test slack, 8e-6 * max |coordinate| (world vertices, camera origin)
@@ -1922,6 +1964,92 @@ inline float rr_probability(const Scene& s, uint32_t path_length, bool delta = f
 	return path_length < s.rr_prob.size() ? s.rr_prob[path_length] : s.rr_prob.back();
 }
 
+// ---- area lights on analytic entities ---------------------------------------------------------------------
+// PlaneEntity::computeSQ (plane.cpp:111-145): the spherical rectangle the plane subtends from `o` (Urena et al. 2013)
+struct SphericalQuad {
+	V3 o, n;
+	float z0, x0, y0, x1, y1, b0, b1, k, S;
+};
+inline SphericalQuad compute_sq(const Scene::ShapeLight& P, V3 o)
+{
+	SphericalQuad sq;
+	sq.o	   = o;
+	sq.n	   = P.Ez;
+	const V3 d = P.S - o;
+	sq.x0	   = dot(d, P.Ex);
+	sq.y0	   = dot(d, P.Ey);
+	sq.z0	   = dot(d, sq.n);
+	sq.x1	   = sq.x0 + P.width;
+	sq.y1	   = sq.y0 + P.height;
+	if (sq.z0 > 0.0f) {
+		sq.z0 = -sq.z0;
+		sq.n  = -sq.n;
+	}
+	const float a[4] = { sq.x0, sq.y1, sq.x1, sq.y0 }, b[4] = { sq.x1, sq.y0, sq.x0, sq.y1 }, c[4] = { sq.y0, sq.x1, sq.y1, sq.x0 };
+	float nz[4];
+	for (int i = 0; i < 4; ++i) {
+		const float diff = a[i] - b[i];
+		const float v	 = c[i] * diff;
+		nz[i]			 = v / std::sqrt(sq.z0 * sq.z0 * diff * diff + v * v);
+	}
+	const float g0 = safe_acos(-nz[0] * nz[1]);
+	const float g1 = safe_acos(-nz[1] * nz[2]);
+	const float g2 = safe_acos(-nz[2] * nz[3]);
+	const float g3 = safe_acos(-nz[3] * nz[0]);
+	sq.b0		   = nz[0];
+	sq.b1		   = nz[2];
+	sq.k		   = 2 * PR_PI_F - g2 - g3;
+	sq.S		   = g0 + g1 - sq.k;
+	return sq;
+}
+// PlaneEntity::sampleParameterPoint(info, rnd) (plane.cpp:147-182): position and area pdf
+inline void plane_light_sample(const Scene::ShapeLight& P, V3 origin, float r0, float r1, V3& p, float& pdf_a)
+{
+	const SphericalQuad sq = compute_sq(P, origin);
+	const float au		   = std::fma(r0, sq.S, sq.k);
+	float sau, cau;
+	sincos_rad(au, sau, cau);
+	const float fu = std::fma(cau, sq.b0, -sq.b1) / sau;
+	const float cu = std::min(1.0f, std::max(-1.0f, std::copysign(1.0f, fu) / std::sqrt(sum_prod(fu, fu, sq.b0, sq.b0))));
+	const float xu = std::min(sq.x1, std::max(sq.x0, -(cu * sq.z0) / std::max(1e-7f, std::sqrt(std::fma(-cu, cu, 1.0f)))));
+	const float d  = std::sqrt(sum_prod(xu, xu, sq.z0, sq.z0));
+	const float h0 = sq.y0 / std::sqrt(sum_prod(d, d, sq.y0, sq.y0));
+	const float h1 = sq.y1 / std::sqrt(sum_prod(d, d, sq.y1, sq.y1));
+	const float hv = std::fma(r1, h1 - h0, h0);
+	const float hv2 = hv * hv;
+	const float yv	= (hv2 < 1.0f - 1e-6f) ? (hv * d) / std::sqrt(1.0f - hv2) : sq.y1;
+	p				= ((sq.o + P.Ex * xu) + P.Ey * yv) + sq.n * sq.z0;
+	const float pdf_s = sq.S > PR_EPS ? 1 / sq.S : 0.0f;
+	const V3 L		  = p - origin;
+	const float dist2 = dot(L, L);
+	const float ndotv = std::fabs(dot(normalized_or_zero(L), P.nrm));
+	pdf_a			  = ndotv <= PR_EPS ? 0.0f : pdf_s * ndotv / dist2; // IS::toArea
+}
+// PlaneEntity::sampleParameterPointPDF(p, info) (plane.cpp:184-195)
+inline float plane_light_pdf(const Scene::ShapeLight& P, V3 p, V3 origin)
+{
+	const float S	  = compute_sq(P, origin).S;
+	const float pdf_s = S > PR_EPS ? 1 / S : 0.0f;
+	const V3 L		  = p - origin;
+	const float dist2 = dot(L, L);
+	const float ndotv = std::fabs(dot(normalized_or_zero(L), P.nrm));
+	return ndotv <= PR_EPS ? 0.0f : pdf_s * std::fabs(ndotv) / dist2;
+}
+// SphereEntity::sampleParameterPoint(info, rnd) (sphere.cpp:106-116): Spherical::cartesian_from_uv (theta = v pi: not area-uniform, as
+// in the reference), flipped towards the observer; pdf = 2 / area
+inline void sphere_light_sample(const Scene::ShapeLight& P, const prgpu_entity& E, V3 origin, float r0, float r1, V3& p, float& pdf_a)
+{
+	float sth, cth, sph, cph;
+	sincos_2pi(0.5f * r1, sth, cth);
+	sincos_2pi(r0, sph, cph);
+	V3 n		   = v3(sth * cph, sth * sph, cth);
+	const V3 local = normalized_or_zero(affine_mul(P.inv, origin));
+	if (dot(local, n) < -PR_EPS)
+		n = -n;
+	p	  = affine_mul(E.transform, n * E.radius);
+	pdf_a = 2 * P.pdf_cache;
+}
+
 // ---- material evaluation for next event estimation: IMaterial::eval in tangent space ---------------------
 inline RoughDistribution rough_distribution(const prgpu_material& m)
 {
@@ -2520,6 +2648,10 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 					const uint32_t lid	= s.entity_light[gp.entity];
 					const float selProb = s.light_cdf[lid + 1] - s.light_cdf[lid]; // pdfEntitySelection
 					float posPDF		= 1.0f / s.world_area[gp.entity];		   // IEntity.h:93-96
+					if (s.entities[gp.entity].kind == PRGPU_ENTITY_PLANE) // seen from the previous vertex (the world origin for camera rays)
+						posPDF = plane_light_pdf(s.shape_light[gp.entity], P, cur.last_pos);
+					else if (s.entities[gp.entity].kind == PRGPU_ENTITY_SPHERE)
+						posPDF = 2 * s.shape_light[gp.entity].pdf_cache; // sphere.cpp:118
 					posPDF				= posPDF * depth2 / std::fabs(cosC);	   // IS::toSolidAngle
 					const float posPDF_S = posPDF * selProb;
 					const float denom	 = bsum(mis_b(cur.prev_path_pdf * posPDF_S)) + bsum(mis_b(cur.path_pdf));
@@ -2620,32 +2752,42 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				}
 				const uint32_t le  = s.light_entity[lid];
 				const prgpu_entity& LE = s.entities[le];
-				// MeshEntity::sampleParameterPoint (mesh.cpp:187-203) with SplitSample2D (SplitSample.h:6-55)
-				const float u0 = rng_float(rnd), u1 = rng_float(rnd);
-				float k0, k1;
-				const float f0		= std::modf(u0 * LE.n_tris, &k0);
-				const float f1		= std::modf(u1 * LE.n_tris, &k1);
-				const uint32_t face = std::min<uint32_t>((uint32_t)k0, LE.n_tris - 1);
-				(void)k1;
-				const uint32_t tri = LE.first_tri + face;
-				const uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
-				const V3 p0 = load3(s.positions, i0), p1 = load3(s.positions, i1), p2 = load3(s.positions, i2);
-				const V3 ee = cross(p1 - p0, p2 - p0);
-				const float area  = 0.5f * std::sqrt(dot(ee, ee)); // Triangle::surfaceArea (local space)
-				const float pdf_a = 1.0f / (LE.n_tris * area * s.vol_scale[le]);
-				float bu, bv; // Triangle::sample (Triangle.h:46-55)
-				if (f1 > f0) {
-					const float x = f0 / 2;
-					bu = x;
-					bv = f1 - x;
-				} else {
-					const float y = f1 / 2;
-					bu = f0 - y;
-					bv = y;
-				}
-				const V3 lp = affine_mul(LE.transform, tri_interp(p0, p1, p2, bu, bv));
+				const float u0 = rng_float(rnd), u1 = rng_float(rnd); // in.RND.get2D() (Light.cpp:161-162)
+				V3 lp;
+				float pdf_a;
 				GeomPoint lgp;
-				geometry_point(s, tri, bu, bv, lp, lgp);
+				if (LE.kind == PRGPU_ENTITY_PLANE) { // spherical-rectangle sampling from the shading point
+					plane_light_sample(s.shape_light[le], P, u0, u1, lp, pdf_a);
+					lgp.N = s.shape_light[le].Ez; // PlaneEntity::provideGeometryPoint (plane.cpp:206-220)
+				} else if (LE.kind == PRGPU_ENTITY_SPHERE) {
+					sphere_light_sample(s.shape_light[le], LE, P, u0, u1, lp, pdf_a);
+					lgp.N = normalized_or_zero(lp - s.sphere_c[le]); // SphereEntity::provideGeometryPoint (sphere.cpp:128-134)
+				} else {
+					// MeshEntity::sampleParameterPoint (mesh.cpp:187-203) with SplitSample2D (SplitSample.h:6-55)
+					float k0, k1;
+					const float f0		= std::modf(u0 * LE.n_tris, &k0);
+					const float f1		= std::modf(u1 * LE.n_tris, &k1);
+					const uint32_t face = std::min<uint32_t>((uint32_t)k0, LE.n_tris - 1);
+					(void)k1;
+					const uint32_t tri = LE.first_tri + face;
+					const uint32_t i0 = s.indices[3 * tri], i1 = s.indices[3 * tri + 1], i2 = s.indices[3 * tri + 2];
+					const V3 p0 = load3(s.positions, i0), p1 = load3(s.positions, i1), p2 = load3(s.positions, i2);
+					const V3 ee = cross(p1 - p0, p2 - p0);
+					const float area = 0.5f * std::sqrt(dot(ee, ee)); // Triangle::surfaceArea (local space)
+					pdf_a			 = 1.0f / (LE.n_tris * area * s.vol_scale[le]);
+					float bu, bv; // Triangle::sample (Triangle.h:46-55)
+					if (f1 > f0) {
+						const float x = f0 / 2;
+						bu = x;
+						bv = f1 - x;
+					} else {
+						const float y = f1 / 2;
+						bu = f0 - y;
+						bv = y;
+					}
+					lp = affine_mul(LE.transform, tri_interp(p0, p1, p2, bu, bv));
+					geometry_point(s, tri, bu, bv, lp, lgp);
+				}
 				// Light::sample area branch (light/Light.cpp:159-225)
 				const V3 L			 = normalized(lp - P);
 				const float cosLight = std::min(1.0f, std::max(-1.0f, -dot(L, lgp.N)));
@@ -2945,9 +3087,9 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("emission index out of range");
 		if (E.has_normals && !s.has_normals_array)
 			return fail("entity wants normals but none given");
-		if (E.kind > PRGPU_ENTITY_SPHERE || (E.kind == PRGPU_ENTITY_PLANE && (E.n_tris != 2 || E.emission != INVALID)))
+		if (E.kind > PRGPU_ENTITY_SPHERE || (E.kind == PRGPU_ENTITY_PLANE && E.n_tris != 2))
 			return fail("bad plane entity");
-		if (E.kind == PRGPU_ENTITY_SPHERE && (E.n_tris != 1 || E.emission != INVALID || !(E.radius > 0)))
+		if (E.kind == PRGPU_ENTITY_SPHERE && (E.n_tris != 1 || !(E.radius > 0)))
 			return fail("bad sphere entity");
 		for (uint32_t t = 0; t < E.n_tris; ++t)
 			s.tri_entity[E.first_tri + t] = e;
@@ -3016,6 +3158,38 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			area += 0.5f * std::sqrt(dot(ee, ee)); // MeshBase::surfaceArea (identity transform)
 		}
 		s.world_area[e] = s.vol_scale[e] * area;
+	}
+	s.shape_light.assign(d->n_entities, Scene::ShapeLight());
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& E = s.entities[e];
+		Scene::ShapeLight& L  = s.shape_light[e];
+		const float* m		  = E.transform;
+		if (E.kind == PRGPU_ENTITY_PLANE) {
+			const uint32_t t0 = E.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0 (plane.cpp:282-296)
+			const V3 v0 = load3(s.positions, s.indices[3 * t0]), v1 = load3(s.positions, s.indices[3 * t0 + 1]), v3p = load3(s.positions, s.indices[3 * t0 + 2]);
+			const V3 x = v3p - v0, y = v1 - v0;
+			L.S		 = affine_mul(m, v0);
+			L.Ex	 = linear_mul(m, x);
+			L.Ey	 = linear_mul(m, y);
+			L.nrm	 = mat3_mul(s.nmat[e].data(), normalized(cross(x, y)));
+			L.Ez	 = L.nrm;
+			L.width	 = std::sqrt(dot(L.Ex, L.Ex));
+			L.height = std::sqrt(dot(L.Ey, L.Ey));
+			L.Ex	 = normalized(L.Ex);
+			L.Ey	 = normalized(L.Ey);
+			L.Ez	 = normalized(L.Ez);
+			s.world_area[e] = L.width * L.height; // PlaneEntity::worldSurfaceArea (plane.cpp:48-54)
+		} else if (E.kind == PRGPU_ENTITY_SPHERE) {
+			// SphereEntity::worldSurfaceArea (sphere.cpp:49-66): Knud Thomsen's formula on the scaled radii; the scaling of a rotation * scale
+			// matrix is the vector of its column norms (Eigen computeRotationScaling)
+			auto col_norm = [&](int j) { return std::sqrt((m[j] * m[j] + m[4 + j] * m[4 + j]) + m[8 + j] * m[8 + j]); };
+			const float a = col_norm(0) * E.radius, b = col_norm(1) * E.radius, c = col_norm(2) * E.radius;
+			const float P = 1.6075f;
+			const float t = (std::pow(a * b, P) + std::pow(a * c, P) + std::pow(b * c, P)) / 3;
+			s.world_area[e] = 4 * PR_PI_F * std::pow(t, 1 / P);
+			L.pdf_cache		= E.radius > PR_EPS ? 1 / s.world_area[e] : 0.0f;
+			affine_inverse(m, L.inv);
+		}
 	}
 	s.sphere_c.assign(d->n_entities, v3(0, 0, 0));
 	s.sphere_r.assign(d->n_entities, 0.0f);

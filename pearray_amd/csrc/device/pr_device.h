@@ -14,6 +14,7 @@ namespace prd {
 
 constexpr float PR_EPS		= 1.1920928955078125e-7f; // FLT_EPSILON, config/Constants.inl:4
 constexpr float PR_INV_PI_F = 0.31830988618379067154f;
+constexpr float PR_PI_F	  = 3.14159265358979323846f; // Constants.inl:8
 constexpr uint32_t INVALID	= PRGPU_INVALID_ID;
 // vcm/Defaults.h:4-13
 constexpr float SHADOW_RAY_MIN = 0.0001f;
@@ -53,7 +54,18 @@ struct DevEntity {
 	uint32_t pad;
 };
 
-constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u;
+constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u, FEAT_SHAPE_LIGHTS = 32u;
+
+// Area-light data of an analytic entity (one per entity, meaningful for emissive planes and spheres):
+// PlaneEntity::cache (plane.cpp:227-243) and SphereEntity (sphere.cpp:23-31,106-118)
+struct DevShapeLight {
+	float S[3], Ex[3], Ey[3], Ez[3], nrm[3]; // plane: world corner, unit axes, unit normal, normalMatrix * plane.normal() (not normalised)
+	float width, height;
+	float inv[12];	 // sphere: invTransform (3 rows of 4)
+	float pdf_cache; // sphere: 1 / worldSurfaceArea
+	float radius;	 // sphere: local radius
+	float pad[2];
+};
 constexpr uint32_t PRIM_SPHERE_BIT = 0x40000000u; // leaf records: the primitive in this slot is an analytic sphere (centre, radius), not a triangle
 
 // Infinite light (include/prgpu.h prgpu_light) with the matrices the kernels need
@@ -87,6 +99,7 @@ struct DevScene {
 	const float* light_cdf;
 	uint32_t n_lights; // area lights; the infinite lights follow them in light_cdf
 	const DevInfLight* inf_lights;
+	const DevShapeLight* shape_lights; // per entity, or null when no plane / sphere emits
 	uint32_t n_inf_lights;
 	float scene_radius; // origin-centred bounding sphere (Scene.cpp:107-118)
 	uint32_t features;	// FEAT_* bits the scene needs beyond Lambert + meshes + area lights (selects the kernel variant)
@@ -121,6 +134,7 @@ struct PathState {
 	float4* throughput;
 	float4* path_pdf;
 	float4* prev_pdf;
+	float4* last_pos; // previous path vertex (TraversalContext::LastPosition, direct.cpp:55,175), kept for scenes with plane lights
 	uint32_t* flags; // depth | mono<<8 | last_delta<<9 | last_emissive<<10
 	uint32_t* iter;	 // sample index of the path currently living in the slot
 	float4* hit;	 // t,u,v, original tri index bits (INVALID on miss)
@@ -221,6 +235,29 @@ __device__ __forceinline__ void pr_sincos_2pi(float u, float& s, float& c)
 	case 2: s = -sn; c = -cs; break;
 	default: s = -cs; c = sn; break;
 	}
+}
+// sin/cos of an angle in radians through the same reduction (the argument is scaled by 1/(2 pi) in fp32; plane.cpp:152-153 calls
+// std::cos / std::sin, which differ from this by an ulp or so -- shared with the device so that both sides agree bit for bit)
+__device__ __forceinline__ void pr_sincos_rad(float x, float& s, float& c) { pr_sincos_2pi(x * 0.15915494309189533577f, s, c); }
+// acos on [-1, 1] (Cephes asinf/acosf minimax polynomial, fp32 operations only); plane.cpp:109 safe_acos clamps the argument
+__device__ __forceinline__ float asin_poly(float x) // |x| <= 0.5
+{
+	const float z = x * x;
+	float p		  = 4.2163199048e-2f;
+	p			  = p * z + 2.4181311049e-2f;
+	p			  = p * z + 4.5470025998e-2f;
+	p			  = p * z + 7.4953002686e-2f;
+	p			  = p * z + 1.6666752422e-1f;
+	return (p * z) * x + x;
+}
+__device__ __forceinline__ float safe_acos(float a)
+{
+	const float x = fmaxf(-1.0f, fminf(1.0f, a));
+	if (x < -0.5f)
+		return 3.14159265358979323846f - 2.0f * asin_poly(sqrtf((1.0f + x) * 0.5f));
+	if (x > 0.5f)
+		return 2.0f * asin_poly(sqrtf((1.0f - x) * 0.5f));
+	return 1.57079632679489661923f - asin_poly(x);
 }
 // Sampling.h:38-57
 __device__ __forceinline__ V3 cos_hemi(float u1, float u2)
@@ -859,6 +896,92 @@ static __device__ __noinline__ V3 mf_transmission_sample(const RoughDistribution
 	bool total;
 	const V3 L = refract_about(eta, wIn, H, total);
 	return total == sv_same_hemisphere(wIn, L) ? L : v3(0, 0, 0);
+}
+
+// ---- area lights on analytic entities ---------------------------------------------------------------------
+// PlaneEntity::computeSQ (plane.cpp:111-145): the spherical rectangle the plane subtends from `o` (Urena et al. 2013)
+struct SphericalQuad {
+	V3 o, n;
+	float z0, x0, y0, x1, y1, b0, b1, k, S;
+};
+__device__ __forceinline__ SphericalQuad compute_sq(const DevShapeLight& P, V3 o)
+{
+	SphericalQuad sq;
+	sq.o	   = o;
+	sq.n	   = v3(P.Ez[0], P.Ez[1], P.Ez[2]);
+	const V3 d = v3(P.S[0], P.S[1], P.S[2]) - o;
+	sq.x0	   = dot(d, v3(P.Ex[0], P.Ex[1], P.Ex[2]));
+	sq.y0	   = dot(d, v3(P.Ey[0], P.Ey[1], P.Ey[2]));
+	sq.z0	   = dot(d, sq.n);
+	sq.x1	   = sq.x0 + P.width;
+	sq.y1	   = sq.y0 + P.height;
+	if (sq.z0 > 0.0f) {
+		sq.z0 = -sq.z0;
+		sq.n  = -sq.n;
+	}
+	const float a[4] = { sq.x0, sq.y1, sq.x1, sq.y0 }, b[4] = { sq.x1, sq.y0, sq.x0, sq.y1 }, c[4] = { sq.y0, sq.x1, sq.y1, sq.x0 };
+	float nz[4];
+	for (int i = 0; i < 4; ++i) {
+		const float diff = a[i] - b[i];
+		const float v	 = c[i] * diff;
+		nz[i]			 = v / sqrtf(sq.z0 * sq.z0 * diff * diff + v * v);
+	}
+	const float g0 = safe_acos(-nz[0] * nz[1]);
+	const float g1 = safe_acos(-nz[1] * nz[2]);
+	const float g2 = safe_acos(-nz[2] * nz[3]);
+	const float g3 = safe_acos(-nz[3] * nz[0]);
+	sq.b0		   = nz[0];
+	sq.b1		   = nz[2];
+	sq.k		   = 2 * PR_PI_F - g2 - g3;
+	sq.S		   = g0 + g1 - sq.k;
+	return sq;
+}
+// PlaneEntity::sampleParameterPoint(info, rnd) (plane.cpp:147-182): position and area pdf
+static __device__ __noinline__ void plane_light_sample(const DevShapeLight& P, V3 origin, float r0, float r1, V3& p, float& pdf_a)
+{
+	const SphericalQuad sq = compute_sq(P, origin);
+	const float au		   = fmaf(r0, sq.S, sq.k);
+	float sau, cau;
+	pr_sincos_rad(au, sau, cau);
+	const float fu = fmaf(cau, sq.b0, -sq.b1) / sau;
+	const float cu = fminf(1.0f, fmaxf(-1.0f, copysignf(1.0f, fu) / sqrtf(sum_prod(fu, fu, sq.b0, sq.b0))));
+	const float xu = fminf(sq.x1, fmaxf(sq.x0, -(cu * sq.z0) / fmaxf(1e-7f, sqrtf(fmaf(-cu, cu, 1.0f)))));
+	const float d  = sqrtf(sum_prod(xu, xu, sq.z0, sq.z0));
+	const float h0 = sq.y0 / sqrtf(sum_prod(d, d, sq.y0, sq.y0));
+	const float h1 = sq.y1 / sqrtf(sum_prod(d, d, sq.y1, sq.y1));
+	const float hv = fmaf(r1, h1 - h0, h0);
+	const float hv2 = hv * hv;
+	const float yv	= (hv2 < 1.0f - 1e-6f) ? (hv * d) / sqrtf(1.0f - hv2) : sq.y1;
+	p				= ((sq.o + v3(P.Ex[0], P.Ex[1], P.Ex[2]) * xu) + v3(P.Ey[0], P.Ey[1], P.Ey[2]) * yv) + sq.n * sq.z0;
+	const float pdf_s = sq.S > PR_EPS ? 1 / sq.S : 0.0f;
+	const V3 L		  = p - origin;
+	const float dist2 = dot(L, L);
+	const float ndotv = fabsf(dot(normalized_or_zero(L), v3(P.nrm[0], P.nrm[1], P.nrm[2])));
+	pdf_a			  = ndotv <= PR_EPS ? 0.0f : pdf_s * ndotv / dist2; // IS::toArea
+}
+// PlaneEntity::sampleParameterPointPDF(p, info) (plane.cpp:184-195)
+static __device__ __noinline__ float plane_light_pdf(const DevShapeLight& P, V3 p, V3 origin)
+{
+	const float S	  = compute_sq(P, origin).S;
+	const float pdf_s = S > PR_EPS ? 1 / S : 0.0f;
+	const V3 L		  = p - origin;
+	const float dist2 = dot(L, L);
+	const float ndotv = fabsf(dot(normalized_or_zero(L), v3(P.nrm[0], P.nrm[1], P.nrm[2])));
+	return ndotv <= PR_EPS ? 0.0f : pdf_s * fabsf(ndotv) / dist2;
+}
+// SphereEntity::sampleParameterPoint(info, rnd) (sphere.cpp:106-116): Spherical::cartesian_from_uv (theta = v pi: not area-uniform, as
+// in the reference), flipped towards the observer; pdf = 2 / area
+static __device__ __noinline__ void sphere_light_sample(const DevShapeLight& P, const float* m, V3 origin, float r0, float r1, V3& p, float& pdf_a)
+{
+	float sth, cth, sph, cph;
+	pr_sincos_2pi(0.5f * r1, sth, cth);
+	pr_sincos_2pi(r0, sph, cph);
+	V3 n		   = v3(sth * cph, sth * sph, cth);
+	const V3 local = normalized_or_zero(affine_mul(P.inv, origin));
+	if (dot(local, n) < -PR_EPS)
+		n = -n;
+	p	  = affine_mul(m, n * P.radius);
+	pdf_a = 2 * P.pdf_cache;
 }
 
 // same acceptance rule for a box entry distance that was computed earlier (stack entries, re-checks)

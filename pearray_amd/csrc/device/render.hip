@@ -659,6 +659,8 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	ps.throughput[slot] = make_float4(1, 1, 1, 1);
 	ps.path_pdf[slot]  = make_float4(1, 1, 1, 1);
 	ps.prev_pdf[slot]  = make_float4(1, 1, 1, 1);
+	if (sc.features & FEAT_SHAPE_LIGHTS)
+		ps.last_pos[slot] = make_float4(0, 0, 0, 0); // TraversalContext::LastPosition starts at the world origin (direct.cpp:55)
 	ps.flags[slot]	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA;
 	ps.iter_xyz[3 * pixel + 0] = 0.0f;
 	ps.iter_xyz[3 * pixel + 1] = 0.0f;
@@ -1282,6 +1284,12 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const uint32_t lid	 = sc.entities[gp.entity].light_id;
 					const float selProb	 = sc.light_cdf[lid + 1] - sc.light_cdf[lid];
 					float posPDF		 = 1.0f / sc.entities[gp.entity].world_area;
+					if (FULL && sc.entities[gp.entity].kind == PRGPU_ENTITY_PLANE) { // seen from the previous vertex (plane.cpp:184-195)
+						const float4 lpos = ps.last_pos[slot];
+						posPDF			  = plane_light_pdf(sc.shape_lights[gp.entity], P, v3(lpos.x, lpos.y, lpos.z));
+					} else if (FULL && sc.entities[gp.entity].kind == PRGPU_ENTITY_SPHERE) {
+						posPDF = 2 * sc.shape_lights[gp.entity].pdf_cache; // sphere.cpp:118
+					}
 					posPDF				 = posPDF * depth2 / fabsf(cosC);
 					const float posPDF_S = posPDF * selProb;
 					const Blob a		 = prev_pdf * posPDF_S;
@@ -1388,30 +1396,41 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					}
 					const uint32_t le  = sc.light_entity[lid];
 					const DevEntity& LE = sc.entities[le];
-					const float u0 = rng_float(rnd), u1 = rng_float(rnd);
-					float k0, k1;
-					const float f0		= modff(u0 * LE.n_tris, &k0);
-					const float f1		= modff(u1 * LE.n_tris, &k1);
-					const uint32_t face = min((uint32_t)k0, LE.n_tris - 1);
-					const uint32_t ltri = LE.first_tri + face;
-					const uint32_t i0 = sc.indices[3 * ltri], i1 = sc.indices[3 * ltri + 1], i2 = sc.indices[3 * ltri + 2];
-					const V3 p0 = load3(sc.positions, i0), p1 = load3(sc.positions, i1), p2 = load3(sc.positions, i2);
-					const V3 ee		  = cross(p1 - p0, p2 - p0);
-					const float area  = 0.5f * sqrtf(dot(ee, ee));
-					const float pdf_a = 1.0f / (LE.n_tris * area * LE.vol_scale);
-					float bu, bv;
-					if (f1 > f0) {
-						const float x = f0 / 2;
-						bu = x;
-						bv = f1 - x;
-					} else {
-						const float y = f1 / 2;
-						bu = f0 - y;
-						bv = y;
-					}
-					const V3 lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
+					const float u0 = rng_float(rnd), u1 = rng_float(rnd); // in.RND.get2D() (Light.cpp:161-162)
+					V3 lp;
+					float pdf_a;
 					GeomPoint lgp;
-					geometry_point<FULL>(sc, ltri, bu, bv, lp, lgp);
+					if (FULL && LE.kind == PRGPU_ENTITY_PLANE) { // spherical-rectangle sampling from the shading point (plane.cpp:147-182)
+						const DevShapeLight& SL = sc.shape_lights[le];
+						plane_light_sample(SL, P, u0, u1, lp, pdf_a);
+						lgp.N = v3(SL.Ez[0], SL.Ez[1], SL.Ez[2]);
+					} else if (FULL && LE.kind == PRGPU_ENTITY_SPHERE) { // sphere.cpp:106-116,128-134
+						sphere_light_sample(sc.shape_lights[le], LE.m, P, u0, u1, lp, pdf_a);
+						lgp.N = normalized_or_zero(lp - v3(LE.m[3], LE.m[7], LE.m[11]));
+					} else {
+						float k0, k1;
+						const float f0		= modff(u0 * LE.n_tris, &k0);
+						const float f1		= modff(u1 * LE.n_tris, &k1);
+						const uint32_t face = min((uint32_t)k0, LE.n_tris - 1);
+						const uint32_t ltri = LE.first_tri + face;
+						const uint32_t i0 = sc.indices[3 * ltri], i1 = sc.indices[3 * ltri + 1], i2 = sc.indices[3 * ltri + 2];
+						const V3 p0 = load3(sc.positions, i0), p1 = load3(sc.positions, i1), p2 = load3(sc.positions, i2);
+						const V3 ee		 = cross(p1 - p0, p2 - p0);
+						const float area = 0.5f * sqrtf(dot(ee, ee));
+						pdf_a			 = 1.0f / (LE.n_tris * area * LE.vol_scale);
+						float bu, bv;
+						if (f1 > f0) {
+							const float x = f0 / 2;
+							bu = x;
+							bv = f1 - x;
+						} else {
+							const float y = f1 / 2;
+							bu = f0 - y;
+							bv = y;
+						}
+						lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
+						geometry_point<FULL>(sc, ltri, bu, bv, lp, lgp);
+					}
 					const V3 L			 = normalized(lp - P);
 					const float cosLight = fminf(1.0f, fmaxf(-1.0f, -dot(L, lgp.N)));
 					const Blob radiance	 = spectrum_eval(sc, sc.emissions[LE.emission].radiance, wl);
@@ -1558,6 +1577,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						ps.throughput[slot] = to4(throughput);
 						ps.path_pdf[slot]	= to4(path_pdf);
 						ps.prev_pdf[slot]	= to4(prev_pdf);
+						if (FULL && (sc.features & FEAT_SHAPE_LIGHTS))
+							ps.last_pos[slot] = make_float4(P.x, P.y, P.z, 0.0f); // current.LastPosition (direct.cpp:175)
 						ps.flags[slot]		= (flags & ~0xFFu) | nd;
 						atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
 						atomicAdd(&bs.v[PRGPU_STAT_BOUNCE_RAYS], 1u);

@@ -716,8 +716,6 @@ struct Loader {
 		for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
 			if (!get_bool(g, flag, true))
 				fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
-		if (g.get("emission"))
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": emissive plane entities are not supported yet (use a quad mesh)");
 		float xa[3] = { 1, 0, 0 }, ya[3] = { 0, 1, 0 };
 		if (!get_vec3(g, "x_axis", xa))
 			get_vec3(g, "axis_x", xa);
@@ -743,6 +741,14 @@ struct Loader {
 		e.first_tri = (uint32_t)(out.indices.size() / 3);
 		e.n_tris	= 2;
 		e.emission	= PRGPU_INVALID_ID;
+		{
+			const Value* ev = g.get("emission");
+			const auto it	= ev && ev->type == Value::STRING ? emission_ids.find(ev->s) : emission_ids.end();
+			if (ev && it == emission_ids.end())
+				fail(PRGPU_EINVAL, where(g) + ": entity '" + name + "' refers to an unknown emission");
+			if (ev)
+				e.emission = it->second;
+		}
 		e.kind		= PRGPU_ENTITY_PLANE;
 		transform_of(g, e.transform);
 		const uint32_t base = (uint32_t)(out.positions.size() / 3);
@@ -772,13 +778,19 @@ struct Loader {
 			for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
 				if (!get_bool(g, flag, true))
 					fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
-			if (g.get("emission"))
-				fail(PRGPU_EUNSUPPORTED, where(g) + ": emissive sphere entities are not supported yet");
 			prgpu_entity e;
 			std::memset(&e, 0, sizeof(e));
 			e.first_tri = (uint32_t)(out.indices.size() / 3);
 			e.n_tris	= 1;
 			e.emission	= PRGPU_INVALID_ID;
+			{
+				const Value* ev = g.get("emission");
+				const auto it	= ev && ev->type == Value::STRING ? emission_ids.find(ev->s) : emission_ids.end();
+				if (ev && it == emission_ids.end())
+					fail(PRGPU_EINVAL, where(g) + ": entity '" + name + "' refers to an unknown emission");
+				if (ev)
+					e.emission = it->second;
+			}
 			e.kind		= PRGPU_ENTITY_SPHERE;
 			e.radius	= (float)get_number(g, "radius", 1.0);
 			if (!(e.radius > 0))

@@ -234,6 +234,65 @@ void entity_tables(const prgpu_scene_desc* d, HostTables& t)
 		}
 		E.world_area = E.vol_scale * area;
 	}
+	// analytic entities: their own surface areas and, when they emit, the data the light samplers need
+	// (PlaneEntity::cache, plane.cpp:227-243; SphereEntity, sphere.cpp:23-31,49-66)
+	bool any = false;
+	for (uint32_t e = 0; e < d->n_entities; ++e)
+		any = any || (d->entities[e].emission != PRGPU_INVALID_ID && d->entities[e].kind != PRGPU_ENTITY_MESH);
+	std::vector<prd::DevShapeLight> lights(d->n_entities);
+	std::memset(lights.data(), 0, lights.size() * sizeof(prd::DevShapeLight));
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& src = d->entities[e];
+		DevEntity& E			= t.entities[e];
+		prd::DevShapeLight& L	= lights[e];
+		const float* m			= src.transform;
+		auto lin = [&](const float v[3], float out[3]) {
+			for (int r = 0; r < 3; ++r)
+				out[r] = (m[4 * r] * v[0] + m[4 * r + 1] * v[1]) + m[4 * r + 2] * v[2];
+		};
+		auto norm3 = [](const float v[3]) { return std::sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); };
+		if (src.kind == PRGPU_ENTITY_PLANE) {
+			const uint32_t t0 = src.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0
+			const float* v0	  = d->positions + 3 * d->indices[3 * t0];
+			const float* v1	  = d->positions + 3 * d->indices[3 * t0 + 1];
+			const float* v3p  = d->positions + 3 * d->indices[3 * t0 + 2];
+			const float x[3] = { v3p[0] - v0[0], v3p[1] - v0[1], v3p[2] - v0[2] }, y[3] = { v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2] };
+			for (int r = 0; r < 3; ++r)
+				L.S[r] = ((m[4 * r] * v0[0] + m[4 * r + 1] * v0[1]) + m[4 * r + 2] * v0[2]) + m[4 * r + 3];
+			lin(x, L.Ex);
+			lin(y, L.Ey);
+			float n[3] = { x[1] * y[2] - x[2] * y[1], x[2] * y[0] - x[0] * y[2], x[0] * y[1] - x[1] * y[0] };
+			const float nl = norm3(n);
+			for (int r = 0; r < 3; ++r)
+				n[r] = n[r] / nl;
+			for (int r = 0; r < 3; ++r)
+				L.nrm[r] = (E.nm[3 * r] * n[0] + E.nm[3 * r + 1] * n[1]) + E.nm[3 * r + 2] * n[2];
+			L.width	 = norm3(L.Ex);
+			L.height = norm3(L.Ey);
+			const float nz = norm3(L.nrm);
+			for (int r = 0; r < 3; ++r) {
+				L.Ex[r] = L.Ex[r] / L.width;
+				L.Ey[r] = L.Ey[r] / L.height;
+				L.Ez[r] = L.nrm[r] / nz;
+			}
+			E.world_area = L.width * L.height;
+		} else if (src.kind == PRGPU_ENTITY_SPHERE) {
+			auto col_norm = [&](int j) { return std::sqrt((m[j] * m[j] + m[4 + j] * m[4 + j]) + m[8 + j] * m[8 + j]); };
+			const float a = col_norm(0) * src.radius, b = col_norm(1) * src.radius, c = col_norm(2) * src.radius;
+			const float P = 1.6075f;
+			const float tt = (std::pow(a * b, P) + std::pow(a * c, P) + std::pow(b * c, P)) / 3;
+			E.world_area  = 4 * 3.14159265358979323846f * std::pow(tt, 1 / P);
+			L.pdf_cache	  = src.radius > EPS_F ? 1 / E.world_area : 0.0f;
+			L.radius	  = src.radius;
+			for (int r = 0; r < 3; ++r) { // Transformf::inverse: linear^-1 = nm^T, translation = -linear^-1 * t
+				for (int c2 = 0; c2 < 3; ++c2)
+					L.inv[4 * r + c2] = E.nm[3 * c2 + r];
+				L.inv[4 * r + 3] = -((L.inv[4 * r] * m[3] + L.inv[4 * r + 1] * m[7]) + L.inv[4 * r + 2] * m[11]);
+			}
+		}
+	}
+	if (any)
+		t.shape_lights.swap(lights);
 }
 
 void sampler_tables(const prgpu_scene_desc* d, HostTables& t)
@@ -674,12 +733,8 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 			return bad("unknown entity kind");
 		if (E.kind == PRGPU_ENTITY_SPHERE && (E.n_tris != 1 || !(E.radius > 0)))
 			return bad("a sphere entity is one placeholder triangle and a positive radius");
-		if (E.kind == PRGPU_ENTITY_SPHERE && E.emission != PRGPU_INVALID_ID)
-			return bad("emissive sphere entities are not supported yet", PRGPU_EUNSUPPORTED);
 		if (E.kind == PRGPU_ENTITY_PLANE && E.n_tris != 2)
 			return bad("a plane entity is exactly two triangles (v0,v1,v3), (v2,v3,v1)");
-		if (E.kind == PRGPU_ENTITY_PLANE && E.emission != PRGPU_INVALID_ID)
-			return bad("emissive plane entities are not supported yet (spherical-rectangle light sampling)", PRGPU_EUNSUPPORTED);
 	}
 	for (uint32_t i = 0; i < d->n_spectra; ++i) {
 		const prgpu_spectrum& n = d->spectra[i];

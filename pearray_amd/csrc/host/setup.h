@@ -18,6 +18,7 @@ struct HostTables {
 	std::vector<uint32_t> light_entity;
 	std::vector<float> light_cdf, light_intensity;
 	std::vector<prd::DevInfLight> inf_lights;
+	std::vector<prd::DevShapeLight> shape_lights; // per entity; empty when no plane / sphere emits
 	float scene_radius = 0.0f;
 	std::vector<float> wl_cdf;
 	float wl_u_offset = 0.0f, wl_u_scale = 1.0f; // cie mapper: truncation window inside the CDF (CIE.h:124-134)

@@ -269,7 +269,12 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	for (uint32_t e = 0; e < d->n_entities; ++e)
 		sc.n_lights += d->entities[e].emission != PRGPU_INVALID_ID;
 	sc.n_inf_lights	 = d->n_lights;
+	sc.shape_lights	 = nullptr;
+	if (!t.shape_lights.empty())
+		UP(sc.shape_lights, t.shape_lights);
 	sc.features		 = d->n_lights ? prd::FEAT_INFINITE_LIGHTS : 0u;
+	if (!t.shape_lights.empty())
+		sc.features |= prd::FEAT_SHAPE_LIGHTS;
 	for (uint32_t i = 0; i < d->n_materials; ++i)
 		if (d->materials[i].kind != PRGPU_MAT_LAMBERT)
 			sc.features |= prd::FEAT_DELTA_MATERIALS;
@@ -331,6 +336,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(ps.throughput, ns, false);
 	AL(ps.path_pdf, ns, false);
 	AL(ps.prev_pdf, ns, false);
+	AL(ps.last_pos, ns, false);
 	AL(ps.flags, ns, false);
 	AL(ps.hit, ns, false);
 	AL(ps.sh_o, ns, false);

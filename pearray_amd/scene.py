@@ -224,18 +224,18 @@ class SceneBuilder:
         """(light :type 'distant' :direction d :irradiance e), distant.cpp:112-121"""
         return self._light(abi.LIGHT_DISTANT, irradiance, None, direction, transform)
 
-    def add_plane(self, material, x_axis=(1, 0, 0), y_axis=(0, 1, 0), width=1.0, height=1.0, centering=False, transform=IDENTITY):
+    def add_plane(self, material, x_axis=(1, 0, 0), y_axis=(0, 1, 0), width=1.0, height=1.0, centering=False, transform=IDENTITY, emission=None):
         """(entity :type 'plane'), plane.cpp:241-258: parallelogram spanned by width * x_axis and height * y_axis"""
         x = np.float32(width) * np.asarray(x_axis, dtype=np.float32)
         y = np.float32(height) * np.asarray(y_axis, dtype=np.float32)
         p = (np.float32(-0.5) * x - np.float32(0.5) * y) if centering else np.zeros(3, dtype=np.float32)   # PlaneEntity::centerOn
-        e = self.add_mesh([p, p + y, (p + y) + x, p + x], [[0, 1, 3], [2, 3, 1]], material, transform=transform)   # plane.cpp:81-84
+        e = self.add_mesh([p, p + y, (p + y) + x, p + x], [[0, 1, 3], [2, 3, 1]], material, transform=transform, emission=emission)   # plane.cpp:81-84
         self.entities[e].kind = abi.ENTITY_PLANE
         return e
 
-    def add_sphere(self, material, radius=1.0, transform=IDENTITY):
+    def add_sphere(self, material, radius=1.0, transform=IDENTITY, emission=None):
         """(entity :type 'sphere' :radius r), sphere.cpp:157-168: one placeholder triangle stands for the analytic primitive"""
-        e = self.add_mesh([[0, 0, 0], [0, 0, 0], [0, 0, 0]], [[0, 1, 2]], material, transform=transform)
+        e = self.add_mesh([[0, 0, 0], [0, 0, 0], [0, 0, 0]], [[0, 1, 2]], material, transform=transform, emission=emission)
         self.entities[e].kind = abi.ENTITY_SPHERE
         self.entities[e].radius = float(radius)
         return e

@@ -2,6 +2,8 @@
 oracle on identical seeded inputs.  Bars: hit ids, sample counts, statistics and feedback planes EXACT;
 images within 1e-3 relative L2 (north_star) -- and, because both sides execute the same fp32 operations,
 bit-identical whenever the pixel filter is a single tap (the reference default)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -606,3 +608,35 @@ def test_principled_material(kw):
     plugin defaults) under NEE + MIS."""
     g, o = render_both(cornell_principled(**kw))
     assert_parity(g, o, exact=True)
+
+
+@pytest.mark.parametrize("kind", ["plane", "sphere"])
+@pytest.mark.parametrize("kw", [dict(), dict(mis=abi.MIS_POWER), dict(nee=0), dict(spectral_hero=0), dict(spectral_mono=1, spectral_start=550.0, spectral_end=830.0)])
+def test_plane_and_sphere_area_lights(kind, kw):
+    """Emissive analytic entities: spherical-rectangle sampling of a plane light, the reference's sphere sampling, and the direct-hit MIS
+    pdfs that go with them (the plane's is taken from the previous path vertex, the world origin for camera rays)."""
+    from test_oracle_shape_lights import light_scene
+    g, o = render_both(light_scene(kind, w=40, h=40, spp=6, **kw))
+    assert_parity(g, o, exact=True)
+
+
+def test_area_lights_of_all_three_kinds_together_in_every_pipeline():
+    from test_oracle_shape_lights import light_scene
+    b = scene.SceneBuilder(48, 40)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, 6
+    ems = b.diffuse_emission(b.smul(b.illuminant_d65(), b.spectrum_const(0.2)))
+    mats = scene._cornell_into(b, material_override={"tallBox": lambda bb: bb.rough_conductor(0.3)})
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.4, 0.2, 1.2)
+    b.add_sphere(mats["backWall"], radius=0.15, transform=T, emission=ems)
+    R = np.array([[1, 0, 0, -0.5], [0, 0, 1, 0.85], [0, -1, 0, 0.9], [0, 0, 0, 1]], np.float32)
+    b.add_plane(mats["backWall"], width=0.3, height=0.4, centering=True, transform=R, emission=ems)
+    sc = b.build()
+    g, o = render_both(sc)
+    assert_parity(g, o, exact=True)
+    for mode in ("lockstep", "streaming"):
+        os.environ["PRGPU_MODE"] = mode
+        try:
+            g2 = backend.RenderContext(sc); g2.start(); g2.waitForFinish()
+        finally:
+            del os.environ["PRGPU_MODE"]
+        assert np.array_equal(g2.output()[0], g.output()[0]), mode

@@ -101,7 +101,7 @@ def test_defaults_follow_the_reference():
 
 @pytest.mark.parametrize("block,code,needle", [
     ("(entity :name 's' :type 'cone' :radius 1)", -4, "entity type 'cone'"),
-    ("(emission :name 'l' :type 'standard') (entity :name 's' :type 'sphere' :emission 'l')", -4, "emissive sphere"),
+    ("(entity :name 's' :type 'sphere' :emission 'nope')", -1, "unknown emission"),
     ("(material :name 'g' :type 'glass' :roughness 'tex')", -4, "must be a number"),
     ("(material :name 'g' :type 'ward')", -4, "material type 'ward'"),
     ("(material :name 'g' :type 'metal' :roughness_x 0.1 :roughness_y 0.2 :vndf false)", -4, "vndf"),
@@ -245,9 +245,8 @@ def test_plane_entity_matches_scene_builder():
     pos = arr(d.positions, 12, np.float32).reshape(4, 3)
     assert pos.tolist() == [[-2, 0, 1.5], [-2, 0, -1.5], [2, 0, -1.5], [2, 0, 1.5]]          # p, p+y, p+y+x, p+x  (plane.cpp:81-84)
     assert arr(d.indices, 6, np.uint32).tolist() == [0, 1, 3, 2, 3, 1]
-    with pytest.raises(abi.PrgpuError) as e:
-        scene.PrcScene(source=MINIMAL % "(emission :name 'l' :type 'standard') (entity :name 'p' :type 'plane' :material 'm' :emission 'l')")
-    assert e.value.args[1] == -4 and "emissive plane" in e.value.args[0]
+    lit = scene.PrcScene(source=MINIMAL % "(emission :name 'l' :type 'standard') (entity :name 'p' :type 'plane' :material 'm' :emission 'l')")
+    assert lit.desc.entities[0].kind == abi.ENTITY_PLANE and lit.desc.entities[0].emission == 0   # emissive planes are area lights
 
 
 def test_infinite_lights_match_scene_builder():
