@@ -3644,6 +3644,26 @@ float orc_mf_reflection(int what, float m1, float m2, int aniso, int vndf, const
 		return mf_reflection_pdf(d, wIn, wOut);
 	return mf_reflection_eval_plain(d, wIn, wOut);
 }
+void orc_reflect_about(const float v[3], const float n[3], float out[3]) // Scattering::reflect(V, N) (Scattering.h:82-85)
+{
+	const V3 r = reflect_about(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]));
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+int orc_refract_about(float eta, const float v[3], const float n[3], float out[3]) // Scattering::refract(eta, V, N, total) (Scattering.h:116-130)
+{
+	bool total;
+	const V3 r = refract_about(eta, v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]), total);
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+	return total ? 1 : 0;
+}
+void orc_halfway(int refractive, float n_in, const float a[3], float n_out, const float b[3], float out[3]) // Scattering.h:149-167
+{
+	const V3 wIn = v3(a[0], a[1], a[2]), wOut = v3(b[0], b[1], b[2]);
+	const V3 h	 = refractive ? -normalized_or_zero(wIn * n_in + wOut * n_out) : normalized_or_zero(wIn + wOut);
+	out[0] = h.x; out[1] = h.y; out[2] = h.z;
+}
+float orc_safe_acos(float x) { return safe_acos(x); }
+void orc_sincos_rad(float x, float* s, float* c) { sincos_rad(x, *s, *c); }
 void orc_reflect(const float v[3], float out[3]) // Scattering::reflect(V) in shading space (Scattering.h:69-72)
 {
 	out[0] = -v[0]; out[1] = -v[1]; out[2] = v[2];

@@ -100,6 +100,11 @@ float    orc_ndf_ggx(const float h[3], float rx, float ry, int aniso);
 float    orc_pdf_ggx(const float h[3], float rx, float ry, int aniso);
 float    orc_mf_reflection(int what /*0 eval, 1 evalConductor, 2 pdf*/, float m1, float m2, int aniso, int vndf, const float w_in[3],
                            const float w_out[3], float ior, float kappa);
+void     orc_reflect_about(const float v[3], const float n[3], float out[3]);
+int      orc_refract_about(float eta, const float v[3], const float n[3], float out[3]); /* returns 1 on total reflection */
+void     orc_halfway(int refractive, float n_in, const float w_in[3], float n_out, const float w_out[3], float out[3]);
+float    orc_safe_acos(float x);                       /* shared fp32 acos used by the plane light (plane.cpp:109) */
+void     orc_sincos_rad(float x, float* s, float* c);  /* shared fp32 sin/cos of an angle in radians (plane.cpp:152-153) */
 void     orc_reflect(const float v[3], float out[3]);
 void     orc_material_eval(orc_scene* s, uint32_t material, const float wvl[4], const float v[3], const float l[3], float weight[4],
                            float pdf[4], int* delta);

@@ -98,6 +98,12 @@ def load():
     lib.orc_ndf_ggx.argtypes = lib.orc_pdf_ggx.argtypes = [_F32P, C.c_float, C.c_float, C.c_int]
     lib.orc_mf_reflection.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _F32P, _F32P, C.c_float, C.c_float]
     lib.orc_reflect.argtypes = [_F32P, _F32P]
+    lib.orc_reflect_about.argtypes = [_F32P, _F32P, _F32P]
+    lib.orc_refract_about.argtypes = [C.c_float, _F32P, _F32P, _F32P]
+    lib.orc_halfway.argtypes = [C.c_int, C.c_float, _F32P, C.c_float, _F32P, _F32P]
+    lib.orc_safe_acos.restype = C.c_float
+    lib.orc_safe_acos.argtypes = [C.c_float]
+    lib.orc_sincos_rad.argtypes = [C.c_float, _F32P, _F32P]
     lib.orc_material_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _F32P, _F32P, _F32P, C.POINTER(C.c_int)]
     lib.orc_rough_sample.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _U64P, _F32P, _F32P, _F32P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = lib
