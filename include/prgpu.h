@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PRGPU_API_VERSION 4
+#define PRGPU_API_VERSION 5
 #define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
 
 enum {
@@ -68,9 +68,14 @@ enum {
  *                                                         src/plugins/main/node/ReflectiveNode.cpp:105-150,224-232, base/math/Scattering.h:219-242;
  *                      table_count = 2N (N <= 4) values at table_offset: B_0..B_{N-1}, C_0..C_{N-1}.  The only node kind that is
  *                      NodeFlag::SpectralVarying (a delta material whose index uses it collapses the hero wavelengths).
- * MUL operands must have a smaller index than the node itself (topological order). */
+ *   CHECKER            CheckerboardNode (`checkerboard`, `grid`)  src/plugins/main/node/CheckerboardNode.cpp:12-50: picks `rhs` where
+ *                      (int)floor(u*su) + (int)floor(v*sv) is even and `lhs` elsewhere, (u, v) the texture coordinates of the shading point;
+ *                      p[0] = su, p[1] = sv, p[2] = 0 (no scale) / 1 (isotropic: su for both) / 2 (anisotropic).  Allowed as a material
+ *                      parameter (possibly nested in another CHECKER), not inside MUL and not as an emission; not on sphere entities
+ *                      (their uv needs atan2/acos).
+ * MUL operands must have a smaller index than the node itself (topological order); so must CHECKER operands. */
 enum { PRGPU_SPEC_CONST = 0, PRGPU_SPEC_PARAMETRIC = 1, PRGPU_SPEC_PARAMETRIC_SCALED = 2,
-       PRGPU_SPEC_TABLE = 3, PRGPU_SPEC_MUL = 4, PRGPU_SPEC_SELLMEIER = 5 };
+       PRGPU_SPEC_TABLE = 3, PRGPU_SPEC_MUL = 4, PRGPU_SPEC_SELLMEIER = 5, PRGPU_SPEC_CHECKER = 6 };
 
 typedef struct prgpu_spectrum {
 	uint32_t kind;
@@ -79,7 +84,7 @@ typedef struct prgpu_spectrum {
 	uint32_t table_count;   /* TABLE: number of samples (>= 2) */
 	float    wl_start;      /* TABLE: wavelength of first sample [nm] */
 	float    wl_end;        /* TABLE: wavelength of last sample [nm] */
-	uint32_t lhs, rhs;      /* MUL: operand node indices */
+	uint32_t lhs, rhs;      /* MUL: operand node indices; CHECKER: op1 (odd cells), op2 (even cells) */
 } prgpu_spectrum;
 
 /* LAMBERT     src/plugins/main/materials/lambert.cpp
@@ -92,7 +97,8 @@ enum { PRGPU_MAT_LAMBERT = 0, PRGPU_MAT_DIELECTRIC = 1, PRGPU_MAT_CONDUCTOR = 2,
                                             Microfacet.h) with the conductor Fresnel term; also `conductor` with a roughness (conductor.cpp:102-106) */
        PRGPU_MAT_ROUGH_DIELECTRIC = 4,   /* roughdielectric.cpp: GGX reflection + refraction (MicrofacetTransmission.h), branch chosen by the hero
                                             wavelength's Fresnel term; also `glass` with a roughness (dielectric.cpp:172-176) */
-       PRGPU_MAT_PRINCIPLED = 5 };       /* principled.cpp: Disney-style diffuse / retro / sheen / GGX specular / refraction / clearcoat lobes with a
+       PRGPU_MAT_PRINCIPLED = 5,
+       PRGPU_MAT_MIRROR = 6 };           /* mirror.cpp: delta reflection weighted by `specularity` (albedo), no Fresnel term */       /* principled.cpp: Disney-style diffuse / retro / sheen / GGX specular / refraction / clearcoat lobes with a
                                             four-way lobe selection (principled.cpp:111-139,418-435); constant scalar parameters only */
 enum { PRGPU_MATF_ANISOTROPIC = 1u,      /* roughness_y given as its own parameter (the reference compares the NODES, not the values) */
        PRGPU_MATF_NO_VNDF = 2u,          /* `:vndf false`: sample the plain GGX normal distribution (isotropic only; the anisotropic variant needs
@@ -144,7 +150,9 @@ typedef struct prgpu_entity {
 	uint32_t has_normals;  /* MESH: 1: interpolate vertex normals (MeshEntity<*,true>), 0: geometric */
 	uint32_t kind;         /* PRGPU_ENTITY_* */
 	float    radius;       /* SPHERE: local radius (`:radius`, default 1) */
-	uint32_t reserved[2];
+	uint32_t has_uvs;      /* MESH: 1: the mesh has texture coordinates (MeshEntity<HasUV>, mesh.cpp:205-228): interpolated uv, and with
+	                          has_normals the tangent frame of Face::tangentFromUV (geometry/Face.h:80-98) */
+	uint32_t reserved;
 	float    transform[16];
 } prgpu_entity;
 
@@ -221,6 +229,7 @@ typedef struct prgpu_scene_desc {
 	uint32_t n_vertices;
 	const float*    positions;       /* 3*n_vertices, local space */
 	const float*    normals;         /* 3*n_vertices or NULL */
+	const float*    uvs;             /* 2*n_vertices or NULL: texture coordinates (`uv`/`t` mesh attribute); entities that use them set has_uvs */
 	uint32_t n_triangles;
 	const uint32_t* indices;         /* 3*n_triangles, into positions/normals */
 	const uint32_t* tri_material;    /* n_triangles, material index or PRGPU_INVALID_ID */

@@ -713,6 +713,7 @@ struct Scene {
 	std::vector<prgpu_emission> emissions;
 	std::vector<prgpu_spectrum> spectra;
 	bool has_normals_array = false;
+	std::vector<float> uvs; // 2 per vertex when given
 
 	// derived geometry
 	std::vector<V3> wv;			   // world-space triangle vertices, 3 per triangle
@@ -1508,6 +1509,7 @@ bool trace_any(Scene& s, V3 o, V3 d, float tmin, float distance, bool brute)
 struct GeomPoint {
 	V3 N, Nx, Ny;
 	uint32_t entity, prim, material, emission;
+	float uv[2] = { 0, 0 }; // GeometryPoint::UV
 };
 inline V3 tri_interp(V3 a0, V3 a1, V3 a2, float u, float v) { return (a1 * u + a2 * v) + a0 * (1 - u - v); }
 inline V3 load3(const std::vector<float>& a, uint32_t i) { return v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
@@ -1545,11 +1547,41 @@ void geometry_point(const Scene& s, uint32_t tri, float u, float v, V3 P, GeomPo
 		g.prim	   = 0; // one Embree quad
 		g.material = s.tri_material[tri];
 		g.emission = E.emission;
+		// pt.UV = query.UV (plane.cpp:214): the quad's parameters; its second triangle (v2, v3, v1) runs them backwards
+		g.uv[0] = tri == E.first_tri ? u : 1 - u;
+		g.uv[1] = tri == E.first_tri ? v : 1 - v;
 		return;
+	}
+	const bool has_uv = E.has_uvs && !s.uvs.empty(); // MeshEntity<.., HasUV> (mesh.cpp:205-228)
+	auto uv_of		  = [&](uint32_t i, int c) { return s.uvs[2 * size_t(i) + c]; };
+	if (has_uv) { // Face::interpolateUVs (Face.h:39-45) = Triangle::interpolate (Triangle.h:23-27)
+		for (int c = 0; c < 2; ++c)
+			g.uv[c] = (uv_of(i1, c) * u + uv_of(i2, c) * v) + uv_of(i0, c) * (1 - u - v);
+	} else {
+		g.uv[0] = u;
+		g.uv[1] = v;
 	}
 	if (E.has_normals && s.has_normals_array) {
 		N = tri_interp(load3(s.normals, i0), load3(s.normals, i1), load3(s.normals, i2), u, v);
-		frame_duff(N, Nx, Ny); // Tangent::unnormalized_frame on the interpolated (unnormalised) normal
+		if (has_uv) { // Face::tangentFromUV (Face.h:80-98) with the interpolated, unnormalised normal
+			const V3 dp1 = load3(s.positions, i1) - load3(s.positions, i0), dp2 = load3(s.positions, i2) - load3(s.positions, i0);
+			const float du1 = uv_of(i1, 0) - uv_of(i0, 0), dv1 = uv_of(i1, 1) - uv_of(i0, 1);
+			const float du2 = uv_of(i2, 0) - uv_of(i0, 0), dv2 = uv_of(i2, 1) - uv_of(i0, 1);
+			const float det = diff_prod(dv2, du1, dv1, du2);
+			if (det <= PR_EPS) { // Tangent::frame
+				frame_duff(N, Nx, Ny);
+				Nx = normalized_or_zero(Nx);
+				Ny = normalized_or_zero(Ny);
+			} else {
+				const V3 t = dp1 * dv2 - dp2 * dv1;
+				Nx		   = v3(t.x / det, t.y / det, t.z / det);
+				Nx		   = Nx - N * dot(N, Nx);
+				Nx		   = normalized_or_zero(Nx);
+				Ny		   = cross(N, Nx);
+			}
+		} else {
+			frame_duff(N, Nx, Ny); // Tangent::unnormalized_frame on the interpolated (unnormalised) normal
+		}
 	} else {
 		// rtcInterpolate dPdu / dPdv of a triangle: p1-p0, p2-p0 (mesh.cpp:51-80,216-219)
 		Nx = load3(s.positions, i1) - load3(s.positions, i0);
@@ -2048,6 +2080,27 @@ inline void sphere_light_sample(const Scene::ShapeLight& P, const prgpu_entity& 
 		n = -n;
 	p	  = affine_mul(E.transform, n * E.radius);
 	pdf_a = 2 * P.pdf_cache;
+}
+
+// CheckerboardNode::eval (CheckerboardNode.cpp:26-48): textured material parameters are resolved to the plain node of the cell the shading
+// point's uv falls into (nested checkers included) before the material is evaluated
+inline uint32_t resolve_texture(const Scene& s, uint32_t id, const float uv[2])
+{
+	while (id != INVALID && s.spectra[id].kind == PRGPU_SPEC_CHECKER) {
+		const prgpu_spectrum& n = s.spectra[id];
+		const int mode			= (int)n.p[2];
+		float a = uv[0], b = uv[1];
+		if (mode == 1) {
+			a = uv[0] * n.p[0];
+			b = uv[1] * n.p[0];
+		} else if (mode == 2) {
+			a = uv[0] * n.p[0];
+			b = uv[1] * n.p[1];
+		}
+		const bool even = ((int)std::floor(a) + (int)std::floor(b)) % 2 == 0;
+		id				= even ? n.rhs : n.lhs;
+	}
+	return id;
 }
 
 // ---- material evaluation for next event estimation: IMaterial::eval in tangent space ---------------------
@@ -2664,11 +2717,15 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		}
 		if (gp.material == INVALID)
 			break;
-		const prgpu_material& mat = s.materials[gp.material];
+		prgpu_material mat = s.materials[gp.material];
+		mat.albedo		   = resolve_texture(s, mat.albedo, gp.uv); // ShadingContext::UV driven nodes
+		mat.ior			   = resolve_texture(s, mat.ior, gp.uv);
+		mat.k			   = resolve_texture(s, mat.k, gp.uv);
+		mat.transmission   = resolve_texture(s, mat.transmission, gp.uv);
 		// tangent-space view vector: MaterialSampleContext::fromIP (MaterialContext.h:27-44)
 		const V3 Vt = to_tangent_space(N, gp.Nx, gp.Ny, -ray.d);
 
-		const bool deltaMat = mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR; // IMaterial::hasOnlyDeltaDistribution
+		const bool deltaMat = mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR || mat.kind == PRGPU_MAT_MIRROR; // IMaterial::hasOnlyDeltaDistribution
 		const bool roughMat = mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED;
 
 		if (cfg.nee && !deltaMat && !hasEmission && !s.light_intensity.empty()) { // direct.cpp:100-101
@@ -2866,6 +2923,11 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		bool sampleDelta	= deltaMat;
 		if (roughMat) {
 			rough_sample(s, mat, ray.wl, Vt, rnd, Lt, integral_weight, pdf_s, sampleDelta, heroCollapsing);
+		} else if (mat.kind == PRGPU_MAT_MIRROR) {
+			// MirrorMaterial::sample (mirror.cpp:51-60): no random number, no spectral-varying flag
+			pdf_s			= blob(1);
+			integral_weight = spectrum_eval(s, mat.albedo, ray.wl);
+			Lt				= v3(-Vt.x, -Vt.y, Vt.z);
 		} else if (mat.kind == PRGPU_MAT_CONDUCTOR) {
 			// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
 			pdf_s		   = blob(1);
@@ -3065,6 +3127,8 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 	s.has_normals_array = d->normals != nullptr;
 	if (d->normals)
 		s.normals.assign(d->normals, d->normals + 3 * size_t(d->n_vertices));
+	if (d->uvs)
+		s.uvs.assign(d->uvs, d->uvs + 2 * size_t(d->n_vertices));
 	s.indices.assign(d->indices, d->indices + 3 * size_t(d->n_triangles));
 	s.tri_material.assign(d->tri_material, d->tri_material + d->n_triangles);
 	s.entities.assign(d->entities, d->entities + d->n_entities);
@@ -3087,6 +3151,8 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("emission index out of range");
 		if (E.has_normals && !s.has_normals_array)
 			return fail("entity wants normals but none given");
+		if (E.has_uvs && s.uvs.empty())
+			return fail("entity wants texture coordinates but none given");
 		if (E.kind > PRGPU_ENTITY_SPHERE || (E.kind == PRGPU_ENTITY_PLANE && E.n_tris != 2))
 			return fail("bad plane entity");
 		if (E.kind == PRGPU_ENTITY_SPHERE && (E.n_tris != 1 || !(E.radius > 0)))
@@ -3101,8 +3167,12 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("material index out of range");
 	for (uint32_t i = 0; i < d->n_spectra; ++i) {
 		const prgpu_spectrum& n = s.spectra[i];
-		if (n.kind > PRGPU_SPEC_SELLMEIER)
+		if (n.kind > PRGPU_SPEC_CHECKER)
 			return fail("unknown spectrum kind");
+		if (n.kind == PRGPU_SPEC_CHECKER && (n.lhs >= i || n.rhs >= i || !(n.p[2] == 0.0f || n.p[2] == 1.0f || n.p[2] == 2.0f)))
+			return fail("bad checkerboard node");
+		if (n.kind == PRGPU_SPEC_MUL && n.lhs < i && n.rhs < i && (s.spectra[n.lhs].kind == PRGPU_SPEC_CHECKER || s.spectra[n.rhs].kind == PRGPU_SPEC_CHECKER))
+			return fail("checkerboard inside a MUL node is not supported");
 		if (n.kind == PRGPU_SPEC_SELLMEIER && (n.table_count < 2 || n.table_count > 8 || (n.table_count & 1) || n.table_offset + n.table_count > d->n_spectral_table_values))
 			return fail("sellmeier coefficients out of range");
 		if (n.kind == PRGPU_SPEC_MUL && (n.lhs >= i || n.rhs >= i))
@@ -3111,7 +3181,7 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("spectrum table out of range");
 	}
 	for (const auto& m : s.materials) {
-		if (m.kind > PRGPU_MAT_PRINCIPLED || m.albedo >= d->n_spectra)
+		if (m.kind > PRGPU_MAT_MIRROR || m.albedo >= d->n_spectra)
 			return fail("bad material");
 		if ((m.kind == PRGPU_MAT_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_CONDUCTOR) && (m.ior >= d->n_spectra || m.k >= d->n_spectra))
 			return fail("bad conductor material");
@@ -3136,8 +3206,19 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 		}
 	}
 	for (const auto& e : s.emissions)
-		if (e.kind != PRGPU_EMS_DIFFUSE || e.radiance >= d->n_spectra)
+		if (e.kind != PRGPU_EMS_DIFFUSE || e.radiance >= d->n_spectra || s.spectra[e.radiance].kind == PRGPU_SPEC_CHECKER)
 			return fail("bad emission");
+	{ // textured material parameters need texture coordinates: not available on analytic spheres (uv_from_normal needs atan2 / acos)
+		auto textured = [&](uint32_t id) { return id != INVALID && id < d->n_spectra && s.spectra[id].kind == PRGPU_SPEC_CHECKER; };
+		for (uint32_t e = 0; e < d->n_entities; ++e) {
+			const prgpu_entity& E = s.entities[e];
+			if (E.kind != PRGPU_ENTITY_SPHERE || s.tri_material[E.first_tri] == INVALID)
+				continue;
+			const prgpu_material& m = s.materials[s.tri_material[E.first_tri]];
+			if (textured(m.albedo) || textured(m.ior) || textured(m.k) || textured(m.transmission))
+				return fail("textured materials on sphere entities are not supported");
+		}
+	}
 
 	// world-space triangles, normal matrices, areas (IEntity::worldSurfaceArea = |det| * local area)
 	s.wv.resize(3 * size_t(d->n_triangles));

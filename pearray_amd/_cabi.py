@@ -9,11 +9,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libprgpu.so")
 
-PRGPU_API_VERSION = 4
+PRGPU_API_VERSION = 5
 INVALID_ID = 0xFFFFFFFF
 
-SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER = range(6)
-MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_ROUGH_CONDUCTOR, MAT_ROUGH_DIELECTRIC, MAT_PRINCIPLED = 0, 1, 2, 3, 4, 5
+SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER, SPEC_CHECKER = range(7)
+MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_ROUGH_CONDUCTOR, MAT_ROUGH_DIELECTRIC, MAT_PRINCIPLED, MAT_MIRROR = 0, 1, 2, 3, 4, 5, 6
 MATF_ANISOTROPIC, MATF_NO_VNDF, MATF_HAS_TRANSMISSION = 1, 2, 4
 PRINCIPLED_PARAMS = ("diffuse_transmission", "specular_transmission", "specular_tint", "anisotropic", "flatness", "metallic", "sheen",
                      "sheen_tint", "clearcoat", "clearcoat_gloss")
@@ -50,7 +50,7 @@ class Emission(C.Structure):
 
 class Entity(C.Structure):
     _fields_ = [("first_tri", C.c_uint32), ("n_tris", C.c_uint32), ("emission", C.c_uint32),
-                ("has_normals", C.c_uint32), ("kind", C.c_uint32), ("radius", C.c_float), ("reserved", C.c_uint32 * 2), ("transform", C.c_float * 16)]
+                ("has_normals", C.c_uint32), ("kind", C.c_uint32), ("radius", C.c_float), ("has_uvs", C.c_uint32), ("reserved", C.c_uint32), ("transform", C.c_float * 16)]
 
 
 class Light(C.Structure):
@@ -78,7 +78,7 @@ class Settings(C.Structure):
 
 class SceneDesc(C.Structure):
     _fields_ = [("api_version", C.c_uint32), ("n_vertices", C.c_uint32), ("positions", C.POINTER(C.c_float)),
-                ("normals", C.POINTER(C.c_float)), ("n_triangles", C.c_uint32),
+                ("normals", C.POINTER(C.c_float)), ("uvs", C.POINTER(C.c_float)), ("n_triangles", C.c_uint32),
                 ("indices", C.POINTER(C.c_uint32)), ("tri_material", C.POINTER(C.c_uint32)),
                 ("n_entities", C.c_uint32), ("entities", C.POINTER(Entity)), ("n_materials", C.c_uint32),
                 ("materials", C.POINTER(Material)), ("n_emissions", C.c_uint32),

@@ -51,10 +51,10 @@ struct DevEntity {
 	float vol_scale, world_area;
 	uint32_t light_id, kind; // kind: PRGPU_ENTITY_*
 	float sphere_r;			 // SPHERE: world radius (sphere.cpp:77-92); the centre is the translation (m[3], m[7], m[11])
-	uint32_t pad;
+	uint32_t has_uvs;		 // MESH: texture coordinates present (interpolated uv, UV-derived tangent frame)
 };
 
-constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u, FEAT_SHAPE_LIGHTS = 32u;
+constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u, FEAT_SHAPE_LIGHTS = 32u, FEAT_TEXTURES = 64u;
 
 // Area-light data of an analytic entity (one per entity, meaningful for emissive planes and spheres):
 // PlaneEntity::cache (plane.cpp:227-243) and SphereEntity (sphere.cpp:23-31,106-118)
@@ -87,6 +87,7 @@ struct DevScene {
 	uint32_t n_tris, n_inner, n_leaf;
 	const float* positions;
 	const float* normals;
+	const float* uvs; // 2 per vertex, or null
 	const uint32_t* indices;
 	const uint32_t* tri_material;
 	const uint32_t* tri_entity;

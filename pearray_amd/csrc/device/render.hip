@@ -358,9 +358,29 @@ __device__ __forceinline__ Blob spectrum_eval(const DevScene& sc, uint32_t id, c
 	return spectrum_leaf(sc, n, wl);
 }
 
+// CheckerboardNode::eval (CheckerboardNode.cpp:26-48): a textured material parameter resolves to the plain node of the uv cell
+__device__ __forceinline__ uint32_t resolve_texture(const DevScene& sc, uint32_t id, const float uv[2])
+{
+	while (id != INVALID && sc.spectra[id].kind == PRGPU_SPEC_CHECKER) {
+		const prgpu_spectrum& n = sc.spectra[id];
+		const int mode			= (int)n.p[2];
+		float a = uv[0], b = uv[1];
+		if (mode == 1) {
+			a = uv[0] * n.p[0];
+			b = uv[1] * n.p[0];
+		} else if (mode == 2) {
+			a = uv[0] * n.p[0];
+			b = uv[1] * n.p[1];
+		}
+		const bool even = ((int)floorf(a) + (int)floorf(b)) % 2 == 0;
+		id				= even ? n.rhs : n.lhs;
+	}
+	return id;
+}
 struct GeomPoint {
 	V3 N, Nx, Ny;
 	uint32_t entity, prim, material, emission;
+	float uv[2]; // GeometryPoint::UV (full variant only)
 };
 __device__ __forceinline__ V3 load3(const float* a, uint32_t i) { return v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
 __device__ __forceinline__ V3 tri_interp(V3 a0, V3 a1, V3 a2, float u, float v) { return (a1 * u + a2 * v) + a0 * (1 - u - v); }
@@ -387,6 +407,7 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 		g.prim	   = 0;
 		g.material = sc.tri_material[tri];
 		g.emission = E.emission;
+		g.uv[0] = g.uv[1] = 0.0f; // Spherical::uv_from_normal is not built (validate rejects textured materials on spheres)
 		return;
 	}
 	if (FULL && E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
@@ -400,11 +421,42 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 		g.prim	   = 0; // one Embree quad
 		g.material = sc.tri_material[tri];
 		g.emission = E.emission;
+		// pt.UV = query.UV (plane.cpp:214): the quad's parameters; its second triangle (v2, v3, v1) runs them backwards
+		g.uv[0] = tri == E.first_tri ? u : 1 - u;
+		g.uv[1] = tri == E.first_tri ? v : 1 - v;
 		return;
+	}
+	const bool has_uv = FULL && E.has_uvs != 0u; // MeshEntity<.., HasUV> (mesh.cpp:205-228)
+	if (FULL) {
+		if (has_uv) { // Face::interpolateUVs (Face.h:39-45) = Triangle::interpolate (Triangle.h:23-27)
+			for (int c = 0; c < 2; ++c)
+				g.uv[c] = (sc.uvs[2 * i1 + c] * u + sc.uvs[2 * i2 + c] * v) + sc.uvs[2 * i0 + c] * (1 - u - v);
+		} else {
+			g.uv[0] = u;
+			g.uv[1] = v;
+		}
 	}
 	if (E.has_normals) {
 		N = tri_interp(load3(sc.normals, i0), load3(sc.normals, i1), load3(sc.normals, i2), u, v);
-		frame_duff(N, Nx, Ny);
+		if (has_uv) { // Face::tangentFromUV (Face.h:80-98) with the interpolated, unnormalised normal
+			const V3 dp1 = load3(sc.positions, i1) - load3(sc.positions, i0), dp2 = load3(sc.positions, i2) - load3(sc.positions, i0);
+			const float du1 = sc.uvs[2 * i1] - sc.uvs[2 * i0], dv1 = sc.uvs[2 * i1 + 1] - sc.uvs[2 * i0 + 1];
+			const float du2 = sc.uvs[2 * i2] - sc.uvs[2 * i0], dv2 = sc.uvs[2 * i2 + 1] - sc.uvs[2 * i0 + 1];
+			const float det = diff_prod(dv2, du1, dv1, du2);
+			if (det <= PR_EPS) { // Tangent::frame
+				frame_duff(N, Nx, Ny);
+				Nx = normalized_or_zero(Nx);
+				Ny = normalized_or_zero(Ny);
+			} else {
+				const V3 t = dp1 * dv2 - dp2 * dv1;
+				Nx		   = v3(t.x / det, t.y / det, t.z / det);
+				Nx		   = Nx - N * dot(N, Nx);
+				Nx		   = normalized_or_zero(Nx);
+				Ny		   = cross(N, Nx);
+			}
+		} else {
+			frame_duff(N, Nx, Ny);
+		}
 	} else {
 		Nx = load3(sc.positions, i1) - load3(sc.positions, i0);
 		Ny = load3(sc.positions, i2) - load3(sc.positions, i0);
@@ -1306,10 +1358,16 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		if (gp.material == INVALID)
 			go_on = false;
 		if (go_on) {
-			const prgpu_material mat = sc.materials[gp.material];
+			prgpu_material mat = sc.materials[gp.material];
+			if (FULL && (sc.features & FEAT_TEXTURES)) { // ShadingContext::UV driven nodes
+				mat.albedo		 = resolve_texture(sc, mat.albedo, gp.uv);
+				mat.ior			 = resolve_texture(sc, mat.ior, gp.uv);
+				mat.k			 = resolve_texture(sc, mat.k, gp.uv);
+				mat.transmission = resolve_texture(sc, mat.transmission, gp.uv);
+			}
 			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
 			uint64_t rnd			 = ps.rng[pixel];
-			const bool deltaMat		 = FULL && (mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR); // IMaterial::hasOnlyDeltaDistribution
+			const bool deltaMat		 = FULL && (mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR || mat.kind == PRGPU_MAT_MIRROR); // IMaterial::hasOnlyDeltaDistribution
 			const bool roughMat		 = FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED);
 			const Blob cie_y_blob	 = blob4(cie.y[0], cie.y[1], cie.y[2], cie.y[3]);
 			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + (FULL ? sc.n_inf_lights : 0u))) { // direct.cpp:100-101
@@ -1505,6 +1563,11 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				bool sampleDelta	= deltaMat;
 				if (roughMat) {
 					rough_sample(sc, mat, wl, cie_y_blob, Vt, rnd, Lt, integral_weight, pdf_s, sampleDelta, heroCollapsing);
+				} else if (FULL && mat.kind == PRGPU_MAT_MIRROR) {
+					// MirrorMaterial::sample (mirror.cpp:51-60)
+					pdf_s			= blob(1);
+					integral_weight = spectrum_eval(sc, mat.albedo, wl);
+					Lt				= v3(-Vt.x, -Vt.y, Vt.z);
 				} else if (FULL && mat.kind == PRGPU_MAT_CONDUCTOR) {
 					// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
 					pdf_s		   = blob(1);

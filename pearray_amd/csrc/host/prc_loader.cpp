@@ -34,7 +34,7 @@ using prgpu_host::dl::Group;
 using prgpu_host::dl::Value;
 
 struct prgpu_prc {
-	std::vector<float> positions, normals, tables;
+	std::vector<float> positions, normals, uvs, tables;
 	std::vector<uint32_t> indices, tri_material;
 	std::vector<prgpu_entity> entities;
 	std::vector<prgpu_material> materials;
@@ -62,7 +62,7 @@ std::string lower(std::string s)
 }
 
 struct Mesh {
-	std::vector<float> p, n;
+	std::vector<float> p, n, uv; // uv: 2 per vertex (`t` / `uv` attribute, MeshParser.cpp:163-167)
 	std::vector<std::vector<uint32_t>> faces;
 	std::vector<uint32_t> slots; // per face material slot (empty: slot 0)
 };
@@ -75,7 +75,7 @@ struct Loader {
 	std::map<std::string, Mesh> meshes;
 	std::map<std::string, prgpu_camera> cameras;
 	std::string first_camera, selected_camera;
-	bool any_normals = false, have_integrator = false, have_filter = false;
+	bool any_normals = false, any_uvs = false, have_integrator = false, have_filter = false;
 	int include_depth = 0;
 
 	Loader(prgpu_prc& o, const prgpu_prc_options* op) : out(o)
@@ -298,6 +298,21 @@ struct Loader {
 				fail(PRGPU_EINVAL, where(e) + ": a spectrum needs at least two values");
 			return spectrum_table(start, end, vals.data(), vals.size());
 		}
+		if (id == "checkerboard" || id == "grid") { // CheckerboardNode.cpp:78-90: (checkerboard a b [su [sv]])
+			const size_t n	 = e.anonymous_count();
+			prgpu_spectrum s = blank(PRGPU_SPEC_CHECKER);
+			string_default	 = 0.8f;
+			s.lhs			 = n > 0 ? spectral_node(e.at(0), e, "op1") : spectrum_const(0.8f);
+			string_default	 = 0.2f;
+			s.rhs			 = n > 1 ? spectral_node(e.at(1), e, "op2") : spectrum_const(0.2f);
+			for (size_t k = 2; k < 4; ++k)
+				if (n > k && !e.at(k).is_number())
+					fail(PRGPU_EUNSUPPORTED, where(e) + ": checkerboard scales must be numbers");
+			s.p[0] = n > 2 ? (float)e.at(2).number() : 5.0f;
+			s.p[1] = n > 3 ? (float)e.at(3).number() : s.p[0];
+			s.p[2] = n <= 2 ? 0.0f : (n == 3 ? 1.0f : 2.0f);
+			return add_spectrum(s);
+		}
 		if (id == "smul") { // SpectralMathNode.cpp:275: product of two spectral nodes
 			if (e.anonymous_count() != 2)
 				fail(PRGPU_EINVAL, where(e) + ": smul takes two operands");
@@ -306,6 +321,8 @@ struct Loader {
 			s.rhs			 = spectral_node(e.at(1), e, "rhs");
 			if (out.spectra[s.lhs].kind == PRGPU_SPEC_MUL || out.spectra[s.rhs].kind == PRGPU_SPEC_MUL)
 				fail(PRGPU_EUNSUPPORTED, where(e) + ": nested smul is not supported (operands must be leaves)");
+			if (out.spectra[s.lhs].kind == PRGPU_SPEC_CHECKER || out.spectra[s.rhs].kind == PRGPU_SPEC_CHECKER)
+				fail(PRGPU_EUNSUPPORTED, where(e) + ": a checkerboard inside smul is not supported");
 			return add_spectrum(s);
 		}
 		if (id == "lookup_index") { // ReflectiveNode.cpp:224-246,387-396: tabulated Sellmeier coefficients (refractiveindex.info)
@@ -341,7 +358,7 @@ struct Loader {
 			}
 			return spectrum_sellmeier(b, c, (int)(n / 2));
 		}
-		fail(PRGPU_EUNSUPPORTED, "spectral expression " + where(e) + " is not supported (number, refl, illum, illuminant, spectrum, smul, lookup_index are)");
+		fail(PRGPU_EUNSUPPORTED, "spectral expression " + where(e) + " is not supported (number, refl, illum, illuminant, spectrum, smul, lookup_index, checkerboard are)");
 	}
 	float string_default = 1.0f; // default of the parameter being parsed (for strings naming unknown nodes)
 	uint32_t spectral_param(const Group& g, std::initializer_list<const char*> keys, float def)
@@ -615,6 +632,10 @@ struct Loader {
 				m.flags |= PRGPU_MATF_HAS_TRANSMISSION;
 			if (!get_bool(g, "vndf", true))
 				fail(PRGPU_EUNSUPPORTED, where(g) + ": principled with :vndf false is not supported (anisotropic closure)");
+		} else if (type == "mirror" || type == "reflection") { // mirror.cpp:79-100
+			m.kind		   = PRGPU_MAT_MIRROR;
+			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);
+			m.transmission = PRGPU_INVALID_ID;
 		} else if (type == "diffuse" || type == "lambert") {
 			m.kind		= PRGPU_MAT_LAMBERT;
 			m.albedo	= spectral_param(g, { "albedo", "base", "diffuse" }, 1.0f);
@@ -667,8 +688,15 @@ struct Loader {
 					load_attr(b, m.p);
 				else if (t == "n")
 					load_attr(b, m.n);
-				else if (t == "t" || t == "uv" || t == "w" || t == "dp" || t == "u")
-					; // texture coordinates, weights, velocities, user attributes: not evaluated by Lambert / diffuse emission
+				else if (t == "t" || t == "uv") { // texture coordinates: two components per vertex
+					std::vector<float> tmp;
+					load_attr(b, tmp);
+					for (size_t j = 0; j + 2 < tmp.size() + 1 && j < tmp.size(); j += 3) {
+						m.uv.push_back(tmp[j]);
+						m.uv.push_back(tmp[j + 1]);
+					}
+				} else if (t == "w" || t == "dp" || t == "u")
+					; // weights, velocities, user attributes: not evaluated on this path
 				else
 					fail(PRGPU_EINVAL, where(b) + ": unknown mesh attribute '" + t + "'");
 			} else if (b.id == "faces") {
@@ -703,6 +731,12 @@ struct Loader {
 			fail(PRGPU_EINVAL, "mesh '" + name + "' has no vertices or faces");
 		if (!m.n.empty() && m.n.size() != m.p.size())
 			fail(PRGPU_EINVAL, "mesh '" + name + "': normal count differs from vertex count");
+		if (!m.uv.empty() && m.uv.size() / 2 != nv)
+			fail(PRGPU_EINVAL, "mesh '" + name + "': texture coordinate count differs from vertex count");
+		if (!m.uv.empty())
+			for (const auto& f : m.faces)
+				if (f.size() == 4) // Face::tangentFromUV / interpolateUVs work on the whole quad (Face.h:39-45,80-98), not on its two triangles
+					fail(PRGPU_EUNSUPPORTED, "mesh '" + name + "': quads with texture coordinates are not supported (triangulate the mesh)");
 		if (!m.slots.empty() && m.slots.size() != m.faces.size())
 			fail(PRGPU_EINVAL, "mesh '" + name + "': material slot count differs from face count");
 		for (const auto& f : m.faces)
@@ -848,6 +882,12 @@ struct Loader {
 			out.normals.resize(size_t(base) * 3, 0.0f);
 			out.normals.insert(out.normals.end(), m.n.begin(), m.n.end());
 			any_normals = true;
+		}
+		e.has_uvs = m.uv.empty() ? 0 : 1;
+		if (e.has_uvs) {
+			out.uvs.resize(size_t(base) * 2, 0.0f);
+			out.uvs.insert(out.uvs.end(), m.uv.begin(), m.uv.end());
+			any_uvs = true;
 		}
 		for (size_t fi = 0; fi < m.faces.size(); ++fi) {
 			const auto& f		= m.faces[fi];
@@ -1088,6 +1128,8 @@ struct Loader {
 			fail(PRGPU_EINVAL, "the scene has no entities");
 		if (any_normals)
 			out.normals.resize(out.positions.size(), 0.0f);
+		if (any_uvs)
+			out.uvs.resize(out.positions.size() / 3 * 2, 0.0f);
 		const uint32_t n_table_values = (uint32_t)out.tables.size();
 		if (out.tables.empty())
 			out.tables.push_back(0.0f); // keep the pointer valid
@@ -1097,6 +1139,7 @@ struct Loader {
 		d.n_vertices			  = (uint32_t)(out.positions.size() / 3);
 		d.positions				  = out.positions.data();
 		d.normals				  = any_normals ? out.normals.data() : nullptr;
+		d.uvs					  = any_uvs ? out.uvs.data() : nullptr;
 		d.n_triangles			  = (uint32_t)(out.indices.size() / 3);
 		d.indices				  = out.indices.data();
 		d.tri_material			  = out.tri_material.data();

@@ -216,7 +216,7 @@ void entity_tables(const prgpu_scene_desc* d, HostTables& t)
 		E.has_normals = (src.has_normals && d->normals) ? 1u : 0u;
 		E.light_id	  = PRGPU_INVALID_ID;
 		E.kind		  = src.kind;
-		E.pad		  = 0;
+		E.has_uvs	  = (src.has_uvs && d->uvs && src.kind == PRGPU_ENTITY_MESH) ? 1u : 0u;
 		E.sphere_r	  = 0.0f;
 		if (src.kind == PRGPU_ENTITY_SPHERE) { // sphere.cpp:77-92: radius * mean column norm of the linear part
 			auto col_norm = [&](int j) { return std::sqrt((m[j] * m[j] + m[4 + j] * m[4 + j]) + m[8 + j] * m[8 + j]); };
@@ -738,8 +738,10 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 	}
 	for (uint32_t i = 0; i < d->n_spectra; ++i) {
 		const prgpu_spectrum& n = d->spectra[i];
-		if (n.kind > PRGPU_SPEC_SELLMEIER)
+		if (n.kind > PRGPU_SPEC_CHECKER)
 			return bad("unknown spectrum kind");
+		if (n.kind == PRGPU_SPEC_CHECKER && (n.lhs >= i || n.rhs >= i || !(n.p[2] == 0.0f || n.p[2] == 1.0f || n.p[2] == 2.0f)))
+			return bad("checkerboard operands must precede the node and its mode is 0, 1 or 2");
 		if (n.kind == PRGPU_SPEC_SELLMEIER && (n.table_count < 2 || n.table_count > 8 || (n.table_count & 1u) || uint64_t(n.table_offset) + n.table_count > d->n_spectral_table_values))
 			return bad("sellmeier coefficients out of range (1..4 B/C pairs in the table array)");
 		if (n.kind == PRGPU_SPEC_TABLE && (n.table_count < 2 || uint64_t(n.table_offset) + n.table_count > d->n_spectral_table_values || !(n.wl_end > n.wl_start)))
@@ -749,11 +751,13 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 				return bad("MUL operands must precede the node");
 			if (d->spectra[n.lhs].kind == PRGPU_SPEC_MUL || d->spectra[n.rhs].kind == PRGPU_SPEC_MUL)
 				return bad("nested MUL spectral nodes are not supported", PRGPU_EUNSUPPORTED);
+			if (d->spectra[n.lhs].kind == PRGPU_SPEC_CHECKER || d->spectra[n.rhs].kind == PRGPU_SPEC_CHECKER)
+				return bad("a checkerboard inside a MUL node is not supported", PRGPU_EUNSUPPORTED);
 		}
 	}
 	for (uint32_t i = 0; i < d->n_materials; ++i) {
 		const prgpu_material& m = d->materials[i];
-		if (m.kind > PRGPU_MAT_PRINCIPLED)
+		if (m.kind > PRGPU_MAT_MIRROR)
 			return bad("unknown material kind", PRGPU_EUNSUPPORTED);
 		const bool conductor = m.kind == PRGPU_MAT_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_CONDUCTOR;
 		const bool glass	 = m.kind == PRGPU_MAT_DIELECTRIC || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC;
@@ -780,6 +784,25 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 				return bad("roughness must be finite and non-negative");
 			if (aniso && (m.flags & PRGPU_MATF_NO_VNDF))
 				return bad("anisotropic roughness without vndf sampling is not supported", PRGPU_EUNSUPPORTED);
+		}
+	}
+	{
+		auto textured = [&](uint32_t id) { return id != PRGPU_INVALID_ID && id < d->n_spectra && d->spectra[id].kind == PRGPU_SPEC_CHECKER; };
+		for (uint32_t i = 0; i < d->n_emissions; ++i)
+			if (textured(d->emissions[i].radiance))
+				return bad("textured emissions are not supported", PRGPU_EUNSUPPORTED);
+		for (uint32_t i = 0; i < d->n_lights; ++i)
+			if (d->lights && (textured(d->lights[i].radiance) || textured(d->lights[i].background)))
+				return bad("textured infinite lights are not supported", PRGPU_EUNSUPPORTED);
+		for (uint32_t e = 0; e < d->n_entities; ++e) {
+			const prgpu_entity& E = d->entities[e];
+			if (E.has_uvs && !d->uvs)
+				return bad("entity wants texture coordinates but none given");
+			if (E.kind != PRGPU_ENTITY_SPHERE || d->tri_material[E.first_tri] == PRGPU_INVALID_ID)
+				continue;
+			const prgpu_material& m = d->materials[d->tri_material[E.first_tri]];
+			if (textured(m.albedo) || textured(m.ior) || textured(m.k) || textured(m.transmission))
+				return bad("textured materials on sphere entities are not supported (their uv needs atan2 / acos)", PRGPU_EUNSUPPORTED);
 		}
 	}
 	if (d->camera.kind > PRGPU_CAMERA_ORTHO)

@@ -244,6 +244,9 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		UP(sc.normals, d->normals, 3 * size_t(d->n_vertices));
 	else
 		UP(sc.normals, d->positions, 3); // never read: no entity has has_normals
+	sc.uvs = nullptr;
+	if (d->uvs)
+		UP(sc.uvs, d->uvs, 2 * size_t(d->n_vertices));
 	UP(sc.indices, d->indices, 3 * size_t(d->n_triangles));
 	UP(sc.tri_material, d->tri_material, d->n_triangles);
 	UP(sc.tri_entity, t.tri_entity);
@@ -275,6 +278,12 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.features		 = d->n_lights ? prd::FEAT_INFINITE_LIGHTS : 0u;
 	if (!t.shape_lights.empty())
 		sc.features |= prd::FEAT_SHAPE_LIGHTS;
+	for (uint32_t i = 0; i < d->n_spectra; ++i)
+		if (d->spectra[i].kind == PRGPU_SPEC_CHECKER)
+			sc.features |= prd::FEAT_TEXTURES;
+	for (uint32_t e = 0; e < d->n_entities; ++e)
+		if (d->entities[e].has_uvs && d->uvs && d->entities[e].kind == PRGPU_ENTITY_MESH)
+			sc.features |= prd::FEAT_TEXTURES; // UV-derived tangent frames need the full variant
 	for (uint32_t i = 0; i < d->n_materials; ++i)
 		if (d->materials[i].kind != PRGPU_MAT_LAMBERT)
 			sc.features |= prd::FEAT_DELTA_MATERIALS;

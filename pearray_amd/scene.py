@@ -40,6 +40,7 @@ class SceneBuilder:
         self._pos, self._nrm, self._idx, self._trimat = [], [], [], []
         self._n_vertices = 0
         self._any_normals = False
+        self._uv, self._any_uvs = [], False
         self.set_camera(IDENTITY)
 
     # ---- spectral nodes -------------------------------------------------------------------------
@@ -85,6 +86,13 @@ class SceneBuilder:
         """(illuminant "D65"), IlluminantNode.cpp:59,89-90: 107 samples 300..830 nm"""
         return self.spectrum_table(300.0, 830.0, _d65_table())
 
+    def checkerboard(self, op1, op2, scale_u=None, scale_v=None):
+        """(checkerboard a b [su [sv]]), CheckerboardNode.cpp:78-90: 2 arguments = unscaled uv, 3 = isotropic, 4 = anisotropic"""
+        mode = 0 if scale_u is None else (1 if scale_v is None else 2)
+        su = 5.0 if scale_u is None else float(scale_u)
+        sv = su if scale_v is None else float(scale_v)
+        return self._add_spec(kind=abi.SPEC_CHECKER, lhs=op1, rhs=op2, p=[su, sv, float(mode)])
+
     def smul(self, a, b):
         return self._add_spec(kind=abi.SPEC_MUL, lhs=a, rhs=b)
 
@@ -127,6 +135,12 @@ class SceneBuilder:
         k = self.spectrum_const(2.605) if k is None else k
         spec = self.spectrum_const(1.0) if specularity is None else specularity
         self.materials.append(abi.Material(abi.MAT_CONDUCTOR, spec, 0, eta, abi.INVALID_ID, 0, k))
+        return len(self.materials) - 1
+
+    def mirror(self, specularity=None):
+        """(material :type 'mirror'|'reflection'), mirror.cpp:79-100"""
+        spec = self.spectrum_const(1.0) if specularity is None else specularity
+        self.materials.append(abi.Material(abi.MAT_MIRROR, spec, 0, 0, abi.INVALID_ID, 0, 0))
         return len(self.materials) - 1
 
     def _rough(self, roughness, roughness_y, vndf):
@@ -172,7 +186,7 @@ class SceneBuilder:
         return len(self.emissions) - 1
 
     # ---- geometry ------------------------------------------------------------------------------------
-    def add_mesh(self, positions, faces, material, normals=None, emission=None, transform=IDENTITY, face_materials=None):
+    def add_mesh(self, positions, faces, material, normals=None, emission=None, transform=IDENTITY, face_materials=None, uvs=None):
         """One `(entity :type 'mesh')`.  Quads are split like Embree quads: (v0,v1,v3) and (v2,v3,v1)."""
         positions = np.asarray(positions, dtype=np.float32).reshape(-1, 3)
         tris, tmat = [], []
@@ -191,6 +205,7 @@ class SceneBuilder:
         e.n_tris = len(tris)
         e.emission = abi.INVALID_ID if emission is None else emission
         e.has_normals = 0 if normals is None else 1
+        e.has_uvs = 0 if uvs is None else 1
         t = np.asarray(transform, dtype=np.float32).reshape(16)
         for i in range(16):
             e.transform[i] = float(t[i])
@@ -201,6 +216,11 @@ class SceneBuilder:
             self._nrm.append(np.asarray(normals, dtype=np.float32).reshape(-1, 3))
         else:
             self._nrm.append(np.zeros_like(positions))
+        if uvs is not None:
+            self._any_uvs = True
+            self._uv.append(np.asarray(uvs, dtype=np.float32).reshape(-1, 2))
+        else:
+            self._uv.append(np.zeros((len(positions), 2), dtype=np.float32))
         self._idx.append(tris + np.uint32(self._n_vertices))
         self._trimat.append(np.asarray([abi.INVALID_ID if m is None else m for m in tmat], dtype=np.uint32))
         self._n_vertices += len(positions)
@@ -264,6 +284,7 @@ class SceneData:
     def __init__(self, b):
         self.positions = np.ascontiguousarray(np.concatenate(b._pos), dtype=np.float32)
         self.normals = np.ascontiguousarray(np.concatenate(b._nrm), dtype=np.float32) if b._any_normals else None
+        self.uvs = np.ascontiguousarray(np.concatenate(b._uv), dtype=np.float32) if b._any_uvs else None
         self.indices = np.ascontiguousarray(np.concatenate(b._idx), dtype=np.uint32)
         self.tri_material = np.ascontiguousarray(np.concatenate(b._trimat), dtype=np.uint32)
         self.entities = (abi.Entity * len(b.entities))(*b.entities)
@@ -276,6 +297,7 @@ class SceneData:
         d.n_vertices = len(self.positions)
         d.positions = self.positions.ctypes.data_as(C.POINTER(C.c_float))
         d.normals = self.normals.ctypes.data_as(C.POINTER(C.c_float)) if self.normals is not None else None
+        d.uvs = self.uvs.ctypes.data_as(C.POINTER(C.c_float)) if self.uvs is not None else None
         d.n_triangles = len(self.indices)
         d.indices = self.indices.ctypes.data_as(C.POINTER(C.c_uint32))
         d.tri_material = self.tri_material.ctypes.data_as(C.POINTER(C.c_uint32))

