@@ -14,8 +14,9 @@ struct BvhBuildInput {
 	const DevEntity* entities;	// device
 };
 struct BvhBuildOutput {
-	Rec128* recs = nullptr; // device: n_inner inner records followed by n_leaf leaf records; record 0 is the root
-	uint32_t n_inner = 0, n_leaf = 0;
+	Rec64* recs = nullptr; // device, addressed in 64-byte units: n_inner inner records (one unit each, unit 0 is the root), then from
+						   // unit leaf_unit0 (even) n_leaf leaf records of two units each
+	uint32_t n_inner = 0, n_leaf = 0, leaf_unit0 = 0;
 };
 bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err);
 } // namespace prd

@@ -256,13 +256,13 @@ struct ChildRef {
 // reference to the subtree `c` (radix-tree child code: >= 0 internal, < 0 single triangle ~pos) as a child of an inner record
 __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
 											   const int* __restrict__ range_first, const int* __restrict__ range_last, const float* __restrict__ boxes,
-											   const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx, uint32_t n_inner)
+											   const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx, uint32_t leaf_unit0)
 {
 	ChildRef r;
 	expandable = false;
 	if (c < 0) {
 		tri_box(wv, sorted_tri[~c], r.lo, r.hi);
-		r.ref = REC_LEAF_BIT | (n_inner + leaf_idx[~c]);
+		r.ref = REC_LEAF_BIT | (leaf_unit0 + 2u * leaf_idx[~c]);
 	} else {
 		for (int a = 0; a < 3; ++a) {
 			r.lo[a] = boxes[6 * c + a];
@@ -270,7 +270,7 @@ __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const fl
 		}
 		const int cnt = range_last[c] - range_first[c] + 1;
 		if (cnt <= 3) {
-			r.ref = REC_LEAF_BIT | (n_inner + leaf_idx[range_first[c]]);
+			r.ref = REC_LEAF_BIT | (leaf_unit0 + 2u * leaf_idx[range_first[c]]);
 		} else {
 			r.ref	   = inner_idx[c]; // valid only when c is at even depth; odd-depth nodes get expanded by the caller
 			expandable = true;
@@ -280,10 +280,71 @@ __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const fl
 	return r;
 }
 
+// Pack <= 4 children into a 64-byte inner record (layout: pr_device.h).  The child boxes (already padded) become bytes on a
+// power-of-two grid anchored at the lower corner of their union; every byte is checked against the decode the traversal
+// performs (origin + byte * step, one rounding), so the decoded box always contains the padded fp32 box.
+__device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int nc)
+{
+	float org[3];
+	uint32_t ebyte[3];
+	uint32_t qlo[3][4], qhi[3][4];
+	for (int a = 0; a < 3; ++a) {
+		float lo = INFINITY, hi = -INFINITY;
+		for (int k = 0; k < nc; ++k) {
+			lo = fminf(lo, ch[k].lo[a]);
+			hi = fmaxf(hi, ch[k].hi[a]);
+		}
+		org[a] = lo;
+		int e  = ilogbf(fmaxf((hi - lo) * (1.0f / 255.0f), 1e-30f)) + 1; // 2^e >= extent / 255
+		for (;; ++e) {
+			const float s = ldexpf(1.0f, e), inv_s = ldexpf(1.0f, -e);
+			bool fits = true;
+			for (int k = 0; k < nc; ++k) {
+				int ql = (int)floorf((ch[k].lo[a] - lo) * inv_s);
+				ql	   = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+				while (ql > 0 && __fmaf_rn((float)ql, s, lo) > ch[k].lo[a])
+					--ql;
+				int qh = (int)ceilf((ch[k].hi[a] - lo) * inv_s);
+				qh	   = qh < 0 ? 0 : qh;
+				while (qh <= 255 && __fmaf_rn((float)qh, s, lo) < ch[k].hi[a])
+					++qh;
+				if (qh > 255) {
+					fits = false;
+					break;
+				}
+				qlo[a][k] = (uint32_t)ql;
+				qhi[a][k] = (uint32_t)qh;
+			}
+			if (fits)
+				break;
+		}
+		ebyte[a] = (uint32_t)(e + 127);
+	}
+	uint32_t w[16];
+	for (int k = 0; k < 16; ++k)
+		w[k] = 0u;
+	w[0] = __float_as_uint(org[0]);
+	w[1] = __float_as_uint(org[1]);
+	w[2] = __float_as_uint(org[2]);
+	w[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16);
+	for (int k = 0; k < 4; ++k) {
+		const bool used = k < nc;
+		for (int a = 0; a < 3; ++a) {
+			const uint32_t l = used ? qlo[a][k] : 255u, h = used ? qhi[a][k] : 0u; // unused slot: inverted box
+			w[4 + a] |= l << (8 * k); // q1.xyz = lo.x, lo.y, lo.z (one byte per child)
+			w[7 + a] |= h << (8 * k); // q1.w, q2.xy = hi.x, hi.y, hi.z
+		}
+		w[12 + k] = used ? ch[k].ref : REC_EMPTY; // q3 = child refs
+	}
+	uint4* dst = reinterpret_cast<uint4*>(rec);
+	for (int q = 0; q < 4; ++q)
+		dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+
 __global__ void k_emit_inner(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
 							 const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
 							 const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
-							 const uint32_t* __restrict__ leaf_idx, uint32_t n_inner, Rec128* __restrict__ recs)
+							 const uint32_t* __restrict__ leaf_idx, uint32_t leaf_unit0, Rec64* __restrict__ recs)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n - 1 || !inner_flag[i])
@@ -293,33 +354,21 @@ __global__ void k_emit_inner(int n, const float4* __restrict__ wv, const uint32_
 	for (int side = 0; side < 2; ++side) {
 		const int c = side == 0 ? left[i] : right[i];
 		bool expandable;
-		const ChildRef direct = make_child(c, expandable, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, n_inner);
+		const ChildRef direct = make_child(c, expandable, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, leaf_unit0);
 		if (!expandable) {
 			ch[nc++] = direct;
 		} else { // odd-depth internal node with > 3 triangles: pull its two children up
 			bool e2;
-			ch[nc++] = make_child(left[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, n_inner);
-			ch[nc++] = make_child(right[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, n_inner);
+			ch[nc++] = make_child(left[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, leaf_unit0);
+			ch[nc++] = make_child(right[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, leaf_unit0);
 		}
 	}
-	float f[32];
-	for (int k = 0; k < 4; ++k) {
-		const bool used = k < nc;
-		for (int a = 0; a < 3; ++a) {
-			f[4 * a + k]	  = used ? ch[k].lo[a] : INFINITY;	// q0..q2: lo x,y,z of the four children
-			f[12 + 4 * a + k] = used ? ch[k].hi[a] : -INFINITY; // q3..q5: hi x,y,z
-		}
-		f[24 + k] = __uint_as_float(used ? ch[k].ref : REC_EMPTY);
-		f[28 + k] = 0.0f;
-	}
-	float4* dst = reinterpret_cast<float4*>(recs + inner_idx[i]);
-	for (int q = 0; q < 8; ++q)
-		dst[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+	write_inner_q(recs + inner_idx[i], ch, nc);
 }
 
 // leaf record: triangle k occupies floats [10k, 10k+10): v0, v1, v2, original triangle index; float 30 = count
 __global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const uint32_t* __restrict__ leaf_flag,
-							  const uint32_t* __restrict__ leaf_count, const uint32_t* __restrict__ leaf_idx, uint32_t n_inner, Rec128* __restrict__ recs)
+							  const uint32_t* __restrict__ leaf_count, const uint32_t* __restrict__ leaf_idx, uint32_t leaf_unit0, Rec64* __restrict__ recs)
 {
 	const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
 	if (pos >= n || !leaf_flag[pos])
@@ -348,20 +397,20 @@ __global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const u
 		f[10 * k + 9] = __uint_as_float(t);
 	}
 	f[30]		= __uint_as_float(cnt);
-	float4* dst = reinterpret_cast<float4*>(recs + n_inner + leaf_idx[pos]);
+	float4* dst = reinterpret_cast<float4*>(recs + leaf_unit0 + 2u * leaf_idx[pos]);
 	for (int q = 0; q < 8; ++q)
 		dst[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
 }
 
 // tiny scenes (n <= 3): one inner record whose only child is the single leaf
-__global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, Rec128* __restrict__ recs)
+__global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, Rec64* __restrict__ recs)
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0)
 		return;
 	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-	float leaf[32], node[32];
+	float leaf[32];
 	for (int k = 0; k < 32; ++k)
-		leaf[k] = node[k] = 0.0f;
+		leaf[k] = 0.0f;
 	for (uint32_t i = 0; i < n; ++i) {
 		float a[3], b[3];
 		const uint32_t t = sorted_tri[i];
@@ -389,19 +438,17 @@ __global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const ui
 	}
 	leaf[30] = __uint_as_float(n);
 	pad_box(lo, hi);
-	for (int k = 0; k < 4; ++k) {
-		for (int a = 0; a < 3; ++a) {
-			node[4 * a + k]		 = k == 0 ? lo[a] : INFINITY;
-			node[12 + 4 * a + k] = k == 0 ? hi[a] : -INFINITY;
-		}
-		node[24 + k] = __uint_as_float(k == 0 ? (REC_LEAF_BIT | 1u) : REC_EMPTY);
+	// unit 0: the root inner record with one child; units 2..3: the leaf
+	ChildRef only;
+	for (int a = 0; a < 3; ++a) {
+		only.lo[a] = lo[a];
+		only.hi[a] = hi[a];
 	}
-	float4* d0 = reinterpret_cast<float4*>(recs);
-	float4* d1 = reinterpret_cast<float4*>(recs + 1);
-	for (int q = 0; q < 8; ++q) {
-		d0[q] = make_float4(node[4 * q], node[4 * q + 1], node[4 * q + 2], node[4 * q + 3]);
+	only.ref = REC_LEAF_BIT | 2u;
+	write_inner_q(recs, &only, 1);
+	float4* d1 = reinterpret_cast<float4*>(recs + 2);
+	for (int q = 0; q < 8; ++q)
 		d1[q] = make_float4(leaf[4 * q], leaf[4 * q + 1], leaf[4 * q + 2], leaf[4 * q + 3]);
-	}
 }
 
 #define HIPC(x)                                  \
@@ -454,10 +501,11 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 		HIPC(hipMalloc(&temp, temp_bytes));
 		HIPC(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
 		if (n <= 3) {
-			HIPC(hipMalloc(&out.recs, sizeof(Rec128) * 2));
+			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * 4));
 			hipLaunchKernelGGL(k_tiny_scene, dim3(1), dim3(64), 0, stream, n, wv, vals_sorted, out.recs);
-			out.n_inner = 1;
-			out.n_leaf	= 1;
+			out.n_inner	   = 1;
+			out.n_leaf	   = 1;
+			out.leaf_unit0 = 2;
 		} else {
 			HIPC(hipMalloc(&left, sizeof(int) * (n - 1)));
 			HIPC(hipMalloc(&right, sizeof(int) * (n - 1)));
@@ -493,10 +541,11 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipStreamSynchronize(stream));
 			out.n_inner = last[0] + last[1];
 			out.n_leaf	= last[2] + last[3];
-			HIPC(hipMalloc(&out.recs, sizeof(Rec128) * (size_t(out.n_inner) + out.n_leaf)));
-			hipLaunchKernelGGL(k_emit_inner, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx,
-							   out.n_inner, out.recs);
-			hipLaunchKernelGGL(k_emit_leaves, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, leaf_flag, leaf_cnt, leaf_idx, out.n_inner, out.recs);
+			out.leaf_unit0 = (out.n_inner + 1u) & ~1u; // leaves are 128-byte aligned
+			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * (size_t(out.leaf_unit0) + 2 * size_t(out.n_leaf))));
+			hipLaunchKernelGGL(k_emit_inner, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes,
+							   inner_flag, inner_idx, leaf_idx, out.leaf_unit0, out.recs);
+			hipLaunchKernelGGL(k_emit_leaves, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, leaf_flag, leaf_cnt, leaf_idx, out.leaf_unit0, out.recs);
 		}
 		HIPC(hipGetLastError());
 		HIPC(hipStreamSynchronize(stream));

@@ -32,15 +32,19 @@ constexpr float CIE_DELTA	   = CIE_RANGE / (CIE_SAMPLES - 1);
 constexpr float CIE_Y_NORM	   = CIE_Y_NORM_SUM * CIE_DELTA;
 
 // ---- device BVH ---------------------------------------------------------------------------------
-// Uniform 128-byte records (= one L2 line), record 0 is the root inner node:
-//   inner: q0..q2 = lo.x/lo.y/lo.z of the four children, q3..q5 = hi.x/hi.y/hi.z, q6 = four child refs
-//   leaf : triangle k (k < 3) in floats [10k, 10k+10) = v0, v1, v2 (world space), original triangle index;
-//          float 30 = triangle count
-// child ref: record index | REC_LEAF_BIT for leaves, REC_EMPTY for an unused slot.
-struct __attribute__((aligned(128))) Rec128 {
-	float4 q[8];
+// The BVH is addressed in 64-byte units; unit 0 is the root inner record.
+//   inner (one unit, 64 B): a 4-wide node whose child boxes are bytes on a per-record power-of-two grid:
+//          q0 = origin.xyz, exponent bytes (ex | ey << 8 | ez << 16; grid step of axis a = 2^(e_a - 127));
+//          q1 = lo.x, lo.y, lo.z, hi.x (one byte per child in each word); q2 = hi.y, hi.z, 0, 0; q3 = four child refs.
+//          decoded bound = origin + byte * step (exact product, one rounding); the builder checks every byte against this
+//          decode, so the decoded box always contains the padded fp32 child box.
+//   leaf  (two units, 128 B = one L2 line, 128-byte aligned): triangle k (k < 3) in floats [10k, 10k+10) = v0, v1, v2
+//          (world space), original triangle index; float 30 = triangle count
+// child ref: unit index | REC_LEAF_BIT for leaves, REC_EMPTY for an unused slot.
+struct __attribute__((aligned(64))) Rec64 {
+	float4 q[4];
 };
-static_assert(sizeof(Rec128) == 128, "Rec128 must be 128 bytes");
+static_assert(sizeof(Rec64) == 64, "Rec64 must be 64 bytes");
 constexpr uint32_t REC_LEAF_BIT = 0x80000000u;
 constexpr uint32_t REC_EMPTY	= 0xFFFFFFFFu;
 
@@ -83,7 +87,7 @@ struct DevCamera {
 
 // Everything the kernels read; passed by value.
 struct DevScene {
-	const Rec128* recs;
+	const Rec64* recs;
 	uint32_t n_tris, n_inner, n_leaf;
 	const float* positions;
 	const float* normals;

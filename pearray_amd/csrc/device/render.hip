@@ -110,31 +110,33 @@ __device__ __forceinline__ void trav_pop(Trav& s, STK& st)
 	}
 }
 
-// Inner step: fetch the 4-wide node (112 of its 128 bytes), test the four child boxes, continue with the nearest
+// Inner step: fetch the 4-wide node (one 64-byte unit), decode the four quantised child boxes (bound = origin + byte * step:
+// the product is exact, so the fused form rounds once), test them with the arithmetic of box_hit, continue with the nearest
 // hit child and push the others far-to-near.  MODE_ANY: order does not matter, children are pushed unsorted (in
 // MODE_MIXED occlusion lanes share the sorted code of the closest-hit lanes; occlusion is order independent).
+#define PR_UB(w, k) ((float)(((w) >> (8 * (k))) & 0xFFu)) /* byte k of a packed word as a float: v_cvt_f32_ubyteK */
 template <int M, typename STK>
-__device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
-											   const float4& q5, const float4& q6)
+__device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3)
 {
 	float t[4];
-	uint32_t c[4] = { __float_as_uint(q6.x), __float_as_uint(q6.y), __float_as_uint(q6.z), __float_as_uint(q6.w) };
+	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
 	bool h[4];
 	{
-		// slab distances of the four child boxes, two children per instruction (v_pk_add_f32 / v_pk_mul_f32): the same
-		// subtract-then-multiply arithmetic as box_hit, so the results are identical to the scalar form
-		typedef float f2 __attribute__((ext_vector_type(2)));
-		const f2 ox = { s.r.o.x, s.r.o.x }, oy = { s.r.o.y, s.r.o.y }, oz = { s.r.o.z, s.r.o.z };
-		const f2 ix = { s.r.inv_d.x, s.r.inv_d.x }, iy = { s.r.inv_d.y, s.r.inv_d.y }, iz = { s.r.inv_d.z, s.r.inv_d.z };
-		const f2 ax[2] = { (f2{ q0.x, q0.y } - ox) * ix, (f2{ q0.z, q0.w } - ox) * ix }, bx[2] = { (f2{ q3.x, q3.y } - ox) * ix, (f2{ q3.z, q3.w } - ox) * ix };
-		const f2 ay[2] = { (f2{ q1.x, q1.y } - oy) * iy, (f2{ q1.z, q1.w } - oy) * iy }, by[2] = { (f2{ q4.x, q4.y } - oy) * iy, (f2{ q4.z, q4.w } - oy) * iy };
-		const f2 az[2] = { (f2{ q2.x, q2.y } - oz) * iz, (f2{ q2.z, q2.w } - oz) * iz }, bz[2] = { (f2{ q5.x, q5.y } - oz) * iz, (f2{ q5.z, q5.w } - oz) * iz };
+		const uint32_t eb = __float_as_uint(q0.w);
+		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+		// near / far plane of each axis picked by the sign of the direction -- the value min(a, b) / max(a, b) of box_hit would
+		// select (the decode and the slab distance are monotonic in the byte), for all four children at once
+		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
+		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
+		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
+		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const float axk = ax[k >> 1][k & 1], bxk = bx[k >> 1][k & 1], ayk = ay[k >> 1][k & 1], byk = by[k >> 1][k & 1], azk = az[k >> 1][k & 1],
-						bzk = bz[k >> 1][k & 1];
-			const float t0 = fmaxf(fmaxf(fminf(axk, bxk), fminf(ayk, byk)), fmaxf(fminf(azk, bzk), s.tmin));
-			const float t1 = fminf(fminf(fmaxf(axk, bxk), fmaxf(ayk, byk)), fminf(fmaxf(azk, bzk), s.best.t));
+			const float axk = (__fmaf_rn(PR_UB(wnx, k), sx, q0.x) - s.r.o.x) * s.r.inv_d.x, bxk = (__fmaf_rn(PR_UB(wfx, k), sx, q0.x) - s.r.o.x) * s.r.inv_d.x;
+			const float ayk = (__fmaf_rn(PR_UB(wny, k), sy, q0.y) - s.r.o.y) * s.r.inv_d.y, byk = (__fmaf_rn(PR_UB(wfy, k), sy, q0.y) - s.r.o.y) * s.r.inv_d.y;
+			const float azk = (__fmaf_rn(PR_UB(wnz, k), sz, q0.z) - s.r.o.z) * s.r.inv_d.z, bzk = (__fmaf_rn(PR_UB(wfz, k), sz, q0.z) - s.r.o.z) * s.r.inv_d.z;
+			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
+			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
 			t[k]		   = t0;
 			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY; // acceptance rule of box_hit
 		}
@@ -178,15 +180,15 @@ template <int M>
 __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& st)
 {
 	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + s.cur);
-	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
-	trav_inner_rec<M>(s, st, q0, q1, q2, q3, q4, q5, q6);
+	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+	trav_inner_rec<M>(s, st, q0, q1, q2, q3);
 }
 
 // Leaf step: fetch the leaf record (<= 3 triangles) and run the watertight test on each.
 // SPH: the leaf may hold analytic spheres (scenes with sphere entities); compiled out of the lean persistent kernel
-template <int M, bool SPH, typename STK>
-__device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
-											  const float4& q5, const float4& q6, const float4& q7)
+template <int M, bool SPH>
+__device__ __forceinline__ void leaf_test(Trav& s, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4, const float4& q5,
+										  const float4& q6, const float4& q7)
 {
 	const bool ANY = M == MODE_ANY || (M == MODE_MIXED && s.any);
 	const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
@@ -217,6 +219,13 @@ __device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0
 			}
 		}
 	}
+}
+template <int M, bool SPH, typename STK>
+__device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
+											  const float4& q5, const float4& q6, const float4& q7)
+{
+	const bool ANY = M == MODE_ANY || (M == MODE_MIXED && s.any);
+	leaf_test<M, SPH>(s, q0, q1, q2, q3, q4, q5, q6, q7);
 	s.cur = REC_EMPTY;
 	if (ANY && s.best.tri != INVALID) { // occluded: done
 		st.reset();
@@ -2061,18 +2070,21 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			const bool go_inner = do_inner && at_inner, go_leaf = (both || !do_inner) && at_leaf;
 			// (Measured and dropped, see DESIGN.md: a cooperative fetch -- eight lanes reading one record's eight chunks, handed over
 			// through an LDS staging buffer: 2x the raw gather rate in tools/micro/gather_bench.hip but 11 % slower here; 4-byte
-			// packed stack entries to make room for a 4th wave per SIMD: +5 % time, and the 4th wave bought nothing.)
+			// packed stack entries to make room for a 4th wave per SIMD: +5 % time, and the 4th wave bought nothing; postponed
+			// leaves -- a ray parks the leaf it reaches and goes on with inner nodes: lane utilisation 0.58 -> 0.63, but 3-4 % more
+			// records from the delayed shrinking of best.t, 1.5 % slower; 8-wide quantised nodes: 23 % fewer inner records, 2.5x the
+			// instructions per step, 13 % slower.)
 			if (go_inner || go_leaf) {
 				const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
-				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6];
+				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3]; // an inner record, or the first half of a leaf
 				if (go_inner) {
 					if (COUNT) {
 						cn_c += s.any ? 0 : 1;
 						cn_a += s.any ? 1 : 0;
 					}
-					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, q3, q4, q5, q6);
+					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, q3);
 				} else {
-					const float4 q7 = rec[7];
+					const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
 					if (COUNT) {
 						cl_c += s.any ? 0 : 1;
 						cl_a += s.any ? 1 : 0;

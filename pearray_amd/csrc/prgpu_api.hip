@@ -940,8 +940,8 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 	out->leaves_closest  = host[PRGPU_STAT_COUNT + 1];
 	out->nodes_any	   = host[PRGPU_STAT_COUNT + 2];
 	out->leaves_any	   = host[PRGPU_STAT_COUNT + 3];
-	out->node_bytes	   = sizeof(prd::Rec128); // inner record
-	out->leaf_bytes	   = sizeof(prd::Rec128); // leaf record (<= 3 triangles)
+	out->node_bytes	   = sizeof(prd::Rec64); // inner record (4-wide, quantised child boxes)
+	out->leaf_bytes	   = 2 * sizeof(prd::Rec64); // leaf record (<= 3 triangles)
 	out->ray_bytes	   = 32; // o,tmin + d,tmax
 	out->hit_bytes	   = 16; // t,u,v,tri
 	out->wave_steps_closest = host[PRGPU_STAT_COUNT + 4];

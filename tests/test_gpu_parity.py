@@ -235,7 +235,7 @@ def test_instrumented_run_changes_nothing_and_counts_work():
     tc = b.traceCounters()
     st = b.statistics()
     assert tc["rays_closest"] == st["primary_rays"] + st["bounce_rays"] and tc["rays_any"] == st["shadow_rays"]
-    assert tc["nodes_closest"] >= tc["rays_closest"] and tc["leaves_closest"] > 0 and tc["node_bytes"] == 128 and tc["leaf_bytes"] == 128
+    assert tc["nodes_closest"] >= tc["rays_closest"] and tc["leaves_closest"] > 0 and tc["node_bytes"] == 64 and tc["leaf_bytes"] == 128
     ms, n = b.kernelTime("path")  # single-tap filter: the persistent path kernel, one launch per render call
     assert n == 1 and ms > 0
     assert tc["shade_batches"] > 0 and tc["shade_lanes"] >= tc["rays_closest"]  # every traced vertex is shaded (+ path ends, slot starts)
