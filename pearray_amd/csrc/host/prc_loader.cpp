@@ -745,11 +745,17 @@ struct Loader {
 					fail(PRGPU_EINVAL, "mesh '" + name + "': face index out of range");
 		meshes[name] = std::move(m);
 	}
-	void add_plane(const Group& g, const std::string& name) // plane.cpp:241-258
+	// Entity visibility flags are parsed by the reference (SceneLoader.cpp:452-497) and stored, but no tracing code ever reads them:
+	// every Embree ray carries MASK_ALL (Scene.cpp:135,166).  Accept them and say so.
+	void note_visibility_flags(const Group& g)
 	{
 		for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
 			if (!get_bool(g, flag, true))
-				fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
+				warn(where(g) + ": visibility flag :" + flag + " false has no effect (the reference stores it and traces with MASK_ALL)");
+	}
+	void add_plane(const Group& g, const std::string& name) // plane.cpp:241-258
+	{
+		note_visibility_flags(g);
 		float xa[3] = { 1, 0, 0 }, ya[3] = { 0, 1, 0 };
 		if (!get_vec3(g, "x_axis", xa))
 			get_vec3(g, "axis_x", xa);
@@ -809,9 +815,7 @@ struct Loader {
 			return;
 		}
 		if (type == "sphere") { // sphere.cpp:157-168
-			for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
-				if (!get_bool(g, flag, true))
-					fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
+			note_visibility_flags(g);
 			prgpu_entity e;
 			std::memset(&e, 0, sizeof(e));
 			e.first_tri = (uint32_t)(out.indices.size() / 3);
@@ -846,9 +850,7 @@ struct Loader {
 		}
 		if (type != "mesh")
 			fail(PRGPU_EUNSUPPORTED, where(g) + ": entity type '" + type + "' is not supported (mesh, plane and sphere are; tessellate other primitives)");
-		for (const char* flag : { "camera_visible", "light_visible", "bounce_visible", "shadow_visible" })
-			if (!get_bool(g, flag, true))
-				fail(PRGPU_EUNSUPPORTED, where(g) + ": visibility flag :" + flag + " false is not supported");
+		note_visibility_flags(g);
 		const auto mit = meshes.find(get_string(g, "mesh", ""));
 		if (mit == meshes.end())
 			fail(PRGPU_EINVAL, where(g) + ": entity '" + name + "' refers to unknown mesh '" + get_string(g, "mesh", "") + "'");

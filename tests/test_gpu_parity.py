@@ -188,6 +188,35 @@ def test_axis_aligned_and_grazing_rays():
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("offset,scale", [((1000.0, -500.0, 250.0), 1.0), ((0.0, 0.0, 0.0), 1e-3), ((3.0e4, 1.0e4, -2.0e4), 300.0)])
+def test_quantised_nodes_far_from_the_origin_and_at_other_scales(offset, scale):
+    """The 64-byte inner records store child boxes as bytes on a per-record grid: hit ids must stay those of the exhaustive
+    test for geometry far from the world origin (few mantissa bits left below the grid step), tiny and huge, with
+    axis-parallel rays whose origins lie exactly on triangle vertices' coordinates (box planes)."""
+    pos, faces = scene.triangle_soup(20_000, seed=7, size=0.02, lo=(-1, -1, -1), hi=(1, 1, 1))
+    M = np.eye(4, dtype=np.float32) * np.float32(scale); M[3, 3] = 1.0; M[:3, 3] = offset
+    b = scene.SceneBuilder(8, 8)
+    b.settings.aa_samples = 1
+    b.add_mesh(pos, faces, b.lambert(b.spectrum_const(0.5)), transform=M)
+    sc = b.build()
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(21)
+    n = 4000
+    world = (pos.astype(np.float32) * np.float32(scale) + np.asarray(offset, dtype=np.float32)).astype(np.float32)
+    org = ((rng.random((n, 3)) * 2 - 1) * scale + offset).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float32)
+    d[: n // 2] = axes[rng.integers(0, 6, n // 2)]
+    # every fourth origin shares two coordinates with a vertex: the ray runs inside box planes of that vertex's leaf
+    pick = world[rng.integers(0, len(world), n // 4)]
+    org[: n // 4, 1:] = pick[:, 1:]
+    tmin = np.float32(1e-4 * scale)
+    a, c = g.traceRays(org, d, tmin, np.inf), o.trace_closest(org, d, tmin, np.inf, brute=True)
+    assert (c[0] != abi.INVALID_ID).sum() > n // 10
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
+
+
 def test_tile_sharding_sums_to_whole_and_matches_oracle_rank():
     """Multi-GPU model on one device: each 'rank' renders its Z-order tiles; the rank frames add up exactly to
     the unsharded frame, and a rank's frame equals the oracle restricted to the same tiles."""
