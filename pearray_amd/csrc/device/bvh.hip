@@ -295,10 +295,13 @@ __device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int n
 			hi = fmaxf(hi, ch[k].hi[a]);
 		}
 		org[a] = lo;
-		int e  = ilogbf(fmaxf((hi - lo) * (1.0f / 255.0f), 1e-30f)) + 1; // 2^e >= extent / 255
-		for (;; ++e) {
+		// 2^e >= extent / 255, kept inside the normal exponent range so that the step decodes as (byte << 23); the loop is bounded
+		// whatever the input (non-finite coordinates end in the full-grid fallback below instead of spinning)
+		int e = (int)fminf(fmaxf((float)ilogbf(fmaxf((hi - lo) * (1.0f / 255.0f), 1e-30f)) + 1.0f, -126.0f), 127.0f);
+		bool fits = false;
+		for (; e <= 127 && !fits; ++e) {
 			const float s = ldexpf(1.0f, e), inv_s = ldexpf(1.0f, -e);
-			bool fits = true;
+			fits		  = true;
 			for (int k = 0; k < nc; ++k) {
 				int ql = (int)floorf((ch[k].lo[a] - lo) * inv_s);
 				ql	   = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
@@ -315,9 +318,13 @@ __device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int n
 				qlo[a][k] = (uint32_t)ql;
 				qhi[a][k] = (uint32_t)qh;
 			}
-			if (fits)
-				break;
 		}
+		--e; // the exponent of the last attempt
+		if (!fits)
+			for (int k = 0; k < nc; ++k) { // lower bound = origin, upper bound = origin + 255 * 2^127 = +inf
+				qlo[a][k] = 0u;
+				qhi[a][k] = 255u;
+			}
 		ebyte[a] = (uint32_t)(e + 127);
 	}
 	uint32_t w[16];

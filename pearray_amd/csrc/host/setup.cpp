@@ -707,9 +707,15 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 	for (uint64_t i = 0; i < 3ull * d->n_triangles; ++i)
 		if (d->indices[i] >= d->n_vertices)
 			return bad("vertex index out of range");
+	for (uint64_t i = 0; i < 3ull * d->n_vertices; ++i)
+		if (!std::isfinite(d->positions[i]))
+			return bad("vertex positions must be finite");
 	uint32_t expect = 0;
 	for (uint32_t e = 0; e < d->n_entities; ++e) {
 		const prgpu_entity& E = d->entities[e];
+		for (int k = 0; k < 12; ++k)
+			if (!std::isfinite(E.transform[k]))
+				return bad("entity transforms must be finite");
 		if (E.first_tri != expect || E.n_tris == 0)
 			return bad("entity triangle ranges must be contiguous, ordered and non-empty");
 		expect += E.n_tris;
