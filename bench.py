@@ -120,6 +120,10 @@ def main():
     ap.add_argument("--triangles", type=int, default=NTRI)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="skip roofline/cpu passes (for rocprofv3 runs)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N>1 rehearsal on a one-GPU box: every rank renders on device 0 and the collectives run over gloo "
+                         "(staged through host memory); exercises tile sharding + reduce end to end, the number is NOT a result")
+    ap.add_argument("--check-frame", action="store_true", help="rank 0: compare the reduced frame with a one-rank render of the same iterations")
     args = ap.parse_args()
 
     import numpy as np
@@ -130,10 +134,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if args.rehearse_on_one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl", rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -189,6 +193,14 @@ def main():
                    "scene_create_s": round(t_create, 3)},
     }
 
+    if args.check_frame and rank == 0:
+        # the reduced frame must equal a one-rank render of the same iterations (single-tap filter: bit for bit)
+        ref = backend.RenderContext(sc, device=local)
+        ref.render(args.warmup + args.steps)
+        ref.waitForFinish()
+        rxyz, rsmp, _ = ref.output()
+        out["frame_check"] = {"xyz_equal": bool(np.array_equal(xyz.cpu().numpy(), rxyz)), "samples_equal": bool(np.array_equal(smp.cpu().numpy(), rsmp))}
+        ref.close()
     if not args.profile_only:
         out["roofline"] = roofline(ctx, rank)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -196,6 +208,8 @@ def main():
         if rank != 0:
             out.pop("roofline", None)
 
+    if args.rehearse_on_one_gpu:
+        out["rehearsal"] = "all ranks on device 0, gloo collectives: not a result"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -7,7 +7,7 @@
 // own bounds, so one sort + one radix-tree pass yields the same two-level structure: the top of the
 // tree separates entities, each entity's subtree is an LBVH over its own triangles.
 //
-// Layout produced (see pr_device.h): uniform 128-byte records -- 4-wide inner nodes (radix tree collapsed by
+// Layout produced (see pr_device.h): 64-byte quantised 4-wide inner nodes and 128-byte leaves (radix tree collapsed by
 // pulling grandchildren up) and leaves of 1..3 triangles in Morton order.
 #include "bvh.h"
 
@@ -215,7 +215,7 @@ __device__ __forceinline__ void pad_box(float* lo, float* hi)
 }
 
 // 6. collapse the radix tree into the 4-wide traversal structure.
-// Records are uniform 128-byte blocks (one L2 line): inner nodes hold up to four child boxes, leaves hold up
+// Inner nodes (64 bytes) hold up to four quantised child boxes, leaves (128 bytes, one L2 line) hold up
 // to three triangles.  Rules (all decidable per node, no top-down pass):
 //   * a subtree with <= 3 triangles whose parent has > 3 is a LEAF record (these partition the triangles);
 //   * an internal node at EVEN depth with > 3 triangles is an INNER record; its children are its radix-tree

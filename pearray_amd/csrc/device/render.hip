@@ -7,7 +7,7 @@
 // replaces; the scalar arithmetic lives in pr_device.h.
 //
 // No MFMA: no stage is a dense contraction.  The kernels are latency/bandwidth bound on BVH-node and
-// triangle fetches (uniform 128-byte records, see DESIGN.md for the bytes-per-ray model).
+// triangle fetches (64-byte inner and 128-byte leaf records, see DESIGN.md for the bytes-per-ray model).
 #include "render.h"
 
 #include <algorithm>
@@ -23,7 +23,7 @@ struct Hit {
 enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES, CNT_SHADE_TICKS, CNT_IDLE_TICKS, CNT_TOTAL_TICKS };
 
 // ---- traversal ------------------------------------------------------------------------------------------------
-// Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one 128-byte
+// Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one
 // record per step and refill idle lanes when too few are active, so a few long rays do not hold 63 idle lanes.
 // The traversal stack lives in LDS (STACK_LDS entries per lane, bank-conflict free layout [entry][lane]); the
 // rare deeper stacks spill their oldest entries to a per-thread slab in HBM.

@@ -17,6 +17,14 @@ def reduce_framebuffer(xyz, samples, dst=0):
     """In-place sum onto rank `dst`: xyz float32 [H,W,3], samples int32 [H,W]."""
     if world()[1] == 1:
         return
+    if dist.get_backend() == "gloo" and xyz.is_cuda:
+        # rehearsal on a one-GPU box (bench.py --rehearse-on-one-gpu): stage through host memory
+        hx, hs = xyz.cpu(), samples.cpu()
+        dist.reduce(hx, dst=dst, op=dist.ReduceOp.SUM)
+        dist.reduce(hs, dst=dst, op=dist.ReduceOp.SUM)
+        xyz.copy_(hx)
+        samples.copy_(hs)
+        return
     dist.reduce(xyz, dst=dst, op=dist.ReduceOp.SUM)
     dist.reduce(samples, dst=dst, op=dist.ReduceOp.SUM)
 
@@ -24,7 +32,7 @@ def reduce_framebuffer(xyz, samples, dst=0):
 def _scalar(value, op, device=None):
     if world()[1] == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=op)
     return float(t.item())
 
