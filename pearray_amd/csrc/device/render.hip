@@ -1853,12 +1853,10 @@ __device__ __forceinline__ uint32_t ring_take(uint32_t* q, uint32_t cap_mask, ui
 	return v;
 }
 
-constexpr int PP_SEGMENTS = 8; // pixel hand-out segments = XCDs of the MI355X
 struct PersistentArgs {
 	const uint32_t* owned; // Morton-ordered list of the pixels this device renders
 	uint32_t n_owned;
-	uint32_t* next_pixel; // PP_SEGMENTS hand-out counters into the segments of `owned` (zeroed before the launch)
-	uint32_t n_segments;  // 1 <= n_segments <= PP_SEGMENTS
+	uint32_t* next_pixel; // hand-out counter into `owned` (zeroed before the launch)
 	uint32_t* error;	  // set when a wave gave up waiting (a lost queue entry: bug)
 	uint32_t slots_per_block;
 	uint32_t iter_begin, iter_end;
@@ -1972,24 +1970,9 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				}
 				bool retired = false;
 				{
-					// 64 neighbouring pixels per wave-full, XCD-aware: the Morton-ordered pixel list is cut into PP_SEGMENTS equal
-					// segments with one hand-out counter each and a block starts with the segment of its XCD (workgroups are dealt
-					// round-robin to the 8 XCDs, so blockIdx % 8 is the XCD), which keeps the primary and shadow rays of one
-					// image region in one L2; an exhausted segment sends the wave on to the next one (work stealing)
-					uint32_t idx	= INVALID;
-					bool unassigned = need_pixel;
-					for (uint32_t k = 0; k < a.n_segments && __any(unassigned); ++k) {
-						const uint32_t seg	= (blockIdx.x + k) % a.n_segments;
-						const uint32_t lo	= (uint32_t)(((unsigned long long)a.n_owned * seg) / a.n_segments);
-						const uint32_t hi	= (uint32_t)(((unsigned long long)a.n_owned * (seg + 1u)) / a.n_segments);
-						const uint32_t cand = lo + wave_append(unassigned, a.next_pixel + seg);
-						if (unassigned && cand < hi) {
-							idx		   = cand;
-							unassigned = false;
-						}
-					}
+					const uint32_t idx = wave_append(need_pixel, a.next_pixel); // 64 neighbouring pixels per wave-full
 					if (need_pixel) {
-						if (idx != INVALID) {
+						if (idx < a.n_owned) {
 							ps.pixel[slot] = a.owned[idx];
 							iter		   = a.iter_begin;
 						} else {
@@ -2318,13 +2301,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.shader_wave	  = shader_wave ? 1u : 0u;
 	a.shade_help	  = (uint32_t)std::max(64, shade_help);
 	a.gstats		  = gstats;
-	{
-		int segs = PP_SEGMENTS;
-		if (const char* env = getenv("PRGPU_PP_SEGMENTS"))
-			segs = atoi(env);
-		a.n_segments = (uint32_t)std::min(PP_SEGMENTS, std::max(1, segs));
-	}
-	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t) * PP_SEGMENTS, st);
+	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks), block(TRAV_BLOCK);
 	const bool full = sc.features != 0; // lean variant for Lambert / mesh / area-light scenes
 #define PR_LAUNCH_PP(KERNEL)                                                                         \

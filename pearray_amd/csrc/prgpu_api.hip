@@ -405,7 +405,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	if (const char* env = getenv("PRGPU_PP_SHADE_MIN"))
 		s->pp_shade_min = atoi(env);
 	AL(s->pp_pixel, ns, false);
-	AL(s->pp_next, 8, true); // prd::PP_SEGMENTS hand-out counters
+	AL(s->pp_next, 1, true);
 	AL(s->pp_error, 1, true);
 	AL(s->gstats, prd::N_DEVICE_COUNTERS, true);
 	{ // persistent traversal grid: a few blocks of 256 threads per CU (32 KB of LDS stack each)
