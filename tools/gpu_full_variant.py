@@ -1,0 +1,25 @@
+"""Throughput of the FULL kernel variant (delta / rough / principled materials, infinite lights, spheres) next to the lean one on
+Cornell-box scenes at 1024x1024 -- the state of the C5 feature set on one GPU.  usage: python tools/gpu_full_variant.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pearray_amd import _cabi as abi
+from pearray_amd import backend, scene
+
+def run(name, sc, iters=64):
+    ctx = backend.RenderContext(sc)
+    ctx.render(4); ctx.waitForFinish()
+    s0 = ctx.statistics()
+    t = time.time(); ctx.render(iters); ctx.waitForFinish(); dt = time.time() - t
+    s1 = ctx.statistics()
+    n = s1["pixel_samples"] - s0["pixel_samples"]
+    rays = sum(s1[k] - s0[k] for k in ("primary_rays", "bounce_rays", "shadow_rays"))
+    depth = (s1["camera_depth"] - s0["camera_depth"]) / max(n, 1)
+    print("%-46s %7.1f Msamples/s %7.0f Mrays/s  mean depth %.2f  %.2f ms/iteration" % (name, n / dt / 1e6, rays / dt / 1e6, depth, dt / iters * 1e3), flush=True)
+    ctx.close()
+
+W = H = 1024
+run("lambert cornell (lean variant)", scene.cornell_box(W, H, spp=256))
+run("glass boxes (bk7)", scene.cornell_glassy(W, H, spp=256))
+run("metal boxes", scene.cornell_metal(W, H, spp=256))
+run("rough conductor/dielectric boxes, vndf", scene.cornell_rough(W, H, spp=256, roughness=0.2, vndf=True))
