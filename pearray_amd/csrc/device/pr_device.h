@@ -58,7 +58,8 @@ struct DevEntity {
 	uint32_t has_uvs;		 // MESH: texture coordinates present (interpolated uv, UV-derived tangent frame)
 };
 
-constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u, FEAT_SHAPE_LIGHTS = 32u, FEAT_TEXTURES = 64u;
+constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u, FEAT_SHAPE_LIGHTS = 32u, FEAT_TEXTURES = 64u,
+				   FEAT_ROUGH_MATERIALS = 128u, FEAT_ALL = 255u;
 
 // Area-light data of an analytic entity (one per entity, meaningful for emissive planes and spheres):
 // PlaneEntity::cache (plane.cpp:227-243) and SphereEntity (sphere.cpp:23-31,106-118)

@@ -400,14 +400,14 @@ __device__ __forceinline__ uint32_t prim_id(const DevScene& sc, uint32_t tri)
 	return E.kind != PRGPU_ENTITY_MESH ? 0u : tri - E.first_tri;
 }
 // MeshEntity::provideGeometryPoint (entities/mesh.cpp:205-250)
-template <bool FULL>
+template <uint32_t FEATS>
 __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri, float u, float v, V3 P, GeomPoint& g)
 {
 	const uint32_t e   = sc.tri_entity[tri];
 	const DevEntity& E = sc.entities[e];
 	const uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
 	V3 N, Nx, Ny;
-	if (FULL && E.kind == PRGPU_ENTITY_SPHERE) { // SphereEntity::provideGeometryPoint (sphere.cpp:118-129)
+	if ((FEATS & FEAT_SPHERES) && E.kind == PRGPU_ENTITY_SPHERE) { // SphereEntity::provideGeometryPoint (sphere.cpp:118-129)
 		g.N = normalized(P - v3(E.m[3], E.m[7], E.m[11]));
 		frame_duff(g.N, g.Nx, g.Ny);
 		g.Nx	   = normalized(g.Nx);
@@ -419,7 +419,7 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 		g.uv[0] = g.uv[1] = 0.0f; // Spherical::uv_from_normal is not built (validate rejects textured materials on spheres)
 		return;
 	}
-	if (FULL && E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
+	if ((FEATS & FEAT_PLANES) && E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
 		const uint32_t t0 = E.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0
 		const V3 v0 = load3(sc.positions, sc.indices[3 * t0]), v1 = load3(sc.positions, sc.indices[3 * t0 + 1]), v3p = load3(sc.positions, sc.indices[3 * t0 + 2]);
 		const V3 x = v3p - v0, y = v1 - v0;
@@ -435,8 +435,8 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 		g.uv[1] = tri == E.first_tri ? v : 1 - v;
 		return;
 	}
-	const bool has_uv = FULL && E.has_uvs != 0u; // MeshEntity<.., HasUV> (mesh.cpp:205-228)
-	if (FULL) {
+	const bool has_uv = (FEATS & FEAT_TEXTURES) && E.has_uvs != 0u; // MeshEntity<.., HasUV> (mesh.cpp:205-228)
+	if (FEATS & (FEAT_TEXTURES | FEAT_AOVS)) {
 		if (has_uv) { // Face::interpolateUVs (Face.h:39-45) = Triangle::interpolate (Triangle.h:23-27)
 			for (int c = 0; c < 2; ++c)
 				g.uv[c] = (sc.uvs[2 * i1 + c] * u + sc.uvs[2 * i2 + c] * v) + sc.uvs[2 * i0 + c] * (1 - u - v);
@@ -803,9 +803,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 // (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53).
 // Processes the path vertex of `slot` whose closest hit is in ps.hit[slot]: adds emission, prepares the NEE shadow ray
 // (returned in sh_*, want_shadow) and the next bounce ray (written to the slot, alive).
-// FULL = false is the lean variant for scenes with Lambert materials, mesh entities and area lights only (DevScene::features == 0,
-// e.g. the C4 benchmark scene): delta materials, infinite lights and plane entities are compiled out, which keeps their registers
-// and spills out of the hot kernel.
+// FEATS = the FEAT_* bits compiled in.  FEATS = 0 is the lean variant for scenes with Lambert materials, mesh entities and area lights only
+// (DevScene::features == 0, e.g. the C4 benchmark scene): delta and rough materials, infinite lights, planes, spheres, textures and AOVs
+// are compiled out, which keeps their registers and spills out of the hot kernel; FEATS = FEAT_DELTA_MATERIALS adds the smooth dielectric /
+// conductor / mirror closures only (glass and metal scenes); FEAT_ALL is everything.
 // one shared out-of-line copy of the spectral node evaluation for the (cold, large) rough / principled closures
 static __device__ __noinline__ Blob spectrum_eval_cold(const DevScene& sc, uint32_t id, const Blob& wl) { return spectrum_eval(sc, id, wl); }
 // ---- material evaluation for next event estimation: IMaterial::eval in tangent space ---------------------
@@ -1129,10 +1130,10 @@ __device__ __noinline__ void rough_eval(const DevScene& s, const prgpu_material&
 	}
 }
 // IMaterial::eval for next event estimation: LambertMaterial::eval (lambert.cpp:33-42) inline, the rough closures out of line
-template <bool FULL>
+template <uint32_t FEATS>
 __device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
 {
-	if (FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED)) {
+	if ((FEATS & FEAT_ROUGH_MATERIALS) && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED)) {
 		rough_eval(s, mat, wl, cie_y, Vt, Lt, weight, pdf, delta);
 		return;
 	}
@@ -1207,7 +1208,7 @@ __device__ __noinline__ void rough_sample(const DevScene& s, const prgpu_materia
 		pdf_s = blob(1);
 }
 
-template <bool FULL>
+template <uint32_t FEATS>
 __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState& ps, uint32_t slot, BlockStats& bs, bool& alive, bool& want_shadow,
 											 float4& sh_o, float4& sh_d, float4& sh_xyz)
 {
@@ -1248,7 +1249,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		if (depth == 0) { // IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53): one fragment per non-delta infinite light
 			atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
 			bool illuminated = false;
-			for (uint32_t k = 0; FULL && k < sc.n_inf_lights; ++k) {
+			for (uint32_t k = 0; (FEATS & FEAT_INFINITE_LIGHTS) && k < sc.n_inf_lights; ++k) {
 				const DevInfLight& il = sc.inf_lights[k];
 				if (il.kind != PRGPU_LIGHT_ENVIRONMENT)
 					continue;
@@ -1261,7 +1262,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
 				apply_fragment(ps, pixel, fb, xyz);
 			}
-		} else if (FULL && sc.n_inf_lights && cfg.direct) {
+		} else if ((FEATS & FEAT_INFINITE_LIGHTS) && sc.n_inf_lights && cfg.direct) {
 			// ---- handleInfLights (direct.cpp:415-456)
 			float denom_mis = 0;
 			Blob radiance	= blob(0);
@@ -1295,7 +1296,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	} else {
 		const V3 P = ray_o + ray_d * hit4.x;
 		GeomPoint gp;
-		geometry_point<FULL>(sc, tri, hit4.y, hit4.z, P, gp);
+		geometry_point<FEATS>(sc, tri, hit4.y, hit4.z, P, gp);
 		const V3 N		   = gp.N;
 		const float NdotV  = dot(ray_d, N);
 		const V3 dP		   = ray_o - P;
@@ -1305,7 +1306,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
 		if (pathLength == 1) {
 			ps.samples[pixel] += 1;
-			if (FULL && ps.aov_mask) { // LocalFrameOutputDevice::commitShadingPoints (LocalFrameOutputDevice.cpp:252-283): plain per-pixel sums
+			if ((FEATS & FEAT_AOVS) && ps.aov_mask) { // LocalFrameOutputDevice::commitShadingPoints (LocalFrameOutputDevice.cpp:252-283): plain per-pixel sums
 				auto add3 = [&](int k, V3 v) {
 					if (ps.aov[k]) {
 						ps.aov[k][3 * pixel] += v.x;
@@ -1345,10 +1346,10 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const uint32_t lid	 = sc.entities[gp.entity].light_id;
 					const float selProb	 = sc.light_cdf[lid + 1] - sc.light_cdf[lid];
 					float posPDF		 = 1.0f / sc.entities[gp.entity].world_area;
-					if (FULL && sc.entities[gp.entity].kind == PRGPU_ENTITY_PLANE) { // seen from the previous vertex (plane.cpp:184-195)
+					if ((FEATS & FEAT_SHAPE_LIGHTS) && sc.entities[gp.entity].kind == PRGPU_ENTITY_PLANE) { // seen from the previous vertex (plane.cpp:184-195)
 						const float4 lpos = ps.last_pos[slot];
 						posPDF			  = plane_light_pdf(sc.shape_lights[gp.entity], P, v3(lpos.x, lpos.y, lpos.z));
-					} else if (FULL && sc.entities[gp.entity].kind == PRGPU_ENTITY_SPHERE) {
+					} else if ((FEATS & FEAT_SHAPE_LIGHTS) && sc.entities[gp.entity].kind == PRGPU_ENTITY_SPHERE) {
 						posPDF = 2 * sc.shape_lights[gp.entity].pdf_cache; // sphere.cpp:118
 					}
 					posPDF				 = posPDF * depth2 / fabsf(cosC);
@@ -1368,7 +1369,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			go_on = false;
 		if (go_on) {
 			prgpu_material mat = sc.materials[gp.material];
-			if (FULL && (sc.features & FEAT_TEXTURES)) { // ShadingContext::UV driven nodes
+			if ((FEATS & FEAT_TEXTURES) && (sc.features & FEAT_TEXTURES)) { // ShadingContext::UV driven nodes
 				mat.albedo		 = resolve_texture(sc, mat.albedo, gp.uv);
 				mat.ior			 = resolve_texture(sc, mat.ior, gp.uv);
 				mat.k			 = resolve_texture(sc, mat.k, gp.uv);
@@ -1376,15 +1377,15 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			}
 			const V3 Vt				 = to_tangent_space(N, gp.Nx, gp.Ny, -ray_d);
 			uint64_t rnd			 = ps.rng[pixel];
-			const bool deltaMat		 = FULL && (mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR || mat.kind == PRGPU_MAT_MIRROR); // IMaterial::hasOnlyDeltaDistribution
-			const bool roughMat		 = FULL && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED);
+			const bool deltaMat		 = (FEATS & FEAT_DELTA_MATERIALS) && (mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR || mat.kind == PRGPU_MAT_MIRROR); // IMaterial::hasOnlyDeltaDistribution
+			const bool roughMat		 = (FEATS & FEAT_ROUGH_MATERIALS) && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED);
 			const Blob cie_y_blob	 = blob4(cie.y[0], cie.y[1], cie.y[2], cie.y[3]);
-			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + (FULL ? sc.n_inf_lights : 0u))) { // direct.cpp:100-101
+			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + ((FEATS & FEAT_INFINITE_LIGHTS) ? sc.n_inf_lights : 0u))) { // direct.cpp:100-101
 				// ---- handleNEE
 				do {
 					float selPdf;
-					const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + (FULL ? sc.n_inf_lights : 0u) + 1, rng_float(rnd), selPdf, nullptr);
-					if (FULL && lid >= sc.n_lights) {
+					const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + ((FEATS & FEAT_INFINITE_LIGHTS) ? sc.n_inf_lights : 0u) + 1, rng_float(rnd), selPdf, nullptr);
+					if ((FEATS & FEAT_INFINITE_LIGHTS) && lid >= sc.n_lights) {
 						// ---- infinite light: Light::sample (Light.cpp:112-150) + the isInfinite branches of handleNEE
 						const DevInfLight& il = sc.inf_lights[lid - sc.n_lights];
 						const float d0 = rng_float(rnd), d1 = rng_float(rnd); // DirectionRND
@@ -1412,7 +1413,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
 						Blob weight, bsdf_pdf;
 						bool evalDelta;
-						material_eval<FULL>(sc, mat, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
+						material_eval<FEATS>(sc, mat, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
 						if (evalDelta) // direct.cpp:269-270
 							break;
 						const Blob bsdfWvlPdfS = bsdf_pdf * hf;
@@ -1467,11 +1468,11 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					V3 lp;
 					float pdf_a;
 					GeomPoint lgp;
-					if (FULL && LE.kind == PRGPU_ENTITY_PLANE) { // spherical-rectangle sampling from the shading point (plane.cpp:147-182)
+					if ((FEATS & FEAT_SHAPE_LIGHTS) && LE.kind == PRGPU_ENTITY_PLANE) { // spherical-rectangle sampling from the shading point (plane.cpp:147-182)
 						const DevShapeLight& SL = sc.shape_lights[le];
 						plane_light_sample(SL, P, u0, u1, lp, pdf_a);
 						lgp.N = v3(SL.Ez[0], SL.Ez[1], SL.Ez[2]);
-					} else if (FULL && LE.kind == PRGPU_ENTITY_SPHERE) { // sphere.cpp:106-116,128-134
+					} else if ((FEATS & FEAT_SHAPE_LIGHTS) && LE.kind == PRGPU_ENTITY_SPHERE) { // sphere.cpp:106-116,128-134
 						sphere_light_sample(sc.shape_lights[le], LE.m, P, u0, u1, lp, pdf_a);
 						lgp.N = normalized_or_zero(lp - v3(LE.m[3], LE.m[7], LE.m[11]));
 					} else {
@@ -1496,7 +1497,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 							bv = y;
 						}
 						lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
-						geometry_point<FULL>(sc, ltri, bu, bv, lp, lgp);
+						geometry_point<FEATS>(sc, ltri, bu, bv, lp, lgp);
 					}
 					const V3 L			 = normalized(lp - P);
 					const float cosLight = fminf(1.0f, fmaxf(-1.0f, -dot(L, lgp.N)));
@@ -1510,7 +1511,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
 					Blob weight, bsdf_pdf;
 					bool evalDelta;
-					material_eval<FULL>(sc, mat, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
+					material_eval<FEATS>(sc, mat, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
 					if (evalDelta) // direct.cpp:269-270
 						break;
 					const Blob bsdfWvlPdfS = bsdf_pdf * hf;
@@ -1572,12 +1573,12 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				bool sampleDelta	= deltaMat;
 				if (roughMat) {
 					rough_sample(sc, mat, wl, cie_y_blob, Vt, rnd, Lt, integral_weight, pdf_s, sampleDelta, heroCollapsing);
-				} else if (FULL && mat.kind == PRGPU_MAT_MIRROR) {
+				} else if ((FEATS & FEAT_DELTA_MATERIALS) && mat.kind == PRGPU_MAT_MIRROR) {
 					// MirrorMaterial::sample (mirror.cpp:51-60)
 					pdf_s			= blob(1);
 					integral_weight = spectrum_eval(sc, mat.albedo, wl);
 					Lt				= v3(-Vt.x, -Vt.y, Vt.z);
-				} else if (FULL && mat.kind == PRGPU_MAT_CONDUCTOR) {
+				} else if ((FEATS & FEAT_DELTA_MATERIALS) && mat.kind == PRGPU_MAT_CONDUCTOR) {
 					// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
 					pdf_s		   = blob(1);
 					const Blob eta = spectrum_eval(sc, mat.ior, wl), kk = spectrum_eval(sc, mat.k, wl);
@@ -1649,7 +1650,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						ps.throughput[slot] = to4(throughput);
 						ps.path_pdf[slot]	= to4(path_pdf);
 						ps.prev_pdf[slot]	= to4(prev_pdf);
-						if (FULL && (sc.features & FEAT_SHAPE_LIGHTS))
+						if ((FEATS & FEAT_SHAPE_LIGHTS) && (sc.features & FEAT_SHAPE_LIGHTS))
 							ps.last_pos[slot] = make_float4(P.x, P.y, P.z, 0.0f); // current.LastPosition (direct.cpp:175)
 						ps.flags[slot]		= (flags & ~0xFFu) | nd;
 						atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
@@ -1682,9 +1683,9 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 	if (i < n_active) {
 		slot = active ? active[i] : slot_base + i;
 		if (sc.features)
-			shade_vertex<true>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+			shade_vertex<FEAT_ALL>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 		else
-			shade_vertex<false>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+			shade_vertex<0u>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 	}
 	// ballot/prefix-scan compaction of survivors, finished paths and of the shadow queue
 	const uint32_t pos_next = wave_append(alive, &counters[0]);
@@ -1872,7 +1873,7 @@ struct PersistentArgs {
 	unsigned long long* gstats;
 };
 
-template <bool COUNT, bool FULL>
+template <bool COUNT, uint32_t FEATS>
 __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathState& ps, const PersistentArgs& a)
 {
 	__shared__ PPShared sh;
@@ -1949,7 +1950,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				bool alive = false, want_shadow = false;
 				float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
 				if (mine && !regen)
-					shade_vertex<FULL>(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+					shade_vertex<FEATS>(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 				// the path ended: fold the sample, then the pixel's next sample or the next pixel
 				const bool ended = mine && (regen || (!alive && !want_shadow));
 				bool need_pixel	 = false;
@@ -2089,7 +2090,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						cl_c += s.any ? 0 : 1;
 						cl_a += s.any ? 1 : 0;
 					}
-					trav_leaf_rec<MODE_MIXED, FULL>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
+					trav_leaf_rec<MODE_MIXED, (FEATS & FEAT_SPHERES) != 0>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
 				}
 			}
 			const bool fin = has_ray && s.cur == REC_EMPTY;
@@ -2157,15 +2158,15 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 }
 // Two register budgets of the same kernel: 2 waves per SIMD (no spills) and 3 waves per SIMD (the compiler spills a few shading
 // temporaries to scratch); which one is faster is a latency-hiding question answered by measurement (PRGPU_PP_OCCUPANCY).
-template <bool COUNT, bool FULL>
+template <bool COUNT, uint32_t FEATS>
 __global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, PathState ps, PersistentArgs a)
 {
-	path_persistent<COUNT, FULL>(sc, ps, a);
+	path_persistent<COUNT, FEATS>(sc, ps, a);
 }
-template <bool COUNT, bool FULL>
+template <bool COUNT, uint32_t FEATS>
 __global__ void __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_path_persistent_occ3(DevScene sc, PathState ps, PersistentArgs a)
 {
-	path_persistent<COUNT, FULL>(sc, ps, a);
+	path_persistent<COUNT, FEATS>(sc, ps, a);
 }
 
 // ---- ray service kernels (IArchive surface) ------------------------------------------------------------
@@ -2303,23 +2304,32 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks), block(TRAV_BLOCK);
-	const bool full = sc.features != 0; // lean variant for Lambert / mesh / area-light scenes
-#define PR_LAUNCH_PP(KERNEL)                                                                         \
-	do {                                                                                             \
-		if (count && full)                                                                           \
-			hipLaunchKernelGGL((KERNEL<true, true>), grid, block, 0, st, sc, ps, a);                 \
-		else if (count)                                                                              \
-			hipLaunchKernelGGL((KERNEL<true, false>), grid, block, 0, st, sc, ps, a);                \
-		else if (full)                                                                               \
-			hipLaunchKernelGGL((KERNEL<false, true>), grid, block, 0, st, sc, ps, a);                \
-		else                                                                                         \
-			hipLaunchKernelGGL((KERNEL<false, false>), grid, block, 0, st, sc, ps, a);               \
+	// smallest compiled variant that covers the scene's features: lean (Lambert / mesh / area lights), + smooth delta materials, everything
+	// (a fourth one for delta + rough / principled materials was measured and dropped: the out-of-line rough closures dominate those
+	// scenes, 156 vs 154 Msamples/s)
+	const int variant = sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : 2);
+#define PR_LAUNCH_PP_V(KERNEL, COUNT)                                                                  \
+	do {                                                                                               \
+		if (variant == 2)                                                                              \
+			hipLaunchKernelGGL((KERNEL<COUNT, FEAT_ALL>), grid, block, 0, st, sc, ps, a);              \
+		else if (variant == 1)                                                                         \
+			hipLaunchKernelGGL((KERNEL<COUNT, FEAT_DELTA_MATERIALS>), grid, block, 0, st, sc, ps, a);  \
+		else                                                                                           \
+			hipLaunchKernelGGL((KERNEL<COUNT, 0u>), grid, block, 0, st, sc, ps, a);                    \
+	} while (0)
+#define PR_LAUNCH_PP(KERNEL)                \
+	do {                                    \
+		if (count)                          \
+			PR_LAUNCH_PP_V(KERNEL, true);   \
+		else                                \
+			PR_LAUNCH_PP_V(KERNEL, false);  \
 	} while (0)
 	if (occupancy >= 3)
 		PR_LAUNCH_PP(k_path_persistent_occ3);
 	else
 		PR_LAUNCH_PP(k_path_persistent);
 #undef PR_LAUNCH_PP
+#undef PR_LAUNCH_PP_V
 }
 
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * TRAV_BLOCK * STACK_SPILL; }

@@ -284,9 +284,13 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	for (uint32_t e = 0; e < d->n_entities; ++e)
 		if (d->entities[e].has_uvs && d->uvs && d->entities[e].kind == PRGPU_ENTITY_MESH)
 			sc.features |= prd::FEAT_TEXTURES; // UV-derived tangent frames need the full variant
-	for (uint32_t i = 0; i < d->n_materials; ++i)
-		if (d->materials[i].kind != PRGPU_MAT_LAMBERT)
+	for (uint32_t i = 0; i < d->n_materials; ++i) {
+		const uint32_t kind = d->materials[i].kind;
+		if (kind == PRGPU_MAT_DIELECTRIC || kind == PRGPU_MAT_CONDUCTOR || kind == PRGPU_MAT_MIRROR)
 			sc.features |= prd::FEAT_DELTA_MATERIALS;
+		else if (kind != PRGPU_MAT_LAMBERT) // rough closures fall back to the smooth ones below roughness 1e-3
+			sc.features |= prd::FEAT_DELTA_MATERIALS | prd::FEAT_ROUGH_MATERIALS;
+	}
 	for (uint32_t e = 0; e < d->n_entities; ++e)
 		if (d->entities[e].kind == PRGPU_ENTITY_PLANE)
 			sc.features |= prd::FEAT_PLANES;
