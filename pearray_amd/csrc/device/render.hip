@@ -2304,14 +2304,19 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks), block(TRAV_BLOCK);
-	// smallest compiled variant that covers the scene's features: lean (Lambert / mesh / area lights), + smooth delta materials, everything
-	// (a fourth one for delta + rough / principled materials was measured and dropped: the out-of-line rough closures dominate those
-	// scenes, 156 vs 154 Msamples/s)
-	const int variant = sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : 2);
+	// smallest compiled variant that covers the scene's features: lean (Lambert / mesh / area lights), + smooth delta materials,
+	// everything but the rough / principled closures, everything.  The out-of-line closures are what the last step pays for: a kernel
+	// that CONTAINS the calls runs a scene that never makes them 25 % slower (metal Cornell box: 3.18 vs 4.02 ms per iteration; leaving
+	// out spheres, AOVs + textures or infinite / shape lights + planes instead changes nothing).  A variant for delta + rough materials
+	// only was measured and dropped: the closures dominate such scenes, 156 vs 154 Msamples/s.
+	constexpr uint32_t FEAT_NO_ROUGH = FEAT_ALL & ~FEAT_ROUGH_MATERIALS;
+	const int variant = sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3));
 #define PR_LAUNCH_PP_V(KERNEL, COUNT)                                                                  \
 	do {                                                                                               \
-		if (variant == 2)                                                                              \
+		if (variant == 3)                                                                              \
 			hipLaunchKernelGGL((KERNEL<COUNT, FEAT_ALL>), grid, block, 0, st, sc, ps, a);              \
+		else if (variant == 2)                                                                         \
+			hipLaunchKernelGGL((KERNEL<COUNT, FEAT_NO_ROUGH>), grid, block, 0, st, sc, ps, a);         \
 		else if (variant == 1)                                                                         \
 			hipLaunchKernelGGL((KERNEL<COUNT, FEAT_DELTA_MATERIALS>), grid, block, 0, st, sc, ps, a);  \
 		else                                                                                           \

@@ -22,4 +22,11 @@ W = H = 1024
 run("lambert cornell (lean variant)", scene.cornell_box(W, H, spp=256))
 run("glass boxes (bk7)", scene.cornell_glassy(W, H, spp=256))
 run("metal boxes", scene.cornell_metal(W, H, spp=256))
+def metal_env():
+    b = scene.SceneBuilder(W, H)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_MJITT, 256
+    scene._cornell_into(b, material_override={"tallBox": lambda bb: bb.conductor(), "shortBox": lambda bb: bb.conductor()})
+    b.environment_light(b.spectrum_const(0.2))
+    return b.build()
+run("metal boxes + environment light (no-rough variant)", metal_env())
 run("rough conductor/dielectric boxes, vndf", scene.cornell_rough(W, H, spp=256, roughness=0.2, vndf=True))
