@@ -169,6 +169,14 @@ def test_reference_cornellbox_prc_equals_the_committed_fixture_scene():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference checkout not present (GPU box)")
+def test_entity_visibility_flags_are_accepted_and_reported_as_inert():
+    """SceneLoader.cpp:452-497 stores the flags, Scene.cpp:135,166 traces every ray with MASK_ALL: they change nothing."""
+    flagged = scene.PrcScene(source=MINIMAL % "(entity :name 's2' :type 'sphere' :radius 0.5 :material 'm' :camera_visible false :shadow_visible false)")
+    plain = scene.PrcScene(source=MINIMAL % "(entity :name 's2' :type 'sphere' :radius 0.5 :material 'm')")
+    assert sum("has no effect" in w for w in flagged.warnings) == 2 and not any("has no effect" in w for w in plain.warnings)
+    assert flagged.desc.n_entities == plain.desc.n_entities and flagged.desc.n_triangles == plain.desc.n_triangles
+
+
 def test_every_reference_example_either_loads_or_names_what_is_missing():
     lib = abi.load()
     loaded, refused = [], []
@@ -185,7 +193,7 @@ def test_every_reference_example_either_loads_or_names_what_is_missing():
             assert rc == -4, (name, rc, lib.prgpu_prc_last_error())   # valid DataLisp, unsupported feature -- never a syntax error
             assert "not supported" in lib.prgpu_prc_last_error().decode() or "not available" in lib.prgpu_prc_last_error().decode(), name
             refused.append(name)
-    assert "cornellbox.prc" in loaded
+    assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and len(loaded) >= 12
 
 
 def test_obj_embed_semantics(tmp_path):
