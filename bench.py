@@ -23,21 +23,43 @@ W, H, SPP, NTRI = 1920, 1080, 1024, 1_000_000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the achievable copy rate
 
 
-def cpu_baseline(scene_desc, iters=4):
-    """CPU checker ("port") on the host cores: `iters` full-frame iterations of the SAME workload."""
+def native_oracle():
+    """The CPU checker rebuilt for THIS host (`g++ -O3 -march=native`, the flags BASELINE.md section 3 promises; -ffp-contract=off kept, so
+    the arithmetic is the checker's).  The shipped library is built -O2 for a generic x86-64 because it travels between machines."""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle", "pr_oracle.cpp")
+    flags = ["-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-shared"]
+    out = os.path.join(tempfile.mkdtemp(prefix="pr_oracle_native_"), "libpr_oracle_native.so")
+    try:
+        subprocess.check_call(["g++"] + flags + [src, "-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return out, "g++ " + " ".join(flags[:2])
+    except Exception:
+        return None, "prebuilt -O2 generic x86-64 (no compiler on this host)"
+
+
+def cpu_baseline(scene_desc, iters=4, tile=32):
+    """CPU checker ("port") on the host cores: `iters` full-frame iterations of the SAME workload, handed to the worker threads as
+    `tile` x `tile`-pixel Z-order tiles so that every hardware thread has work (the reference's 8 x 8 grid feeds at most 64)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_binding import OracleScene
+    import oracle_binding
     cores = os.cpu_count() or 1
+    path, how = native_oracle()
+    lib = oracle_binding.load_from(path) if path else None
     t0 = time.time()
-    o = OracleScene(scene_desc)
+    o = oracle_binding.OracleScene(scene_desc, lib=lib)
     t_build = time.time() - t0
+    tx, ty = (scene_desc.width + tile - 1) // tile, (scene_desc.height + tile - 1) // tile
+    o.set_tile_grid(tx, ty)
     t0 = time.time()
     o.render(iters, threads=cores)
     dt = time.time() - t0
     st = o.statistics()
-    return {"value": round(st["pixel_samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d iteration(s) of the full %dx%d frame of the same 1M-triangle scene (%d samples, %.1f s render, %.1f s SAH BVH build excluded); "
-                      "CPU restatement, not Embree" % (iters, W, H, st["pixel_samples"], dt, t_build)}
+    return {"value": round(st["pixel_samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "threads_busy": min(cores, tx * ty),
+            "kind": "port", "build": how,
+            "sample": "%d iteration(s) of the full %dx%d frame of the same 1M-triangle scene (%d samples, %.1f s render, %.1f s SAH BVH build excluded), "
+                      "%d tiles of %dx%d pixels for %d threads; CPU restatement, not Embree"
+                      % (iters, scene_desc.width, scene_desc.height, st["pixel_samples"], dt, t_build, tx * ty, tile, tile, cores)}
 
 
 def pmc_traffic(kernel_substr):

@@ -54,7 +54,8 @@ enum {
 	PRGPU_EINVAL      = -1, /* malformed description (bad index, empty scene, ...) */
 	PRGPU_ENODEVICE   = -2, /* no usable HIP device / device index out of range */
 	PRGPU_EDEVICE     = -3, /* a HIP runtime call failed; see prgpu_last_error() */
-	PRGPU_EUNSUPPORTED = -4 /* valid PearRay feature that this backend does not implement */
+	PRGPU_EUNSUPPORTED = -4, /* valid PearRay feature that this backend does not implement */
+	PRGPU_EIO         = -5  /* a file could not be opened, read or written */
 };
 
 /* ---- spectral nodes (flattened shading network) ------------------------------------------
@@ -196,7 +197,7 @@ enum { PRGPU_MAPPER_SPD_CMIS = 0, PRGPU_MAPPER_RANDOM = 1, PRGPU_MAPPER_SPD_HERO
                                     CIE domain is PRGPU_EINVAL (the reference factory returns no mapper, cie.cpp:93-102) */
        PRGPU_MAPPER_CIE_Y = 4 }; /* the same with the Y-only CDF ('cie_y', 'visible_y' or :only_y true, cie.cpp:109-113) */
 enum { PRGPU_FILTER_BLOCK = 0, PRGPU_FILTER_TRIANGLE = 1, PRGPU_FILTER_GAUSSIAN = 2,
-       PRGPU_FILTER_MITCHELL = 3, PRGPU_FILTER_LANCZOS = 4 }; /* src/plugins/main/filter/*.cpp */
+       PRGPU_FILTER_MITCHELL = 3, PRGPU_FILTER_LANCZOS = 4 }; /* src/plugins/main/filter/ */
 enum { PRGPU_MIS_BALANCE = 0, PRGPU_MIS_POWER = 1 };
 
 /* RenderSettings (src/core/renderer/RenderSettings.cpp:11-31) + `direct` parameters

@@ -772,6 +772,7 @@ struct Scene {
 	// debugging aid: rays of one pixel (kind, iter, o[3], d[3], tmin, tmax|distance, result)
 	int64_t dbg_pixel = -1;
 	std::vector<float> dbg_rays;
+	int tile_grid_x = 8, tile_grid_y = 8; // worker tile grid (RenderTileMap.cpp:30-35); orc_set_tile_grid
 };
 
 // ---- spectral node evaluation (loader/shader/ConstNode.cpp, EquidistantSpectrumNode.h:19-28,
@@ -3009,12 +3010,15 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 struct TileRect {
 	int x0, y0, x1, y1;
 };
-std::vector<TileRect> make_tiles(int W, int H)
+std::vector<TileRect> make_tiles(int W, int H, int grid_x = 8, int grid_y = 8)
 {
-	const int tx = std::min(8, W), ty = std::min(8, H);
+	const int tx = std::min(grid_x, W), ty = std::min(grid_y, H);
 	const int tw = (W + tx - 1) / tx, th = (H + ty - 1) / ty;
 	std::vector<TileRect> tiles;
-	for (uint64_t m = 0; m < 64 * 64 && (int)tiles.size() < tx * ty; ++m) {
+	uint64_t side = 1;
+	while ((int)side < std::max(tx, ty))
+		side *= 2;
+	for (uint64_t m = 0; m < side * side && (int)tiles.size() < tx * ty; ++m) {
 		uint32_t x, y;
 		morton_2_xy(m, x, y);
 		if ((int)x >= tx || (int)y >= ty)
@@ -3029,7 +3033,7 @@ std::vector<TileRect> make_tiles(int W, int H)
 void render_iteration(Scene& s, uint32_t iter, int threads)
 {
 	const int W = (int)s.cfg.width, H = (int)s.cfg.height, r = (int)s.cfg.filter_radius;
-	const std::vector<TileRect> tiles = make_tiles(W, H);
+	const std::vector<TileRect> tiles = make_tiles(W, H, s.tile_grid_x, s.tile_grid_y);
 	std::vector<TileOut> outs(tiles.size());
 	std::atomic<size_t> next{ 0 };
 	auto worker = [&]() {
@@ -3387,6 +3391,16 @@ int orc_set_tiles(orc_scene* h, const prgpu_tile* tiles, uint32_t n)
 	return PRGPU_OK;
 }
 
+// Tile grid of the worker hand-out (default: the reference's 8 x 8, RenderTileMap.cpp:30-35).  Results do not depend on it for
+// single-tap pixel filters; the CPU-baseline timing uses a finer grid so that every host thread has work.
+int orc_set_tile_grid(orc_scene* h, uint32_t tiles_x, uint32_t tiles_y)
+{
+	if (!h || tiles_x == 0 || tiles_y == 0 || tiles_x > 4096 || tiles_y > 4096)
+		return fail("tile grid must be 1..4096 per axis");
+	h->s.tile_grid_x = (int)tiles_x;
+	h->s.tile_grid_y = (int)tiles_y;
+	return PRGPU_OK;
+}
 int orc_render(orc_scene* h, uint32_t iter_begin, uint32_t iter_end, int threads)
 {
 	if (threads <= 0)

@@ -25,6 +25,8 @@ int  orc_set_tiles(orc_scene* s, const prgpu_tile* tiles, uint32_t n_tiles);
 /* threads <= 0: hardware concurrency.  Tiles of the reference's 8x8 Z-order grid are rendered by
  * `threads` workers, merged in tile order after each iteration (deterministic). */
 int  orc_render(orc_scene* s, uint32_t iter_begin, uint32_t iter_end, int threads);
+/* Worker tile grid (default 8 x 8 like RenderTileMap.cpp:30-35).  Timing runs use a finer grid so that tiles >= threads. */
+int  orc_set_tile_grid(orc_scene* s, uint32_t tiles_x, uint32_t tiles_y);
 int  orc_download(orc_scene* s, float* xyz, uint32_t* samples, uint32_t* feedback);
 int  orc_stats(orc_scene* s, uint64_t out[PRGPU_STAT_COUNT]);
 int  orc_enable_aovs(orc_scene* s, uint32_t mask);                  /* LocalFrameOutputDevice.cpp:252-283 */

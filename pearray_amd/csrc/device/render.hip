@@ -1794,7 +1794,7 @@ constexpr uint32_t PP_EMPTY		= 0xFFFFFFFFu;
 constexpr uint32_t PP_ANY		= 0x80000000u; // ray entry: the slot's shadow ray (else its path ray)
 constexpr uint32_t PP_REGEN		= 0x80000000u; // shade entry: the slot's path has ended (else: shade the vertex at ps.hit)
 constexpr uint32_t PP_DEAD		= 0x100u;	   // pending word: no bounce ray follows the rays in flight
-constexpr uint32_t PP_SPIN_LIMIT = 1u << 24;   // safety net: an idle wave gives up (and flags an error) after this many polls
+constexpr unsigned long long PP_IDLE_LIMIT_TICKS = 30ull * 100000000ull; // safety net: a wave that has seen no work for 30 s of wall clock (100 MHz ticks) gives up and flags an error
 
 struct PPShared {
 	uint2 stack[STACK_LDS * TRAV_BLOCK];
@@ -1909,6 +1909,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	bool has_ray	  = false;
 	uint32_t my_entry = 0;
 	uint32_t spins	  = 0;
+	unsigned long long t_idle_since = 0;
 	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, sbatches = 0, slanes = 0;
 	unsigned long long t_shade = 0, t_idle = 0;
 	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
@@ -2043,7 +2044,9 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			if (COUNT)
 				t_idle += wall_clock64() - t0;
 			if (n_shade == 0u && n_queued == 0u) {
-				if (++spins > PP_SPIN_LIMIT) {
+				if (spins++ == 0u)
+					t_idle_since = wall_clock64();
+				else if ((spins & 1023u) == 0u && wall_clock64() - t_idle_since > PP_IDLE_LIMIT_TICKS) {
 					if (lane == 0) {
 						__hip_atomic_store(&sh.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						atomicExch(a.error, 1u);

@@ -47,6 +47,8 @@ struct Reader {
 	const std::string& src;
 	size_t pos = 0;
 	int line   = 1;
+	int depth  = 0;
+	static constexpr int MAX_DEPTH = 256; // nesting of ( and [ groups
 	std::string error;
 
 	explicit Reader(const std::string& s) : src(s) {}
@@ -145,6 +147,14 @@ struct Reader {
 	}
 	bool read_group(Group& g)
 	{
+		// a hostile or broken file must end in a parse error, not in a host stack overflow
+		struct DepthGuard {
+			int& d;
+			explicit DepthGuard(int& d_) : d(d_) { ++d; }
+			~DepthGuard() { --d; }
+		} guard(depth);
+		if (depth > MAX_DEPTH)
+			return fail("nesting too deep");
 		const char open	 = src[pos++];
 		const char close = open == '(' ? ')' : ']';
 		g.is_array		 = open == '[';

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../../include/prgpu.h"
+#include "setup.h"
 
 namespace {
 void put(std::vector<char>& b, const void* p, size_t n) { b.insert(b.end(), static_cast<const char*>(p), static_cast<const char*>(p) + n); }
@@ -31,12 +32,13 @@ void attribute(std::vector<char>& b, const char* name, const char* type, const s
 extern "C" int prgpu_write_exr(const char* path, uint32_t width, uint32_t height, uint32_t n_channels, const char* const* names,
 							   const float* const* planes, const uint32_t* strides)
 {
+	using prgpu_host::set_last_error;
 	if (!path || !names || !planes || !width || !height || !n_channels)
-		return PRGPU_EINVAL;
+		return set_last_error(PRGPU_EINVAL, "prgpu_write_exr: null or empty argument");
 	std::vector<uint32_t> order(n_channels);
 	for (uint32_t c = 0; c < n_channels; ++c) {
 		if (!names[c] || !planes[c] || !names[c][0] || std::strlen(names[c]) > 255)
-			return PRGPU_EINVAL;
+			return set_last_error(PRGPU_EINVAL, "prgpu_write_exr: bad channel name or null plane");
 		order[c] = c;
 	}
 	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return std::strcmp(names[a], names[b]) < 0; });
@@ -100,7 +102,7 @@ extern "C" int prgpu_write_exr(const char* path, uint32_t width, uint32_t height
 		put_v<uint64_t>(head, first + uint64_t(y) * block_bytes);
 	FILE* f = std::fopen(path, "wb");
 	if (!f)
-		return PRGPU_EINVAL;
+		return set_last_error(PRGPU_EIO, std::string("prgpu_write_exr: cannot open '") + path + "' for writing");
 	bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
 	std::vector<float> row(size_t(n_channels) * width);
 	for (uint32_t y = 0; ok && y < height; ++y) {
@@ -117,5 +119,5 @@ extern "C" int prgpu_write_exr(const char* path, uint32_t width, uint32_t height
 		ok = std::fwrite(&yy, 4, 1, f) == 1 && std::fwrite(&nbytes, 4, 1, f) == 1 && std::fwrite(row.data(), 1, row_bytes, f) == row_bytes;
 	}
 	ok = (std::fclose(f) == 0) && ok;
-	return ok ? PRGPU_OK : PRGPU_EINVAL;
+	return ok ? PRGPU_OK : set_last_error(PRGPU_EIO, std::string("prgpu_write_exr: short write to '") + path + "'");
 }

@@ -11,6 +11,8 @@
 namespace prgpu_host {
 
 void rgb_to_coeffs(const float rgb[3], float out[3]);
+// sets the message prgpu_last_error() returns on this thread and passes `code` through (defined in prgpu_api.hip)
+int set_last_error(int code, const std::string& msg);
 
 struct HostTables {
 	std::vector<prd::DevEntity> entities;

@@ -35,6 +35,12 @@ int fail(int code, const std::string& msg)
 			return fail(PRGPU_EDEVICE, std::string(#expr) + " failed: " + hipGetErrorString(_e));           \
 	} while (0)
 
+} // namespace
+namespace prgpu_host {
+int set_last_error(int code, const std::string& msg) { return fail(code, msg); }
+} // namespace prgpu_host
+namespace {
+
 struct TimedLaunch {
 	hipEvent_t start, stop;
 	int family;
@@ -94,6 +100,9 @@ struct prgpu_scene {
 	uint64_t family_launches[N_FAMILIES] = { 0 };
 	uint64_t rays_closest = 0, rays_any = 0;
 	uint32_t next_iteration = 0;
+	bool poisoned = false; // a device-side error was reported: further render calls are refused
+	uint64_t pp_launch_samples = 128ull << 20; // persistent mode: camera samples per launch (render calls are cut into bounded launches)
+	uint32_t pp_launch_min_iters = 8;
 
 	template <typename T>
 	int alloc(T*& ptr, size_t count, bool zero = false)
@@ -408,6 +417,10 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		s->pp_partial_act = atoi(env);
 	if (const char* env = getenv("PRGPU_PP_SHADE_MIN"))
 		s->pp_shade_min = atoi(env);
+	if (const char* env = getenv("PRGPU_PP_LAUNCH_SAMPLES"))
+		s->pp_launch_samples = (uint64_t)std::max(1ll, atoll(env));
+	if (const char* env = getenv("PRGPU_PP_LAUNCH_MIN_ITERS"))
+		s->pp_launch_min_iters = (uint32_t)std::max(1, atoi(env));
 	AL(s->pp_pixel, ns, false);
 	AL(s->pp_next, 1, true);
 	AL(s->pp_error, 1, true);
@@ -711,14 +724,24 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 		return PRGPU_OK;
 	prd::PathState ps = s->ps;
 	ps.pixel		  = s->pp_pixel; // s->ps.pixel is the Morton-ordered list of owned pixels
-	s->time_begin(6, s->stream);
-	prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, iter_begin, iter_end, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act, s->pp_refill_min, s->pp_both_below,
-								s->pp_occupancy, s->pp_shader_wave, s->pp_shade_help,
-								s->pp_next,
-								s->pp_error,
-								s->gstats, s->stream);
-	s->time_end(s->stream);
-	HIP_TRY(hipGetLastError());
+	// Bounded launches: a render call of many iterations is cut into launches of about pp_launch_samples camera samples (~1 s of
+	// work on the 1 M-triangle scene), so that a long render has sync points for progress / cancellation and the in-kernel idle
+	// watchdog is never near a legitimate wait.  Per-pixel state lives in the planes, so consecutive launches continue exactly
+	// where the previous one stopped (identical results for any chunking).
+	const uint64_t per_iter = std::max<uint64_t>(1, s->n_slots);
+	const uint32_t chunk	= (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(s->pp_launch_min_iters, s->pp_launch_samples / per_iter));
+	for (uint32_t b = iter_begin; b < iter_end;) {
+		const uint32_t e = (uint32_t)std::min<uint64_t>(iter_end, uint64_t(b) + chunk);
+		s->time_begin(6, s->stream);
+		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act, s->pp_refill_min, s->pp_both_below,
+									s->pp_occupancy, s->pp_shader_wave, s->pp_shade_help,
+									s->pp_next,
+									s->pp_error,
+									s->gstats, s->stream);
+		s->time_end(s->stream);
+		HIP_TRY(hipGetLastError());
+		b = e;
+	}
 	return PRGPU_OK;
 }
 
@@ -729,8 +752,12 @@ int check_watchdog(prgpu_scene* s)
 		return PRGPU_OK;
 	uint32_t flag = 0;
 	HIP_TRY(hipMemcpy(&flag, s->pp_error, sizeof(flag), hipMemcpyDeviceToHost));
-	if (flag)
-		return fail(PRGPU_EDEVICE, "persistent path kernel: a wave timed out waiting for queued work (internal error)");
+	if (flag) { // report once, then keep the scene unusable: the frame is incomplete and the pixel RNG streams have moved on
+		flag = 0;
+		HIP_TRY(hipMemcpy(s->pp_error, &flag, sizeof(flag), hipMemcpyHostToDevice));
+		s->poisoned = true;
+		return fail(PRGPU_EDEVICE, "persistent path kernel: a wave timed out waiting for queued work (internal error); the scene object must be recreated");
+	}
 	return PRGPU_OK;
 }
 
@@ -835,6 +862,8 @@ int prgpu_set_tiles(prgpu_scene* s, const prgpu_tile* tiles, uint32_t n_tiles)
 {
 	if (!s || (n_tiles && !tiles))
 		return fail(PRGPU_EINVAL, "null argument");
+	if (s->next_iteration != 0) // a pixel that changes hands mid-render would fold its samples onto a zero history
+		return fail(PRGPU_EINVAL, "tiles must be set before the first iteration");
 	HIP_TRY(hipSetDevice(s->device));
 	return apply_tiles(s, tiles, n_tiles);
 }
@@ -860,6 +889,11 @@ int prgpu_bind_framebuffer(prgpu_scene* s, void* d_xyz, void* d_samples, void* d
 	s->ps.out_xyz  = static_cast<float*>(d_xyz);
 	s->ps.samples  = static_cast<uint32_t*>(d_samples);
 	s->ps.feedback = d_feedback ? static_cast<uint32_t*>(d_feedback) : s->own_feedback;
+	for (auto& g : s->groups) { // the pixel groups of the lockstep / streaming pipelines carry copies of the path state
+		g.ps.out_xyz  = s->ps.out_xyz;
+		g.ps.samples  = s->ps.samples;
+		g.ps.feedback = s->ps.feedback;
+	}
 	return PRGPU_OK;
 }
 
@@ -867,6 +901,8 @@ int prgpu_render(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 {
 	if (!s)
 		return fail(PRGPU_EINVAL, "null scene");
+	if (s->poisoned)
+		return fail(PRGPU_EDEVICE, "scene object is unusable after a device-side error; recreate it");
 	if (iter_begin != s->next_iteration || iter_end < iter_begin)
 		return fail(PRGPU_EINVAL, "iterations must be rendered in order (pixel RNG streams are sequential)");
 	HIP_TRY(hipSetDevice(s->device));

@@ -20,7 +20,16 @@ def load():
         return _lib
     if not os.path.exists(LIB):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "libpr_oracle.so"])
-    lib = C.CDLL(LIB)
+    _lib = bind(C.CDLL(LIB))
+    return _lib
+
+
+def load_from(path):
+    """Another build of the same source (bench.py's cpu_baseline leg: -O3 -march=native on the timing host)."""
+    return bind(C.CDLL(path))
+
+
+def bind(lib):
     lib.orc_last_error.restype = C.c_char_p
     lib.orc_scene_create.restype = C.c_void_p
     lib.orc_scene_create.argtypes = [C.POINTER(abi.SceneDesc)]
@@ -106,7 +115,7 @@ def load():
     lib.orc_sincos_rad.argtypes = [C.c_float, _F32P, _F32P]
     lib.orc_material_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _F32P, _F32P, _F32P, C.POINTER(C.c_int)]
     lib.orc_rough_sample.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _U64P, _F32P, _F32P, _F32P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    _lib = lib
+    lib.orc_set_tile_grid.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     return lib
 
 
@@ -119,8 +128,8 @@ def _p(a, t=C.c_float):
 
 
 class OracleScene:
-    def __init__(self, scene):
-        self.lib = load()
+    def __init__(self, scene, lib=None):
+        self.lib = lib if lib is not None else load()
         self.scene = scene
         self.h = self.lib.orc_scene_create(C.byref(scene.desc))
         if not self.h:
@@ -135,6 +144,10 @@ class OracleScene:
 
     def __del__(self):
         self.close()
+
+    def set_tile_grid(self, tiles_x, tiles_y):
+        """Worker tile grid (default 8 x 8); results are grid independent for single-tap filters."""
+        assert self.lib.orc_set_tile_grid(self.h, int(tiles_x), int(tiles_y)) == 0
 
     def set_tiles(self, tiles):
         tiles = list(tiles)

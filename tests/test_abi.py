@@ -118,3 +118,18 @@ def test_tiling_partitions_the_film():
     assert tiling.tiles_for_rank(7, 5, 0, 1, tile=4) == [(0, 0, 4, 4), (4, 0, 7, 4), (0, 4, 4, 5), (4, 4, 7, 5)]
     with pytest.raises(ValueError):
         tiling.tiles_for_rank(8, 8, 2, 2)
+
+
+def test_cie_tables_of_product_and_checker_are_the_same_data():
+    """Both sides include their own copy of the generated CIE / D65 tables; a drift would make 'bit-exact vs oracle' compare different data."""
+    a = open(os.path.join(ROOT, "oracle", "pr_tables.inl"), "rb").read()
+    b = open(os.path.join(ROOT, "pearray_amd", "csrc", "tables", "pr_tables.inl"), "rb").read()
+    assert a == b
+
+
+def test_no_built_binaries_are_tracked():
+    import subprocess
+    tracked = subprocess.check_output(["git", "-C", ROOT, "ls-files"]).decode().split()
+    for f in tracked:
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            assert fh.read(4) != b"\x7fELF", f

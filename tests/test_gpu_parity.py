@@ -330,6 +330,61 @@ def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypat
         assert ref[2] == out[2], env
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("flt,r", [(abi.FILTER_MITCHELL, 1), (abi.FILTER_GAUSSIAN, 2)])
+def test_bound_framebuffer_receives_every_plane_in_every_pipeline(monkeypatch, mode, flt, r):
+    """prgpu_bind_framebuffer: xyz, sample and feedback planes land in the caller's device buffers whichever pipeline runs (the
+    lockstep / streaming pixel groups carry their own copy of the path state; a multi-tap filter forces lockstep)."""
+    import torch
+    monkeypatch.setenv("PRGPU_MODE", mode)
+    sc = scene.cornell_box(72, 56, spp=4, filter=flt, filter_radius=r, spectral_mono=1, spectral_start=520.0)  # mono: feedback bits are set
+    ref = backend.RenderContext(sc)
+    ref.render(4)
+    ref.waitForFinish()
+    rx, rs, rf = ref.output()
+    assert rf.any() and rs.any()
+    g = backend.RenderContext(sc)
+    dev = torch.device("cuda", 0)
+    xyz = torch.zeros((56, 72, 3), dtype=torch.float32, device=dev)
+    smp = torch.zeros((56, 72), dtype=torch.int32, device=dev)
+    fb = torch.zeros((56, 72), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    g.bindFramebuffer(xyz.data_ptr(), smp.data_ptr(), fb.data_ptr())
+    g.render(4)
+    g.waitForFinish()
+    assert np.array_equal(xyz.cpu().numpy(), rx)
+    assert np.array_equal(smp.cpu().numpy().astype(np.uint32), rs)
+    assert np.array_equal(fb.cpu().numpy().astype(np.uint32), rf)
+    ox, os_, of = g.output()  # prgpu_download reads the bound planes
+    assert np.array_equal(ox, rx) and np.array_equal(os_, rs) and np.array_equal(of, rf)
+
+
+def test_tiles_cannot_change_after_the_first_iteration():
+    g = backend.RenderContext(scene.cornell_box(32, 32, spp=4))
+    g.setTiles([(0, 0, 16, 32)])
+    g.render(1)
+    g.waitForFinish()
+    with pytest.raises(abi.PrgpuError, match="before the first iteration"):
+        g.setTiles([(0, 0, 32, 32)])
+
+
+def test_persistent_render_call_is_cut_into_bounded_launches(monkeypatch):
+    """A render call becomes several launches of the persistent kernel (progress / cancel points); the frame does not depend on the cut."""
+    sc = scene.cornell_soup(120, 80, spp=12, n_triangles=5_000)
+    ref = _render_mode(monkeypatch, "persistent", sc, [12])
+    monkeypatch.setenv("PRGPU_PP_LAUNCH_SAMPLES", "1")
+    monkeypatch.setenv("PRGPU_PP_LAUNCH_MIN_ITERS", "5")
+    g = backend.RenderContext(sc)
+    g.setTiming(True)
+    g.render(12)
+    g.waitForFinish()
+    assert g.kernelTime("path")[1] == 3  # 5 + 5 + 2 iterations
+    out = (g.output(), g.primaryHits(), g.statistics())
+    for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+        assert np.array_equal(a, b)
+    assert ref[2] == out[2]
+
+
 def test_full_size_properties_1m_triangles():
     """BASELINE C4 geometry at full triangle count: size-independent properties instead of an oracle render --
     hit ids of 20k rays against the oracle BVH, energy bound, determinism, sample plane == spp on hit pixels."""

@@ -240,3 +240,21 @@ def test_analytic_sphere_hits_match_the_closed_form():
     inside = np.tile(np.array([[1, -0.5, 3]], dtype=np.float32), (64, 1))
     e2, p2, _, _, t2 = o.trace_closest(inside, d[:64], 1e-4, np.inf)
     assert (e2 == 0).all() and np.allclose(t2, 1.5, atol=1e-5)
+
+
+def test_worker_tile_grid_and_native_build_do_not_change_the_frame(tmp_path):
+    """bench.py's cpu_baseline leg times the checker with 32 x 32-pixel worker tiles and an -O3 -march=native rebuild: both must
+    produce the very frame of the default 8 x 8 grid / -O2 build (single-tap filter: tile-layout independent)."""
+    import bench
+    sc = scene.cornell_box(48, 40, spp=4)
+    a = ob.OracleScene(sc)
+    a.render(3, threads=2)
+    path, how = bench.native_oracle()
+    assert path is not None and "-O3" in how
+    b = ob.OracleScene(sc, lib=ob.load_from(path))
+    b.set_tile_grid(7, 5)
+    b.render(3, threads=3)
+    for x, y in zip(a.output(), b.output()):
+        assert np.array_equal(x, y)
+    assert a.statistics() == b.statistics()
+    assert b.lib.orc_set_tile_grid(b.h, 0, 4) != 0

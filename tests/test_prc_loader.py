@@ -80,6 +80,20 @@ def test_syntax_errors_are_reported_with_line_numbers():
         assert needle in lib.prgpu_prc_last_error().decode(), (src, lib.prgpu_prc_last_error())
 
 
+def test_deep_nesting_is_a_parse_error_not_a_stack_overflow():
+    lib = abi.load()
+    h = C.c_void_p()
+    src = "(scene " + "(a " * 100000
+    assert lib.prgpu_prc_load_string(src.encode(), None, None, C.byref(h)) == -1
+    assert "nesting too deep" in lib.prgpu_prc_last_error().decode()
+    src = "(scene :k " + "[" * 100000
+    assert lib.prgpu_prc_load_string(src.encode(), None, None, C.byref(h)) == -1
+    assert "nesting too deep" in lib.prgpu_prc_last_error().decode()
+    ok = "(scene :k " + "[" * 200 + "1" + "]" * 200 + ")"  # legal depth still parses (then fails semantically, not syntactically)
+    lib.prgpu_prc_load_string(ok.encode(), None, None, C.byref(h))
+    assert "nesting" not in lib.prgpu_prc_last_error().decode()
+
+
 MINIMAL = """(scene :render_width 8 :render_height 8
   (camera :name 'c' :type 'standard')
   (material :name 'm' :type 'diffuse')
