@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PRGPU_API_VERSION 5
+#define PRGPU_API_VERSION 6
 #define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
 
 enum {
@@ -102,8 +102,8 @@ enum { PRGPU_MAT_LAMBERT = 0, PRGPU_MAT_DIELECTRIC = 1, PRGPU_MAT_CONDUCTOR = 2,
        PRGPU_MAT_MIRROR = 6 };           /* mirror.cpp: delta reflection weighted by `specularity` (albedo), no Fresnel term */       /* principled.cpp: Disney-style diffuse / retro / sheen / GGX specular / refraction / clearcoat lobes with a
                                             four-way lobe selection (principled.cpp:111-139,418-435); constant scalar parameters only */
 enum { PRGPU_MATF_ANISOTROPIC = 1u,      /* roughness_y given as its own parameter (the reference compares the NODES, not the values) */
-       PRGPU_MATF_NO_VNDF = 2u,          /* `:vndf false`: sample the plain GGX normal distribution (isotropic only; the anisotropic variant needs
-                                            atan/tan, so PRINCIPLED, whose closure is always anisotropic, requires vndf) */
+       PRGPU_MATF_NO_VNDF = 2u,          /* `:vndf false`: sample the plain GGX normal distribution (Microfacet.h:225-256; the anisotropic form
+                                            through the backend's shared fp32 tan / atan) */
        PRGPU_MATF_HAS_TRANSMISSION = 4u }; /* PRINCIPLED: a transmission parameter was given (principled.cpp:657-666 picks the template by presence) */
 /* PRINCIPLED scalar parameters (principled.cpp:634-655; defaults 0 except roughness 0.5 in roughness_x) */
 enum { PRGPU_PRINCIPLED_DIFFUSE_TRANSMISSION = 0, PRGPU_PRINCIPLED_SPECULAR_TRANSMISSION = 1, PRGPU_PRINCIPLED_SPECULAR_TINT = 2,
@@ -162,18 +162,39 @@ typedef struct prgpu_entity {
  *                light's local z axis (environment.cpp:84-100), pdf |z| / pi (:71); camera rays that leave the scene see
  *                `background` (:56-63), bounce rays see `radiance` weighted by MIS (direct.cpp:415-456).
  *   DISTANT      distant.cpp: delta light arriving from `direction` (transformed by the light's normal matrix) with `radiance` =
- *                irradiance; only reachable through NEE (direct.cpp:321, Light.cpp:118-150).
+ *                irradiance; only reachable through NEE (direct.cpp:321, Light.cpp:118-150).  Also SunDeltaLight (sun.cpp:150-246,
+ *                `sun` with radius <= eps): the same light with direction = ElevationAzimuth::toDirection() and a TABLE radiance.
+ *   SKY          sky.cpp SkyLight<ExtendToGround>: radiance from a host-supplied table sky[elevation][azimuth][band] (SkyModel.h:18-23:
+ *                nearest cell, 11 bands of 40 nm from 320 nm interpolated linearly, sky.cpp:161-176), importance sampled through a
+ *                Distribution2D over (azimuth, elevation) built from the table (sky.cpp:127-159) with the 1 / (2 pi^2 cos el) Jacobian
+ *                (:51-97).  The table is the output of PearRay's SkyModel (src/skysun/skysun/SkyModel.cpp: Hosek-Wilkie, a third-party
+ *                dataset that stays with the host); it lives in prgpu_scene_desc::spectral_tables at `table_offset`,
+ *                elevation_count * azimuth_count * 11 floats.  flags: PRGPU_SKYF_*.
+ *   SUN          sun.cpp SunLight (radius > eps): a cone of half angle acos(cos_theta) around `direction` (= ElevationAzimuth::
+ *                toDirection() of the sun position, transformed by the normal matrix and normalised), uniform cone sampling
+ *                (Sampling.h:101-114), `radiance` = TABLE node with the 64 samples of 360-760 nm (sun.cpp:21-23,42-46; host computed:
+ *                computeSunRadiance * power_scale / radius^2); visible to bounce rays inside the cone (:61-77).
  * They follow the area lights in the light-selection distribution with intensity 2 pi R mean(power) (LightSampler.cpp:20,62-71),
- * R = radius of the origin-centred bounding sphere of the scene (Scene.cpp:107-118). */
-enum { PRGPU_LIGHT_ENVIRONMENT = 0, PRGPU_LIGHT_DISTANT = 1 };
+ * R = radius of the origin-centred bounding sphere of the scene (Scene.cpp:107-118); power() of SKY is its zenith radiance
+ * (sky.cpp:113), of SUN its spectrum (sun.cpp:106-112). */
+enum { PRGPU_LIGHT_ENVIRONMENT = 0, PRGPU_LIGHT_DISTANT = 1, PRGPU_LIGHT_SKY = 2, PRGPU_LIGHT_SUN = 3 };
+enum { PRGPU_SKYF_EXTEND = 1u,        /* `:extend` (default true): the distribution covers elevations -pi/2..pi/2, the ground half scaled
+                                         by GROUND_PENALTY = 0.001 (sky.cpp:23,127-159); without it directions below the horizon are black */
+       PRGPU_SKYF_COMPENSATION = 2u }; /* `:compensation` (default false): Distribution2D::applyCompensation (Distribution2D.cpp:38-76) */
+enum { PRGPU_LIGHTF_SUN_DELTA = 4u };  /* DISTANT standing in for SunDeltaLight: power() is the plain table lookup (sun.cpp:222-228)
+                                         instead of NodeUtils::average (distant.cpp:93) -- an ulp in the light-selection weights */
+#define PRGPU_SKY_BANDS 11            /* AR_SPECTRAL_BANDS; band k is 320 + 40 k nm (src/skysun/skysun/SkySunConfig.h:6-9) */
 typedef struct prgpu_light {
 	uint32_t kind;
-	uint32_t radiance;     /* spectrum index: ENVIRONMENT `radiance`, DISTANT `irradiance` */
+	uint32_t radiance;     /* spectrum index: ENVIRONMENT `radiance`, DISTANT `irradiance`, SUN the sun's TABLE node; unused for SKY */
 	uint32_t background;   /* ENVIRONMENT: `background` spectrum index, or PRGPU_INVALID_ID = radiance */
-	uint32_t reserved;
-	float    direction[3]; /* DISTANT: `direction` (default 0 0 1) */
-	float    reserved2;
+	uint32_t flags;        /* SKY: PRGPU_SKYF_* */
+	float    direction[3]; /* DISTANT: `direction` (default 0 0 1); SUN: ElevationAzimuth::toDirection() of the sun position */
+	float    cos_theta;    /* SUN: cos(SUN_VIS_RADIUS * radius), SUN_VIS_RADIUS = 0.5358 deg / 2 (sun.cpp:24,36) */
 	float    transform[16];
+	uint32_t table_offset; /* SKY: first float of the table in prgpu_scene_desc::spectral_tables */
+	uint32_t azimuth_count, elevation_count; /* SKY: table resolution (`azimuth_resolution` 512, `elevation_resolution` 256) */
+	uint32_t reserved;
 } prgpu_light;
 
 /* PerspectiveCamera, src/plugins/main/cameras/perspective.cpp:16-113; OrthoCamera, ortho.cpp:14-75 */
@@ -362,16 +383,36 @@ int prgpu_write_exr(const char* path, uint32_t width, uint32_t height, uint32_t 
  * `direct` hot path evaluates: (scene :render_width :render_height :camera :spectral_domain :spectral_hero), (sampler), (filter),
  * (spectral_mapper), (integrator :type 'direct'), (camera :type 'standard'), (material :type 'diffuse'), (emission :type 'standard'),
  * spectral expressions number / (refl r g b) / (illum r g b) / (illuminant "D65") / (spectrum :start :end v...) / (smul a b),
- * inline (mesh (attribute :type 'p'|'n' ...) (faces ...) (materials ...)), (entity :type 'mesh' ...), (include "file").
+ * inline (mesh (attribute :type 'p'|'n' ...) (faces ...) (materials ...)), (entity :type 'mesh' ...), (include "file"),
+ * (light :type 'env'|'distant'|'sun'|'sky') -- the sky with a host-supplied table (prgpu_prc_sky).
  * Constructs this backend cannot render fail with PRGPU_EUNSUPPORTED and a message naming the block; output blocks are skipped
  * with a warning.  The returned object owns every array the description points to. */
 typedef struct prgpu_prc prgpu_prc;
+/* The table a (light :type 'sky') evaluates: SkyModel::mData (src/skysun/skysun/SkyModel.cpp:17-60), which PearRay fills from the
+ * Hosek-Wilkie dataset while it loads the scene.  The dataset stays with the host (pr_lib_skysun); the loader takes the finished table.
+ * A sky light without a matching entry fails with PRGPU_EUNSUPPORTED and a message that names what is needed. */
+typedef struct prgpu_prc_sky {
+	const char*  light_name;       /* :name of the light this table belongs to; NULL = any sky light */
+	const float* table;            /* elevation_count * azimuth_count * 11 floats, [elevation][azimuth][band] */
+	uint32_t     azimuth_count, elevation_count; /* must equal :azimuth_resolution (512) / :elevation_resolution (256) of the light */
+} prgpu_prc_sky;
 typedef struct prgpu_prc_options {
 	uint32_t width, height; /* 0: keep :render_width / :render_height */
 	uint32_t aa_samples;    /* 0: keep the aa sampler's :sample_count */
 	uint32_t force_direct;  /* 1: accept any (integrator :type ...) and render it with `direct` at default parameters */
 	uint64_t seed;          /* 0: RenderSettings default (42) */
+	uint32_t n_skies;       /* host-supplied sky tables (may be 0) */
+	uint32_t reserved;
+	const prgpu_prc_sky* skies;
 } prgpu_prc_options;
+/* Sun position (elevation, azimuth in radians; up is +z) for a date, time and map location: computeSunEA,
+ * src/skysun/skysun/SunLocation.cpp:11-105 -- what (light :type 'sun'|'sky') blocks without :direction / :theta / :elevation use
+ * (defaults: 2020-05-06 12:00:00, latitude 49.235422, longitude 6.9965744, timezone 2).  A host that generates the sky table needs it. */
+void  prgpu_sun_position(int year, int month, int day, int hour, int minute, float seconds, float latitude, float longitude, float timezone,
+                         float* elevation, float* azimuth);
+/* Sun radiance through the atmosphere [W / (m^2 nm sr)] at `wavelength` nm for the zenith angle `theta` and a turbidity:
+ * computeSunRadiance, src/skysun/skysun/SunRadiance.cpp:76-118 (the loader tabulates it for `sun` lights, sun.cpp:42-46,166-170). */
+float prgpu_sun_radiance(float wavelength, float theta, float turbidity);
 int prgpu_prc_load_file(const char* path, const prgpu_prc_options* options, prgpu_prc** out);
 int prgpu_prc_load_string(const char* source, const char* include_dir, const prgpu_prc_options* options, prgpu_prc** out);
 const prgpu_scene_desc* prgpu_prc_desc(const prgpu_prc* scene);

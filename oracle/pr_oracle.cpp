@@ -307,6 +307,39 @@ inline float safe_acos(float a)
 	return 1.57079632679489661923f - asin_poly(x);
 }
 
+// atan2 through fp32 operations only (Cephes atanf: reduction at tan(3 pi/8) and tan(pi/8), odd polynomial).  Stands in for the
+// std::atan2 of Spherical::from_direction (base/math/Spherical.h:8-15) so that CPU and GPU agree bit for bit (~1 ulp from libm).
+inline float atan_fp32(float xx)
+{
+	float x = std::fabs(xx), y = 0.0f;
+	if (x > 2.414213562373095f) {
+		y = 1.57079632679489661923f;
+		x = -(1.0f / x);
+	} else if (x > 0.4142135623730950f) {
+		y = 0.78539816339744830962f;
+		x = (x - 1.0f) / (x + 1.0f);
+	}
+	const float z = x * x;
+	float p		  = 8.05374449538e-2f;
+	p			  = p * z - 1.38776856032e-1f;
+	p			  = p * z + 1.99777106478e-1f;
+	p			  = p * z - 3.33329491539e-1f;
+	y			  = y + ((p * z) * x + x);
+	return xx < 0.0f ? -y : y;
+}
+inline float atan2_fp32(float y, float x)
+{
+	if (x == 0.0f) {
+		if (y == 0.0f)
+			return 0.0f;
+		return y > 0.0f ? 1.57079632679489661923f : -1.57079632679489661923f;
+	}
+	const float a = atan_fp32(y / x);
+	if (x > 0.0f)
+		return a;
+	return y < 0.0f ? a - 3.14159265358979323846f : a + 3.14159265358979323846f;
+}
+
 // base/math/Sampling.h:38-57 cos_hemi
 inline V3 cos_hemi(float u1, float u2)
 {
@@ -441,6 +474,64 @@ inline float distribution_continuous_pdf(const float* cdf, uint32_t size, float 
 	const size_t off = std::min<size_t>(size - 2, (size_t)(x * (size - 1)));
 	return (cdf[off + 1] - cdf[off]) * float(size - 1);
 }
+
+// core/sampler/Distribution2D.{h,cpp}: a marginal over the rows and one conditional per row
+struct Distribution2D {
+	uint32_t w = 0, h = 0;
+	std::vector<float> marginal;				 // h + 1
+	std::vector<std::vector<float>> conditional; // h x (w + 1)
+	template <typename Func>
+	void generate(uint32_t width, uint32_t height, Func func) // Distribution2D.h:23-36
+	{
+		w = width;
+		h = height;
+		conditional.assign(h, std::vector<float>(w + 1));
+		marginal.assign(h + 1, 0.0f);
+		std::vector<float> integrals(h, 0.0f), row(w);
+		for (uint32_t y = 0; y < h; ++y) {
+			for (uint32_t x = 0; x < w; ++x)
+				row[x] = func(x, y);
+			distribution_generate(row.data(), w, conditional[y].data(), &integrals[y]);
+		}
+		distribution_generate(integrals.data(), h, marginal.data(), nullptr);
+	}
+	void sample_continuous(float u0, float u1, float& x, float& y, float& pdf) const // Distribution2D.cpp:14-22
+	{
+		float pdfs[2], rem;
+		const uint32_t moff = distribution_sample_discrete(marginal.data(), h + 1, u1, pdfs[1], &rem);
+		pdfs[1] *= float(h);
+		y = (float(moff) + rem) / float(h);
+		x = distribution_sample_continuous(conditional[moff].data(), w + 1, u0, pdfs[0]);
+		pdf = pdfs[0] * pdfs[1];
+	}
+	float continuous_pdf(float x, float y) const // Distribution2D.cpp:24-30
+	{
+		const size_t moff = std::min<size_t>(h - 1, (size_t)(y * h));
+		const float pdf1  = (marginal[moff + 1] - marginal[moff]) * float(h);
+		const float pdf0  = distribution_continuous_pdf(conditional[moff].data(), w + 1, x);
+		return pdf0 * pdf1;
+	}
+	void apply_compensation() // Distribution2D.cpp:38-76 over Distribution1D::reducePDFBy (Distribution1D.inl:37-51)
+	{
+		std::vector<float> avgs(h, 0.0f);
+		for (uint32_t y = 0; y < h; ++y) {
+			for (uint32_t x = 0; x < w; ++x)
+				avgs[y] += conditional[y][x + 1] - conditional[y][x];
+			avgs[y] /= w;
+		}
+		float single_avg = 0;
+		for (float f : avgs)
+			single_avg += f;
+		single_avg /= h;
+		std::vector<float> integrals(h, 0.0f), pdfs(w);
+		for (uint32_t y = 0; y < h; ++y) {
+			for (uint32_t x = 0; x < w; ++x)
+				pdfs[x] = std::max(0.0f, (conditional[y][x + 1] - conditional[y][x]) - single_avg);
+			distribution_generate(pdfs.data(), w, conditional[y].data(), &integrals[y]);
+		}
+		distribution_generate(integrals.data(), h, marginal.data(), nullptr);
+	}
+};
 
 // ------------------------------------------------------------------------------------------------
 // spectral/EquidistantSpectrum.inl:34-41 lookup
@@ -749,7 +840,11 @@ struct Scene {
 	struct InfLight {
 		prgpu_light l;
 		float nm[9], inv_nm[9]; // ITransformable::normalMatrix / invNormalMatrix
-		V3 outgoing;			// DISTANT: (normalMatrix * direction).normalized(), distant.cpp:24
+		V3 outgoing;			// DISTANT: (normalMatrix * direction).normalized(), distant.cpp:24; SUN: mDirection, sun.cpp:35
+		V3 dx, dy;				// SUN: Tangent::frame(mDirection), sun.cpp:40
+		float cone_pdf = 0;		// SUN: Sampling::uniform_cone_pdf(mCosTheta), sun.cpp:37
+		Distribution2D dist;	// SKY: mDistribution, sky.cpp:127-159
+		const float* sky = nullptr; // SKY: SkyModel::mData [elevation][azimuth][band] (a view into Scene::tables)
 	};
 	std::vector<InfLight> inf_lights;
 	float scene_radius = 0; // Scene::boundingSphere().radius(), Scene.cpp:107-118
@@ -984,6 +1079,23 @@ inline V3 sample_ndf_ggx(float u0, float u1, float roughness)
 	sincos_2pi(u0, sinPhi, cosPhi);
 	return v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
+// Microfacet.h:238-256 sample_ndf_ggx (anisotropic): phi = atan(ry / rx * tan(pi + 2 pi u0)) + pi * floor(2 u0 + 0.5).  std::tan,
+// std::atan, std::sin and std::cos are replaced by the shared fp32 forms (sincos_rad, atan_fp32), ~1 ulp from libm each.
+inline V3 sample_ndf_ggx_aniso(float u0, float u1, float rx, float ry)
+{
+	float st, ct;
+	sincos_rad(PR_PI_F + 2 * PR_PI_F * u0, st, ct);
+	const float phi = atan_fp32(ry / rx * (st / ct)) + PR_PI_F * std::floor(2 * u0 + 0.5f);
+	float sinPhi, cosPhi;
+	sincos_rad(phi, sinPhi, cosPhi);
+	const float f1	   = cosPhi / rx;
+	const float f2	   = sinPhi / ry;
+	const float alpha2 = 1 / (f1 * f1 + f2 * f2);
+	const float t2	   = alpha2 * u1 / (1 - u1);
+	const float cosTheta = std::max(0.001f, 1.0f / std::sqrt(1 + t2));
+	const float sinTheta = std::sqrt(1 - cosTheta * cosTheta);
+	return v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta); // Spherical::cartesian
+}
 // Microfacet.h:274-331 sample_vndf_ggx (Heitz 2018, the "#if 1" branch)
 inline V3 sample_vndf_ggx(float u0, float u1, V3 nV, float rx, float ry)
 {
@@ -1045,7 +1157,7 @@ struct RoughDistribution {
 			return v3(0, 0, 1);
 		if (vndf)
 			return sample_vndf_ggx(u0, u1, sv_positive(V), m1, m2);
-		return sample_ndf_ggx(u0, u1, m1);
+		return aniso ? sample_ndf_ggx_aniso(u0, u1, m1, m2) : sample_ndf_ggx(u0, u1, m1);
 	}
 };
 inline bool v3_is_zero(V3 v, float prec) { return std::fabs(v.x) <= prec && std::fabs(v.y) <= prec && std::fabs(v.z) <= prec; } // Eigen isZero(prec)
@@ -1740,7 +1852,188 @@ inline void aa_sample(const Scene& s, Rng& rnd, uint32_t index, float& x, float&
 }
 
 // ------------------------------------------------------------------------------------------------
-// lights: LightSampler ctor (light/LightSampler.cpp:11-132), area lights only
+// sky and sun: plugins/main/infinitelights/sky.cpp, sun.cpp over skysun/ElevationAzimuth.h and skysun/SkyModel.h.  The table the sky
+// reads (SkyModel::mData) and the sun's 64-sample spectrum come with the scene description: both are evaluations of third-party
+// models (Hosek-Wilkie, Preetham) that PearRay performs while it loads the scene (SkyModel.cpp:17-60, sun.cpp:42-46).
+struct ElevationAzimuth {
+	float Elevation, Azimuth;
+};
+constexpr float ELEVATION_RANGE = PR_PI_F * 0.5f; // ElevationAzimuth.h:6-7
+constexpr float AZIMUTH_RANGE	= PR_PI_F * 2;
+constexpr int AR_SPECTRAL_BANDS = PRGPU_SKY_BANDS; // SkySunConfig.h:6-9
+constexpr float AR_SPECTRAL_DELTA = 40, AR_SPECTRAL_START = 320;
+// ElevationAzimuth::fromDirection (ElevationAzimuth.h:26-30) = fromThetaPhi(Spherical::from_direction(D)) (Spherical.h:8-15);
+// atan2 / acos through the shared fp32 forms (the reference's std::acos is NaN for |z| a rounding step beyond 1: clamped)
+inline ElevationAzimuth ea_from_direction(V3 D)
+{
+	const float x = (D.x == 0 && D.y == 0) ? 1e-5f : D.x;
+	float phi	  = atan2_fp32(D.y, x);
+	phi			  = phi < 0 ? phi + 2 * PR_PI_F : phi;
+	const float theta = safe_acos(D.z);
+	ElevationAzimuth ea{ 0.5f * PR_PI_F - theta, phi };
+	if (ea.Azimuth < 0)
+		ea.Azimuth += 2 * PR_PI_F;
+	return ea;
+}
+// ElevationAzimuth::toDirection (ElevationAzimuth.h:32-35) = Spherical::cartesian(theta(), phi()) (Spherical.h:36-48)
+inline V3 ea_to_direction(const ElevationAzimuth& ea)
+{
+	float thSin, thCos, phSin, phCos;
+	sincos_rad(0.5f * PR_PI_F - ea.Elevation, thSin, thCos);
+	sincos_rad(ea.Azimuth, phSin, phCos);
+	return v3(thSin * phCos, thSin * phSin, thCos);
+}
+// SkyModel::radiance (SkyModel.h:18-23)
+inline float sky_model_radiance(const Scene::InfLight& il, int wvl_band, const ElevationAzimuth& ea)
+{
+	const int azc = (int)il.l.azimuth_count, elc = (int)il.l.elevation_count;
+	const int az_in = std::max(0, std::min<int>(azc - 1, int(ea.Azimuth / AZIMUTH_RANGE * azc)));
+	const int el_in = std::max(0, std::min<int>(elc - 1, int(ea.Elevation / ELEVATION_RANGE * elc)));
+	return il.sky[size_t(el_in) * azc * AR_SPECTRAL_BANDS + size_t(az_in) * AR_SPECTRAL_BANDS + wvl_band];
+}
+// SkyLight::radiance (sky.cpp:161-176)
+inline Blob sky_light_radiance(const Scene::InfLight& il, const Blob& wvls, const ElevationAzimuth& ea)
+{
+	Blob b;
+	for (int i = 0; i < 4; ++i) {
+		const float af	= std::max(0.0f, (wvls[i] - AR_SPECTRAL_START) / AR_SPECTRAL_DELTA);
+		const int index = (int)std::min<float>(AR_SPECTRAL_BANDS - 2, af);
+		const float t	= std::min<float>(AR_SPECTRAL_BANDS - 1, af) - index;
+		b[i]			= sky_model_radiance(il, index, ea) * (1 - t) + sky_model_radiance(il, index + 1, ea) * t;
+	}
+	return b;
+}
+// the solid-angle factor of sky.cpp:60-62,74-76,93-95: 1 / (2 pi^2 cos(elevation)), 0 at the poles
+inline float sky_direction_factor(float elevation)
+{
+	float sn, f;
+	sincos_rad(elevation, sn, f);
+	const float denom = 2 * PR_PI_F * PR_PI_F * f;
+	return (denom <= PR_EPS) ? 0.0f : 1.0f / denom;
+}
+// SkyLight::buildDistribution (sky.cpp:127-159); host-side setup, libm cosine as in the reference
+void sky_build_distribution(Scene::InfLight& il)
+{
+	const bool extend		= (il.l.flags & PRGPU_SKYF_EXTEND) != 0;
+	const uint32_t azc = il.l.azimuth_count, elc = il.l.elevation_count;
+	constexpr float GROUND_PENALTY = 0.001f; // sky.cpp:23
+	const Blob WVLS = blob4(560.0f, 540.0f, 400.0f, 600.0f);
+	il.dist.generate(azc, extend ? 2 * elc : elc, [&](uint32_t x, uint32_t y) {
+		const float azimuth = AZIMUTH_RANGE * x / (float)azc;
+		float elevation;
+		if (extend)
+			elevation = (2 * ELEVATION_RANGE) * (y / (float)(2 * elc) - 0.5f);
+		else
+			elevation = ELEVATION_RANGE * y / (float)elc;
+		const float f	= std::cos(elevation);
+		const Blob r	= sky_light_radiance(il, WVLS, ElevationAzimuth{ elevation, azimuth });
+		const float val = std::max(0.0f, f * std::max(std::max(r[0], r[1]), std::max(r[2], r[3])));
+		return (extend && elevation < 0.0f) ? val * GROUND_PENALTY : val;
+	});
+	if (il.l.flags & PRGPU_SKYF_COMPENSATION)
+		il.dist.apply_compensation();
+}
+// Sampling::uniform_cone (base/math/Sampling.h:101-107)
+inline V3 uniform_cone(float u1, float u2, float cos_theta_max)
+{
+	const float cosTheta = std::fma(u1, cos_theta_max, 1 - u1);
+	const float sinTheta = std::sqrt(std::max(0.0f, diff_prod(1, 1, cosTheta, cosTheta)));
+	float sinPhi, cosPhi;
+	sincos_2pi(u2, sinPhi, cosPhi); // phi = 2 pi u2
+	return v3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+}
+// IInfiniteLight::power: NodeUtils::average for environment / distant lights, the zenith radiance for the sky (sky.cpp:113),
+// the spectrum itself for the sun (sun.cpp:106-112, :222-228)
+Blob node_average(const Scene& s, uint32_t id, const Blob& wl);
+Blob inf_light_power(const Scene& s, const Scene::InfLight& il, const Blob& wl)
+{
+	if (il.l.kind == PRGPU_LIGHT_SKY)
+		return sky_light_radiance(il, wl, ElevationAzimuth{ 0.5f * PR_PI_F - 0.0f, 0.0f }); // fromDirection((0, 0, 1))
+	if (il.l.kind == PRGPU_LIGHT_SUN || (il.l.kind == PRGPU_LIGHT_DISTANT && (il.l.flags & PRGPU_LIGHTF_SUN_DELTA)))
+		return spectrum_eval(s, il.l.radiance, wl);
+	return node_average(s, il.l.radiance, wl);
+}
+// IInfiniteLight::eval for direction `dir` (pointing away from the scene): environment.cpp:53-73, sky.cpp:51-79, sun.cpp:61-77
+void inf_light_eval(const Scene& s, const Scene::InfLight& il, V3 dir, const Blob& wl, bool camera_ray, Blob& radiance, float& direction_pdf_s)
+{
+	switch (il.l.kind) {
+	case PRGPU_LIGHT_SKY: {
+		const ElevationAzimuth ea = ea_from_direction(mat3_mul(il.inv_nm, dir));
+		if (il.l.flags & PRGPU_SKYF_EXTEND) {
+			radiance		= sky_light_radiance(il, wl, ea);
+			direction_pdf_s = il.dist.continuous_pdf(ea.Azimuth / AZIMUTH_RANGE, ea.Elevation / (2 * ELEVATION_RANGE) + 0.5f);
+			direction_pdf_s *= sky_direction_factor(ea.Elevation);
+		} else if (ea.Elevation < 0) {
+			radiance		= blob(0);
+			direction_pdf_s = 0;
+		} else {
+			radiance		= sky_light_radiance(il, wl, ea);
+			direction_pdf_s = il.dist.continuous_pdf(ea.Azimuth / AZIMUTH_RANGE, ea.Elevation / ELEVATION_RANGE);
+			direction_pdf_s *= sky_direction_factor(ea.Elevation);
+		}
+		break;
+	}
+	case PRGPU_LIGHT_SUN: {
+		const float cosine = std::max(0.0f, dot(dir, il.outgoing));
+		if (cosine < il.l.cos_theta) {
+			radiance		= blob(0);
+			direction_pdf_s = 0;
+		} else {
+			radiance		= spectrum_eval(s, il.l.radiance, wl); // mSpectrum.lookup
+			direction_pdf_s = il.cone_pdf;
+		}
+		break;
+	}
+	default: { // EnvironmentLight, untextured: camera rays see the background
+		const uint32_t node = (camera_ray && il.l.background != INVALID) ? il.l.background : il.l.radiance;
+		radiance			= spectrum_eval(s, node, wl);
+		const V3 ld			= mat3_mul(il.inv_nm, dir);
+		direction_pdf_s		= std::fabs(ld.z) * PR_INV_PI_F; // cos_hemi_pdf(|z|)
+		break;
+	}
+	}
+}
+// IInfiniteLight::sampleDir: distant.cpp:58-77, environment.cpp:75-116 (no distribution), sky.cpp:81-98, sun.cpp:79-88
+void inf_light_sample_dir(const Scene& s, const Scene::InfLight& il, float rnd0, float rnd1, const Blob& wl, V3& outgoing, float& direction_pdf_s, Blob& radiance)
+{
+	switch (il.l.kind) {
+	case PRGPU_LIGHT_DISTANT:
+		outgoing		= il.outgoing;
+		direction_pdf_s = 1.0f;
+		radiance		= spectrum_eval(s, il.l.radiance, wl);
+		break;
+	case PRGPU_LIGHT_SKY: {
+		float u, v;
+		il.dist.sample_continuous(rnd0, rnd1, u, v, direction_pdf_s);
+		ElevationAzimuth ea;
+		if (il.l.flags & PRGPU_SKYF_EXTEND)
+			ea = ElevationAzimuth{ 2 * ELEVATION_RANGE * (v - 0.5f), AZIMUTH_RANGE * u };
+		else
+			ea = ElevationAzimuth{ ELEVATION_RANGE * v, AZIMUTH_RANGE * u };
+		outgoing = mat3_mul(il.nm, ea_to_direction(ea));
+		direction_pdf_s *= sky_direction_factor(ea.Elevation);
+		radiance = sky_light_radiance(il, wl, ea);
+		break;
+	}
+	case PRGPU_LIGHT_SUN: {
+		const V3 dir	= uniform_cone(rnd0, rnd1, il.l.cos_theta);
+		outgoing		= from_tangent_space(il.outgoing, il.dx, il.dy, dir);
+		direction_pdf_s = il.cone_pdf;
+		radiance		= spectrum_eval(s, il.l.radiance, wl);
+		break;
+	}
+	default: {
+		const V3 lo		= cos_hemi(rnd0, rnd1);
+		direction_pdf_s = lo.z * PR_INV_PI_F;
+		outgoing		= mat3_mul(il.nm, lo);
+		radiance		= spectrum_eval(s, il.l.radiance, wl);
+		break;
+	}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// lights: LightSampler ctor (light/LightSampler.cpp:11-132)
 int setup_lights(Scene& s)
 {
 	const uint32_t ne = (uint32_t)s.entities.size();
@@ -1766,13 +2059,13 @@ int setup_lights(Scene& s)
 	// infinite lights (approximate intensities), LightSampler.cpp:20,62-71
 	const float scene_area = 2 * PR_PI_F * s.scene_radius;
 	for (const auto& il : s.inf_lights) {
-		const Range node = spectrum_range(s, il.l.radiance);
+		const Range node = il.l.kind == PRGPU_LIGHT_SKY ? Range{} : spectrum_range(s, il.l.radiance); // SkyLight::spectralRange: unbounded (sky.cpp:114)
 		const float rs = node.start < 0 ? s.cfg.spectral_start : node.start;
 		const float re = node.end < 0 ? s.cfg.spectral_end : node.end;
 		Blob wl;
 		for (int k = 0; k < 4; ++k)
 			wl[k] = rs + (re - rs) * test_wvl_distr[k];
-		const Blob pw = node_average(s, il.l.radiance, wl);
+		const Blob pw = inf_light_power(s, il, wl);
 		s.light_intensity.push_back(scene_area * (bsum(pw) / 4.0f));
 	}
 	const uint32_t nl = (uint32_t)s.light_intensity.size();
@@ -1823,7 +2116,7 @@ void setup_wavelengths(Scene& s)
 	std::vector<float> full(bins, 0.0f), lp(bins, 0.0f);
 	const uint32_t n_area = (uint32_t)s.light_entity.size();
 	for (uint32_t l = 0; l < n_area + s.inf_lights.size(); ++l) { // Light::averagePower (Light.cpp:42-51): emission or infinite light power
-		const uint32_t node = l < n_area ? s.emissions[s.entities[s.light_entity[l]].emission].radiance : s.inf_lights[l - n_area].l.radiance;
+		const uint32_t node = l < n_area ? s.emissions[s.entities[s.light_entity[l]].emission].radiance : 0u;
 		for (uint32_t i = 0; i < bins; i += 4) {
 			const uint32_t k = std::min<uint32_t>(bins - i, 4);
 			Blob wl = blob(0);
@@ -1831,7 +2124,7 @@ void setup_wavelengths(Scene& s)
 				wl[j] = bin2wvl(i + j);
 			for (uint32_t j = k; j < 4; ++j)
 				wl[j] = wl[0];
-			const Blob out = node_average(s, node, wl);
+			const Blob out = l < n_area ? node_average(s, node, wl) : inf_light_power(s, s.inf_lights[l - n_area], wl);
 			for (uint32_t j = 0; j < k; ++j)
 				lp[i + j] = out[j];
 		}
@@ -2602,20 +2895,19 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 			// depth 0: IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53);
 			// depth>0: handleInfLights (direct.cpp:415-456) when the scene has infinite lights, else handleZero (:459-464)
 			st[PRGPU_STAT_BACKGROUND_HITS]++;
-			// EnvironmentLight::eval (environment.cpp:53-73): depth 0 sees the background, deeper rays the radiance
-			auto env_radiance = [&](const Scene::InfLight& il) {
-				const uint32_t node = (ray.depth == 0 && il.l.background != INVALID) ? il.l.background : il.l.radiance;
-				return spectrum_eval(s, node, ray.wl);
-			};
+						// IInfiniteLight::eval (environment.cpp:53-73: depth 0 sees the background; sky.cpp:51-79; sun.cpp:61-77)
 			if (ray.depth == 0) {
 				st[PRGPU_STAT_CAMERA_DEPTH]++;
 				const Blob one	 = blob(1);
 				bool illuminated = false;
 				for (const auto& il : s.inf_lights) { // one fragment per non-delta infinite light
-					if (il.l.kind != PRGPU_LIGHT_ENVIRONMENT)
+										if (il.l.kind == PRGPU_LIGHT_DISTANT) // hasDeltaDistribution
 						continue;
 					illuminated = true;
-					push_fragment(s, out, lx, ly, one, one, grp_importance, env_radiance(il), ray.mono, wl, blend, path_sum);
+					Blob lrad;
+					float lpdf;
+					inf_light_eval(s, il, ray.d, ray.wl, true, lrad, lpdf);
+					push_fragment(s, out, lx, ly, one, one, grp_importance, lrad, ray.mono, wl, blend, path_sum);
 				}
 				if (!illuminated)
 					push_fragment(s, out, lx, ly, one, one, grp_importance, blob(0), ray.mono, wl, blend, path_sum);
@@ -2627,13 +2919,13 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				const uint32_t n_area = (uint32_t)s.light_entity.size();
 				for (uint32_t k = 0; k < s.inf_lights.size(); ++k) {
 					const auto& il = s.inf_lights[k];
-					if (il.l.kind != PRGPU_LIGHT_ENVIRONMENT)
+										if (il.l.kind == PRGPU_LIGHT_DISTANT)
 						continue;
-					const V3 ld			= mat3_mul(il.inv_nm, ray.d);
-					const float dir_pdf = std::fabs(ld.z) * PR_INV_PI_F; // cos_hemi_pdf(|z|)
+					Blob er;
+					float dir_pdf;
+					inf_light_eval(s, il, ray.d, ray.wl, false, er, dir_pdf);
 					const float selProb = s.light_cdf[n_area + k + 1] - s.light_cdf[n_area + k]; // pdfLightSelection
 					const float pdf_S	= dir_pdf * selProb;
-					const Blob er = env_radiance(il);
 					for (int c = 0; c < 4; ++c)
 						radiance[c] += er[c];
 					denom_mis += bsum(mis_b(cur.prev_path_pdf * pdf_S));
@@ -2743,17 +3035,8 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 					V3 L;
 					float dirPdf;
 					Blob radiance;
-					const bool delta = il.l.kind == PRGPU_LIGHT_DISTANT;
-					if (delta) { // distant.cpp:58-77
-						L		 = il.outgoing;
-						dirPdf	 = 1.0f;
-						radiance = spectrum_eval(s, il.l.radiance, ray.wl);
-					} else { // environment.cpp:75-116 (no distribution)
-						const V3 lo = cos_hemi(d0, d1);
-						dirPdf		= lo.z * PR_INV_PI_F;
-						L			= mat3_mul(il.nm, lo);
-						radiance	= spectrum_eval(s, il.l.radiance, ray.wl);
-					}
+										const bool delta = il.l.kind == PRGPU_LIGHT_DISTANT;
+					inf_light_sample_dir(s, il, d0, d1, ray.wl, L, dirPdf, radiance);
 					const V3 lpos	 = P + L * s.scene_radius; // LightPosition
 					const V3 dLP	 = lpos - P;
 					const float sqrD = dot(dLP, dLP);
@@ -3194,8 +3477,6 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 		if (m.kind == PRGPU_MAT_PRINCIPLED) {
 			if (m.ior >= d->n_spectra)
 				return fail("bad principled material");
-			if (m.flags & PRGPU_MATF_NO_VNDF)
-				return fail("principled without vndf sampling is not supported");
 			for (int i = 0; i < PRGPU_PRINCIPLED_COUNT; ++i)
 				if (!std::isfinite(m.principled[i]))
 					return fail("bad principled parameter");
@@ -3205,8 +3486,6 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 		if (m.kind == PRGPU_MAT_ROUGH_CONDUCTOR || m.kind == PRGPU_MAT_ROUGH_DIELECTRIC) {
 			if (!(m.roughness_x >= 0.0f) || !((m.flags & PRGPU_MATF_ANISOTROPIC) == 0 || m.roughness_y >= 0.0f) || !std::isfinite(m.roughness_x) || !std::isfinite(m.roughness_y))
 				return fail("bad roughness");
-			if ((m.flags & PRGPU_MATF_ANISOTROPIC) && (m.flags & PRGPU_MATF_NO_VNDF))
-				return fail("anisotropic roughness without vndf sampling is not supported");
 		}
 	}
 	for (const auto& e : s.emissions)
@@ -3310,13 +3589,31 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 	for (uint32_t i = 0; i < d->n_lights; ++i) {
 		Scene::InfLight il;
 		il.l = d->lights[i];
-		if (il.l.kind > PRGPU_LIGHT_DISTANT || il.l.radiance >= d->n_spectra || (il.l.background != INVALID && il.l.background >= d->n_spectra))
+				if (il.l.kind > PRGPU_LIGHT_SUN)
 			return fail("bad infinite light");
+		if (il.l.kind == PRGPU_LIGHT_SKY) {
+			const uint64_t need = uint64_t(il.l.azimuth_count) * il.l.elevation_count * PRGPU_SKY_BANDS;
+			if (il.l.azimuth_count == 0 || il.l.elevation_count == 0 || uint64_t(il.l.table_offset) + need > s.tables.size())
+				return fail("bad sky table");
+			il.sky = s.tables.data() + il.l.table_offset;
+		} else if (il.l.radiance >= d->n_spectra || (il.l.background != INVALID && il.l.background >= d->n_spectra)) {
+			return fail("bad infinite light");
+		}
 		float det;
 		normal_matrix(il.l.transform, il.nm, det);
 		mat3_inverse(il.nm, il.inv_nm);
 		il.outgoing = normalized(mat3_mul(il.nm, v3(il.l.direction[0], il.l.direction[1], il.l.direction[2])));
-		s.inf_lights.push_back(il);
+		if (il.l.kind == PRGPU_LIGHT_SUN) { // SunLight ctor (sun.cpp:31-46)
+			if (s.spectra[il.l.radiance].kind != PRGPU_SPEC_TABLE || !(il.l.cos_theta >= 0.0f && il.l.cos_theta < 1.0f))
+				return fail("bad sun light");
+			frame_duff(il.outgoing, il.dx, il.dy); // Tangent::frame = unnormalized_frame + normalize
+			il.dx		= normalized(il.dx);
+			il.dy		= normalized(il.dy);
+			il.cone_pdf = 0.15915494309189533577f / (1 - il.l.cos_theta); // Sampling::uniform_cone_pdf
+		}
+		if (il.l.kind == PRGPU_LIGHT_SKY)
+			sky_build_distribution(il);
+		s.inf_lights.push_back(std::move(il));
 	}
 	setup_camera(s);
 	{
@@ -3756,6 +4053,45 @@ void orc_halfway(int refractive, float n_in, const float a[3], float n_out, cons
 	const V3 wIn = v3(a[0], a[1], a[2]), wOut = v3(b[0], b[1], b[2]);
 	const V3 h	 = refractive ? -normalized_or_zero(wIn * n_in + wOut * n_out) : normalized_or_zero(wIn + wOut);
 	out[0] = h.x; out[1] = h.y; out[2] = h.z;
+}
+float orc_atan2(float y, float x) { return atan2_fp32(y, x); }
+void orc_ea_from_direction(const float d[3], float* elevation, float* azimuth)
+{
+	const ElevationAzimuth ea = ea_from_direction(v3(d[0], d[1], d[2]));
+	*elevation				  = ea.Elevation;
+	*azimuth				  = ea.Azimuth;
+}
+void orc_ea_to_direction(float elevation, float azimuth, float out[3])
+{
+	const V3 d = ea_to_direction(ElevationAzimuth{ elevation, azimuth });
+	out[0] = d.x;
+	out[1] = d.y;
+	out[2] = d.z;
+}
+void orc_uniform_cone(float u1, float u2, float cos_theta_max, float out[3])
+{
+	const V3 d = uniform_cone(u1, u2, cos_theta_max);
+	out[0] = d.x;
+	out[1] = d.y;
+	out[2] = d.z;
+}
+void orc_inf_light_eval(orc_scene* h, uint32_t light, const float dir[3], const float wvl[4], int camera_ray, float radiance[4], float* pdf)
+{
+	Blob r;
+	inf_light_eval(h->s, h->s.inf_lights[light], v3(dir[0], dir[1], dir[2]), blob4(wvl[0], wvl[1], wvl[2], wvl[3]), camera_ray != 0, r, *pdf);
+	for (int k = 0; k < 4; ++k)
+		radiance[k] = r[k];
+}
+void orc_inf_light_sample(orc_scene* h, uint32_t light, float u0, float u1, const float wvl[4], float outgoing[3], float* pdf, float radiance[4])
+{
+	Blob r;
+	V3 L;
+	inf_light_sample_dir(h->s, h->s.inf_lights[light], u0, u1, blob4(wvl[0], wvl[1], wvl[2], wvl[3]), L, *pdf, r);
+	outgoing[0] = L.x;
+	outgoing[1] = L.y;
+	outgoing[2] = L.z;
+	for (int k = 0; k < 4; ++k)
+		radiance[k] = r[k];
 }
 float orc_safe_acos(float x) { return safe_acos(x); }
 void orc_sincos_rad(float x, float* s, float* c) { sincos_rad(x, *s, *c); }

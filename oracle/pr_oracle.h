@@ -105,6 +105,14 @@ float    orc_mf_reflection(int what /*0 eval, 1 evalConductor, 2 pdf*/, float m1
 void     orc_reflect_about(const float v[3], const float n[3], float out[3]);
 int      orc_refract_about(float eta, const float v[3], const float n[3], float out[3]); /* returns 1 on total reflection */
 void     orc_halfway(int refractive, float n_in, const float w_in[3], float n_out, const float w_out[3], float out[3]);
+/* sky / sun lights (plugins/main/infinitelights/sky.cpp, sun.cpp; skysun/ElevationAzimuth.h) */
+float    orc_atan2(float y, float x);                   /* shared fp32 atan2 (Spherical::from_direction) */
+void     orc_ea_from_direction(const float d[3], float* elevation, float* azimuth);
+void     orc_ea_to_direction(float elevation, float azimuth, float out[3]);
+void     orc_uniform_cone(float u1, float u2, float cos_theta_max, float out[3]); /* Sampling.h:101-107 */
+void     orc_inf_light_eval(orc_scene* s, uint32_t light, const float dir[3], const float wvl[4], int camera_ray, float radiance[4], float* pdf);
+void     orc_inf_light_sample(orc_scene* s, uint32_t light, float u0, float u1, const float wvl[4], float outgoing[3], float* pdf,
+                              float radiance[4]);
 float    orc_safe_acos(float x);                       /* shared fp32 acos used by the plane light (plane.cpp:109) */
 void     orc_sincos_rad(float x, float* s, float* c);  /* shared fp32 sin/cos of an angle in radians (plane.cpp:152-153) */
 void     orc_reflect(const float v[3], float out[3]);

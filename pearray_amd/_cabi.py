@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libprgpu.so")
 
-PRGPU_API_VERSION = 5
+PRGPU_API_VERSION = 6
 INVALID_ID = 0xFFFFFFFF
 
 SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER, SPEC_CHECKER = range(7)
@@ -18,7 +18,9 @@ MATF_ANISOTROPIC, MATF_NO_VNDF, MATF_HAS_TRANSMISSION = 1, 2, 4
 PRINCIPLED_PARAMS = ("diffuse_transmission", "specular_transmission", "specular_tint", "anisotropic", "flatness", "metallic", "sheen",
                      "sheen_tint", "clearcoat", "clearcoat_gloss")
 ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE = 0, 1, 2
-LIGHT_ENVIRONMENT, LIGHT_DISTANT = 0, 1
+LIGHT_ENVIRONMENT, LIGHT_DISTANT, LIGHT_SKY, LIGHT_SUN = 0, 1, 2, 3
+SKYF_EXTEND, SKYF_COMPENSATION = 1, 2
+SKY_BANDS = 11
 CAMERA_PERSPECTIVE, CAMERA_ORTHO = 0, 1
 AOV_NAMES = ("position", "normal", "normal_g", "tangent", "bitangent", "view", "entity_id", "material_id", "emission_id", "depth")
 EMS_DIFFUSE = 0
@@ -54,8 +56,9 @@ class Entity(C.Structure):
 
 
 class Light(C.Structure):
-    _fields_ = [("kind", C.c_uint32), ("radiance", C.c_uint32), ("background", C.c_uint32), ("reserved", C.c_uint32),
-                ("direction", C.c_float * 3), ("reserved2", C.c_float), ("transform", C.c_float * 16)]
+    _fields_ = [("kind", C.c_uint32), ("radiance", C.c_uint32), ("background", C.c_uint32), ("flags", C.c_uint32),
+                ("direction", C.c_float * 3), ("cos_theta", C.c_float), ("transform", C.c_float * 16),
+                ("table_offset", C.c_uint32), ("azimuth_count", C.c_uint32), ("elevation_count", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -100,9 +103,13 @@ class TraceCounters(C.Structure):
                 ("shade_ticks", C.c_uint64), ("idle_ticks", C.c_uint64), ("total_ticks", C.c_uint64)]
 
 
+class PrcSky(C.Structure):
+    _fields_ = [("light_name", C.c_char_p), ("table", C.POINTER(C.c_float)), ("azimuth_count", C.c_uint32), ("elevation_count", C.c_uint32)]
+
+
 class PrcOptions(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("aa_samples", C.c_uint32), ("force_direct", C.c_uint32),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("n_skies", C.c_uint32), ("reserved", C.c_uint32), ("skies", C.POINTER(PrcSky))]
 
 
 def default_settings(width, height):
@@ -145,6 +152,8 @@ SYMBOLS = {
     "prgpu_aov_channels": (C.c_uint32, [C.c_uint32]),
     "prgpu_download_aov": (C.c_int, [_VP, C.c_uint32, _F32P]),
     "prgpu_write_exr": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(_F32P), _U32P]),
+    "prgpu_sun_position": (None, [C.c_int] * 5 + [C.c_float] * 4 + [_F32P, _F32P]),
+    "prgpu_sun_radiance": (C.c_float, [C.c_float] * 3),
     "prgpu_prc_load_file": (C.c_int, [C.c_char_p, C.POINTER(PrcOptions), C.POINTER(_VP)]),
     "prgpu_prc_load_string": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(PrcOptions), C.POINTER(_VP)]),
     "prgpu_prc_desc": (C.POINTER(SceneDesc), [_VP]),

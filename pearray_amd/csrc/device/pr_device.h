@@ -75,10 +75,19 @@ constexpr uint32_t PRIM_SPHERE_BIT = 0x40000000u; // leaf records: the primitive
 
 // Infinite light (include/prgpu.h prgpu_light) with the matrices the kernels need
 struct DevInfLight {
-	uint32_t kind, radiance, background, pad;
+	uint32_t kind, radiance, background, flags;
 	float nm[9], inv_nm[9]; // ITransformable::normalMatrix / invNormalMatrix of the light's transform
-	float outgoing[3];		// DISTANT: normalized(nm * direction)
+	float outgoing[3];		// DISTANT, SUN: normalized(nm * direction)
+	float dx[3], dy[3];		// SUN: Tangent::frame(outgoing) (sun.cpp:40)
+	float cos_theta, cone_pdf; // SUN: cone half angle cosine, Sampling::uniform_cone_pdf (sun.cpp:36-37)
+	uint32_t table_offset, az_count, el_count; // SKY: table in DevScene::tables, [elevation][azimuth][band]
+	uint32_t dist_offset, dist_w, dist_h;	   // SKY: Distribution2D in DevScene::sky_cdf: marginal (dist_h + 1 floats), then dist_h conditionals of dist_w + 1
 };
+constexpr int SKY_BANDS			 = PRGPU_SKY_BANDS; // AR_SPECTRAL_BANDS (skysun/SkySunConfig.h:6-9)
+constexpr float SKY_BAND_START	 = 320.0f;
+constexpr float SKY_BAND_DELTA	 = 40.0f;
+constexpr float ELEVATION_RANGE = PR_PI_F * 0.5f; // skysun/ElevationAzimuth.h:6-7
+constexpr float AZIMUTH_RANGE	 = PR_PI_F * 2;
 
 struct DevCamera {
 	float o[3], right[3], up[3], focal[3], xap[3], yap[3];
@@ -107,6 +116,7 @@ struct DevScene {
 	const DevInfLight* inf_lights;
 	const DevShapeLight* shape_lights; // per entity, or null when no plane / sphere emits
 	uint32_t n_inf_lights;
+	const float* sky_cdf; // Distribution2D tables of the SKY lights (DevInfLight::dist_offset), or null
 	float scene_radius; // origin-centred bounding sphere (Scene.cpp:107-118)
 	uint32_t features;	// FEAT_* bits the scene needs beyond Lambert + meshes + area lights (selects the kernel variant)
 	const float* wl_cdf;
@@ -265,6 +275,105 @@ __device__ __forceinline__ float safe_acos(float a)
 		return 2.0f * asin_poly(sqrtf((1.0f - x) * 0.5f));
 	return 1.57079632679489661923f - asin_poly(x);
 }
+// diffProd / sumProd (base/config/MathGlue.inl:6-25): explicit fused multiply-adds
+__device__ __forceinline__ float diff_prod(float a, float b, float c, float d)
+{
+	const float cd	= c * d;
+	const float err = __fmaf_rn(-c, d, cd);
+	const float dop = __fmaf_rn(a, b, -cd);
+	return dop + err;
+}
+__device__ __forceinline__ float sum_prod(float a, float b, float c, float d) { return __fmaf_rn(a, b, c * d); }
+// atan2 in fp32 operations only (Cephes atanf: two range reductions + a degree-4 polynomial in x^2), shared with the checker like
+// safe_acos: Spherical::from_direction (base/math/Spherical.h:8-15) calls std::atan2, which differs from this by an ulp or so
+__device__ __forceinline__ float atan_poly(float xx)
+{
+	float x = fabsf(xx), y = 0.0f;
+	if (x > 2.414213562373095f) { // tan(3 pi / 8)
+		y = 1.57079632679489661923f;
+		x = -(1.0f / x);
+	} else if (x > 0.4142135623730950f) { // tan(pi / 8)
+		y = 0.78539816339744830962f;
+		x = (x - 1.0f) / (x + 1.0f);
+	}
+	const float z = x * x;
+	float p		  = 8.05374449538e-2f;
+	p			  = p * z - 1.38776856032e-1f;
+	p			  = p * z + 1.99777106478e-1f;
+	p			  = p * z - 3.33329491539e-1f;
+	y			  = y + ((p * z) * x + x);
+	return xx < 0.0f ? -y : y;
+}
+__device__ __forceinline__ float pr_atan2(float y, float x)
+{
+	if (x == 0.0f) {
+		if (y == 0.0f)
+			return 0.0f;
+		return y > 0.0f ? 1.57079632679489661923f : -1.57079632679489661923f;
+	}
+	const float a = atan_poly(y / x);
+	if (x > 0.0f)
+		return a;
+	return y < 0.0f ? a - 3.14159265358979323846f : a + 3.14159265358979323846f;
+}
+// ElevationAzimuth (skysun/ElevationAzimuth.h): up is +z, elevation in [-pi/2, pi/2], azimuth in [0, 2 pi]
+struct ElAz {
+	float el, az;
+};
+__device__ __forceinline__ ElAz ea_from_direction(V3 D) // ::fromDirection over Spherical::from_direction (Spherical.h:8-15) and ::fromThetaPhi
+{
+	const float x = (D.x == 0.0f && D.y == 0.0f) ? 1e-5f : D.x;
+	float phi	  = pr_atan2(D.y, x);
+	phi			  = phi < 0.0f ? phi + 2 * PR_PI_F : phi;
+	const float theta = safe_acos(D.z); // std::acos in the reference: NaN for |z| > 1 by an ulp, clamped here
+	ElAz ea{ 0.5f * PR_PI_F - theta, phi };
+	if (ea.az < 0.0f)
+		ea.az += 2 * PR_PI_F;
+	return ea;
+}
+__device__ __forceinline__ V3 ea_to_direction(ElAz ea) // ::toDirection = Spherical::cartesian(theta, phi) (Spherical.h:36-48)
+{
+	float st, ct, sp, cp;
+	pr_sincos_rad(0.5f * PR_PI_F - ea.el, st, ct);
+	pr_sincos_rad(ea.az, sp, cp);
+	return v3(st * cp, st * sp, ct);
+}
+// 1 / (2 pi^2 cos(elevation)): solid angle Jacobian of the (azimuth, elevation) parametrisation (sky.cpp:60-62,74-76,93-95)
+__device__ __forceinline__ float sky_jacobian(float elevation)
+{
+	float s, f;
+	pr_sincos_rad(elevation, s, f);
+	const float denom = 2 * PR_PI_F * PR_PI_F * f;
+	return denom <= PR_EPS ? 0.0f : 1.0f / denom;
+}
+// SkyModel::radiance (skysun/SkyModel.h:18-23): nearest table cell
+__device__ __forceinline__ float sky_model_radiance(const float* table, uint32_t az_count, uint32_t el_count, int band, ElAz ea)
+{
+	const int az_in = max(0, min((int)az_count - 1, (int)(ea.az / AZIMUTH_RANGE * az_count)));
+	const int el_in = max(0, min((int)el_count - 1, (int)(ea.el / ELEVATION_RANGE * el_count)));
+	return table[(size_t)el_in * az_count * SKY_BANDS + (size_t)az_in * SKY_BANDS + band];
+}
+// SkyLight::radiance (sky.cpp:161-176): linear interpolation between the 40 nm bands
+__device__ __forceinline__ Blob sky_radiance(const float* table, uint32_t az_count, uint32_t el_count, const Blob& wl, ElAz ea)
+{
+	Blob b;
+	for (int i = 0; i < 4; ++i) {
+		const float af	= fmaxf(0.0f, (wl.v[i] - SKY_BAND_START) / SKY_BAND_DELTA);
+		const int index = (int)fminf(float(SKY_BANDS - 2), af);
+		const float t	= fminf(float(SKY_BANDS - 1), af) - index;
+		b.v[i] = sky_model_radiance(table, az_count, el_count, index, ea) * (1 - t) + sky_model_radiance(table, az_count, el_count, index + 1, ea) * t;
+	}
+	return b;
+}
+// Sampling::uniform_cone (base/math/Sampling.h:101-107)
+__device__ __forceinline__ V3 uniform_cone(float u1, float u2, float cos_theta_max)
+{
+	const float cosTheta = fmaf(u1, cos_theta_max, 1 - u1);
+	const float sinTheta = sqrtf(fmaxf(0.0f, diff_prod(1, 1, cosTheta, cosTheta)));
+	float s, c;
+	pr_sincos_2pi(u2, s, c);
+	return v3(c * sinTheta, s * sinTheta, cosTheta);
+}
 // Sampling.h:38-57
 __device__ __forceinline__ V3 cos_hemi(float u1, float u2)
 {
@@ -361,6 +470,37 @@ __device__ __forceinline__ float distribution_sample_continuous(const float* cdf
 	const uint32_t off = distribution_sample_discrete(cdf, size, u, pdf, &rem);
 	pdf *= float(size - 1);
 	return (float(off) + rem) / float(size - 1);
+}
+
+// Distribution1D::sampleContinuous with the offset output (Distribution1D.inl:71-82)
+__device__ __forceinline__ float distribution_sample_continuous_off(const float* cdf, uint32_t size, float u, float& pdf, uint32_t& off)
+{
+	float rem;
+	off = distribution_sample_discrete(cdf, size, u, pdf, &rem);
+	pdf *= float(size - 1);
+	return (float(off) + rem) / float(size - 1);
+}
+// Distribution1D::continuousPdf (Distribution1D.inl:89-95)
+__device__ __forceinline__ float distribution_continuous_pdf(const float* cdf, uint32_t size, float x, uint32_t& off)
+{
+	off = (uint32_t)min((size_t)(size - 2), (size_t)(x * (size - 1)));
+	return (cdf[off + 1] - cdf[off]) * float(size - 1);
+}
+// Distribution2D (core/sampler/Distribution2D.cpp:14-31): marginal over rows (v), one conditional per row (u)
+__device__ __forceinline__ void distribution2d_sample(const float* d, uint32_t w, uint32_t h, float u0, float u1, float& x, float& y, float& pdf)
+{
+	float p0, p1;
+	uint32_t moff, coff;
+	y	= distribution_sample_continuous_off(d, h + 1, u1, p1, moff);
+	x	= distribution_sample_continuous_off(d + (h + 1) + (size_t)moff * (w + 1), w + 1, u0, p0, coff);
+	pdf = p0 * p1;
+}
+__device__ __forceinline__ float distribution2d_pdf(const float* d, uint32_t w, uint32_t h, float x, float y)
+{
+	uint32_t moff, coff;
+	const float pdf1 = distribution_continuous_pdf(d, h + 1, y, moff);
+	const float pdf0 = distribution_continuous_pdf(d + (h + 1) + (size_t)moff * (w + 1), w + 1, x, coff);
+	return pdf0 * pdf1;
 }
 
 // EquidistantSpectrum.inl:34-41
@@ -545,15 +685,6 @@ __device__ __forceinline__ bool box_hit(const RayPre& r, const float* lo, const 
 	return t0 <= t1 * 1.000001f + r.eps_t;
 }
 // ---- delta dielectric helpers (same operations as the checker) ---------------------------------------------------
-// diffProd / sumProd (base/config/MathGlue.inl:6-25): explicit fused multiply-adds
-__device__ __forceinline__ float diff_prod(float a, float b, float c, float d)
-{
-	const float cd	= c * d;
-	const float err = __fmaf_rn(-c, d, cd);
-	const float dop = __fmaf_rn(a, b, -cd);
-	return dop + err;
-}
-__device__ __forceinline__ float sum_prod(float a, float b, float c, float d) { return __fmaf_rn(a, b, c * d); }
 // Scattering::refraction_angle (base/math/Scattering.h:51-62)
 __device__ __forceinline__ float refraction_angle(float cosI, float eta)
 {
@@ -714,6 +845,22 @@ __device__ __forceinline__ V3 sample_ndf_ggx(float u0, float u1, float roughness
 	pr_sincos_2pi(u0, sinPhi, cosPhi);
 	return v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
+// Microfacet.h:238-256 sample_ndf_ggx (anisotropic); tan / atan / sin / cos through the shared fp32 forms like the checker
+__device__ __forceinline__ V3 sample_ndf_ggx_aniso(float u0, float u1, float rx, float ry)
+{
+	float st, ct;
+	pr_sincos_rad(PR_PI_F + 2 * PR_PI_F * u0, st, ct);
+	const float phi = atan_poly(ry / rx * (st / ct)) + PR_PI_F * floorf(2 * u0 + 0.5f);
+	float sinPhi, cosPhi;
+	pr_sincos_rad(phi, sinPhi, cosPhi);
+	const float f1		 = cosPhi / rx;
+	const float f2		 = sinPhi / ry;
+	const float alpha2	 = 1 / (f1 * f1 + f2 * f2);
+	const float t2		 = alpha2 * u1 / (1 - u1);
+	const float cosTheta = fmaxf(0.001f, 1.0f / sqrtf(1 + t2));
+	const float sinTheta = sqrtf(1 - cosTheta * cosTheta);
+	return v3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+}
 // Microfacet.h:274-331 sample_vndf_ggx (Heitz 2018, the "#if 1" branch)
 __device__ __forceinline__ V3 sample_vndf_ggx(float u0, float u1, V3 nV, float rx, float ry)
 {
@@ -769,13 +916,13 @@ struct RoughDistribution {
 			return pdf_ggx_vndf(sv_positive(V), sv_positive(H), m1, m2);
 		return pdf_ggx(H, m1, m2, aniso);
 	}
-	__device__ __forceinline__ V3 sample(float u0, float u1, V3 V) const // :105-120 (the anisotropic non-VNDF sampler is not built: validate rejects it)
+	__device__ __forceinline__ V3 sample(float u0, float u1, V3 V) const // :105-120
 	{
 		if (is_delta())
 			return v3(0, 0, 1);
 		if (vndf)
 			return sample_vndf_ggx(u0, u1, sv_positive(V), m1, m2);
-		return sample_ndf_ggx(u0, u1, m1);
+		return aniso ? sample_ndf_ggx_aniso(u0, u1, m1, m2) : sample_ndf_ggx(u0, u1, m1);
 	}
 };
 __device__ __forceinline__ bool v3_is_zero(V3 v, float prec) { return fabsf(v.x) <= prec && fabsf(v.y) <= prec && fabsf(v.z) <= prec; } // Eigen isZero(prec)

@@ -8,6 +8,12 @@
 //
 // No MFMA: no stage is a dense contraction.  The kernels are latency/bandwidth bound on BVH-node and
 // triangle fetches (64-byte inner and 128-byte leaf records, see DESIGN.md for the bytes-per-ray model).
+// This file is compiled five times (Makefile: -DPR_TU=0..4) so that the large kernels build in parallel: translation unit 0 holds the
+// wavefront (lockstep / streaming) kernels, the ray service and the launchers; units 1..4 hold one feature-mask variant of the
+// persistent path kernel each (launch_pp_variant_1..4).  The device functions above the kernels are shared source, not shared objects.
+#ifndef PR_TU
+#error "compile with -DPR_TU=0..4 (see the Makefile)"
+#endif
 #include "render.h"
 
 #include <algorithm>
@@ -731,6 +737,7 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	atomicAdd(&bs.v[PRGPU_STAT_PRIMARY_RAYS], 1u);
 }
 
+#if PR_TU == 0
 __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PathState ps, uint32_t slot_base, uint32_t n_slots, uint32_t iter, unsigned long long* gstats)
 {
 	__shared__ BlockStats bs;
@@ -799,6 +806,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 	trace_persistent<false, COUNT>(sc, n_active, queue_head, spill, refill_below, load, store, gstats);
 }
 
+#endif // PR_TU == 0
 // handleCameraVertex / handleDirectHit / handleNEE / handleScattering (direct.cpp:73-412), Walker::traverse
 // (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53).
 // Processes the path vertex of `slot` whose closest hit is in ps.hit[slot]: adds emission, prepares the NEE shadow ray
@@ -1208,6 +1216,66 @@ __device__ __noinline__ void rough_sample(const DevScene& s, const prgpu_materia
 		pdf_s = blob(1);
 }
 
+// IInfiniteLight::eval for a ray that leaves the scene in direction `dir`: EnvironmentLight (environment.cpp:53-73; camera rays see the
+// background), SkyLight (sky.cpp:51-79), SunLight (sun.cpp:61-77).  Delta lights (DISTANT) are never evaluated.
+__device__ __forceinline__ void inf_light_eval(const DevScene& sc, const DevInfLight& il, V3 dir, const Blob& wl, bool camera_ray, Blob& radiance, float& dir_pdf)
+{
+	if (il.kind == PRGPU_LIGHT_SKY) {
+		const ElAz ea	  = ea_from_direction(mat3_mul(il.inv_nm, dir));
+		const bool extend = (il.flags & PRGPU_SKYF_EXTEND) != 0;
+		if (!extend && ea.el < 0.0f) {
+			radiance = blob(0);
+			dir_pdf	 = 0.0f;
+			return;
+		}
+		radiance = sky_radiance(sc.tables + il.table_offset, il.az_count, il.el_count, wl, ea);
+		dir_pdf	 = distribution2d_pdf(sc.sky_cdf + il.dist_offset, il.dist_w, il.dist_h, ea.az / AZIMUTH_RANGE,
+									  extend ? ea.el / (2 * ELEVATION_RANGE) + 0.5f : ea.el / ELEVATION_RANGE);
+		dir_pdf *= sky_jacobian(ea.el);
+		return;
+	}
+	if (il.kind == PRGPU_LIGHT_SUN) {
+		const float cosine = fmaxf(0.0f, dot(dir, v3(il.outgoing[0], il.outgoing[1], il.outgoing[2])));
+		if (cosine < il.cos_theta) {
+			radiance = blob(0);
+			dir_pdf	 = 0.0f;
+		} else {
+			radiance = spectrum_eval(sc, il.radiance, wl);
+			dir_pdf	 = il.cone_pdf;
+		}
+		return;
+	}
+	radiance	= spectrum_eval(sc, (camera_ray && il.background != INVALID) ? il.background : il.radiance, wl);
+	const V3 ld = mat3_mul(il.inv_nm, dir);
+	dir_pdf		= fabsf(ld.z) * PR_INV_PI_F;
+}
+// IInfiniteLight::sampleDir: distant.cpp:58-77, environment.cpp:75-116 (no distribution), sky.cpp:81-98, sun.cpp:79-88
+__device__ __forceinline__ void inf_light_sample(const DevScene& sc, const DevInfLight& il, float d0, float d1, const Blob& wl, V3& L, float& dir_pdf, Blob& radiance)
+{
+	if (il.kind == PRGPU_LIGHT_DISTANT) {
+		L		 = v3(il.outgoing[0], il.outgoing[1], il.outgoing[2]);
+		dir_pdf	 = 1.0f;
+		radiance = spectrum_eval(sc, il.radiance, wl);
+	} else if (il.kind == PRGPU_LIGHT_SKY) {
+		float u, v;
+		distribution2d_sample(sc.sky_cdf + il.dist_offset, il.dist_w, il.dist_h, d0, d1, u, v, dir_pdf);
+		const ElAz ea = (il.flags & PRGPU_SKYF_EXTEND) ? ElAz{ 2 * ELEVATION_RANGE * (v - 0.5f), AZIMUTH_RANGE * u } : ElAz{ ELEVATION_RANGE * v, AZIMUTH_RANGE * u };
+		L			  = mat3_mul(il.nm, ea_to_direction(ea));
+		dir_pdf *= sky_jacobian(ea.el);
+		radiance = sky_radiance(sc.tables + il.table_offset, il.az_count, il.el_count, wl, ea);
+	} else if (il.kind == PRGPU_LIGHT_SUN) {
+		const V3 dir = uniform_cone(d0, d1, il.cos_theta);
+		L			 = from_tangent_space(v3(il.outgoing[0], il.outgoing[1], il.outgoing[2]), v3(il.dx[0], il.dx[1], il.dx[2]), v3(il.dy[0], il.dy[1], il.dy[2]), dir);
+		dir_pdf		 = il.cone_pdf;
+		radiance	 = spectrum_eval(sc, il.radiance, wl);
+	} else {
+		const V3 lo = cos_hemi(d0, d1);
+		dir_pdf		= lo.z * PR_INV_PI_F;
+		L			= mat3_mul(il.nm, lo);
+		radiance	= spectrum_eval(sc, il.radiance, wl);
+	}
+}
+
 template <uint32_t FEATS>
 __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState& ps, uint32_t slot, BlockStats& bs, bool& alive, bool& want_shadow,
 											 float4& sh_o, float4& sh_d, float4& sh_xyz)
@@ -1251,10 +1319,12 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			bool illuminated = false;
 			for (uint32_t k = 0; (FEATS & FEAT_INFINITE_LIGHTS) && k < sc.n_inf_lights; ++k) {
 				const DevInfLight& il = sc.inf_lights[k];
-				if (il.kind != PRGPU_LIGHT_ENVIRONMENT)
+				if (il.kind == PRGPU_LIGHT_DISTANT) // hasDeltaDistribution
 					continue;
 				illuminated = true;
-				const Blob radiance = spectrum_eval(sc, il.background != INVALID ? il.background : il.radiance, wl); // environment.cpp:56-63
+				Blob radiance;
+				float dir_pdf;
+				inf_light_eval(sc, il, ray_d, wl, true, radiance, dir_pdf);
 				fb = fragment_value(sc, blob(1), blob(1), grp_imp, radiance, mono, cie, blend, xyz);
 				apply_fragment(ps, pixel, fb, xyz);
 			}
@@ -1268,13 +1338,13 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			Blob radiance	= blob(0);
 			for (uint32_t k = 0; k < sc.n_inf_lights; ++k) {
 				const DevInfLight& il = sc.inf_lights[k];
-				if (il.kind != PRGPU_LIGHT_ENVIRONMENT)
+				if (il.kind == PRGPU_LIGHT_DISTANT)
 					continue;
-				const V3 ld			= mat3_mul(il.inv_nm, ray_d);
-				const float dir_pdf = fabsf(ld.z) * PR_INV_PI_F;
+				Blob er;
+				float dir_pdf;
+				inf_light_eval(sc, il, ray_d, wl, false, er, dir_pdf);
 				const float selProb = sc.light_cdf[sc.n_lights + k + 1] - sc.light_cdf[sc.n_lights + k];
 				const float pdf_S	= dir_pdf * selProb;
-				const Blob er		= spectrum_eval(sc, il.radiance, wl);
 				for (int c = 0; c < 4; ++c)
 					radiance.v[c] += er.v[c];
 				const Blob a = prev_pdf * pdf_S;
@@ -1393,16 +1463,9 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						(void)rng_float(rnd);
 						V3 L;
 						float dirPdf;
-						const bool delta	= il.kind == PRGPU_LIGHT_DISTANT;
-						const Blob radiance = spectrum_eval(sc, il.radiance, wl);
-						if (delta) { // distant.cpp:58-77
-							L	   = v3(il.outgoing[0], il.outgoing[1], il.outgoing[2]);
-							dirPdf = 1.0f;
-						} else { // environment.cpp:75-116 (no distribution)
-							const V3 lo = cos_hemi(d0, d1);
-							dirPdf		= lo.z * PR_INV_PI_F;
-							L			= mat3_mul(il.nm, lo);
-						}
+						const bool delta = il.kind == PRGPU_LIGHT_DISTANT;
+						Blob radiance;
+						inf_light_sample(sc, il, d0, d1, wl, L, dirPdf, radiance);
 						const V3 lpos	 = P + L * sc.scene_radius;
 						const V3 dLP	 = lpos - P;
 						const float sqrD = dot(dLP, dLP);
@@ -1665,6 +1728,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	}
 }
 
+#if PR_TU == 0
 __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const uint32_t* __restrict__ active, uint32_t slot_base, uint32_t n_active,
 											  uint32_t* __restrict__ next_active, uint32_t* __restrict__ counters /* [0]=next, [1]=shadow, [2]=dead */,
 											  uint32_t* __restrict__ dead_list, uint32_t* queue_head_closest, uint32_t* queue_head_shadow,
@@ -1778,6 +1842,7 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 // clears the per-iteration plane of the pixels a path wrote (owned pixels are re-zeroed by raygen; this
 // covers nothing else, the plane is zero-initialised once) -- kept for symmetry with mCopySpectral->clear.
 
+#endif // PR_TU == 0
 // ---- persistent path kernel -----------------------------------------------------------------------------------
 // The whole render call as ONE launch (single-tap pixel filters).  Every block owns `slots_per_block` path slots and two
 // ring queues in LDS -- rays to trace (closest and occlusion rays mixed) and vertices to shade -- and its four waves
@@ -2172,6 +2237,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu
 	path_persistent<COUNT, FEATS>(sc, ps, a);
 }
 
+#if PR_TU == 0
 // ---- ray service kernels (IArchive surface) ------------------------------------------------------------
 __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
 															   const float* __restrict__ tmin_a, const float* __restrict__ tmax_a, uint32_t* entity,
@@ -2271,6 +2337,46 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 					   ws.refill_below, gstats);
 }
 
+#endif // PR_TU == 0
+
+// ---- persistent path kernel: one translation unit per feature-mask variant ------------------------------------------------------
+constexpr uint32_t FEAT_NO_ROUGH = FEAT_ALL & ~FEAT_ROUGH_MATERIALS;
+void launch_pp_variant_1(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st);
+void launch_pp_variant_2(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st);
+void launch_pp_variant_3(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st);
+void launch_pp_variant_4(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st);
+#if PR_TU >= 1
+#if PR_TU == 1
+#define PR_PP_FEATS 0u
+#define PR_PP_LAUNCHER launch_pp_variant_1
+#elif PR_TU == 2
+#define PR_PP_FEATS FEAT_DELTA_MATERIALS
+#define PR_PP_LAUNCHER launch_pp_variant_2
+#elif PR_TU == 3
+#define PR_PP_FEATS FEAT_NO_ROUGH
+#define PR_PP_LAUNCHER launch_pp_variant_3
+#else
+#define PR_PP_FEATS FEAT_ALL
+#define PR_PP_LAUNCHER launch_pp_variant_4
+#endif
+void PR_PP_LAUNCHER(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st)
+{
+	const dim3 block(TRAV_BLOCK);
+	if (occupancy >= 3) {
+		if (count)
+			hipLaunchKernelGGL((k_path_persistent_occ3<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+		else
+			hipLaunchKernelGGL((k_path_persistent_occ3<false, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+	} else {
+		if (count)
+			hipLaunchKernelGGL((k_path_persistent<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+		else
+			hipLaunchKernelGGL((k_path_persistent<false, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+	}
+}
+#endif // PR_TU >= 1
+
+#if PR_TU == 0
 PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, uint32_t max_slots_per_block)
 {
 	PersistentGeometry g;
@@ -2306,40 +2412,23 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.shade_help	  = (uint32_t)std::max(64, shade_help);
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
-	const dim3 grid(g.n_blocks), block(TRAV_BLOCK);
+	const dim3 grid(g.n_blocks);
 	// smallest compiled variant that covers the scene's features: lean (Lambert / mesh / area lights), + smooth delta materials,
 	// everything but the rough / principled closures, everything.  The out-of-line closures are what the last step pays for: a kernel
 	// that CONTAINS the calls runs a scene that never makes them 25 % slower (metal Cornell box: 3.18 vs 4.02 ms per iteration; leaving
 	// out spheres, AOVs + textures or infinite / shape lights + planes instead changes nothing).  A variant for delta + rough materials
 	// only was measured and dropped: the closures dominate such scenes, 156 vs 154 Msamples/s.
-	constexpr uint32_t FEAT_NO_ROUGH = FEAT_ALL & ~FEAT_ROUGH_MATERIALS;
-	const int variant = sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3));
-#define PR_LAUNCH_PP_V(KERNEL, COUNT)                                                                  \
-	do {                                                                                               \
-		if (variant == 3)                                                                              \
-			hipLaunchKernelGGL((KERNEL<COUNT, FEAT_ALL>), grid, block, 0, st, sc, ps, a);              \
-		else if (variant == 2)                                                                         \
-			hipLaunchKernelGGL((KERNEL<COUNT, FEAT_NO_ROUGH>), grid, block, 0, st, sc, ps, a);         \
-		else if (variant == 1)                                                                         \
-			hipLaunchKernelGGL((KERNEL<COUNT, FEAT_DELTA_MATERIALS>), grid, block, 0, st, sc, ps, a);  \
-		else                                                                                           \
-			hipLaunchKernelGGL((KERNEL<COUNT, 0u>), grid, block, 0, st, sc, ps, a);                    \
-	} while (0)
-#define PR_LAUNCH_PP(KERNEL)                \
-	do {                                    \
-		if (count)                          \
-			PR_LAUNCH_PP_V(KERNEL, true);   \
-		else                                \
-			PR_LAUNCH_PP_V(KERNEL, false);  \
-	} while (0)
-	if (occupancy >= 3)
-		PR_LAUNCH_PP(k_path_persistent_occ3);
+	if (sc.features == 0)
+		launch_pp_variant_1(sc, ps, a, grid, count, occupancy, st);
+	else if ((sc.features & ~FEAT_DELTA_MATERIALS) == 0)
+		launch_pp_variant_2(sc, ps, a, grid, count, occupancy, st);
+	else if ((sc.features & FEAT_ROUGH_MATERIALS) == 0)
+		launch_pp_variant_3(sc, ps, a, grid, count, occupancy, st);
 	else
-		PR_LAUNCH_PP(k_path_persistent);
-#undef PR_LAUNCH_PP
-#undef PR_LAUNCH_PP_V
+		launch_pp_variant_4(sc, ps, a, grid, count, occupancy, st);
 }
 
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * TRAV_BLOCK * STACK_SPILL; }
+#endif // PR_TU == 0
 
 } // namespace prd

@@ -482,7 +482,7 @@ struct Loader {
 		settings.emissive_scatter	= get_bool(g, "emissive_scatter", true) ? 1 : 0;
 		have_integrator				= true;
 	}
-	void add_light(const Group& g) // SceneLoader.cpp:558-600, environment.cpp:152-205, distant.cpp:112-121
+	void add_light(const Group& g) // SceneLoader.cpp:558-600, environment.cpp:152-205, distant.cpp:112-121, sun.cpp:250-267, sky.cpp:180-198
 	{
 		const std::string type = lower(get_string(g, "type", ""));
 		prgpu_light l;
@@ -512,10 +512,95 @@ struct Loader {
 				std::memcpy(l.direction, d, sizeof(d));
 			if (l.direction[0] == 0 && l.direction[1] == 0 && l.direction[2] == 0)
 				fail(PRGPU_EINVAL, where(g) + ": distant light with a zero :direction");
+		} else if (type == "sun") { // SunLightFactory::create (sun.cpp:250-267)
+			float el, az;
+			sun_position(g, el, az);
+			const float radius	  = (float)get_number(g, "radius", 1.0);
+			const float turbidity = (float)get_number(g, "turbidity", 3.0);
+			float scale			  = (float)get_number(g, "power_scale", 1.0);
+			const float SUN_VIS_RADIUS = (3.14159265358979323846f / 180.0f) * 0.5358f * 0.5f; // sun.cpp:24
+			const bool delta	  = radius <= 1.1920928955078125e-7f;
+			if (delta) // SunDeltaLight ctor (sun.cpp:164-170): the solid angle of the visible disc instead of a cone
+				scale *= 1.0f;
+			else
+				scale /= (radius * radius); // SunLight ctor (sun.cpp:42)
+			const float theta = 0.5f * 3.14159265358979323846f - el; // ElevationAzimuth::theta
+			float values[64];
+			const float start = 360.0f, end = 760.0f, delta_nm = (end - start) / (64 - 1);
+			const float solid_angle = 2 * 3.14159265358979323846f * (1 - std::cos(SUN_VIS_RADIUS));
+			for (int i = 0; i < 64; ++i) {
+				const float r = prgpu_sun_radiance(start + i * delta_nm, theta, turbidity);
+				values[i]	  = delta ? r * solid_angle * scale : r * scale;
+			}
+			l.radiance = spectrum_table(start, end, values, 64);
+			// ElevationAzimuth::toDirection = Spherical::cartesian(theta, phi) (Spherical.h:36-48)
+			l.direction[0] = std::sin(theta) * std::cos(az);
+			l.direction[1] = std::sin(theta) * std::sin(az);
+			l.direction[2] = std::cos(theta);
+			if (delta) {
+				l.kind	= PRGPU_LIGHT_DISTANT;
+				l.flags = PRGPU_LIGHTF_SUN_DELTA;
+			} else {
+				l.kind		= PRGPU_LIGHT_SUN;
+				l.cos_theta = std::cos(SUN_VIS_RADIUS * radius);
+			}
+		} else if (type == "sky") { // SkyLightFactory::create (sky.cpp:180-198); the table is the host's SkyModel
+			const std::string name = get_string(g, "name", "__unknown");
+			const prgpu_prc_sky* sky = nullptr;
+			for (uint32_t i = 0; i < opt.n_skies && opt.skies; ++i)
+				if (!opt.skies[i].light_name || name == opt.skies[i].light_name) {
+					sky = &opt.skies[i];
+					break;
+				}
+			if (!sky || !sky->table)
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": light type 'sky' needs the table of PearRay's SkyModel (Hosek-Wilkie evaluation, src/skysun): "
+												  "supply it through prgpu_prc_options::skies for light '" + name + "'");
+			const uint32_t azc = (uint32_t)get_number(g, "azimuth_resolution", 512), elc = (uint32_t)get_number(g, "elevation_resolution", 256);
+			if (azc != sky->azimuth_count || elc != sky->elevation_count)
+				fail(PRGPU_EINVAL, where(g) + ": the supplied sky table is " + std::to_string(sky->azimuth_count) + " x " + std::to_string(sky->elevation_count)
+										+ " but the light asks for " + std::to_string(azc) + " x " + std::to_string(elc));
+			l.kind			  = PRGPU_LIGHT_SKY;
+			l.radiance		  = PRGPU_INVALID_ID;
+			l.flags			  = (get_bool(g, "extend", true) ? PRGPU_SKYF_EXTEND : 0u) | (get_bool(g, "compensation", false) ? PRGPU_SKYF_COMPENSATION : 0u);
+			l.table_offset	  = (uint32_t)out.tables.size();
+			l.azimuth_count	  = azc;
+			l.elevation_count = elc;
+			out.tables.insert(out.tables.end(), sky->table, sky->table + size_t(azc) * elc * PRGPU_SKY_BANDS);
 		} else {
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": light type '" + type + "' is not supported (env/environment/background and distant/direction are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": light type '" + type + "' is not supported (env/environment/background, distant/direction, sun and sky are)");
 		}
 		out.lights.push_back(l);
+	}
+	// computeSunEA(ParameterGroup) (skysun/SunLocation.cpp:107-130): :direction | :theta :phi | :elevation :azimuth | date, time, location
+	void sun_position(const Group& g, float& elevation, float& azimuth)
+	{
+		const float PI = 3.14159265358979323846f;
+		auto from_theta_phi = [&](float theta, float phi) { // ElevationAzimuth::fromThetaPhi
+			elevation = 0.5f * PI - theta;
+			azimuth	  = phi;
+			if (azimuth < 0)
+				azimuth += 2 * PI;
+		};
+		float d[3];
+		if (g.get("direction")) {
+			if (!get_vec3(g, "direction", d)) {
+				d[0] = d[1] = 0;
+				d[2]		= 1;
+			}
+			const float x = (d[0] == 0 && d[1] == 0) ? 1e-5f : d[0]; // Spherical::from_direction (Spherical.h:8-15)
+			float phi	  = std::atan2(d[1], x);
+			phi			  = phi < 0 ? phi + 2 * PI : phi;
+			from_theta_phi(std::acos(d[2]), phi);
+		} else if (g.get("theta")) {
+			from_theta_phi((float)get_number(g, "theta", 0), (float)get_number(g, "phi", 0));
+		} else if (g.get("elevation")) {
+			elevation = (float)get_number(g, "elevation", 0);
+			azimuth	  = (float)get_number(g, "azimuth", 0);
+		} else {
+			prgpu_sun_position((int)get_number(g, "year", 2020), (int)get_number(g, "month", 5), (int)get_number(g, "day", 6), (int)get_number(g, "hour", 12),
+							   (int)get_number(g, "minute", 0), (float)get_number(g, "seconds", 0.0), (float)get_number(g, "latitude", 49.235422),
+							   (float)get_number(g, "longitude", 6.9965744), (float)get_number(g, "timezone", 2), &elevation, &azimuth);
+		}
 	}
 	void add_camera(const Group& g) // perspective.cpp:141-165
 	{
@@ -572,8 +657,6 @@ struct Loader {
 			}
 			if (!get_bool(g, "vndf", true))
 				mm.flags |= PRGPU_MATF_NO_VNDF;
-			if ((mm.flags & PRGPU_MATF_ANISOTROPIC) && (mm.flags & PRGPU_MATF_NO_VNDF))
-				fail(PRGPU_EUNSUPPORTED, where(g) + ": anisotropic roughness with :vndf false is not supported");
 		};
 		const bool rough_glass = type == "roughglass" || type == "roughdielectric" || type == "rough_glass" || type == "rough_dielectric";
 		const bool rough_metal = type == "roughconductor" || type == "roughmirror" || type == "roughmetal";
@@ -630,8 +713,8 @@ struct Loader {
 			m.principled[PRGPU_PRINCIPLED_CLEARCOAT_GLOSS]		= scalar({ "clearcoat_gloss" }, 0.0f);
 			if (g.get("specular_transmission") || g.get("spec_trans") || g.get("diffuse_transmission") || g.get("diff_trans")) // :657-666
 				m.flags |= PRGPU_MATF_HAS_TRANSMISSION;
-			if (!get_bool(g, "vndf", true))
-				fail(PRGPU_EUNSUPPORTED, where(g) + ": principled with :vndf false is not supported (anisotropic closure)");
+			if (!get_bool(g, "vndf", true)) // PrincipledMaterialPlugin::create (principled.cpp:677-685)
+				m.flags |= PRGPU_MATF_NO_VNDF;
 		} else if (type == "mirror" || type == "reflection") { // mirror.cpp:79-100
 			m.kind		   = PRGPU_MAT_MIRROR;
 			m.albedo	   = spectral_param(g, { "specularity" }, 1.0f);

@@ -174,6 +174,42 @@ void spectral_range(const prgpu_scene_desc* d, uint32_t id, float& start, float&
 	}
 }
 
+// SkyModel::radiance + SkyLight::radiance on the host (SkyModel.h:18-23, sky.cpp:161-176); same arithmetic as the device functions
+float sky_cell(const prgpu_scene_desc* d, const prgpu_light& l, int band, float elevation, float azimuth)
+{
+	const float AZ = 3.14159265358979323846f * 2, EL = 3.14159265358979323846f * 0.5f;
+	const int az_in = std::max(0, std::min<int>((int)l.azimuth_count - 1, int(azimuth / AZ * l.azimuth_count)));
+	const int el_in = std::max(0, std::min<int>((int)l.elevation_count - 1, int(elevation / EL * l.elevation_count)));
+	return d->spectral_tables[l.table_offset + (size_t)el_in * l.azimuth_count * PRGPU_SKY_BANDS + (size_t)az_in * PRGPU_SKY_BANDS + band];
+}
+V4 sky_radiance(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl, float elevation, float azimuth)
+{
+	V4 out;
+	for (int i = 0; i < 4; ++i) {
+		const float af	= std::max(0.0f, (wl.v[i] - 320.0f) / 40.0f);
+		const int index = (int)std::min<float>(PRGPU_SKY_BANDS - 2, af);
+		const float t	= std::min<float>(PRGPU_SKY_BANDS - 1, af) - index;
+		out.v[i]		= sky_cell(d, l, index, elevation, azimuth) * (1 - t) + sky_cell(d, l, index + 1, elevation, azimuth) * t;
+	}
+	return out;
+}
+// IInfiniteLight::power: environment / distant average their node (environment.cpp, distant.cpp:93), the sky returns its zenith
+// radiance (sky.cpp:113: ElevationAzimuth::fromDirection((0, 0, 1)) = {pi/2, 0}), the sun looks its spectrum up (sun.cpp:106-112,222-228)
+V4 inf_light_power(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl)
+{
+	if (l.kind == PRGPU_LIGHT_SKY)
+		return sky_radiance(d, l, wl, 0.5f * 3.14159265358979323846f - 0.0f, 0.0f);
+	if (l.kind == PRGPU_LIGHT_SUN || (l.kind == PRGPU_LIGHT_DISTANT && (l.flags & PRGPU_LIGHTF_SUN_DELTA)))
+		return eval_spectrum(d, l.radiance, wl);
+	return average_power(d, l.radiance, wl);
+}
+void inf_light_range(const prgpu_scene_desc* d, const prgpu_light& l, float& start, float& end) // IInfiniteLight::spectralRange
+{
+	start = end = -1.0f; // SkyLight: SpectralRange() (sky.cpp:114)
+	if (l.kind != PRGPU_LIGHT_SKY)
+		spectral_range(d, l.radiance, start, end);
+}
+
 void make_cdf(const std::vector<float>& values, std::vector<float>& cdf, float* total) // Distribution1D::generate
 {
 	const size_t n = values.size();
@@ -396,7 +432,7 @@ void light_tables(const prgpu_scene_desc* d, HostTables& t)
 	const float scene_area = 2 * 3.14159265358979323846f * t.scene_radius;
 	for (uint32_t i = 0; i < d->n_lights; ++i) {
 		float rs, re;
-		spectral_range(d, d->lights[i].radiance, rs, re);
+		inf_light_range(d, d->lights[i], rs, re);
 		if (rs < 0)
 			rs = d->settings.spectral_start;
 		if (re < 0)
@@ -404,7 +440,7 @@ void light_tables(const prgpu_scene_desc* d, HostTables& t)
 		V4 wl;
 		for (int k = 0; k < 4; ++k)
 			wl.v[k] = rs + (re - rs) * probe[k];
-		const V4 pw		 = average_power(d, d->lights[i].radiance, wl);
+		const V4 pw		 = inf_light_power(d, d->lights[i], wl);
 		const float mean = (((pw.v[0] + pw.v[1]) + pw.v[2]) + pw.v[3]) / 4.0f;
 		t.light_intensity.push_back(scene_area * mean);
 	}
@@ -465,7 +501,6 @@ void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 		L.kind				   = src.kind;
 		L.radiance			   = src.radiance;
 		L.background		   = src.background;
-		L.pad				   = 0;
 		{ // (M^-1)^T = cofactor / det, same expression as entity_tables
 			const float* m = src.transform;
 			const float a = m[0], b = m[1], c = m[2], dd = m[4], ee = m[5], f = m[6], g = m[8], h = m[9], i2 = m[10];
@@ -491,6 +526,71 @@ void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 		const float len = std::sqrt((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]);
 		for (int r = 0; r < 3; ++r)
 			L.outgoing[r] = o[r] / len;
+		L.flags = src.flags;
+		for (int r = 0; r < 3; ++r)
+			L.dx[r] = L.dy[r] = 0.0f;
+		L.cos_theta = L.cone_pdf = 0.0f;
+		L.table_offset = L.az_count = L.el_count = L.dist_offset = L.dist_w = L.dist_h = 0;
+		if (src.kind == PRGPU_LIGHT_SUN) { // SunLight ctor (sun.cpp:31-46): Tangent::frame(mDirection), uniform_cone_pdf
+			const float* N	 = L.outgoing;
+			const float sign = std::copysign(1.0f, N[2]); // frame_duff (Tangent.h:50-58), then normalised
+			const float a	 = -1.0f / (sign + N[2]);
+			const float b	 = N[0] * N[1] * a;
+			float nx[3] = { 1.0f + sign * N[0] * N[0] * a, sign * b, -sign * N[0] }, ny[3] = { b, sign + N[1] * N[1] * a, -N[1] };
+			const float lx = std::sqrt((nx[0] * nx[0] + nx[1] * nx[1]) + nx[2] * nx[2]), ly = std::sqrt((ny[0] * ny[0] + ny[1] * ny[1]) + ny[2] * ny[2]);
+			for (int r = 0; r < 3; ++r) {
+				L.dx[r] = nx[r] / lx;
+				L.dy[r] = ny[r] / ly;
+			}
+			L.cos_theta = src.cos_theta;
+			L.cone_pdf	= 0.15915494309189533577f / (1 - src.cos_theta); // Sampling::uniform_cone_pdf (Sampling.h:110-114)
+		}
+		if (src.kind == PRGPU_LIGHT_SKY) { // SkyLight::buildDistribution (sky.cpp:127-159)
+			const bool extend = (src.flags & PRGPU_SKYF_EXTEND) != 0;
+			const uint32_t W = src.azimuth_count, H = extend ? 2 * src.elevation_count : src.elevation_count;
+			L.table_offset = src.table_offset;
+			L.az_count	   = src.azimuth_count;
+			L.el_count	   = src.elevation_count;
+			L.dist_offset  = (uint32_t)t.sky_cdf.size();
+			L.dist_w	   = W;
+			L.dist_h	   = H;
+			const float AZ = 3.14159265358979323846f * 2, EL = 3.14159265358979323846f * 0.5f;
+			const V4 probe{ { 560.0f, 540.0f, 400.0f, 600.0f } }; // "Preset of wavelengths to test"
+			std::vector<std::vector<float>> cond(H);
+			std::vector<float> integrals(H, 0.0f), row(W), marginal;
+			for (uint32_t y = 0; y < H; ++y) {
+				const float elevation = extend ? (2 * EL) * (y / (float)(2 * src.elevation_count) - 0.5f) : EL * y / (float)src.elevation_count;
+				const float f		  = std::cos(elevation);
+				for (uint32_t x = 0; x < W; ++x) {
+					const float azimuth = AZ * x / (float)src.azimuth_count;
+					const V4 r			= sky_radiance(d, src, probe, elevation, azimuth);
+					const float val		= std::max(0.0f, f * std::max(std::max(r.v[0], r.v[1]), std::max(r.v[2], r.v[3])));
+					row[x]				= (extend && elevation < 0.0f) ? val * 0.001f /* GROUND_PENALTY */ : val;
+				}
+				make_cdf(row, cond[y], &integrals[y]);
+			}
+			if (src.flags & PRGPU_SKYF_COMPENSATION) { // Distribution2D::applyCompensation (Distribution2D.cpp:38-76)
+				std::vector<float> avgs(H, 0.0f);
+				for (uint32_t y = 0; y < H; ++y) {
+					for (uint32_t x = 0; x < W; ++x)
+						avgs[y] += cond[y][x + 1] - cond[y][x];
+					avgs[y] /= W;
+				}
+				float single_avg = 0;
+				for (float f : avgs)
+					single_avg += f;
+				single_avg /= H;
+				for (uint32_t y = 0; y < H; ++y) { // Distribution1D::reducePDFBy (Distribution1D.inl:37-51)
+					for (uint32_t x = 0; x < W; ++x)
+						row[x] = std::max(0.0f, (cond[y][x + 1] - cond[y][x]) - single_avg);
+					make_cdf(row, cond[y], &integrals[y]);
+				}
+			}
+			make_cdf(integrals, marginal, nullptr);
+			t.sky_cdf.insert(t.sky_cdf.end(), marginal.begin(), marginal.end());
+			for (uint32_t y = 0; y < H; ++y)
+				t.sky_cdf.insert(t.sky_cdf.end(), cond[y].begin(), cond[y].end());
+		}
 	}
 }
 
@@ -536,7 +636,7 @@ void wavelength_table(const prgpu_scene_desc* d, HostTables& t, size_t n_lights)
 	auto wavelength_of = [&](uint32_t bin) { return start + (bin / float(bins - 1)) * span; };
 	std::vector<float> total(bins, 0.0f), one(bins, 0.0f);
 	for (size_t l = 0; l < n_lights + d->n_lights; ++l) { // area lights, then infinite lights (Light::averagePower)
-		const uint32_t node = l < n_lights ? d->emissions[d->entities[t.light_entity[l]].emission].radiance : d->lights[l - n_lights].radiance;
+		const uint32_t node = l < n_lights ? d->emissions[d->entities[t.light_entity[l]].emission].radiance : 0u;
 		for (uint32_t i = 0; i < bins; i += 4) {
 			const uint32_t k = std::min<uint32_t>(bins - i, 4);
 			V4 wl{ { 0, 0, 0, 0 } };
@@ -544,7 +644,7 @@ void wavelength_table(const prgpu_scene_desc* d, HostTables& t, size_t n_lights)
 				wl.v[j] = wavelength_of(i + j);
 			for (uint32_t j = k; j < 4; ++j)
 				wl.v[j] = wl.v[0];
-			const V4 p = average_power(d, node, wl);
+			const V4 p = l < n_lights ? average_power(d, node, wl) : inf_light_power(d, d->lights[l - n_lights], wl);
 			for (uint32_t j = 0; j < k; ++j)
 				one[i + j] = p.v[j];
 		}
@@ -776,8 +876,6 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		if (m.kind == PRGPU_MAT_PRINCIPLED) {
 			if (m.ior >= d->n_spectra)
 				return bad("principled index spectrum out of range");
-			if (m.flags & PRGPU_MATF_NO_VNDF)
-				return bad("the principled closure is anisotropic: sampling without vndf is not supported", PRGPU_EUNSUPPORTED);
 			for (int k = 0; k < PRGPU_PRINCIPLED_COUNT; ++k)
 				if (!std::isfinite(m.principled[k]))
 					return bad("principled parameters must be finite");
@@ -788,8 +886,6 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 			const bool aniso = (m.flags & PRGPU_MATF_ANISOTROPIC) != 0;
 			if (!(m.roughness_x >= 0.0f) || !std::isfinite(m.roughness_x) || !std::isfinite(m.roughness_y) || (aniso && !(m.roughness_y >= 0.0f)))
 				return bad("roughness must be finite and non-negative");
-			if (aniso && (m.flags & PRGPU_MATF_NO_VNDF))
-				return bad("anisotropic roughness without vndf sampling is not supported", PRGPU_EUNSUPPORTED);
 		}
 	}
 	{
@@ -798,7 +894,7 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 			if (textured(d->emissions[i].radiance))
 				return bad("textured emissions are not supported", PRGPU_EUNSUPPORTED);
 		for (uint32_t i = 0; i < d->n_lights; ++i)
-			if (d->lights && (textured(d->lights[i].radiance) || textured(d->lights[i].background)))
+			if (d->lights && d->lights[i].kind != PRGPU_LIGHT_SKY && (textured(d->lights[i].radiance) || textured(d->lights[i].background)))
 				return bad("textured infinite lights are not supported", PRGPU_EUNSUPPORTED);
 		for (uint32_t e = 0; e < d->n_entities; ++e) {
 			const prgpu_entity& E = d->entities[e];
@@ -817,10 +913,29 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		return bad("n_lights without a lights array");
 	for (uint32_t i = 0; i < d->n_lights; ++i) {
 		const prgpu_light& l = d->lights[i];
-		if (l.kind > PRGPU_LIGHT_DISTANT)
+		if (l.kind > PRGPU_LIGHT_SUN)
 			return bad("unknown infinite light kind");
+		if (l.kind == PRGPU_LIGHT_SKY) {
+			if (l.azimuth_count == 0 || l.elevation_count == 0 || l.azimuth_count > 8192 || l.elevation_count > 8192)
+				return bad("sky light: table resolution must be 1..8192 per axis");
+			const uint64_t need = uint64_t(l.azimuth_count) * l.elevation_count * PRGPU_SKY_BANDS;
+			if (!d->spectral_tables || uint64_t(l.table_offset) + need > d->n_spectral_table_values)
+				return bad("sky light: table outside spectral_tables");
+			for (uint64_t k = 0; k < need; ++k)
+				if (!(d->spectral_tables[l.table_offset + k] >= 0.0f) || !std::isfinite(d->spectral_tables[l.table_offset + k]))
+					return bad("sky light: table values must be finite and non-negative (SkyModel.cpp:52 clamps at 0)");
+			continue;
+		}
 		if (l.radiance >= d->n_spectra || (l.background != PRGPU_INVALID_ID && l.background >= d->n_spectra))
 			return bad("infinite light spectrum index out of range");
+		if (l.kind == PRGPU_LIGHT_SUN) {
+			if (d->spectra[l.radiance].kind != PRGPU_SPEC_TABLE)
+				return bad("sun light: radiance must be a TABLE node (the 64 samples of 360-760 nm, sun.cpp:21-23)");
+			if (!(l.cos_theta >= 0.0f && l.cos_theta < 1.0f))
+				return bad("sun light: cos_theta must be in [0, 1) (radius > 0; a zero radius is the DISTANT kind)");
+			if (!((l.direction[0] != 0) || (l.direction[1] != 0) || (l.direction[2] != 0)))
+				return bad("sun light with a zero direction");
+		}
 		if (l.kind == PRGPU_LIGHT_DISTANT && !((l.direction[0] != 0) || (l.direction[1] != 0) || (l.direction[2] != 0)))
 			return bad("distant light with a zero direction");
 	}

@@ -20,6 +20,7 @@ struct HostTables {
 	std::vector<uint32_t> light_entity;
 	std::vector<float> light_cdf, light_intensity;
 	std::vector<prd::DevInfLight> inf_lights;
+	std::vector<float> sky_cdf; // Distribution2D tables of the SKY lights (DevInfLight::dist_offset)
 	std::vector<prd::DevShapeLight> shape_lights; // per entity; empty when no plane / sphere emits
 	float scene_radius = 0.0f;
 	std::vector<float> wl_cdf;

@@ -272,6 +272,9 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 			il.resize(1); // never read
 		UP(sc.inf_lights, il);
 	}
+	sc.sky_cdf = nullptr;
+	if (!t.sky_cdf.empty())
+		UP(sc.sky_cdf, t.sky_cdf);
 	UP(sc.wl_cdf, t.wl_cdf);
 	UP(sc.sobol2d, t.sobol2d);
 	UP(sc.rr_prob, t.rr_prob);

@@ -244,6 +244,36 @@ class SceneBuilder:
         """(light :type 'distant' :direction d :irradiance e), distant.cpp:112-121"""
         return self._light(abi.LIGHT_DISTANT, irradiance, None, direction, transform)
 
+    SUN_VIS_RADIUS = np.float32(np.float32(np.pi) / np.float32(180.0)) * np.float32(0.5358) * np.float32(0.5)  # sun.cpp:24
+
+    @staticmethod
+    def ea_to_direction(elevation, azimuth):
+        """ElevationAzimuth::toDirection (ElevationAzimuth.h:32-35): Spherical::cartesian(pi/2 - elevation, azimuth), up is +z"""
+        theta = 0.5 * np.pi - elevation
+        return (np.sin(theta) * np.cos(azimuth), np.sin(theta) * np.sin(azimuth), np.cos(theta))
+
+    def sky_light(self, table, extend=True, compensation=False, transform=IDENTITY):
+        """(light :type 'sky'), sky.cpp:180-198.  `table`: float32 [elevation_count, azimuth_count, 11] = SkyModel::mData (the
+        Hosek-Wilkie evaluation stays with the host, SkyModel.cpp:17-60)."""
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        assert table.ndim == 3 and table.shape[2] == abi.SKY_BANDS
+        k = self._light(abi.LIGHT_SKY, abi.INVALID_ID, None, (0, 0, 1), transform)
+        l = self.lights[k]
+        l.flags = (abi.SKYF_EXTEND if extend else 0) | (abi.SKYF_COMPENSATION if compensation else 0)
+        l.table_offset = len(self.tables)
+        l.elevation_count, l.azimuth_count = table.shape[0], table.shape[1]
+        self.tables.extend(table.reshape(-1).tolist())
+        return k
+
+    def sun_light(self, radiance_64, elevation, azimuth, radius=1.0, transform=IDENTITY):
+        """(light :type 'sun' :radius r > 0), sun.cpp:26-137.  `radiance_64`: the 64 samples of 360..760 nm, i.e. computeSunRadiance *
+        power_scale / radius^2 (sun.cpp:42-46; the Preetham tables stay with the host)."""
+        assert len(radiance_64) == 64 and radius > 1.1920929e-7
+        node = self.spectrum_table(360.0, 760.0, radiance_64)
+        k = self._light(abi.LIGHT_SUN, node, None, self.ea_to_direction(elevation, azimuth), transform)
+        self.lights[k].cos_theta = float(np.cos(np.float32(self.SUN_VIS_RADIUS * np.float32(radius))))
+        return k
+
     def add_plane(self, material, x_axis=(1, 0, 0), y_axis=(0, 1, 0), width=1.0, height=1.0, centering=False, transform=IDENTITY, emission=None):
         """(entity :type 'plane'), plane.cpp:241-258: parallelogram spanned by width * x_axis and height * y_axis"""
         x = np.float32(width) * np.asarray(x_axis, dtype=np.float32)
@@ -340,9 +370,16 @@ class PrcScene:
     """A scene parsed from PearRay's .prc language by the backend library (prgpu_prc_*, csrc/host/prc_loader.cpp).
     Quacks like SceneData: .desc, .settings, .width, .height, .spp."""
 
-    def __init__(self, path=None, source=None, include_dir=None, width=0, height=0, spp=0, force_direct=False, seed=0):
+    def __init__(self, path=None, source=None, include_dir=None, width=0, height=0, spp=0, force_direct=False, seed=0, skies=None):
+        """skies: {light name or None: float32 [elevation, azimuth, 11]} -- the SkyModel tables of the scene's sky lights"""
         lib = abi.load()
         opt = abi.PrcOptions(width, height, spp, 1 if force_direct else 0, seed)
+        if skies:
+            self._sky_arrays = [np.ascontiguousarray(t, dtype=np.float32) for t in skies.values()]
+            self._sky_structs = (abi.PrcSky * len(skies))(*[
+                abi.PrcSky(None if name is None else name.encode(), t.ctypes.data_as(C.POINTER(C.c_float)), t.shape[1], t.shape[0])
+                for name, t in zip(skies.keys(), self._sky_arrays)])
+            opt.n_skies, opt.skies = len(skies), self._sky_structs
         h = C.c_void_p()
         if path is not None:
             rc = lib.prgpu_prc_load_file(os.fsencode(path), C.byref(opt), C.byref(h))

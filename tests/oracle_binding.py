@@ -116,6 +116,13 @@ def bind(lib):
     lib.orc_material_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _F32P, _F32P, _F32P, C.POINTER(C.c_int)]
     lib.orc_rough_sample.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _U64P, _F32P, _F32P, _F32P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.orc_set_tile_grid.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    lib.orc_atan2.restype = C.c_float
+    lib.orc_atan2.argtypes = [C.c_float, C.c_float]
+    lib.orc_ea_from_direction.argtypes = [_F32P, _F32P, _F32P]
+    lib.orc_ea_to_direction.argtypes = [C.c_float, C.c_float, _F32P]
+    lib.orc_uniform_cone.argtypes = [C.c_float, C.c_float, C.c_float, _F32P]
+    lib.orc_inf_light_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, C.c_int, _F32P, _F32P]
+    lib.orc_inf_light_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, _F32P, _F32P, _F32P, _F32P]
     return lib
 
 

@@ -554,6 +554,76 @@ def test_infinite_lights_bit_exact(lights, kw):
     assert g.statistics()["background_hits"] > 0
 
 
+def _sky_table(elc=32, azc=64, sun=(0.9, 2.0)):
+    """Synthetic stand-in for SkyModel::mData (the Hosek-Wilkie evaluation stays with the host): horizon glow + a lobe around the sun."""
+    el = np.arange(elc) / elc * (np.pi / 2)
+    az = np.arange(azc) / azc * (2 * np.pi)
+    E, A = np.meshgrid(el, az, indexing="ij")
+    cosg = np.sin(E) * np.sin(sun[0]) + np.cos(E) * np.cos(sun[0]) * np.cos(A - sun[1])
+    base = 0.3 + 0.7 * np.cos(E) ** 2 + 4.0 * np.exp(8.0 * (cosg - 1.0))
+    bands = 0.5 + 0.5 * np.sin(np.arange(abi.SKY_BANDS) * 0.7 + 3) ** 2
+    return (base[..., None] * bands[None, None, :]).astype(np.float32)
+
+
+def _sky_scene(kind, spp=6, materials="lambert", **settings):
+    """The open scene of the infinite-light tests (y up) under sky / sun lights whose frame maps the light's +z (up) onto world +y."""
+    b = scene.SceneBuilder(96, 72)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+    T = np.array([[1, 0, 0, 0], [0, 0.8, 0.6, 2.2], [0, -0.6, 0.8, 3.0], [0, 0, 0, 1]], dtype=np.float32)
+    b.set_camera(T, width=0.9, height=0.675, near=0.01, far=100.0, local_direction=(0, 0, -1), local_up=(0, 1, 0), local_right=(1, 0, 0))
+    white = b.lambert(b.refl(0.7, 0.7, 0.7))
+    if materials == "c5":   # the material classes of examples/complex.prc: glass, smooth + nearly smooth conductor, principled
+        box_m = b.dielectric(b.lookup_index("bk7"))
+        box2_m = b.principled(base=b.refl(0.98, 0.17, 0.03), roughness=0.4, metallic=0.3)
+        ball_m = b.rough_conductor(0.01, eta=b.spectrum_const(0.051585), k=b.spectrum_const(3.9046))
+    else:
+        box_m, box2_m, ball_m = b.lambert(b.refl(0.2, 0.5, 0.7)), white, white
+    b.add_plane(white, x_axis=(1, 0, 0), y_axis=(0, 0, -1), width=8, height=8, centering=True)
+    cube_p = [[x, y, z] for x in (-0.5, 0.5) for y in (0, 1) for z in (-0.5, 0.5)]
+    cube_f = [[0, 1, 3, 2], [4, 6, 7, 5], [0, 4, 5, 1], [2, 3, 7, 6], [0, 2, 6, 4], [1, 5, 7, 3]]
+    b.add_mesh(cube_p, cube_f, box_m, transform=np.array([[0.8, 0, 0.6, -0.7], [0, 1.2, 0, 0], [-0.6, 0, 0.8, 0], [0, 0, 0, 1]], dtype=np.float32))
+    b.add_mesh(cube_p, cube_f, box2_m, transform=np.array([[0.6, 0, 0, 0.9], [0, 0.6, 0, 0], [0, 0, 0.6, 0.6], [0, 0, 0, 1]], dtype=np.float32))
+    if materials == "c5":
+        S = np.eye(4, dtype=np.float32); S[:3, 3] = [0.1, 0.4, 1.2]
+        b.add_sphere(ball_m, radius=0.4, transform=S)
+    up_y = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=np.float32)   # light +z -> world +y
+    sun_spectrum = (2.0e4 * (0.6 + 0.4 * np.sin(np.arange(64) * 0.11))).astype(np.float32)
+    if "sky" in kind:
+        b.sky_light(_sky_table(), extend="noext" not in kind, compensation="comp" in kind, transform=up_y)
+    if "sun" in kind:
+        b.sun_light(sun_spectrum / 16.0, 0.9, 2.0, radius=4.0, transform=up_y)
+    if "lamp" in kind:
+        b.add_mesh([[-0.4, 2.5, -0.4], [0.4, 2.5, -0.4], [0.4, 2.5, 0.4], [-0.4, 2.5, 0.4]], [[0, 3, 2, 1]], white, emission=b.diffuse_emission(b.illum(9, 9, 8)))
+    return b.build()
+
+
+@pytest.mark.parametrize("kind,kw", [("sky", {}), ("sky_noext", {}), ("sky_comp", {}), ("sun", {}), ("sky+sun", {}), ("sky+sun+lamp", dict(mis=abi.MIS_POWER)),
+                                     ("sky+sun", dict(nee=0)), ("sky+sun", dict(spectral_hero=0)), ("sky", dict(mapper=abi.MAPPER_RANDOM))])
+def test_sky_and_sun_lights_bit_exact(kind, kw):
+    """sky.cpp (table lookup, Distribution2D sampling with the 1 / (2 pi^2 cos el) Jacobian, extended / compensated variants) and
+    sun.cpp (uniform cone): NEE, background hits of camera and bounce rays with MIS -- identical to the checker."""
+    g, o = render_both(_sky_scene(kind, **kw))
+    assert_parity(g, o, exact=True)
+    st = g.statistics()
+    assert st["background_hits"] > 0 and st["shadow_rays"] > 0 or kw.get("nee") == 0
+
+
+def test_c5_class_scene_sky_sun_principled_glass_spheres_in_every_pipeline(monkeypatch):
+    """The ingredients of BASELINE config C5 (examples/complex.prc): sky + sun, glass (Sellmeier), nearly smooth rough conductor,
+    principled, a sphere entity, sobol, Mitchell r = 0 -- bit-exact in all three pipelines."""
+    sc = _sky_scene("sky+sun", materials="c5", spp=5, filter=abi.FILTER_MITCHELL, filter_radius=0)
+    g, o = render_both(sc)
+    assert_parity(g, o, exact=True)
+    ref = _render_mode(monkeypatch, "lockstep", sc, [5])
+    for mode in ("streaming", "persistent"):
+        out = _render_mode(monkeypatch, mode, sc, [5])
+        for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+            assert np.array_equal(a, b), mode
+        assert ref[2] == out[2], mode
+
+
 def test_infinite_lights_with_glass_and_in_every_pipeline(monkeypatch):
     sc = _open_scene(("env_split_rot", "sun"), glass=True)
     g, o = render_both(sc)

@@ -166,12 +166,6 @@ def test_cornell_with_rough_boxes_renders():
 
 def test_validation():
     b = scene.SceneBuilder(8, 8)
-    m = b.rough_conductor(0.2, roughness_y=0.4, vndf=False)
-    b.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]], m)
-    sc = b.build()
-    assert not ob.load().orc_scene_create(C.byref(sc.desc))
-    assert b"anisotropic" in ob.load().orc_last_error()
-    b = scene.SceneBuilder(8, 8)
     m = b.rough_dielectric(-0.1)
     b.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]], m)
     sc = b.build()
@@ -195,8 +189,37 @@ def test_loader_material_names():
         m = s.desc.materials[0]
         assert (m.kind, m.flags) == (kind, flags), text
         assert m.roughness_x == np.float32(rx) and m.roughness_y == np.float32(ry)
-    with pytest.raises(RuntimeError, match="vndf"):
-        scene.PrcScene(source=body % ":type 'roughmetal' :roughness_x 0.1 :roughness_y 0.2 :vndf false")
+    s = scene.PrcScene(source=body % ":type 'roughmetal' :roughness_x 0.1 :roughness_y 0.2 :vndf false")
+    assert s.desc.materials[0].flags == abi.MATF_ANISOTROPIC | abi.MATF_NO_VNDF
+
+
+def test_anisotropic_sampling_without_vndf_follows_its_pdf():
+    """Microfacet::sample_ndf_ggx(u0, u1, rx, ry) (Microfacet.h:238-256), reached by RoughDistribution<true, false> -- rough materials
+    with two roughnesses and principled materials with `:vndf false` (examples/complex.prc).  The half vectors it draws are
+    distributed like pdf_ggx = D(H) |cos|: a histogram over the azimuth must follow the anisotropy (more spread along the rougher axis)."""
+    b = scene.SceneBuilder(8, 8)
+    m = b.rough_conductor(0.15, roughness_y=0.45, vndf=False)
+    b.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]], m)
+    o = ob.OracleScene(b.build())
+    wl = ob.f32(500, 550, 600, 650)
+    V = np.array([0.0, 0.0, 1.0], dtype=np.float32)   # normal incidence: L = reflect(V, H), so H = normalize(V + L)
+    rng = C.c_uint64(12345)
+    hx, hy = [], []
+    for _ in range(4000):
+        L, w, pdf = (C.c_float * 3)(), (C.c_float * 4)(), (C.c_float * 4)()
+        delta, hero = C.c_int(), C.c_int()
+        o.lib.orc_rough_sample(o.h, 0, wl, ob.f32(*V), C.byref(rng), L, w, pdf, C.byref(delta), C.byref(hero))
+        Lv = np.array(L[:])
+        if not Lv.any():
+            continue
+        H = (V + Lv) / np.linalg.norm(V + Lv)
+        hx.append(H[0]); hy.append(H[1])
+    hx, hy = np.array(hx), np.array(hy)
+    assert len(hx) > 3500
+    # slopes of GGX half vectors scale with the roughness of their axis: E|h_y| / E|h_x| ~ ry / rx = 3
+    ratio = np.median(np.abs(hy)) / np.median(np.abs(hx))
+    assert 2.3 < ratio < 3.9, ratio
+    assert abs(np.mean(hx)) < 0.02 and abs(np.mean(hy)) < 0.04   # symmetric in every quadrant (the floor(2 u0 + 0.5) branch)
 
 
 # ---- principled (principled.cpp) ----------------------------------------------------------------------------------------

@@ -121,8 +121,8 @@ def test_defaults_follow_the_reference():
     ("(entity :name 's' :type 'sphere' :emission 'nope')", -1, "unknown emission"),
     ("(material :name 'g' :type 'glass' :roughness 'tex')", -4, "must be a number"),
     ("(material :name 'g' :type 'ward')", -4, "material type 'ward'"),
-    ("(material :name 'g' :type 'metal' :roughness_x 0.1 :roughness_y 0.2 :vndf false)", -4, "vndf"),
-    ("(light :name 'sky' :type 'sky')", -4, "light type 'sky'"),
+    ("(light :name 'sky' :type 'sky')", -4, "needs the table"),
+    ("(light :name 'l' :type 'spot')", -4, "light type 'spot'"),
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
     ("(sampler :type 'blue_noise')", -4, "sampler type 'blue_noise'"),
     ("(filter :type 'box3')", -1, "unknown filter type 'box3'"),
@@ -205,7 +205,8 @@ def test_every_reference_example_either_loads_or_names_what_is_missing():
             lib.prgpu_prc_free(h)
         else:
             assert rc == -4, (name, rc, lib.prgpu_prc_last_error())   # valid DataLisp, unsupported feature -- never a syntax error
-            assert "not supported" in lib.prgpu_prc_last_error().decode() or "not available" in lib.prgpu_prc_last_error().decode(), name
+            msg = lib.prgpu_prc_last_error().decode()
+            assert "not supported" in msg or "not available" in msg or "needs the table" in msg, name
             refused.append(name)
     assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and len(loaded) >= 12
 
@@ -291,3 +292,82 @@ def test_infinite_lights_match_scene_builder():
     assert_same_desc(s.desc, want.desc)
     rot = np.array(list(s.desc.lights[0].transform), dtype=np.float32).reshape(4, 4)
     assert np.allclose(rot[:3, :3], [[1, 0, 0], [0, 0, -1], [0, 1, 0]], atol=1e-6)
+
+
+def test_sun_and_sky_lights_match_scene_builder():
+    """(light :type 'sun') is tabulated by the loader (Preetham model, sun.cpp:42-46), (light :type 'sky') takes the host's table."""
+    lib = abi.load()
+    src = MINIMAL % ("(light :name 'sun' :type 'sun' :turbidity 2.5 :radius 4 :elevation 0.9 :azimuth 2.0 :power_scale 0.5)"
+                     "(light :name 'sky' :type 'sky' :elevation_resolution 4 :azimuth_resolution 8 :extend false :rotation (euler 90 0 0))"
+                     "(light :name 'dot' :type 'sun' :radius 0 :theta 0.4 :phi -1.0)")
+    table = np.arange(4 * 8 * 11, dtype=np.float32).reshape(4, 8, 11) / 100
+    with pytest.raises(abi.PrgpuError, match="needs the table"):
+        scene.PrcScene(source=src)
+    with pytest.raises(abi.PrgpuError, match="8 x 4"):
+        scene.PrcScene(source=src, skies={"sky": np.zeros((5, 8, 11), np.float32)})
+    s = scene.PrcScene(source=src, skies={"other": np.zeros((4, 8, 11), np.float32), "sky": table})
+    b = scene.SceneBuilder(8, 8)
+    b.set_camera(scene.IDENTITY, near=1e-6, local_direction=(0, 1, 0), local_up=(0, 0, 1), local_right=(1, 0, 0))
+    m = b.lambert(b.spectrum_const(1.0))
+    theta = np.float32(0.5) * np.float32(np.pi) - np.float32(0.9)
+    sun = [lib.prgpu_sun_radiance(360.0 + i * ((760.0 - 360.0) / 63), float(theta), 2.5) for i in range(64)]
+    b.sun_light((np.array(sun, np.float32) * np.float32(np.float32(0.5) / np.float32(16.0))).tolist(), 0.9, 2.0, radius=4.0)
+    b.sky_light(table, extend=False, transform=np.array(list(s.desc.lights[1].transform), dtype=np.float32).reshape(4, 4))
+    # radius 0: SunDeltaLight = a distant light whose irradiance is radiance * solid angle of the disc (sun.cpp:164-170)
+    theta2 = np.float32(0.4)
+    el2 = np.float32(0.5) * np.float32(np.pi) - theta2
+    theta2b = np.float32(0.5) * np.float32(np.pi) - el2
+    omega = np.float32(2) * np.float32(np.pi) * (np.float32(1) - np.cos(np.float32(np.float32(np.pi) / np.float32(180) * np.float32(0.5358) * np.float32(0.5))))
+    dot = [np.float32(lib.prgpu_sun_radiance(360.0 + i * ((760.0 - 360.0) / 63), float(theta2b), 3.0)) * omega * np.float32(1.0) for i in range(64)]
+    node = b.spectrum_table(360.0, 760.0, dot)
+    az2 = np.float32(-1.0) + np.float32(2) * np.float32(np.pi)
+    k = b.distant_light(node, direction=(np.sin(theta2b) * np.cos(az2), np.sin(theta2b) * np.sin(az2), np.cos(theta2b)))
+    b.lights[k].flags = 4   # PRGPU_LIGHTF_SUN_DELTA
+    b.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]], m)
+    want = b.build()
+    d = s.desc
+    assert d.lights[0].kind == abi.LIGHT_SUN and d.lights[1].kind == abi.LIGHT_SKY and d.lights[2].kind == abi.LIGHT_DISTANT
+    assert d.lights[1].flags == 0 and (d.lights[1].azimuth_count, d.lights[1].elevation_count) == (8, 4)
+    assert abs(d.lights[0].cos_theta - np.cos(np.deg2rad(0.5358) * 2)) < 1e-7
+    for f in ("n_spectra", "n_spectral_table_values", "n_lights"):
+        assert getattr(d, f) == getattr(want.desc, f), f
+    got_t, want_t = arr(d.spectral_tables, d.n_spectral_table_values, np.float32), arr(want.desc.spectral_tables, d.n_spectral_table_values, np.float32)
+    assert np.allclose(got_t, want_t, rtol=2e-6)   # the python side rounds products in a different order than the loader's floats
+    assert np.array_equal(got_t[64:64 + table.size], table.reshape(-1))
+    for i in range(3):
+        for f in ("kind", "radiance", "background", "flags", "table_offset", "azimuth_count", "elevation_count"):
+            assert getattr(d.lights[i], f) == getattr(want.desc.lights[i], f), (i, f)
+        assert np.allclose(list(d.lights[i].direction), list(want.desc.lights[i].direction), atol=1e-6)
+        assert abs(d.lights[i].cos_theta - want.desc.lights[i].cos_theta) < 1e-7
+    # the sun's spectrum is physically plausible: tens of thousands of W / (m^2 nm sr) at noon, redder towards the horizon
+    hi = np.array([lib.prgpu_sun_radiance(w, 0.2, 3.0) for w in (450.0, 650.0)])
+    lo = np.array([lib.prgpu_sun_radiance(w, 1.45, 3.0) for w in (450.0, 650.0)])
+    assert 1.0e4 < hi[0] < 3.5e4 and lo[0] / lo[1] < 0.5 * hi[0] / hi[1]
+
+
+def test_sun_position_defaults_to_the_reference_example_value():
+    """SunLocation.h:7-8: 'Default is Saarbruecken 2020.05.06 12:00:00 (midday) which results in Elevation: 52.87 Azimuth: 143.27'."""
+    lib = abi.load()
+    el, az = C.c_float(), C.c_float()
+    lib.prgpu_sun_position(2020, 5, 6, 12, 0, 0.0, 49.235422, 6.9965744, 2.0, C.byref(el), C.byref(az))
+    assert abs(np.rad2deg(el.value) - 52.87) < 0.05 and abs(np.rad2deg(az.value) - 143.27) < 0.05   # the comment rounds
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference checkout absent")
+def test_complex_prc_loads_with_a_host_supplied_sky_table():
+    """BASELINE config C5: examples/complex.prc needs the SkyModel table of its 'sky' light (512 x 256 cells x 11 bands)."""
+    table = np.full((256, 512, 11), 0.5, dtype=np.float32)
+    s = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "complex.prc"), skies={"sky": table})
+    d = s.desc
+    assert (d.settings.width, d.settings.height, d.settings.aa_samples, d.settings.filter_radius) == (1920, 1080, 4096, 0)
+    kinds = sorted(d.lights[i].kind for i in range(d.n_lights))
+    assert kinds == [abi.LIGHT_SKY, abi.LIGHT_SUN]
+    sun = [d.lights[i] for i in range(d.n_lights) if d.lights[i].kind == abi.LIGHT_SUN][0]
+    assert abs(sun.cos_theta - np.cos(np.deg2rad(0.5358) * 2)) < 1e-7        # :radius 4
+    el, az = C.c_float(), C.c_float()
+    abi.load().prgpu_sun_position(2020, 5, 6, 16, 0, 0.0, 49.235422, 6.9965744, 2.0, C.byref(el), C.byref(az))   # :hour 16
+    assert np.allclose(list(sun.direction), [np.cos(el.value) * np.cos(az.value), np.cos(el.value) * np.sin(az.value), np.sin(el.value)], atol=1e-6)
+    mats = sorted(d.materials[i].kind for i in range(d.n_materials))
+    assert abi.MAT_PRINCIPLED in mats and abi.MAT_DIELECTRIC in mats and abi.MAT_LAMBERT in mats
+    assert sum(d.entities[i].kind == abi.ENTITY_SPHERE for i in range(d.n_entities)) == 4 and d.n_triangles > 50000
+    assert any("output specification" in w for w in s.warnings)
