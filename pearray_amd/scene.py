@@ -402,6 +402,113 @@ class PrcScene:
     spp = SceneData.spp
 
 
+# ---- scene cache: a prgpu_scene_desc as one .npz file -----------------------------------------------------------
+
+_STRUCT_ARRAYS = (("entities", "n_entities", abi.Entity), ("materials", "n_materials", abi.Material), ("emissions", "n_emissions", abi.Emission),
+                  ("spectra", "n_spectra", abi.Spectrum), ("lights", "n_lights", abi.Light))
+
+
+def save_scene_npz(path, desc, drop_sky_tables=True):
+    """Write a scene description (from SceneBuilder or the .prc loader) as a compressed .npz.  The tables of SKY lights -- host
+    supplied, 5.8 MB each at the default resolution -- are left out by default and given again to load_scene_npz."""
+    def arr(ptr, n, dt):
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy() if n and ptr else np.zeros(0, dt)
+    out = {"positions": arr(desc.positions, 3 * desc.n_vertices, np.float32), "normals": arr(desc.normals, 3 * desc.n_vertices, np.float32),
+           "uvs": arr(desc.uvs, 2 * desc.n_vertices, np.float32), "indices": arr(desc.indices, 3 * desc.n_triangles, np.uint32),
+           "tri_material": arr(desc.tri_material, desc.n_triangles, np.uint32),
+           "camera": np.frombuffer(C.string_at(C.addressof(desc.camera), C.sizeof(abi.Camera)), dtype=np.uint8).copy(),
+           "settings": np.frombuffer(C.string_at(C.addressof(desc.settings), C.sizeof(abi.Settings)), dtype=np.uint8).copy(),
+           "api_version": np.array([desc.api_version], dtype=np.uint32)}
+    tables = arr(desc.spectral_tables, desc.n_spectral_table_values, np.float32)
+    lights = [abi.Light.from_buffer_copy(C.string_at(C.addressof(desc.lights[i]), C.sizeof(abi.Light))) for i in range(desc.n_lights)]
+    spectra = [abi.Spectrum.from_buffer_copy(C.string_at(C.addressof(desc.spectra[i]), C.sizeof(abi.Spectrum))) for i in range(desc.n_spectra)]
+    if drop_sky_tables:
+        cuts = sorted((l.table_offset, l.azimuth_count * l.elevation_count * abi.SKY_BANDS) for l in lights if l.kind == abi.LIGHT_SKY)
+        keep = np.ones(len(tables), dtype=bool)
+        for off, n in cuts:
+            keep[off:off + n] = False
+        shift = lambda off: off - sum(n for o, n in cuts if o < off)  # noqa: E731
+        for sp in spectra:
+            if sp.kind in (abi.SPEC_TABLE, abi.SPEC_SELLMEIER):
+                sp.table_offset = shift(sp.table_offset)
+        tables = tables[keep]
+    out["tables"] = tables
+    for name, count, cls in _STRUCT_ARRAYS:
+        n = getattr(desc, count)
+        src = lights if name == "lights" else (spectra if name == "spectra" else [getattr(desc, name)[i] for i in range(n)])
+        out[name] = np.frombuffer(b"".join(C.string_at(C.addressof(x), C.sizeof(cls)) for x in src), dtype=np.uint8).copy()
+    np.savez_compressed(path, **out)
+
+
+class ArrayScene:
+    """A scene description rebuilt from save_scene_npz; quacks like SceneData (.desc, .settings, .width, .height, .spp)."""
+
+    def __init__(self, path, sky_tables=None):
+        z = np.load(path)
+        assert int(z["api_version"][0]) == abi.PRGPU_API_VERSION, "scene cache written for another ABI version"
+        self.positions, self.indices, self.tri_material = z["positions"], z["indices"], z["tri_material"]
+        self.normals = z["normals"] if len(z["normals"]) else None
+        self.uvs = z["uvs"] if len(z["uvs"]) else None
+        tables = [z["tables"]]
+        self._structs = {}
+        for name, count, cls in _STRUCT_ARRAYS:
+            raw = z[name].tobytes()
+            n = len(raw) // C.sizeof(cls)
+            self._structs[name] = (cls * max(1, n)).from_buffer_copy(raw.ljust(C.sizeof(cls) * max(1, n), b"\0"))
+            self._structs[name + "_n"] = n
+        offset = len(tables[0])
+        skies = list(sky_tables or [])
+        for i in range(self._structs["lights_n"]):
+            l = self._structs["lights"][i]
+            if l.kind == abi.LIGHT_SKY:
+                t = np.ascontiguousarray(skies.pop(0), dtype=np.float32)
+                assert t.shape == (l.elevation_count, l.azimuth_count, abi.SKY_BANDS), "sky table shape %s" % (t.shape,)
+                l.table_offset = offset
+                tables.append(t.reshape(-1))
+                offset += t.size
+        self.tables = np.ascontiguousarray(np.concatenate(tables), dtype=np.float32)
+        if not len(self.tables):
+            self.tables = np.zeros(1, np.float32)
+        d = abi.SceneDesc()
+        d.api_version = abi.PRGPU_API_VERSION
+        f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        d.n_vertices = len(self.positions) // 3
+        d.positions = self.positions.ctypes.data_as(f32p)
+        d.normals = self.normals.ctypes.data_as(f32p) if self.normals is not None else None
+        d.uvs = self.uvs.ctypes.data_as(f32p) if self.uvs is not None else None
+        d.n_triangles = len(self.indices) // 3
+        d.indices = self.indices.ctypes.data_as(u32p)
+        d.tri_material = self.tri_material.ctypes.data_as(u32p)
+        for name, count, cls in _STRUCT_ARRAYS:
+            setattr(d, count, self._structs[name + "_n"])
+            setattr(d, name, self._structs[name])
+        d.n_spectral_table_values = offset
+        d.spectral_tables = self.tables.ctypes.data_as(f32p)
+        d.camera = abi.Camera.from_buffer_copy(z["camera"].tobytes())
+        d.settings = abi.Settings.from_buffer_copy(z["settings"].tobytes())
+        self.desc = d
+
+
+for _p in ("settings", "width", "height", "spp"):
+    setattr(ArrayScene, _p, getattr(SceneData, _p))
+
+
+def synthetic_sky_table(elevation_count=256, azimuth_count=512, sun_elevation=0.6, sun_azimuth=3.7, turbidity=3.0):
+    """A stand-in for SkyModel::mData where the Hosek-Wilkie evaluation is not available (tests, bench): a smooth clear-sky shaped
+    table -- horizon brightening, a circumsolar lobe, bluer towards the zenith -- in W / (m^2 nm sr)-like magnitudes.  NOT the
+    Hosek-Wilkie model; images rendered with it are not comparable with PearRay's, the code path and its cost are the same."""
+    el = (np.arange(elevation_count) / elevation_count * (np.pi / 2)).astype(np.float64)
+    az = (np.arange(azimuth_count) / azimuth_count * (2 * np.pi)).astype(np.float64)
+    E, A = np.meshgrid(el, az, indexing="ij")
+    cosg = np.clip(np.sin(E) * np.sin(sun_elevation) + np.cos(E) * np.cos(sun_elevation) * np.cos(A - sun_azimuth), -1, 1)
+    gamma = np.arccos(cosg)
+    lum = (1 + 0.6 * np.exp(-3.0 * np.sin(E))) * (0.25 + 5.0 * np.exp(-3.0 * gamma) + 0.4 * cosg ** 2) * (0.04 * turbidity + 0.03)
+    wl = 320.0 + 40.0 * np.arange(abi.SKY_BANDS)
+    blue = (550.0 / wl) ** (2.0 + 1.5 * np.sin(E)[..., None])          # Rayleigh-like tilt, stronger towards the zenith
+    band = np.exp(-0.5 * ((wl - 480.0) / 220.0) ** 2)                  # roll-off towards UV / IR
+    return (lum[..., None] * blue * band[None, None, :]).astype(np.float32)
+
+
 def load_prc(path, **overrides):
     """SceneLoader::loadFromFile for the supported part of the scene language."""
     return PrcScene(path=path, **overrides)

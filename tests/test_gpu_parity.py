@@ -624,6 +624,27 @@ def test_c5_class_scene_sky_sun_principled_glass_spheres_in_every_pipeline(monke
         assert ref[2] == out[2], mode
 
 
+def _complex_c5(width, height, spp):
+    """BASELINE config C5: the scene of examples/complex.prc (fixture written by tools/make_c5_fixture.py) with a synthetic table in
+    place of the Hosek-Wilkie sky, which stays with the host."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "complex_c5.npz")
+    sc = scene.ArrayScene(path, sky_tables=[scene.synthetic_sky_table()])
+    sc.desc.settings.width, sc.desc.settings.height, sc.desc.settings.aa_samples = width, height, spp
+    return sc
+
+
+def test_c5_complex_prc_scene_bit_exact():
+    """examples/complex.prc as shipped (sky + sun, glass with Sellmeier indices, rough conductor, two principled materials sampled
+    without VNDF, 4 spheres, 304 k triangles, sobol, Mitchell r = 0) at reduced resolution: identical to the checker."""
+    sc = _complex_c5(160, 90, 6)
+    g, o = render_both(sc, iters=6)
+    assert_parity(g, o, exact=True)
+    st = g.statistics()
+    assert st["shadow_rays"] > 0 and st["background_hits"] > 0 and st["monochrome_rays"] > 0   # sky/sun NEE, sky hits, dispersive glass
+    ent, _ = g.primaryHits()
+    assert len(np.unique(ent)) > 20
+
+
 def test_infinite_lights_with_glass_and_in_every_pipeline(monkeypatch):
     sc = _open_scene(("env_split_rot", "sun"), glass=True)
     g, o = render_both(sc)

@@ -371,3 +371,49 @@ def test_complex_prc_loads_with_a_host_supplied_sky_table():
     assert abi.MAT_PRINCIPLED in mats and abi.MAT_DIELECTRIC in mats and abi.MAT_LAMBERT in mats
     assert sum(d.entities[i].kind == abi.ENTITY_SPHERE for i in range(d.n_entities)) == 4 and d.n_triangles > 50000
     assert any("output specification" in w for w in s.warnings)
+
+
+def test_scene_cache_round_trips_a_description_and_drops_sky_tables(tmp_path):
+    table = (np.arange(4 * 8 * 11, dtype=np.float32).reshape(4, 8, 11) + 1) / 50
+    src = MINIMAL % ("(light :name 'sky' :type 'sky' :elevation_resolution 4 :azimuth_resolution 8)"
+                     "(light :name 'sun' :type 'sun' :radius 2 :elevation 0.7 :azimuth 1.0)"
+                     "(material :name 'g' :type 'glass' :index (lookup_index 'bk7'))")
+    s = scene.PrcScene(source=src, skies={"sky": table})
+    path = str(tmp_path / "cache.npz")
+    scene.save_scene_npz(path, s.desc)
+    assert os.path.getsize(path) < 20000
+    back = scene.ArrayScene(path, sky_tables=[table])
+    a, b = s.desc, back.desc
+    # tables are reordered (the sky's go last), so compare what the nodes see
+    for f in ("n_vertices", "n_triangles", "n_entities", "n_materials", "n_spectra", "n_lights", "n_spectral_table_values"):
+        assert getattr(a, f) == getattr(b, f), f
+    ta, tb = arr(a.spectral_tables, a.n_spectral_table_values, np.float32), arr(b.spectral_tables, b.n_spectral_table_values, np.float32)
+    for i in range(a.n_spectra):
+        x, y = a.spectra[i], b.spectra[i]
+        assert (x.kind, x.table_count) == (y.kind, y.table_count)
+        assert np.array_equal(ta[x.table_offset:x.table_offset + x.table_count], tb[y.table_offset:y.table_offset + y.table_count])
+    la, lb = a.lights[0], b.lights[0]
+    n = 4 * 8 * 11
+    assert np.array_equal(ta[la.table_offset:la.table_offset + n], tb[lb.table_offset:lb.table_offset + n])
+    assert struct_bytes(a.camera) == struct_bytes(b.camera) and struct_bytes(a.settings) == struct_bytes(b.settings)
+    assert np.array_equal(arr(a.positions, 9, np.float32), arr(b.positions, 9, np.float32))
+    with pytest.raises(AssertionError, match="sky table shape"):
+        scene.ArrayScene(path, sky_tables=[np.zeros((5, 8, 11), np.float32)])
+
+
+def test_c5_fixture_is_the_reference_scene():
+    """tests/golden/scenes/complex_c5.npz (tools/make_c5_fixture.py) against a fresh load of examples/complex.prc."""
+    path = os.path.join(HERE, "golden", "scenes", "complex_c5.npz")
+    table = scene.synthetic_sky_table(256, 512)
+    assert table.shape == (256, 512, 11) and np.isfinite(table).all() and table.min() >= 0
+    fx = scene.ArrayScene(path, sky_tables=[table])
+    assert (fx.desc.n_triangles, fx.desc.n_entities, fx.desc.n_materials, fx.desc.n_lights) == (304046, 68, 6, 2)
+    if not os.path.isdir(REF_EXAMPLES):
+        return
+    ref = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "complex.prc"), skies={"sky": table})
+    for f in ("n_vertices", "n_triangles", "n_entities", "n_materials", "n_spectra", "n_lights"):
+        assert getattr(fx.desc, f) == getattr(ref.desc, f), f
+    assert np.array_equal(arr(fx.desc.positions, 3 * fx.desc.n_vertices, np.float32), arr(ref.desc.positions, 3 * ref.desc.n_vertices, np.float32))
+    assert np.array_equal(arr(fx.desc.indices, 3 * fx.desc.n_triangles, np.uint32), arr(ref.desc.indices, 3 * ref.desc.n_triangles, np.uint32))
+    for i in range(fx.desc.n_materials):
+        assert struct_bytes(fx.desc.materials[i]) == struct_bytes(ref.desc.materials[i])
