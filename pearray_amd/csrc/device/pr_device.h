@@ -10,6 +10,17 @@
 
 #include "../../../include/prgpu.h"
 
+// The rough / principled closures: out of line (one shared copy, small kernels) or inlined into the shading body that uses them
+// (PR_INLINE_CLOSURES=1: the compiler then shares the wavelength-independent terms of the four per-wavelength evaluations).
+#ifndef PR_INLINE_CLOSURES
+#define PR_INLINE_CLOSURES 0
+#endif
+#if PR_INLINE_CLOSURES
+#define PR_CLOSURE __forceinline__
+#else
+#define PR_CLOSURE __noinline__
+#endif
+
 namespace prd {
 
 constexpr float PR_EPS		= 1.1920928955078125e-7f; // FLT_EPSILON, config/Constants.inl:4
@@ -105,6 +116,7 @@ struct DevScene {
 	const uint32_t* indices;
 	const uint32_t* tri_material;
 	const uint32_t* tri_entity;
+	const uint8_t* tri_class; // material class of every triangle (0: no rough / principled closure, 1: rough or principled), the bin of the persistent kernel's shade queues
 	const DevEntity* entities;
 	const prgpu_material* materials;
 	const prgpu_emission* emissions;
@@ -954,7 +966,7 @@ __device__ __forceinline__ float refractive_jacobian(float eta, float cosI, floa
 	return denom2 <= PR_EPS ? 0.0f : fabsf(cosO) / denom2;
 }
 // MicrofacetReflection.h
-static __device__ __noinline__ float mf_reflection_eval(const RoughDistribution& d, V3 wIn, V3 wOut, bool conductor, float n_in_or_ior, float n_out_or_kappa) // :31-74
+static __device__ PR_CLOSURE float mf_reflection_eval(const RoughDistribution& d, V3 wIn, V3 wOut, bool conductor, float n_in_or_ior, float n_out_or_kappa) // :31-74
 {
 	if (!sv_same_hemisphere(wIn, wOut))
 		return 0.0f;
@@ -968,7 +980,7 @@ static __device__ __noinline__ float mf_reflection_eval(const RoughDistribution&
 	const float jacobian = reflective_jacobian(cosI);
 	return F * d.dg_norm(H, wIn, wOut) * jacobian;
 }
-static __device__ __noinline__ float mf_reflection_eval_plain(const RoughDistribution& d, V3 wIn, V3 wOut) // :76-90 eval() without a Fresnel term
+static __device__ PR_CLOSURE float mf_reflection_eval_plain(const RoughDistribution& d, V3 wIn, V3 wOut) // :76-90 eval() without a Fresnel term
 {
 	if (!sv_same_hemisphere(wIn, wOut))
 		return 0.0f;
@@ -979,7 +991,7 @@ static __device__ __noinline__ float mf_reflection_eval_plain(const RoughDistrib
 	const float jacobian = reflective_jacobian(cosI);
 	return d.dg_norm(H, wIn, wOut) * jacobian;
 }
-static __device__ __noinline__ float mf_reflection_pdf(const RoughDistribution& d, V3 wIn, V3 wOut) // :92-105 (H is not flipped here)
+static __device__ PR_CLOSURE float mf_reflection_pdf(const RoughDistribution& d, V3 wIn, V3 wOut) // :92-105 (H is not flipped here)
 {
 	if (!sv_same_hemisphere(wIn, wOut))
 		return 0.0f;
@@ -990,7 +1002,7 @@ static __device__ __noinline__ float mf_reflection_pdf(const RoughDistribution& 
 	const float jacobian = reflective_jacobian(cosI);
 	return jacobian * d.pdf(H, wIn);
 }
-static __device__ __noinline__ V3 mf_reflection_sample(const RoughDistribution& d, float u0, float u1, V3 wIn) // :107-120
+static __device__ PR_CLOSURE V3 mf_reflection_sample(const RoughDistribution& d, float u0, float u1, V3 wIn) // :107-120
 {
 	const V3 H = d.sample(u0, u1, wIn);
 	if (v3_is_zero(H, PR_EPS))
@@ -1016,7 +1028,7 @@ __device__ __forceinline__ bool mf_transmission_halfway(V3 wIn, V3 wOut, float i
 	eta = in_ior / out_ior;
 	return true;
 }
-static __device__ __noinline__ float mf_transmission_eval(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :34-63, camera paths (spread = 1)
+static __device__ PR_CLOSURE float mf_transmission_eval(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :34-63, camera paths (spread = 1)
 {
 	V3 H;
 	float cosI, cosO, eta;
@@ -1029,7 +1041,7 @@ static __device__ __noinline__ float mf_transmission_eval(const RoughDistributio
 	const float spread	 = 1.0f;
 	return (1 - F) * d.dg_norm(H, wIn, wOut) * jacobian * spread;
 }
-static __device__ __noinline__ float mf_transmission_pdf(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :93-118
+static __device__ PR_CLOSURE float mf_transmission_pdf(const RoughDistribution& d, V3 wIn, V3 wOut, float inner, float outer) // :93-118
 {
 	V3 H;
 	float cosI, cosO, eta;
@@ -1040,7 +1052,7 @@ static __device__ __noinline__ float mf_transmission_pdf(const RoughDistribution
 	const float jacobian = refractive_jacobian(eta, cosI, cosO);
 	return d.pdf(H, wIn) * jacobian;
 }
-static __device__ __noinline__ V3 mf_transmission_sample(const RoughDistribution& d, float u0, float u1, V3 wIn, float inner, float outer) // :120-139
+static __device__ PR_CLOSURE V3 mf_transmission_sample(const RoughDistribution& d, float u0, float u1, V3 wIn, float inner, float outer) // :120-139
 {
 	const V3 H = d.sample(u0, u1, wIn);
 	if (v3_is_zero(H, PR_EPS))

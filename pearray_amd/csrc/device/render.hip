@@ -8,9 +8,9 @@
 //
 // No MFMA: no stage is a dense contraction.  The kernels are latency/bandwidth bound on BVH-node and
 // triangle fetches (64-byte inner and 128-byte leaf records, see DESIGN.md for the bytes-per-ray model).
-// This file is compiled five times (Makefile: -DPR_TU=0..4) so that the large kernels build in parallel: translation unit 0 holds the
-// wavefront (lockstep / streaming) kernels, the ray service and the launchers; units 1..4 hold one feature-mask variant of the
-// persistent path kernel each (launch_pp_variant_1..4).  The device functions above the kernels are shared source, not shared objects.
+// This file is compiled seventeen times (Makefile: -DPR_TU=0..4, -DPR_SUB=0..3) so that the large kernels build in parallel: translation
+// unit 0 holds the wavefront (lockstep / streaming) kernels, the ray service and the launchers; units (v, s) hold ONE instantiation of the
+// persistent path kernel each (launch_pp_<v>_<s>).  The device functions above the kernels are shared source, not shared objects.
 #ifndef PR_TU
 #error "compile with -DPR_TU=0..4 (see the Makefile)"
 #endif
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 // are compiled out, which keeps their registers and spills out of the hot kernel; FEATS = FEAT_DELTA_MATERIALS adds the smooth dielectric /
 // conductor / mirror closures only (glass and metal scenes); FEAT_ALL is everything.
 // one shared out-of-line copy of the spectral node evaluation for the (cold, large) rough / principled closures
-static __device__ __noinline__ Blob spectrum_eval_cold(const DevScene& sc, uint32_t id, const Blob& wl) { return spectrum_eval(sc, id, wl); }
+static __device__ PR_CLOSURE Blob spectrum_eval_cold(const DevScene& sc, uint32_t id, const Blob& wl) { return spectrum_eval(sc, id, wl); }
 // ---- material evaluation for next event estimation: IMaterial::eval in tangent space ---------------------
 __device__ __forceinline__ RoughDistribution rough_distribution(const prgpu_material& m)
 {
@@ -1072,12 +1072,12 @@ struct Principled {
 	}
 };
 // out-of-line entry points: the closure's lobes are large, and every caller shares one copy
-static __device__ __noinline__ void principled_eval_pdf(const Principled& c, V3 V, V3 L, Blob& weight, Blob& pdf)
+static __device__ PR_CLOSURE void principled_eval_pdf(const Principled& c, V3 V, V3 L, Blob& weight, Blob& pdf)
 {
 	weight = c.eval(V, L);
 	pdf	   = c.pdf(V, L);
 }
-static __device__ __noinline__ V3 principled_sample(const Principled& c, uint64_t& rnd, V3 V) { return c.sample(rnd, V); }
+static __device__ PR_CLOSURE V3 principled_sample(const Principled& c, uint64_t& rnd, V3 V) { return c.sample(rnd, V); }
 __device__ __forceinline__ Principled principled_closure(const DevScene& s, const prgpu_material& m, const Blob& wl, const Blob& cie_y) // createClosure :475-497, ctor :63-84
 {
 	Principled p;
@@ -1102,7 +1102,7 @@ __device__ __forceinline__ Principled principled_closure(const DevScene& s, cons
 }
 // RoughConductorMaterial::eval (roughconductor.cpp:41-65), RoughDielectricMaterial::eval (roughdielectric.cpp:184-205).
 // `delta`: MaterialSampleFlag::DeltaDistribution.  Out of line: only scenes with rough materials pay for it.
-__device__ __noinline__ void rough_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
+static __device__ PR_CLOSURE void rough_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
 {
 	if (mat.kind == PRGPU_MAT_PRINCIPLED) { // PrincipledMaterial::eval (principled.cpp:499-528)
 		const Principled c = principled_closure(s, mat, wl, cie_y);
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_mat
 	pdf				= blob(dt * PR_INV_PI_F);
 }
 // RoughConductorMaterial::sample (roughconductor.cpp:83-117), RoughDielectricMaterial::sample (roughdielectric.cpp:222-254)
-__device__ __noinline__ void rough_sample(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, uint64_t& rnd, V3& Lt, Blob& integral_weight, Blob& pdf_s,
+static __device__ PR_CLOSURE void rough_sample(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, uint64_t& rnd, V3& Lt, Blob& integral_weight, Blob& pdf_s,
 										  bool& delta, bool& hero_collapsing)
 {
 	if (mat.kind == PRGPU_MAT_PRINCIPLED) { // PrincipledMaterial::sample (principled.cpp:548-590)
@@ -1861,12 +1861,16 @@ constexpr uint32_t PP_REGEN		= 0x80000000u; // shade entry: the slot's path has 
 constexpr uint32_t PP_DEAD		= 0x100u;	   // pending word: no bounce ray follows the rays in flight
 constexpr unsigned long long PP_IDLE_LIMIT_TICKS = 30ull * 100000000ull; // safety net: a wave that has seen no work for 30 s of wall clock (100 MHz ticks) gives up and flags an error
 
+// NQ shade queues, one per material class (HitStream::setup / getNextGroup, trace/HitStream.cpp:57-118, sort hits into runs of equal
+// entity so that one shading group runs one material; here vertices are binned by the CLASS of the material they hit, DevScene::
+// tri_class): a shading pass takes a wave-full from ONE queue and runs a body that contains only that class's code.
+template <int NQ>
 struct PPShared {
 	uint2 stack[STACK_LDS * TRAV_BLOCK];
 	uint32_t q_ray[2 * PP_SLOTS_MAX]; // a slot has at most two rays queued or in flight
-	uint32_t q_shade[PP_SLOTS_MAX];
+	uint32_t q_shade[NQ][PP_SLOTS_MAX];
 	uint32_t pending[PP_SLOTS_MAX];
-	uint32_t ray_head, ray_tail, shade_head, shade_tail;
+	uint32_t ray_head, ray_tail, shade_head[NQ], shade_tail[NQ];
 	uint32_t live; // slots that still own, or may still acquire, a pixel
 	uint32_t error;
 	BlockStats bs;
@@ -1941,22 +1945,29 @@ struct PersistentArgs {
 template <bool COUNT, uint32_t FEATS>
 __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathState& ps, const PersistentArgs& a)
 {
-	__shared__ PPShared sh;
+	// material classes: 0 = everything but the rough / principled closures, 1 = those (only kernels that contain them have the queue)
+	constexpr int NQ = (FEATS & FEAT_ROUGH_MATERIALS) ? 2 : 1;
+	constexpr uint32_t FEATS_PLAIN = FEATS & ~FEAT_ROUGH_MATERIALS;
+	__shared__ PPShared<NQ> sh;
 	constexpr uint32_t RAY_MASK = 2 * PP_SLOTS_MAX - 1, SHADE_MASK = PP_SLOTS_MAX - 1;
 	const uint32_t lane	 = threadIdx.x & 63u;
 	const uint32_t slot0 = blockIdx.x * a.slots_per_block;
 	for (uint32_t i = threadIdx.x; i < 2 * PP_SLOTS_MAX; i += TRAV_BLOCK)
 		sh.q_ray[i] = PP_EMPTY;
 	for (uint32_t i = threadIdx.x; i < PP_SLOTS_MAX; i += TRAV_BLOCK) {
-		sh.q_shade[i] = i < a.slots_per_block ? (i | PP_REGEN) : PP_EMPTY; // every slot starts by acquiring a pixel
+		sh.q_shade[0][i] = i < a.slots_per_block ? (i | PP_REGEN) : PP_EMPTY; // every slot starts by acquiring a pixel
+		for (int q = 1; q < NQ; ++q)
+			sh.q_shade[q][i] = PP_EMPTY;
 		sh.pending[i] = 0;
 		if (i < a.slots_per_block)
 			ps.pixel[slot0 + i] = INVALID;
 	}
 	if (threadIdx.x == 0) {
 		sh.ray_head = sh.ray_tail = 0;
-		sh.shade_head			  = 0;
-		sh.shade_tail			  = a.slots_per_block;
+		sh.shade_head[0]		  = 0;
+		sh.shade_tail[0]		  = a.slots_per_block;
+		for (int q = 1; q < NQ; ++q)
+			sh.shade_head[q] = sh.shade_tail[q] = 0;
 		sh.live					  = a.slots_per_block;
 		sh.error				  = 0;
 	}
@@ -1983,7 +1994,16 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	const uint32_t shade_full = a.shader_wave != 0u ? a.shade_help : a.shade_min;
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
-		uint32_t n_shade  = wave_bcast0(lds_load(&sh.shade_tail) - lds_load(&sh.shade_head));
+		// the fullest class queue decides: a pass shades one class
+		uint32_t n_shade = wave_bcast0(lds_load(&sh.shade_tail[0]) - lds_load(&sh.shade_head[0]));
+		int cls			 = 0;
+		for (int q = 1; q < NQ; ++q) {
+			const uint32_t nq = wave_bcast0(lds_load(&sh.shade_tail[q]) - lds_load(&sh.shade_head[q]));
+			if (nq > n_shade) {
+				n_shade = nq;
+				cls		= q;
+			}
+		}
 		uint32_t n_queued = wave_bcast0(lds_load(&sh.ray_tail) - lds_load(&sh.ray_head));
 
 		// ---- shade: a full wave of waiting vertices, or whatever is there when this wave is short of rays anyway
@@ -1996,7 +2016,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			shade_now = n_shade >= a.shade_min || (n_queued == 0u && ((n_shade >= a.shade_partial && n_act < a.partial_act) || (n_shade > 0u && n_act == 0)));
 		if (shade_now) {
 			uint32_t first;
-			const uint32_t n = ring_claim(&sh.shade_head, &sh.shade_tail, 64u, first);
+			const uint32_t n = ring_claim(&sh.shade_head[cls], &sh.shade_tail[cls], 64u, first);
 			if (n) {
 				spins			  = 0;
 				const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
@@ -2008,15 +2028,20 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				uint32_t slot_l	  = 0;
 				bool regen		  = false;
 				if (mine) {
-					const uint32_t e = ring_take(sh.q_shade, SHADE_MASK, first + lane);
+					const uint32_t e = ring_take(sh.q_shade[cls], SHADE_MASK, first + lane);
 					slot_l			 = e & ~PP_REGEN;
 					regen			 = (e & PP_REGEN) != 0;
 				}
 				const uint32_t slot = slot0 + slot_l;
 				bool alive = false, want_shadow = false;
 				float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
-				if (mine && !regen)
-					shade_vertex<FEATS>(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+				if (NQ > 1 && cls == 1) { // wave-uniform: the body with the rough / principled closures
+					if (mine && !regen)
+						shade_vertex<FEATS>(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+				} else {
+					if (mine && !regen)
+						shade_vertex<FEATS_PLAIN>(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+				}
 				// the path ended: fold the sample, then the pixel's next sample or the next pixel
 				const bool ended = mine && (regen || (!alive && !want_shadow));
 				bool need_pixel	 = false;
@@ -2165,6 +2190,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			if (__any(fin)) {
 				bool last	   = false;
 				uint32_t entry = 0;
+				int qcls	   = 0;
 				if (fin) {
 					const uint32_t slot_l = my_entry & ~PP_ANY;
 					const uint32_t slot	  = slot0 + slot_l;
@@ -2187,15 +2213,23 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					const uint32_t old = __hip_atomic_fetch_sub(&sh.pending[slot_l], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
 					last			   = (old & 0xFFu) == 1u;
 					entry			   = slot_l | ((old & PP_DEAD) ? PP_REGEN : 0u);
-					has_ray			   = false;
+					if (NQ > 1 && last && !(old & PP_DEAD)) { // class of the material the slot's path ray hit (the shadow ray may finish last)
+						const uint32_t tri = s.any ? __float_as_uint(ps.hit[slot].w) : s.best.tri;
+						qcls			   = tri == INVALID ? 0 : (int)sc.tri_class[tri];
+					}
+					has_ray = false;
 				}
-				ring_push(sh.q_shade, SHADE_MASK, &sh.shade_tail, last, entry);
+				for (int q = 0; q < NQ; ++q)
+					ring_push(sh.q_shade[q], SHADE_MASK, &sh.shade_tail[q], last && qcls == q, entry);
 			}
 			const int active = __popcll(__ballot(has_ray));
 			if (active == 0)
 				break;
 			if (active < a.refill_below) { // under-occupied: leave if there is anything to refill from or to shade
-				const uint32_t nq = lds_load(&sh.ray_tail) - lds_load(&sh.ray_head), nsh = lds_load(&sh.shade_tail) - lds_load(&sh.shade_head);
+				uint32_t nsh = lds_load(&sh.shade_tail[0]) - lds_load(&sh.shade_head[0]);
+				for (int q = 1; q < NQ; ++q)
+					nsh = max(nsh, lds_load(&sh.shade_tail[q]) - lds_load(&sh.shade_head[q]));
+				const uint32_t nq = lds_load(&sh.ray_tail) - lds_load(&sh.ray_head);
 				if (wave_bcast0(((nq > 0u && (nq >= a.refill_min || threadIdx.x < 64u)) || nsh >= shade_full || (a.shader_wave == 0u && nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
 					break;
 			}
@@ -2339,40 +2373,38 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 
 #endif // PR_TU == 0
 
-// ---- persistent path kernel: one translation unit per feature-mask variant ------------------------------------------------------
+// ---- persistent path kernel: one translation unit per kernel (feature-mask variant x {3, 2 waves per SIMD} x {plain, instrumented}) ----
 constexpr uint32_t FEAT_NO_ROUGH = FEAT_ALL & ~FEAT_ROUGH_MATERIALS;
-void launch_pp_variant_1(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st);
-void launch_pp_variant_2(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st);
-void launch_pp_variant_3(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st);
-void launch_pp_variant_4(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st);
+#define PR_PP_DECL(V, S) void launch_pp_##V##_##S(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st);
+#define PR_PP_DECL4(V) PR_PP_DECL(V, 0) PR_PP_DECL(V, 1) PR_PP_DECL(V, 2) PR_PP_DECL(V, 3)
+PR_PP_DECL4(1) PR_PP_DECL4(2) PR_PP_DECL4(3) PR_PP_DECL4(4)
 #if PR_TU >= 1
+#ifndef PR_SUB
+#error "compile the persistent-kernel units with -DPR_SUB=0..3"
+#endif
 #if PR_TU == 1
 #define PR_PP_FEATS 0u
-#define PR_PP_LAUNCHER launch_pp_variant_1
 #elif PR_TU == 2
 #define PR_PP_FEATS FEAT_DELTA_MATERIALS
-#define PR_PP_LAUNCHER launch_pp_variant_2
 #elif PR_TU == 3
 #define PR_PP_FEATS FEAT_NO_ROUGH
-#define PR_PP_LAUNCHER launch_pp_variant_3
 #else
 #define PR_PP_FEATS FEAT_ALL
-#define PR_PP_LAUNCHER launch_pp_variant_4
 #endif
-void PR_PP_LAUNCHER(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, bool count, int occupancy, hipStream_t st)
+#define PR_PP_CAT2(V, S) launch_pp_##V##_##S
+#define PR_PP_CAT(V, S) PR_PP_CAT2(V, S)
+void PR_PP_CAT(PR_TU, PR_SUB)(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st)
 {
 	const dim3 block(TRAV_BLOCK);
-	if (occupancy >= 3) {
-		if (count)
-			hipLaunchKernelGGL((k_path_persistent_occ3<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
-		else
-			hipLaunchKernelGGL((k_path_persistent_occ3<false, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
-	} else {
-		if (count)
-			hipLaunchKernelGGL((k_path_persistent<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
-		else
-			hipLaunchKernelGGL((k_path_persistent<false, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
-	}
+#if PR_SUB == 0
+	hipLaunchKernelGGL((k_path_persistent_occ3<false, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+#elif PR_SUB == 1
+	hipLaunchKernelGGL((k_path_persistent_occ3<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+#elif PR_SUB == 2
+	hipLaunchKernelGGL((k_path_persistent<false, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+#else
+	hipLaunchKernelGGL((k_path_persistent<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+#endif
 }
 #endif // PR_TU >= 1
 
@@ -2418,14 +2450,11 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	// that CONTAINS the calls runs a scene that never makes them 25 % slower (metal Cornell box: 3.18 vs 4.02 ms per iteration; leaving
 	// out spheres, AOVs + textures or infinite / shape lights + planes instead changes nothing).  A variant for delta + rough materials
 	// only was measured and dropped: the closures dominate such scenes, 156 vs 154 Msamples/s.
-	if (sc.features == 0)
-		launch_pp_variant_1(sc, ps, a, grid, count, occupancy, st);
-	else if ((sc.features & ~FEAT_DELTA_MATERIALS) == 0)
-		launch_pp_variant_2(sc, ps, a, grid, count, occupancy, st);
-	else if ((sc.features & FEAT_ROUGH_MATERIALS) == 0)
-		launch_pp_variant_3(sc, ps, a, grid, count, occupancy, st);
-	else
-		launch_pp_variant_4(sc, ps, a, grid, count, occupancy, st);
+	typedef void (*LaunchFn)(const DevScene&, const PathState&, const PersistentArgs&, dim3, hipStream_t);
+	static const LaunchFn table[4][4] = { { launch_pp_1_0, launch_pp_1_1, launch_pp_1_2, launch_pp_1_3 }, { launch_pp_2_0, launch_pp_2_1, launch_pp_2_2, launch_pp_2_3 },
+										   { launch_pp_3_0, launch_pp_3_1, launch_pp_3_2, launch_pp_3_3 }, { launch_pp_4_0, launch_pp_4_1, launch_pp_4_2, launch_pp_4_3 } };
+	const int variant = sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3));
+	table[variant][(occupancy >= 3 ? 0 : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
 }
 
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * TRAV_BLOCK * STACK_SPILL; }

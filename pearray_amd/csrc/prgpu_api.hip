@@ -259,6 +259,17 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	UP(sc.indices, d->indices, 3 * size_t(d->n_triangles));
 	UP(sc.tri_material, d->tri_material, d->n_triangles);
 	UP(sc.tri_entity, t.tri_entity);
+	{ // material class per triangle: which shading body the vertex needs
+		std::vector<uint8_t> cls(d->n_triangles, 0);
+		for (uint32_t i = 0; i < d->n_triangles; ++i) {
+			const uint32_t m = d->tri_material[i];
+			if (m != PRGPU_INVALID_ID) {
+				const uint32_t kind = d->materials[m].kind;
+				cls[i] = (kind == PRGPU_MAT_ROUGH_CONDUCTOR || kind == PRGPU_MAT_ROUGH_DIELECTRIC || kind == PRGPU_MAT_PRINCIPLED) ? 1 : 0;
+			}
+		}
+		UP(sc.tri_class, cls);
+	}
 	UP(sc.entities, t.entities);
 	UP(sc.materials, d->materials, d->n_materials);
 	UP(sc.emissions, d->emissions, d->n_emissions);
@@ -308,6 +319,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 			sc.features |= prd::FEAT_PLANES;
 		else if (d->entities[e].kind == PRGPU_ENTITY_SPHERE)
 			sc.features |= prd::FEAT_SPHERES;
+	if (const char* env = getenv("PRGPU_FORCE_FEATURES")) // measurement aid: run a scene with a larger kernel variant than it needs (same results)
+		sc.features |= (uint32_t)strtoul(env, nullptr, 0) & prd::FEAT_ALL;
 	sc.scene_radius	 = t.scene_radius;
 	sc.wl_cdf_size	 = (uint32_t)t.wl_cdf.size();
 	sc.wl_u_offset	 = t.wl_u_offset;

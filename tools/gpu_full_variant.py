@@ -15,7 +15,10 @@ def run(name, sc, iters=64):
     n = s1["pixel_samples"] - s0["pixel_samples"]
     rays = sum(s1[k] - s0[k] for k in ("primary_rays", "bounce_rays", "shadow_rays"))
     depth = (s1["camera_depth"] - s0["camera_depth"]) / max(n, 1)
-    print("%-46s %7.1f Msamples/s %7.0f Mrays/s  mean depth %.2f  %.2f ms/iteration" % (name, n / dt / 1e6, rays / dt / 1e6, depth, dt / iters * 1e3), flush=True)
+    tc0 = ctx.traceCounters(); ctx.setInstrumentation(True); ctx.render(4); ctx.waitForFinish(); ctx.setInstrumentation(False); tc1 = ctx.traceCounters()
+    d = {k: tc1[k] - tc0[k] for k in tc1 if isinstance(tc1[k], int)}
+    print("%-52s %7.1f Msamples/s %7.0f Mrays/s  mean depth %.2f  %.2f ms/iteration | shading %4.1f %% of wave time, pass fill %.2f" % (
+        name, n / dt / 1e6, rays / dt / 1e6, depth, dt / iters * 1e3, 100.0 * d["shade_ticks"] / max(d["total_ticks"], 1), d["shade_lanes"] / max(64 * d["shade_batches"], 1)), flush=True)
     ctx.close()
 
 W = H = 1024
@@ -30,3 +33,10 @@ def metal_env():
     return b.build()
 run("metal boxes + environment light (no-rough variant)", metal_env())
 run("rough conductor/dielectric boxes, vndf", scene.cornell_rough(W, H, spp=256, roughness=0.2, vndf=True))
+os.environ["PRGPU_FORCE_FEATURES"] = "255"
+run("metal boxes, ALL-FEATURES kernel forced", scene.cornell_metal(W, H, spp=256))
+run("lambert cornell, ALL-FEATURES kernel forced", scene.cornell_box(W, H, spp=256))
+del os.environ["PRGPU_FORCE_FEATURES"]
+os.environ["PRGPU_PP_OCCUPANCY"] = "2"
+run("rough boxes, 2 waves per SIMD (256 VGPRs)", scene.cornell_rough(W, H, spp=256, roughness=0.2, vndf=True))
+del os.environ["PRGPU_PP_OCCUPANCY"]
