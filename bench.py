@@ -38,12 +38,39 @@ def native_oracle():
         return None, "prebuilt -O2 generic x86-64 (no compiler on this host)"
 
 
+def host_cpu_share():
+    """Hardware threads this process may actually use: the smaller of the machine's count, the affinity mask and the cgroup CPU quota
+    (a GPU box hands a container a share of its host CPUs: os.cpu_count() alone overstates it)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()
+            if q != "max":
+                quota = float(q) / float(p)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # cgroup v1
+                q, p = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / p
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, (os.cpu_count() or 1), quota
+
+
 def cpu_baseline(scene_desc, iters=4, tile=32):
     """CPU checker ("port") on the host cores: `iters` full-frame iterations of the SAME workload, handed to the worker threads as
     `tile` x `tile`-pixel Z-order tiles so that every hardware thread has work (the reference's 8 x 8 grid feeds at most 64)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding
-    cores = os.cpu_count() or 1
+    cores, host_threads, quota = host_cpu_share()
     path, how = native_oracle()
     lib = oracle_binding.load_from(path) if path else None
     t0 = time.time()
@@ -56,7 +83,7 @@ def cpu_baseline(scene_desc, iters=4, tile=32):
     dt = time.time() - t0
     st = o.statistics()
     return {"value": round(st["pixel_samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "threads_busy": min(cores, tx * ty),
-            "kind": "port", "build": how,
+            "host_threads": host_threads, "cgroup_cpu_quota": quota, "kind": "port", "build": how,
             "sample": "%d iteration(s) of the full %dx%d frame of the same 1M-triangle scene (%d samples, %.1f s render, %.1f s SAH BVH build excluded), "
                       "%d tiles of %dx%d pixels for %d threads; CPU restatement, not Embree"
                       % (iters, scene_desc.width, scene_desc.height, st["pixel_samples"], dt, t_build, tx * ty, tile, tile, cores)}
@@ -185,16 +212,36 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The path's one collective goes through the C ABI (prgpu_comm_* / prgpu_reduce: RCCL called from libprgpu on the scene's stream);
+    # torch.distributed only launches the ranks, ships rank 0's communicator id and provides the barrier.  The one-GPU rehearsal
+    # keeps the host-staged gloo reduce (RCCL refuses two ranks on one device).
+    comm = None
+    if not args.rehearse_on_one_gpu:
+        def exchange(raw):
+            if world == 1:
+                return raw
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = backend.Communicator(world, rank, device=local, exchange=exchange)
+
+    def reduce_frame():
+        if comm is not None:
+            ctx.reduce(comm, root=0)
+            ctx.waitForFinish()
+        else:
+            distributed.reduce_framebuffer(xyz, smp)
+
+    if world > 1:  # warm the collective up while the frame is still all zeros (communicator channels, buffer registration)
+        reduce_frame()
     ctx.render(args.warmup)
     ctx.waitForFinish()
-    if world > 1:  # warm the collective up on scratch buffers of the same shape (communicator channels, registration)
-        distributed.reduce_framebuffer(torch.zeros_like(xyz), torch.zeros_like(smp))
     before = ctx.statistics()
     barrier()
     t0 = time.perf_counter()
     ctx.render(args.steps)                      # K iterations of the hot path
     ctx.waitForFinish()
-    distributed.reduce_framebuffer(xyz, smp)    # the path's one collective: RCCL sum onto rank 0 (no-op at N=1)
+    reduce_frame()                              # RCCL sum onto rank 0 (a checked no-op at N=1)
     barrier()
     dt = time.perf_counter() - t0
     after = ctx.statistics()

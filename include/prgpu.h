@@ -21,6 +21,7 @@
  *     src/core/renderer/RenderFactory.cpp:16-42
  *   FrameOutputDevice (AOV_Output XYZ + AOV_SampleCount planes)   prgpu_download / prgpu_bind_framebuffer
  *     src/loader/output/FrameOutputDevice.cpp:83-221
+ *   image tiles merged across devices (tools/pr_imagemerge.py)    prgpu_comm_* / prgpu_reduce (RCCL)
  *   RenderStatistics (11 counters)                                prgpu_stats
  *     src/core/renderer/RenderStatistics.h:9-23
  *   IArchive::traceRays / traceSingleRay / traceShadowRay         prgpu_trace_closest / prgpu_trace_any
@@ -360,6 +361,25 @@ int  prgpu_download_primary_hits(prgpu_scene* s, uint32_t* entity, uint32_t* pri
  * ("trace_closest", "trace_any", "shade", "raygen", "resolve", "sort"). Requires prgpu_set_timing(s,1). */
 int  prgpu_set_timing(prgpu_scene* s, int enabled);
 int  prgpu_kernel_time_ms(prgpu_scene* s, const char* family, double* total_ms, uint64_t* launches);
+
+/* -- multi-GPU: tile-parallel rendering + one framebuffer reduce ------------------------------------------------
+ * Replaces the reference's ways of combining image tiles: FrameOutputDevice::mergeLocal inside one process
+ * (src/loader/output/FrameOutputDevice.cpp:83-200) and `--itx/--ity` image tiles (src/core/renderer/RenderFactory.cpp:16-42) summed
+ * offline by tools/pr_imagemerge.py.  Every rank (one process or host thread per GPU) creates the SAME scene, takes its tiles with
+ * prgpu_set_tiles, renders, and calls prgpu_reduce once: RCCL over xGMI sums the XYZ and sample-count planes and ORs the feedback
+ * plane onto `root`'s framebuffer (the bound one, or the library's).  No collective runs while rendering.
+ *   rank 0:  prgpu_comm_unique_id(id);  ship the 128 bytes to the other ranks (MPI, a socket, a file -- the host's business)
+ *   all:     prgpu_comm_create(id, n_ranks, rank, device, &comm);  ...render...;  prgpu_reduce(scene, comm, 0);  prgpu_sync(scene);
+ * With n_ranks == 1 no RCCL call is made and prgpu_reduce only validates its arguments. */
+#define PRGPU_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+typedef struct prgpu_comm prgpu_comm;
+int  prgpu_comm_unique_id(uint8_t id[PRGPU_COMM_ID_BYTES]);
+int  prgpu_comm_create(const uint8_t id[PRGPU_COMM_ID_BYTES], int n_ranks, int rank, int device, prgpu_comm** out);
+void prgpu_comm_destroy(prgpu_comm* comm);
+int  prgpu_comm_size(const prgpu_comm* comm);   /* n_ranks, or PRGPU_EINVAL */
+/* Asynchronous on the scene's stream (after the render calls queued there); prgpu_sync / prgpu_download wait for it.  In place:
+ * on `root` the planes hold the sums afterwards, on the other ranks they are unchanged. */
+int  prgpu_reduce(prgpu_scene* s, prgpu_comm* comm, int root);
 
 /* -- shading-point AOVs and image files ------------------------------------------------------
  * LocalFrameOutputDevice::commitShadingPoints (src/loader/output/LocalFrameOutputDevice.cpp:252-283): every camera sample whose

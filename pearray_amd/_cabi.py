@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libprgpu.so")
 
 PRGPU_API_VERSION = 6
 INVALID_ID = 0xFFFFFFFF
+COMM_ID_BYTES = 128
 
 SPEC_CONST, SPEC_PARAMETRIC, SPEC_PARAMETRIC_SCALED, SPEC_TABLE, SPEC_MUL, SPEC_SELLMEIER, SPEC_CHECKER = range(7)
 MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_ROUGH_CONDUCTOR, MAT_ROUGH_DIELECTRIC, MAT_PRINCIPLED, MAT_MIRROR = 0, 1, 2, 3, 4, 5, 6
@@ -148,6 +149,11 @@ SYMBOLS = {
     "prgpu_download_primary_hits": (C.c_int, [_VP, _U32P, _U32P]),
     "prgpu_set_timing": (C.c_int, [_VP, C.c_int]),
     "prgpu_kernel_time_ms": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_double), _U64P]),
+    "prgpu_comm_unique_id": (C.c_int, [_U8P]),
+    "prgpu_comm_create": (C.c_int, [_U8P, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "prgpu_comm_destroy": (None, [_VP]),
+    "prgpu_comm_size": (C.c_int, [_VP]),
+    "prgpu_reduce": (C.c_int, [_VP, _VP, C.c_int]),
     "prgpu_enable_aovs": (C.c_int, [_VP, C.c_uint32]),
     "prgpu_aov_channels": (C.c_uint32, [C.c_uint32]),
     "prgpu_download_aov": (C.c_int, [_VP, C.c_uint32, _F32P]),

@@ -58,6 +58,10 @@ class RenderContext:
         abi.check(self.lib.prgpu_bind_framebuffer(self._h, C.c_void_p(xyz_ptr), C.c_void_p(samples_ptr),
                                                   C.c_void_p(feedback_ptr) if feedback_ptr else None))
 
+    def reduce(self, comm, root=0):
+        """Sum this rank's frame onto `root` (RCCL over xGMI); asynchronous on the scene's stream."""
+        abi.check(self.lib.prgpu_reduce(self._h, comm._h, int(root)))
+
     def setInstrumentation(self, on):
         abi.check(self.lib.prgpu_set_instrumentation(self._h, 1 if on else 0))
 
@@ -146,6 +150,40 @@ class RenderContext:
         abi.check(self.lib.prgpu_trace_any(self._h, n, _f32p(org), _f32p(direction), _f32p(tmin), _f32p(distance),
                                            occ.ctypes.data_as(C.POINTER(C.c_uint8))))
         return occ.astype(bool)
+
+
+class Communicator:
+    """prgpu_comm: the ranks of a tile-parallel render (one per GPU).  `exchange(bytes or None) -> bytes` ships rank 0's unique id
+    to every rank -- the host's transport (bench.py: a torch.distributed broadcast; a C++ host: MPI, a socket, a file)."""
+
+    def __init__(self, n_ranks, rank, device=0, exchange=None):
+        self.lib = abi.load()
+        self._h = C.c_void_p()
+        ident = None
+        if n_ranks > 1 or os.environ.get("PRGPU_COMM_FORCE_RCCL", "0") not in ("", "0"):
+            raw = None
+            if rank == 0:
+                buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
+                abi.check(self.lib.prgpu_comm_unique_id(buf))
+                raw = bytes(buf)
+            raw = exchange(raw) if exchange is not None else raw
+            ident = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(raw)
+        abi.check(self.lib.prgpu_comm_create(ident, int(n_ranks), int(rank), int(device), C.byref(self._h)))
+
+    @property
+    def size(self):
+        return self.lib.prgpu_comm_size(self._h)
+
+    def close(self):
+        if self._h:
+            self.lib.prgpu_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def write_exr(path, channels):

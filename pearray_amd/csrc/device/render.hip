@@ -2374,7 +2374,7 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 #endif // PR_TU == 0
 
 // ---- persistent path kernel: one translation unit per kernel (feature-mask variant x {3, 2 waves per SIMD} x {plain, instrumented}) ----
-constexpr uint32_t FEAT_NO_ROUGH = FEAT_ALL & ~FEAT_ROUGH_MATERIALS;
+[[maybe_unused]] constexpr uint32_t FEAT_NO_ROUGH = FEAT_ALL & ~FEAT_ROUGH_MATERIALS;
 #define PR_PP_DECL(V, S) void launch_pp_##V##_##S(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st);
 #define PR_PP_DECL4(V) PR_PP_DECL(V, 0) PR_PP_DECL(V, 1) PR_PP_DECL(V, 2) PR_PP_DECL(V, 3)
 PR_PP_DECL4(1) PR_PP_DECL4(2) PR_PP_DECL4(3) PR_PP_DECL4(4)

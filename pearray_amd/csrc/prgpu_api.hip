@@ -4,6 +4,7 @@
 // per-path state and the frame planes, and drives the kernels of device/render.hip on one HIP stream.
 // There is no CPU rendering path in this library: without a HIP device prgpu_scene_create fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1132,6 +1133,165 @@ int prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* d
 	TRY_OR_CLEAN(hipStreamSynchronize(s->stream));
 	TRY_OR_CLEAN(hipMemcpy(occluded, d_occ, size_t(n), hipMemcpyDeviceToHost));
 	cleanup();
+	return PRGPU_OK;
+}
+
+// ---- multi-GPU reduce over RCCL --------------------------------------------------------------------------------------------
+// RCCL is bound at run time (dlopen by soname): a host that already carries one (PyTorch bundles its own librccl.so.1) keeps using
+// that copy, and a single-GPU host never needs the library at all.
+namespace {
+typedef int nccl_result_t;
+struct NcclId {
+	char internal[PRGPU_COMM_ID_BYTES];
+};
+struct Rccl {
+	void* lib = nullptr;
+	nccl_result_t (*GetUniqueId)(NcclId*)									= nullptr;
+	nccl_result_t (*CommInitRank)(void**, int, NcclId, int)				= nullptr;
+	nccl_result_t (*CommDestroy)(void*)										= nullptr;
+	nccl_result_t (*GroupStart)()											= nullptr;
+	nccl_result_t (*GroupEnd)()												= nullptr;
+	nccl_result_t (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+	const char* (*GetErrorString)(nccl_result_t)							= nullptr;
+	std::string error;
+};
+Rccl& rccl()
+{
+	static Rccl r;
+	if (r.lib || !r.error.empty())
+		return r;
+	for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+		r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+		if (r.lib)
+			break;
+	}
+	if (!r.lib) {
+		r.error = std::string("RCCL is not available: ") + dlerror();
+		return r;
+	}
+	bool ok = true;
+	auto sym = [&](const char* n) {
+		void* p = dlsym(r.lib, n);
+		ok		= ok && p != nullptr;
+		return p;
+	};
+	r.GetUniqueId	 = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+	r.CommInitRank	 = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+	r.CommDestroy	 = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+	r.GroupStart	 = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+	r.GroupEnd		 = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+	r.Reduce		 = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
+	r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+	if (!ok) {
+		r.error = "RCCL library lacks an expected entry point";
+		r.lib	= nullptr;
+	}
+	return r;
+}
+// ncclDataType_t / ncclRedOp_t values of rccl.h (stable since NCCL 2.0)
+constexpr int NCCL_UINT32 = 3, NCCL_FLOAT32 = 7, NCCL_SUM = 0, NCCL_MAX = 2;
+} // namespace
+
+struct prgpu_comm {
+	int n_ranks = 1, rank = 0, device = 0;
+	void* nccl = nullptr; // ncclComm_t, null for a one-rank communicator without RCCL
+};
+
+#define NCCL_TRY(expr)                                                                                                          \
+	do {                                                                                                                        \
+		const nccl_result_t _r = (expr);                                                                                        \
+		if (_r != 0)                                                                                                            \
+			return fail(PRGPU_EDEVICE, std::string(#expr) + " failed: " + (rccl().GetErrorString ? rccl().GetErrorString(_r) : "?")); \
+	} while (0)
+
+int prgpu_comm_unique_id(uint8_t id[PRGPU_COMM_ID_BYTES])
+{
+	if (!id)
+		return fail(PRGPU_EINVAL, "null argument");
+	Rccl& r = rccl();
+	if (!r.lib)
+		return fail(PRGPU_ENODEVICE, r.error);
+	NcclId nid;
+	NCCL_TRY(r.GetUniqueId(&nid));
+	std::memcpy(id, nid.internal, PRGPU_COMM_ID_BYTES);
+	return PRGPU_OK;
+}
+
+int prgpu_comm_create(const uint8_t id[PRGPU_COMM_ID_BYTES], int n_ranks, int rank, int device, prgpu_comm** out)
+{
+	if (!out)
+		return fail(PRGPU_EINVAL, "null output handle");
+	*out = nullptr;
+	if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
+		return fail(PRGPU_EINVAL, "rank must be in [0, n_ranks)");
+	const bool force = getenv("PRGPU_COMM_FORCE_RCCL") && atoi(getenv("PRGPU_COMM_FORCE_RCCL")) != 0; // tests: a real one-rank communicator
+	prgpu_comm* c	 = new prgpu_comm();
+	c->n_ranks		 = n_ranks;
+	c->rank			 = rank;
+	c->device		 = device;
+	if (n_ranks > 1 || force) {
+		if (!id) {
+			delete c;
+			return fail(PRGPU_EINVAL, "a communicator of several ranks needs the unique id of rank 0");
+		}
+		Rccl& r = rccl();
+		if (!r.lib) {
+			delete c;
+			return fail(PRGPU_ENODEVICE, r.error);
+		}
+		int n_dev = 0;
+		if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
+			delete c;
+			return fail(PRGPU_ENODEVICE, "device index out of range");
+		}
+		if (hipSetDevice(device) != hipSuccess) {
+			delete c;
+			return fail(PRGPU_EDEVICE, "hipSetDevice failed");
+		}
+		NcclId nid;
+		std::memcpy(nid.internal, id, PRGPU_COMM_ID_BYTES);
+		const nccl_result_t rc = r.CommInitRank(&c->nccl, n_ranks, nid, rank);
+		if (rc != 0) {
+			delete c;
+			return fail(PRGPU_EDEVICE, std::string("ncclCommInitRank failed: ") + r.GetErrorString(rc));
+		}
+	}
+	*out = c;
+	return PRGPU_OK;
+}
+
+void prgpu_comm_destroy(prgpu_comm* c)
+{
+	if (!c)
+		return;
+	if (c->nccl && rccl().lib) {
+		(void)hipSetDevice(c->device);
+		(void)rccl().CommDestroy(c->nccl);
+	}
+	delete c;
+}
+
+int prgpu_comm_size(const prgpu_comm* c) { return c ? c->n_ranks : fail(PRGPU_EINVAL, "null communicator"); }
+
+int prgpu_reduce(prgpu_scene* s, prgpu_comm* c, int root)
+{
+	if (!s || !c)
+		return fail(PRGPU_EINVAL, "null argument");
+	if (root < 0 || root >= c->n_ranks)
+		return fail(PRGPU_EINVAL, "root must be a rank of the communicator");
+	if (!c->nccl)
+		return PRGPU_OK; // one rank: the frame is already complete
+	if (c->device != s->device)
+		return fail(PRGPU_EINVAL, "the communicator and the scene live on different devices");
+	HIP_TRY(hipSetDevice(s->device));
+	Rccl& r = rccl();
+	// one group = one fused launch: XYZ (fp32 sum), sample counts (u32 sum), feedback bits (a pixel's bits are only ever set by the
+	// rank that owns it, so MAX over the ranks is the OR of mergeLocal, FrameOutputDevice.cpp:121)
+	NCCL_TRY(r.GroupStart());
+	NCCL_TRY(r.Reduce(s->ps.out_xyz, s->ps.out_xyz, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+	NCCL_TRY(r.Reduce(s->ps.samples, s->ps.samples, size_t(s->n_pixels), NCCL_UINT32, NCCL_SUM, root, c->nccl, s->stream));
+	NCCL_TRY(r.Reduce(s->ps.feedback, s->ps.feedback, size_t(s->n_pixels), NCCL_UINT32, NCCL_MAX, root, c->nccl, s->stream));
+	NCCL_TRY(r.GroupEnd());
 	return PRGPU_OK;
 }
 

@@ -133,3 +133,19 @@ def test_no_built_binaries_are_tracked():
     for f in tracked:
         with open(os.path.join(ROOT, f), "rb") as fh:
             assert fh.read(4) != b"\x7fELF", f
+
+
+def test_communicator_argument_checks_without_a_gpu():
+    """prgpu_comm_* / prgpu_reduce: a one-rank communicator needs neither RCCL nor a device; bad arguments are EINVAL."""
+    lib = abi.load()
+    h = C.c_void_p()
+    assert lib.prgpu_comm_create(None, 1, 0, 0, C.byref(h)) == 0 and h.value
+    assert lib.prgpu_comm_size(h) == 1
+    assert lib.prgpu_reduce(None, h, 0) == -1 and b"null" in lib.prgpu_last_error()
+    lib.prgpu_comm_destroy(h)
+    h = C.c_void_p()
+    assert lib.prgpu_comm_create(None, 2, 2, 0, C.byref(h)) == -1 and b"rank" in lib.prgpu_last_error()
+    assert lib.prgpu_comm_create(None, 2, 0, 0, C.byref(h)) == -1 and b"unique id" in lib.prgpu_last_error()
+    assert lib.prgpu_comm_create(None, 0, 0, 0, C.byref(h)) == -1
+    assert lib.prgpu_comm_size(None) == -1
+    lib.prgpu_comm_destroy(None)

@@ -385,6 +385,33 @@ def test_persistent_render_call_is_cut_into_bounded_launches(monkeypatch):
     assert ref[2] == out[2]
 
 
+def test_reduce_one_rank_noop_and_a_real_rccl_communicator(monkeypatch):
+    """prgpu_reduce through the ABI: with one rank nothing may change; PRGPU_COMM_FORCE_RCCL=1 builds a genuine one-rank RCCL
+    communicator (ncclGetUniqueId / ncclCommInitRank / grouped ncclReduce on the scene's stream), whose sum over one rank is the identity."""
+    sc = scene.cornell_box(64, 48, spp=4, spectral_mono=1, spectral_start=520.0)
+    g = backend.RenderContext(sc)
+    g.render(4)
+    g.waitForFinish()
+    ref = g.output()
+    comm = backend.Communicator(1, 0)
+    assert comm.size == 1
+    g.reduce(comm)
+    g.waitForFinish()
+    for a, b in zip(ref, g.output()):
+        assert np.array_equal(a, b)
+    with pytest.raises(abi.PrgpuError, match="root"):
+        g.reduce(comm, root=1)
+    comm.close()
+    monkeypatch.setenv("PRGPU_COMM_FORCE_RCCL", "1")
+    real = backend.Communicator(1, 0)
+    g.reduce(real)
+    g.waitForFinish()
+    for a, b in zip(ref, g.output()):
+        assert np.array_equal(a, b)
+    assert ref[2].any()   # feedback bits went through the MAX reduce unchanged
+    real.close()
+
+
 def test_full_size_properties_1m_triangles():
     """BASELINE C4 geometry at full triangle count: size-independent properties instead of an oracle render --
     hit ids of 20k rays against the oracle BVH, energy bound, determinism, sample plane == spp on hit pixels."""
