@@ -1895,6 +1895,31 @@ __device__ __forceinline__ void ring_push(uint32_t* q, uint32_t cap_mask, uint32
 	if (pred)
 		__hip_atomic_store(&q[(base + __popcll(mask & ((1ull << lane) - 1ull))) & cap_mask], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// the same, with the wave's entries ordered by a 3-bit key (the direction octant of the ray): rays that are handed out together then
+// share the near/far child order.  Counting sort inside the wave: eight ballots.
+__device__ __forceinline__ void ring_push_sorted(uint32_t* q, uint32_t cap_mask, uint32_t* tail, bool pred, uint32_t value, uint32_t key)
+{
+	const unsigned long long mask = __ballot(pred);
+	if (mask == 0ull)
+		return;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t base		= 0;
+	const int leader	= __ffsll((long long)mask) - 1;
+	if ((int)lane == leader)
+		base = __hip_atomic_fetch_add(tail, (uint32_t)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	base = __shfl(base, leader, 64);
+	uint32_t before = 0, rank = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < 8; ++k) {
+		const unsigned long long mk = __ballot(pred && key == k);
+		if (key == k)
+			rank = before + __popcll(mk & ((1ull << lane) - 1ull));
+		before += (uint32_t)__popcll(mk);
+	}
+	if (pred)
+		__hip_atomic_store(&q[(base + rank) & cap_mask], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t direction_octant(float x, float y, float z) { return (x < 0.0f ? 1u : 0u) | (y < 0.0f ? 2u : 0u) | (z < 0.0f ? 4u : 0u); }
 // claim up to `want` entries; returns how many (wave-uniform) and the ring position of the first one
 __device__ __forceinline__ uint32_t ring_claim(uint32_t* head, const uint32_t* tail, uint32_t want, uint32_t& first)
 {
@@ -1939,6 +1964,7 @@ struct PersistentArgs {
 	uint32_t refill_min; // waves other than the block's first one refill only when at least this many rays are queued
 	uint32_t shader_wave; // 1: the block's last wave only shades (any batch size, never holds rays); the others trace and help
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
+	uint32_t sort_rays;	  // 1: a shading pass queues its rays ordered by direction octant
 	unsigned long long* gstats;
 };
 
@@ -2089,8 +2115,14 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					__hip_atomic_store(&sh.pending[slot_l], (alive ? 1u : 0u) + (want_shadow ? 1u : 0u) + (alive ? 0u : PP_DEAD), __ATOMIC_RELAXED,
 									   __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
-				ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY);
-				ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, alive, slot_l);
+				if (a.sort_rays) { // "sorted ray queues": order the wave's new rays by direction octant (measured: see DESIGN.md)
+					const float4 bd = alive ? ps.ray_d[slot] : make_float4(0, 0, 0, 0);
+					ring_push_sorted(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY, direction_octant(sh_d.x, sh_d.y, sh_d.z));
+					ring_push_sorted(sh.q_ray, RAY_MASK, &sh.ray_tail, alive, slot_l, direction_octant(bd.x, bd.y, bd.z));
+				} else {
+					ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY);
+					ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, alive, slot_l);
+				}
 				{ // rays in flight were parked during the pass: rebuild their traversal constants (same values) rather than
 				  // holding them in registers across the shading code
 					const uint32_t pslot = slot0 + (has_ray ? (my_entry & ~PP_ANY) : 0u);
@@ -2442,6 +2474,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.both_below	  = std::min(65, std::max(0, both_below));
 	a.shader_wave	  = shader_wave ? 1u : 0u;
 	a.shade_help	  = (uint32_t)std::max(64, shade_help);
+	a.sort_rays		  = getenv("PRGPU_PP_SORT") && atoi(getenv("PRGPU_PP_SORT")) != 0 ? 1u : 0u;
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks);
