@@ -172,7 +172,9 @@ struct PathState {
 	float4* sh_xyz;	   // xyz if visible, w = feedback bits (visible | occluded<<8)
 	uint32_t* sh_slot; // owning slot
 	// frame planes (per pixel)
-	float* iter_xyz;	// this iteration's per-pixel XYZ sums (W*H*3)
+	float* iter_xyz;	// this iteration's per-pixel XYZ sums (W*H*3); with plane_stride != 0 the first of a ring of such planes
+	uint32_t plane_stride; // floats between consecutive planes of the ring (0: one plane); iteration i uses plane i - iter_base
+	uint32_t iter_base;
 	float* out_xyz;		// running mean (W*H*3)
 	uint32_t* samples;	// sample count plane
 	uint32_t* feedback; // feedback bit plane

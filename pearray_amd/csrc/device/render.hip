@@ -543,14 +543,20 @@ __device__ __forceinline__ uint32_t fragment_feedback_zero(const Blob& mis, cons
 	}
 	return fb;
 }
-__device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pixel, uint32_t fb, const float xyz[3])
+// where the sample living in `slot` accumulates: the pixel's entry of the iteration plane -- THE plane, or with a ring of planes
+// (persistent kernel + multi-tap pixel filter) the plane of the slot's iteration
+__device__ __forceinline__ size_t iter_entry(const PathState& ps, uint32_t slot, uint32_t pixel)
+{
+	return (ps.plane_stride ? size_t(ps.iter[slot] - ps.iter_base) * ps.plane_stride : size_t(0)) + size_t(3) * pixel;
+}
+__device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pixel, size_t entry, uint32_t fb, const float xyz[3])
 {
 	if (fb) {
 		ps.feedback[pixel] |= fb;
 	} else {
-		ps.iter_xyz[3 * pixel + 0] += xyz[0];
-		ps.iter_xyz[3 * pixel + 1] += xyz[1];
-		ps.iter_xyz[3 * pixel + 2] += xyz[2];
+		ps.iter_xyz[entry + 0] += xyz[0];
+		ps.iter_xyz[entry + 1] += xyz[1];
+		ps.iter_xyz[entry + 2] += xyz[2];
 	}
 }
 
@@ -729,9 +735,12 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	if (sc.features & FEAT_SHAPE_LIGHTS)
 		ps.last_pos[slot] = make_float4(0, 0, 0, 0); // TraversalContext::LastPosition starts at the world origin (direct.cpp:55)
 	ps.flags[slot]	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA;
-	ps.iter_xyz[3 * pixel + 0] = 0.0f;
-	ps.iter_xyz[3 * pixel + 1] = 0.0f;
-	ps.iter_xyz[3 * pixel + 2] = 0.0f;
+	{
+		const size_t entry = (ps.plane_stride ? size_t(iter - ps.iter_base) * ps.plane_stride : size_t(0)) + size_t(3) * pixel; // = iter_entry: ps.iter[slot] == iter
+		ps.iter_xyz[entry + 0] = 0.0f;
+		ps.iter_xyz[entry + 1] = 0.0f;
+		ps.iter_xyz[entry + 2] = 0.0f;
+	}
 	atomicAdd(&bs.v[PRGPU_STAT_PIXEL_SAMPLES], 1u);
 	atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
 	atomicAdd(&bs.v[PRGPU_STAT_PRIMARY_RAYS], 1u);
@@ -1282,6 +1291,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 {
 	const prgpu_settings& cfg = sc.cfg;
 	const uint32_t pixel = ps.pixel[slot];
+	const size_t entry	 = iter_entry(ps, slot, pixel);
 	const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
 	const V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
 	const float4 hit4  = ps.hit[slot];
@@ -1326,11 +1336,11 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				float dir_pdf;
 				inf_light_eval(sc, il, ray_d, wl, true, radiance, dir_pdf);
 				fb = fragment_value(sc, blob(1), blob(1), grp_imp, radiance, mono, cie, blend, xyz);
-				apply_fragment(ps, pixel, fb, xyz);
+				apply_fragment(ps, pixel, entry, fb, xyz);
 			}
 			if (!illuminated) {
 				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
-				apply_fragment(ps, pixel, fb, xyz);
+				apply_fragment(ps, pixel, entry, fb, xyz);
 			}
 		} else if ((FEATS & FEAT_INFINITE_LIGHTS) && sc.n_inf_lights && cfg.direct) {
 			// ---- handleInfLights (direct.cpp:415-456)
@@ -1358,10 +1368,10 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				const Blob mis	  = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
 				fb				  = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
 			}
-			apply_fragment(ps, pixel, fb, xyz);
+			apply_fragment(ps, pixel, entry, fb, xyz);
 		} else {
 			fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, blob(0), mono, cie, blend, xyz);
-			apply_fragment(ps, pixel, fb, xyz);
+			apply_fragment(ps, pixel, entry, fb, xyz);
 		}
 	} else {
 		const V3 P = ray_o + ray_d * hit4.x;
@@ -1430,7 +1440,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const Blob mis		 = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
 					fb					 = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
 				}
-				apply_fragment(ps, pixel, fb, xyz);
+				apply_fragment(ps, pixel, entry, fb, xyz);
 			}
 			if (!cfg.emissive_scatter)
 				go_on = false;
@@ -1521,7 +1531,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 							sh_d		= make_float4(L.x, L.y, L.z, INFINITY); // distance = PR_INF (direct.cpp:329)
 							sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8)));
 						} else {
-							apply_fragment(ps, pixel, fb_occ, xyz_occ);
+							apply_fragment(ps, pixel, entry, fb_occ, xyz_occ);
 						}
 						break;
 					}
@@ -1615,7 +1625,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						sh_d		= make_float4(L.x, L.y, L.z, distance);
 						sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8)));
 					} else {
-						apply_fragment(ps, pixel, fb_occ, xyz_occ);
+						apply_fragment(ps, pixel, entry, fb_occ, xyz_occ);
 					}
 				} while (false);
 			}
@@ -1788,13 +1798,14 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_shadow(DevScene sc, PathSt
 		const float4 x		 = ps.sh_xyz[i];
 		const uint32_t fbs	 = __float_as_uint(x.w);
 		const uint32_t pixel = ps.pixel[ps.sh_slot[i]];
+		const size_t entry	 = iter_entry(ps, ps.sh_slot[i], pixel);
 		if (h.tri != INVALID) { // occluded
 			const uint32_t fb = (fbs >> 8) & 0xFFu;
 			if (fb)
 				ps.feedback[pixel] |= fb;
 		} else {
 			const float xyz[3] = { x.x, x.y, x.z };
-			apply_fragment(ps, pixel, fbs & 0xFFu, xyz);
+			apply_fragment(ps, pixel, entry, fbs & 0xFFu, xyz);
 		}
 	};
 	trace_persistent<true, COUNT>(sc, n, queue_head, spill, refill_below, load, store, gstats);
@@ -2076,10 +2087,13 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					const uint32_t pixel = ps.pixel[slot];
 					need_pixel			 = true;
 					if (pixel != INVALID) {
-						iter		   = ps.iter[slot];
-						const float it = (float)(iter + 1), itm1 = (float)iter;
-						for (int c = 0; c < 3; ++c)
-							ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + ps.iter_xyz[3 * pixel + c]) / it;
+						iter = ps.iter[slot];
+						if (!ps.plane_stride) { // single-tap filter: the sample folds into the running mean right here; with a ring of
+												// planes the launch only fills the planes and k_resolve gathers the taps afterwards
+							const float it = (float)(iter + 1), itm1 = (float)iter;
+							for (int c = 0; c < 3; ++c)
+								ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + ps.iter_xyz[3 * pixel + c]) / it;
+						}
 						if (iter + 1 < a.iter_end) {
 							need_pixel = false;
 							iter	   = iter + 1;
@@ -2230,13 +2244,14 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						const float4 x		 = ps.sh_xyz[slot];
 						const uint32_t fbs	 = __float_as_uint(x.w);
 						const uint32_t pixel = ps.pixel[slot];
+						const size_t entry	 = iter_entry(ps, slot, pixel);
 						if (s.best.tri != INVALID) {
 							const uint32_t fb = (fbs >> 8) & 0xFFu;
 							if (fb)
 								ps.feedback[pixel] |= fb;
 						} else {
 							const float xyz[3] = { x.x, x.y, x.z };
-							apply_fragment(ps, pixel, fbs & 0xFFu, xyz);
+							apply_fragment(ps, pixel, entry, fbs & 0xFFu, xyz);
 						}
 					} else {
 						ps.hit[slot] = make_float4(s.best.t, s.best.u, s.best.v, __uint_as_float(s.best.tri));

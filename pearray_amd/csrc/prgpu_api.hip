@@ -69,6 +69,7 @@ struct prgpu_scene {
 	enum Mode { LOCKSTEP, STREAMING, PERSISTENT };
 	Mode mode = LOCKSTEP;
 	uint32_t pp_slots = 512;
+	uint32_t pp_planes = 1; // iteration planes of the persistent pipeline (> 1 with a multi-tap pixel filter)
 	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 0, pp_occupancy = 3, pp_shader_wave = 0, pp_shade_help = 128;
 	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
@@ -382,7 +383,15 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(ps.sh_d, ns, false);
 	AL(ps.sh_xyz, ns, false);
 	AL(ps.sh_slot, ns, false);
-	AL(ps.iter_xyz, size_t(np) * 3, true);
+	// persistent pipeline with a multi-tap pixel filter: a ring of iteration planes (pixels advance through their samples at their own
+	// pace, sample i of a pixel lands in plane i - iter_base; after the launch k_resolve gathers the filter taps plane by plane, exactly
+	// like the lockstep pipeline does after each of its iterations)
+	s->pp_planes = t.single_tap ? 1u : 8u;
+	if (const char* env = getenv("PRGPU_PP_PLANES"))
+		s->pp_planes = t.single_tap ? 1u : (uint32_t)std::min(64, std::max(1, atoi(env)));
+	AL(ps.iter_xyz, size_t(np) * 3 * s->pp_planes, true);
+	ps.plane_stride = 0;
+	ps.iter_base	= 0;
 	AL(s->own_xyz, size_t(np) * 3, true);
 	AL(s->own_samples, np, true);
 	AL(s->own_feedback, np, true);
@@ -401,20 +410,18 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	// streaming (pixels advance through their samples independently) is bit-identical for single-tap filters but measured
 	// ~6% slower than the iteration-synchronous pipeline on MI355X (finished paths wait one round before their pixel's
 	// next sample starts); it stays available behind PRGPU_STREAMING=1
-	s->mode = t.single_tap ? prgpu_scene::PERSISTENT : prgpu_scene::LOCKSTEP;
-	if (t.single_tap) {
-		if (getenv("PRGPU_STREAMING") && atoi(getenv("PRGPU_STREAMING")) != 0)
-			s->mode = prgpu_scene::STREAMING;
-		if (const char* env = getenv("PRGPU_MODE")) {
-			if (std::strcmp(env, "streaming") == 0)
-				s->mode = prgpu_scene::STREAMING;
-			else if (std::strcmp(env, "persistent") == 0)
-				s->mode = prgpu_scene::PERSISTENT;
-			else if (std::strcmp(env, "lockstep") == 0)
-				s->mode = prgpu_scene::LOCKSTEP;
-			else
-				return fail(PRGPU_EINVAL, "PRGPU_MODE must be lockstep, streaming or persistent");
-		}
+	s->mode = prgpu_scene::PERSISTENT;
+	if (t.single_tap && getenv("PRGPU_STREAMING") && atoi(getenv("PRGPU_STREAMING")) != 0)
+		s->mode = prgpu_scene::STREAMING;
+	if (const char* env = getenv("PRGPU_MODE")) {
+		if (std::strcmp(env, "streaming") == 0)
+			s->mode = t.single_tap ? prgpu_scene::STREAMING : prgpu_scene::LOCKSTEP; // streaming folds per pixel: single-tap filters only
+		else if (std::strcmp(env, "persistent") == 0)
+			s->mode = prgpu_scene::PERSISTENT;
+		else if (std::strcmp(env, "lockstep") == 0)
+			s->mode = prgpu_scene::LOCKSTEP;
+		else
+			return fail(PRGPU_EINVAL, "PRGPU_MODE must be lockstep, streaming or persistent");
 	}
 	if (const char* env = getenv("PRGPU_PP_SLOTS"))
 		s->pp_slots = (uint32_t)std::max(256, atoi(env));
@@ -746,9 +753,15 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	// watchdog is never near a legitimate wait.  Per-pixel state lives in the planes, so consecutive launches continue exactly
 	// where the previous one stopped (identical results for any chunking).
 	const uint64_t per_iter = std::max<uint64_t>(1, s->n_slots);
-	const uint32_t chunk	= (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(s->pp_launch_min_iters, s->pp_launch_samples / per_iter));
+	uint32_t chunk			= (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(s->pp_launch_min_iters, s->pp_launch_samples / per_iter));
+	const bool ring			= !s->sc.single_tap; // multi-tap filter: one launch fills at most pp_planes iteration planes
+	if (ring) {
+		chunk			= std::min(chunk, s->pp_planes);
+		ps.plane_stride = 3u * s->n_pixels;
+	}
 	for (uint32_t b = iter_begin; b < iter_end;) {
 		const uint32_t e = (uint32_t)std::min<uint64_t>(iter_end, uint64_t(b) + chunk);
+		ps.iter_base = b;
 		s->time_begin(6, s->stream);
 		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act, s->pp_refill_min, s->pp_both_below,
 									s->pp_occupancy, s->pp_shader_wave, s->pp_shade_help,
@@ -757,6 +770,16 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 									s->gstats, s->stream);
 		s->time_end(s->stream);
 		HIP_TRY(hipGetLastError());
+		if (ring) { // filter taps + running mean, iteration by iteration in order (FrameOutputDevice.cpp:202-221)
+			prd::PathState pr = s->ps;
+			for (uint32_t i = b; i < e; ++i) {
+				pr.iter_xyz = s->ps.iter_xyz + size_t(i - b) * ps.plane_stride;
+				s->time_begin(4, s->stream);
+				prd::launch_resolve(s->sc, pr, i, s->stream);
+				s->time_end(s->stream);
+			}
+			HIP_TRY(hipGetLastError());
+		}
 		b = e;
 	}
 	return PRGPU_OK;

@@ -359,6 +359,31 @@ def test_bound_framebuffer_receives_every_plane_in_every_pipeline(monkeypatch, m
     assert np.array_equal(ox, rx) and np.array_equal(os_, rs) and np.array_equal(of, rf)
 
 
+@pytest.mark.parametrize("flt,r", [(abi.FILTER_GAUSSIAN, 2), (abi.FILTER_MITCHELL, 3), (abi.FILTER_BLOCK, 1)])
+def test_persistent_pipeline_with_multi_tap_filters_equals_lockstep(monkeypatch, flt, r):
+    """Multi-tap pixel filters in the persistent pipeline: the launch fills a ring of iteration planes, k_resolve gathers the taps
+    plane by plane -- the arithmetic of the lockstep pipeline, so the frames are identical bit for bit, for any ring size, for
+    resumed calls and with tile ownership (aprons spill into foreign pixels)."""
+    sc = scene.cornell_soup(112, 80, spp=11, n_triangles=5_000, filter=flt, filter_radius=r)
+    tiles = tiling.tiles_for_rank(112, 80, 0, 2, tile=16)
+    for tl in (None, tiles):
+        ref = _render_mode(monkeypatch, "lockstep", sc, [11], tl)
+        for env, chunks in ((dict(), [11]), (dict(PRGPU_PP_PLANES="3"), [11]), (dict(PRGPU_PP_PLANES="1"), [4, 7]), (dict(PRGPU_PP_PLANES="64"), [2, 9])):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            out = _render_mode(monkeypatch, "persistent", sc, chunks, tl)
+            for k in env:
+                monkeypatch.delenv(k)
+            for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+                assert np.array_equal(a, b), (env, chunks, tl is not None)
+            assert ref[2] == out[2]
+    if tl is not None:
+        owned = np.zeros((80, 112), bool)
+        for x0, y0, x1, y1 in tiles:
+            owned[y0:y1, x0:x1] = True
+        assert (out[0][0][~owned].sum() > 0) == (r > 0)   # aprons of owned pixels reach foreign pixels
+
+
 def test_tiles_cannot_change_after_the_first_iteration():
     g = backend.RenderContext(scene.cornell_box(32, 32, spp=4))
     g.setTiles([(0, 0, 16, 32)])
