@@ -41,6 +41,7 @@
 #ifndef PRGPU_H
 #define PRGPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -336,6 +337,7 @@ int  prgpu_sync(prgpu_scene* s);
  * OutputFeedback bits, src/core/output/Feedback.h:6-12) to HOST memory; any pointer may be NULL. */
 int  prgpu_download(prgpu_scene* s, float* xyz, uint32_t* samples, uint32_t* feedback);
 int  prgpu_stats(prgpu_scene* s, uint64_t out[PRGPU_STAT_COUNT]);
+int  prgpu_film_size(prgpu_scene* s, uint32_t* width, uint32_t* height); /* RenderSettings::filmWidth / filmHeight of the scene */
 int  prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out);
 /* Enable/disable node+triangle counting inside the traversal kernels (slower; default off). */
 int  prgpu_set_instrumentation(prgpu_scene* s, int enabled);
@@ -392,6 +394,37 @@ enum { PRGPU_AOV_POSITION = 0, PRGPU_AOV_NORMAL, PRGPU_AOV_NORMAL_G, PRGPU_AOV_T
 int      prgpu_enable_aovs(prgpu_scene* s, uint32_t mask);           /* bit k enables PRGPU_AOV_k */
 uint32_t prgpu_aov_channels(uint32_t aov);                           /* 3 or 1; 0 for an unknown id */
 int      prgpu_download_aov(prgpu_scene* s, uint32_t aov, float* out);
+/* AOV_OnlineMean / AOV_OnlineVariance (src/loader/output/FrameContainer.h): Welford's online estimate of the per-iteration frame value,
+ * VarianceEstimator::addValue (src/core/buffer/VarianceEstimator.inl:15-27), updated ONCE per pixel and iteration where the iteration's
+ * value folds into the running mean.  Deviation, on purpose: the reference calls addValue from mergeLocal (FrameOutputDevice.cpp:104-109),
+ * i.e. once per TILE touching the pixel, so apron pixels are updated several times per iteration with partial values and the result
+ * depends on the thread-tile grid.  Enable before the first iteration; planes are W*H*3 floats. */
+int prgpu_enable_variance(prgpu_scene* s);
+int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance); /* either pointer may be NULL */
+/* ToneMapper::map (src/core/spectral/ToneMapper.cpp:12-79): XYZ triplets -> `out_elems` (>= 3) floats per pixel in the colour mode of
+ * an output channel (`:color 'srgb'|'xyz'|'norm_xyz'|'lum'`, OutputSpecification.cpp:262-272); SRGB is RGBConverter::fromXYZ
+ * (src/core/spectral/RGBConverter.cpp:15-24: linear sRGB, clamped at 0).  `weight` (per pixel, may be NULL) divides, `scale` multiplies.
+ * XYZ_NORM scales what `rgb` already holds by 1 / (X + Y + Z) exactly like the reference does (:34-45).  Host arrays. */
+enum { PRGPU_TONE_SRGB = 0, PRGPU_TONE_XYZ = 1, PRGPU_TONE_XYZ_NORM = 2, PRGPU_TONE_LUMINANCE = 3 };
+int prgpu_tonemap(uint32_t mode, float scale, const float* xyz, const float* weight, float* rgb, uint32_t out_elems, size_t pixel_count);
+/* Output channels: one `(channel :type ... :color ... )` of an `(output :name ...)` block (OutputSpecification.cpp:254-365) and how
+ * ImageWriter::save (src/loader/output/io/ImageWriter.cpp:52-251) writes it: SPECTRAL channels tone mapped to three floats named
+ * R, G, B (name.R ... when named; raw for the online mean / variance), 3D and 1D AOVs divided by the pixel's sample count, named
+ * name.x/.y/.z or name, COUNTER planes as floats.  Channels with a light path expression (:lpe) and the `uvw` AOV are not provided. */
+enum { PRGPU_CHANNEL_SPECTRAL = 0, PRGPU_CHANNEL_3D = 1, PRGPU_CHANNEL_1D = 2, PRGPU_CHANNEL_COUNTER = 3 };
+enum { PRGPU_SPECTRAL_OUTPUT = 0, PRGPU_SPECTRAL_ONLINE_MEAN = 1, PRGPU_SPECTRAL_ONLINE_VARIANCE = 2 };
+enum { PRGPU_COUNTER_SAMPLES = 0, PRGPU_COUNTER_FEEDBACK = 1 };
+typedef struct prgpu_output_channel {
+	uint32_t file;     /* index of the (output ...) block the channel belongs to */
+	uint32_t kind;     /* PRGPU_CHANNEL_* */
+	uint32_t variable; /* SPECTRAL: PRGPU_SPECTRAL_*; 3D, 1D: PRGPU_AOV_*; COUNTER: PRGPU_COUNTER_* */
+	uint32_t tone;     /* SPECTRAL: PRGPU_TONE_* */
+	char     name[64]; /* channel base name as ImageWriter writes it ("" for the colour channel: R, G, B) */
+} prgpu_output_channel;
+/* Allocate the AOV / variance planes the channels need (before the first iteration). */
+int prgpu_outputs_enable(prgpu_scene* s, const prgpu_output_channel* channels, uint32_t n_channels);
+/* Write the channels of output block `file` as one float EXR (prgpu_write_exr): downloads the planes, tone maps, weights. */
+int prgpu_outputs_save(prgpu_scene* s, const prgpu_output_channel* channels, uint32_t n_channels, uint32_t file, const char* path);
 /* Minimal OpenEXR 2 writer (scanline, uncompressed, 32-bit float channels; replaces the OIIO path of src/loader/output/io for
  * plain frames).  `planes[c]` points to width*height floats of channel `names[c]`, read with a stride of `strides[c]` floats
  * (1 = planar, 3 = one component of an interleaved XYZ frame).  Channels are stored in the alphabetical order EXR requires. */
@@ -437,6 +470,9 @@ int prgpu_prc_load_file(const char* path, const prgpu_prc_options* options, prgp
 int prgpu_prc_load_string(const char* source, const char* include_dir, const prgpu_prc_options* options, prgpu_prc** out);
 const prgpu_scene_desc* prgpu_prc_desc(const prgpu_prc* scene);
 const char* prgpu_prc_warnings(const prgpu_prc* scene); /* newline separated */
+/* The scene's (output ...) blocks: their channels (all files, in file order) and the :name of file k (NULL beyond the last). */
+const prgpu_output_channel* prgpu_prc_outputs(const prgpu_prc* scene, uint32_t* n_channels);
+const char* prgpu_prc_output_name(const prgpu_prc* scene, uint32_t file);
 const char* prgpu_prc_last_error(void);                 /* message of the last failed prgpu_prc_load_* on this thread */
 void prgpu_prc_free(prgpu_prc* scene);
 

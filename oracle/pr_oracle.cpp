@@ -862,6 +862,7 @@ struct Scene {
 	std::vector<float> last_xyz; // unfiltered per-path sums of the last iteration
 	std::vector<uint32_t> samples, feedback, prim_entity, prim_prim;
 	std::vector<float> aov[PRGPU_AOV_COUNT]; // shading-point AOV sums (enabled planes are non-empty)
+	std::vector<float> online_mean, online_variance; // AOV_OnlineMean / AOV_OnlineVariance (W*H*3), empty unless enabled
 	std::atomic<uint64_t> stats[PRGPU_STAT_COUNT];
 	std::atomic<uint64_t> cnt_nodes{ 0 }, cnt_tris{ 0 };
 	// debugging aid: rays of one pixel (kind, iter, o[3], d[3], tmin, tmax|distance, result)
@@ -3384,6 +3385,19 @@ void render_iteration(Scene& s, uint32_t iter, int threads)
 	// FrameOutputDevice::onEndOfIteration (FrameOutputDevice.cpp:202-221), iteration = iter+1
 	const float it = (float)(iter + 1), itm1 = (float)iter;
 	for (size_t i = 0; i < s.xyz.size(); ++i) {
+		if (!s.online_mean.empty()) {
+			// VarianceEstimator::addValue (buffer/VarianceEstimator.inl:15-27) with value = this iteration's frame value of the
+			// pixel, once per pixel and iteration.  (The reference calls it from mergeLocal, FrameOutputDevice.cpp:104-109, once per
+			// TILE that touches the pixel -- apron pixels several times per iteration with partial values -- which ties the result
+			// to the tile grid; the per-iteration form is the estimator the code is after.)
+			const float value = s.iter_xyz[i];
+			float& mean		  = s.online_mean[i];
+			float& var		  = s.online_variance[i];
+			const float delta = value - mean;
+			mean += delta / it;
+			const float delta2 = value - mean;
+			var				   = (var * itm1 + delta * delta2) / it;
+		}
 		s.xyz[i]	  = (s.xyz[i] * itm1 + s.iter_xyz[i]) / it;
 		s.iter_xyz[i] = 0;
 	}
@@ -3730,6 +3744,23 @@ int orc_enable_aovs(orc_scene* h, uint32_t mask)
 	for (uint32_t k = 0; k < PRGPU_AOV_COUNT; ++k)
 		if ((mask >> k) & 1u)
 			h->s.aov[k].assign(np * (k < PRGPU_AOV_ENTITY_ID ? 3 : 1), 0.0f);
+	return 0;
+}
+int orc_enable_variance(orc_scene* h)
+{
+	const size_t np = size_t(h->s.cfg.width) * h->s.cfg.height;
+	h->s.online_mean.assign(np * 3, 0.0f);
+	h->s.online_variance.assign(np * 3, 0.0f);
+	return 0;
+}
+int orc_download_variance(orc_scene* h, float* mean, float* variance)
+{
+	if (h->s.online_mean.empty())
+		return -1;
+	if (mean)
+		std::memcpy(mean, h->s.online_mean.data(), h->s.online_mean.size() * sizeof(float));
+	if (variance)
+		std::memcpy(variance, h->s.online_variance.data(), h->s.online_variance.size() * sizeof(float));
 	return 0;
 }
 int orc_download_aov(orc_scene* h, uint32_t aov, float* out)

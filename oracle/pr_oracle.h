@@ -31,6 +31,8 @@ int  orc_download(orc_scene* s, float* xyz, uint32_t* samples, uint32_t* feedbac
 int  orc_stats(orc_scene* s, uint64_t out[PRGPU_STAT_COUNT]);
 int  orc_enable_aovs(orc_scene* s, uint32_t mask);                  /* LocalFrameOutputDevice.cpp:252-283 */
 int  orc_download_aov(orc_scene* s, uint32_t aov, float* out);
+int  orc_enable_variance(orc_scene* s);                              /* AOV_OnlineMean / AOV_OnlineVariance, VarianceEstimator.inl:15-27 */
+int  orc_download_variance(orc_scene* s, float* mean, float* variance);
 int  orc_download_primary_hits(orc_scene* s, uint32_t* entity, uint32_t* prim);
 /* Per-pixel filter-free radiance sums of the LAST iteration: W*H*3, sum over the path's fragments of
  * blend * XYZ(fragment) in push order -- the quantity the device keeps per path. */

@@ -104,6 +104,14 @@ class TraceCounters(C.Structure):
                 ("shade_ticks", C.c_uint64), ("idle_ticks", C.c_uint64), ("total_ticks", C.c_uint64)]
 
 
+class OutputChannel(C.Structure):
+    _fields_ = [("file", C.c_uint32), ("kind", C.c_uint32), ("variable", C.c_uint32), ("tone", C.c_uint32), ("name", C.c_char * 64)]
+
+
+CHANNEL_SPECTRAL, CHANNEL_3D, CHANNEL_1D, CHANNEL_COUNTER = range(4)
+TONE_SRGB, TONE_XYZ, TONE_XYZ_NORM, TONE_LUMINANCE = range(4)
+
+
 class PrcSky(C.Structure):
     _fields_ = [("light_name", C.c_char_p), ("table", C.POINTER(C.c_float)), ("azimuth_count", C.c_uint32), ("elevation_count", C.c_uint32)]
 
@@ -154,6 +162,14 @@ SYMBOLS = {
     "prgpu_comm_destroy": (None, [_VP]),
     "prgpu_comm_size": (C.c_int, [_VP]),
     "prgpu_reduce": (C.c_int, [_VP, _VP, C.c_int]),
+    "prgpu_film_size": (C.c_int, [_VP, _U32P, _U32P]),
+    "prgpu_enable_variance": (C.c_int, [_VP]),
+    "prgpu_download_variance": (C.c_int, [_VP, _F32P, _F32P]),
+    "prgpu_tonemap": (C.c_int, [C.c_uint32, C.c_float, _F32P, _F32P, _F32P, C.c_uint32, C.c_size_t]),
+    "prgpu_outputs_enable": (C.c_int, [_VP, C.POINTER(OutputChannel), C.c_uint32]),
+    "prgpu_outputs_save": (C.c_int, [_VP, C.POINTER(OutputChannel), C.c_uint32, C.c_uint32, C.c_char_p]),
+    "prgpu_prc_outputs": (C.POINTER(OutputChannel), [_VP, _U32P]),
+    "prgpu_prc_output_name": (C.c_char_p, [_VP, C.c_uint32]),
     "prgpu_enable_aovs": (C.c_int, [_VP, C.c_uint32]),
     "prgpu_aov_channels": (C.c_uint32, [C.c_uint32]),
     "prgpu_download_aov": (C.c_int, [_VP, C.c_uint32, _F32P]),

@@ -113,6 +113,37 @@ class RenderContext:
             mask |= 1 << abi.AOV_NAMES.index(n)
         abi.check(self.lib.prgpu_enable_aovs(self._h, mask))
 
+    def enableVariance(self):
+        """AOV_OnlineMean / AOV_OnlineVariance (Welford per pixel and iteration); enable before the first iteration."""
+        abi.check(self.lib.prgpu_enable_variance(self._h))
+
+    def variance(self):
+        n = self.width * self.height * 3
+        mean, var = np.empty(n, np.float32), np.empty(n, np.float32)
+        abi.check(self.lib.prgpu_download_variance(self._h, _f32p(mean), _f32p(var)))
+        return mean.reshape(self.height, self.width, 3), var.reshape(self.height, self.width, 3)
+
+    def enableOutputs(self, prc_scene):
+        """Allocate the planes the scene's (output ...) blocks ask for (OutputSpecification::setup)."""
+        ch, n = prc_scene.outputs()
+        if n:
+            abi.check(self.lib.prgpu_outputs_enable(self._h, ch, n))
+
+    def saveOutputs(self, prc_scene, directory, suffix=""):
+        """OutputSpecification::save: one EXR per (output :name ...) block, named <name><suffix>.exr; returns the paths."""
+        ch, n = prc_scene.outputs()
+        paths = []
+        k = 0
+        while True:
+            name = self.lib.prgpu_prc_output_name(prc_scene._h, k)
+            if name is None:
+                break
+            path = os.path.join(directory, name.decode() + suffix + ".exr")
+            abi.check(self.lib.prgpu_outputs_save(self._h, ch, n, k, os.fsencode(path)))
+            paths.append(path)
+            k += 1
+        return paths
+
     def aov(self, name):
         k = abi.AOV_NAMES.index(name)
         ch = self.lib.prgpu_aov_channels(k)
@@ -198,7 +229,16 @@ def write_exr(path, channels):
     abi.check(lib.prgpu_write_exr(os.fsencode(path), w, h, len(names), c_names, c_planes, strides))
 
 
+def tonemap(xyz, mode=abi.TONE_SRGB, scale=1.0, weight=None):
+    """ToneMapper::map through the library (prgpu_tonemap): xyz [..., 3] float32 -> rgb of the same shape."""
+    lib = abi.load()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    rgb = np.zeros_like(xyz)
+    w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float32)
+    abi.check(lib.prgpu_tonemap(int(mode), float(scale), _f32p(xyz), None if w is None else _f32p(w), _f32p(rgb), 3, xyz.size // 3))
+    return rgb
+
+
 def xyz_to_srgb_linear(xyz):
     """RGBConverter::fromXYZ (spectral/RGBConverter.cpp:15-24): XYZ -> linear sRGB, clamped at 0."""
-    m = np.array([[3.240479, -1.537150, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]], dtype=np.float32)
-    return np.maximum(0.0, xyz @ m.T)
+    return tonemap(xyz, abi.TONE_SRGB)

@@ -560,6 +560,24 @@ __device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pix
 	}
 }
 
+// FrameOutputDevice::onEndOfIteration (FrameOutputDevice.cpp:202-221) for one pixel: running mean of the iteration values and, when
+// enabled, the online mean / variance planes (VarianceEstimator::addValue, buffer/VarianceEstimator.inl:15-27; once per pixel and iteration)
+__device__ __forceinline__ void fold_iteration(const PathState& ps, uint32_t pixel, uint32_t iter, const float value[3])
+{
+	const float it = (float)(iter + 1), itm1 = (float)iter;
+	for (int c = 0; c < 3; ++c) {
+		if (ps.online_mean) {
+			float mean		  = ps.online_mean[3 * pixel + c];
+			const float var	  = ps.online_variance[3 * pixel + c];
+			const float delta = value[c] - mean;
+			mean += delta / it;
+			const float delta2				  = value[c] - mean;
+			ps.online_mean[3 * pixel + c]	  = mean;
+			ps.online_variance[3 * pixel + c] = (var * itm1 + delta * delta2) / it;
+		}
+		ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + value[c]) / it;
+	}
+}
 __device__ __forceinline__ float rr_probability(const DevScene& sc, uint32_t L)
 {
 	return sc.rr_prob[L < sc.rr_size ? L : sc.rr_size - 1];
@@ -774,9 +792,8 @@ __global__ void __launch_bounds__(256) k_regen(DevScene sc, PathState ps, const 
 		slot				 = dead[i];
 		const uint32_t pixel = ps.pixel[slot];
 		const uint32_t iter	 = ps.iter[slot];
-		const float it = (float)(iter + 1), itm1 = (float)iter;
-		for (int c = 0; c < 3; ++c)
-			ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + ps.iter_xyz[3 * pixel + c]) / it;
+		const float v[3] = { ps.iter_xyz[3 * pixel], ps.iter_xyz[3 * pixel + 1], ps.iter_xyz[3 * pixel + 2] };
+		fold_iteration(ps, pixel, iter, v);
 		if (iter + 1 < iter_end) {
 			ps.iter[slot] = iter + 1;
 			camera_path(sc, ps, slot, iter + 1, bs);
@@ -1845,9 +1862,7 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 			}
 		}
 	}
-	const float it = (float)(iter + 1), itm1 = (float)iter;
-	for (int c = 0; c < 3; ++c)
-		ps.out_xyz[3 * p + c] = (ps.out_xyz[3 * p + c] * itm1 + acc[c]) / it;
+	fold_iteration(ps, p, iter, acc);
 }
 
 // clears the per-iteration plane of the pixels a path wrote (owned pixels are re-zeroed by raygen; this
@@ -2090,9 +2105,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						iter = ps.iter[slot];
 						if (!ps.plane_stride) { // single-tap filter: the sample folds into the running mean right here; with a ring of
 												// planes the launch only fills the planes and k_resolve gathers the taps afterwards
-							const float it = (float)(iter + 1), itm1 = (float)iter;
-							for (int c = 0; c < 3; ++c)
-								ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + ps.iter_xyz[3 * pixel + c]) / it;
+							const float v[3] = { ps.iter_xyz[3 * pixel], ps.iter_xyz[3 * pixel + 1], ps.iter_xyz[3 * pixel + 2] };
+							fold_iteration(ps, pixel, iter, v);
 						}
 						if (iter + 1 < a.iter_end) {
 							need_pixel = false;

@@ -41,6 +41,8 @@ struct prgpu_prc {
 	std::vector<prgpu_emission> emissions;
 	std::vector<prgpu_spectrum> spectra;
 	std::vector<prgpu_light> lights;
+	std::vector<prgpu_output_channel> outputs;
+	std::vector<std::string> output_names;
 	prgpu_scene_desc desc;
 	std::string warnings;
 };
@@ -570,6 +572,94 @@ struct Loader {
 			fail(PRGPU_EUNSUPPORTED, where(g) + ": light type '" + type + "' is not supported (env/environment/background, distant/direction, sun and sky are)");
 		}
 		out.lights.push_back(l);
+	}
+	// OutputSpecification::parse (src/loader/output/io/OutputSpecification.cpp:254-365): the channels of one output file
+	void add_output(const Group& g)
+	{
+		const Value* nm = g.get("name");
+		if (!nm || nm->type != Value::STRING) {
+			warn(where(g) + ": no name given for output (ignored, as in the reference)");
+			return;
+		}
+		const uint32_t file = (uint32_t)out.output_names.size();
+		out.output_names.push_back(nm->s);
+		struct Var { const char* str; uint32_t kind, variable; };
+		static const Var vars[] = {
+			{ "color", PRGPU_CHANNEL_SPECTRAL, PRGPU_SPECTRAL_OUTPUT }, { "spectral", PRGPU_CHANNEL_SPECTRAL, PRGPU_SPECTRAL_OUTPUT },
+			{ "output", PRGPU_CHANNEL_SPECTRAL, PRGPU_SPECTRAL_OUTPUT }, { "rgb", PRGPU_CHANNEL_SPECTRAL, PRGPU_SPECTRAL_OUTPUT },
+			{ "online_mean", PRGPU_CHANNEL_SPECTRAL, PRGPU_SPECTRAL_ONLINE_MEAN }, { "variance", PRGPU_CHANNEL_SPECTRAL, PRGPU_SPECTRAL_ONLINE_VARIANCE },
+			{ "online_variance", PRGPU_CHANNEL_SPECTRAL, PRGPU_SPECTRAL_ONLINE_VARIANCE }, { "var", PRGPU_CHANNEL_SPECTRAL, PRGPU_SPECTRAL_ONLINE_VARIANCE },
+			{ "entity_id", PRGPU_CHANNEL_1D, PRGPU_AOV_ENTITY_ID }, { "entity", PRGPU_CHANNEL_1D, PRGPU_AOV_ENTITY_ID }, { "id", PRGPU_CHANNEL_1D, PRGPU_AOV_ENTITY_ID },
+			{ "material_id", PRGPU_CHANNEL_1D, PRGPU_AOV_MATERIAL_ID }, { "material", PRGPU_CHANNEL_1D, PRGPU_AOV_MATERIAL_ID }, { "mat", PRGPU_CHANNEL_1D, PRGPU_AOV_MATERIAL_ID },
+			{ "emission_id", PRGPU_CHANNEL_1D, PRGPU_AOV_EMISSION_ID }, { "emission", PRGPU_CHANNEL_1D, PRGPU_AOV_EMISSION_ID },
+			{ "depth", PRGPU_CHANNEL_1D, PRGPU_AOV_DEPTH }, { "d", PRGPU_CHANNEL_1D, PRGPU_AOV_DEPTH },
+			{ "sample_count", PRGPU_CHANNEL_COUNTER, PRGPU_COUNTER_SAMPLES }, { "samples", PRGPU_CHANNEL_COUNTER, PRGPU_COUNTER_SAMPLES }, { "s", PRGPU_CHANNEL_COUNTER, PRGPU_COUNTER_SAMPLES },
+			{ "feedback", PRGPU_CHANNEL_COUNTER, PRGPU_COUNTER_FEEDBACK }, { "f", PRGPU_CHANNEL_COUNTER, PRGPU_COUNTER_FEEDBACK }, { "error", PRGPU_CHANNEL_COUNTER, PRGPU_COUNTER_FEEDBACK },
+			{ "position", PRGPU_CHANNEL_3D, PRGPU_AOV_POSITION }, { "pos", PRGPU_CHANNEL_3D, PRGPU_AOV_POSITION }, { "p", PRGPU_CHANNEL_3D, PRGPU_AOV_POSITION },
+			{ "normal", PRGPU_CHANNEL_3D, PRGPU_AOV_NORMAL }, { "norm", PRGPU_CHANNEL_3D, PRGPU_AOV_NORMAL }, { "n", PRGPU_CHANNEL_3D, PRGPU_AOV_NORMAL },
+			{ "normal_geometric", PRGPU_CHANNEL_3D, PRGPU_AOV_NORMAL_G }, { "ng", PRGPU_CHANNEL_3D, PRGPU_AOV_NORMAL_G },
+			{ "tangent", PRGPU_CHANNEL_3D, PRGPU_AOV_TANGENT }, { "tan", PRGPU_CHANNEL_3D, PRGPU_AOV_TANGENT }, { "nx", PRGPU_CHANNEL_3D, PRGPU_AOV_TANGENT },
+			{ "bitangent", PRGPU_CHANNEL_3D, PRGPU_AOV_BITANGENT }, { "binormal", PRGPU_CHANNEL_3D, PRGPU_AOV_BITANGENT }, { "bi", PRGPU_CHANNEL_3D, PRGPU_AOV_BITANGENT },
+			{ "ny", PRGPU_CHANNEL_3D, PRGPU_AOV_BITANGENT }, { "view", PRGPU_CHANNEL_3D, PRGPU_AOV_VIEW }, { "v", PRGPU_CHANNEL_3D, PRGPU_AOV_VIEW },
+		};
+		// variableToString returns the FIRST spelling of a variable (OutputSpecification.cpp:196-248): the channel's name in the file
+		auto canonical = [&](uint32_t kind, uint32_t variable) {
+			for (const Var& v : vars)
+				if (v.kind == kind && v.variable == variable)
+					return std::string(v.str);
+			return std::string();
+		};
+		for (const auto& e : g.entries) {
+			if (!e.key.empty() || e.value.type != Value::GROUP)
+				continue;
+			const Group& c = *e.value.g;
+			if (c.id == "custom_channel") {
+				warn(where(c) + ": custom output channels are not provided (skipped)");
+				continue;
+			}
+			if (c.id != "channel")
+				continue;
+			const Value* ty = c.get("type");
+			if (!ty || ty->type != Value::STRING)
+				continue;
+			const std::string type = lower(ty->s);
+			if (const Value* l = c.get("lpe"))
+				if (l->type == Value::STRING && !l->s.empty()) {
+					warn(where(c) + ": light path expression channels are not provided (skipped)");
+					continue;
+				}
+			if (type == "texture" || type == "uvw" || type == "uv" || type == "tex" || type == "displace_id" || type == "displace") {
+				warn(where(c) + ": the '" + type + "' AOV is not provided (skipped)");
+				continue;
+			}
+			const Var* found = nullptr;
+			for (const Var& v : vars)
+				if (type == v.str) {
+					found = &v;
+					break;
+				}
+			if (!found) {
+				warn(where(c) + ": unknown channel type '" + type + "' (skipped, as in the reference)");
+				continue;
+			}
+			prgpu_output_channel ch;
+			std::memset(&ch, 0, sizeof(ch));
+			ch.file		= file;
+			ch.kind		= found->kind;
+			ch.variable = found->variable;
+			ch.tone		= PRGPU_TONE_SRGB;
+			const std::string color = lower(get_string(c, "color", ""));
+			if (color == "xyz")
+				ch.tone = PRGPU_TONE_XYZ;
+			else if (color == "norm_xyz")
+				ch.tone = PRGPU_TONE_XYZ_NORM;
+			else if (color == "lum" || color == "luminance" || color == "gray")
+				ch.tone = PRGPU_TONE_LUMINANCE;
+			// the colour channel keeps an empty name (R, G, B); every other channel is named after its variable
+			const std::string name = (found->kind == PRGPU_CHANNEL_SPECTRAL && found->variable == PRGPU_SPECTRAL_OUTPUT) ? std::string() : canonical(found->kind, found->variable);
+			std::strncpy(ch.name, name.c_str(), sizeof(ch.name) - 1);
+			out.outputs.push_back(ch);
+		}
 	}
 	// computeSunEA(ParameterGroup) (skysun/SunLocation.cpp:107-130): :direction | :theta :phi | :elevation :azimuth | date, time, location
 	void sun_position(const Group& g, float& elevation, float& azimuth)
@@ -1146,7 +1236,7 @@ struct Loader {
 		else if (id == "camera")
 			add_camera(b);
 		else if (id == "output")
-			warn(where(b) + ": output specification ignored (the backend produces the XYZ frame, sample count and feedback planes)");
+			add_output(b);
 		else if (id == "embed" || id == "graph")
 			add_embed(b, dir);
 		else if (id == "light")
@@ -1300,6 +1390,16 @@ int prgpu_prc_load_file(const char* path, const prgpu_prc_options* opt, prgpu_pr
 
 const prgpu_scene_desc* prgpu_prc_desc(const prgpu_prc* p) { return p ? &p->desc : nullptr; }
 const char* prgpu_prc_warnings(const prgpu_prc* p) { return p ? p->warnings.c_str() : ""; }
+const prgpu_output_channel* prgpu_prc_outputs(const prgpu_prc* scene, uint32_t* n_channels)
+{
+	if (n_channels)
+		*n_channels = scene ? (uint32_t)scene->outputs.size() : 0u;
+	return scene && !scene->outputs.empty() ? scene->outputs.data() : nullptr;
+}
+const char* prgpu_prc_output_name(const prgpu_prc* scene, uint32_t file)
+{
+	return scene && file < scene->output_names.size() ? scene->output_names[file].c_str() : nullptr;
+}
 const char* prgpu_prc_last_error(void) { return g_prc_error.c_str(); }
 void prgpu_prc_free(prgpu_prc* p) { delete p; }
 

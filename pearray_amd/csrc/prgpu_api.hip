@@ -1002,6 +1002,17 @@ int prgpu_stats(prgpu_scene* s, uint64_t out[PRGPU_STAT_COUNT])
 	return PRGPU_OK;
 }
 
+int prgpu_film_size(prgpu_scene* s, uint32_t* width, uint32_t* height)
+{
+	if (!s)
+		return fail(PRGPU_EINVAL, "null scene");
+	if (width)
+		*width = s->cfg.width;
+	if (height)
+		*height = s->cfg.height;
+	return PRGPU_OK;
+}
+
 int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 {
 	if (!s || !out)
@@ -1314,6 +1325,13 @@ int prgpu_reduce(prgpu_scene* s, prgpu_comm* c, int root)
 	NCCL_TRY(r.Reduce(s->ps.out_xyz, s->ps.out_xyz, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
 	NCCL_TRY(r.Reduce(s->ps.samples, s->ps.samples, size_t(s->n_pixels), NCCL_UINT32, NCCL_SUM, root, c->nccl, s->stream));
 	NCCL_TRY(r.Reduce(s->ps.feedback, s->ps.feedback, size_t(s->n_pixels), NCCL_UINT32, NCCL_MAX, root, c->nccl, s->stream));
+	if (s->ps.online_mean) { // every pixel's estimator lives on the rank that owns the pixel, zero elsewhere (single-tap filters)
+		NCCL_TRY(r.Reduce(s->ps.online_mean, s->ps.online_mean, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+		NCCL_TRY(r.Reduce(s->ps.online_variance, s->ps.online_variance, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+	}
+	for (uint32_t k = 0; k < PRGPU_AOV_COUNT; ++k) // shading-point AOV sums: plain sums of the owner's samples
+		if (s->ps.aov[k])
+			NCCL_TRY(r.Reduce(s->ps.aov[k], s->ps.aov[k], size_t(s->n_pixels) * prgpu_aov_channels(k), NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
 	NCCL_TRY(r.GroupEnd());
 	return PRGPU_OK;
 }
@@ -1344,6 +1362,44 @@ int prgpu_enable_aovs(prgpu_scene* s, uint32_t mask)
 		g.ps.aov_mask = s->ps.aov_mask;
 	}
 	HIP_TRY(hipStreamSynchronize(s->stream));
+	return PRGPU_OK;
+}
+
+int prgpu_enable_variance(prgpu_scene* s)
+{
+	if (!s)
+		return fail(PRGPU_EINVAL, "null scene");
+	if (s->next_iteration != 0)
+		return fail(PRGPU_EINVAL, "the variance estimator must be enabled before the first iteration");
+	HIP_TRY(hipSetDevice(s->device));
+	if (!s->ps.online_mean) {
+		int rc = s->alloc(s->ps.online_mean, size_t(s->n_pixels) * 3, true);
+		if (rc != PRGPU_OK)
+			return rc;
+		rc = s->alloc(s->ps.online_variance, size_t(s->n_pixels) * 3, true);
+		if (rc != PRGPU_OK)
+			return rc;
+	}
+	for (auto& g : s->groups) {
+		g.ps.online_mean	 = s->ps.online_mean;
+		g.ps.online_variance = s->ps.online_variance;
+	}
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return PRGPU_OK;
+}
+
+int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance)
+{
+	if (!s)
+		return fail(PRGPU_EINVAL, "null scene");
+	if (!s->ps.online_mean)
+		return fail(PRGPU_EINVAL, "variance estimator not enabled");
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	if (mean)
+		HIP_TRY(hipMemcpy(mean, s->ps.online_mean, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
+	if (variance)
+		HIP_TRY(hipMemcpy(variance, s->ps.online_variance, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
 	return PRGPU_OK;
 }
 

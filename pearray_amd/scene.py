@@ -391,6 +391,12 @@ class PrcScene:
         self.desc = lib.prgpu_prc_desc(h).contents
         self.warnings = [w for w in lib.prgpu_prc_warnings(h).decode().split("\n") if w]
 
+    def outputs(self):
+        """(channel array, count) of the scene's (output ...) blocks (OutputSpecification.cpp:254-365)."""
+        n = C.c_uint32()
+        ch = self._lib.prgpu_prc_outputs(self._h, C.byref(n))
+        return ch, n.value
+
     def __del__(self):
         if getattr(self, "_h", None):
             self._lib.prgpu_prc_free(self._h)

@@ -189,6 +189,17 @@ class OracleScene:
         self.lib.orc_enable_aovs.argtypes = [C.c_void_p, C.c_uint32]
         self.lib.orc_enable_aovs(self.h, mask)
 
+    def enable_variance(self):
+        self.lib.orc_enable_variance.argtypes = [C.c_void_p]
+        assert self.lib.orc_enable_variance(self.h) == 0
+
+    def variance(self):
+        n = self.width * self.height * 3
+        mean, var = np.empty(n, np.float32), np.empty(n, np.float32)
+        self.lib.orc_download_variance.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        assert self.lib.orc_download_variance(self.h, _p(mean), _p(var)) == 0
+        return mean.reshape(self.height, self.width, 3), var.reshape(self.height, self.width, 3)
+
     def aov(self, name):
         k = abi.AOV_NAMES.index(name)
         ch = 3 if k < 6 else 1

@@ -98,3 +98,100 @@ def test_shading_point_aovs_match_the_checker_and_the_geometry():
     h = backend.RenderContext(sc)
     with pytest.raises(abi.PrgpuError):
         h.aov("depth")                                              # not enabled
+
+
+def test_tone_mapper_modes():
+    """ToneMapper::map (ToneMapper.cpp:12-79) with RGBConverter::fromXYZ (RGBConverter.cpp:15-24)."""
+    xyz = np.array([[0.9505, 1.0, 1.089], [0.4124, 0.2126, 0.0193], [0.0, 0.0, 0.0], [0.2, -0.5, 0.1]], dtype=np.float32)
+    rgb = backend.tonemap(xyz)
+    assert np.allclose(rgb[0], [1, 1, 1], atol=2e-3) and np.allclose(rgb[1], [1, 0, 0], atol=2e-3)      # D65 white, the red primary
+    assert (rgb >= 0).all() and rgb[3].min() == 0.0                                                      # clamped at zero
+    m = np.array([[3.240970, -1.537383, -0.4986108], [-0.9692436, 1.875968, 0.04155506], [0.05563008, -0.2039770, 1.056972]], dtype=np.float32)
+    assert np.allclose(rgb, np.maximum(0, xyz @ m.T), rtol=1e-6, atol=1e-7)
+    assert np.array_equal(backend.tonemap(xyz, abi.TONE_XYZ), xyz)
+    lum = backend.tonemap(xyz, abi.TONE_LUMINANCE)
+    assert np.array_equal(lum, np.repeat(xyz[:, 1:2], 3, axis=1))
+    w = np.array([2.0, 0.0, 1.0, 4.0], dtype=np.float32)
+    half = backend.tonemap(xyz, abi.TONE_XYZ, scale=3.0, weight=w)
+    assert np.allclose(half[0], xyz[0] / 2 * 3) and np.allclose(half[1], xyz[1] * 3)                      # weight <= eps leaves the pixel
+    assert np.array_equal(backend.tonemap(xyz, abi.TONE_XYZ_NORM), np.zeros_like(xyz))                  # scales what the output holds (zeros here)
+    lib = abi.load()
+    assert lib.prgpu_tonemap(9, 1.0, backend._f32p(xyz), None, backend._f32p(rgb), 3, 4) == -1
+    assert lib.prgpu_tonemap(0, 1.0, backend._f32p(xyz), None, backend._f32p(xyz), 3, 4) == -1            # in place
+
+
+def test_output_blocks_are_parsed_like_the_reference():
+    src = """(scene :render_width 8 :render_height 8
+      (camera :name 'c' :type 'standard') (material :name 'm' :type 'diffuse')
+      (mesh :name 'q' (attribute :type 'p' [0,0,0],[1,0,0],[0,1,0]) (faces [0,1,2]))
+      (entity :name 'e' :type 'mesh' :mesh 'q' :materials 'm')
+      (output :name 'image'
+        (channel :type 'color' :color 'srgb') (channel :type 'n') (channel :type 'ng') (channel :type 'feedback')
+        (channel :type 'color' :color 'srgb' :lpe 'CS*DL') (channel :type 'uv'))
+      (output :name 'extra' (channel :type 'RGB' :color 'XYZ') (channel :type 'var') (channel :type 'd') (channel :type 'samples') (channel :type 'nope'))
+      (output (channel :type 'color')))"""
+    s = scene.PrcScene(source=src)
+    ch, n = s.outputs()
+    got = [(ch[i].file, ch[i].kind, ch[i].variable, ch[i].tone, ch[i].name.decode()) for i in range(n)]
+    A = abi.AOV_NAMES.index
+    assert got == [(0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, ""), (0, abi.CHANNEL_3D, A("normal"), 0, "normal"), (0, abi.CHANNEL_3D, A("normal_g"), 0, "normal_geometric"),
+                   (0, abi.CHANNEL_COUNTER, 1, 0, "feedback"),
+                   (1, abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, ""), (1, abi.CHANNEL_SPECTRAL, 2, 0, "variance"), (1, abi.CHANNEL_1D, A("depth"), 0, "depth"),
+                   (1, abi.CHANNEL_COUNTER, 0, 0, "sample_count")]
+    lib = abi.load()
+    assert lib.prgpu_prc_output_name(s._h, 0) == b"image" and lib.prgpu_prc_output_name(s._h, 1) == b"extra" and lib.prgpu_prc_output_name(s._h, 2) is None
+    w = "\n".join(s.warnings)
+    assert "light path expression" in w and "'uv' AOV" in w and "unknown channel type 'nope'" in w and "no name given" in w
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flt,r,mode", [(abi.FILTER_MITCHELL, 1, "persistent"), (abi.FILTER_MITCHELL, 1, "lockstep"), (abi.FILTER_MITCHELL, 1, "streaming"),
+                                        (abi.FILTER_GAUSSIAN, 2, "persistent"), (abi.FILTER_GAUSSIAN, 2, "lockstep")])
+def test_online_mean_and_variance_match_the_checker(monkeypatch, flt, r, mode):
+    """Welford's update once per pixel and iteration (VarianceEstimator.inl:15-27) at the fold of every pipeline."""
+    monkeypatch.setenv("PRGPU_MODE", mode)
+    sc = scene.cornell_box(72, 60, spp=7, filter=flt, filter_radius=r)
+    g = backend.RenderContext(sc); g.enableVariance(); g.render(3); g.render(4); g.waitForFinish()
+    o = ob.OracleScene(sc); o.enable_variance(); o.render(7, threads=8)
+    gm, gv = g.variance()
+    om, ov = o.variance()
+    if r == 1:   # single live tap: identical arithmetic
+        assert np.array_equal(gm, om) and np.array_equal(gv, ov)
+        assert np.array_equal(g.output()[0], o.output()[0])
+    else:        # gather vs splat order of the taps
+        assert np.allclose(gm, om, rtol=1e-4, atol=1e-7) and np.allclose(gv, ov, rtol=2e-3, atol=1e-7)
+    assert gv.max() > 0 and (gv >= -1e-6).all()
+    assert np.allclose(gm, g.output()[0], rtol=1e-4, atol=1e-6)        # the online mean IS the running mean of the frame
+    with pytest.raises(abi.PrgpuError):
+        g.enableVariance()
+
+
+@pytest.mark.gpu
+def test_output_blocks_end_to_end(tmp_path):
+    """(output ...) of a .prc: planes enabled, rendered, written as EXR with the reference's channel names and weighting."""
+    src = """(scene :render_width 40 :render_height 32 :camera 'c'
+      (sampler :slot 'aa' :type 'sobol' :sample_count 4)
+      (camera :name 'c' :type 'standard' :width 1 :height 0.8 :local_direction [0,0,-1] :local_up [0,1,0] :local_right [1,0,0] :position [0,1,4])
+      (emission :name 'lamp' :type 'standard' :radiance (illum 6 6 5))
+      (material :name 'white' :type 'diffuse' :albedo (refl 0.7 0.7 0.7))
+      (mesh :name 'quad' (attribute :type 'p' [-1,0,-1],[1,0,-1],[1,0,1],[-1,0,1]) (faces [0,1,2,3]))
+      (entity :name 'floor' :type 'mesh' :mesh 'quad' :materials 'white' :scale 2)
+      (entity :name 'lamp' :type 'mesh' :mesh 'quad' :materials 'white' :emission 'lamp' :rotation (euler 180 0 0) :position [0,2,0] :scale 0.3)
+      (output :name 'image' (channel :type 'color' :color 'srgb') (channel :type 'n') (channel :type 'feedback') (channel :type 'depth') (channel :type 'variance')))"""
+    s = scene.PrcScene(source=src)
+    g = backend.RenderContext(s)
+    g.enableOutputs(s)
+    g.start(); g.waitForFinish()
+    paths = g.saveOutputs(s, str(tmp_path))
+    assert [os.path.basename(p) for p in paths] == ["image.exr"]
+    img = read_exr_uncompressed(paths[0])
+    assert sorted(img) == sorted(["R", "G", "B", "variance.R", "variance.G", "variance.B", "normal.x", "normal.y", "normal.z", "depth", "feedback"])
+    xyz, smp, fb = g.output()
+    rgb = backend.tonemap(xyz)
+    for k, c in enumerate("RGB"):
+        assert np.array_equal(img[c], rgb[..., k])
+        assert np.array_equal(img["variance." + c], g.variance()[1][..., k])
+    hit = smp > 0
+    assert np.allclose(img["normal.y"][hit], (g.aov("normal")[..., 1] / np.maximum(smp, 1))[hit]) and np.allclose(np.abs(img["normal.y"][hit]), 1, atol=1e-5)
+    assert np.allclose(img["depth"][hit], (g.aov("depth") / np.maximum(smp, 1))[hit]) and img["depth"][hit].min() > 1
+    assert np.array_equal(img["feedback"], fb.astype(np.float32))

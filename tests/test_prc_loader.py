@@ -150,7 +150,8 @@ def test_force_direct_and_overrides():
 def test_two_quads_scene_matches_hand_assembly():
     s = scene.PrcScene(path=os.path.join(SCENES, "two_quads.prc"))
     d = s.desc
-    assert any("output specification ignored" in w for w in s.warnings)
+    ch, n = s.outputs()
+    assert n == 1 and (ch[0].kind, ch[0].variable, ch[0].tone, ch[0].name) == (abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, b"")
     b, lamp, grey, tab, qp = two_quads_by_hand()
     # lamp: T(0,1.5,0) * Rx(180 deg) * S(0.5);   card: T * R(quaternion 45 deg about y) * S(0.3,1,0.3)
     got_lamp = np.array(list(d.entities[1].transform), dtype=np.float32).reshape(4, 4)
@@ -370,7 +371,9 @@ def test_complex_prc_loads_with_a_host_supplied_sky_table():
     mats = sorted(d.materials[i].kind for i in range(d.n_materials))
     assert abi.MAT_PRINCIPLED in mats and abi.MAT_DIELECTRIC in mats and abi.MAT_LAMBERT in mats
     assert sum(d.entities[i].kind == abi.ENTITY_SPHERE for i in range(d.n_entities)) == 4 and d.n_triangles > 50000
-    assert any("output specification" in w for w in s.warnings)
+    ch, n = s.outputs()   # complex.prc:27-34: color (srgb), n, ng, feedback; the commented-out LPE channel is not there
+    assert [(ch[i].kind, ch[i].name) for i in range(n)] == [(abi.CHANNEL_SPECTRAL, b""), (abi.CHANNEL_3D, b"normal"), (abi.CHANNEL_3D, b"normal_geometric"),
+                                                           (abi.CHANNEL_COUNTER, b"feedback")]
 
 
 def test_scene_cache_round_trips_a_description_and_drops_sky_tables(tmp_path):
