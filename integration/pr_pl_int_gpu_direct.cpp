@@ -1,0 +1,233 @@
+// pr_pl_int_gpu_direct.cpp -- PearRay-side adapter: the `gpu_direct` integrator plugin on top of libprgpu.so.
+//
+// NOT part of this repository's build: it is the file a PearRay maintainer adds under src/plugins/ (it includes PearRay's own
+// headers, Eigen etc.) and links against libprgpu.so.  It exports `_pr_exports` through PR_PLUGIN_INIT exactly like the stock
+// integrators (src/loader/plugin/Plugin.h:28-66; loaded by PluginManager.cpp:35-37,198-206 when the shared object is named
+// pr_pl_int_gpu_direct.so).  Everything it calls in libprgpu.so is declared in include/prgpu.h.
+//
+// How the scene crosses: core interfaces (IEntity, IMaterial) do not expose triangles or closure parameters, so the adapter does not
+// walk Scene -- it hands the SAME scene file the host is loading to the library's own loader (prgpu_prc_load_file), which produces
+// the flat prgpu_scene_desc, and supplies what only the host can compute: the SkyModel tables of `sky` lights (pr_lib_skysun).
+// How the frame comes back: results bypass the per-fragment queue (RenderTileSession::pushSpectralFragment is a per-sample virtual
+// call); at onEnd() the XYZ / sample-count / feedback planes are downloaded into the host's FrameOutputDevice buffers.
+#include "Environment.h"
+#include "Logger.h"
+#include "SceneLoadContext.h"
+#include "buffer/FrameBuffer.h"
+#include "integrator/IIntegrator.h"
+#include "integrator/IIntegratorFactory.h"
+#include "integrator/IIntegratorPlugin.h"
+#include "output/FrameOutputDevice.h"
+#include "output/OutputSystem.h"
+#include "renderer/RenderContext.h"
+#include "renderer/RenderTile.h"
+#include "renderer/RenderTileSession.h"
+#include "skysun/SkyModel.h"
+#include "skysun/SunLocation.h"
+
+#include <prgpu.h>
+
+#include <atomic>
+#include <map>
+
+namespace PR {
+struct GpuDirectSetup {
+	std::filesystem::path SceneFile;						// the .prc being loaded (SceneLoadContext::currentFile)
+	prgpu_settings Integrator;								// `direct` parameters (direct.cpp:500-515)
+	std::map<std::string, std::vector<float>> SkyTables;	// SkyModel::mData per sky light, [elevation][azimuth][band]
+	std::map<std::string, std::pair<uint32, uint32>> SkyResolution;
+};
+
+// flatten(ctx): everything the device needs, from the scene FILE plus the host-side tables
+static prgpu_prc* flatten(const GpuDirectSetup& setup, const RenderSettings& rs)
+{
+	std::vector<prgpu_prc_sky> skies;
+	for (const auto& kv : setup.SkyTables) {
+		prgpu_prc_sky s;
+		s.light_name	  = kv.first.c_str();
+		s.table			  = kv.second.data();
+		s.azimuth_count	  = setup.SkyResolution.at(kv.first).first;
+		s.elevation_count = setup.SkyResolution.at(kv.first).second;
+		skies.push_back(s);
+	}
+	prgpu_prc_options opt;
+	std::memset(&opt, 0, sizeof(opt));
+	opt.width		 = rs.filmWidth; // the host's settings win over the file (command line overrides)
+	opt.height		 = rs.filmHeight;
+	opt.seed		 = rs.seed;
+	opt.force_direct = 1; // the file says (integrator :type 'gpu_direct'); render it with the direct path
+	opt.n_skies		 = (uint32)skies.size();
+	opt.skies		 = skies.data();
+	prgpu_prc* file	 = nullptr;
+	if (prgpu_prc_load_file(setup.SceneFile.generic_string().c_str(), &opt, &file) != PRGPU_OK) {
+		PR_LOG(L_ERROR) << "[gpu_direct] " << prgpu_prc_last_error() << std::endl;
+		return nullptr;
+	}
+	return file;
+}
+
+class IntGpuDirect;
+class IntGpuDirectInstance : public IIntegratorInstance {
+public:
+	IntGpuDirectInstance(IntGpuDirect* parent)
+		: mParent(parent)
+	{
+	}
+	void onTile(RenderTileSession& session) override;
+
+private:
+	IntGpuDirect* mParent;
+};
+
+class IntGpuDirect : public IIntegrator {
+public:
+	explicit IntGpuDirect(const GpuDirectSetup& setup)
+		: mSetup(setup)
+	{
+	}
+	~IntGpuDirect() override
+	{
+		prgpu_scene_destroy(mScene);
+		prgpu_prc_free(mFile);
+	}
+
+	// RenderContext::start calls onInit once, before the threads exist (RenderContext.cpp:103)
+	void onInit(RenderContext* ctx) override
+	{
+		mContext = ctx;
+		mFile	 = flatten(mSetup, ctx->settings());
+		if (!mFile)
+			throw std::runtime_error("gpu_direct: could not load the scene for the GPU backend");
+		prgpu_scene_desc desc = *prgpu_prc_desc(mFile);
+		// integrator parameters come from the host's parameter group, everything else from the file
+		desc.settings.max_ray_depth		 = mSetup.Integrator.max_ray_depth;
+		desc.settings.soft_max_ray_depth = mSetup.Integrator.soft_max_ray_depth;
+		desc.settings.mis				 = mSetup.Integrator.mis;
+		desc.settings.nee				 = mSetup.Integrator.nee;
+		desc.settings.direct			 = mSetup.Integrator.direct;
+		desc.settings.emissive_scatter	 = mSetup.Integrator.emissive_scatter;
+		if (prgpu_scene_create(&desc, /*device*/ 0, &mScene) != PRGPU_OK)
+			throw std::runtime_error(prgpu_last_error()); // same policy as Scene.cpp:103-104
+		uint32 n = 0;
+		if (const prgpu_output_channel* ch = prgpu_prc_outputs(mFile, &n))
+			prgpu_outputs_enable(mScene, ch, n); // the AOV planes the (output ...) blocks ask for
+		mNextIteration = 0;
+	}
+
+	void onEnd() override
+	{
+		if (!mScene || !mContext)
+			return;
+		// the frame: XYZ running mean, sample counts, feedback bits -> the host's frame buffers (FrameBuffer.h:98-147, [pixel*3+c])
+		for (const auto& dev : mContext->output()->outputDevices()) {
+			auto frame = std::dynamic_pointer_cast<FrameOutputDevice>(dev);
+			if (!frame)
+				continue;
+			auto xyz	  = frame->data().getInternalChannel_Spectral(AOV_Output);
+			auto samples  = frame->data().getInternalChannel_Counter(AOV_SampleCount);
+			auto feedback = frame->data().getInternalChannel_Counter(AOV_Feedback);
+			if (prgpu_download(mScene, xyz ? xyz->ptr() : nullptr, samples ? samples->ptr() : nullptr, feedback ? feedback->ptr() : nullptr) != PRGPU_OK)
+				PR_LOG(L_ERROR) << "[gpu_direct] " << prgpu_last_error() << std::endl;
+		}
+	}
+
+	std::shared_ptr<IIntegratorInstance> createThreadInstance(RenderContext*, size_t) override
+	{
+		return std::make_shared<IntGpuDirectInstance>(this);
+	}
+
+	// RenderThread::main hands every (tile, iteration) to onTile from N threads (RenderThread.cpp:36-70).  The device renders ALL
+	// tiles of an iteration in one call, so the first thread that sees a new iteration issues it; the others only account their
+	// samples, which keeps the host's iteration barrier, progress display and stop handling working (RenderContext.cpp:234-296).
+	void renderIteration(uint32 iteration)
+	{
+		uint32 expected = iteration;
+		if (mNextIteration.compare_exchange_strong(expected, iteration + 1)) {
+			if (prgpu_render(mScene, iteration, iteration + 1) != PRGPU_OK || prgpu_sync(mScene) != PRGPU_OK)
+				PR_LOG(L_ERROR) << "[gpu_direct] " << prgpu_last_error() << std::endl;
+		}
+	}
+
+private:
+	const GpuDirectSetup mSetup;
+	RenderContext* mContext = nullptr;
+	prgpu_prc* mFile		= nullptr;
+	prgpu_scene* mScene		= nullptr;
+	std::atomic<uint32> mNextIteration{ 0 };
+};
+
+void IntGpuDirectInstance::onTile(RenderTileSession& session)
+{
+	mParent->renderIteration(session.context()->currentIteration().Iteration);
+	session.tile()->statistics().add(RenderStatisticEntry::PixelSampleCount, session.tile()->viewSize().area());
+}
+
+class IntGpuDirectFactory : public IIntegratorFactory {
+public:
+	explicit IntGpuDirectFactory(const GpuDirectSetup& setup)
+		: mSetup(setup)
+	{
+	}
+	std::shared_ptr<IIntegrator> createInstance() const override { return std::make_shared<IntGpuDirect>(mSetup); }
+
+private:
+	const GpuDirectSetup mSetup;
+};
+
+class IntGpuDirectPlugin : public IIntegratorPlugin {
+public:
+	std::shared_ptr<IIntegratorFactory> create(const std::string&, const SceneLoadContext& ctx) override
+	{
+		const ParameterGroup& p = ctx.parameters();
+		GpuDirectSetup setup;
+		setup.SceneFile = ctx.currentFile();
+		prgpu_settings_default(&setup.Integrator); // the defaults of direct.cpp:34-39
+		setup.Integrator.max_ray_depth		= p.getUInt("max_ray_depth", setup.Integrator.max_ray_depth);
+		setup.Integrator.soft_max_ray_depth = std::min<uint32>(setup.Integrator.max_ray_depth, p.getUInt("soft_max_ray_depth", setup.Integrator.soft_max_ray_depth));
+		setup.Integrator.mis				= p.getString("mis", "balance") == "power" ? PRGPU_MIS_POWER : PRGPU_MIS_BALANCE;
+		setup.Integrator.nee				= p.getBool("nee", true);
+		setup.Integrator.direct				= p.getBool("direct", true);
+		setup.Integrator.emissive_scatter	= p.getBool("emissive_scatter", true);
+		// `sky` lights: the integrator block may name them with their parameters (:sky_lights ['sky']); the table is the host's
+		// SkyModel evaluated exactly as sky.cpp:195 does.  A scene without sky lights needs nothing here.
+		for (const std::string& name : p.getStringArray("sky_lights")) {
+			SceneLoadContext light_ctx(ctx.environment(), ctx.currentFile());
+			light_ctx.parameters() = ctx.environment()->lightParameters(name); // the (light :name ...) block's parameter group
+			const ElevationAzimuth sunEA = computeSunEA(light_ctx.parameters());
+			const SkyModel model(light_ctx.lookupSpectralNode("albedo", 0.15f), sunEA, light_ctx.parameters());
+			std::vector<float> table(model.elevationCount() * model.azimuthCount() * AR_SPECTRAL_BANDS);
+			for (size_t el = 0; el < model.elevationCount(); ++el)
+				for (size_t az = 0; az < model.azimuthCount(); ++az)
+					for (size_t b = 0; b < AR_SPECTRAL_BANDS; ++b)
+						table[(el * model.azimuthCount() + az) * AR_SPECTRAL_BANDS + b] = model.radiance((int)b,
+							ElevationAzimuth{ ELEVATION_RANGE * (el + 0.5f) / model.elevationCount(), AZIMUTH_RANGE * (az + 0.5f) / model.azimuthCount() });
+			setup.SkyTables[name]	  = std::move(table);
+			setup.SkyResolution[name] = { (uint32)model.azimuthCount(), (uint32)model.elevationCount() };
+		}
+		return std::make_shared<IntGpuDirectFactory>(setup);
+	}
+
+	const std::vector<std::string>& getNames() const override
+	{
+		static const std::vector<std::string> names({ "gpu_direct" }); // or { "direct", "standard", "default" } to replace the CPU integrator
+		return names;
+	}
+
+	PluginSpecification specification(const std::string&) const override
+	{
+		return PluginSpecificationBuilder("GPU Direct Integrator", "The direct integrator on an MI355X through libprgpu")
+			.Identifiers(getNames())
+			.Inputs()
+			.UInt("max_ray_depth", "Maximum ray depth", 64)
+			.UInt("soft_max_ray_depth", "Depth after which russian roulette starts", 4)
+			.Option("mis", "MIS mode", "balance", { "balance", "power" })
+			.Bool("nee", "Next event estimation", true)
+			.Bool("direct", "Direct hits of lights", true)
+			.Bool("emissive_scatter", "Emissive surfaces scatter", true)
+			.Specification()
+			.get();
+	}
+};
+} // namespace PR
+
+PR_PLUGIN_INIT(PR::IntGpuDirectPlugin, _PR_PLUGIN_NAME, PR_PLUGIN_VERSION)

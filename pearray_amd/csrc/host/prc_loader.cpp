@@ -27,6 +27,8 @@
 
 #include "../../../include/prgpu.h"
 #include "../tables/pr_tables.inl"
+#include <zlib.h>
+
 #include "datalisp.h"
 #include "setup.h"
 
@@ -1094,14 +1096,22 @@ struct Loader {
 	// meshes have one index per corner, so such a mesh is expanded to one vertex per face corner (same geometry, same normals).
 	void add_embed(const Group& g, const std::string& dir)
 	{
-		const std::string loader = lower(get_string(g, "loader", "obj"));
-		if (loader != "obj")
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": embed loader '" + loader + "' is not supported (obj only)");
+		const std::string loader = get_string(g, "loader", "obj"); // compared as written (SceneLoader.cpp:799-842)
+		if (loader != "obj" && loader != "ply" && loader != "mts")
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": embed loader '" + loader + "' is not supported (obj, ply and mts are)");
 		std::string path = get_string(g, "file", "");
 		if (path.empty())
 			fail(PRGPU_EINVAL, where(g) + ": embed without a :file");
 		if (path[0] != '/' && !dir.empty())
 			path = dir + "/" + path;
+		if (loader == "ply") {
+			add_embed_ply(g, path);
+			return;
+		}
+		if (loader == "mts") {
+			add_embed_mts(g, path);
+			return;
+		}
 		std::ifstream f(path);
 		if (!f)
 			fail(PRGPU_EINVAL, where(g) + ": cannot open '" + path + "'");
@@ -1185,6 +1195,289 @@ struct Loader {
 					m.faces.push_back({ base, base + k, base + k + 1 });
 			}
 		}
+		meshes[name] = std::move(m);
+	}
+
+	// PlyLoader::load (src/loader/archives/PlyLoader.cpp:225-333): ascii / binary little / big endian, float vertex properties
+	// x y z [nx ny nz] [u v] (other float properties are skipped by position), faces as `list <count type> <index type> vertex_indices`
+	// of triangles and quads; normals are normalised on load (:141-148)
+	void add_embed_ply(const Group& g, const std::string& path)
+	{
+		std::ifstream f(path, std::ios::in | std::ios::binary);
+		if (!f)
+			fail(PRGPU_EINVAL, where(g) + ": cannot open '" + path + "'");
+		std::string magic;
+		f >> magic;
+		if (magic != "ply")
+			fail(PRGPU_EINVAL, path + ": not a ply file");
+		std::string method, line;
+		int n_vertices = 0, n_faces = 0, elem[8] = { -1, -1, -1, -1, -1, -1, -1, -1 } /* x y z nx ny nz u v */, n_props = 0, ind_elem = -1, face_props = 0;
+		static const char* prop_names[8] = { "x", "y", "z", "nx", "ny", "nz", "u", "v" };
+		while (std::getline(f, line)) {
+			std::istringstream ls(line);
+			std::string action;
+			ls >> action;
+			if (action == "comment")
+				continue;
+			if (action == "format") {
+				ls >> method;
+			} else if (action == "element") {
+				std::string type;
+				ls >> type;
+				if (type == "vertex")
+					ls >> n_vertices;
+				else if (type == "face")
+					ls >> n_faces;
+			} else if (action == "property") {
+				std::string type;
+				ls >> type;
+				if (type == "float") {
+					std::string name;
+					ls >> name;
+					for (int k = 0; k < 8; ++k)
+						if (name == prop_names[k])
+							elem[k] = n_props;
+					++n_props;
+				} else if (type == "list") {
+					++face_props;
+					std::string count_type, ind_type, name;
+					ls >> count_type >> ind_type >> name;
+					if (count_type != "uchar" && count_type != "int" && count_type != "uint8" && count_type != "uint") {
+						warn(path + ": only 'property list uchar int' is supported");
+						continue;
+					}
+					if (name == "vertex_indices")
+						ind_elem = face_props - 1;
+				} else {
+					warn(path + ": only float or list properties are read; '" + type + "' is skipped as one 4-byte property");
+					++n_props;
+				}
+			} else if (action == "end_header") {
+				break;
+			}
+		}
+		if (elem[0] < 0 || elem[1] < 0 || elem[2] < 0 || ind_elem < 0 || n_vertices <= 0 || n_faces <= 0)
+			fail(PRGPU_EINVAL, path + ": the ply file does not contain valid mesh data");
+		const bool ascii = method == "ascii", swap = method == "binary_big_endian";
+		const bool has_n = elem[3] >= 0 && elem[4] >= 0 && elem[5] >= 0, has_uv = elem[6] >= 0 && elem[7] >= 0;
+		auto read_f32 = [&]() {
+			unsigned char b[4] = { 0, 0, 0, 0 };
+			f.read(reinterpret_cast<char*>(b), 4);
+			if (swap)
+				std::swap(b[0], b[3]), std::swap(b[1], b[2]);
+			float v;
+			std::memcpy(&v, b, 4);
+			return v;
+		};
+		Mesh m;
+		for (int i = 0; i < n_vertices; ++i) {
+			float val[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+			if (ascii) {
+				if (!std::getline(f, line))
+					fail(PRGPU_EINVAL, path + ": not enough vertices given");
+				std::istringstream ls(line);
+				float x;
+				for (int e = 0; ls >> x; ++e)
+					for (int k = 0; k < 8; ++k)
+						if (elem[k] == e)
+							val[k] = x;
+			} else {
+				for (int e = 0; e < n_props; ++e) {
+					const float x = read_f32();
+					for (int k = 0; k < 8; ++k)
+						if (elem[k] == e)
+							val[k] = x;
+				}
+			}
+			m.p.insert(m.p.end(), val, val + 3);
+			if (has_n) {
+				float norm = std::sqrt(val[3] * val[3] + val[4] * val[4] + val[5] * val[5]);
+				if (norm <= 1.1920928955078125e-7f)
+					norm = 1.0f;
+				for (int k = 3; k < 6; ++k)
+					m.n.push_back(val[k] / norm);
+			}
+			if (has_uv)
+				m.uv.insert(m.uv.end(), val + 6, val + 8);
+		}
+		if (!ascii && !f)
+			fail(PRGPU_EINVAL, path + ": not enough vertices given");
+		for (int i = 0; i < n_faces; ++i) {
+			std::vector<uint32_t> face;
+			if (ascii) {
+				if (!std::getline(f, line))
+					fail(PRGPU_EINVAL, path + ": not enough indices given");
+				std::istringstream ls(line);
+				uint32_t n = 0, ind;
+				ls >> n;
+				for (uint32_t j = 0; j < n && (ls >> ind); ++j)
+					face.push_back(ind);
+			} else {
+				unsigned char n = 0;
+				f.read(reinterpret_cast<char*>(&n), 1);
+				for (unsigned j = 0; j < n; ++j) {
+					unsigned char b[4] = { 0, 0, 0, 0 };
+					f.read(reinterpret_cast<char*>(b), 4);
+					if (swap)
+						std::swap(b[0], b[3]), std::swap(b[1], b[2]);
+					uint32_t ind;
+					std::memcpy(&ind, b, 4);
+					face.push_back(ind);
+				}
+				if (!f)
+					fail(PRGPU_EINVAL, path + ": not enough indices given");
+			}
+			if (face.size() != 3 && face.size() != 4)
+				fail(PRGPU_EINVAL, path + ": only triangles or quads are allowed in ply files");
+			for (uint32_t ind : face)
+				if (ind >= (uint32_t)n_vertices)
+					fail(PRGPU_EINVAL, path + ": face index out of range");
+			m.faces.push_back(face);
+		}
+		const std::string name = get_string(g, "name", "");
+		if (name.empty())
+			fail(PRGPU_EINVAL, where(g) + ": embedded mesh has no name");
+		meshes[name] = std::move(m);
+	}
+	// MtsSerializedLoader::load (src/loader/archives/MtsSerializedLoader.cpp:130-328): Mitsuba's .serialized container -- u16 0x041C,
+	// u16 version (>= 3), zlib streams per shape, the shape offsets (u64, u32 for version 3) and the shape count at the end of the
+	// file; a stream holds flags, [name], vertex and triangle counts, positions, [normals], [uvs], [colours], indices.
+	void add_embed_mts(const Group& g, const std::string& path)
+	{
+		std::ifstream f(path, std::ios::in | std::ios::binary);
+		if (!f)
+			fail(PRGPU_EINVAL, where(g) + ": cannot open '" + path + "'");
+		std::vector<unsigned char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+		auto rd = [&](size_t off, void* dst, size_t n) {
+			if (off + n > file.size())
+				fail(PRGPU_EINVAL, path + ": truncated Mitsuba serialized file");
+			std::memcpy(dst, file.data() + off, n);
+		};
+		uint16_t ident = 0, version = 0;
+		rd(0, &ident, 2);
+		if (ident != 0x041C)
+			fail(PRGPU_EINVAL, path + ": not a valid Mitsuba serialized file");
+		rd(2, &version, 2);
+		if (version < 3)
+			fail(PRGPU_EINVAL, path + ": insufficient version number " + std::to_string(version) + " < 3");
+		const uint32_t shape = (uint32_t)get_number(g, "shape", 0);
+		uint32_t count = 0;
+		rd(file.size() - 4, &count, 4);
+		if (shape >= count)
+			fail(PRGPU_EINVAL, path + ": cannot access shape " + std::to_string(shape) + ", the file contains " + std::to_string(count));
+		const size_t osz = version >= 4 ? 8 : 4;
+		auto offset_of = [&](uint32_t k) {
+			uint64_t o = 0;
+			rd(file.size() - 4 - osz * (count - k), &o, osz);
+			return o;
+		};
+		const uint64_t start = offset_of(shape), end = shape == count - 1 ? file.size() - 4 - 0 : offset_of(shape + 1);
+		if (start + 4 > end || end > file.size())
+			fail(PRGPU_EINVAL, path + ": bad shape offsets");
+		// inflate the shape's stream (zlib, window 15) in one go
+		std::vector<unsigned char> data;
+		{
+			z_stream zs;
+			std::memset(&zs, 0, sizeof(zs));
+			if (inflateInit2(&zs, 15) != Z_OK)
+				fail(PRGPU_EINVAL, path + ": could not initialise zlib");
+			zs.next_in	= file.data() + start + 4;
+			zs.avail_in = (uInt)(end - start - 4);
+			unsigned char buf[1 << 15];
+			int rc = Z_OK;
+			while (rc == Z_OK) {
+				zs.next_out	 = buf;
+				zs.avail_out = sizeof(buf);
+				rc			 = inflate(&zs, Z_NO_FLUSH);
+				if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
+					inflateEnd(&zs);
+					fail(PRGPU_EINVAL, path + ": zlib data error in shape " + std::to_string(shape));
+				}
+				data.insert(data.end(), buf, buf + (sizeof(buf) - zs.avail_out));
+				if (rc == Z_BUF_ERROR && zs.avail_in == 0)
+					break;
+			}
+			inflateEnd(&zs);
+		}
+		size_t pos = 0;
+		auto take = [&](void* dst, size_t n) {
+			if (pos + n > data.size())
+				fail(PRGPU_EINVAL, path + ": attempting to read past the end of the stream");
+			std::memcpy(dst, data.data() + pos, n);
+			pos += n;
+		};
+		enum { MF_VERTEXNORMALS = 0x0001, MF_TEXCOORDS = 0x0002, MF_VERTEXCOLORS = 0x0008, MF_DOUBLE = 0x2000 };
+		uint32_t flags = 0;
+		take(&flags, 4);
+		if (version >= 4) {
+			unsigned char c = 1;
+			while (c != 0)
+				take(&c, 1); // shape name, ignored
+		}
+		uint64_t n_vertices = 0, n_tris = 0;
+		take(&n_vertices, 8);
+		take(&n_tris, 8);
+		if (n_vertices == 0 || n_tris == 0 || n_vertices > 0xFFFFFFFFull || n_tris > 0x7FFFFFFFull)
+			fail(PRGPU_EINVAL, path + ": no valid mesh in shape " + std::to_string(shape));
+		auto floats = [&](std::vector<float>& dst, size_t n) {
+			dst.resize(n);
+			if (flags & MF_DOUBLE) {
+				for (size_t i = 0; i < n; ++i) {
+					double d;
+					take(&d, 8);
+					dst[i] = static_cast<float>(d);
+				}
+			} else {
+				take(dst.data(), n * 4);
+			}
+		};
+		Mesh m;
+		floats(m.p, n_vertices * 3);
+		if (flags & MF_VERTEXNORMALS)
+			floats(m.n, n_vertices * 3);
+		if (flags & MF_TEXCOORDS)
+			floats(m.uv, n_vertices * 2);
+		if (flags & MF_VERTEXCOLORS) {
+			std::vector<float> ignored;
+			floats(ignored, n_vertices * 3);
+		}
+		for (uint64_t t = 0; t < n_tris; ++t) {
+			uint32_t tri[3];
+			take(tri, 12);
+			for (uint32_t ind : tri)
+				if (ind >= n_vertices)
+					fail(PRGPU_EINVAL, path + ": triangle index out of range");
+			m.faces.push_back({ tri[0], tri[1], tri[2] });
+		}
+		if (!(flags & MF_VERTEXNORMALS)) { // MeshBase::buildSmoothNormals (src/core/mesh/MeshBase.cpp:15-60): the LAST face of a vertex wins
+			m.n.assign(n_vertices * 3, 0.0f);
+			for (const auto& face : m.faces) {
+				const float *p0 = &m.p[3 * face[0]], *p1 = &m.p[3 * face[1]], *p2 = &m.p[3 * face[2]];
+				const float a[3] = { p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2] }, b[3] = { p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2] };
+				float n[3]		 = { a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0] };
+				const float z	 = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+				if (z > 0) { // Triangle::normal = cross.normalized() (Eigen leaves a zero vector alone)
+					const float l = std::sqrt(z);
+					for (float& c : n)
+						c /= l;
+				}
+				for (uint32_t ind : face)
+					for (int c = 0; c < 3; ++c)
+						m.n[3 * ind + c] = n[c];
+			}
+			for (uint64_t i = 0; i < n_vertices; ++i) {
+				float* n	  = &m.n[3 * i];
+				const float z = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2];
+				if (z > 0) {
+					const float l = std::sqrt(z);
+					for (int c = 0; c < 3; ++c)
+						n[c] /= l;
+				}
+			}
+		}
+		const std::string name = get_string(g, "name", "");
+		if (name.empty())
+			fail(PRGPU_EINVAL, where(g) + ": embedded mesh has no name");
 		meshes[name] = std::move(m);
 	}
 

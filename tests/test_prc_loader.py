@@ -420,3 +420,96 @@ def test_c5_fixture_is_the_reference_scene():
     assert np.array_equal(arr(fx.desc.indices, 3 * fx.desc.n_triangles, np.uint32), arr(ref.desc.indices, 3 * ref.desc.n_triangles, np.uint32))
     for i in range(fx.desc.n_materials):
         assert struct_bytes(fx.desc.materials[i]) == struct_bytes(ref.desc.materials[i])
+
+
+EMBED = """(scene :render_width 8 :render_height 8
+  (camera :name 'c' :type 'standard')
+  (material :name 'm' :type 'diffuse')
+  (embed :loader '%s' :file '%s' :name 'shape' %s)
+  (entity :name 'e' :type 'mesh' :mesh 'shape' :materials 'm'))"""
+
+
+def _embed_reference(positions, faces, normals=None, uvs=None):
+    b = scene.SceneBuilder(8, 8)
+    b.set_camera(scene.IDENTITY, near=1e-6, local_direction=(0, 1, 0), local_up=(0, 0, 1), local_right=(1, 0, 0))
+    m = b.lambert(b.spectrum_const(1.0))
+    b.add_mesh(positions, faces, m, normals=normals, uvs=uvs)
+    return b.build()
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary_little_endian", "binary_big_endian"])
+def test_ply_embed_semantics(tmp_path, fmt):
+    """PlyLoader.cpp: float properties by position (an unknown one is skipped), normals normalised on load, triangles and quads."""
+    import struct
+    P = [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 0.5, 1]]
+    N = [[0, 0, 2], [0, 0, 1], [0, 3, 0], [0, 0, 0], [1, 1, 1]]           # unnormalised; a zero normal stays zero (norm := 1)
+    UV = [[0, 0], [1, 0], [1, 1], [0, 1], [0.5, 0.5]]
+    F = [[0, 1, 2, 3], [0, 1, 4], [1, 2, 4]]
+    header = "ply\nformat %s 1.0\ncomment made by a test\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\nproperty float confidence\n" \
+             "property float nx\nproperty float ny\nproperty float nz\nproperty float u\nproperty float v\nelement face 3\nproperty list uchar int vertex_indices\nend_header\n" % fmt
+    path = tmp_path / "m.ply"
+    if fmt == "ascii":
+        body = "".join("%g %g %g 0.5 %g %g %g %g %g\n" % (*p, *n, *uv) for p, n, uv in zip(P, N, UV)) + "".join("%d %s\n" % (len(f), " ".join(map(str, f))) for f in F)
+        path.write_text(header + body)
+    else:
+        e = "<" if "little" in fmt else ">"
+        body = b"".join(struct.pack(e + "9f", *p, 0.5, *n, *uv) for p, n, uv in zip(P, N, UV)) + b"".join(struct.pack(e + "B%di" % len(f), len(f), *f) for f in F)
+        path.write_bytes(header.encode() + body)
+    s = scene.PrcScene(source=EMBED % ("ply", str(path), ""))
+    Nn = [np.array(n, np.float32) / (np.float32(np.sqrt(np.float32(sum(np.float32(c) * np.float32(c) for c in n)))) or np.float32(1)) for n in N]
+    want = _embed_reference(P, F, normals=Nn, uvs=UV)
+    assert_same_desc(s.desc, want.desc)
+    assert s.desc.n_triangles == 4 and s.desc.entities[0].has_uvs == 1
+    with pytest.raises(abi.PrgpuError, match="not a ply file"):
+        (tmp_path / "bad.ply").write_text("plx\n")
+        scene.PrcScene(source=EMBED % ("ply", str(tmp_path / "bad.ply"), ""))
+    with pytest.raises(abi.PrgpuError, match="embed loader 'stl'"):
+        scene.PrcScene(source=EMBED % ("stl", str(path), ""))
+
+
+@pytest.mark.parametrize("version,double,with_normals", [(4, False, True), (3, True, False), (4, False, False)])
+def test_mitsuba_serialized_embed_semantics(tmp_path, version, double, with_normals):
+    """MtsSerializedLoader.cpp: zlib streams, end-of-file shape dictionary (u64 offsets, u32 in version 3), :shape selects one;
+    meshes without normals get MeshBase::buildSmoothNormals (the last face of a vertex wins, MeshBase.cpp:15-60)."""
+    import struct, zlib
+    shapes = [([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 2]]),
+              ([[0, 0, 0], [2, 0, 0], [2, 2, 0], [0, 2, 0], [1, 1, 3]], [[0, 1, 2], [0, 2, 3], [0, 1, 4], [2, 3, 4]])]
+    # shape k's record starts with its own 4-byte header; offsets are absolute file positions of those headers
+    recs, blob = [], b""
+    for k, (P, F) in enumerate(shapes):
+        recs.append(len(blob))
+        flags = (0x2000 if double else 0x1000) | (0x0001 if with_normals else 0) | 0x0008
+        raw = struct.pack("<I", flags) + (b"shape%d\0" % k if version >= 4 else b"") + struct.pack("<QQ", len(P), len(F))
+        ft = "d" if double else "f"
+        raw += struct.pack("<%d%s" % (3 * len(P), ft), *[c for p in P for c in p])
+        if with_normals:
+            raw += struct.pack("<%d%s" % (3 * len(P), ft), *([0.0, 0.0, 1.0] * len(P)))
+        raw += struct.pack("<%d%s" % (3 * len(P), ft), *([0.5] * 3 * len(P)))
+        raw += struct.pack("<%dI" % (3 * len(F)), *[i for f in F for i in f])
+        blob += struct.pack("<HH", 0x041C, version) + zlib.compress(raw)
+    blob += b"".join(struct.pack("<Q" if version >= 4 else "<I", r) for r in recs) + struct.pack("<I", len(shapes))
+    path = tmp_path / "m.serialized"
+    path.write_bytes(blob)
+    for k, (P, F) in enumerate(shapes):
+        s = scene.PrcScene(source=EMBED % ("mts", str(path), ":shape %d" % k))
+        if with_normals:
+            N = [[0, 0, 1]] * len(P)
+        else:
+            N = np.zeros((len(P), 3), np.float32)
+            Pa = np.array(P, np.float32)
+            for f in F:
+                n = np.cross(Pa[f[1]] - Pa[f[0]], Pa[f[2]] - Pa[f[0]]).astype(np.float32)
+                n = n / np.float32(np.sqrt(np.float32(n @ n)))
+                for i in f:
+                    N[i] = n
+        want = _embed_reference(P, F, normals=N)
+        d, w = s.desc, want.desc
+        assert (d.n_vertices, d.n_triangles) == (w.n_vertices, w.n_triangles)
+        assert np.array_equal(arr(d.positions, 3 * d.n_vertices, np.float32), arr(w.positions, 3 * w.n_vertices, np.float32))
+        assert np.array_equal(arr(d.indices, 3 * d.n_triangles, np.uint32), arr(w.indices, 3 * w.n_triangles, np.uint32))
+        assert np.allclose(arr(d.normals, 3 * d.n_vertices, np.float32), arr(w.normals, 3 * w.n_vertices, np.float32), atol=1e-6)
+    with pytest.raises(abi.PrgpuError, match="cannot access shape 2"):
+        scene.PrcScene(source=EMBED % ("mts", str(path), ":shape 2"))
+    (tmp_path / "bad.serialized").write_bytes(b"\x00\x00\x04\x00" + b"\0" * 16)
+    with pytest.raises(abi.PrgpuError, match="not a valid Mitsuba"):
+        scene.PrcScene(source=EMBED % ("mts", str(tmp_path / "bad.serialized"), ""))
