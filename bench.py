@@ -89,21 +89,38 @@ def cpu_baseline(scene_desc, iters=4, tile=32):
                       % (iters, scene_desc.width, scene_desc.height, st["pixel_samples"], dt, t_build, tx * ty, tile, tile, cores)}
 
 
-def pmc_traffic(kernel_substr):
-    """HBM-side bytes per ITERATION of the dominant kernel from the newest committed rocprofv3 --pmc summary (PMC counters
-    cannot be read from inside this process): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the gfx950 correction of
-    MI355X_MICROARCH.md (HBM: FETCH_SIZE tallies 128-B requests at 64 B)."""
+def kernel_source_sha16():
+    """Fingerprint of the device sources the hot kernel is built from; a PMC summary taken from another build is not quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pearray_amd/csrc/device/render.hip", "pearray_amd/csrc/device/pr_device.h", "pearray_amd/csrc/device/bvh.hip"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_signature):
+    """HBM-side bytes per ITERATION of the dominant kernel from the newest committed rocprofv3 --pmc summary (PMC counters cannot
+    be read from inside this process): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the gfx950 correction of MI355X_MICROARCH.md (HBM:
+    FETCH_SIZE tallies 128-B requests at 64 B).  Only a summary of THIS kernel (same template instantiation) built from THESE
+    sources counts; otherwise traffic is null and the reason is reported."""
     import glob
+    reason = "no profiles/r*_pmc_summary.json"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
         try:
             with open(path) as f:
                 summ = json.load(f)
-            for name, k in summ["kernels"].items():
-                if kernel_substr in name and "FETCH_SIZE_per_iteration" in k:
-                    return (2.0 * k["FETCH_SIZE_per_iteration"] + k["WRITE_SIZE_per_iteration"]) * 1024.0, os.path.relpath(path, ROOT)
         except Exception:
             continue
-    return None, None
+        rel = os.path.relpath(path, ROOT)
+        if summ.get("kernel_source_sha16") != kernel_source_sha16():
+            reason = "%s was taken from another build of the kernel sources" % rel
+            continue
+        for name, k in summ["kernels"].items():
+            if kernel_signature in name.replace(" ", "") and "FETCH_SIZE_per_iteration" in k:
+                return (2.0 * k["FETCH_SIZE_per_iteration"] + k["WRITE_SIZE_per_iteration"]) * 1024.0, rel, None
+        reason = "%s holds no counters for %s" % (rel, kernel_signature)
+    return None, None, reason
 
 
 def roofline(ctx, rank, iters=8):
@@ -129,7 +146,7 @@ def roofline(ctx, rank, iters=8):
     persistent = fam["path"][1] > 0
     if persistent:
         # one launch = `iters` iterations of everything: closest-hit and occlusion traversal + shading, fused
-        kernel, substr = "k_path_persistent_occ3", "k_path_persistent"
+        kernel, substr = "k_path_persistent_occ3", "k_path_persistent_occ3<false,0u>"  # the lean instantiation the C4 scene runs
         ms, n = fam["path"]
         alg_bytes = (bytes_closest + bytes_any) / n          # per launch
         iters_per_launch = iters / n
@@ -140,14 +157,14 @@ def roofline(ctx, rank, iters=8):
         iters_per_launch = iters / n
     avg_ms = ms / max(n, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    t_iter, src = pmc_traffic(substr)
+    t_iter, src, why_not = pmc_traffic(substr)
     if t_iter is not None and not persistent:
-        t_iter = None  # lockstep summaries are per launch of one path depth; not comparable here
+        t_iter, why_not = None, "lockstep summaries are per launch of one path depth"
     traffic_bytes = t_iter * iters_per_launch if t_iter is not None else None
     records = d["nodes_closest"] + d["leaves_closest"] + d["nodes_any"] + d["leaves_any"]
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1) if traffic_bytes else None,
-            "traffic_bytes_per_launch": traffic_bytes, "traffic_source": src, "kernel": kernel, "avg_launch_ms": round(avg_ms, 4),
+            "traffic_bytes_per_launch": traffic_bytes, "traffic_source": src, "traffic_unavailable": why_not, "kernel": kernel, "avg_launch_ms": round(avg_ms, 4),
             "launches": n, "iterations_per_launch": iters_per_launch, "algorithmic_bytes_per_launch": round(alg_bytes),
             "algorithmic_bytes_per_closest_ray": round(bytes_closest / max(d["rays_closest"], 1), 1),
             "algorithmic_bytes_per_occlusion_ray": round(bytes_any / max(d["rays_any"], 1), 1),

@@ -437,6 +437,22 @@ def test_reduce_one_rank_noop_and_a_real_rccl_communicator(monkeypatch):
     real.close()
 
 
+@pytest.mark.parametrize("config", ["C2", "C3", "C3b"])
+def test_baseline_configs_at_full_resolution(config):
+    """BASELINE configs C2 (sphere + area light 512x512, mjitt 64 spp schedule), C3 (cornellbox 1024x1024, mjitt 256 spp schedule) and
+    C3b (evaluation scene 256x256, sobol 128 spp schedule) at FULL resolution, the first iterations of their schedule against the
+    checker: hit ids, frame, sample and feedback planes, statistics identical."""
+    if config == "C2":
+        sc, iters = scene.sphere_light(512, 512, spp=64), 3
+    elif config == "C3":
+        sc, iters = scene.cornell_box(1024, 1024, spp=256), 2
+    else:
+        sc, iters = scene.cbox_eval(256, 256, spp=128), 6
+    g, o = render_both(sc, iters=iters, threads=16)
+    assert_parity(g, o, exact=True)
+    assert g.statistics()["pixel_samples"] == sc.width * sc.height * iters
+
+
 def test_full_size_properties_1m_triangles():
     """BASELINE C4 geometry at full triangle count: size-independent properties instead of an oracle render --
     hit ids of 20k rays against the oracle BVH, energy bound, determinism, sample plane == spp on hit pixels."""

@@ -195,11 +195,14 @@ def test_entity_visibility_flags_are_accepted_and_reported_as_inert():
 def test_every_reference_example_either_loads_or_names_what_is_missing():
     lib = abi.load()
     loaded, refused = [], []
+    table = np.full((256, 512, 11), 0.1, dtype=np.float32)
+    sky = (abi.PrcSky * 1)(abi.PrcSky(None, table.ctypes.data_as(C.POINTER(C.c_float)), 512, 256))
     for name in sorted(os.listdir(REF_EXAMPLES)):
         if not name.endswith(".prc"):
             continue
         h = C.c_void_p()
         opt = abi.PrcOptions(0, 0, 0, 1, 0)
+        opt.n_skies, opt.skies = 1, sky     # any sky light gets this (flat) table: the Hosek-Wilkie evaluation is the host's
         rc = lib.prgpu_prc_load_file(os.path.join(REF_EXAMPLES, name).encode(), C.byref(opt), C.byref(h))
         if rc == 0:
             loaded.append(name)
@@ -209,7 +212,7 @@ def test_every_reference_example_either_loads_or_names_what_is_missing():
             msg = lib.prgpu_prc_last_error().decode()
             assert "not supported" in msg or "not available" in msg or "needs the table" in msg, name
             refused.append(name)
-    assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and len(loaded) >= 12
+    assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and "complex.prc" in loaded and "material_array.prc" in loaded and len(loaded) >= 14
 
 
 def test_obj_embed_semantics(tmp_path):

@@ -1,4 +1,4 @@
-"""Turn a tools/gpu_profile_r01.sh run (gpurun_out/TAG_*) into the committed artefacts profiles/TAG_kernel_stats.csv and
+"""Turn a tools/gpu_profile.sh run (gpurun_out/TAG_*) into the committed artefacts profiles/TAG_kernel_stats.csv and
 profiles/TAG_pmc_summary.json.  usage: profile_to_summary.py TAG ITERS_PMC   (ITERS_PMC = iterations rendered in each --pmc pass)"""
 import collections, csv, glob, json, os, shutil, sys
 tag, iters = sys.argv[1], int(sys.argv[2])
@@ -24,8 +24,10 @@ for sub in ("fetch", "write", "l2", "sq"):
             o[c + "_per_launch"] = v / len(n[k])
             o[c + "_per_iteration"] = v / iters
         o["launches_" + sub] = len(n[k])
-json.dump({"command": "rocprofv3 --pmc <counter set> --kernel-trace -- python3 bench.py --steps %d --warmup 1 --profile-only "
-                      "(one pass per counter set; tools/gpu_profile_r01.sh)" % (iters - 1),
+sys.path.insert(0, root)
+import bench  # noqa: E402  (kernel_source_sha16: bench.py quotes a summary only for the build it was taken from)
+json.dump({"kernel_source_sha16": bench.kernel_source_sha16(), "command": "rocprofv3 --pmc <counter set> --kernel-trace -- python3 bench.py --steps %d --warmup 1 --profile-only "
+                      "(one pass per counter set; tools/gpu_profile.sh)" % (iters - 1),
            "iterations_per_pass": iters,
            "note": "FETCH_SIZE/WRITE_SIZE in KiB as reported by rocprofv3; FETCH_SIZE under-reports wide reads by 2x on gfx950 "
                    "(MI355X_MICROARCH.md, HBM); *_per_iteration = total over the pass / iterations rendered (raygen-to-fold of every pixel once)",
