@@ -1,0 +1,21 @@
+"""Render exactly N iterations of a named scene (no checks, no instrumentation): the program rocprofv3 wraps for the scenes bench.py
+does not cover.  usage: python3 tools/profile_scene.py c5|rough|metal_all N"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pearray_amd import backend, scene
+
+name, iters = sys.argv[1], int(sys.argv[2])
+if name == "c5":
+    sc = scene.ArrayScene(os.path.join(ROOT, "tests", "golden", "scenes", "complex_c5.npz"), sky_tables=[scene.synthetic_sky_table()])
+elif name == "rough":
+    sc = scene.cornell_rough(1024, 1024, spp=256, roughness=0.2, vndf=True)
+elif name == "metal_all":
+    os.environ["PRGPU_FORCE_FEATURES"] = "255"
+    sc = scene.cornell_metal(1024, 1024, spp=256)
+else:
+    raise SystemExit("unknown scene")
+ctx = backend.RenderContext(sc)
+ctx.render(iters)
+ctx.waitForFinish()
+print("rendered %d iterations of %s: %s" % (iters, name, ctx.statistics()))

@@ -8,7 +8,7 @@ stats = glob.glob(base + "trace/*/*_kernel_stats.csv")
 if stats:
     shutil.copy(stats[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 out = collections.OrderedDict()
-for sub in ("fetch", "write", "l2", "sq"):
+for sub in ("fetch", "write", "l2", "sq", "ta", "tcp"):
     fs = glob.glob(base + sub + "/*/*_counter_collection.csv")
     if not fs:
         continue
