@@ -33,6 +33,11 @@ if which == "small":
     compare("cornell 256x256 x16", scene.cornell_box(256, 256, spp=16), 16)
     compare("soup20k 320x200 x8", scene.cornell_soup(320, 200, spp=8, n_triangles=20_000), 8)
     compare("sphere 128x128 x8", scene.sphere_light(128, 128, spp=8), 8)
+elif which == "filters":
+    from pearray_amd import _cabi as abi
+    W, H = 1920, 1080
+    for flt, r, name in ((abi.FILTER_GAUSSIAN, 2, "gaussian r=2"), (abi.FILTER_MITCHELL, 3, "mitchell r=3"), (abi.FILTER_TRIANGLE, 1, "triangle r=1")):
+        compare("C4 full frame, %s x16" % name, scene.cornell_soup(W, H, spp=1024, n_triangles=1_000_000, filter=flt, filter_radius=r), 16, warm=2)
 else:
     W, H = 1920, 1080
     sc = scene.cornell_soup(W, H, spp=1024, n_triangles=1_000_000)
