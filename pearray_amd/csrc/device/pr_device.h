@@ -82,6 +82,26 @@ struct DevShapeLight {
 	float radius;	 // sphere: local radius
 	float pad[2];
 };
+// One record per AREA light (light id order) with everything next event estimation needs about a mesh light, so that sampling a
+// light point is two dependent fetches (this record, then the light triangle's record) instead of the walk light id -> entity ->
+// index buffer -> vertex / normal buffers; 128 bytes = one L2 line.  Values are copies: the arithmetic on them is unchanged.
+struct __attribute__((aligned(128))) DevLight {
+	float m[12];  // rows 0..2 of the entity transform
+	float nm[9];  // normal matrix
+	uint32_t entity, kind, n_tris, tri_offset; // tri_offset: first record of the light's triangles in DevScene::light_tris
+	uint32_t has_normals, radiance;			   // radiance: spectrum node of the emission
+	float vol_scale;
+	prgpu_spectrum node, lhs, rhs; // copies of the radiance node and, for a product node, of its two operands
+	uint32_t pad[3];
+};
+static_assert(sizeof(DevLight) == 256, "DevLight must be two 128-byte lines");
+// A material with a copy of its albedo / specularity node next to it (one fetch instead of material -> node)
+struct __attribute__((aligned(128))) DevMaterial {
+	prgpu_material m;
+	prgpu_spectrum albedo; // copy of spectra[m.albedo]; a product node still fetches its operands
+};
+static_assert(sizeof(DevMaterial) == 128, "DevMaterial must be one 128-byte line");
+constexpr uint32_t LIGHT_TRI_FLOATS = 20; // per light triangle: local positions p0 p1 p2 (9), vertex normals n0 n1 n2 (9, zero without normals), 2 pad
 constexpr uint32_t PRIM_SPHERE_BIT = 0x40000000u; // leaf records: the primitive in this slot is an analytic sphere (centre, radius), not a triangle
 
 // Infinite light (include/prgpu.h prgpu_light) with the matrices the kernels need
@@ -118,11 +138,13 @@ struct DevScene {
 	const uint32_t* tri_entity;
 	const uint8_t* tri_class; // material class of every triangle (0: no rough / principled closure, 1: rough or principled), the bin of the persistent kernel's shade queues
 	const DevEntity* entities;
-	const prgpu_material* materials;
+	const DevMaterial* materials;
 	const prgpu_emission* emissions;
 	const prgpu_spectrum* spectra;
 	const float* tables;
 	const uint32_t* light_entity;
+	const DevLight* lights;	 // per area light (light id order)
+	const float* light_tris; // LIGHT_TRI_FLOATS per triangle of every mesh light
 	const float* light_cdf;
 	uint32_t n_lights; // area lights; the infinite lights follow them in light_cdf
 	const DevInfLight* inf_lights;

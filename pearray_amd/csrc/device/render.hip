@@ -373,6 +373,20 @@ __device__ __forceinline__ Blob spectrum_eval(const DevScene& sc, uint32_t id, c
 	return spectrum_leaf(sc, n, wl);
 }
 
+// the same for a node (and the operands of a product node) already in registers: DevLight / DevMaterial carry copies
+__device__ __forceinline__ Blob spectrum_eval_copy(const DevScene& sc, const prgpu_spectrum& n, const prgpu_spectrum& lhs, const prgpu_spectrum& rhs, const Blob& wl)
+{
+	if (n.kind == PRGPU_SPEC_MUL)
+		return spectrum_leaf(sc, lhs, wl) * spectrum_leaf(sc, rhs, wl);
+	return spectrum_leaf(sc, n, wl);
+}
+// albedo / specularity of a material: the copy next to the material unless a texture resolved the parameter to another node
+__device__ __forceinline__ Blob albedo_eval(const DevScene& sc, const prgpu_material& mat, const prgpu_spectrum& copy, uint32_t copy_id, const Blob& wl)
+{
+	if (mat.albedo != copy_id || copy.kind == PRGPU_SPEC_MUL)
+		return spectrum_eval(sc, mat.albedo, wl);
+	return spectrum_leaf(sc, copy, wl);
+}
 // CheckerboardNode::eval (CheckerboardNode.cpp:26-48): a textured material parameter resolves to the plain node of the uv cell
 __device__ __forceinline__ uint32_t resolve_texture(const DevScene& sc, uint32_t id, const float uv[2])
 {
@@ -1165,7 +1179,7 @@ static __device__ PR_CLOSURE void rough_eval(const DevScene& s, const prgpu_mate
 }
 // IMaterial::eval for next event estimation: LambertMaterial::eval (lambert.cpp:33-42) inline, the rough closures out of line
 template <uint32_t FEATS>
-__device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_material& mat, const Blob& wl, const Blob& cie_y, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
+__device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_material& mat, const Blob& albedo, const Blob& wl, const Blob& cie_y, V3 Vt, V3 Lt, Blob& weight, Blob& pdf, bool& delta)
 {
 	if ((FEATS & FEAT_ROUGH_MATERIALS) && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED)) {
 		rough_eval(s, mat, wl, cie_y, Vt, Lt, weight, pdf, delta);
@@ -1174,7 +1188,7 @@ __device__ __forceinline__ void material_eval(const DevScene& s, const prgpu_mat
 	delta			= false;
 	const bool same = signbit(Vt.z) == signbit(Lt.z);
 	const float dt	= same ? (mat.two_sided ? fabsf(Lt.z) : fmaxf(0.0f, Lt.z)) : 0.0f;
-	weight			= (spectrum_eval(s, mat.albedo, wl) * dt) * PR_INV_PI_F;
+	weight			= (albedo * dt) * PR_INV_PI_F;
 	pdf				= blob(dt * PR_INV_PI_F);
 }
 // RoughConductorMaterial::sample (roughconductor.cpp:83-117), RoughDielectricMaterial::sample (roughdielectric.cpp:222-254)
@@ -1465,7 +1479,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		if (gp.material == INVALID)
 			go_on = false;
 		if (go_on) {
-			prgpu_material mat = sc.materials[gp.material];
+			const DevMaterial& dmat = sc.materials[gp.material];
+			prgpu_material mat		= dmat.m;
 			if ((FEATS & FEAT_TEXTURES) && (sc.features & FEAT_TEXTURES)) { // ShadingContext::UV driven nodes
 				mat.albedo		 = resolve_texture(sc, mat.albedo, gp.uv);
 				mat.ior			 = resolve_texture(sc, mat.ior, gp.uv);
@@ -1477,11 +1492,20 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 			const bool deltaMat		 = (FEATS & FEAT_DELTA_MATERIALS) && (mat.kind == PRGPU_MAT_DIELECTRIC || mat.kind == PRGPU_MAT_CONDUCTOR || mat.kind == PRGPU_MAT_MIRROR); // IMaterial::hasOnlyDeltaDistribution
 			const bool roughMat		 = (FEATS & FEAT_ROUGH_MATERIALS) && (mat.kind == PRGPU_MAT_ROUGH_CONDUCTOR || mat.kind == PRGPU_MAT_ROUGH_DIELECTRIC || mat.kind == PRGPU_MAT_PRINCIPLED);
 			const Blob cie_y_blob	 = blob4(cie.y[0], cie.y[1], cie.y[2], cie.y[3]);
+			// albedo / specularity at the path's wavelengths, once: IMaterial::eval and ::sample of a vertex evaluate the same node at
+			// the same wavelengths (lambert.cpp:38,66; mirror / conductor / dielectric sample).  The rough closures fetch their own.
+			const Blob albedo_v = roughMat ? blob(0) : albedo_eval(sc, mat, dmat.albedo, dmat.m.albedo, wl);
 			if (cfg.nee && !deltaMat && !hasEmission && (sc.n_lights + ((FEATS & FEAT_INFINITE_LIGHTS) ? sc.n_inf_lights : 0u))) { // direct.cpp:100-101
 				// ---- handleNEE
 				do {
 					float selPdf;
-					const uint32_t lid = distribution_sample_discrete(sc.light_cdf, sc.n_lights + ((FEATS & FEAT_INFINITE_LIGHTS) ? sc.n_inf_lights : 0u) + 1, rng_float(rnd), selPdf, nullptr);
+					const uint32_t n_sel = sc.n_lights + ((FEATS & FEAT_INFINITE_LIGHTS) ? sc.n_inf_lights : 0u);
+					const float u_sel	 = rng_float(rnd);
+					uint32_t lid		 = 0;
+					if (n_sel == 1) // one light: cdf = {0, 1}, the search returns entry 0 with pdf 1 - 0 whatever u is
+						selPdf = 1.0f;
+					else
+						lid = distribution_sample_discrete(sc.light_cdf, n_sel + 1, u_sel, selPdf, nullptr);
 					if ((FEATS & FEAT_INFINITE_LIGHTS) && lid >= sc.n_lights) {
 						// ---- infinite light: Light::sample (Light.cpp:112-150) + the isInfinite branches of handleNEE
 						const DevInfLight& il = sc.inf_lights[lid - sc.n_lights];
@@ -1503,7 +1527,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
 						Blob weight, bsdf_pdf;
 						bool evalDelta;
-						material_eval<FEATS>(sc, mat, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
+						material_eval<FEATS>(sc, mat, albedo_v, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
 						if (evalDelta) // direct.cpp:269-270
 							break;
 						const Blob bsdfWvlPdfS = bsdf_pdf * hf;
@@ -1552,8 +1576,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						}
 						break;
 					}
-					const uint32_t le  = sc.light_entity[lid];
-					const DevEntity& LE = sc.entities[le];
+					const DevLight& LE = sc.lights[lid]; // one 128-byte record instead of light id -> entity id -> entity
+					const uint32_t le  = LE.entity;
 					const float u0 = rng_float(rnd), u1 = rng_float(rnd); // in.RND.get2D() (Light.cpp:161-162)
 					V3 lp;
 					float pdf_a;
@@ -1570,9 +1594,9 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						const float f0		= modff(u0 * LE.n_tris, &k0);
 						const float f1		= modff(u1 * LE.n_tris, &k1);
 						const uint32_t face = min((uint32_t)k0, LE.n_tris - 1);
-						const uint32_t ltri = LE.first_tri + face;
-						const uint32_t i0 = sc.indices[3 * ltri], i1 = sc.indices[3 * ltri + 1], i2 = sc.indices[3 * ltri + 2];
-						const V3 p0 = load3(sc.positions, i0), p1 = load3(sc.positions, i1), p2 = load3(sc.positions, i2);
+						// the light triangle's record: local positions and vertex normals (copies of the mesh buffers' values)
+						const float* lt = sc.light_tris + size_t(LE.tri_offset + face) * LIGHT_TRI_FLOATS;
+						const V3 p0 = v3(lt[0], lt[1], lt[2]), p1 = v3(lt[3], lt[4], lt[5]), p2 = v3(lt[6], lt[7], lt[8]);
 						const V3 ee		 = cross(p1 - p0, p2 - p0);
 						const float area = 0.5f * sqrtf(dot(ee, ee));
 						pdf_a			 = 1.0f / (LE.n_tris * area * LE.vol_scale);
@@ -1587,11 +1611,18 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 							bv = y;
 						}
 						lp = affine_mul(LE.m, tri_interp(p0, p1, p2, bu, bv));
-						geometry_point<FEATS>(sc, ltri, bu, bv, lp, lgp);
+						// the normal of MeshEntity::provideGeometryPoint (mesh.cpp:205-250): interpolated vertex normals, or the edge
+						// cross product of meshes without normals, through the normal matrix -- the arithmetic of geometry_point()
+						V3 Nl;
+						if (LE.has_normals)
+							Nl = tri_interp(v3(lt[9], lt[10], lt[11]), v3(lt[12], lt[13], lt[14]), v3(lt[15], lt[16], lt[17]), bu, bv);
+						else
+							Nl = cross(p1 - p0, p2 - p0);
+						lgp.N = normalized(mat3_mul(LE.nm, Nl));
 					}
 					const V3 L			 = normalized(lp - P);
 					const float cosLight = fminf(1.0f, fmaxf(-1.0f, -dot(L, lgp.N)));
-					const Blob radiance	 = spectrum_eval(sc, sc.emissions[LE.emission].radiance, wl);
+					const Blob radiance	 = spectrum_eval_copy(sc, LE.node, LE.lhs, LE.rhs, wl);
 					const V3 dLP		 = lp - P;
 					const float sqrD	 = dot(dLP, dLP);
 					const float cosC	 = fabsf(dot(L, N));
@@ -1601,7 +1632,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const V3 Lt = to_tangent_space(N, gp.Nx, gp.Ny, L);
 					Blob weight, bsdf_pdf;
 					bool evalDelta;
-					material_eval<FEATS>(sc, mat, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
+					material_eval<FEATS>(sc, mat, albedo_v, wl, cie_y_blob, Vt, Lt, weight, bsdf_pdf, evalDelta);
 					if (evalDelta) // direct.cpp:269-270
 						break;
 					const Blob bsdfWvlPdfS = bsdf_pdf * hf;
@@ -1666,7 +1697,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				} else if ((FEATS & FEAT_DELTA_MATERIALS) && mat.kind == PRGPU_MAT_MIRROR) {
 					// MirrorMaterial::sample (mirror.cpp:51-60)
 					pdf_s			= blob(1);
-					integral_weight = spectrum_eval(sc, mat.albedo, wl);
+					integral_weight = albedo_v;
 					Lt				= v3(-Vt.x, -Vt.y, Vt.z);
 				} else if ((FEATS & FEAT_DELTA_MATERIALS) && mat.kind == PRGPU_MAT_CONDUCTOR) {
 					// ConductorMaterial::sample (conductor.cpp:54-71): mirror, per-wavelength Fresnel term, no random number
@@ -1675,7 +1706,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					Blob fresnel;
 					for (int i = 0; i < 4; ++i)
 						fresnel.v[i] = fresnel_conductor(fabsf(Vt.z), 1.0f, eta.v[i], kk.v[i]);
-					integral_weight = fresnel * spectrum_eval(sc, mat.albedo, wl);
+					integral_weight = fresnel * albedo_v;
 					Lt				= v3(-Vt.x, -Vt.y, Vt.z);
 					heroCollapsing	= sc.spectra[mat.ior].kind == PRGPU_SPEC_SELLMEIER || sc.spectra[mat.k].kind == PRGPU_SPEC_SELLMEIER;
 				} else if (deltaMat) {
@@ -1685,7 +1716,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					float F		  = fresnel_dielectric(Vt.z, DIELECTRIC_AIR, n2.v[0]);
 					if (mat.thin && F < 1.0f)
 						F += (1 - F) * F / (F + 1);
-					const Blob rWeight = spectrum_eval(sc, mat.albedo, wl);
+					const Blob rWeight = albedo_v;
 					if (rng_float(rnd) <= F) {
 						Lt				= v3(-Vt.x, -Vt.y, Vt.z);
 						integral_weight = rWeight;
@@ -1707,7 +1738,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				} else {
 					const float s1 = rng_float(rnd), s2 = rng_float(rnd);
 					Lt				= cos_hemi(s1, s2);
-					integral_weight = spectrum_eval(sc, mat.albedo, wl);
+					integral_weight = albedo_v;
 					pdf_s			= blob(Lt.z * PR_INV_PI_F);
 					if (signbit(Vt.z) != signbit(Lt.z))
 						Lt = -Lt;

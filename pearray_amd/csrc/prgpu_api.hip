@@ -273,12 +273,65 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		UP(sc.tri_class, cls);
 	}
 	UP(sc.entities, t.entities);
-	UP(sc.materials, d->materials, d->n_materials);
+	{
+		std::vector<prd::DevMaterial> mats(std::max<uint32_t>(1, d->n_materials));
+		std::memset(mats.data(), 0, mats.size() * sizeof(prd::DevMaterial));
+		for (uint32_t i = 0; i < d->n_materials; ++i) {
+			mats[i].m	   = d->materials[i];
+			mats[i].albedo = d->spectra[d->materials[i].albedo];
+		}
+		UP(sc.materials, mats);
+	}
 	UP(sc.emissions, d->emissions, d->n_emissions);
 	UP(sc.spectra, d->spectra, d->n_spectra);
 	UP(sc.tables, d->spectral_tables, d->n_spectral_table_values);
 	UP(sc.light_entity, t.light_entity);
 	UP(sc.light_cdf, t.light_cdf);
+	{ // flattened area-light records (DevLight + one record per light triangle)
+		std::vector<prd::DevLight> lights;
+		std::vector<float> ltris;
+		for (uint32_t e : t.light_entity) {
+			if (e >= d->n_entities || d->entities[e].emission == PRGPU_INVALID_ID)
+				continue;
+			const prd::DevEntity& E = t.entities[e];
+			prd::DevLight L;
+			std::memset(&L, 0, sizeof(L));
+			std::memcpy(L.m, E.m, sizeof(L.m));
+			std::memcpy(L.nm, E.nm, sizeof(L.nm));
+			L.entity	  = e;
+			L.kind		  = E.kind;
+			L.n_tris	  = E.n_tris;
+			L.tri_offset  = (uint32_t)(ltris.size() / prd::LIGHT_TRI_FLOATS);
+			L.has_normals = E.has_normals;
+			L.radiance	  = d->emissions[E.emission].radiance;
+			L.node		  = d->spectra[L.radiance];
+			if (L.node.kind == PRGPU_SPEC_MUL) {
+				L.lhs = d->spectra[L.node.lhs];
+				L.rhs = d->spectra[L.node.rhs];
+			}
+			L.vol_scale	  = E.vol_scale;
+			if (E.kind == PRGPU_ENTITY_MESH) {
+				for (uint32_t k = 0; k < E.n_tris; ++k) {
+					const uint32_t* idx = d->indices + 3 * size_t(E.first_tri + k);
+					float rec[prd::LIGHT_TRI_FLOATS] = { 0 };
+					for (int v = 0; v < 3; ++v)
+						for (int c = 0; c < 3; ++c) {
+							rec[3 * v + c] = d->positions[3 * size_t(idx[v]) + c];
+							if (E.has_normals && d->normals)
+								rec[9 + 3 * v + c] = d->normals[3 * size_t(idx[v]) + c];
+						}
+					ltris.insert(ltris.end(), rec, rec + prd::LIGHT_TRI_FLOATS);
+				}
+			}
+			lights.push_back(L);
+		}
+		if (lights.empty())
+			lights.resize(1);
+		if (ltris.empty())
+			ltris.assign(prd::LIGHT_TRI_FLOATS, 0.0f);
+		UP(sc.lights, lights);
+		UP(sc.light_tris, ltris);
+	}
 	{
 		std::vector<prd::DevInfLight> il = t.inf_lights;
 		if (il.empty())
