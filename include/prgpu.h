@@ -218,7 +218,11 @@ enum { PRGPU_MAPPER_SPD_CMIS = 0, PRGPU_MAPPER_RANDOM = 1, PRGPU_MAPPER_SPD_HERO
        PRGPU_MAPPER_CIE = 3,     /* spectralmapper/cie.cpp: each wavelength drawn from the X+Y+Z CDF (CIE.h:97-101), truncated to the
                                     spectral range when it lies inside the CIE domain (CIE.h:110-118); a range reaching outside the
                                     CIE domain is PRGPU_EINVAL (the reference factory returns no mapper, cie.cpp:93-102) */
-       PRGPU_MAPPER_CIE_Y = 4 }; /* the same with the Y-only CDF ('cie_y', 'visible_y' or :only_y true, cie.cpp:109-113) */
+       PRGPU_MAPPER_CIE_Y = 4,   /* the same with the Y-only CDF ('cie_y', 'visible_y' or :only_y true, cie.cpp:109-113) */
+       PRGPU_MAPPER_AGH_CMIS = 5, /* spectralmapper/agh.cpp:37-82: wavelengths drawn from sech^2(A (l - B)), A = 0.0072, B = 538 nm (Radziszewski et
+                                     al., "An Improved Technique for Full Spectral Rendering"), four independent draws; exp / log through the
+                                     backend's shared fp32 forms */
+       PRGPU_MAPPER_AGH_HERO = 6 }; /* :cmis false (agh.cpp:84-124): one draw, rotated hero wavelengths */
 enum { PRGPU_FILTER_BLOCK = 0, PRGPU_FILTER_TRIANGLE = 1, PRGPU_FILTER_GAUSSIAN = 2,
        PRGPU_FILTER_MITCHELL = 3, PRGPU_FILTER_LANCZOS = 4 }; /* src/plugins/main/filter/ */
 enum { PRGPU_MIS_BALANCE = 0, PRGPU_MIS_POWER = 1 };
@@ -304,6 +308,10 @@ void prgpu_settings_default(prgpu_settings* s); /* reference defaults, see struc
 /* (refl r g b)/(illum r g b) node creation: Jakob-Hanika sigmoid-polynomial coefficients for an
  * sRGB colour (replaces the srgb.coeff table lookup, SpectralUpsampler.cpp:78-146). Host only. */
 int  prgpu_rgb_to_coeffs(const float rgb[3], float coeffs[3]);
+/* The whole lookup table as a file PearRay can load in place of its (missing) src/loader/embed/srgb.coeff: "SPEC", u32 resolution,
+ * `resolution` floats of scale, 3 * resolution^3 * 3 floats of coefficients (SpectralUpsampler.cpp:15-37; 64 is the reference's
+ * resolution, 9.4 MB and 786 k fits -- about a minute on 8 threads).  prgpu_rgb_to_coeffs is `convert` (:78-146) on that table. */
+int  prgpu_write_rgb_coeff_table(const char* path, uint32_t resolution, int threads);
 
 /* -- scene -------------------------------------------------------------------------------- */
 /* Validates + uploads the scene to HIP device `device`, builds the two-level LBVH on the device,

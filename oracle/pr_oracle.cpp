@@ -340,6 +340,73 @@ inline float atan2_fp32(float y, float x)
 	return y < 0.0f ? a - 3.14159265358979323846f : a + 3.14159265358979323846f;
 }
 
+// exp / log through fp32 operations only (Cephes expf / logf), standing in for the std::atanh / std::cosh of the agh spectral mapper
+// (agh.cpp:27-36) so that CPU and GPU agree bit for bit (~1 ulp from libm)
+inline float exp_fp32(float x)
+{
+	x			  = std::min(88.0f, std::max(-87.0f, x));
+	const float n = std::floor(1.44269504088896341f * x + 0.5f);
+	x			  = x - n * 0.693359375f;
+	x			  = x - n * -2.12194440e-4f;
+	const float z = x * x;
+	float p		  = 1.9875691500e-4f;
+	p			  = p * x + 1.3981999507e-3f;
+	p			  = p * x + 8.3334519073e-3f;
+	p			  = p * x + 4.1665795894e-2f;
+	p			  = p * x + 1.6666665459e-1f;
+	p			  = p * x + 5.0000001201e-1f;
+	const float r = (p * z + x) + 1.0f;
+	const uint32_t sb = (uint32_t)((int)n + 127) << 23;
+	float scale;
+	std::memcpy(&scale, &sb, 4);
+	return r * scale;
+}
+inline float log_fp32(float x) // x > 0, normal
+{
+	uint32_t bits;
+	std::memcpy(&bits, &x, 4);
+	int e			  = (int)((bits >> 23) & 0xFFu) - 126;
+	const uint32_t mb = (bits & 0x007FFFFFu) | 0x3F000000u;
+	float m;
+	std::memcpy(&m, &mb, 4); // [0.5, 1)
+	if (m < 0.707106781186547524f) {
+		e -= 1;
+		m = (m + m) - 1.0f;
+	} else {
+		m = m - 1.0f;
+	}
+	const float z = m * m;
+	float p		  = 7.0376836292e-2f;
+	p			  = p * m - 1.1514610310e-1f;
+	p			  = p * m + 1.1676998740e-1f;
+	p			  = p * m - 1.2420140846e-1f;
+	p			  = p * m + 1.4249322787e-1f;
+	p			  = p * m - 1.6668057665e-1f;
+	p			  = p * m + 2.0000714765e-1f;
+	p			  = p * m - 2.4999993993e-1f;
+	p			  = p * m + 3.3333331174e-1f;
+	float y		   = (p * m) * z;
+	const float fe = (float)e;
+	y			   = y + -2.12194440e-4f * fe;
+	y			   = y - 0.5f * z;
+	float r		   = m + y;
+	r			   = r + 0.693359375f * fe;
+	return r;
+}
+// spectralmapper/agh.cpp:17-36: sech^2 shaped wavelength density, AStd = 0.0072, BStd = 538
+constexpr float AGH_A = 0.0072f, AGH_B = 538.0f;
+inline float agh_sample(float u, float N, float C)
+{
+	const float y = C - N * u;
+	return AGH_B - (0.5f * log_fp32((1.0f + y) / (1.0f - y))) / AGH_A; // B - atanh(C - N u) / A
+}
+inline float agh_pdf(float lambda, float N)
+{
+	const float e = exp_fp32(AGH_A * (lambda - AGH_B));
+	const float K = 0.5f * (e + 1.0f / e); // cosh(A (lambda - B))
+	return 1 / (K * K * N);
+}
+
 // base/math/Sampling.h:38-57 cos_hemi
 inline V3 cos_hemi(float u1, float u2)
 {
@@ -851,6 +918,7 @@ struct Scene {
 	// wavelength distribution (spd mapper)
 	std::vector<float> wl_cdf;
 	float wl_cdf_start = 0.0f, wl_cdf_end = 1.0f; // cie mapper truncation window
+	float agh_c = 0.0f, agh_n = 1.0f;			   // agh mapper: mCameraC, mCameraN
 	// integrator
 	std::vector<float> rr_prob; // by path length
 	std::vector<float> filter;
@@ -2086,6 +2154,13 @@ int setup_lights(Scene& s)
 // complete sampling floor 1e-2)
 void setup_wavelengths(Scene& s)
 {
+	if (s.cfg.mapper == PRGPU_MAPPER_AGH_CMIS || s.cfg.mapper == PRGPU_MAPPER_AGH_HERO) { // ctor, agh.cpp:44-45 (libm tanh, once)
+		s.agh_c = std::tanh(AGH_A * (AGH_B - s.cfg.spectral_start));
+		s.agh_n = std::tanh(AGH_A * (AGH_B - s.cfg.spectral_start)) - std::tanh(AGH_A * (AGH_B - s.cfg.spectral_end));
+		s.wl_cdf.assign(2, 0.0f);
+		s.wl_cdf[1] = 1.0f;
+		return;
+	}
 	if (s.cfg.mapper == PRGPU_MAPPER_CIE || s.cfg.mapper == PRGPU_MAPPER_CIE_Y) {
 		// StaticCDF (Distribution1D.h:13-46) over NM_TO_Y or NM_TO_X+Y+Z (CIE.cpp:431-433)
 		const uint32_t n = CIE_SAMPLES;
@@ -2831,6 +2906,19 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		for (int k = 1; k < 4; ++k)
 			wl[k] = cfg.spectral_start + std::fmod(hero - cfg.spectral_start + k * delta, span);
 		wl_pdf = blob(pdf);
+	} else if (cfg.mapper == PRGPU_MAPPER_AGH_CMIS) { // CMISAGHSpectralMapper::sample, agh.cpp:50-57
+		for (int k = 0; k < 4; ++k) {
+			wl[k]	  = agh_sample(rng_float(rnd), s.agh_n, s.agh_c);
+			wl_pdf[k] = agh_pdf(wl[k], s.agh_n);
+		}
+	} else if (cfg.mapper == PRGPU_MAPPER_AGH_HERO) { // HeroAGHSpectralMapper::sample, agh.cpp:98-103
+		const float span  = cfg.spectral_end - cfg.spectral_start;
+		const float hero  = agh_sample(rng_float(rnd), s.agh_n, s.agh_c);
+		const float delta = span / 4;
+		wl[0]			  = hero;
+		for (int k = 1; k < 4; ++k)
+			wl[k] = cfg.spectral_start + std::fmod(hero - cfg.spectral_start + k * delta, span);
+		wl_pdf = blob(agh_pdf(hero, s.agh_n));
 	} else if (cfg.mapper == PRGPU_MAPPER_CIE || cfg.mapper == PRGPU_MAPPER_CIE_Y) {
 		// cie.cpp:59-68 TruncatedCIESpectralMapper::sample -> CIE.h:80-87,110-134 (the full-domain mapper, cie.cpp:21-30, is the
 		// window (0, 1) of the same arithmetic)
@@ -4124,6 +4212,10 @@ void orc_inf_light_sample(orc_scene* h, uint32_t light, float u0, float u1, cons
 	for (int k = 0; k < 4; ++k)
 		radiance[k] = r[k];
 }
+float orc_exp(float x) { return exp_fp32(x); }
+float orc_log(float x) { return log_fp32(x); }
+float orc_agh_sample(float u, float N, float C) { return agh_sample(u, N, C); }
+float orc_agh_pdf(float lambda, float N) { return agh_pdf(lambda, N); }
 float orc_safe_acos(float x) { return safe_acos(x); }
 void orc_sincos_rad(float x, float* s, float* c) { sincos_rad(x, *s, *c); }
 void orc_reflect(const float v[3], float out[3]) // Scattering::reflect(V) in shading space (Scattering.h:69-72)

@@ -115,6 +115,10 @@ void     orc_uniform_cone(float u1, float u2, float cos_theta_max, float out[3])
 void     orc_inf_light_eval(orc_scene* s, uint32_t light, const float dir[3], const float wvl[4], int camera_ray, float radiance[4], float* pdf);
 void     orc_inf_light_sample(orc_scene* s, uint32_t light, float u0, float u1, const float wvl[4], float outgoing[3], float* pdf,
                               float radiance[4]);
+float    orc_exp(float x);                               /* shared fp32 exp / log (agh mapper) */
+float    orc_log(float x);
+float    orc_agh_sample(float u, float N, float C);      /* spectralmapper/agh.cpp:33-36 */
+float    orc_agh_pdf(float lambda, float N);             /* agh.cpp:27-31 */
 float    orc_safe_acos(float x);                       /* shared fp32 acos used by the plane light (plane.cpp:109) */
 void     orc_sincos_rad(float x, float* s, float* c);  /* shared fp32 sin/cos of an angle in radians (plane.cpp:152-153) */
 void     orc_reflect(const float v[3], float out[3]);

@@ -26,7 +26,7 @@ CAMERA_PERSPECTIVE, CAMERA_ORTHO = 0, 1
 AOV_NAMES = ("position", "normal", "normal_g", "tangent", "bitangent", "view", "entity_id", "material_id", "emission_id", "depth")
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_HAMMERSLEY, SAMPLER_UNIFORM, SAMPLER_STRATIFIED = range(7)
-MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO, MAPPER_CIE, MAPPER_CIE_Y = range(5)
+MAPPER_SPD_CMIS, MAPPER_RANDOM, MAPPER_SPD_HERO, MAPPER_CIE, MAPPER_CIE_Y, MAPPER_AGH_CMIS, MAPPER_AGH_HERO = range(7)
 FILTER_BLOCK, FILTER_TRIANGLE, FILTER_GAUSSIAN, FILTER_MITCHELL, FILTER_LANCZOS = range(5)
 MIS_BALANCE, MIS_POWER = range(2)
 
@@ -141,6 +141,7 @@ SYMBOLS = {
     "prgpu_device_count": (C.c_int, []),
     "prgpu_settings_default": (None, [C.POINTER(Settings)]),
     "prgpu_rgb_to_coeffs": (C.c_int, [_F32P, _F32P]),
+    "prgpu_write_rgb_coeff_table": (C.c_int, [C.c_char_p, C.c_uint32, C.c_int]),
     "prgpu_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.c_int, C.POINTER(_VP)]),
     "prgpu_scene_destroy": (None, [_VP]),
     "prgpu_set_tiles": (C.c_int, [_VP, C.POINTER(Tile), C.c_uint32]),

@@ -156,6 +156,7 @@ struct DevScene {
 	const float* wl_cdf;
 	uint32_t wl_cdf_size;
 	float wl_u_offset, wl_u_scale; // cie mapper truncation window (CIE.h:124-134); (0, 1) over the full CIE domain
+	float agh_c, agh_n;			   // agh mapper: tanh(A (B - start)) and its difference to the value at the end of the camera range (agh.cpp:44-45)
 	const float* sobol2d;
 	const float* rr_prob;
 	uint32_t rr_size;
@@ -353,6 +354,66 @@ __device__ __forceinline__ float pr_atan2(float y, float x)
 	if (x > 0.0f)
 		return a;
 	return y < 0.0f ? a - 3.14159265358979323846f : a + 3.14159265358979323846f;
+}
+// exp and log in fp32 operations only (Cephes expf / logf: range reduction + minimax polynomial), shared with the checker: the agh
+// spectral mapper calls std::atanh and std::cosh (agh.cpp:27-36), which differ from these by an ulp or so
+__device__ __forceinline__ float pr_exp(float x)
+{
+	x			  = fminf(88.0f, fmaxf(-87.0f, x));
+	const float n = floorf(1.44269504088896341f * x + 0.5f);
+	x			  = x - n * 0.693359375f;
+	x			  = x - n * -2.12194440e-4f;
+	const float z = x * x;
+	float p		  = 1.9875691500e-4f;
+	p			  = p * x + 1.3981999507e-3f;
+	p			  = p * x + 8.3334519073e-3f;
+	p			  = p * x + 4.1665795894e-2f;
+	p			  = p * x + 1.6666665459e-1f;
+	p			  = p * x + 5.0000001201e-1f;
+	const float r = (p * z + x) + 1.0f;
+	return r * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+__device__ __forceinline__ float pr_log(float x) // x > 0, normal
+{
+	const uint32_t bits = __float_as_uint(x);
+	int e				= (int)((bits >> 23) & 0xFFu) - 126;
+	float m				= __uint_as_float((bits & 0x007FFFFFu) | 0x3F000000u); // [0.5, 1)
+	if (m < 0.707106781186547524f) {
+		e -= 1;
+		m = (m + m) - 1.0f;
+	} else {
+		m = m - 1.0f;
+	}
+	const float z = m * m;
+	float p		  = 7.0376836292e-2f;
+	p			  = p * m - 1.1514610310e-1f;
+	p			  = p * m + 1.1676998740e-1f;
+	p			  = p * m - 1.2420140846e-1f;
+	p			  = p * m + 1.4249322787e-1f;
+	p			  = p * m - 1.6668057665e-1f;
+	p			  = p * m + 2.0000714765e-1f;
+	p			  = p * m - 2.4999993993e-1f;
+	p			  = p * m + 3.3333331174e-1f;
+	float y		  = (p * m) * z;
+	const float fe = (float)e;
+	y			  = y + -2.12194440e-4f * fe;
+	y			  = y - 0.5f * z;
+	float r		  = m + y;
+	r			  = r + 0.693359375f * fe;
+	return r;
+}
+// agh.cpp:17-36 with A = 0.0072, B = 538
+constexpr float AGH_A = 0.0072f, AGH_B = 538.0f;
+__device__ __forceinline__ float agh_sample(float u, float N, float C)
+{
+	const float y = C - N * u;
+	return AGH_B - (0.5f * pr_log((1.0f + y) / (1.0f - y))) / AGH_A; // atanh
+}
+__device__ __forceinline__ float agh_pdf(float lambda, float N)
+{
+	const float e = pr_exp(AGH_A * (lambda - AGH_B));
+	const float K = 0.5f * (e + 1.0f / e); // cosh
+	return 1 / (K * K * N);
 }
 // ElevationAzimuth (skysun/ElevationAzimuth.h): up is +z, elevation in [-pi/2, pi/2], azimuth in [0, 2 pi]
 struct ElAz {

@@ -708,6 +708,19 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 		for (int k = 1; k < 4; ++k)
 			wl.v[k] = cfg.spectral_start + fmodf(hero - cfg.spectral_start + k * delta, span);
 		wl_pdf = blob(pdf);
+	} else if (cfg.mapper == PRGPU_MAPPER_AGH_CMIS) { // agh.cpp:50-57
+		for (int k = 0; k < 4; ++k) {
+			wl.v[k]		= agh_sample(rng_float(rnd), sc.agh_n, sc.agh_c);
+			wl_pdf.v[k] = agh_pdf(wl.v[k], sc.agh_n);
+		}
+	} else if (cfg.mapper == PRGPU_MAPPER_AGH_HERO) { // agh.cpp:98-103 + Standard.h constructHeroWavelength
+		const float span  = cfg.spectral_end - cfg.spectral_start;
+		const float hero  = agh_sample(rng_float(rnd), sc.agh_n, sc.agh_c);
+		const float delta = span / 4;
+		wl.v[0]			  = hero;
+		for (int k = 1; k < 4; ++k)
+			wl.v[k] = cfg.spectral_start + fmodf(hero - cfg.spectral_start + k * delta, span);
+		wl_pdf = blob(agh_pdf(hero, sc.agh_n));
 	} else if (cfg.mapper == PRGPU_MAPPER_CIE || cfg.mapper == PRGPU_MAPPER_CIE_Y) { // cie.cpp:21-30,59-68 over CIE.h:110-134
 		const float span = cfg.spectral_end - cfg.spectral_start;
 		for (int k = 0; k < 4; ++k) {
@@ -2022,6 +2035,7 @@ struct PersistentArgs {
 	uint32_t shader_wave; // 1: the block's last wave only shades (any batch size, never holds rays); the others trace and help
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
 	uint32_t sort_rays;	  // 1: a shading pass queues its rays ordered by direction octant
+	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
 	unsigned long long* gstats;
 };
 
@@ -2251,7 +2265,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			// filled wave takes the majority kind only.  Either way the record is fetched before the branch, so the two kinds'
 			// memory latencies overlap.
 			const bool both		= n_inner + n_leaf < a.both_below;
-			const bool do_inner = both ? n_inner > 0 : n_inner >= n_leaf;
+			const bool do_inner = both ? n_inner > 0 : n_inner * 100 >= n_leaf * a.leaf_bias;
 			const bool go_inner = do_inner && at_inner, go_leaf = (both || !do_inner) && at_leaf;
 			// (Measured and dropped, see DESIGN.md: a cooperative fetch -- eight lanes reading one record's eight chunks, handed over
 			// through an LDS staging buffer: 2x the raw gather rate in tools/micro/gather_bench.hip but 11 % slower here; 4-byte
@@ -2535,6 +2549,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.shader_wave	  = shader_wave ? 1u : 0u;
 	a.shade_help	  = (uint32_t)std::max(64, shade_help);
 	a.sort_rays		  = getenv("PRGPU_PP_SORT") && atoi(getenv("PRGPU_PP_SORT")) != 0 ? 1u : 0u;
+	a.leaf_bias		  = getenv("PRGPU_PP_LEAF_BIAS") ? std::max(1, atoi(getenv("PRGPU_PP_LEAF_BIAS"))) : 100;
 	a.gstats		  = gstats;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks);

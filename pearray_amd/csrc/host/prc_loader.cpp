@@ -464,8 +464,10 @@ struct Loader {
 		} else if (type == "cie" || type == "cie_y" || type == "visible" || type == "visible_y") { // cie.cpp:107-120
 			const bool only_y = type == "cie_y" || type == "visible_y" || get_bool(g, "only_y", false);
 			settings.mapper	  = only_y ? PRGPU_MAPPER_CIE_Y : PRGPU_MAPPER_CIE;
+		} else if (type == "agh") { // agh.cpp:150-157
+			settings.mapper = get_bool(g, "cmis", true) ? PRGPU_MAPPER_AGH_CMIS : PRGPU_MAPPER_AGH_HERO;
 		} else {
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": spectral mapper '" + type + "' is not supported (spd, random, cie, cie_y are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": spectral mapper '" + type + "' is not supported (spd, random, cie, cie_y, agh are)");
 		}
 	}
 	void add_integrator(const Group& g) // SceneLoader.cpp:354-384, direct.cpp:498-512,545-563

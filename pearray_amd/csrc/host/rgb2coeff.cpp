@@ -11,9 +11,14 @@
 //   (Gauss-Newton on the CIELAB residual, Simpson 3/8 quadrature on a 3x refined 5 nm grid).
 // Special cases for black/white follow SpectralUpsampler.cpp:63-76,92-103.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "../tables/pr_tables.inl"
 
@@ -207,6 +212,70 @@ static double smoothstep(double x) { return x * x * (3.0 - 2.0 * x); }
 // does (scale[k] = smoothstep(smoothstep(k/(res-1))), cell corners fitted exactly): the 8 corners of the
 // cell are fitted on demand and interpolated trilinearly, so the result carries the same interpolation
 // error as the reference's table lookup.
+// coefficients of table entry (largest, zi, yi, xi): the colour with component `largest` = scale[zi] and the two others at
+// xi/(res-1), yi/(res-1) of it (the parametrisation `convert` inverts, SpectralUpsampler.cpp:104-119)
+static void table_entry(int res, const float* scale, int largest, int zi, int yi, int xi, float out[3])
+{
+	const double b	= scale[zi];
+	const double gx = double(xi) / (res - 1), gy = double(yi) / (res - 1);
+	double rgb[3], c[3];
+	rgb[largest]		   = b;
+	rgb[(largest + 1) % 3] = gx * b;
+	rgb[(largest + 2) % 3] = gy * b;
+	if (rgb[0] <= 1e-9 && rgb[1] <= 1e-9 && rgb[2] <= 1e-9) {
+		c[0] = c[1] = 0;
+		c[2] = -50.0;
+	} else {
+		fit_exact(rgb, c);
+	}
+	for (int j = 0; j < 3; ++j)
+		out[j] = (float)c[j];
+}
+
+// A coefficient table in the format SpectralUpsampler reads (SpectralUpsampler.cpp:15-37): "SPEC", u32 res, res floats of scale,
+// 3 * res^3 * 3 floats of coefficients indexed (((largest * res + z) * res + y) * res + x) * 3.  `threads` workers fit the entries.
+int write_coeff_table(const char* path, uint32_t res, int threads, std::string& err)
+{
+	if (!path || res < 2 || res > 256) {
+		err = "resolution must be 2..256";
+		return -1;
+	}
+	init_tables(); // before the workers start (not thread safe)
+	std::vector<float> scale(res);
+	for (uint32_t k = 0; k < res; ++k)
+		scale[k] = (float)smoothstep(smoothstep(double(k) / double(res - 1)));
+	std::vector<float> data(size_t(3) * res * res * res * 3);
+	std::atomic<uint32_t> next{ 0 };
+	auto worker = [&]() {
+		for (;;) {
+			const uint32_t job = next.fetch_add(1);
+			if (job >= 3 * res)
+				return;
+			const int l = (int)(job / res), z = (int)(job % res);
+			for (uint32_t y = 0; y < res; ++y)
+				for (uint32_t x = 0; x < res; ++x)
+					table_entry((int)res, scale.data(), l, z, (int)y, (int)x, &data[((((size_t)l * res + z) * res + y) * res + x) * 3]);
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int i = 1; i < std::max(1, threads); ++i)
+		pool.emplace_back(worker);
+	worker();
+	for (auto& t : pool)
+		t.join();
+	FILE* f = std::fopen(path, "wb");
+	if (!f) {
+		err = std::string("cannot open '") + path + "' for writing";
+		return -5;
+	}
+	bool ok = std::fwrite("SPEC", 1, 4, f) == 4 && std::fwrite(&res, 4, 1, f) == 1 && std::fwrite(scale.data(), 4, res, f) == res
+			  && std::fwrite(data.data(), 4, data.size(), f) == data.size();
+	ok = (std::fclose(f) == 0) && ok;
+	if (!ok)
+		err = std::string("short write to '") + path + "'";
+	return ok ? 0 : -5;
+}
+
 void rgb_to_coeffs(const float rgb_in[3], float out[3])
 {
 	const float EPS = 0.0001f; // SpectralUpsampler.cpp:63

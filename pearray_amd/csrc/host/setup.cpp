@@ -631,6 +631,13 @@ void wavelength_table(const prgpu_scene_desc* d, HostTables& t, size_t n_lights)
 		cie_wavelength_table(d, t);
 		return;
 	}
+	if (d->settings.mapper == PRGPU_MAPPER_AGH_CMIS || d->settings.mapper == PRGPU_MAPPER_AGH_HERO) { // agh.cpp:44-45 (host libm, once)
+		t.agh_c = std::tanh(0.0072f * (538.0f - d->settings.spectral_start));
+		t.agh_n = std::tanh(0.0072f * (538.0f - d->settings.spectral_start)) - std::tanh(0.0072f * (538.0f - d->settings.spectral_end));
+		t.wl_cdf.assign(2, 0.0f);
+		t.wl_cdf[1] = 1.0f;
+		return;
+	}
 	const uint32_t bins = 440;
 	const float start = d->settings.spectral_start, span = d->settings.spectral_end - d->settings.spectral_start;
 	auto wavelength_of = [&](uint32_t bin) { return start + (bin / float(bins - 1)) * span; };
@@ -792,7 +799,7 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		return bad("film too large");
 	if (c.filter_radius > 3)
 		return bad("filter radius > 3 is not supported", PRGPU_EUNSUPPORTED);
-	if (c.aa_sampler > PRGPU_SAMPLER_STRATIFIED || ((c.aa_sampler == PRGPU_SAMPLER_HALTON || c.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) && (c.aa_base_x == 1 || c.aa_base_y == 1)) || c.mapper > PRGPU_MAPPER_CIE_Y || c.filter > PRGPU_FILTER_LANCZOS || c.mis > PRGPU_MIS_POWER)
+	if (c.aa_sampler > PRGPU_SAMPLER_STRATIFIED || ((c.aa_sampler == PRGPU_SAMPLER_HALTON || c.aa_sampler == PRGPU_SAMPLER_HAMMERSLEY) && (c.aa_base_x == 1 || c.aa_base_y == 1)) || c.mapper > PRGPU_MAPPER_AGH_HERO || c.filter > PRGPU_FILTER_LANCZOS || c.mis > PRGPU_MIS_POWER)
 		return bad("unknown sampler / mapper / filter / mis selector");
 	if (!c.aa_samples || !c.lens_samples || !c.time_samples || !c.spectral_samples)
 		return bad("sample counts must be positive");

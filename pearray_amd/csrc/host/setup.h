@@ -11,6 +11,7 @@
 namespace prgpu_host {
 
 void rgb_to_coeffs(const float rgb[3], float out[3]);
+int write_coeff_table(const char* path, uint32_t res, int threads, std::string& err); // 0, or a PRGPU_E* code with `err` set
 // sets the message prgpu_last_error() returns on this thread and passes `code` through (defined in prgpu_api.hip)
 int set_last_error(int code, const std::string& msg);
 
@@ -25,6 +26,7 @@ struct HostTables {
 	float scene_radius = 0.0f;
 	std::vector<float> wl_cdf;
 	float wl_u_offset = 0.0f, wl_u_scale = 1.0f; // cie mapper: truncation window inside the CDF (CIE.h:124-134)
+	float agh_c = 0.0f, agh_n = 1.0f;			  // agh mapper: mCameraC, mCameraN (agh.cpp:44-45)
 	std::vector<float> sobol2d; // tabulated AA samples (sobol, halton or hammersley)
 	uint32_t halton_bx = 13, halton_by = 47, halton_burnin = 47;
 	std::vector<float> rr_prob;

@@ -380,6 +380,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.wl_cdf_size	 = (uint32_t)t.wl_cdf.size();
 	sc.wl_u_offset	 = t.wl_u_offset;
 	sc.wl_u_scale	 = t.wl_u_scale;
+	sc.agh_c		 = t.agh_c;
+	sc.agh_n		 = t.agh_n;
 	sc.rr_size		 = (uint32_t)t.rr_prob.size();
 	sc.cam			 = t.cam;
 	sc.cfg			 = d->settings;
@@ -899,6 +901,13 @@ int prgpu_rgb_to_coeffs(const float rgb[3], float coeffs[3])
 			return fail(PRGPU_EINVAL, "rgb must be finite and non-negative");
 	prgpu_host::rgb_to_coeffs(rgb, coeffs);
 	return PRGPU_OK;
+}
+
+int prgpu_write_rgb_coeff_table(const char* path, uint32_t resolution, int threads)
+{
+	std::string err;
+	const int rc = prgpu_host::write_coeff_table(path, resolution, threads, err);
+	return rc == 0 ? PRGPU_OK : fail(rc == -5 ? PRGPU_EIO : PRGPU_EINVAL, "prgpu_write_rgb_coeff_table: " + err);
 }
 
 int prgpu_scene_create(const prgpu_scene_desc* desc, int device, prgpu_scene** out)

@@ -116,6 +116,9 @@ def bind(lib):
     lib.orc_material_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _F32P, _F32P, _F32P, C.POINTER(C.c_int)]
     lib.orc_rough_sample.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _U64P, _F32P, _F32P, _F32P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.orc_set_tile_grid.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    for f, n in (("orc_exp", 1), ("orc_log", 1), ("orc_agh_sample", 3), ("orc_agh_pdf", 2)):
+        getattr(lib, f).restype = C.c_float
+        getattr(lib, f).argtypes = [C.c_float] * n
     lib.orc_atan2.restype = C.c_float
     lib.orc_atan2.argtypes = [C.c_float, C.c_float]
     lib.orc_ea_from_direction.argtypes = [_F32P, _F32P, _F32P]

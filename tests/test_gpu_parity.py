@@ -64,7 +64,8 @@ def test_cornell_c1_bit_exact():
 
 @pytest.mark.parametrize("sampler", [abi.SAMPLER_RANDOM, abi.SAMPLER_MJITT, abi.SAMPLER_SOBOL, abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY,
                                      abi.SAMPLER_UNIFORM, abi.SAMPLER_STRATIFIED])
-@pytest.mark.parametrize("mapper", [abi.MAPPER_SPD_CMIS, abi.MAPPER_RANDOM, abi.MAPPER_SPD_HERO, abi.MAPPER_CIE, abi.MAPPER_CIE_Y])
+@pytest.mark.parametrize("mapper", [abi.MAPPER_SPD_CMIS, abi.MAPPER_RANDOM, abi.MAPPER_SPD_HERO, abi.MAPPER_CIE, abi.MAPPER_CIE_Y, abi.MAPPER_AGH_CMIS,
+                                    abi.MAPPER_AGH_HERO])
 def test_samplers_and_mappers(sampler, mapper):
     g, o = render_both(scene.cornell_box(48, 40, spp=6, sampler=sampler, mapper=mapper))
     assert_parity(g, o, exact=True)

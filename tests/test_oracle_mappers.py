@@ -120,3 +120,31 @@ def test_loader_names():
                               ("visible_y", "", abi.MAPPER_CIE_Y), ("cie", ":only_y true", abi.MAPPER_CIE_Y)]:
         s = scene.PrcScene(source=body % (name, extra))
         assert s.desc.settings.mapper == want
+
+
+def test_agh_mapper_density_and_shared_exp_log():
+    """spectralmapper/agh.cpp: wavelengths follow sech^2(A (l - B)) / N over the camera range; exp / log are the shared fp32 forms."""
+    lib = ob.load()
+    xs = np.linspace(-3.0, 3.0, 601).astype(np.float32)
+    got = np.array([lib.orc_exp(float(x)) for x in xs], dtype=np.float32)
+    assert np.max(np.abs(got - np.exp(xs.astype(np.float64))) / np.spacing(np.exp(xs.astype(np.float64)).astype(np.float32))) <= 2.0
+    ys = np.geomspace(1e-3, 1e3, 601).astype(np.float32)
+    got = np.array([lib.orc_log(float(y)) for y in ys], dtype=np.float32)
+    want = np.log(ys.astype(np.float64))
+    assert np.max(np.abs(got - want)) <= 4e-7 * np.maximum(1.0, np.abs(want)).max()
+    A, B, lo, hi = 0.0072, 538.0, 390.0, 830.0
+    Cc, N = np.tanh(A * (B - lo)), np.tanh(A * (B - lo)) - np.tanh(A * (B - hi))
+    us = (np.arange(2000) + 0.5) / 2000
+    wl = np.array([lib.orc_agh_sample(float(u), float(N), float(Cc)) for u in us])
+    assert wl.min() >= lo - 1e-2 and wl.max() <= hi + 1e-2 and np.all(np.diff(wl) > 0)      # the inverse CDF: monotone from start to end
+    assert np.allclose(wl, B - np.arctanh(Cc - N * us) / A, atol=2e-3)
+    pdf = np.array([lib.orc_agh_pdf(float(x), float(N)) for x in wl])
+    assert np.allclose(pdf, 1 / (np.cosh(A * (wl - B)) ** 2 * N), rtol=1e-5)
+    # d(wavelength)/du = 1 / (A pdf): the reference's pdf omits the factor A ("A already included" in N, agh.cpp:45) -- restated as it is
+    dwl = np.gradient(wl, us)
+    assert np.allclose(dwl[50:-50] * pdf[50:-50] * A, 1.0, rtol=2e-2)
+    for m in (abi.MAPPER_AGH_CMIS, abi.MAPPER_AGH_HERO):
+        o = ob.OracleScene(scene.cornell_box(24, 24, spp=8, mapper=m))
+        o.render(8, threads=4)
+        xyz = o.output()[0]
+        assert np.isfinite(xyz).all() and xyz.mean() > 0.01

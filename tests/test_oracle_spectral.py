@@ -7,6 +7,7 @@ import pytest
 
 import oracle_binding as ob
 from oracle_binding import f32
+from pearray_amd import _cabi as abi
 from pearray_amd import scene
 
 WAVELENGTHS = [532, 615, 346, 720, 416]
@@ -78,3 +79,36 @@ def test_spectral_nodes():
     assert abs(sc.spectra[il].p[3] - 34.0) < 1e-6
     o.lib.orc_spectrum_eval(o.h, il, wl, out)
     assert all(0 <= v <= 34.0 for v in out[:])
+
+
+def test_coefficient_table_file_matches_the_on_demand_lookup(tmp_path):
+    """prgpu_write_rgb_coeff_table writes the SpectralUpsampler format ("SPEC", res, scale, 3 * res^3 * 3 floats,
+    SpectralUpsampler.cpp:15-37).  Its grid at resolution 4 is a sub-grid of the resolution-64 table prgpu_rgb_to_coeffs emulates
+    (k/3 = 21k/63), so entries must equal the on-demand coefficients of the same colours."""
+    import struct
+    lib = abi.load()
+    path = str(tmp_path / "srgb4.coeff")
+    assert lib.prgpu_write_rgb_coeff_table(path.encode(), 4, 4) == 0
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"SPEC" and struct.unpack_from("<I", raw, 4)[0] == 4 and len(raw) == 8 + 4 * 4 + 3 * 4 ** 3 * 3 * 4
+    scale = np.frombuffer(raw, np.float32, 4, 8)
+    sm = lambda x: x * x * (3 - 2 * x)
+    assert np.allclose(scale, [sm(sm(k / 3)) for k in range(4)], atol=1e-7)
+    data = np.frombuffer(raw, np.float32, 3 * 64 * 3, 8 + 16).reshape(3, 4, 4, 4, 3)
+    for largest, z, y, x in [(0, 3, 1, 2), (1, 2, 3, 0), (2, 1, 2, 2), (0, 2, 0, 0), (1, 3, 3, 3)]:
+        rgb = np.zeros(3, np.float32)
+        rgb[largest] = scale[z]
+        rgb[(largest + 1) % 3] = np.float32(x / 3) * scale[z]
+        rgb[(largest + 2) % 3] = np.float32(y / 3) * scale[z]
+        if (rgb >= 1 - 1e-4).all():
+            continue                                     # the white special case of prepare() (SpectralUpsampler.cpp:92-97)
+        src, dst = (C.c_float * 3)(*rgb), (C.c_float * 3)()
+        assert lib.prgpu_rgb_to_coeffs(src, dst) == 0
+        wl = np.linspace(400, 700, 7, dtype=np.float32)
+        a, b = np.empty(7, np.float32), np.empty(7, np.float32)
+        ob.load().orc_upsample_eval(ob.f32(*data[largest, z, y, x]), wl.ctypes.data_as(C.POINTER(C.c_float)), a.ctypes.data_as(C.POINTER(C.c_float)), 7)
+        ob.load().orc_upsample_eval(dst, wl.ctypes.data_as(C.POINTER(C.c_float)), b.ctypes.data_as(C.POINTER(C.c_float)), 7)
+        assert np.allclose(a, b, atol=2e-3), (largest, z, y, x)
+    assert np.allclose(data[0, 0, 1, 1], [0, 0, -50])     # the black row of the table
+    assert lib.prgpu_write_rgb_coeff_table(b"/nonexistent-dir/x.coeff", 4, 1) == -5
+    assert lib.prgpu_write_rgb_coeff_table(path.encode(), 1, 1) == -1

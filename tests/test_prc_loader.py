@@ -126,7 +126,7 @@ def test_defaults_follow_the_reference():
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
     ("(sampler :type 'blue_noise')", -4, "sampler type 'blue_noise'"),
     ("(filter :type 'box3')", -1, "unknown filter type 'box3'"),
-    ("(spectral_mapper :type 'agh')", -4, "spectral mapper 'agh'"),
+    ("(spectral_mapper :type 'wide')", -4, "spectral mapper 'wide'"),
     ("(emission :name 'x' :type 'standard' :radiance (illuminant 'A'))", -4, "illuminant 'a'"),
     ("(material :name 'x' :type 'diffuse' :albedo (perlin 1 2))", -4, "perlin"),
     ("(entity :name 'e2' :type 'mesh' :mesh 'nope' :materials 'm')", -1, "unknown mesh 'nope'"),
@@ -244,7 +244,7 @@ f -4/7/1 -1/8/1 -2/9/1
     # pentagon: indexed, fanned around its first corner
     assert (idx[3:6] - 9).tolist() == [[0, 1, 2], [0, 2, 3], [0, 3, 4]]
     with pytest.raises(abi.PrgpuError) as e:
-        scene.PrcScene(source=MINIMAL % "(embed :loader 'ply' :file 'm.ply')", include_dir=str(tmp_path))
+        scene.PrcScene(source=MINIMAL % "(embed :loader 'stl' :file 'm.stl')", include_dir=str(tmp_path))
     assert e.value.args[1] == -4
 
 
