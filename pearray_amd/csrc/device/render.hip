@@ -2048,24 +2048,25 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	__shared__ PPShared<NQ> sh;
 	constexpr uint32_t RAY_MASK = 2 * PP_SLOTS_MAX - 1, SHADE_MASK = PP_SLOTS_MAX - 1;
 	const uint32_t lane	 = threadIdx.x & 63u;
-	const uint32_t slot0 = blockIdx.x * a.slots_per_block;
+	const uint32_t block_slots = a.slots_per_block;
+	const uint32_t slot0	   = blockIdx.x * block_slots;
 	for (uint32_t i = threadIdx.x; i < 2 * PP_SLOTS_MAX; i += TRAV_BLOCK)
 		sh.q_ray[i] = PP_EMPTY;
 	for (uint32_t i = threadIdx.x; i < PP_SLOTS_MAX; i += TRAV_BLOCK) {
-		sh.q_shade[0][i] = i < a.slots_per_block ? (i | PP_REGEN) : PP_EMPTY; // every slot starts by acquiring a pixel
+		sh.q_shade[0][i] = i < block_slots ? (i | PP_REGEN) : PP_EMPTY; // every slot starts by acquiring a pixel
 		for (int q = 1; q < NQ; ++q)
 			sh.q_shade[q][i] = PP_EMPTY;
 		sh.pending[i] = 0;
-		if (i < a.slots_per_block)
+		if (i < block_slots)
 			ps.pixel[slot0 + i] = INVALID;
 	}
 	if (threadIdx.x == 0) {
 		sh.ray_head = sh.ray_tail = 0;
 		sh.shade_head[0]		  = 0;
-		sh.shade_tail[0]		  = a.slots_per_block;
+		sh.shade_tail[0]		  = block_slots;
 		for (int q = 1; q < NQ; ++q)
 			sh.shade_head[q] = sh.shade_tail[q] = 0;
-		sh.live					  = a.slots_per_block;
+		sh.live					  = block_slots;
 		sh.error				  = 0;
 	}
 	stats_init(sh.bs);
@@ -2361,6 +2362,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			atomicAdd(&a.gstats[CNT_IDLE_TICKS], t_idle);
 			atomicAdd(&a.gstats[CNT_TOTAL_TICKS], wall_clock64() - t_start);
 		}
+		if (threadIdx.x == 0) // diagnostics (PRGPU_DUMP_BLOCK_LIFE): the block's lifetime and vertex count, in its own first spill entry (no longer needed)
+			a.spill[blockIdx.x * TRAV_BLOCK] = make_uint2((uint32_t)(wall_clock64() - t_start), sh.bs.v[PRGPU_STAT_CAMERA_DEPTH] + sh.bs.v[PRGPU_STAT_BACKGROUND_HITS]);
 	}
 	stats_flush(sh.bs, a.gstats);
 }
@@ -2518,9 +2521,12 @@ void PR_PP_CAT(PR_TU, PR_SUB)(const DevScene& sc, const PathState& ps, const Per
 PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, uint32_t max_slots_per_block)
 {
 	PersistentGeometry g;
+	// every block of the grid gets the same share of a small pixel set (no rounding to wave-fulls: 1/8 of the C4 frame is 338 pixels
+	// for each of 768 blocks, and rounding that up to 384 would leave 93 blocks without work)
 	const uint32_t per_block = (n_owned + max_blocks - 1) / std::max(1u, max_blocks);
 	const uint32_t cap		 = std::min((uint32_t)PP_SLOTS_MAX, std::max(256u, max_slots_per_block / 64u * 64u));
-	g.slots_per_block		 = std::min(cap, std::max(256u, (per_block + 63u) / 64u * 64u));
+	static const uint32_t min_slots = getenv("PRGPU_PP_MIN_SLOTS") ? (uint32_t)std::min(256, std::max(1, atoi(getenv("PRGPU_PP_MIN_SLOTS")))) : 256u;
+	g.slots_per_block		 = std::min(cap, std::max(min_slots, per_block));
 	g.n_blocks				 = std::max(1u, std::min(max_blocks, (n_owned + g.slots_per_block - 1) / g.slots_per_block));
 	return g;
 }

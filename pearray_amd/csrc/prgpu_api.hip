@@ -70,7 +70,7 @@ struct prgpu_scene {
 	Mode mode = LOCKSTEP;
 	uint32_t pp_slots = 512;
 	uint32_t pp_planes = 1; // iteration planes of the persistent pipeline (> 1 with a multi-tap pixel filter)
-	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 0, pp_occupancy = 3, pp_shader_wave = 0, pp_shade_help = 128;
+	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 0, pp_occupancy = 3, pp_shader_wave = -1 /* auto: see render_persistent */, pp_shade_help = 128;
 	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
 	prd::TraceWorkspace ws;	   // workspace of the ray-service launches
@@ -809,6 +809,12 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	// where the previous one stopped (identical results for any chunking).
 	const uint64_t per_iter = std::max<uint64_t>(1, s->n_slots);
 	uint32_t chunk			= (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(s->pp_launch_min_iters, s->pp_launch_samples / per_iter));
+	// A small tile share (every owned pixel in flight at once, no slot ever takes a second pixel) is bound by the LATENCY of a pixel's
+	// chain of samples, not by throughput: there the block's last wave only shades (batches of any size, the moment a vertex waits)
+	// and the other three only trace, so that no ray in flight is parked behind a shading pass (1/8 of the C4 frame: 2.62 -> 2.30 ms
+	// per iteration, 1/16: 2.23 -> 1.83).  With more pixels than slots the shared scheme is faster (full frame 13.7 vs 14.3 ms).
+	const bool all_in_flight = uint64_t(s->n_slots) <= uint64_t(s->ws_pp.max_blocks) * s->pp_slots;
+	const int shader_wave	 = s->pp_shader_wave >= 0 ? s->pp_shader_wave : (all_in_flight ? 1 : 0);
 	const bool ring			= !s->sc.single_tap; // multi-tap filter: one launch fills at most pp_planes iteration planes
 	if (ring) {
 		chunk			= std::min(chunk, s->pp_planes);
@@ -819,7 +825,7 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 		ps.iter_base = b;
 		s->time_begin(6, s->stream);
 		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act, s->pp_refill_min, s->pp_both_below,
-									s->pp_occupancy, s->pp_shader_wave, s->pp_shade_help,
+									s->pp_occupancy, shader_wave, s->pp_shade_help,
 									s->pp_next,
 									s->pp_error,
 									s->gstats, s->stream);
@@ -1033,6 +1039,15 @@ int prgpu_sync(prgpu_scene* s)
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->collect_timing();
+	if (const char* path = s->instrument && s->mode == prgpu_scene::PERSISTENT ? getenv("PRGPU_DUMP_BLOCK_LIFE") : nullptr) { // diagnostics: one line per block of the last instrumented launch
+		std::vector<uint2> rows(size_t(s->ws_pp.max_blocks) * 256u);
+		HIP_TRY(hipMemcpy(rows.data(), s->ws_pp.spill, rows.size() * sizeof(uint2), hipMemcpyDeviceToHost));
+		if (FILE* f = std::fopen(path, "w")) {
+			for (uint32_t b = 0; b < s->ws_pp.max_blocks; ++b)
+				std::fprintf(f, "%u %u %u\n", b, rows[size_t(b) * 256u].x, rows[size_t(b) * 256u].y);
+			std::fclose(f);
+		}
+	}
 	return check_watchdog(s);
 }
 
