@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PRGPU_API_VERSION 6
+#define PRGPU_API_VERSION 7
 #define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
 
 enum {
@@ -179,10 +179,16 @@ typedef struct prgpu_entity {
  * They follow the area lights in the light-selection distribution with intensity 2 pi R mean(power) (LightSampler.cpp:20,62-71),
  * R = radius of the origin-centred bounding sphere of the scene (Scene.cpp:107-118); power() of SKY is its zenith radiance
  * (sky.cpp:113), of SUN its spectrum (sun.cpp:106-112). */
-enum { PRGPU_LIGHT_ENVIRONMENT = 0, PRGPU_LIGHT_DISTANT = 1, PRGPU_LIGHT_SKY = 2, PRGPU_LIGHT_SUN = 3 };
+enum { PRGPU_LIGHT_ENVIRONMENT = 0, PRGPU_LIGHT_DISTANT = 1, PRGPU_LIGHT_SKY = 2, PRGPU_LIGHT_SUN = 3,
+       PRGPU_LIGHT_CIE_SKY = 4 }; /* cie_sky.cpp CIESimpleSkyLight ('uniform_sky', 'cloudy_sky'): radiance by the local z of the direction,
+                                    (zenith c1 a + ground brightness c2 b) / (a + b), a = (z + 1.01)^10, b = 1 / a (cie_sky.cpp:108-126;
+                                    the power of ten by squaring in fp32), `radiance` = :zenith, `background` = :ground_tint (PRGPU_INVALID_ID
+                                    = the zenith tint), cosine-hemisphere sampling like ENVIRONMENT (:48-66), power() = the radiance
+                                    towards +z (:80).  flags: PRGPU_SKYF_CLOUDY */
 enum { PRGPU_SKYF_EXTEND = 1u,        /* `:extend` (default true): the distribution covers elevations -pi/2..pi/2, the ground half scaled
                                          by GROUND_PENALTY = 0.001 (sky.cpp:23,127-159); without it directions below the horizon are black */
        PRGPU_SKYF_COMPENSATION = 2u }; /* `:compensation` (default false): Distribution2D::applyCompensation (Distribution2D.cpp:38-76) */
+enum { PRGPU_SKYF_CLOUDY = 8u };      /* CIE_SKY: 'cloudy_sky' (c1 = (1 + 2 z) / 3, c2 = 0.7777777); without it 'uniform_sky' (c1 = c2 = 1) */
 enum { PRGPU_LIGHTF_SUN_DELTA = 4u };  /* DISTANT standing in for SunDeltaLight: power() is the plain table lookup (sun.cpp:222-228)
                                          instead of NodeUtils::average (distant.cpp:93) -- an ulp in the light-selection weights */
 #define PRGPU_SKY_BANDS 11            /* AR_SPECTRAL_BANDS; band k is 320 + 40 k nm (src/skysun/skysun/SkySunConfig.h:6-9) */
@@ -196,11 +202,16 @@ typedef struct prgpu_light {
 	float    transform[16];
 	uint32_t table_offset; /* SKY: first float of the table in prgpu_scene_desc::spectral_tables */
 	uint32_t azimuth_count, elevation_count; /* SKY: table resolution (`azimuth_resolution` 512, `elevation_resolution` 256) */
-	uint32_t reserved;
+	float    ground_brightness; /* CIE_SKY: `ground_brightness` (default 0.2) */
 } prgpu_light;
 
 /* PerspectiveCamera, src/plugins/main/cameras/perspective.cpp:16-113; OrthoCamera, ortho.cpp:14-75 */
-enum { PRGPU_CAMERA_PERSPECTIVE = 0, PRGPU_CAMERA_ORTHO = 1 };
+enum { PRGPU_CAMERA_PERSPECTIVE = 0, PRGPU_CAMERA_ORTHO = 1,
+       PRGPU_CAMERA_SPHERICAL = 2, /* spherical.cpp:50-78: pixel -> (theta, phi) over [theta_start, theta_end] x [phi_start, phi_end] */
+       PRGPU_CAMERA_FISHEYE = 3 }; /* fisheye.cpp:61-124: equidistant fisheye, theta = r fov / 2; `map` circular / cropped / full; with
+                                      `clip_range` samples outside the unit circle produce NO camera ray (the sample is counted and
+                                      consumes its random numbers, RenderTile.cpp:71-131, but nothing is traced or splatted) */
+enum { PRGPU_FISHEYE_CIRCULAR = 0, PRGPU_FISHEYE_CROPPED = 1, PRGPU_FISHEYE_FULL = 2 };
 typedef struct prgpu_camera {
 	float transform[16];      /* row-major 4x4 */
 	float width, height;      /* sensor size */
@@ -208,6 +219,11 @@ typedef struct prgpu_camera {
 	float local_direction[3], local_right[3], local_up[3];
 	float fstop, aperture_radius; /* PERSPECTIVE: DOF active iff both > FLT_EPSILON (perspective.cpp:158) */
 	uint32_t kind;            /* PRGPU_CAMERA_*: perspective.cpp, or ortho.cpp (parallel rays from the sensor rectangle, ortho.cpp:29-33,61-66) */
+	float theta_start, theta_end, phi_start, phi_end; /* SPHERICAL (radians; defaults 0, pi/2, -pi, pi: spherical.cpp:97-100) */
+	float fov;                /* FISHEYE: full field of view in radians (default pi, fisheye.cpp:152) */
+	uint32_t fisheye_map;     /* FISHEYE: PRGPU_FISHEYE_* */
+	uint32_t clip_range;      /* FISHEYE: `clip_range` (default true, fisheye.cpp:166) */
+	uint32_t reserved;        /* sin / cos of the two cameras go through the backend's shared fp32 forms (not libm) */
 } prgpu_camera;
 
 /* RandomSampler.cpp, MultiJitteredSampler.cpp, SobolSampler.cpp, HaltonSampler.cpp (halton + hammersley) of src/plugins/main/sampler */

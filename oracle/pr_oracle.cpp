@@ -895,6 +895,7 @@ struct Scene {
 	// camera cache (perspective.cpp:84-113)
 	V3 cam_o, cam_right, cam_up, cam_focal, cam_xap, cam_yap;
 	bool cam_dof = false, cam_ortho = false;
+	V3 cam_dir_c, cam_right_c, cam_up_c; // spherical / fisheye: mDirection_Cache, mRight_Cache, mUp_Cache (transform.linear() * local axis)
 	// samplers
 	uint32_t spp = 0;
 	uint32_t mj_x = 1, mj_y = 1, mj_seed = 0;
@@ -2014,8 +2015,29 @@ inline V3 uniform_cone(float u1, float u2, float cos_theta_max)
 // IInfiniteLight::power: NodeUtils::average for environment / distant lights, the zenith radiance for the sky (sky.cpp:113),
 // the spectrum itself for the sun (sun.cpp:106-112, :222-228)
 Blob node_average(const Scene& s, uint32_t id, const Blob& wl);
+// CIESimpleSkyLight::radiance (cie_sky.cpp:108-126) for a world direction; (z + 1.01)^10 by squaring in fp32 (the reference calls pow)
+Blob cie_sky_radiance(const Scene& s, const Scene::InfLight& il, const Blob& wl, V3 dir)
+{
+	const V3 tD		  = mat3_mul(il.inv_nm, dir);
+	const float x	  = tD.z + 1.01f;
+	const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+	const float a	  = x8 * x2;
+	const float b	  = 1 / a;
+	const float denom = 1 / (a + b);
+	float c1 = 1, c2 = 1;
+	if (il.l.flags & PRGPU_SKYF_CLOUDY) {
+		c1 = (1 + 2.0f * tD.z) / 3.0f;
+		c2 = 0.7777777f;
+	}
+	const Blob zenith = spectrum_eval(s, il.l.radiance, wl);
+	const Blob ground = spectrum_eval(s, il.l.background != INVALID ? il.l.background : il.l.radiance, wl);
+	const Blob za = zenith * (c1 * a), gb = ground * (il.l.ground_brightness * c2 * b);
+	return blob4(za[0] + gb[0], za[1] + gb[1], za[2] + gb[2], za[3] + gb[3]) * denom;
+}
 Blob inf_light_power(const Scene& s, const Scene::InfLight& il, const Blob& wl)
 {
+	if (il.l.kind == PRGPU_LIGHT_CIE_SKY)
+		return cie_sky_radiance(s, il, wl, v3(0, 0, 1)); // cie_sky.cpp:80
 	if (il.l.kind == PRGPU_LIGHT_SKY)
 		return sky_light_radiance(il, wl, ElevationAzimuth{ 0.5f * PR_PI_F - 0.0f, 0.0f }); // fromDirection((0, 0, 1))
 	if (il.l.kind == PRGPU_LIGHT_SUN || (il.l.kind == PRGPU_LIGHT_DISTANT && (il.l.flags & PRGPU_LIGHTF_SUN_DELTA)))
@@ -2051,6 +2073,11 @@ void inf_light_eval(const Scene& s, const Scene::InfLight& il, V3 dir, const Blo
 			radiance		= spectrum_eval(s, il.l.radiance, wl); // mSpectrum.lookup
 			direction_pdf_s = il.cone_pdf;
 		}
+		break;
+	}
+	case PRGPU_LIGHT_CIE_SKY: { // cie_sky.cpp:48-53
+		radiance		= cie_sky_radiance(s, il, wl, dir);
+		direction_pdf_s = std::fabs(mat3_mul(il.inv_nm, dir).z) * PR_INV_PI_F;
 		break;
 	}
 	default: { // EnvironmentLight, untextured: camera rays see the background
@@ -2091,6 +2118,13 @@ void inf_light_sample_dir(const Scene& s, const Scene::InfLight& il, float rnd0,
 		radiance		= spectrum_eval(s, il.l.radiance, wl);
 		break;
 	}
+	case PRGPU_LIGHT_CIE_SKY: { // cie_sky.cpp:55-66
+		const V3 lo		= cos_hemi(rnd0, rnd1);
+		direction_pdf_s = lo.z * PR_INV_PI_F;
+		outgoing		= mat3_mul(il.nm, lo);
+		radiance		= cie_sky_radiance(s, il, wl, outgoing);
+		break;
+	}
 	default: {
 		const V3 lo		= cos_hemi(rnd0, rnd1);
 		direction_pdf_s = lo.z * PR_INV_PI_F;
@@ -2128,7 +2162,7 @@ int setup_lights(Scene& s)
 	// infinite lights (approximate intensities), LightSampler.cpp:20,62-71
 	const float scene_area = 2 * PR_PI_F * s.scene_radius;
 	for (const auto& il : s.inf_lights) {
-		const Range node = il.l.kind == PRGPU_LIGHT_SKY ? Range{} : spectrum_range(s, il.l.radiance); // SkyLight::spectralRange: unbounded (sky.cpp:114)
+		const Range node = (il.l.kind == PRGPU_LIGHT_SKY || il.l.kind == PRGPU_LIGHT_CIE_SKY) ? Range{} : spectrum_range(s, il.l.radiance); // SkyLight / CIESimpleSkyLight::spectralRange: unbounded (sky.cpp:114, cie_sky.cpp:81)
 		const float rs = node.start < 0 ? s.cfg.spectral_start : node.start;
 		const float re = node.end < 0 ? s.cfg.spectral_end : node.end;
 		Blob wl;
@@ -2238,6 +2272,9 @@ void setup_camera(Scene& s)
 	V3 right	   = linear_mul(c.transform, v3(c.local_right[0], c.local_right[1], c.local_right[2]));
 	V3 up		   = linear_mul(c.transform, v3(c.local_up[0], c.local_up[1], c.local_up[2]));
 	s.cam_o		   = v3(c.transform[3], c.transform[7], c.transform[11]);
+	s.cam_dir_c	   = dir;
+	s.cam_right_c  = right;
+	s.cam_up_c	   = up;
 	s.cam_dof	   = c.kind == PRGPU_CAMERA_PERSPECTIVE && c.aperture_radius > PR_EPS && c.fstop > PR_EPS; // perspective.cpp:158
 	s.cam_ortho	   = c.kind == PRGPU_CAMERA_ORTHO;
 	if (s.cam_ortho) { // ortho.cpp:29-31
@@ -2258,15 +2295,76 @@ void setup_camera(Scene& s)
 		s.cam_up	= up * (0.5f * c.height * (c.fstop + 1));
 	}
 }
-// perspective.cpp:45-82
-inline void camera_ray(const Scene& s, float px, float py, float r1, float r2, V3& o, V3& d)
+// SphericalCamera::constructRay (spherical.cpp:50-78); sin / cos through the shared fp32 form
+inline void spherical_camera_ray(const Scene& s, float px, float py, V3& o, V3& d)
 {
+	const prgpu_camera& c = s.d.camera;
+	const float nx		  = px / (float)s.cfg.width;
+	const float ny		  = 1 - py / (float)s.cfg.height;
+	o					  = s.cam_o;
+	const float theta	  = c.theta_start + ny * (c.theta_end - c.theta_start);
+	const float phi		  = c.phi_start + nx * (c.phi_end - c.phi_start);
+	float sT, cT, sP, cP;
+	sincos_rad(theta, sT, cT);
+	sincos_rad(phi, sP, cP);
+	d = normalized(from_tangent_space(s.cam_up_c, s.cam_right_c, s.cam_dir_c, v3(sP * cT, cP * cT, sT)));
+}
+// FisheyeCamera::constructRay (fisheye.cpp:61-124); false = the sample lies outside the clipped image circle (no ray)
+inline bool fisheye_camera_ray(const Scene& s, float px, float py, V3& o, V3& d)
+{
+	const prgpu_camera& c = s.d.camera;
+	const float W = (float)s.cfg.width, H = (float)s.cfg.height;
+	const float aspect = W / H;
+	float xaspect, yaspect;
+	switch (c.fisheye_map) {
+	default:
+	case PRGPU_FISHEYE_CIRCULAR:
+		xaspect = aspect < 1 ? 1 : aspect;
+		yaspect = aspect > 1 ? 1 : aspect;
+		break;
+	case PRGPU_FISHEYE_CROPPED:
+		xaspect = aspect < 1 ? 1 / aspect : 1;
+		yaspect = aspect > 1 ? 1 / aspect : 1;
+		break;
+	case PRGPU_FISHEYE_FULL: {
+		const float diameter = std::sqrt(aspect * aspect + 1.0f) * H;
+		const float k		 = std::min(W, H);
+		const float f		 = diameter / k;
+		xaspect				 = aspect < 1 ? 1 : 1 / aspect;
+		yaspect				 = aspect > 1 ? 1 : aspect;
+		xaspect *= f;
+		yaspect *= f;
+	} break;
+	}
+	const float nx = 2 * (px / W - 0.5f) / xaspect;
+	const float ny = -(2 * (py / H - 0.5f) / yaspect);
+	if (c.clip_range && nx * nx + ny * ny > 1)
+		return false;
+	o				  = s.cam_o;
+	const float r	  = std::sqrt(nx * nx + ny * ny);
+	const float theta = r * c.fov / 2;
+	float sT, cT;
+	sincos_rad(theta, sT, cT);
+	const float sP = r < PR_EPS ? 0 : ny / r;
+	const float cP = r < PR_EPS ? 0 : nx / r;
+	d			   = normalized(from_tangent_space(s.cam_dir_c, s.cam_right_c, s.cam_up_c, v3(cP * sT, sP * sT, cT)));
+	return true;
+}
+// perspective.cpp:45-82
+inline bool camera_ray(const Scene& s, float px, float py, float r1, float r2, V3& o, V3& d)
+{
+	if (s.d.camera.kind == PRGPU_CAMERA_SPHERICAL) {
+		spherical_camera_ray(s, px, py, o, d);
+		return true;
+	}
+	if (s.d.camera.kind == PRGPU_CAMERA_FISHEYE)
+		return fisheye_camera_ray(s, px, py, o, d);
 	const float nx = 2 * (px / (float)s.cfg.width - 0.5f);
 	const float ny = -(2 * (py / (float)s.cfg.height - 0.5f));
 	if (s.cam_ortho) { // ortho.cpp:61-66
 		o = (s.cam_o + s.cam_right * nx) + s.cam_up * ny;
 		d = s.cam_focal;
-		return;
+		return true;
 	}
 	o			   = s.cam_o;
 	d			   = (s.cam_right * nx + s.cam_up * ny) + s.cam_focal;
@@ -2278,6 +2376,7 @@ inline void camera_ray(const Scene& s, float px, float py, float r1, float r2, V
 		d		   = d - e;
 	}
 	d = normalized(d);
+	return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2941,7 +3040,10 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 		wl_pdf = blob(1.0f);
 	}
 	RayState ray;
-	camera_ray(s, px, py, l1, l2, ray.o, ray.d);
+	if (!camera_ray(s, px, py, l1, l2, ray.o, ray.d)) {
+		s.rng[pixel] = rnd.s;
+		return; // no camera ray (StreamPipeline.cpp:104-105): the sample is counted and its random numbers are spent, nothing is traced
+	}
 	ray.tmin  = s.d.camera.near_t;
 	ray.tmax  = s.d.camera.far_t;
 	ray.wl	  = wl;
@@ -3691,7 +3793,7 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 	for (uint32_t i = 0; i < d->n_lights; ++i) {
 		Scene::InfLight il;
 		il.l = d->lights[i];
-				if (il.l.kind > PRGPU_LIGHT_SUN)
+		if (il.l.kind > PRGPU_LIGHT_CIE_SKY)
 			return fail("bad infinite light");
 		if (il.l.kind == PRGPU_LIGHT_SKY) {
 			const uint64_t need = uint64_t(il.l.azimuth_count) * il.l.elevation_count * PRGPU_SKY_BANDS;
@@ -4087,12 +4189,13 @@ void orc_refract(float eta, const float w[3], float out[3])
 	out[2] = r.z;
 }
 
-void orc_camera_ray(orc_scene* h, float px, float py, float r1, float r2, float org[3], float dir[3])
+int orc_camera_ray(orc_scene* h, float px, float py, float r1, float r2, float org[3], float dir[3])
 {
-	V3 o, d;
-	camera_ray(h->s, px, py, r1, r2, o, d);
+	V3 o = v3(0, 0, 0), d = v3(0, 0, 0);
+	const bool ok = camera_ray(h->s, px, py, r1, r2, o, d);
 	org[0] = o.x; org[1] = o.y; org[2] = o.z;
 	dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+	return ok ? 1 : 0;
 }
 void orc_wavelength_cdf(orc_scene* h, uint32_t* size, const float** cdf)
 {
@@ -4200,6 +4303,12 @@ void orc_inf_light_eval(orc_scene* h, uint32_t light, const float dir[3], const 
 	inf_light_eval(h->s, h->s.inf_lights[light], v3(dir[0], dir[1], dir[2]), blob4(wvl[0], wvl[1], wvl[2], wvl[3]), camera_ray != 0, r, *pdf);
 	for (int k = 0; k < 4; ++k)
 		radiance[k] = r[k];
+}
+void orc_inf_light_power(orc_scene* h, uint32_t light, const float wvl[4], float power[4])
+{
+	const Blob p = inf_light_power(h->s, h->s.inf_lights[light], blob4(wvl[0], wvl[1], wvl[2], wvl[3]));
+	for (int k = 0; k < 4; ++k)
+		power[k] = p[k];
 }
 void orc_inf_light_sample(orc_scene* h, uint32_t light, float u0, float u1, const float wvl[4], float outgoing[3], float* pdf, float radiance[4])
 {

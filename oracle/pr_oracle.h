@@ -88,7 +88,7 @@ float    orc_halton(uint32_t index, uint32_t base);                     /* Halto
 float    orc_fresnel_dielectric(float cosI, float n_in, float n_out);   /* Fresnel::dielectric, base/math/Fresnel.h:19-31 */
 float    orc_fresnel_conductor(float cosI, float n_in, float n_out, float k); /* Fresnel::conductor, base/math/Fresnel.h:33-59 */
 void     orc_refract(float eta, const float w[3], float out[3]);         /* Scattering::refract, base/math/Scattering.h:94-105 */
-void     orc_camera_ray(orc_scene* s, float px, float py, float r1, float r2, float org[3], float dir[3]);
+int      orc_camera_ray(orc_scene* s, float px, float py, float r1, float r2, float org[3], float dir[3]); /* 0: the camera has no ray for the sample */
 void     orc_wavelength_cdf(orc_scene* s, uint32_t* size, const float** cdf);
 void     orc_light_selector(orc_scene* s, uint32_t* n_lights, const float** cdf, const float** intensities);
 void     orc_normal_matrix(const float m[16], float out[9], float* abs_det);
@@ -113,6 +113,7 @@ void     orc_ea_from_direction(const float d[3], float* elevation, float* azimut
 void     orc_ea_to_direction(float elevation, float azimuth, float out[3]);
 void     orc_uniform_cone(float u1, float u2, float cos_theta_max, float out[3]); /* Sampling.h:101-107 */
 void     orc_inf_light_eval(orc_scene* s, uint32_t light, const float dir[3], const float wvl[4], int camera_ray, float radiance[4], float* pdf);
+void     orc_inf_light_power(orc_scene* s, uint32_t light, const float wvl[4], float power[4]); /* IInfiniteLight::power */
 void     orc_inf_light_sample(orc_scene* s, uint32_t light, float u0, float u1, const float wvl[4], float outgoing[3], float* pdf,
                               float radiance[4]);
 float    orc_exp(float x);                               /* shared fp32 exp / log (agh mapper) */

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libprgpu.so")
 
-PRGPU_API_VERSION = 6
+PRGPU_API_VERSION = 7
 INVALID_ID = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -19,10 +19,11 @@ MATF_ANISOTROPIC, MATF_NO_VNDF, MATF_HAS_TRANSMISSION = 1, 2, 4
 PRINCIPLED_PARAMS = ("diffuse_transmission", "specular_transmission", "specular_tint", "anisotropic", "flatness", "metallic", "sheen",
                      "sheen_tint", "clearcoat", "clearcoat_gloss")
 ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE = 0, 1, 2
-LIGHT_ENVIRONMENT, LIGHT_DISTANT, LIGHT_SKY, LIGHT_SUN = 0, 1, 2, 3
-SKYF_EXTEND, SKYF_COMPENSATION = 1, 2
+LIGHT_ENVIRONMENT, LIGHT_DISTANT, LIGHT_SKY, LIGHT_SUN, LIGHT_CIE_SKY = 0, 1, 2, 3, 4
+SKYF_EXTEND, SKYF_COMPENSATION, SKYF_CLOUDY = 1, 2, 8
 SKY_BANDS = 11
-CAMERA_PERSPECTIVE, CAMERA_ORTHO = 0, 1
+CAMERA_PERSPECTIVE, CAMERA_ORTHO, CAMERA_SPHERICAL, CAMERA_FISHEYE = 0, 1, 2, 3
+FISHEYE_CIRCULAR, FISHEYE_CROPPED, FISHEYE_FULL = 0, 1, 2
 AOV_NAMES = ("position", "normal", "normal_g", "tangent", "bitangent", "view", "entity_id", "material_id", "emission_id", "depth")
 EMS_DIFFUSE = 0
 SAMPLER_RANDOM, SAMPLER_MJITT, SAMPLER_SOBOL, SAMPLER_HALTON, SAMPLER_HAMMERSLEY, SAMPLER_UNIFORM, SAMPLER_STRATIFIED = range(7)
@@ -59,14 +60,16 @@ class Entity(C.Structure):
 class Light(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("radiance", C.c_uint32), ("background", C.c_uint32), ("flags", C.c_uint32),
                 ("direction", C.c_float * 3), ("cos_theta", C.c_float), ("transform", C.c_float * 16),
-                ("table_offset", C.c_uint32), ("azimuth_count", C.c_uint32), ("elevation_count", C.c_uint32), ("reserved", C.c_uint32)]
+                ("table_offset", C.c_uint32), ("azimuth_count", C.c_uint32), ("elevation_count", C.c_uint32), ("ground_brightness", C.c_float)]
 
 
 class Camera(C.Structure):
     _fields_ = [("transform", C.c_float * 16), ("width", C.c_float), ("height", C.c_float),
                 ("near_t", C.c_float), ("far_t", C.c_float), ("local_direction", C.c_float * 3),
                 ("local_right", C.c_float * 3), ("local_up", C.c_float * 3), ("fstop", C.c_float),
-                ("aperture_radius", C.c_float), ("kind", C.c_uint32)]
+                ("aperture_radius", C.c_float), ("kind", C.c_uint32),
+                ("theta_start", C.c_float), ("theta_end", C.c_float), ("phi_start", C.c_float), ("phi_end", C.c_float),
+                ("fov", C.c_float), ("fisheye_map", C.c_uint32), ("clip_range", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Settings(C.Structure):

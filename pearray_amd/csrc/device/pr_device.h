@@ -113,6 +113,7 @@ struct DevInfLight {
 	float cos_theta, cone_pdf; // SUN: cone half angle cosine, Sampling::uniform_cone_pdf (sun.cpp:36-37)
 	uint32_t table_offset, az_count, el_count; // SKY: table in DevScene::tables, [elevation][azimuth][band]
 	uint32_t dist_offset, dist_w, dist_h;	   // SKY: Distribution2D in DevScene::sky_cdf: marginal (dist_h + 1 floats), then dist_h conditionals of dist_w + 1
+	float ground_brightness;				   // CIE_SKY
 };
 constexpr int SKY_BANDS			 = PRGPU_SKY_BANDS; // AR_SPECTRAL_BANDS (skysun/SkySunConfig.h:6-9)
 constexpr float SKY_BAND_START	 = 320.0f;
@@ -124,6 +125,11 @@ struct DevCamera {
 	float o[3], right[3], up[3], focal[3], xap[3], yap[3];
 	float near_t, far_t;
 	uint32_t dof, ortho; // ortho: parallel rays, `focal` is the normalised view direction
+	// SPHERICAL / FISHEYE: right, up, focal hold the cached axes transform.linear() * local_{right, up, direction}
+	uint32_t kind;		  // PRGPU_CAMERA_*
+	float angles[4];	  // SPHERICAL: theta_start, theta_end, phi_start, phi_end
+	float fov, xaspect, yaspect; // FISHEYE (fisheye.cpp:66-90: the aspect factors of the map type)
+	uint32_t clip;		  // FISHEYE: clip_range
 };
 
 // Everything the kernels read; passed by value.
@@ -213,6 +219,7 @@ struct PathState {
 constexpr uint32_t FLAG_MONO		  = 1u << 8;
 constexpr uint32_t FLAG_LAST_DELTA	  = 1u << 9;
 constexpr uint32_t FLAG_LAST_EMISSIVE = 1u << 10;
+constexpr uint32_t FLAG_NO_RAY		  = 1u << 12; // the camera produced no ray for this sample (clipped fisheye): the path ends at once, without a fragment
 constexpr uint32_t FLAG_GROUP_MONO	  = 1u << 11; // the camera ray started monochrome (ray-group importance, RenderTile.cpp:126-127)
 
 // ---- vector helpers -------------------------------------------------------------------------------

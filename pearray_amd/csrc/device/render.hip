@@ -650,7 +650,10 @@ __device__ __forceinline__ float halton(uint32_t index, uint32_t base)
 	}
 	return result;
 }
-__device__ __forceinline__ void camera_path(const DevScene& sc, const PathState& ps, uint32_t slot, uint32_t iter, BlockStats& bs)
+// Returns false when the camera has no ray for the sample (clipped fisheye, fisheye.cpp:91-94): the sample is counted and its random
+// numbers are spent (RenderTile.cpp:71-131), the slot gets a ray that cannot hit anything and FLAG_NO_RAY, and shade_vertex ends
+// the path without a fragment.
+__device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState& ps, uint32_t slot, uint32_t iter, BlockStats& bs)
 {
 	const prgpu_settings& cfg = sc.cfg;
 	const uint32_t pixel	  = ps.pixel[slot];
@@ -745,7 +748,29 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	const DevCamera& cam = sc.cam;
 	V3 o = v3(cam.o[0], cam.o[1], cam.o[2]);
 	V3 d = (v3(cam.right[0], cam.right[1], cam.right[2]) * nx + v3(cam.up[0], cam.up[1], cam.up[2]) * ny) + v3(cam.focal[0], cam.focal[1], cam.focal[2]);
-	if (cam.ortho) { // OrthoCamera::constructRay (ortho.cpp:61-66)
+	bool has_ray = true;
+	if (cam.kind == PRGPU_CAMERA_SPHERICAL) { // SphericalCamera::constructRay (spherical.cpp:50-78)
+		const float sx = px / (float)cfg.width, sy = 1 - py / (float)cfg.height;
+		const float theta = cam.angles[0] + sy * (cam.angles[1] - cam.angles[0]);
+		const float phi	  = cam.angles[2] + sx * (cam.angles[3] - cam.angles[2]);
+		float sT, cT, sP, cP;
+		pr_sincos_rad(theta, sT, cT);
+		pr_sincos_rad(phi, sP, cP);
+		d = normalized(from_tangent_space(v3(cam.up[0], cam.up[1], cam.up[2]), v3(cam.right[0], cam.right[1], cam.right[2]), v3(cam.focal[0], cam.focal[1], cam.focal[2]),
+										  v3(sP * cT, cP * cT, sT)));
+	} else if (cam.kind == PRGPU_CAMERA_FISHEYE) { // FisheyeCamera::constructRay (fisheye.cpp:61-124)
+		const float fx = 2 * (px / (float)cfg.width - 0.5f) / cam.xaspect;
+		const float fy = -(2 * (py / (float)cfg.height - 0.5f) / cam.yaspect);
+		has_ray		   = !(cam.clip && fx * fx + fy * fy > 1);
+		const float r	  = sqrtf(fx * fx + fy * fy);
+		const float theta = r * cam.fov / 2;
+		float sT, cT;
+		pr_sincos_rad(theta, sT, cT);
+		const float sP = r < PR_EPS ? 0 : fy / r;
+		const float cP = r < PR_EPS ? 0 : fx / r;
+		d = normalized(from_tangent_space(v3(cam.focal[0], cam.focal[1], cam.focal[2]), v3(cam.right[0], cam.right[1], cam.right[2]), v3(cam.up[0], cam.up[1], cam.up[2]),
+										  v3(cP * sT, sP * sT, cT)));
+	} else if (cam.ortho) { // OrthoCamera::constructRay (ortho.cpp:61-66)
 		o = (o + v3(cam.right[0], cam.right[1], cam.right[2]) * nx) + v3(cam.up[0], cam.up[1], cam.up[2]) * ny;
 		d = v3(cam.focal[0], cam.focal[1], cam.focal[2]);
 	} else {
@@ -760,8 +785,13 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	}
 	const bool mono	   = cfg.spectral_mono || !cfg.spectral_hero; // RenderTile.cpp:123-124
 	ps.rng[pixel]	   = rnd;
-	ps.ray_o[slot]	   = make_float4(o.x, o.y, o.z, cam.near_t);
-	ps.ray_d[slot]	   = make_float4(d.x, d.y, d.z, cam.far_t);
+	if (has_ray) {
+		ps.ray_o[slot] = make_float4(o.x, o.y, o.z, cam.near_t);
+		ps.ray_d[slot] = make_float4(d.x, d.y, d.z, cam.far_t);
+	} else { // an empty interval: the traversal misses at the root
+		ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 1.0f);
+		ps.ray_d[slot] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+	}
 	ps.wl[slot]		   = to4(wl);
 	ps.wl_pdf[slot]	   = to4(wl_pdf);
 	{ // the path's wavelengths are fixed: evaluate the CIE response once instead of once per fragment
@@ -779,7 +809,7 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 	ps.prev_pdf[slot]  = make_float4(1, 1, 1, 1);
 	if (sc.features & FEAT_SHAPE_LIGHTS)
 		ps.last_pos[slot] = make_float4(0, 0, 0, 0); // TraversalContext::LastPosition starts at the world origin (direct.cpp:55)
-	ps.flags[slot]	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA;
+	ps.flags[slot]	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA | (has_ray ? 0u : FLAG_NO_RAY);
 	{
 		const size_t entry = (ps.plane_stride ? size_t(iter - ps.iter_base) * ps.plane_stride : size_t(0)) + size_t(3) * pixel; // = iter_entry: ps.iter[slot] == iter
 		ps.iter_xyz[entry + 0] = 0.0f;
@@ -787,8 +817,11 @@ __device__ __forceinline__ void camera_path(const DevScene& sc, const PathState&
 		ps.iter_xyz[entry + 2] = 0.0f;
 	}
 	atomicAdd(&bs.v[PRGPU_STAT_PIXEL_SAMPLES], 1u);
-	atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
-	atomicAdd(&bs.v[PRGPU_STAT_PRIMARY_RAYS], 1u);
+	if (has_ray) {
+		atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
+		atomicAdd(&bs.v[PRGPU_STAT_PRIMARY_RAYS], 1u);
+	}
+	return has_ray;
 }
 
 #if PR_TU == 0
@@ -1269,6 +1302,28 @@ static __device__ PR_CLOSURE void rough_sample(const DevScene& s, const prgpu_ma
 		pdf_s = blob(1);
 }
 
+// CIESimpleSkyLight::radiance (cie_sky.cpp:108-126) for a world direction; (z + 1.01)^10 by squaring in fp32
+__device__ __forceinline__ Blob cie_sky_radiance(const DevScene& sc, const DevInfLight& il, const Blob& wl, V3 dir)
+{
+	const V3 tD		  = mat3_mul(il.inv_nm, dir);
+	const float x	  = tD.z + 1.01f;
+	const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+	const float a	  = x8 * x2;
+	const float b	  = 1 / a;
+	const float denom = 1 / (a + b);
+	float c1 = 1, c2 = 1;
+	if (il.flags & PRGPU_SKYF_CLOUDY) {
+		c1 = (1 + 2.0f * tD.z) / 3.0f;
+		c2 = 0.7777777f;
+	}
+	const Blob zenith = spectrum_eval(sc, il.radiance, wl);
+	const Blob ground = spectrum_eval(sc, il.background != INVALID ? il.background : il.radiance, wl);
+	const float wz = c1 * a, wg = il.ground_brightness * c2 * b;
+	Blob out;
+	for (int k = 0; k < 4; ++k)
+		out.v[k] = (zenith.v[k] * wz + ground.v[k] * wg) * denom;
+	return out;
+}
 // IInfiniteLight::eval for a ray that leaves the scene in direction `dir`: EnvironmentLight (environment.cpp:53-73; camera rays see the
 // background), SkyLight (sky.cpp:51-79), SunLight (sun.cpp:61-77).  Delta lights (DISTANT) are never evaluated.
 __device__ __forceinline__ void inf_light_eval(const DevScene& sc, const DevInfLight& il, V3 dir, const Blob& wl, bool camera_ray, Blob& radiance, float& dir_pdf)
@@ -1298,6 +1353,11 @@ __device__ __forceinline__ void inf_light_eval(const DevScene& sc, const DevInfL
 		}
 		return;
 	}
+	if (il.kind == PRGPU_LIGHT_CIE_SKY) { // cie_sky.cpp:48-53
+		radiance = cie_sky_radiance(sc, il, wl, dir);
+		dir_pdf	 = fabsf(mat3_mul(il.inv_nm, dir).z) * PR_INV_PI_F;
+		return;
+	}
 	radiance	= spectrum_eval(sc, (camera_ray && il.background != INVALID) ? il.background : il.radiance, wl);
 	const V3 ld = mat3_mul(il.inv_nm, dir);
 	dir_pdf		= fabsf(ld.z) * PR_INV_PI_F;
@@ -1325,7 +1385,7 @@ __device__ __forceinline__ void inf_light_sample(const DevScene& sc, const DevIn
 		const V3 lo = cos_hemi(d0, d1);
 		dir_pdf		= lo.z * PR_INV_PI_F;
 		L			= mat3_mul(il.nm, lo);
-		radiance	= spectrum_eval(sc, il.radiance, wl);
+		radiance	= il.kind == PRGPU_LIGHT_CIE_SKY ? cie_sky_radiance(sc, il, wl, L) : spectrum_eval(sc, il.radiance, wl); // cie_sky.cpp:55-66
 	}
 }
 
@@ -1341,6 +1401,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	const float4 hit4  = ps.hit[slot];
 	const uint32_t tri = __float_as_uint(hit4.w);
 	uint32_t flags	   = ps.flags[slot];
+	if (flags & FLAG_NO_RAY) // the camera had no ray for this sample (camera_path): nothing was traced, nothing is splatted
+		return;
 	const uint32_t depth = flags & 0xFFu;
 	const bool mono		 = (flags & FLAG_MONO) != 0;
 	const Blob wl		 = from4(ps.wl[slot]);

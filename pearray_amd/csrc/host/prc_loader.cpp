@@ -100,6 +100,11 @@ struct Loader {
 	static double get_number(const Group& g, const char* key, double def)
 	{
 		const Value* v = g.get(key);
+		if (v && v->type == Value::GROUP && (v->g->id == "deg2rad" || v->g->id == "rad2deg") && v->g->anonymous_count() == 1 && v->g->at(0).is_number()) {
+			// SceneLoader::unpackShadingNetwork (SceneLoader.cpp:1025-1034): (deg2rad x) = x * PR_DEG2RAD in fp32
+			const float pi = 3.14159265358979323846f;
+			return v->g->id == "deg2rad" ? (float)v->g->at(0).number() * (pi / 180.0f) : (float)v->g->at(0).number() * (180.0f / pi);
+		}
 		return v && v->is_number() ? v->number() : def;
 	}
 	static bool get_bool(const Group& g, const char* key, bool def)
@@ -572,8 +577,20 @@ struct Loader {
 			l.azimuth_count	  = azc;
 			l.elevation_count = elc;
 			out.tables.insert(out.tables.end(), sky->table, sky->table + size_t(azc) * elc * PRGPU_SKY_BANDS);
+		} else if (type == "uniform_sky" || type == "cloudy_sky") { // CIESkyLightFactory::create, cie_sky.cpp:134-160
+			l.kind	= PRGPU_LIGHT_CIE_SKY;
+			l.flags = type == "cloudy_sky" ? PRGPU_SKYF_CLOUDY : 0u;
+			const Value* zen = g.get("zenith");
+			string_default	 = 1.0f;
+			l.radiance		 = zen ? spectral_node(*zen, g, "zenith") : spectrum_const(1.0f);
+			if (const Value* gt = g.get("ground_tint")) {
+				string_default = 0.0f;
+				l.background   = spectral_node(*gt, g, "ground_tint");
+			}
+			string_default		= 1.0f;
+			l.ground_brightness = (float)get_number(g, "ground_brightness", 0.2);
 		} else {
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": light type '" + type + "' is not supported (env/environment/background, distant/direction, sun and sky are)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": light type '" + type + "' is not supported (env/environment/background, distant/direction, sun, sky, uniform_sky and cloudy_sky are)");
 		}
 		out.lights.push_back(l);
 	}
@@ -700,11 +717,24 @@ struct Loader {
 	{
 		const std::string type = lower(get_string(g, "type", "standard"));
 		const bool ortho = type == "ortho" || type == "orthographic"; // ortho.cpp:78-92
-		if (!ortho && type != "standard_camera" && type != "standard" && type != "default" && type != "perspective")
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": camera type '" + type + "' is not supported (perspective and orthographic are)");
+		const bool spherical = type == "spherical", fisheye = type == "fisheye"; // spherical.cpp:107-111, fisheye.cpp:175-179
+		if (!ortho && !spherical && !fisheye && type != "standard_camera" && type != "standard" && type != "default" && type != "perspective")
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": camera type '" + type + "' is not supported (perspective, orthographic, spherical and fisheye are)");
 		prgpu_camera c;
 		std::memset(&c, 0, sizeof(c));
-		c.kind = ortho ? PRGPU_CAMERA_ORTHO : PRGPU_CAMERA_PERSPECTIVE;
+		c.kind = ortho ? PRGPU_CAMERA_ORTHO : (spherical ? PRGPU_CAMERA_SPHERICAL : (fisheye ? PRGPU_CAMERA_FISHEYE : PRGPU_CAMERA_PERSPECTIVE));
+		if (spherical) { // spherical.cpp:96-100
+			c.theta_start = (float)get_number(g, "theta_start", 0.0);
+			c.theta_end	  = (float)get_number(g, "theta_end", 1.57079632679489661923f);
+			c.phi_start	  = (float)get_number(g, "phi_start", -3.14159265358979323846f);
+			c.phi_end	  = (float)get_number(g, "phi_end", 3.14159265358979323846f);
+		}
+		if (fisheye) { // fisheye.cpp:137-173
+			const std::string map = lower(get_string(g, "map", "circular"));
+			c.fisheye_map		  = map == "cropped" ? PRGPU_FISHEYE_CROPPED : (map == "full" ? PRGPU_FISHEYE_FULL : PRGPU_FISHEYE_CIRCULAR);
+			c.fov				  = (float)get_number(g, "fov", 180.0f * (3.14159265358979323846f / 180.0f));
+			c.clip_range		  = get_bool(g, "clip_range", true) ? 1u : 0u;
+		}
 		transform_of(g, c.transform);
 		c.width			  = (float)get_number(g, "width", 1);
 		c.height		  = (float)get_number(g, "height", 1);
@@ -1594,8 +1624,26 @@ struct Loader {
 		const std::string cam = selected_camera.empty() ? first_camera : selected_camera;
 		if (!cameras.count(cam))
 			fail(PRGPU_EINVAL, "the scene's :camera '" + cam + "' does not exist");
-		if (out.entities.empty())
-			fail(PRGPU_EINVAL, "the scene has no entities");
+		if (out.entities.empty()) {
+			// A scene without entities is legal (examples/skylens.prc: a sky seen through a fisheye lens; every camera ray leaves the
+			// scene, Scene.cpp:107-118 keeps the default bounding sphere).  The backend's tree wants at least one primitive: one
+			// zero-area triangle at the origin, without a material, which no ray can hit.  The scene radius only scales the
+			// selection weight of ALL infinite lights alike (LightSampler.cpp:62-71), so it does not matter that it is 0 here.
+			prgpu_entity e;
+			std::memset(&e, 0, sizeof(e));
+			identity(e.transform);
+			e.kind		= PRGPU_ENTITY_MESH;
+			e.first_tri = 0;
+			e.n_tris	= 1;
+			e.emission	= PRGPU_INVALID_ID;
+			out.positions.assign(9, 0.0f);
+			out.indices.assign(3, 0u);
+			out.indices[1] = 1;
+			out.indices[2] = 2;
+			out.tri_material.assign(1, PRGPU_INVALID_ID);
+			out.entities.push_back(e);
+			warn("the scene has no entities: every camera ray sees the background");
+		}
 		if (any_normals)
 			out.normals.resize(out.positions.size(), 0.0f);
 		if (any_uvs)

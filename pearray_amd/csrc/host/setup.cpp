@@ -193,20 +193,66 @@ V4 sky_radiance(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl, f
 	}
 	return out;
 }
+// ITransformable::normalMatrix / invNormalMatrix of a light
+void light_matrices(const float* transform, float nm[9], float inv_nm[9])
+{
+	{ // (M^-1)^T = cofactor / det, same expression as entity_tables
+		const float* m = transform;
+		const float a = m[0], b = m[1], c = m[2], dd = m[4], ee = m[5], f = m[6], g = m[8], h = m[9], i2 = m[10];
+		const float cof[9] = { ee * i2 - f * h, f * g - dd * i2, dd * h - ee * g, c * h - b * i2, a * i2 - c * g, b * g - a * h, b * f - c * ee, c * dd - a * f, a * ee - b * dd };
+		const float det	   = (a * cof[0] + b * cof[1]) + c * cof[2];
+		for (int k = 0; k < 9; ++k)
+			nm[k] = cof[k] / det;
+	}
+	{ // inverse of the normal matrix: transposed cofactors / det
+		const float* m = nm;
+		const float a = m[0], b = m[1], c = m[2], dd = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i2 = m[8];
+		const float c00 = e * i2 - f * h, c01 = f * g - dd * i2, c02 = dd * h - e * g;
+		const float c10 = c * h - b * i2, c11 = a * i2 - c * g, c12 = b * g - a * h;
+		const float c20 = b * f - c * e, c21 = c * dd - a * f, c22 = a * e - b * dd;
+		const float det = (a * c00 + b * c01) + c * c02;
+		const float inv[9] = { c00 / det, c10 / det, c20 / det, c01 / det, c11 / det, c21 / det, c02 / det, c12 / det, c22 / det };
+		std::memcpy(inv_nm, inv, sizeof(inv));
+	}
+}
+// CIESimpleSkyLight::radiance for the world direction (0, 0, 1) (cie_sky.cpp:80,108-126); same arithmetic as the device function
+V4 cie_sky_zenith(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl)
+{
+	float nm[9], inv[9];
+	light_matrices(l.transform, nm, inv);
+	const float z	  = (inv[6] * 0.0f + inv[7] * 0.0f) + inv[8] * 1.0f;
+	const float x	  = z + 1.01f;
+	const float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+	const float a	  = x8 * x2;
+	const float b	  = 1 / a;
+	const float denom = 1 / (a + b);
+	float c1 = 1, c2 = 1;
+	if (l.flags & PRGPU_SKYF_CLOUDY) {
+		c1 = (1 + 2.0f * z) / 3.0f;
+		c2 = 0.7777777f;
+	}
+	const V4 zen = eval_spectrum(d, l.radiance, wl), gnd = eval_spectrum(d, l.background != PRGPU_INVALID_ID ? l.background : l.radiance, wl);
+	V4 out;
+	for (int k = 0; k < 4; ++k)
+		out.v[k] = (zen.v[k] * (c1 * a) + gnd.v[k] * (l.ground_brightness * c2 * b)) * denom;
+	return out;
+}
 // IInfiniteLight::power: environment / distant average their node (environment.cpp, distant.cpp:93), the sky returns its zenith
 // radiance (sky.cpp:113: ElevationAzimuth::fromDirection((0, 0, 1)) = {pi/2, 0}), the sun looks its spectrum up (sun.cpp:106-112,222-228)
 V4 inf_light_power(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl)
 {
 	if (l.kind == PRGPU_LIGHT_SKY)
 		return sky_radiance(d, l, wl, 0.5f * 3.14159265358979323846f - 0.0f, 0.0f);
+	if (l.kind == PRGPU_LIGHT_CIE_SKY)
+		return cie_sky_zenith(d, l, wl);
 	if (l.kind == PRGPU_LIGHT_SUN || (l.kind == PRGPU_LIGHT_DISTANT && (l.flags & PRGPU_LIGHTF_SUN_DELTA)))
 		return eval_spectrum(d, l.radiance, wl);
 	return average_power(d, l.radiance, wl);
 }
 void inf_light_range(const prgpu_scene_desc* d, const prgpu_light& l, float& start, float& end) // IInfiniteLight::spectralRange
 {
-	start = end = -1.0f; // SkyLight: SpectralRange() (sky.cpp:114)
-	if (l.kind != PRGPU_LIGHT_SKY)
+	start = end = -1.0f; // SkyLight, CIESimpleSkyLight: SpectralRange() (sky.cpp:114, cie_sky.cpp:81)
+	if (l.kind != PRGPU_LIGHT_SKY && l.kind != PRGPU_LIGHT_CIE_SKY)
 		spectral_range(d, l.radiance, start, end);
 }
 
@@ -501,24 +547,7 @@ void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 		L.kind				   = src.kind;
 		L.radiance			   = src.radiance;
 		L.background		   = src.background;
-		{ // (M^-1)^T = cofactor / det, same expression as entity_tables
-			const float* m = src.transform;
-			const float a = m[0], b = m[1], c = m[2], dd = m[4], ee = m[5], f = m[6], g = m[8], h = m[9], i2 = m[10];
-			const float cof[9] = { ee * i2 - f * h, f * g - dd * i2, dd * h - ee * g, c * h - b * i2, a * i2 - c * g, b * g - a * h, b * f - c * ee, c * dd - a * f, a * ee - b * dd };
-			const float det	   = (a * cof[0] + b * cof[1]) + c * cof[2];
-			for (int k = 0; k < 9; ++k)
-				L.nm[k] = cof[k] / det;
-		}
-		{ // inverse of the normal matrix: transposed cofactors / det
-			const float* m = L.nm;
-			const float a = m[0], b = m[1], c = m[2], dd = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i2 = m[8];
-			const float c00 = e * i2 - f * h, c01 = f * g - dd * i2, c02 = dd * h - e * g;
-			const float c10 = c * h - b * i2, c11 = a * i2 - c * g, c12 = b * g - a * h;
-			const float c20 = b * f - c * e, c21 = c * dd - a * f, c22 = a * e - b * dd;
-			const float det = (a * c00 + b * c01) + c * c02;
-			const float inv[9] = { c00 / det, c10 / det, c20 / det, c01 / det, c11 / det, c21 / det, c02 / det, c12 / det, c22 / det };
-			std::memcpy(L.inv_nm, inv, sizeof(inv));
-		}
+		light_matrices(src.transform, L.nm, L.inv_nm);
 		const float* dv = src.direction;
 		float o[3];
 		for (int r = 0; r < 3; ++r)
@@ -530,6 +559,7 @@ void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 		for (int r = 0; r < 3; ++r)
 			L.dx[r] = L.dy[r] = 0.0f;
 		L.cos_theta = L.cone_pdf = 0.0f;
+		L.ground_brightness		 = src.ground_brightness;
 		L.table_offset = L.az_count = L.el_count = L.dist_offset = L.dist_w = L.dist_h = 0;
 		if (src.kind == PRGPU_LIGHT_SUN) { // SunLight ctor (sun.cpp:31-46): Tangent::frame(mDirection), uniform_cone_pdf
 			const float* N	 = L.outgoing;
@@ -695,9 +725,50 @@ void camera_cache(const prgpu_scene_desc* d, HostTables& t)
 	o.o[1] = c.transform[7];
 	o.o[2] = c.transform[11];
 	o.ortho	 = c.kind == PRGPU_CAMERA_ORTHO ? 1u : 0u;
-	o.dof	 = (!o.ortho && c.aperture_radius > EPS_F && c.fstop > EPS_F) ? 1u : 0u;
+	o.dof	 = (c.kind == PRGPU_CAMERA_PERSPECTIVE && c.aperture_radius > EPS_F && c.fstop > EPS_F) ? 1u : 0u;
 	o.near_t = c.near_t;
 	o.far_t	 = c.far_t;
+	o.kind	 = c.kind;
+	o.angles[0] = c.theta_start;
+	o.angles[1] = c.theta_end;
+	o.angles[2] = c.phi_start;
+	o.angles[3] = c.phi_end;
+	o.fov		= c.fov;
+	o.clip		= c.clip_range ? 1u : 0u;
+	o.xaspect = o.yaspect = 1.0f;
+	if (c.kind == PRGPU_CAMERA_SPHERICAL || c.kind == PRGPU_CAMERA_FISHEYE) { // the cached axes (spherical.cpp:33-35, fisheye.cpp:42-44)
+		for (int k = 0; k < 3; ++k) {
+			o.focal[k] = dir[k];
+			o.right[k] = right[k];
+			o.up[k]	   = up[k];
+			o.xap[k] = o.yap[k] = 0.0f;
+		}
+		if (c.kind == PRGPU_CAMERA_FISHEYE) { // fisheye.cpp:63-90
+			const float W = (float)d->settings.width, H = (float)d->settings.height;
+			const float aspect = W / H;
+			switch (c.fisheye_map) {
+			default:
+			case PRGPU_FISHEYE_CIRCULAR:
+				o.xaspect = aspect < 1 ? 1 : aspect;
+				o.yaspect = aspect > 1 ? 1 : aspect;
+				break;
+			case PRGPU_FISHEYE_CROPPED:
+				o.xaspect = aspect < 1 ? 1 / aspect : 1;
+				o.yaspect = aspect > 1 ? 1 / aspect : 1;
+				break;
+			case PRGPU_FISHEYE_FULL: {
+				const float diameter = std::sqrt(aspect * aspect + 1.0f) * H;
+				const float k		 = std::min(W, H);
+				const float f		 = diameter / k;
+				o.xaspect			 = aspect < 1 ? 1 : 1 / aspect;
+				o.yaspect			 = aspect > 1 ? 1 : aspect;
+				o.xaspect *= f;
+				o.yaspect *= f;
+			} break;
+			}
+		}
+		return;
+	}
 	if (o.ortho) { // ortho.cpp:29-31: normalised direction, half-extent axes
 		const float len = std::sqrt((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
 		for (int k = 0; k < 3; ++k) {
@@ -914,14 +985,21 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 				return bad("textured materials on sphere entities are not supported (their uv needs atan2 / acos)", PRGPU_EUNSUPPORTED);
 		}
 	}
-	if (d->camera.kind > PRGPU_CAMERA_ORTHO)
+	if (d->camera.kind > PRGPU_CAMERA_FISHEYE)
 		return bad("unknown camera kind");
+	if (d->camera.kind == PRGPU_CAMERA_FISHEYE && (d->camera.fisheye_map > PRGPU_FISHEYE_FULL || !(d->camera.fov > 0.0f) || !std::isfinite(d->camera.fov)))
+		return bad("fisheye camera: fov must be positive and finite, map one of PRGPU_FISHEYE_*");
+	if (d->camera.kind == PRGPU_CAMERA_SPHERICAL
+		&& !(std::isfinite(d->camera.theta_start) && std::isfinite(d->camera.theta_end) && std::isfinite(d->camera.phi_start) && std::isfinite(d->camera.phi_end)))
+		return bad("spherical camera: theta / phi range must be finite");
 	if (d->n_lights && !d->lights)
 		return bad("n_lights without a lights array");
 	for (uint32_t i = 0; i < d->n_lights; ++i) {
 		const prgpu_light& l = d->lights[i];
-		if (l.kind > PRGPU_LIGHT_SUN)
+		if (l.kind > PRGPU_LIGHT_CIE_SKY)
 			return bad("unknown infinite light kind");
+		if (l.kind == PRGPU_LIGHT_CIE_SKY && !(l.ground_brightness >= 0.0f && std::isfinite(l.ground_brightness)))
+			return bad("cie sky light: ground_brightness must be finite and non-negative");
 		if (l.kind == PRGPU_LIGHT_SKY) {
 			if (l.azimuth_count == 0 || l.elevation_count == 0 || l.azimuth_count > 8192 || l.elevation_count > 8192)
 				return bad("sky light: table resolution must be 1..8192 per axis");

@@ -274,6 +274,13 @@ class SceneBuilder:
         self.lights[k].cos_theta = float(np.cos(np.float32(self.SUN_VIS_RADIUS * np.float32(radius))))
         return k
 
+    def cie_sky_light(self, zenith, ground_tint=None, ground_brightness=0.2, cloudy=False, transform=IDENTITY):
+        """(light :type 'uniform_sky' | 'cloudy_sky' :zenith z [:ground_tint g] [:ground_brightness b]), cie_sky.cpp:134-160"""
+        k = self._light(abi.LIGHT_CIE_SKY, zenith, ground_tint, (0, 0, 1), transform)
+        self.lights[k].flags = abi.SKYF_CLOUDY if cloudy else 0
+        self.lights[k].ground_brightness = float(ground_brightness)
+        return k
+
     def add_plane(self, material, x_axis=(1, 0, 0), y_axis=(0, 1, 0), width=1.0, height=1.0, centering=False, transform=IDENTITY, emission=None):
         """(entity :type 'plane'), plane.cpp:241-258: parallelogram spanned by width * x_axis and height * y_axis"""
         x = np.float32(width) * np.asarray(x_axis, dtype=np.float32)
@@ -303,6 +310,21 @@ class SceneBuilder:
             c.local_up[i] = local_up[i]
         c.fstop, c.aperture_radius = fstop, aperture_radius
         c.kind = abi.CAMERA_ORTHO if ortho else abi.CAMERA_PERSPECTIVE
+
+    def set_spherical_camera(self, transform, theta_start=0.0, theta_end=float(np.float32(np.pi) / np.float32(2)), phi_start=-float(np.float32(np.pi)),
+                             phi_end=float(np.float32(np.pi)), **frame):
+        """(camera :type 'spherical'), spherical.cpp:91-105"""
+        self.set_camera(transform, **frame)
+        c = self.camera
+        c.kind = abi.CAMERA_SPHERICAL
+        c.theta_start, c.theta_end, c.phi_start, c.phi_end = theta_start, theta_end, phi_start, phi_end
+
+    def set_fisheye_camera(self, transform, fov=float(np.float32(180.0) * (np.float32(np.pi) / np.float32(180.0))), map_type=abi.FISHEYE_CIRCULAR, clip_range=True, **frame):
+        """(camera :type 'fisheye' :fov f :map 'circular'|'cropped'|'full' :clip_range b), fisheye.cpp:137-173"""
+        self.set_camera(transform, **frame)
+        c = self.camera
+        c.kind = abi.CAMERA_FISHEYE
+        c.fov, c.fisheye_map, c.clip_range = fov, map_type, 1 if clip_range else 0
 
     def build(self):
         return SceneData(self)
@@ -451,7 +473,8 @@ class ArrayScene:
 
     def __init__(self, path, sky_tables=None):
         z = np.load(path)
-        assert int(z["api_version"][0]) == abi.PRGPU_API_VERSION, "scene cache written for another ABI version"
+        # v6 caches load unchanged: prgpu_light kept its size, and the v6 prgpu_camera is a prefix of the v7 one (the new fields are zero)
+        assert int(z["api_version"][0]) in (6, abi.PRGPU_API_VERSION), "scene cache written for another ABI version"
         self.positions, self.indices, self.tri_material = z["positions"], z["indices"], z["tri_material"]
         self.normals = z["normals"] if len(z["normals"]) else None
         self.uvs = z["uvs"] if len(z["uvs"]) else None
@@ -490,7 +513,7 @@ class ArrayScene:
             setattr(d, name, self._structs[name])
         d.n_spectral_table_values = offset
         d.spectral_tables = self.tables.ctypes.data_as(f32p)
-        d.camera = abi.Camera.from_buffer_copy(z["camera"].tobytes())
+        d.camera = abi.Camera.from_buffer_copy(z["camera"].tobytes().ljust(C.sizeof(abi.Camera), b"\0"))
         d.settings = abi.Settings.from_buffer_copy(z["settings"].tobytes())
         self.desc = d
 

@@ -97,6 +97,7 @@ def bind(lib):
     lib.orc_refract.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.orc_spectrum_eval.restype = None
     lib.orc_spectrum_eval.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.orc_camera_ray.restype = C.c_int
     lib.orc_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, _F32P, _F32P]
     lib.orc_wavelength_cdf.argtypes = [C.c_void_p, _U32P, C.POINTER(_F32P)]
     lib.orc_light_selector.argtypes = [C.c_void_p, _U32P, C.POINTER(_F32P), C.POINTER(_F32P)]
@@ -126,6 +127,8 @@ def bind(lib):
     lib.orc_uniform_cone.argtypes = [C.c_float, C.c_float, C.c_float, _F32P]
     lib.orc_inf_light_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, C.c_int, _F32P, _F32P]
     lib.orc_inf_light_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, _F32P, _F32P, _F32P, _F32P]
+    lib.orc_inf_light_power.restype = None
+    lib.orc_inf_light_power.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P]
     return lib
 
 

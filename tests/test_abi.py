@@ -62,7 +62,7 @@ def test_error_reporting_without_a_gpu():
     assert lib.prgpu_scene_create(None, 0, C.byref(h)) == -1
     assert b"null" in lib.prgpu_last_error()
     sc = scene.cornell_box(8, 8, spp=1)
-    sc.desc.api_version = 7
+    sc.desc.api_version = 99
     assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"api_version" in lib.prgpu_last_error()
     sc = scene.cornell_box(8, 8, spp=1)
     sc.indices[5] = 99999

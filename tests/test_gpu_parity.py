@@ -911,3 +911,100 @@ def test_textured_cornell_with_nested_checkers():
     scene._cornell_into(b, material_override={"floor": floor, "tallBox": lambda bb: bb.rough_dielectric(0.2, ior=bb.checkerboard(bb.spectrum_const(1.3), bb.lookup_index("bk7"), 5))})
     g, o = render_both(b.build())
     assert_parity(g, o, exact=True)
+
+
+def _camera_scene(camera, lights=("cloudy",), size=(96, 64), spp=5, **settings):
+    """The open scene (y up) seen through a spherical / fisheye camera under CIE sky lights (frames: light +z -> world +y)."""
+    b = scene.SceneBuilder(*size)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, spp
+    for k, v in settings.items():
+        setattr(b.settings, k, v)
+    T = np.array([[1, 0, 0, 0.1], [0, 1, 0, 1.4], [0, 0, 1, 2.6], [0, 0, 0, 1]], dtype=np.float32)
+    frame = dict(near=0.01, far=100.0, local_direction=(0, 0, -1), local_up=(0, 1, 0), local_right=(1, 0, 0))
+    if camera == "spherical":
+        b.set_spherical_camera(T, theta_start=-1.570796, **frame)
+    elif camera == "spherical_window":
+        b.set_spherical_camera(T, theta_start=-0.6, theta_end=0.9, phi_start=-1.2, phi_end=1.0, **frame)
+    else:
+        kind, clip = camera
+        b.set_fisheye_camera(T, fov=float(np.float32(np.deg2rad(170.0))), map_type=kind, clip_range=clip, **frame)
+    white = b.lambert(b.refl(0.7, 0.7, 0.7))
+    b.add_plane(white, x_axis=(1, 0, 0), y_axis=(0, 0, -1), width=8, height=8, centering=True)
+    cube_p = [[x, y, z] for x in (-0.5, 0.5) for y in (0, 1) for z in (-0.5, 0.5)]
+    cube_f = [[0, 1, 3, 2], [4, 6, 7, 5], [0, 4, 5, 1], [2, 3, 7, 6], [0, 2, 6, 4], [1, 5, 7, 3]]
+    b.add_mesh(cube_p, cube_f, b.dielectric(b.lookup_index("bk7")), transform=np.array([[0.8, 0, 0.6, -0.7], [0, 1.2, 0, 0], [-0.6, 0, 0.8, 0], [0, 0, 0, 1]], dtype=np.float32))
+    b.add_mesh(cube_p, cube_f, b.lambert(b.refl(0.2, 0.5, 0.7)), transform=np.array([[0.6, 0, 0, 0.9], [0, 0.6, 0, 0], [0, 0, 0.6, 0.6], [0, 0, 0, 1]], dtype=np.float32))
+    R = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=np.float32)     # light +z -> world +y
+    for l in lights:
+        if l == "cloudy":
+            b.cie_sky_light(b.illuminant_d65(), cloudy=True, transform=R)
+        elif l == "uniform_tinted":
+            b.cie_sky_light(b.illum(1.0, 0.95, 0.9), ground_tint=b.refl(0.3, 0.25, 0.2), ground_brightness=0.5, cloudy=False, transform=R)
+        elif l == "sun":
+            b.distant_light(b.illum(4, 4, 3.5), direction=(0.3, 0.9, 0.2))
+    return b.build()
+
+
+@pytest.mark.parametrize("camera,size", [("spherical", (96, 48)), ("spherical_window", (80, 64)),
+                                         ((abi.FISHEYE_CIRCULAR, True), (96, 64)), ((abi.FISHEYE_CIRCULAR, False), (64, 96)),
+                                         ((abi.FISHEYE_CROPPED, True), (96, 64)), ((abi.FISHEYE_FULL, True), (96, 64)), ((abi.FISHEYE_CIRCULAR, True), (64, 64))])
+def test_spherical_and_fisheye_cameras_bit_exact(camera, size):
+    """spherical.cpp / fisheye.cpp camera rays through the shared fp32 sin / cos: identical images; a clipped fisheye sample is counted,
+    spends its random numbers and traces nothing (the statistics agree too)."""
+    g, o = render_both(_camera_scene(camera, size=size))
+    assert_parity(g, o, exact=True)
+    st = g.statistics()
+    if isinstance(camera, tuple) and camera[1] and camera[0] != abi.FISHEYE_FULL:
+        assert st["primary_rays"] < 0.95 * st["pixel_samples"]
+    elif isinstance(camera, tuple) and camera[1]:   # 'full': the image circle circumscribes the sensor; only jittered corner samples fall outside
+        assert 0.999 * st["pixel_samples"] < st["primary_rays"] <= st["pixel_samples"]
+    else:
+        assert st["primary_rays"] == st["pixel_samples"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_clipped_fisheye_in_every_pipeline(monkeypatch, mode):
+    monkeypatch.setenv("PRGPU_MODE", mode)
+    g, o = render_both(_camera_scene((abi.FISHEYE_CIRCULAR, True), lights=("uniform_tinted", "sun"), size=(72, 48), spp=4))
+    assert_parity(g, o, exact=True)
+    xyz, smp, _ = g.output()
+    assert np.all(xyz[0, 0] == 0) and smp[0, 0] == 0 and xyz[24, 36].sum() > 0     # a corner outside the image circle, the centre inside
+
+
+@pytest.mark.parametrize("lights,kw", [(("cloudy",), {}), (("uniform_tinted",), {}), (("cloudy", "sun"), dict(mis=abi.MIS_POWER)),
+                                       (("uniform_tinted",), dict(nee=0)), (("cloudy", "uniform_tinted"), dict(spectral_hero=0))])
+def test_cie_sky_lights_bit_exact(lights, kw):
+    """cie_sky.cpp uniform / cloudy sky: radiance by local z with zenith and ground tints, cosine-hemisphere NEE, MIS on background hits."""
+    g, o = render_both(_camera_scene("spherical_window", lights=lights, size=(80, 64), **kw))
+    assert_parity(g, o, exact=True)
+    assert g.statistics()["background_hits"] > 0
+
+
+def test_reference_sky_examples_render_like_the_oracle():
+    """examples/sky.prc (spherical camera, cloudy sky + sun, a glass sphere) and examples/skylens.prc (fisheye, sky light, NO entity)
+    as written by hand here: the reference files themselves do not travel to the GPU box."""
+    src = """(scene :render_width 64 :render_height 32
+      (sampler :slot 'aa' :type 'sobol' :sample_count 4)
+      (filter :slot 'pixel' :type 'mitchell' :radius 1)
+      (integrator :type 'direct')
+      (camera :name 'Camera' :type 'spherical' :theta_start -1.570796)
+      (light :name 'sky' :type 'cloudy_sky' :zenith (illuminant "D65"))
+      (light :name 'sun' :type 'sun' :turbidity 3 :radius 1)
+      (material :name 'Sphere' :type 'glass' :index (lookup_index "bk7"))
+      (entity :name 'Sphere' :type 'sphere' :material 'Sphere' :radius 1.5 :position [0,4,0]))"""
+    sc = scene.PrcScene(source=src)
+    assert sc.desc.camera.kind == abi.CAMERA_SPHERICAL
+    g, o = render_both(sc)
+    assert_parity(g, o, exact=True)
+    lens = """(scene :render_width 48 :render_height 48
+      (sampler :slot 'aa' :type 'sobol' :sample_count 4)
+      (filter :slot 'pixel' :type 'mitchell' :radius 0)
+      (integrator :type 'direct')
+      (camera :name 'Camera' :type 'fisheye' :fov (deg2rad 180) :local_direction [0,0,1] :local_up [0,1,0] :local_right [1,0,0])
+      (light :name 'sky' :zenith (illuminant "D65") :type 'sky' :turbidity 3 :azimuth_resolution 64 :elevation_resolution 32))"""
+    sc = scene.PrcScene(source=lens, skies={"sky": _sky_table()})
+    assert sc.desc.camera.kind == abi.CAMERA_FISHEYE and sc.desc.n_triangles == 1
+    g, o = render_both(sc)
+    assert_parity(g, o, exact=True)
+    st = g.statistics()
+    assert st["entity_hits"] == 0 and 0 < st["background_hits"] == st["primary_rays"] < st["pixel_samples"]

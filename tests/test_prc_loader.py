@@ -212,7 +212,7 @@ def test_every_reference_example_either_loads_or_names_what_is_missing():
             msg = lib.prgpu_prc_last_error().decode()
             assert "not supported" in msg or "not available" in msg or "needs the table" in msg, name
             refused.append(name)
-    assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and "complex.prc" in loaded and "material_array.prc" in loaded and len(loaded) >= 14
+    assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and "complex.prc" in loaded and "material_array.prc" in loaded and "sky.prc" in loaded and "skylens.prc" in loaded and len(loaded) >= 16
 
 
 def test_obj_embed_semantics(tmp_path):
