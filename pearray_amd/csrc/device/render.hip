@@ -136,11 +136,14 @@ __device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q
 		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
 		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
 		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
+		// plane - origin as (node origin - ray origin) + byte * step: the product is exact, so this rounds twice like the two-step
+		// form (decode the plane, subtract the origin) but costs one operation less per plane
+		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const float axk = (__fmaf_rn(PR_UB(wnx, k), sx, q0.x) - s.r.o.x) * s.r.inv_d.x, bxk = (__fmaf_rn(PR_UB(wfx, k), sx, q0.x) - s.r.o.x) * s.r.inv_d.x;
-			const float ayk = (__fmaf_rn(PR_UB(wny, k), sy, q0.y) - s.r.o.y) * s.r.inv_d.y, byk = (__fmaf_rn(PR_UB(wfy, k), sy, q0.y) - s.r.o.y) * s.r.inv_d.y;
-			const float azk = (__fmaf_rn(PR_UB(wnz, k), sz, q0.z) - s.r.o.z) * s.r.inv_d.z, bzk = (__fmaf_rn(PR_UB(wfz, k), sz, q0.z) - s.r.o.z) * s.r.inv_d.z;
+			const float axk = __fmaf_rn(PR_UB(wnx, k), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn(PR_UB(wfx, k), sx, dx) * s.r.inv_d.x;
+			const float ayk = __fmaf_rn(PR_UB(wny, k), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn(PR_UB(wfy, k), sy, dy) * s.r.inv_d.y;
+			const float azk = __fmaf_rn(PR_UB(wnz, k), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn(PR_UB(wfz, k), sz, dz) * s.r.inv_d.z;
 			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
 			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
 			t[k]		   = t0;
