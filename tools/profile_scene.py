@@ -1,5 +1,5 @@
 """Render exactly N iterations of a named scene (no checks, no instrumentation): the program rocprofv3 wraps for the scenes bench.py
-does not cover.  usage: python3 tools/profile_scene.py c5|rough|metal_all N"""
+does not cover.  usage: python3 tools/profile_scene.py c5|rough|metal_all|share8 N   (share8 = rank 0's tiles of the C4 frame at 8 ranks)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,9 +13,14 @@ elif name == "rough":
 elif name == "metal_all":
     os.environ["PRGPU_FORCE_FEATURES"] = "255"
     sc = scene.cornell_metal(1024, 1024, spp=256)
+elif name.startswith("share"):
+    sc = scene.cornell_soup(1920, 1080, spp=1024, n_triangles=1_000_000)
 else:
     raise SystemExit("unknown scene")
 ctx = backend.RenderContext(sc)
+if name.startswith("share"):
+    from pearray_amd import tiling
+    ctx.setTiles(tiling.tiles_for_rank(1920, 1080, 0, int(name[5:])))
 ctx.render(iters)
 ctx.waitForFinish()
 print("rendered %d iterations of %s: %s" % (iters, name, ctx.statistics()))
