@@ -425,6 +425,12 @@ int      prgpu_download_aov(prgpu_scene* s, uint32_t aov, float* out);
  * depends on the thread-tile grid.  Enable before the first iteration; planes are W*H*3 floats. */
 int prgpu_enable_variance(prgpu_scene* s);
 int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance); /* either pointer may be NULL */
+
+/* Scheduling statistic of the persistent pipeline: path vertices traced per pixel so far (W*H u32; kept only while every owned pixel is in
+ * flight at once -- a small tile share --, 0 otherwise and in the other pipelines).  The
+ * backend uses it to hand the pixels with the longest sample chains to the fastest blocks of a small tile share; exposed for
+ * diagnostics (tools/gpu_block_life.py).  No reference counterpart. */
+int prgpu_path_cost(prgpu_scene* s, uint32_t* vertices);
 /* ToneMapper::map (src/core/spectral/ToneMapper.cpp:12-79): XYZ triplets -> `out_elems` (>= 3) floats per pixel in the colour mode of
  * an output channel (`:color 'srgb'|'xyz'|'norm_xyz'|'lum'`, OutputSpecification.cpp:262-272); SRGB is RGBConverter::fromXYZ
  * (src/core/spectral/RGBConverter.cpp:15-24: linear sRGB, clamped at 0).  `weight` (per pixel, may be NULL) divides, `scale` multiplies.

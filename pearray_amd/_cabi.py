@@ -169,6 +169,7 @@ SYMBOLS = {
     "prgpu_film_size": (C.c_int, [_VP, _U32P, _U32P]),
     "prgpu_enable_variance": (C.c_int, [_VP]),
     "prgpu_download_variance": (C.c_int, [_VP, _F32P, _F32P]),
+    "prgpu_path_cost": (C.c_int, [_VP, _U32P]),
     "prgpu_tonemap": (C.c_int, [C.c_uint32, C.c_float, _F32P, _F32P, _F32P, C.c_uint32, C.c_size_t]),
     "prgpu_outputs_enable": (C.c_int, [_VP, C.POINTER(OutputChannel), C.c_uint32]),
     "prgpu_outputs_save": (C.c_int, [_VP, C.POINTER(OutputChannel), C.c_uint32, C.c_uint32, C.c_char_p]),

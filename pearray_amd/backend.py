@@ -123,6 +123,12 @@ class RenderContext:
         abi.check(self.lib.prgpu_download_variance(self._h, _f32p(mean), _f32p(var)))
         return mean.reshape(self.height, self.width, 3), var.reshape(self.height, self.width, 3)
 
+    def pathCost(self):
+        """Path vertices traced per pixel so far (persistent pipeline; scheduling statistic)."""
+        out = np.empty(self.width * self.height, dtype=np.uint32)
+        abi.check(self.lib.prgpu_path_cost(self._h, _u32p(out)))
+        return out.reshape(self.height, self.width)
+
     def enableOutputs(self, prc_scene):
         """Allocate the planes the scene's (output ...) blocks ask for (OutputSpecification::setup)."""
         ch, n = prc_scene.outputs()

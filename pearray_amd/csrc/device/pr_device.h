@@ -212,6 +212,7 @@ struct PathState {
 	// shading-point AOV sums (LocalFrameOutputDevice::commitShadingPoints), null when disabled; index = PRGPU_AOV_*
 	float* online_mean;		// AOV_OnlineMean / AOV_OnlineVariance (W*H*3 each), null unless enabled: Welford update per pixel and iteration
 	float* online_variance; // (VarianceEstimator.inl:15-27) at the point where the iteration's value folds into the running mean
+	uint32_t* cost;			// persistent pipeline: path vertices traced per pixel so far (scheduling statistic, see prgpu_path_cost), or null
 	float* aov[PRGPU_AOV_COUNT];
 	uint32_t aov_mask;
 };

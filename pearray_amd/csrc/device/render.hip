@@ -2101,6 +2101,7 @@ struct PersistentArgs {
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
 	uint32_t sort_rays;	  // 1: a shading pass queues its rays ordered by direction octant
 	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
+	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
 	unsigned long long* gstats;
 };
 
@@ -2214,6 +2215,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					need_pixel			 = true;
 					if (pixel != INVALID) {
 						iter = ps.iter[slot];
+						if (ps.cost)
+							ps.cost[pixel] += (ps.flags[slot] & 0xFFu) + 1u;
 						if (!ps.plane_stride) { // single-tap filter: the sample folds into the running mean right here; with a ring of
 												// planes the launch only fills the planes and k_resolve gathers the taps afterwards
 							const float v[3] = { ps.iter_xyz[3 * pixel], ps.iter_xyz[3 * pixel + 1], ps.iter_xyz[3 * pixel + 2] };
@@ -2227,7 +2230,11 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				}
 				bool retired = false;
 				{
-					const uint32_t idx = wave_append(need_pixel, a.next_pixel); // 64 neighbouring pixels per wave-full
+					uint32_t idx;
+					if (a.direct_map)
+						idx = need_pixel && ps.pixel[slot] == INVALID ? slot : a.n_owned; // the slot's one and only pixel, then retirement
+					else
+						idx = wave_append(need_pixel, a.next_pixel); // 64 neighbouring pixels per wave-full
 					if (need_pixel) {
 						if (idx < a.n_owned) {
 							ps.pixel[slot] = a.owned[idx];
@@ -2602,6 +2609,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st)
 {
 	const PersistentGeometry g = persistent_geometry(n_owned, ws.max_blocks, max_slots_per_block);
+	const bool all_in_flight   = uint64_t(g.n_blocks) * g.slots_per_block >= n_owned;
 	PersistentArgs a;
 	a.owned			  = owned;
 	a.n_owned		  = n_owned;
@@ -2622,6 +2630,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.sort_rays		  = getenv("PRGPU_PP_SORT") && atoi(getenv("PRGPU_PP_SORT")) != 0 ? 1u : 0u;
 	a.leaf_bias		  = getenv("PRGPU_PP_LEAF_BIAS") ? std::max(1, atoi(getenv("PRGPU_PP_LEAF_BIAS"))) : 100;
 	a.gstats		  = gstats;
+	a.direct_map	  = all_in_flight ? 1u : 0u;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks);
 	// smallest compiled variant that covers the scene's features: lean (Lambert / mesh / area lights), + smooth delta materials,

@@ -102,6 +102,7 @@ struct prgpu_scene {
 	uint64_t family_launches[N_FAMILIES] = { 0 };
 	uint64_t rays_closest = 0, rays_any = 0;
 	uint32_t next_iteration = 0;
+	uint32_t order_tuned_at = 0; // iteration count the pixel order was last tuned at (tune_pixel_order)
 	bool poisoned = false; // a device-side error was reported: further render calls are refused
 	uint64_t pp_launch_samples = 128ull << 20; // persistent mode: camera samples per launch (render calls are cut into bounded launches)
 	uint32_t pp_launch_min_iters = 8;
@@ -462,6 +463,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(s->dead_a, np, false);
 	AL(s->dead_b, np, false);
 	AL(ps.iter, ns, true);
+	AL(ps.cost, np, true);
 	// streaming (pixels advance through their samples independently) is bit-identical for single-tap filters but measured
 	// ~6% slower than the iteration-synchronous pipeline on MI355X (finished paths wait one round before their pixel's
 	// next sample starts); it stays available behind PRGPU_STREAMING=1
@@ -815,6 +817,8 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	// per iteration, 1/16: 2.23 -> 1.83).  With more pixels than slots the shared scheme is faster (full frame 13.7 vs 14.3 ms).
 	const bool all_in_flight = uint64_t(s->n_slots) <= uint64_t(s->ws_pp.max_blocks) * s->pp_slots;
 	const int shader_wave	 = s->pp_shader_wave >= 0 ? s->pp_shader_wave : (all_in_flight ? 1 : 0);
+	if (!all_in_flight)
+		ps.cost = nullptr; // the per-pixel path cost only serves tune_pixel_order
 	const bool ring			= !s->sc.single_tap; // multi-tap filter: one launch fills at most pp_planes iteration planes
 	if (ring) {
 		chunk			= std::min(chunk, s->pp_planes);
@@ -843,6 +847,94 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 		}
 		b = e;
 	}
+	return PRGPU_OK;
+}
+
+// Small tile shares (every owned pixel in flight at once, slot k renders owned[k]) are bound by the longest CHAIN of samples, not by
+// work: a block lives as long as its deepest pixel needs (vertices per sample x per-vertex latency), and the per-vertex latency differs
+// by dispatch layer -- of the three blocks a CU holds, the first-dispatched steps ~8 % faster than the second and ~19 % faster than
+// the third, whatever their load (measured on 1/8 of the C4 frame: block lifetimes 1.75 / 2.1 / 2.45 ms per iteration at equal work;
+// rotating s_setprio among them, handing the slow layers fewer pixels, or throttling the fast layer changes nothing).  So once the
+// per-pixel cost is known (PathState::cost, after the first few iterations) the pixels whose chains are too long for a slow layer
+// move to a faster one: cost above c_max / speed ratio of layer 1 -> layer 0 only, above c_max / ratio of layer 2 -> layers 0 and 1;
+// everything else keeps the strided mix.  Pure scheduling: the image does not depend on which slot renders a pixel.
+// Called from prgpu_sync (the stream is idle).
+int tune_pixel_order(prgpu_scene* s)
+{
+	// the estimate sharpens with the sample count: tune after 4 iterations, again whenever the count has doubled
+	if (s->mode != prgpu_scene::PERSISTENT || s->next_iteration < std::max(4u, 2u * s->order_tuned_at) || !s->n_slots)
+		return PRGPU_OK;
+	s->order_tuned_at = s->next_iteration;
+	if (const char* env = getenv("PRGPU_PP_TUNE_ORDER"))
+		if (atoi(env) == 0)
+			return PRGPU_OK;
+	const prd::PersistentGeometry g = prd::persistent_geometry(s->n_slots, s->ws_pp.max_blocks, s->pp_slots);
+	if (uint64_t(g.n_blocks) * g.slots_per_block < s->n_slots || g.n_blocks != s->ws_pp.max_blocks || g.n_blocks % 3u != 0u)
+		return PRGPU_OK; // pixels are handed out dynamically, or the grid is not three full layers
+	float r1 = 1.12f, r2 = 1.25f; // measured optimum on 1/8 of the C4 frame (2.29 -> 2.20 ms per iteration); larger ratios shift too much WORK onto the fast layer
+	if (const char* env = getenv("PRGPU_PP_LAYER_SPEED"))
+		(void)sscanf(env, "%f,%f", &r1, &r2);
+	const uint32_t n = s->n_slots, spb = g.slots_per_block, B = g.n_blocks, LB = B / 3u;
+	std::vector<uint32_t> owned(n), cost(s->n_pixels);
+	HIP_TRY(hipMemcpy(owned.data(), s->ps.pixel, size_t(n) * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(cost.data(), s->ps.cost, size_t(s->n_pixels) * 4, hipMemcpyDeviceToHost));
+	// path depth varies smoothly over the image: a 5 x 5 box over the owned neighbours (x 16 to keep fractions) takes the sampling
+	// noise out of a young estimate
+	std::vector<uint32_t> c(n);
+	{
+		const int W = (int)s->cfg.width, H = (int)s->cfg.height;
+		for (uint32_t i = 0; i < n; ++i) {
+			const int px = (int)(owned[i] % (uint32_t)W), py = (int)(owned[i] / (uint32_t)W);
+			uint64_t sum = 0;
+			uint32_t cnt = 0;
+			for (int y = std::max(0, py - 2); y <= std::min(H - 1, py + 2); ++y)
+				for (int x = std::max(0, px - 2); x <= std::min(W - 1, px + 2); ++x) {
+					const uint32_t v = cost[size_t(y) * W + x];
+					if (v) {
+						sum += v;
+						++cnt;
+					}
+				}
+			c[i] = cnt ? (uint32_t)(sum * 16u / cnt) : 0u;
+		}
+	}
+	std::vector<uint32_t> sorted(c);
+	const size_t k = size_t(double(n) * 0.999);
+	std::nth_element(sorted.begin(), sorted.begin() + k, sorted.end());
+	const float c_ref = (float)sorted[k];
+	const float t1 = c_ref / r1, t2 = c_ref / r2;
+	std::vector<uint32_t> fill(B, 0u), cap(B);
+	for (uint32_t b = 0; b < B; ++b)
+		cap[b] = (uint32_t)std::min<uint64_t>(spb, uint64_t(n) > uint64_t(b) * spb ? uint64_t(n) - uint64_t(b) * spb : 0u);
+	std::vector<uint32_t> out(n);
+	uint32_t cursor[3] = { 0, 0, 0 }; // round-robin position of the three deals
+	auto deal = [&](uint32_t pixel, uint32_t n_blocks, uint32_t& cur) -> bool {
+		for (uint32_t tries = 0; tries < n_blocks; ++tries) {
+			const uint32_t b = cur;
+			cur				 = cur + 1 == n_blocks ? 0 : cur + 1;
+			if (fill[b] < cap[b]) {
+				out[size_t(b) * spb + fill[b]++] = pixel;
+				return true;
+			}
+		}
+		return false;
+	};
+	for (int pass = 0; pass < 3; ++pass) // deepest chains first, so that they find room in the fast layers
+		for (uint32_t i = 0; i < n; ++i) {
+			const int cls = (float)c[i] > t1 ? 0 : ((float)c[i] > t2 ? 1 : 2);
+			if (cls != pass)
+				continue;
+			bool ok = false;
+			if (cls == 0)
+				ok = deal(owned[i], LB, cursor[0]);
+			if (!ok && cls <= 1)
+				ok = deal(owned[i], 2 * LB, cursor[1]);
+			if (!ok)
+				ok = deal(owned[i], B, cursor[2]);
+			if (!ok)
+				return fail(PRGPU_EDEVICE, "tune_pixel_order: no room for a pixel (internal error)");
+		}
+	HIP_TRY(hipMemcpy(s->ps.pixel, out.data(), size_t(n) * 4, hipMemcpyHostToDevice));
 	return PRGPU_OK;
 }
 
@@ -1039,6 +1131,11 @@ int prgpu_sync(prgpu_scene* s)
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	s->collect_timing();
+	{
+		const int rc = tune_pixel_order(s);
+		if (rc != PRGPU_OK)
+			return rc;
+	}
 	if (const char* path = s->instrument && s->mode == prgpu_scene::PERSISTENT ? getenv("PRGPU_DUMP_BLOCK_LIFE") : nullptr) { // diagnostics: one line per block of the last instrumented launch
 		std::vector<uint2> rows(size_t(s->ws_pp.max_blocks) * 256u);
 		HIP_TRY(hipMemcpy(rows.data(), s->ws_pp.spill, rows.size() * sizeof(uint2), hipMemcpyDeviceToHost));
@@ -1477,6 +1574,16 @@ int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance)
 		HIP_TRY(hipMemcpy(mean, s->ps.online_mean, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
 	if (variance)
 		HIP_TRY(hipMemcpy(variance, s->ps.online_variance, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
+	return PRGPU_OK;
+}
+
+int prgpu_path_cost(prgpu_scene* s, uint32_t* vertices)
+{
+	if (!s || !vertices)
+		return fail(PRGPU_EINVAL, "null argument");
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	HIP_TRY(hipMemcpy(vertices, s->ps.cost, size_t(s->n_pixels) * 4, hipMemcpyDeviceToHost));
 	return PRGPU_OK;
 }
 

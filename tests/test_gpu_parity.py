@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before libprgpu.so: both carry a HIP runtime, and torch finds no device when it comes second
 
 import oracle_binding as ob
 from pearray_amd import _cabi as abi
@@ -1008,3 +1009,31 @@ def test_reference_sky_examples_render_like_the_oracle():
     assert_parity(g, o, exact=True)
     st = g.statistics()
     assert st["entity_hits"] == 0 and 0 < st["background_hits"] == st["primary_rays"] < st["pixel_samples"]
+
+
+def test_small_share_scheduling_does_not_change_the_image(monkeypatch):
+    """A tile share small enough for every pixel to be in flight at once runs with a shading wave per block, slot k -> owned[k], and --
+    after the first synchronisation -- a pixel order tuned by the measured path depth per pixel (tune_pixel_order).  All of it is
+    scheduling: the frame equals the one of the plain dynamic hand-out bit for bit, and the path-cost plane counts every vertex."""
+    W, H = 1920, 1080
+    sc = scene.cornell_box(W, H, spp=16, sampler=abi.SAMPLER_SOBOL)
+    tiles = tiling.tiles_for_rank(W, H, 0, 8)
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = backend.RenderContext(sc)
+        g.setTiles(tiles)
+        for n in (5, 3, 4):       # a synchronisation after 5 and after 8 iterations: the order is tuned once
+            g.render(n)
+            g.waitForFinish()
+        out = (g.output(), g.statistics(), g.pathCost())
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+    (xyz, smp, fb), st, cost = run({})
+    (xyz0, smp0, fb0), st0, cost0 = run({"PRGPU_PP_TUNE_ORDER": "0", "PRGPU_PP_SHADER": "0", "PRGPU_PP_SLOTS": "256"})   # dynamic hand-out, no shading wave
+    assert np.array_equal(xyz, xyz0) and np.array_equal(smp, smp0) and np.array_equal(fb, fb0) and st == st0
+    assert not cost0.any()     # the statistic is only kept while slot k renders owned[k]
+    assert st["pixel_samples"] < cost.sum() <= st["camera_depth"] + st["background_hits"]     # path length of every sample, summed per pixel
+    assert (cost > 0).sum() == sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles)
