@@ -1,5 +1,5 @@
 """What bounds a small tile share: rank 0's 1/8 share of the C4 frame at several iterations per render call, with the trace
-counters of an instrumented pass next to the timing.  usage: python tools/gpu_probe_share8.py [world] [iterations ...]"""
+counters of an instrumented pass next to the timing.  usage: [TILE=16] python tools/gpu_probe_share8.py [world] [iterations ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pearray_amd import backend, scene, tiling
@@ -10,7 +10,7 @@ sc = scene.cornell_soup(W, H, spp=1024, n_triangles=1_000_000)
 for iters in [int(a) for a in sys.argv[2:]] or [8, 32, 96, 256]:
     ctx = backend.RenderContext(sc)
     if world > 1:
-        ctx.setTiles(tiling.tiles_for_rank(W, H, 0, world))
+        ctx.setTiles(tiling.tiles_for_rank(W, H, int(os.environ.get("RANK_PROBE", "0")), world, tile=int(os.environ.get("TILE", "64"))))
     ctx.render(8); ctx.waitForFinish()
     t = time.time(); ctx.render(iters); ctx.waitForFinish(); dt = (time.time() - t) / iters * 1e3
     tc0 = ctx.traceCounters(); ctx.setInstrumentation(True); ctx.render(iters); ctx.waitForFinish(); ctx.setInstrumentation(False); tc1 = ctx.traceCounters()
