@@ -2235,6 +2235,9 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						idx = need_pixel && ps.pixel[slot] == INVALID ? slot : a.n_owned; // the slot's one and only pixel, then retirement
 					else
 						idx = wave_append(need_pixel, a.next_pixel); // 64 neighbouring pixels per wave-full
+					// (Measured and dropped: eight hand-out counters, one per group of blocks that share an XCD -- blockIdx % 8 --, each
+					// dealing its own contiguous eighth of the Morton list first so that an XCD's L2 holds one image region's part of the
+					// tree: 13.75 - 13.86 vs 13.43 ms per iteration on C4.)
 					if (need_pixel) {
 						if (idx < a.n_owned) {
 							ps.pixel[slot] = a.owned[idx];
@@ -2599,6 +2602,12 @@ PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, ui
 	const uint32_t cap		 = std::min((uint32_t)PP_SLOTS_MAX, std::max(256u, max_slots_per_block / 64u * 64u));
 	static const uint32_t min_slots = getenv("PRGPU_PP_MIN_SLOTS") ? (uint32_t)std::min(256, std::max(1, atoi(getenv("PRGPU_PP_MIN_SLOTS")))) : 256u;
 	g.slots_per_block		 = std::min(cap, std::max(min_slots, per_block));
+	// more pixels than slots (dynamic hand-out): the traversal-bound C4 frame likes 320 slots per block of 256 lanes a little better
+	// (13.3 vs 13.5 - 13.7 ms per iteration at 512; 256: 14.6), every shading-heavy scene likes 512 much better (fuller shading passes:
+	// C5 134 vs 126 Msamples/s, rough Cornell 257 vs 228, glass 287 vs 266) -- 512 stays; PRGPU_PP_DYN_SLOTS for experiments
+	static const uint32_t dyn_slots = getenv("PRGPU_PP_DYN_SLOTS") ? (uint32_t)std::min(PP_SLOTS_MAX, std::max(256, atoi(getenv("PRGPU_PP_DYN_SLOTS")) / 64 * 64)) : (uint32_t)PP_SLOTS_MAX;
+	if (per_block > cap)
+		g.slots_per_block = std::min(cap, dyn_slots);
 	g.n_blocks				 = std::max(1u, std::min(max_blocks, (n_owned + g.slots_per_block - 1) / g.slots_per_block));
 	return g;
 }
