@@ -4,12 +4,13 @@ import collections, csv, glob, json, os, shutil, sys
 tag, iters = sys.argv[1], int(sys.argv[2])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(root, "gpurun_out", tag + "_")
-stats = glob.glob(base + "trace/*/*_kernel_stats.csv")
+newest = lambda files: sorted(files, key=os.path.getmtime)[-1:]   # noqa: E731  -- gpurun_out keeps the files of earlier runs
+stats = newest(glob.glob(base + "trace/*/*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(root, "profiles", tag + "_kernel_stats.csv"))
 out = collections.OrderedDict()
 for sub in ("fetch", "write", "l2", "sq", "ta", "tcp"):
-    fs = glob.glob(base + sub + "/*/*_counter_collection.csv")
+    fs = newest(glob.glob(base + sub + "/*/*_counter_collection.csv"))
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
