@@ -105,8 +105,8 @@ def pmc_traffic(kernel_signature):
     FETCH_SIZE tallies 128-B requests at 64 B).  Only a summary of THIS kernel (same template instantiation) built from THESE
     sources counts; otherwise traffic is null and the reason is reported."""
     import glob
-    reason = "no profiles/r*_pmc_summary.json"
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+    reason = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):   # newest round first
         try:
             with open(path) as f:
                 summ = json.load(f)
@@ -114,13 +114,13 @@ def pmc_traffic(kernel_signature):
             continue
         rel = os.path.relpath(path, ROOT)
         if summ.get("kernel_source_sha16") != kernel_source_sha16():
-            reason = "%s was taken from another build of the kernel sources" % rel
+            reason = reason or "%s was taken from another build of the kernel sources" % rel
             continue
         for name, k in summ["kernels"].items():
             if kernel_signature in name.replace(" ", "") and "FETCH_SIZE_per_iteration" in k:
                 return (2.0 * k["FETCH_SIZE_per_iteration"] + k["WRITE_SIZE_per_iteration"]) * 1024.0, rel, None
-        reason = "%s holds no counters for %s" % (rel, kernel_signature)
-    return None, None, reason
+        reason = reason or "%s holds no counters for %s" % (rel, kernel_signature)
+    return None, None, reason or "no profiles/r*_pmc_summary.json"
 
 
 def roofline(ctx, rank, iters=8):
