@@ -2479,6 +2479,280 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uin
 	};
 	trace_persistent<false, true>(sc, n, queue_head, spill, refill_below, load, store, gstats);
 }
+// ---- PROTOTYPE (PRGPU_TRACE_SPLIT=1, ray service only): leaf tests handed to whole waves through an LDS task queue -------------------
+// A wave step of the production traversal serves ONE kind of record, so 42 % of the lanes idle (lane utilisation 0.58).  Here a lane
+// that reaches a leaf does not test it: it queues (owner lane, leaf record) in an LDS ring and goes on with its stack; whenever 64
+// tasks wait, the next wave that comes by tests 64 leaves at full lane fill and merges each hit into the owner's best hit with ONE
+// 64-bit LDS minimum over (t, triangle id) -- exactly the reference's rule "closer, or equally close with the smaller id".  A ray is
+// finished when its stack is empty and none of its tasks is outstanding; u, v come from one more test of the winning triangle
+// (found through tri_slot: triangle -> leaf unit and slot).  Inner steps see the best t one batch late (more records visited).
+constexpr uint32_t SPLIT_Q = 1024;
+constexpr bool COUNT_SPLIT_STEPS = true;
+struct SplitShared {
+	uint2 stack[STACK_LDS * TRAV_BLOCK];
+	float4 rc[2][TRAV_BLOCK];			   // per owner lane: (o.xyz, packed kx/ky/kz), (Sx, Sy, Sz, tmin)
+	unsigned long long best[TRAV_BLOCK];   // (t bits << 32) | triangle id
+	uint32_t pending[TRAV_BLOCK];		   // tasks of the lane's ray not yet merged
+	uint32_t q[SPLIT_Q];
+	uint32_t q_head, q_tail;
+};
+// inner step of the split traversal: hit children that are leaves become tasks at once (they never enter the stack), the inner ones
+// are sorted and pushed as in trav_inner_rec.  Returns nothing; *n_tasks = leaves queued by this lane.
+template <typename STK>
+__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, uint32_t* q, uint32_t* q_tail,
+												 uint32_t* pending_own, uint32_t tid, bool active)
+{
+	float t[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
+	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
+	bool h[4] = { false, false, false, false };
+	if (active) {
+		const uint32_t eb = __float_as_uint(q0.w);
+		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
+		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
+		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
+		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
+		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const float axk = __fmaf_rn(PR_UB(wnx, k), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn(PR_UB(wfx, k), sx, dx) * s.r.inv_d.x;
+			const float ayk = __fmaf_rn(PR_UB(wny, k), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn(PR_UB(wfy, k), sy, dy) * s.r.inv_d.y;
+			const float azk = __fmaf_rn(PR_UB(wnz, k), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn(PR_UB(wfz, k), sz, dz) * s.r.inv_d.z;
+			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
+			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
+			t[k]		   = t0;
+			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY;
+		}
+	}
+	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts through three ballots)
+	bool lf[4];
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		lf[k] = h[k] && (c[k] & REC_LEAF_BIT) != 0u;
+		cnt += lf[k] ? 1u : 0u;
+	}
+	{
+		const uint32_t lane			   = tid & 63u;
+		const unsigned long long below = (1ull << lane) - 1ull;
+		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
+		const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+		if (total != 0u) {
+			uint32_t base = 0;
+			if (lane == 0)
+				base = __hip_atomic_fetch_add(q_tail, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			base		 = wave_bcast0(base);
+			uint32_t pos = base + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+			if (cnt)
+				__hip_atomic_fetch_add(pending_own, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				if (lf[k])
+					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], ((c[k] & ~REC_LEAF_BIT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+	if (!active)
+		return;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const bool in = h[k] && !lf[k];
+		t[k]		  = in ? t[k] : INFINITY;
+		c[k]		  = in ? c[k] : REC_EMPTY;
+	}
+#define PR_CSWAP(a, b)                                          \
+	{                                                           \
+		const bool sw	  = t[b] < t[a];                        \
+		const float ta = t[a], tb = t[b];                       \
+		const uint32_t ca = c[a], cb = c[b];                    \
+		t[a] = sw ? tb : ta; t[b] = sw ? ta : tb;               \
+		c[a] = sw ? cb : ca; c[b] = sw ? ca : cb;               \
+	}
+	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+#undef PR_CSWAP
+	st.reserve(3);
+	st.push_if(c[3] != REC_EMPTY, c[3], t[3]);
+	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
+	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
+	s.cur = c[0];
+	trav_pop<MODE_CLOSEST>(s, st);
+}
+__global__ void k_tri_slot(DevScene sc, uint32_t* __restrict__ tri_slot)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= sc.n_leaf)
+		return;
+	const uint32_t unit = ((sc.n_inner + 1u) & ~1u) + 2u * i;
+	const float* f		= reinterpret_cast<const float*>(sc.recs + unit);
+	const uint32_t cnt	= __float_as_uint(f[30]);
+	for (uint32_t k = 0; k < cnt && k < 3u; ++k)
+		tri_slot[__float_as_uint(f[10 * k + 9]) & ~PRIM_SPHERE_BIT] = (unit << 2) | k;
+}
+__global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
+																	 const float* __restrict__ tmin_a, const float* __restrict__ tmax_a, uint32_t* entity,
+																	 uint32_t* prim, float* u, float* v, float* t, uint32_t* queue_head, uint2* spill,
+																	 const uint32_t* __restrict__ tri_slot, int refill_below, unsigned long long* gstats)
+{
+	__shared__ SplitShared sh;
+	const uint32_t tid = threadIdx.x, lane = tid & 63u;
+	for (uint32_t i = tid; i < SPLIT_Q; i += TRAV_BLOCK)
+		sh.q[i] = PP_EMPTY;
+	sh.pending[tid] = 0;
+	if (tid == 0)
+		sh.q_head = sh.q_tail = 0;
+	__syncthreads();
+	Stack st;
+	st.lds			= sh.stack + tid;
+	st.spill_stride = gridDim.x * TRAV_BLOCK;
+	st.spill		= spill + (blockIdx.x * TRAV_BLOCK + tid);
+	st.reset();
+	Trav s;
+	s.cur		   = REC_EMPTY;
+	s.any		   = false;
+	uint32_t my_ray = 0;
+	bool has_ray   = false;
+	bool exhausted = false;
+	uint32_t cn = 0, cl = 0, witers = 0, spins = 0;
+
+	// test up to 64 queued leaves with this wave; false when nothing could be claimed
+	auto leaf_batch = [&]() -> bool {
+		uint32_t first;
+		const uint32_t nt = ring_claim(&sh.q_head, &sh.q_tail, 64u, first);
+		if (nt == 0u)
+			return false;
+		if (lane < nt) {
+			const uint32_t task	 = ring_take(sh.q, SPLIT_Q - 1u, first + lane);
+			const uint32_t owner = task & 0xFFu, unit = task >> 8;
+			RayPre r;
+			const float4 ra = sh.rc[0][owner], rb = sh.rc[1][owner];
+			r.o				  = v3(ra.x, ra.y, ra.z);
+			const uint32_t kk = __float_as_uint(ra.w);
+			r.kx			  = (int)(kk & 3u);
+			r.ky			  = (int)((kk >> 2) & 3u);
+			r.kz			  = (int)((kk >> 4) & 3u);
+			r.Sx			  = rb.x;
+			r.Sy			  = rb.y;
+			r.Sz			  = rb.z;
+			const float tmin  = rb.w;
+			const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + unit);
+			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+			const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+								  q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w };
+			const uint32_t count = __float_as_uint(f[30]);
+			unsigned long long key = ~0ull;
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				if ((uint32_t)k < count) {
+					float tt, uu, vv;
+					if (woop(r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]), v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), tt, uu, vv)
+						&& tt > tmin) {
+						const unsigned long long kk2 = ((unsigned long long)__float_as_uint(tt) << 32) | __float_as_uint(f[10 * k + 9]);
+						key							 = kk2 < key ? kk2 : key;
+					}
+				}
+			}
+			if (key != ~0ull)
+				__hip_atomic_fetch_min(&sh.best[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_sub(&sh.pending[owner], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			++cl;
+		}
+		return true;
+	};
+
+	bool drained = false; // the lane's ray has an empty stack and no task outstanding: its result waits for the next refill round
+	for (;;) {
+		// rays that are done: one more test of the winning triangle for u, v (batched here, outside the stepping loop)
+		if (drained) {
+			const unsigned long long key = __hip_atomic_load(&sh.best[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const uint32_t tri			 = (uint32_t)key;
+			float tt = tmax_a[my_ray], uu = 0.0f, vv = 0.0f;
+			if (tri != INVALID) {
+				const uint32_t slot = tri_slot[tri];
+				const float* f		= reinterpret_cast<const float*>(sc.recs + (slot >> 2)) + 10u * (slot & 3u);
+				(void)woop(s.r, v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), v3(f[6], f[7], f[8]), tt, uu, vv);
+			}
+			entity[my_ray] = tri != INVALID ? sc.tri_entity[tri] : INVALID;
+			prim[my_ray]   = tri != INVALID ? prim_id(sc, tri) : INVALID;
+			u[my_ray]	   = uu;
+			v[my_ray]	   = vv;
+			t[my_ray]	   = tt;
+			has_ray		   = false;
+			drained		   = false;
+		}
+		if (!exhausted) {
+			const unsigned long long idle = __ballot(!has_ray);
+			if (idle) {
+				uint32_t base	 = 0;
+				const int leader = __ffsll((long long)idle) - 1;
+				if ((int)lane == leader)
+					base = atomicAdd(queue_head, (uint32_t)__popcll(idle));
+				base = __shfl(base, leader, 64);
+				if (!has_ray) {
+					const uint32_t i = base + __popcll(idle & ((1ull << lane) - 1ull));
+					if (i < n) {
+						const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+						trav_begin(s, st, o, d, tmin_a[i], tmax_a[i], sc.eps_t);
+						sh.rc[0][tid] = make_float4(o.x, o.y, o.z, __uint_as_float((uint32_t)s.r.kx | ((uint32_t)s.r.ky << 2) | ((uint32_t)s.r.kz << 4)));
+						sh.rc[1][tid] = make_float4(s.r.Sx, s.r.Sy, s.r.Sz, s.tmin);
+						__hip_atomic_store(&sh.best[tid], ((unsigned long long)__float_as_uint(tmax_a[i]) << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						my_ray	= i;
+						has_ray = true;
+					}
+				}
+				exhausted = base + (uint32_t)__popcll(idle) >= n;
+			}
+		}
+		if (!__any(has_ray))
+			break;
+		for (;;) {
+			const uint32_t nq	 = wave_bcast0(lds_load(&sh.q_tail) - lds_load(&sh.q_head));
+			const bool can_inner = __any(has_ray && s.cur != REC_EMPTY);
+			if (nq >= 64u || (nq > 0u && !can_inner)) {
+				(void)leaf_batch();
+				spins = 0;
+			} else if (can_inner) {
+				if (COUNT_SPLIT_STEPS && lane == 0)
+					++witers;
+				// room for the (at most 4 x 64) tasks of this step
+				while (wave_bcast0(lds_load(&sh.q_tail) - lds_load(&sh.q_head)) + 256u > SPLIT_Q)
+					if (!leaf_batch())
+						__builtin_amdgcn_s_sleep(1);
+				{
+					const bool act = has_ray && s.cur != REC_EMPTY; // every such lane is at an inner node: leaves never stay in s.cur
+					float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+					if (act) {
+						s.best.t = __uint_as_float((uint32_t)(__hip_atomic_load(&sh.best[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
+						++cn;
+						const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + s.cur);
+						q0 = rec[0];
+						q1 = rec[1];
+						q2 = rec[2];
+						q3 = rec[3];
+					}
+					trav_inner_split(s, st, q0, q1, q2, q3, sh.q, &sh.q_tail, &sh.pending[tid], tid, act);
+				}
+				spins = 0;
+			} else { // every ray of the wave waits for tasks another wave holds
+				__builtin_amdgcn_s_sleep(2);
+				if (++spins > (1u << 24))
+					break; // safety net of the prototype: never hang the device
+			}
+			drained = has_ray && s.cur == REC_EMPTY && st.sp == 0;
+			if (drained)
+				drained = __hip_atomic_load(&sh.pending[tid], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;
+			const int active = __popcll(__ballot(has_ray && !drained));
+			if (active == 0 || (!exhausted && active < refill_below))
+				break;
+		}
+		if (spins > (1u << 24))
+			break;
+	}
+	if (cn)
+		atomicAdd(&gstats[CNT_NODES_CLOSEST], (unsigned long long)cn);
+	if (cl)
+		atomicAdd(&gstats[CNT_TRIS_CLOSEST], (unsigned long long)cl);
+	if (witers)
+		atomicAdd(&gstats[CNT_WAVE_ITERS_CLOSEST], (unsigned long long)witers);
+}
 __global__ void __launch_bounds__(TRAV_BLOCK) k_service_any(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
 														   const float* __restrict__ tmin_a, const float* __restrict__ distance, uint8_t* occluded,
 														   uint32_t* queue_head, uint2* spill, int refill_below, unsigned long long* gstats)
@@ -2546,6 +2820,15 @@ void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, co
 	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
 	hipLaunchKernelGGL(k_service_closest, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
 					   ws.spill, ws.refill_below, gstats);
+}
+void launch_service_closest_split(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
+								  uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, uint32_t* tri_slot,
+								  unsigned long long* gstats, hipStream_t st)
+{
+	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
+	hipLaunchKernelGGL(k_tri_slot, grid_for(sc.n_leaf), dim3(256), 0, st, sc, tri_slot);
+	hipLaunchKernelGGL(k_service_closest_split, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
+					   ws.spill, tri_slot, ws.refill_below, gstats);
 }
 void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* distance,
 						uint8_t* occluded, const TraceWorkspace& ws, unsigned long long* gstats, hipStream_t st)
