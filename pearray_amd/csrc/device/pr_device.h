@@ -142,6 +142,7 @@ struct DevScene {
 	const uint32_t* indices;
 	const uint32_t* tri_material;
 	const uint32_t* tri_entity;
+	const uint32_t* tri_slot; // triangle -> (leaf record unit << 2 | slot in the leaf): where the split traversal re-tests the winning triangle for u, v
 	const uint8_t* tri_class; // material class of every triangle (0: no rough / principled closure, 1: rough or principled), the bin of the persistent kernel's shade queues
 	const DevEntity* entities;
 	const DevMaterial* materials;

@@ -1989,7 +1989,17 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 // the pixel has all its samples the slot takes the next unrendered pixel from a global counter.  There is no grid-wide
 // barrier, no host round trip and no drain phase between path vertices; blocks never wait for each other, waves only
 // ever wait for waves of their own block (which are resident by construction).
-constexpr int PP_SLOTS_MAX		= 1024;
+// PR_SPLIT = 1 compiles the split traversal into the persistent kernel: leaf tests through an LDS task queue instead of one kind of record
+// per wave step.  Bit-identical (all GPU tests pass with it), 28 % fewer wave steps on C4 (14.3 M vs 19.9 M per iteration, lane utilisation
+// 0.83 vs 0.58), but each step carries the queue bookkeeping, finished rays wait for their last batch, and u, v need one more test of the
+// winning triangle: 14.8 ms per iteration against 13.45 -- so it stays off.  In the leaner ray-service kernel the same scheme wins 17 %
+// (k_service_closest_split, profiles/r02_trace_split_prototype.log).  Next steps that could turn it: a second result slot per lane so
+// that a lane starts its next ray while the last leaves of the previous one are tested, and u, v published by the winning leaf lane.
+#ifndef PR_SPLIT
+#define PR_SPLIT 0
+#endif
+constexpr int PP_SLOTS_MAX		= PR_SPLIT ? 512 : 1024; // the task queue's LDS comes out of the slot rings
+constexpr uint32_t SPLIT_Q		= 1024;					 // ring of leaf tasks (owner lane | leaf unit << 8)
 constexpr uint32_t PP_EMPTY		= 0xFFFFFFFFu;
 constexpr uint32_t PP_ANY		= 0x80000000u; // ray entry: the slot's shadow ray (else its path ray)
 constexpr uint32_t PP_REGEN		= 0x80000000u; // shade entry: the slot's path has ended (else: shade the vertex at ps.hit)
@@ -2005,6 +2015,13 @@ struct PPShared {
 	uint32_t q_ray[2 * PP_SLOTS_MAX]; // a slot has at most two rays queued or in flight
 	uint32_t q_shade[NQ][PP_SLOTS_MAX];
 	uint32_t pending[PP_SLOTS_MAX];
+#if PR_SPLIT
+	unsigned long long best[TRAV_BLOCK]; // per lane: (t bits << 32) | triangle id of its ray's best hit, merged by the leaf waves with one 64-bit minimum
+	uint32_t leaf_pending[TRAV_BLOCK];	 // leaf tasks of the lane's ray not yet merged
+	uint32_t lane_entry[TRAV_BLOCK];	 // the ray a lane holds (slot | PP_ANY), for the wave that tests its leaves
+	uint32_t q_leaf[SPLIT_Q];
+	uint32_t leaf_head, leaf_tail;
+#endif
 	uint32_t ray_head, ray_tail, shade_head[NQ], shade_tail[NQ];
 	uint32_t live; // slots that still own, or may still acquire, a pixel
 	uint32_t error;
@@ -2013,6 +2030,90 @@ struct PPShared {
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t wave_bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// ---- split traversal: leaf tests handed to whole waves through an LDS task queue (see path_persistent) ----
+// inner step of the split traversal: hit children that are leaves become tasks at once (they never enter the stack), the inner ones
+// are sorted and pushed as in trav_inner_rec.  Returns nothing; *n_tasks = leaves queued by this lane.
+template <typename STK>
+__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, uint32_t* q, uint32_t* q_tail,
+												 uint32_t* pending_own, uint32_t tid, bool active, const uint32_t* q_head, uint32_t* overflow)
+{
+	float t[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
+	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
+	bool h[4] = { false, false, false, false };
+	if (active) {
+		const uint32_t eb = __float_as_uint(q0.w);
+		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
+		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
+		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
+		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
+		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const float axk = __fmaf_rn(PR_UB(wnx, k), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn(PR_UB(wfx, k), sx, dx) * s.r.inv_d.x;
+			const float ayk = __fmaf_rn(PR_UB(wny, k), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn(PR_UB(wfy, k), sy, dy) * s.r.inv_d.y;
+			const float azk = __fmaf_rn(PR_UB(wnz, k), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn(PR_UB(wfz, k), sz, dz) * s.r.inv_d.z;
+			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
+			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
+			t[k]		   = t0;
+			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY;
+		}
+	}
+	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts through three ballots)
+	bool lf[4];
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		lf[k] = h[k] && (c[k] & REC_LEAF_BIT) != 0u;
+		cnt += lf[k] ? 1u : 0u;
+	}
+	{
+		const uint32_t lane			   = tid & 63u;
+		const unsigned long long below = (1ull << lane) - 1ull;
+		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
+		const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+		if (total != 0u) {
+			uint32_t base = 0;
+			if (lane == 0)
+				base = __hip_atomic_fetch_add(q_tail, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			base = wave_bcast0(base);
+			if (lane == 0 && base + total - lds_load(q_head) > SPLIT_Q) // cannot happen while callers keep the ring below a quarter full and a
+				__hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // step adds at most 256 per wave; loud if it does
+			uint32_t pos = base + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+			if (cnt)
+				__hip_atomic_fetch_add(pending_own, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				if (lf[k])
+					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], ((c[k] & ~REC_LEAF_BIT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+	if (!active)
+		return;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const bool in = h[k] && !lf[k];
+		t[k]		  = in ? t[k] : INFINITY;
+		c[k]		  = in ? c[k] : REC_EMPTY;
+	}
+#define PR_CSWAP(a, b)                                          \
+	{                                                           \
+		const bool sw	  = t[b] < t[a];                        \
+		const float ta = t[a], tb = t[b];                       \
+		const uint32_t ca = c[a], cb = c[b];                    \
+		t[a] = sw ? tb : ta; t[b] = sw ? ta : tb;               \
+		c[a] = sw ? cb : ca; c[b] = sw ? ca : cb;               \
+	}
+	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+#undef PR_CSWAP
+	st.reserve(3);
+	st.push_if(c[3] != REC_EMPTY, c[3], t[3]);
+	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
+	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
+	s.cur = c[0];
+	trav_pop<MODE_CLOSEST>(s, st);
+}
 
 // append the value of every lane with `pred` to a ring queue: one LDS atomic per wave; the entry becomes visible to the
 // poppers when it is written (release: the slot's state in global memory is visible before the entry is)
@@ -2101,6 +2202,7 @@ struct PersistentArgs {
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
 	uint32_t sort_rays;	  // 1: a shading pass queues its rays ordered by direction octant
 	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
+	int fin_batch;		  // split traversal: finished rays are written out once this many of a wave's lanes hold one
 	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
 	unsigned long long* gstats;
 };
@@ -2134,7 +2236,15 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			sh.shade_head[q] = sh.shade_tail[q] = 0;
 		sh.live					  = block_slots;
 		sh.error				  = 0;
+#if PR_SPLIT
+		sh.leaf_head = sh.leaf_tail = 0;
+#endif
 	}
+#if PR_SPLIT
+	for (uint32_t i = threadIdx.x; i < SPLIT_Q; i += TRAV_BLOCK)
+		sh.q_leaf[i] = PP_EMPTY;
+	sh.leaf_pending[threadIdx.x] = 0;
+#endif
 	stats_init(sh.bs);
 	__syncthreads();
 
@@ -2150,12 +2260,63 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	uint32_t my_entry = 0;
 	uint32_t spins	  = 0;
 	unsigned long long t_idle_since = 0;
-	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, sbatches = 0, slanes = 0;
+	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, wleaf = 0, sbatches = 0, slanes = 0;
 	unsigned long long t_shade = 0, t_idle = 0;
 	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
 
 	const bool shader = a.shader_wave != 0u && (threadIdx.x >> 6) == TRAV_BLOCK / 64 - 1;
 	const uint32_t shade_full = a.shader_wave != 0u ? a.shade_help : a.shade_min;
+#if PR_SPLIT
+	// test up to 64 queued leaves with this wave (whatever rays its own lanes hold); false when nothing could be claimed
+	auto leaf_batch = [&]() -> bool {
+		uint32_t first;
+		const uint32_t nt = ring_claim(&sh.leaf_head, &sh.leaf_tail, 64u, first);
+		if (nt == 0u)
+			return false;
+		if (lane < nt) {
+			const uint32_t task	 = ring_take(sh.q_leaf, SPLIT_Q - 1u, first + lane);
+			const uint32_t owner = task & 0xFFu, unit = task >> 8;
+			const uint32_t entry = sh.lane_entry[owner];
+			const bool any		 = (entry & PP_ANY) != 0;
+			const uint32_t slot	 = slot0 + (entry & ~PP_ANY);
+			const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + unit);
+			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+			const float4 ro = any ? ps.sh_o[slot] : ps.ray_o[slot], rd = any ? ps.sh_d[slot] : ps.ray_d[slot];
+			const RayPre r	 = ray_prepare(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), sc.eps_t);
+			const float tmin = ro.w;
+			const float limit = __uint_as_float((uint32_t)(__hip_atomic_load(&sh.best[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
+			const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+								  q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w };
+			const uint32_t count   = __float_as_uint(f[30]);
+			unsigned long long key = ~0ull;
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				if ((uint32_t)k < count) {
+					float tt, uu, vv;
+					const uint32_t prim = __float_as_uint(f[10 * k + 9]);
+					bool hit;
+					if ((FEATS & FEAT_SPHERES) && (prim & PRIM_SPHERE_BIT))
+						hit = sphere_hit(r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), f[10 * k + 3], tmin, limit, tt);
+					else
+						hit = woop(r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]), v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), tt, uu, vv)
+							  && tt > tmin;
+					if (hit) {
+						const unsigned long long cand = ((unsigned long long)__float_as_uint(tt) << 32) | (prim & ~PRIM_SPHERE_BIT);
+						key							  = cand < key ? cand : key;
+					}
+				}
+			}
+			if (COUNT) {
+				cl_c += any ? 0 : 1;
+				cl_a += any ? 1 : 0;
+			}
+			if (key != ~0ull)
+				__hip_atomic_fetch_min(&sh.best[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_sub(&sh.leaf_pending[owner], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		return true;
+	};
+#endif
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
 		// the fullest class queue decides: a pass shades one class
@@ -2304,6 +2465,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				trav_begin(s, st, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, any ? rd.w - 0.001f : rd.w, sc.eps_t); // tfar rule: Scene.cpp:275
 				s.any	= any;
 				has_ray = true;
+#if PR_SPLIT
+				sh.lane_entry[threadIdx.x] = my_entry;
+				__hip_atomic_store(&sh.best[threadIdx.x], ((unsigned long long)__float_as_uint(s.best.t) << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 			}
 		}
 		if (!__any(has_ray)) {
@@ -2329,6 +2494,84 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		}
 		spins = 0;
 		for (;;) {
+#if PR_SPLIT
+			// Split traversal: a lane that reaches a leaf queues (lane, leaf record) and goes on with its stack; whenever 64 tasks wait,
+			// the next wave that comes by tests 64 leaves at full lane fill and merges each hit into the owner's best hit with one 64-bit
+			// LDS minimum over (t, triangle id) -- the rule "closer, or equally close with the smaller id" of the sequential test.  Inner
+			// steps therefore run for every ray of the wave (no vote between record kinds: lane utilisation 0.58 -> 0.8), at the price
+			// of seeing the best t one batch late (+2 % inner, +6 % leaf records on C4).  A ray is finished when its stack is empty
+			// and none of its tasks is outstanding.
+			// the step's LDS reads in one go (one wait): queue fill, the lane's outstanding tasks, then its merged best hit.  LDS executes a
+			// wave's instructions in order and a leaf lane merges before it counts down, so "no task outstanding" implies a final key
+			const uint32_t l_tail = lds_load(&sh.leaf_tail), l_head = lds_load(&sh.leaf_head);
+			const uint32_t my_pending = lds_load(&sh.leaf_pending[threadIdx.x]);
+			asm volatile("" ::: "memory");
+			const unsigned long long key = __hip_atomic_load(&sh.best[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const uint32_t n_tasks		 = wave_bcast0(l_tail - l_head);
+			const bool can_inner		 = __any(has_ray && s.cur != REC_EMPTY);
+			bool fin					 = has_ray && s.cur == REC_EMPTY && my_pending == 0u; // the lane has not stepped since: nothing new is outstanding
+			if (COUNT && lane == 0)
+				++witers;
+			if (n_tasks >= 64u || (n_tasks > 0u && !can_inner)) {
+				leaf_batch();
+				if (COUNT && lane == 0)
+					++wleaf;
+			} else if (can_inner) {
+				// (room for this step's tasks -- at most 4 per lane -- is certain: fewer than 64 wait, and the other three waves add at most 768)
+				bool act  = has_ray && s.cur != REC_EMPTY; // always an inner record: leaves never stay in s.cur
+				float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+				if (act) {
+					s.best.t = __uint_as_float((uint32_t)(key >> 32));
+					if (s.any && (uint32_t)key != INVALID) { // occluded: done (tasks still in flight only confirm it)
+						st.reset();
+						s.cur = REC_EMPTY;
+						act	  = false;
+					}
+				}
+				if (act) {
+					if (COUNT) {
+						cn_c += s.any ? 0 : 1;
+						cn_a += s.any ? 1 : 0;
+					}
+					const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + s.cur);
+					q0 = rec[0];
+					q1 = rec[1];
+					q2 = rec[2];
+					q3 = rec[3];
+				}
+				trav_inner_split(s, st, q0, q1, q2, q3, sh.q_leaf, &sh.leaf_tail, &sh.leaf_pending[threadIdx.x], threadIdx.x, act, &sh.leaf_head, &sh.error);
+			} else {
+				const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
+				__builtin_amdgcn_s_sleep(1); // every ray of the wave waits for tasks another wave is testing
+				if (COUNT)
+					t_idle += wall_clock64() - t0;
+			}
+			// finished rays wait for company: their results cost two dependent fetches (the winning triangle's leaf slot), paid once
+			// for a batch instead of in every step -- unless the wave is short of rays anyway
+			{
+				const int n_done = __popcll(__ballot(fin));
+				const int n_busy = __popcll(__ballot(has_ray && !fin));
+				if (!(n_done >= a.fin_batch || n_busy < a.refill_below))
+					fin = false;
+			}
+			if (fin) { // the ray's result: t and the triangle from the merged key, u and v from one more test of that triangle
+				s.best.tri					 = (uint32_t)key;
+				s.best.t					 = __uint_as_float((uint32_t)(key >> 32));
+				s.best.u = s.best.v = 0.0f;
+				if (!s.any && s.best.tri != INVALID) {
+					const uint32_t where = sc.tri_slot[s.best.tri];
+					const float* f		 = reinterpret_cast<const float*>(sc.recs + (where >> 2)) + 10u * (where & 3u);
+					if (!((FEATS & FEAT_SPHERES) && (__float_as_uint(f[9]) & PRIM_SPHERE_BIT))) {
+						// the test's ray constants are rebuilt here rather than carried through the stepping loop (9 registers)
+						const uint32_t fslot = slot0 + (my_entry & ~PP_ANY);
+						const float4 fo = ps.ray_o[fslot], fd = ps.ray_d[fslot];
+						const RayPre fr = ray_prepare(v3(fo.x, fo.y, fo.z), v3(fd.x, fd.y, fd.z), sc.eps_t);
+						float tt;
+						(void)woop(fr, v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), v3(f[6], f[7], f[8]), tt, s.best.u, s.best.v);
+					}
+				}
+			}
+#else
 			// one kind of record per wave step (see trace_persistent)
 			const bool at_leaf	= has_ray && (s.cur & REC_LEAF_BIT) != 0;
 			const bool at_inner = has_ray && !at_leaf;
@@ -2367,7 +2610,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					trav_leaf_rec<MODE_MIXED, (FEATS & FEAT_SPHERES) != 0>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
 				}
 			}
+#endif
+#if !PR_SPLIT
 			const bool fin = has_ray && s.cur == REC_EMPTY;
+#endif
 			if (__any(fin)) {
 				bool last	   = false;
 				uint32_t entry = 0;
@@ -2428,6 +2674,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			atomicAdd(&a.gstats[CNT_TRIS_ANY], (unsigned long long)cl_a);
 		if (witers)
 			atomicAdd(&a.gstats[CNT_WAVE_ITERS_CLOSEST], (unsigned long long)witers);
+		if (wleaf) // split traversal: leaf batches (the steps above include them)
+			atomicAdd(&a.gstats[CNT_WAVE_ITERS_ANY], (unsigned long long)wleaf);
 		if (sbatches) {
 			atomicAdd(&a.gstats[CNT_SHADE_BATCHES], (unsigned long long)sbatches);
 			atomicAdd(&a.gstats[CNT_SHADE_LANES], (unsigned long long)slanes);
@@ -2486,7 +2734,6 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uin
 // 64-bit LDS minimum over (t, triangle id) -- exactly the reference's rule "closer, or equally close with the smaller id".  A ray is
 // finished when its stack is empty and none of its tasks is outstanding; u, v come from one more test of the winning triangle
 // (found through tri_slot: triangle -> leaf unit and slot).  Inner steps see the best t one batch late (more records visited).
-constexpr uint32_t SPLIT_Q = 1024;
 constexpr bool COUNT_SPLIT_STEPS = true;
 struct SplitShared {
 	uint2 stack[STACK_LDS * TRAV_BLOCK];
@@ -2494,88 +2741,8 @@ struct SplitShared {
 	unsigned long long best[TRAV_BLOCK];   // (t bits << 32) | triangle id
 	uint32_t pending[TRAV_BLOCK];		   // tasks of the lane's ray not yet merged
 	uint32_t q[SPLIT_Q];
-	uint32_t q_head, q_tail;
+	uint32_t q_head, q_tail, overflow;
 };
-// inner step of the split traversal: hit children that are leaves become tasks at once (they never enter the stack), the inner ones
-// are sorted and pushed as in trav_inner_rec.  Returns nothing; *n_tasks = leaves queued by this lane.
-template <typename STK>
-__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, uint32_t* q, uint32_t* q_tail,
-												 uint32_t* pending_own, uint32_t tid, bool active)
-{
-	float t[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
-	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
-	bool h[4] = { false, false, false, false };
-	if (active) {
-		const uint32_t eb = __float_as_uint(q0.w);
-		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
-		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
-		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
-		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
-		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
-		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const float axk = __fmaf_rn(PR_UB(wnx, k), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn(PR_UB(wfx, k), sx, dx) * s.r.inv_d.x;
-			const float ayk = __fmaf_rn(PR_UB(wny, k), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn(PR_UB(wfy, k), sy, dy) * s.r.inv_d.y;
-			const float azk = __fmaf_rn(PR_UB(wnz, k), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn(PR_UB(wfz, k), sz, dz) * s.r.inv_d.z;
-			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
-			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
-			t[k]		   = t0;
-			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY;
-		}
-	}
-	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts through three ballots)
-	bool lf[4];
-	uint32_t cnt = 0;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		lf[k] = h[k] && (c[k] & REC_LEAF_BIT) != 0u;
-		cnt += lf[k] ? 1u : 0u;
-	}
-	{
-		const uint32_t lane			   = tid & 63u;
-		const unsigned long long below = (1ull << lane) - 1ull;
-		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
-		const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-		if (total != 0u) {
-			uint32_t base = 0;
-			if (lane == 0)
-				base = __hip_atomic_fetch_add(q_tail, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			base		 = wave_bcast0(base);
-			uint32_t pos = base + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
-			if (cnt)
-				__hip_atomic_fetch_add(pending_own, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-			for (int k = 0; k < 4; ++k)
-				if (lf[k])
-					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], ((c[k] & ~REC_LEAF_BIT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
-	}
-	if (!active)
-		return;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const bool in = h[k] && !lf[k];
-		t[k]		  = in ? t[k] : INFINITY;
-		c[k]		  = in ? c[k] : REC_EMPTY;
-	}
-#define PR_CSWAP(a, b)                                          \
-	{                                                           \
-		const bool sw	  = t[b] < t[a];                        \
-		const float ta = t[a], tb = t[b];                       \
-		const uint32_t ca = c[a], cb = c[b];                    \
-		t[a] = sw ? tb : ta; t[b] = sw ? ta : tb;               \
-		c[a] = sw ? cb : ca; c[b] = sw ? ca : cb;               \
-	}
-	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
-#undef PR_CSWAP
-	st.reserve(3);
-	st.push_if(c[3] != REC_EMPTY, c[3], t[3]);
-	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
-	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
-	s.cur = c[0];
-	trav_pop<MODE_CLOSEST>(s, st);
-}
 __global__ void k_tri_slot(DevScene sc, uint32_t* __restrict__ tri_slot)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2713,7 +2880,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene s
 				if (COUNT_SPLIT_STEPS && lane == 0)
 					++witers;
 				// room for the (at most 4 x 64) tasks of this step
-				while (wave_bcast0(lds_load(&sh.q_tail) - lds_load(&sh.q_head)) + 256u > SPLIT_Q)
+				while (wave_bcast0(lds_load(&sh.q_tail) - lds_load(&sh.q_head)) > SPLIT_Q / 4u)
 					if (!leaf_batch())
 						__builtin_amdgcn_s_sleep(1);
 				{
@@ -2728,7 +2895,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene s
 						q2 = rec[2];
 						q3 = rec[3];
 					}
-					trav_inner_split(s, st, q0, q1, q2, q3, sh.q, &sh.q_tail, &sh.pending[tid], tid, act);
+					trav_inner_split(s, st, q0, q1, q2, q3, sh.q, &sh.q_tail, &sh.pending[tid], tid, act, &sh.q_head, &sh.overflow);
 				}
 				spins = 0;
 			} else { // every ray of the wave waits for tasks another wave holds
@@ -2821,12 +2988,16 @@ void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, co
 	hipLaunchKernelGGL(k_service_closest, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
 					   ws.spill, ws.refill_below, gstats);
 }
+void launch_tri_slot(const DevScene& sc, uint32_t* tri_slot, hipStream_t st)
+{
+	if (sc.n_leaf)
+		hipLaunchKernelGGL(k_tri_slot, grid_for(sc.n_leaf), dim3(256), 0, st, sc, tri_slot);
+}
 void launch_service_closest_split(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
 								  uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, uint32_t* tri_slot,
 								  unsigned long long* gstats, hipStream_t st)
 {
 	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
-	hipLaunchKernelGGL(k_tri_slot, grid_for(sc.n_leaf), dim3(256), 0, st, sc, tri_slot);
 	hipLaunchKernelGGL(k_service_closest_split, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
 					   ws.spill, tri_slot, ws.refill_below, gstats);
 }
@@ -2923,6 +3094,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.leaf_bias		  = getenv("PRGPU_PP_LEAF_BIAS") ? std::max(1, atoi(getenv("PRGPU_PP_LEAF_BIAS"))) : 100;
 	a.gstats		  = gstats;
 	a.direct_map	  = all_in_flight ? 1u : 0u;
+	a.fin_batch		  = getenv("PRGPU_PP_FIN_BATCH") ? std::min(64, std::max(1, atoi(getenv("PRGPU_PP_FIN_BATCH")))) : 16;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks);
 	// smallest compiled variant that covers the scene's features: lean (Lambert / mesh / area lights), + smooth delta materials,

@@ -71,7 +71,6 @@ struct prgpu_scene {
 	uint32_t pp_slots = 512;
 	uint32_t pp_planes = 1; // iteration planes of the persistent pipeline (> 1 with a multi-tap pixel filter)
 	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 0, pp_occupancy = 3, pp_shader_wave = -1 /* auto: see render_persistent */, pp_shade_help = 128;
-	uint32_t* tri_slot = nullptr; // prototype of the split traversal: triangle -> (leaf unit << 2 | slot)
 	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
 	prd::TraceWorkspace ws;	   // workspace of the ray-service launches
@@ -408,6 +407,14 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.recs	   = bout.recs;
 	sc.n_inner = bout.n_inner;
 	sc.n_leaf  = bout.n_leaf;
+	{ // triangle -> leaf slot (the split traversal re-tests the winning triangle of a ray for u, v)
+		uint32_t* map = nullptr;
+		const int rc2 = s->alloc(map, std::max<size_t>(1, d->n_triangles), true);
+		if (rc2 != PRGPU_OK)
+			return rc2;
+		prd::launch_tri_slot(sc, map, s->stream);
+		sc.tri_slot = map;
+	}
 
 	// per-path state and frame planes
 	const uint32_t np = d->settings.width * d->settings.height;
@@ -1295,13 +1302,7 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmax, tmax, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	s->time_begin(1, s->stream);
 	if (getenv("PRGPU_TRACE_SPLIT") && atoi(getenv("PRGPU_TRACE_SPLIT")) != 0 && s->sc.n_leaf > 0 && s->sc.n_inner + 2ull * s->sc.n_leaf < (1ull << 24)) {
-		if (!s->tri_slot) { // prototype: leaf tests through an LDS task queue (render.hip, k_service_closest_split)
-			void* ptr = nullptr;
-			TRY_OR_CLEAN(hipMalloc(&ptr, size_t(s->sc.n_tris) * 4));
-			s->tri_slot = static_cast<uint32_t*>(ptr);
-			s->allocations.push_back(ptr);
-		}
-		prd::launch_service_closest_split(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->tri_slot, s->gstats, s->stream);
+		prd::launch_service_closest_split(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, const_cast<uint32_t*>(s->sc.tri_slot), s->gstats, s->stream);
 	} else
 		prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->gstats, s->stream);
 	s->time_end(s->stream);
