@@ -2727,7 +2727,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uin
 	};
 	trace_persistent<false, true>(sc, n, queue_head, spill, refill_below, load, store, gstats);
 }
-// ---- PROTOTYPE (PRGPU_TRACE_SPLIT=1, ray service only): leaf tests handed to whole waves through an LDS task queue -------------------
+// ---- ray service, closest hit (default; PRGPU_TRACE_SPLIT=0 selects k_service_closest): leaf tests handed to whole waves through an LDS task queue ----
 // A wave step of the production traversal serves ONE kind of record, so 42 % of the lanes idle (lane utilisation 0.58).  Here a lane
 // that reaches a leaf does not test it: it queues (owner lane, leaf record) in an LDS ring and goes on with its stack; whenever 64
 // tasks wait, the next wave that comes by tests 64 leaves at full lane fill and merges each hit into the owner's best hit with ONE

@@ -524,14 +524,16 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		if (const char* env = getenv("PRGPU_REFILL"))
 			refill = std::min(64, std::max(1, atoi(env)));
 		const uint32_t max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * blocks_per_cu;
-		auto make_ws = [&](prd::TraceWorkspace& w) -> int {
-			w.max_blocks   = max_blocks;
+		auto make_ws = [&](prd::TraceWorkspace& w, uint32_t n_blocks) -> int {
+			w.max_blocks   = n_blocks;
 			w.refill_below = refill;
 			AL(w.queue_head, 1, true);
-			AL(w.spill, prd::trace_workspace_spill_entries(max_blocks), false);
+			AL(w.spill, prd::trace_workspace_spill_entries(n_blocks), false);
 			return PRGPU_OK;
 		};
-		rc = make_ws(s->ws);
+		// the ray service (IArchive surface) runs three blocks per CU: 8 M incoherent closest-hit rays in the C4 scene take 8.0 instead of
+		// 10.3 ms, and 6.9 ms with the split traversal (profiles/r02_trace_split_prototype.log); the wavefront pipelines gain nothing from it
+		rc = make_ws(s->ws, getenv("PRGPU_BLOCKS_PER_CU") ? max_blocks : (uint32_t)std::max(1, prop.multiProcessorCount) * 3u);
 		if (rc != PRGPU_OK)
 			return rc;
 		{ // persistent path kernel: its own grid (measured best: 3 blocks per CU at 3 waves per SIMD, refill below 48 lanes)
@@ -564,10 +566,10 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 			HIP_TRY(hipEventCreateWithFlags(&gr.ev_shadow, hipEventDisableTiming));
 			AL(gr.counters, 4, true);
 			HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&gr.h_counters), 4 * sizeof(uint32_t), hipHostMallocDefault));
-			rc = make_ws(gr.ws_closest);
+			rc = make_ws(gr.ws_closest, max_blocks);
 			if (rc != PRGPU_OK)
 				return rc;
-			rc = make_ws(gr.ws_shadow);
+			rc = make_ws(gr.ws_shadow, max_blocks);
 			if (rc != PRGPU_OK)
 				return rc;
 		}
@@ -1301,7 +1303,10 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmin, tmin, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	TRY_OR_CLEAN(hipMemcpyAsync(d_tmax, tmax, size_t(n) * 4, hipMemcpyHostToDevice, s->stream));
 	s->time_begin(1, s->stream);
-	if (getenv("PRGPU_TRACE_SPLIT") && atoi(getenv("PRGPU_TRACE_SPLIT")) != 0 && s->sc.n_leaf > 0 && s->sc.n_inner + 2ull * s->sc.n_leaf < (1ull << 24)) {
+	// closest-hit service rays take the split traversal (leaf tests through an LDS task queue: identical results, 17 % faster) unless
+	// PRGPU_TRACE_SPLIT=0 or the tree has too many records for the 24-bit task field
+	const bool split = !(getenv("PRGPU_TRACE_SPLIT") && atoi(getenv("PRGPU_TRACE_SPLIT")) == 0);
+	if (split && s->sc.n_leaf > 0 && s->sc.n_inner + 2ull * s->sc.n_leaf < (1ull << 24) && !(s->sc.features & prd::FEAT_SPHERES)) {
 		prd::launch_service_closest_split(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, const_cast<uint32_t*>(s->sc.tri_slot), s->gstats, s->stream);
 	} else
 		prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->gstats, s->stream);

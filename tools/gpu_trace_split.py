@@ -1,4 +1,4 @@
-"""Prototype check: the ray service's closest-hit kernel against the split-traversal prototype (PRGPU_TRACE_SPLIT=1: leaf tests handed to
+"""The ray service's plain closest-hit kernel (PRGPU_TRACE_SPLIT=0) against its split traversal (the default: leaf tests handed to
 whole waves through an LDS task queue) on incoherent rays inside the 1 M-triangle C4 scene -- identical results, kernel time side by side.
 usage: python tools/gpu_trace_split.py [million rays]"""
 import os, sys
