@@ -215,9 +215,10 @@ def main():
     t0 = time.time()
     ctx = backend.RenderContext(sc, device=local)
     t_create = time.time() - t0
-    # 16x16 tiles dealt round-robin along the Z-order curve: the slowest rank's share is 3 % faster than with 64x64 tiles at
-    # N = 8 (tools/gpu_probe_balance.py: max over ranks 2.91 vs 2.99 ms per iteration)
-    tiles = tiling.tiles_for_rank(width, height, rank, world, tile=16) if world > 1 else []
+    # tiles dealt round-robin along the Z-order curve; the slowest rank's share decides (tools/gpu_probe_share8.py with RANK_PROBE / TILE,
+    # ms per iteration, max over ranks): N = 8: 16x16 tiles 2.38, 32x32 2.47, 64x64 2.39 (rank 0 alone 2.20), 8x8 2.40;
+    # N = 4: 4.28 / 4.31 / 4.39; N = 2: 7.67 / 7.53 / 7.45 -- small tiles balance better, large ones keep more coherence
+    tiles = tiling.tiles_for_rank(width, height, rank, world, tile=64 if world <= 2 else 16) if world > 1 else []
     ctx.setTiles(tiles)
     xyz = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
     smp = torch.zeros((height, width), dtype=torch.int32, device=dev)
