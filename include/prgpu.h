@@ -437,6 +437,21 @@ int prgpu_path_cost(prgpu_scene* s, uint32_t* vertices);
  * XYZ_NORM scales what `rgb` already holds by 1 / (X + Y + Z) exactly like the reference does (:34-45).  Host arrays. */
 enum { PRGPU_TONE_SRGB = 0, PRGPU_TONE_XYZ = 1, PRGPU_TONE_XYZ_NORM = 2, PRGPU_TONE_LUMINANCE = 3 };
 int prgpu_tonemap(uint32_t mode, float scale, const float* xyz, const float* weight, float* rgb, uint32_t out_elems, size_t pixel_count);
+/* prcmp / imgcmp (src/tools/imgcmp/main.cpp:151-330): per-channel statistics of an image against a reference -- the reporting format of
+ * the reference's image comparisons.  `image` and `reference` hold `width * height` pixels whose compared value sits `*_stride` floats
+ * apart (interleaved planes: pass the channel's first float and the pixel stride).  crop = {sx, sy, ex, ey} in pixels, or NULL for the
+ * whole image (clamped like :283-301).  Accumulation in fp32 in row-major order like the reference; Inf / NaN pixels of `image` are
+ * counted and skipped (:311-317).  prgpu_image_stats_merge is mergeStats (:169-196): the "Global" block over several channels. */
+typedef struct prgpu_image_stats {
+	uint64_t n;                                  /* pixels in the region */
+	float min, min_ref, min_diff, max, max_ref, max_diff;
+	float mean, mean_ref, mean_diff, mean_sqr, mean_sqr_ref;
+	float mse, mape;                             /* mean squared / mean absolute percentage (fraction, not %) difference */
+	uint64_t inf_count, nan_count;
+} prgpu_image_stats;
+int  prgpu_image_compare(const float* image, uint32_t image_stride, const float* reference, uint32_t reference_stride, uint32_t width,
+                         uint32_t height, const uint32_t crop[4], prgpu_image_stats* out);
+void prgpu_image_stats_merge(prgpu_image_stats* dst, const prgpu_image_stats* src);
 /* Output channels: one `(channel :type ... :color ... )` of an `(output :name ...)` block (OutputSpecification.cpp:254-365) and how
  * ImageWriter::save (src/loader/output/io/ImageWriter.cpp:52-251) writes it: SPECTRAL channels tone mapped to three floats named
  * R, G, B (name.R ... when named; raw for the online mean / variance), 3D and 1D AOVs divided by the pixel's sample count, named

@@ -107,6 +107,13 @@ class TraceCounters(C.Structure):
                 ("shade_ticks", C.c_uint64), ("idle_ticks", C.c_uint64), ("total_ticks", C.c_uint64)]
 
 
+class ImageStats(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("min", C.c_float), ("min_ref", C.c_float), ("min_diff", C.c_float), ("max", C.c_float),
+                ("max_ref", C.c_float), ("max_diff", C.c_float), ("mean", C.c_float), ("mean_ref", C.c_float), ("mean_diff", C.c_float),
+                ("mean_sqr", C.c_float), ("mean_sqr_ref", C.c_float), ("mse", C.c_float), ("mape", C.c_float),
+                ("inf_count", C.c_uint64), ("nan_count", C.c_uint64)]
+
+
 class OutputChannel(C.Structure):
     _fields_ = [("file", C.c_uint32), ("kind", C.c_uint32), ("variable", C.c_uint32), ("tone", C.c_uint32), ("name", C.c_char * 64)]
 
@@ -170,6 +177,8 @@ SYMBOLS = {
     "prgpu_enable_variance": (C.c_int, [_VP]),
     "prgpu_download_variance": (C.c_int, [_VP, _F32P, _F32P]),
     "prgpu_path_cost": (C.c_int, [_VP, _U32P]),
+    "prgpu_image_compare": (C.c_int, [_F32P, C.c_uint32, _F32P, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, C.POINTER(ImageStats)]),
+    "prgpu_image_stats_merge": (None, [C.POINTER(ImageStats), C.POINTER(ImageStats)]),
     "prgpu_tonemap": (C.c_int, [C.c_uint32, C.c_float, _F32P, _F32P, _F32P, C.c_uint32, C.c_size_t]),
     "prgpu_outputs_enable": (C.c_int, [_VP, C.POINTER(OutputChannel), C.c_uint32]),
     "prgpu_outputs_save": (C.c_int, [_VP, C.POINTER(OutputChannel), C.c_uint32, C.c_uint32, C.c_char_p]),

@@ -248,3 +248,45 @@ def tonemap(xyz, mode=abi.TONE_SRGB, scale=1.0, weight=None):
 def xyz_to_srgb_linear(xyz):
     """RGBConverter::fromXYZ (spectral/RGBConverter.cpp:15-24): XYZ -> linear sRGB, clamped at 0."""
     return tonemap(xyz, abi.TONE_SRGB)
+
+
+def image_compare(image, reference, crop=None):
+    """prcmp statistics (src/tools/imgcmp/main.cpp) of one channel: `image`, `reference` float32 [H, W] (any stride-1 view of a plane).
+    Returns the dict of the reference's PerChannelStats fields."""
+    lib = abi.load()
+    a = np.ascontiguousarray(image, dtype=np.float32)
+    b = np.ascontiguousarray(reference, dtype=np.float32)
+    assert a.shape == b.shape and a.ndim == 2, "two planes of the same shape"
+    st = abi.ImageStats()
+    c = None if crop is None else (C.c_uint32 * 4)(*[int(v) for v in crop])
+    abi.check(lib.prgpu_image_compare(_f32p(a), 1, _f32p(b), 1, a.shape[1], a.shape[0], c, C.byref(st)))
+    return st
+
+
+def image_stats_merge(stats):
+    """mergeStats over several channels (the "Global" block of prcmp)."""
+    lib = abi.load()
+    g = abi.ImageStats()
+    for st in stats:
+        lib.prgpu_image_stats_merge(C.byref(g), C.byref(st))
+    return g
+
+
+def image_stats_report(st):
+    """The lines prcmp prints for one PerChannelStats (printStat, main.cpp:198-237), as (label, value) pairs."""
+    f = np.float32
+    with np.errstate(all="ignore"):
+        var = f(st.mean_sqr) - f(st.mean) * f(st.mean)
+        var_ref = f(st.mean_sqr_ref) - f(st.mean_ref) * f(st.mean_ref)
+        var_diff = f(st.mse) - f(st.mean_diff) * f(st.mean_diff)
+        psnr = f(st.max_ref) * f(st.max_ref) / f(st.mse)
+        snr, snr_ref, snr_diff = f(st.mean) / np.sqrt(var), f(st.mean_ref) / np.sqrt(var_ref), f(st.mean_diff) / np.sqrt(var_diff)
+        snt = (f(st.mean) - f(st.mean_ref)) / (np.sqrt(var) - np.sqrt(var_ref))
+        db = lambda v: 10 * np.log10(v)  # noqa: E731
+        return [("Min", st.min), ("Max", st.max), ("Mean", st.mean), ("MeanSqr", st.mean_sqr), ("MinRef", st.min_ref), ("MaxRef", st.max_ref),
+                ("MeanRef", st.mean_ref), ("MeanSqrRef", st.mean_sqr_ref), ("MinDiff", st.min_diff), ("MaxDiff", st.max_diff),
+                ("MeanDiff", st.mean_diff), ("MSE", st.mse), ("RMSE", float(np.sqrt(f(st.mse)))), ("MAE", st.mean_diff),
+                ("MAPE", "%g %%" % (st.mape * 100)), ("PSNR", "%g [%g dB]" % (psnr, db(psnr))), ("SNR", "%g [%g dB]" % (snr, db(snr))),
+                ("SNRRef", "%g [%g dB]" % (snr_ref, db(snr_ref))), ("SNRDiff", "%g [%g dB]" % (snr_diff, db(snr_diff))), ("SNT", float(snt)),
+                ("Variance", float(var)), ("VarianceRef", float(var_ref)), ("VarianceDiff", float(var_diff)), ("StdDev", float(np.sqrt(var))),
+                ("StdDevRef", float(np.sqrt(var_ref))), ("StdDevDiff", float(np.sqrt(var_diff)))]

@@ -4,7 +4,9 @@
 // (src/core/spectral/ToneMapper.cpp:12-79), RGBConverter::fromXYZ (src/core/spectral/RGBConverter.cpp:15-24) and the per-pixel
 // channel assembly of ImageWriter::save (src/loader/output/io/ImageWriter.cpp:52-251).
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -12,6 +14,92 @@
 #include "setup.h"
 
 extern "C" {
+
+// prcmp statistics (src/tools/imgcmp/main.cpp:283-330): fp32 accumulation in row-major order, averages over the whole region
+int prgpu_image_compare(const float* image, uint32_t image_stride, const float* reference, uint32_t reference_stride, uint32_t width, uint32_t height,
+						const uint32_t crop[4], prgpu_image_stats* out)
+{
+	using prgpu_host::set_last_error;
+	if (!image || !reference || !out || !image_stride || !reference_stride || !width || !height)
+		return set_last_error(PRGPU_EINVAL, "prgpu_image_compare: null buffer, zero stride or empty image");
+	size_t sx = 0, sy = 0, ex = width, ey = height;
+	if (crop) {
+		sx = std::max(sx, std::min<size_t>(ex - 1, crop[0]));
+		sy = std::max(sy, std::min<size_t>(ey - 1, crop[1]));
+		ex = std::max(sx + 1, std::min<size_t>(ex, crop[2]));
+		ey = std::max(sy + 1, std::min<size_t>(ey, crop[3]));
+	}
+	const size_t nw = ex - sx, nh = ey - sy;
+	prgpu_image_stats st;
+	std::memset(&st, 0, sizeof(st));
+	st.min = st.min_ref = st.min_diff = std::numeric_limits<float>::infinity();
+	st.max = st.max_ref = -std::numeric_limits<float>::infinity();
+	const float avg = 1.0f / (nw * nh);
+	for (size_t y = sy; y < ey; ++y)
+		for (size_t x = sx; x < ex; ++x) {
+			const size_t i = y * width + x;
+			const float A = image[i * image_stride], B = reference[i * reference_stride];
+			if (std::isinf(A)) {
+				st.inf_count += 1;
+				continue;
+			} else if (std::isnan(A)) {
+				st.nan_count += 1;
+				continue;
+			}
+			st.max = std::max(A, st.max);
+			st.min = std::min(A, st.min);
+			st.mean += A;
+			st.mean_sqr += A * A;
+			st.max_ref = std::max(B, st.max_ref);
+			st.min_ref = std::min(B, st.min_ref);
+			st.mean_ref += B;
+			st.mean_sqr_ref += B * B;
+			const float diff = std::abs(A - B);
+			st.max_diff		 = std::max(diff, st.max_diff);
+			st.min_diff		 = std::min(diff, st.min_diff);
+			st.mean_diff += diff;
+			st.mse += diff * diff;
+			if (B != 0)
+				st.mape += diff / std::abs(B);
+		}
+	st.mean *= avg;
+	st.mean_ref *= avg;
+	st.mean_diff *= avg;
+	st.mean_sqr *= avg;
+	st.mean_sqr_ref *= avg;
+	st.mse *= avg;
+	st.mape *= avg;
+	st.n = nw * nh;
+	*out = st;
+	return PRGPU_OK;
+}
+
+void prgpu_image_stats_merge(prgpu_image_stats* dst, const prgpu_image_stats* src) // mergeStats (:169-196)
+{
+	if (!dst || !src)
+		return;
+	auto mean_add = [](float a, uint64_t n1, float b, uint64_t n2) { return (n1 + n2 == 0) ? 0.0f : (a * n1 + b * n2) / (n1 + n2); };
+	if (dst->n == 0 && dst->min == 0 && dst->max == 0) { // a zero-initialised accumulator starts like the reference's default PerChannelStats
+		dst->min = dst->min_ref = dst->min_diff = std::numeric_limits<float>::infinity();
+		dst->max = dst->max_ref = -std::numeric_limits<float>::infinity();
+	}
+	dst->min		  = std::min(dst->min, src->min);
+	dst->min_ref	  = std::min(dst->min_ref, src->min_ref);
+	dst->min_diff	  = std::min(dst->min_diff, src->min_diff);
+	dst->max		  = std::max(dst->max, src->max);
+	dst->max_ref	  = std::max(dst->max_ref, src->max_ref);
+	dst->max_diff	  = std::max(dst->max_diff, src->max_diff);
+	dst->mean		  = mean_add(dst->mean, dst->n, src->mean, src->n);
+	dst->mean_ref	  = mean_add(dst->mean_ref, dst->n, src->mean_ref, src->n);
+	dst->mean_diff	  = mean_add(dst->mean_diff, dst->n, src->mean_diff, src->n);
+	dst->mean_sqr	  = mean_add(dst->mean_sqr, dst->n, src->mean_sqr, src->n);
+	dst->mean_sqr_ref = mean_add(dst->mean_sqr_ref, dst->n, src->mean_sqr_ref, src->n);
+	dst->mse		  = mean_add(dst->mse, dst->n, src->mse, src->n);
+	dst->mape		  = mean_add(dst->mape, dst->n, src->mape, src->n);
+	dst->inf_count += src->inf_count;
+	dst->nan_count += src->nan_count;
+	dst->n += src->n;
+}
 
 int prgpu_tonemap(uint32_t mode, float scale, const float* xyz, const float* weight, float* rgb, uint32_t out_elems, size_t pixel_count)
 {

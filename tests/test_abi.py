@@ -27,7 +27,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     import subprocess
     structs = {"prgpu_spectrum": abi.Spectrum, "prgpu_material": abi.Material, "prgpu_emission": abi.Emission,
                "prgpu_entity": abi.Entity, "prgpu_camera": abi.Camera, "prgpu_settings": abi.Settings,
-               "prgpu_scene_desc": abi.SceneDesc, "prgpu_tile": abi.Tile, "prgpu_trace_counters": abi.TraceCounters}
+               "prgpu_scene_desc": abi.SceneDesc, "prgpu_tile": abi.Tile, "prgpu_trace_counters": abi.TraceCounters,
+               "prgpu_light": abi.Light, "prgpu_image_stats": abi.ImageStats, "prgpu_output_channel": abi.OutputChannel}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "prgpu.h"', "int main(void){"]
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
