@@ -426,6 +426,24 @@ int      prgpu_download_aov(prgpu_scene* s, uint32_t aov, float* out);
 int prgpu_enable_variance(prgpu_scene* s);
 int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance); /* either pointer may be NULL */
 
+/* Light path expressions (src/core/path/LPE_*.cpp, LightPathExpression.h): up to PRGPU_LPE_MAX extra spectral planes, each receiving
+ * exactly the fragments of the main output whose light path matches its expression (LocalFrameOutputDevice.cpp:99-113) and averaged
+ * over the iterations like it.  A path is the token sequence the `direct` integrator builds (direct.cpp:67,125,197,338-351,387,409):
+ * C, one <type, event> token per scattering (the material's MaterialScatteringType), then E (emissive surface) or B (background /
+ * infinite light); next-event fragments carry the evaluated scattering type before their E / B.  Grammar and token classes as in
+ * LPE_Parser.cpp / LPE_RegState.h: C first, then D S E L B R T . <T,E>, groups ( ), unions [ ], and * + ? {n} {n,m}; labelled tokens
+ * (<T,E,"label">: material labels live in the host's registry) and expressions that need more than PRGPU_LPE_MAX_STATES automaton
+ * states are PRGPU_EUNSUPPORTED.  Enable before the first iteration; needs a single-tap pixel filter and selects the persistent
+ * pipeline.  prgpu_lpe_check only parses (0 = valid). */
+#define PRGPU_LPE_MAX 4
+#define PRGPU_LPE_MAX_STATES 32
+int prgpu_lpe_check(const char* expression);
+/* LightPathExpression::match on an explicit token sequence: symbols[i] = scattering type * 3 + event (types Camera 0, Emissive 1, Refraction 2,
+ * Reflection 3, Background 4; events Diffuse 0, Specular 1, None 2 -- LightPathToken.h:6-20).  1 = match, 0 = no match, < 0 = error. */
+int prgpu_lpe_match(const char* expression, const uint8_t* symbols, uint32_t count);
+int prgpu_enable_lpe(prgpu_scene* s, uint32_t n, const char* const* expressions);
+int prgpu_download_lpe(prgpu_scene* s, uint32_t index, float* xyz); /* W*H*3 fp32 */
+
 /* Scheduling statistic of the persistent pipeline: path vertices traced per pixel so far (W*H u32; kept only while every owned pixel is in
  * flight at once -- a small tile share --, 0 otherwise and in the other pipelines).  The
  * backend uses it to hand the pixels with the longest sample chains to the fastest blocks of a small tile share; exposed for
@@ -455,7 +473,8 @@ void prgpu_image_stats_merge(prgpu_image_stats* dst, const prgpu_image_stats* sr
 /* Output channels: one `(channel :type ... :color ... )` of an `(output :name ...)` block (OutputSpecification.cpp:254-365) and how
  * ImageWriter::save (src/loader/output/io/ImageWriter.cpp:52-251) writes it: SPECTRAL channels tone mapped to three floats named
  * R, G, B (name.R ... when named; raw for the online mean / variance), 3D and 1D AOVs divided by the pixel's sample count, named
- * name.x/.y/.z or name, COUNTER planes as floats.  Channels with a light path expression (:lpe) and the `uvw` AOV are not provided. */
+ * name.x/.y/.z or name, COUNTER planes as floats.  Colour channels may carry a light path expression (:lpe, at most PRGPU_LPE_MAX distinct ones
+ * per scene: prgpu_outputs_enable enables them in order of first appearance); :lpe on AOV / counter channels and the `uvw` AOV are not provided. */
 enum { PRGPU_CHANNEL_SPECTRAL = 0, PRGPU_CHANNEL_3D = 1, PRGPU_CHANNEL_1D = 2, PRGPU_CHANNEL_COUNTER = 3 };
 enum { PRGPU_SPECTRAL_OUTPUT = 0, PRGPU_SPECTRAL_ONLINE_MEAN = 1, PRGPU_SPECTRAL_ONLINE_VARIANCE = 2 };
 enum { PRGPU_COUNTER_SAMPLES = 0, PRGPU_COUNTER_FEEDBACK = 1 };
@@ -465,6 +484,7 @@ typedef struct prgpu_output_channel {
 	uint32_t variable; /* SPECTRAL: PRGPU_SPECTRAL_*; 3D, 1D: PRGPU_AOV_*; COUNTER: PRGPU_COUNTER_* */
 	uint32_t tone;     /* SPECTRAL: PRGPU_TONE_* */
 	char     name[64]; /* channel base name as ImageWriter writes it ("" for the colour channel: R, G, B) */
+	char     lpe[64];  /* SPECTRAL OUTPUT only: light path expression (`:lpe`), "" = none; the channel is then named "[expression]" (OutputSpecification.cpp:323-324) */
 } prgpu_output_channel;
 /* Allocate the AOV / variance planes the channels need (before the first iteration). */
 int prgpu_outputs_enable(prgpu_scene* s, const prgpu_output_channel* channels, uint32_t n_channels);

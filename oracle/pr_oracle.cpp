@@ -861,6 +861,205 @@ struct BvhNode {
 	uint32_t count; // 0: inner
 };
 
+// ---- light path expressions (src/core/path/LPE_Parser.cpp grammar, LPE_RegState.h token classes), matched directly on the explicit
+// token sequence of a path: match(node, i) = the set of positions a match of `node` starting at token i can end at.  (The device tracks
+// DFA states instead; the two implementations share nothing.)
+struct LpeNode {
+	enum Kind { TOKEN, CONCAT, UNION, REPEAT } kind = TOKEN;
+	char type = '.', event = '.';
+	uint32_t lo = 1, hi = 1; // REPEAT; hi == 0: unbounded
+	std::vector<LpeNode> kids;
+};
+struct LpeParser {
+	const std::string& s;
+	size_t pos = 0;
+	bool ok	   = true;
+	explicit LpeParser(const std::string& str) : s(str) {}
+	char cur() const { return pos < s.size() ? s[pos] : '\0'; }
+	bool accept(char c)
+	{
+		if (cur() != c)
+			return ok = false;
+		++pos;
+		return true;
+	}
+	LpeNode token(char t, char e)
+	{
+		LpeNode n;
+		n.type	= t;
+		n.event = e;
+		return n;
+	}
+	LpeNode op(LpeNode n)
+	{
+		LpeNode r;
+		r.kind = LpeNode::REPEAT;
+		if (cur() == '*') {
+			++pos;
+			r.lo = 0;
+			r.hi = 0;
+		} else if (cur() == '+') {
+			++pos;
+			r.lo = 1;
+			r.hi = 0;
+		} else if (cur() == '?') {
+			++pos;
+			r.lo = 0;
+			r.hi = 1;
+		} else if (cur() == '{') {
+			++pos;
+			auto number = [&]() {
+				uint32_t v = 0;
+				if (!std::isdigit((unsigned char)cur()))
+					ok = false;
+				while (std::isdigit((unsigned char)cur()) && v < 1000)
+					v = v * 10 + uint32_t(s[pos++] - '0');
+				return v;
+			};
+			r.lo = r.hi = number();
+			if (cur() == ',') {
+				++pos;
+				r.hi = number();
+			}
+			accept('}');
+			if (r.hi < r.lo)
+				ok = false;
+			if (r.lo == 0 && r.hi == 0)
+				r.hi = 0; // repeatLast(0, 0): the star
+		} else {
+			return n;
+		}
+		r.kids.push_back(std::move(n));
+		return r;
+	}
+	LpeNode term()
+	{
+		const char c = cur();
+		if (c == '(') {
+			++pos;
+			LpeNode e = expr();
+			accept(')');
+			return op(std::move(e));
+		}
+		if (c == '[') {
+			++pos;
+			if (cur() == '^')
+				ok = false;
+			LpeNode u;
+			u.kind = LpeNode::UNION;
+			do {
+				u.kids.push_back(term());
+			} while (ok && pos < s.size() && cur() != ']');
+			accept(']');
+			return op(std::move(u));
+		}
+		if (c == 'D' || c == 'S') {
+			++pos;
+			return op(token('.', c));
+		}
+		if (c == 'E' || c == 'L' || c == 'B' || c == 'R' || c == 'T' || c == '.') {
+			++pos;
+			return op(token(c, '.'));
+		}
+		if (c == '<') {
+			++pos;
+			const char t = cur();
+			if (!std::strchr("ELBRT.", t) || t == '\0')
+				ok = false;
+			++pos;
+			if (cur() == ',')
+				++pos;
+			const char e = cur();
+			if (!(e == 'D' || e == 'S' || e == '.'))
+				ok = false;
+			++pos;
+			if (cur() == '"' || cur() == ',')
+				ok = false; // labels: not supported
+			accept('>');
+			return op(token(t, e));
+		}
+		ok = false;
+		return LpeNode();
+	}
+	LpeNode expr()
+	{
+		LpeNode cat;
+		cat.kind = LpeNode::CONCAT;
+		do {
+			cat.kids.push_back(term());
+		} while (ok && pos < s.size() && cur() != ')');
+		return cat;
+	}
+	LpeNode full()
+	{
+		LpeNode cat;
+		cat.kind = LpeNode::CONCAT;
+		accept('C');
+		cat.kids.push_back(token('C', '.'));
+		cat.kids.push_back(expr());
+		if (pos != s.size())
+			ok = false;
+		return cat;
+	}
+};
+inline bool lpe_token_matches(const LpeNode& n, uint8_t symbol)
+{
+	const int t = symbol / 3, e = symbol % 3; // ScatteringType Camera, Emissive, Refraction, Reflection, Background; ScatteringEvent Diffuse, Specular, None
+	bool mt;
+	switch (n.type) {
+	case 'C': mt = t == 0; break;
+	case 'E': mt = t == 1; break;
+	case 'B': mt = t == 4; break;
+	case 'L': mt = t == 1 || t == 4; break;
+	case 'R': mt = t == 3; break;
+	case 'T': mt = t == 2; break;
+	default: mt = t == 2 || t == 3; break;
+	}
+	const bool me = n.event == 'D' ? e == 0 : (n.event == 'S' ? e == 1 : true);
+	return mt && me;
+}
+typedef unsigned __int128 LpeSet; // bit j: a match may end before token j (paths have at most 1 + 64 + 2 tokens)
+inline LpeSet lpe_ends(const LpeNode& n, const uint8_t* tok, uint32_t count, LpeSet starts)
+{
+	switch (n.kind) {
+	case LpeNode::TOKEN: {
+		LpeSet out = 0;
+		for (uint32_t i = 0; i < count; ++i)
+			if (((starts >> i) & 1) && lpe_token_matches(n, tok[i]))
+				out |= LpeSet(1) << (i + 1);
+		return out;
+	}
+	case LpeNode::CONCAT: {
+		LpeSet cur = starts;
+		for (const LpeNode& k : n.kids)
+			cur = lpe_ends(k, tok, count, cur);
+		return cur;
+	}
+	case LpeNode::UNION: {
+		LpeSet out = 0;
+		for (const LpeNode& k : n.kids)
+			out |= lpe_ends(k, tok, count, starts);
+		return out;
+	}
+	default: {
+		LpeSet cur = starts, out = n.lo == 0 ? starts : 0;
+		const uint32_t limit = n.hi == 0 ? count + 1 : n.hi;
+		for (uint32_t rep = 1; rep <= limit && cur; ++rep) {
+			cur = lpe_ends(n.kids[0], tok, count, cur);
+			if (rep >= n.lo)
+				out |= cur;
+		}
+		return out;
+	}
+	}
+}
+inline bool lpe_matches(const LpeNode& full, const uint8_t* tok, uint32_t count)
+{
+	return count < 127 && ((lpe_ends(full, tok, count, LpeSet(1)) >> count) & 1);
+}
+constexpr uint8_t LPE_CAMERA = 0 * 3 + 2, LPE_EMISSIVE = 1 * 3 + 2, LPE_BACKGROUND = 4 * 3 + 2;
+constexpr uint8_t LPE_DIFF_REFL = 3 * 3 + 0, LPE_SPEC_REFL = 3 * 3 + 1, LPE_DIFF_TRANS = 2 * 3 + 0, LPE_SPEC_TRANS = 2 * 3 + 1;
+
 struct Scene {
 	prgpu_scene_desc d;
 	prgpu_settings cfg;
@@ -932,6 +1131,8 @@ struct Scene {
 	std::vector<uint32_t> samples, feedback, prim_entity, prim_prim;
 	std::vector<float> aov[PRGPU_AOV_COUNT]; // shading-point AOV sums (enabled planes are non-empty)
 	std::vector<float> online_mean, online_variance; // AOV_OnlineMean / AOV_OnlineVariance (W*H*3), empty unless enabled
+	std::vector<LpeNode> lpe;						 // light path expressions (orc_enable_lpe)
+	std::vector<float> lpe_xyz[PRGPU_LPE_MAX], lpe_iter[PRGPU_LPE_MAX]; // their running means / per-iteration sums, like xyz / iter_xyz
 	std::atomic<uint64_t> stats[PRGPU_STAT_COUNT];
 	std::atomic<uint64_t> cnt_nodes{ 0 }, cnt_tris{ 0 };
 	// debugging aid: rays of one pixel (kind, iter, o[3], d[3], tmin, tmax|distance, result)
@@ -2384,6 +2585,7 @@ inline bool camera_ray(const Scene& s, float px, float py, float r1, float r2, V
 struct TileOut {
 	int x0, y0, w, h, r; // tile origin, extended size incl. apron
 	std::vector<float> xyz;
+	std::vector<float> lpe[PRGPU_LPE_MAX];
 	std::vector<uint32_t> samples, feedback;
 	uint64_t stats[PRGPU_STAT_COUNT] = { 0 };
 };
@@ -2405,7 +2607,7 @@ struct RayState {
 // RenderTileSession::pushSpectralFragment (RenderTileSession.cpp:133-142) +
 // LocalFrameOutputDevice::commitSpectrals2 (LocalFrameOutputDevice.cpp:88-164)
 inline void push_fragment(const Scene& s, TileOut& out, int lx, int ly, const Blob& mis, const Blob& importance,
-						  const Blob& grp_importance, const Blob& radiance, bool mono, const Blob& grp_wl, float blend, float* path_sum)
+						  const Blob& grp_importance, const Blob& radiance, bool mono, const Blob& grp_wl, float blend, float* path_sum, uint32_t lpe_mask = 0)
 {
 	const Blob imp		  = grp_importance * importance;
 	const Blob heroFactor = mono ? hero_only() : blob(1);
@@ -2452,6 +2654,10 @@ inline void push_fragment(const Scene& s, TileOut& out, int lx, int ly, const Bl
 				const float w = fw * blend;
 				for (int c = 0; c < 3; ++c)
 					out.xyz[(size_t(py) * out.w + px) * 3 + c] += w * triplet[c];
+				for (int k = 0; k < PRGPU_LPE_MAX; ++k) // LocalFrameOutputDevice.cpp:106-112
+					if (lpe_mask & (1u << k))
+						for (int c = 0; c < 3; ++c)
+							out.lpe[k][(size_t(py) * out.w + px) * 3 + c] += w * triplet[c];
 			}
 		}
 	}
@@ -3064,8 +3270,34 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 	cur.last_pos = v3(0, 0, 0);
 	cur.last_n	 = v3(0, 0, 0);
 
+	// the light path of the sample (direct.cpp:67,125,197,338-351,387,409): C, one token per scattering; fragments add their own tail
+	std::vector<uint8_t> path_tokens{ LPE_CAMERA };
+	auto lpe_mask = [&](std::initializer_list<uint8_t> tail) -> uint32_t {
+		if (s.lpe.empty())
+			return 0u;
+		std::vector<uint8_t> t(path_tokens);
+		t.insert(t.end(), tail.begin(), tail.end());
+		uint32_t m = 0;
+		for (size_t k = 0; k < s.lpe.size(); ++k)
+			if (lpe_matches(s.lpe[k], t.data(), (uint32_t)t.size()))
+				m |= 1u << k;
+		return m;
+	};
+	// MaterialScatteringType of a material for (V, L) in tangent space as a token (lambert.cpp:41,69; conductor.cpp:40,70; mirror.cpp:35,57;
+	// roughconductor.cpp:44,108; dielectric.cpp:79-107; roughdielectric.cpp:198-252; principled.cpp:511-521,565-575)
+	auto scatter_token = [](const prgpu_material& m, V3 Vt, V3 Lt) -> uint8_t {
+		const bool same = std::signbit(Vt.z) == std::signbit(Lt.z);
+		switch (m.kind) {
+		case PRGPU_MAT_LAMBERT: return LPE_DIFF_REFL;
+		case PRGPU_MAT_DIELECTRIC:
+		case PRGPU_MAT_ROUGH_DIELECTRIC: return same ? LPE_SPEC_REFL : LPE_SPEC_TRANS;
+		case PRGPU_MAT_PRINCIPLED: return m.roughness_x < 0.5f ? (same ? LPE_SPEC_REFL : LPE_SPEC_TRANS) : (same ? LPE_DIFF_REFL : LPE_DIFF_TRANS);
+		default: return LPE_SPEC_REFL;
+		}
+	};
+	uint32_t frag_mask = 0; // set before each push
 	auto push = [&](const Blob& mis, const Blob& radiance, bool mono) {
-		push_fragment(s, out, lx, ly, mis, cur.throughput, grp_importance, radiance, mono, wl, blend, path_sum);
+		push_fragment(s, out, lx, ly, mis, cur.throughput, grp_importance, radiance, mono, wl, blend, path_sum, frag_mask);
 	};
 	auto hero_factor = [](bool mono) { return mono ? hero_only() : blob(1); };
 	const bool power_mis = cfg.mis == PRGPU_MIS_POWER;
@@ -3098,10 +3330,10 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 					Blob lrad;
 					float lpdf;
 					inf_light_eval(s, il, ray.d, ray.wl, true, lrad, lpdf);
-					push_fragment(s, out, lx, ly, one, one, grp_importance, lrad, ray.mono, wl, blend, path_sum);
+					push_fragment(s, out, lx, ly, one, one, grp_importance, lrad, ray.mono, wl, blend, path_sum, lpe_mask({ LPE_BACKGROUND }));
 				}
 				if (!illuminated)
-					push_fragment(s, out, lx, ly, one, one, grp_importance, blob(0), ray.mono, wl, blend, path_sum);
+					push_fragment(s, out, lx, ly, one, one, grp_importance, blob(0), ray.mono, wl, blend, path_sum, lpe_mask({ LPE_BACKGROUND }));
 			} else if (!s.inf_lights.empty() && cfg.direct) {
 				// ---- handleInfLights (direct.cpp:415-456)
 				const Blob hf	= hero_factor(ray.mono);
@@ -3122,13 +3354,16 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 					denom_mis += bsum(mis_b(cur.prev_path_pdf * pdf_S));
 				}
 				if (!cfg.nee || cur.last_delta) {
+					frag_mask = lpe_mask({ LPE_BACKGROUND }); // direct.cpp:125
 					push(hf / (cur.wvl_pdf * bsum(hf)), radiance, ray.mono);
 				} else {
 					const float denom = bsum(mis_b(cur.path_pdf)) + denom_mis;
+					frag_mask = lpe_mask({ LPE_BACKGROUND });
 					push((hf * mis_f(cur.path_pdf[0])) / (mis_b(cur.wvl_pdf) * denom), radiance, ray.mono);
 				}
 			} else {
 				const Blob hf = hero_factor(ray.mono);
+				frag_mask = lpe_mask({ LPE_BACKGROUND });
 				push(hf / (cur.wvl_pdf * bsum(hf)), blob(0), ray.mono);
 			}
 			break;
@@ -3180,6 +3415,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				const Blob radiance = behind ? blob(0) : spectrum_eval(s, s.emissions[gp.emission].radiance, ray.wl);
 				const Blob hf		= hero_factor(ray.mono);
 				if (!cfg.nee || behind || cur.last_delta) {
+					frag_mask = lpe_mask({ LPE_EMISSIVE }); // direct.cpp:387
 					push(hf / (cur.wvl_pdf * bsum(hf)), radiance, ray.mono);
 				} else {
 					const uint32_t lid	= s.entity_light[gp.entity];
@@ -3193,6 +3429,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 					const float posPDF_S = posPDF * selProb;
 					const float denom	 = bsum(mis_b(cur.prev_path_pdf * posPDF_S)) + bsum(mis_b(cur.path_pdf));
 					const Blob mis		 = (hf * mis_f(cur.path_pdf[0])) / (mis_b(cur.wvl_pdf) * denom);
+					frag_mask = lpe_mask({ LPE_EMISSIVE }); // direct.cpp:409
 					push(mis, radiance, ray.mono);
 				}
 			}
@@ -3279,6 +3516,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 					}
 					const Blob contrib = visible ? connectionW / lightPdfS2[0] : blob(0);
 					st[PRGPU_STAT_BACKGROUND_HITS]++;
+					frag_mask = lpe_mask({ scatter_token(mat, Vt, Lt), LPE_BACKGROUND }); // direct.cpp:338-342
 					push(mis, contrib, ray.mono);
 					break;
 				}
@@ -3376,6 +3614,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				}
 				const Blob contrib = visible ? connectionW / lightPdfS2[0] : blob(0);
 				st[PRGPU_STAT_ENTITY_HITS]++;
+				frag_mask = lpe_mask({ scatter_token(mat, Vt, Lt), LPE_EMISSIVE }); // direct.cpp:338-345
 				push(mis, contrib, ray.mono);
 			} while (false);
 		}
@@ -3448,6 +3687,7 @@ void trace_sample(Scene& s, TileOut& out, int gx, int gy, uint32_t iter)
 				Lt = -Lt;
 		}
 		const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt)); // MaterialSampleOutput::globalL
+		path_tokens.push_back(scatter_token(mat, Vt, Lt)); // mCameraPath.addToken(sout.Type) (direct.cpp:197)
 		cur.last_delta	  = sampleDelta;
 		cur.prev_path_pdf = cur.path_pdf;
 		cur.path_pdf	  = cur.path_pdf * (pdf_s * scatProb);
@@ -3523,6 +3763,8 @@ void render_iteration(Scene& s, uint32_t iter, int threads)
 			o.w				  = (t.x1 - t.x0) + 2 * r;
 			o.h				  = (t.y1 - t.y0) + 2 * r;
 			o.xyz.assign(size_t(o.w) * o.h * 3, 0.0f);
+			for (size_t k = 0; k < s.lpe.size(); ++k)
+				o.lpe[k].assign(size_t(o.w) * o.h * 3, 0.0f);
 			o.samples.assign(size_t(o.w) * o.h, 0);
 			o.feedback.assign(size_t(o.w) * o.h, 0);
 			// StreamPipeline::fillWithCameraRays (StreamPipeline.cpp:83-133): Morton order over the tile
@@ -3565,6 +3807,9 @@ void render_iteration(Scene& s, uint32_t iter, int threads)
 				const size_t src = size_t(y) * o.w + x, dst = size_t(gy) * W + gx;
 				for (int c = 0; c < 3; ++c)
 					s.iter_xyz[dst * 3 + c] += o.xyz[src * 3 + c];
+				for (size_t k = 0; k < s.lpe.size(); ++k)
+					for (int c = 0; c < 3; ++c)
+						s.lpe_iter[k][dst * 3 + c] += o.lpe[k][src * 3 + c];
 				s.samples[dst] += o.samples[src];
 				s.feedback[dst] |= o.feedback[src];
 			}
@@ -3590,6 +3835,10 @@ void render_iteration(Scene& s, uint32_t iter, int threads)
 		}
 		s.xyz[i]	  = (s.xyz[i] * itm1 + s.iter_xyz[i]) / it;
 		s.iter_xyz[i] = 0;
+		for (size_t k = 0; k < s.lpe.size(); ++k) {
+			s.lpe_xyz[k][i]	 = (s.lpe_xyz[k][i] * itm1 + s.lpe_iter[k][i]) / it;
+			s.lpe_iter[k][i] = 0;
+		}
 	}
 }
 
@@ -3942,6 +4191,42 @@ int orc_enable_variance(orc_scene* h)
 	h->s.online_mean.assign(np * 3, 0.0f);
 	h->s.online_variance.assign(np * 3, 0.0f);
 	return 0;
+}
+int orc_enable_lpe(orc_scene* h, uint32_t n, const char* const* expressions)
+{
+	if (n > PRGPU_LPE_MAX || !h->s.lpe.empty())
+		return -1;
+	const size_t np = size_t(h->s.cfg.width) * h->s.cfg.height;
+	for (uint32_t k = 0; k < n; ++k) {
+		const std::string expr(expressions[k]);
+		LpeParser p(expr);
+		LpeNode tree = p.full();
+		if (!p.ok) {
+			h->s.lpe.clear();
+			return -1;
+		}
+		h->s.lpe.push_back(std::move(tree));
+		h->s.lpe_xyz[k].assign(np * 3, 0.0f);
+		h->s.lpe_iter[k].assign(np * 3, 0.0f);
+	}
+	return 0;
+}
+int orc_download_lpe(orc_scene* h, uint32_t index, float* xyz)
+{
+	if (index >= h->s.lpe.size())
+		return -1;
+	std::memcpy(xyz, h->s.lpe_xyz[index].data(), h->s.lpe_xyz[index].size() * sizeof(float));
+	return 0;
+}
+// 1: the expression is valid and matches the token sequence (symbols = type * 3 + event), 0: no match, -1: invalid expression
+int orc_lpe_match(const char* expression, const uint8_t* symbols, uint32_t count)
+{
+	const std::string expr(expression);
+	LpeParser p(expr);
+	const LpeNode tree = p.full();
+	if (!p.ok)
+		return -1;
+	return lpe_matches(tree, symbols, count) ? 1 : 0;
 }
 int orc_download_variance(orc_scene* h, float* mean, float* variance)
 {

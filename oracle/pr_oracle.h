@@ -33,6 +33,9 @@ int  orc_enable_aovs(orc_scene* s, uint32_t mask);                  /* LocalFram
 int  orc_download_aov(orc_scene* s, uint32_t aov, float* out);
 int  orc_enable_variance(orc_scene* s);                              /* AOV_OnlineMean / AOV_OnlineVariance, VarianceEstimator.inl:15-27 */
 int  orc_download_variance(orc_scene* s, float* mean, float* variance);
+int  orc_enable_lpe(orc_scene* s, uint32_t n, const char* const* expressions); /* light path expressions, LocalFrameOutputDevice.cpp:99-113 */
+int  orc_download_lpe(orc_scene* s, uint32_t index, float* xyz);
+int  orc_lpe_match(const char* expression, const uint8_t* symbols, uint32_t count); /* LightPathExpression::match on explicit tokens */
 int  orc_download_primary_hits(orc_scene* s, uint32_t* entity, uint32_t* prim);
 /* Per-pixel filter-free radiance sums of the LAST iteration: W*H*3, sum over the path's fragments of
  * blend * XYZ(fragment) in push order -- the quantity the device keeps per path. */

@@ -22,6 +22,7 @@ ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE = 0, 1, 2
 LIGHT_ENVIRONMENT, LIGHT_DISTANT, LIGHT_SKY, LIGHT_SUN, LIGHT_CIE_SKY = 0, 1, 2, 3, 4
 SKYF_EXTEND, SKYF_COMPENSATION, SKYF_CLOUDY = 1, 2, 8
 SKY_BANDS = 11
+LPE_MAX, LPE_MAX_STATES = 4, 32
 CAMERA_PERSPECTIVE, CAMERA_ORTHO, CAMERA_SPHERICAL, CAMERA_FISHEYE = 0, 1, 2, 3
 FISHEYE_CIRCULAR, FISHEYE_CROPPED, FISHEYE_FULL = 0, 1, 2
 AOV_NAMES = ("position", "normal", "normal_g", "tangent", "bitangent", "view", "entity_id", "material_id", "emission_id", "depth")
@@ -115,7 +116,8 @@ class ImageStats(C.Structure):
 
 
 class OutputChannel(C.Structure):
-    _fields_ = [("file", C.c_uint32), ("kind", C.c_uint32), ("variable", C.c_uint32), ("tone", C.c_uint32), ("name", C.c_char * 64)]
+    _fields_ = [("file", C.c_uint32), ("kind", C.c_uint32), ("variable", C.c_uint32), ("tone", C.c_uint32), ("name", C.c_char * 64),
+                ("lpe", C.c_char * 64)]
 
 
 CHANNEL_SPECTRAL, CHANNEL_3D, CHANNEL_1D, CHANNEL_COUNTER = range(4)
@@ -177,6 +179,10 @@ SYMBOLS = {
     "prgpu_enable_variance": (C.c_int, [_VP]),
     "prgpu_download_variance": (C.c_int, [_VP, _F32P, _F32P]),
     "prgpu_path_cost": (C.c_int, [_VP, _U32P]),
+    "prgpu_lpe_check": (C.c_int, [C.c_char_p]),
+    "prgpu_lpe_match": (C.c_int, [C.c_char_p, _U8P, C.c_uint32]),
+    "prgpu_enable_lpe": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_char_p)]),
+    "prgpu_download_lpe": (C.c_int, [_VP, C.c_uint32, _F32P]),
     "prgpu_image_compare": (C.c_int, [_F32P, C.c_uint32, _F32P, C.c_uint32, C.c_uint32, C.c_uint32, _U32P, C.POINTER(ImageStats)]),
     "prgpu_image_stats_merge": (None, [C.POINTER(ImageStats), C.POINTER(ImageStats)]),
     "prgpu_tonemap": (C.c_int, [C.c_uint32, C.c_float, _F32P, _F32P, _F32P, C.c_uint32, C.c_size_t]),

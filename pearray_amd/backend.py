@@ -123,6 +123,16 @@ class RenderContext:
         abi.check(self.lib.prgpu_download_variance(self._h, _f32p(mean), _f32p(var)))
         return mean.reshape(self.height, self.width, 3), var.reshape(self.height, self.width, 3)
 
+    def enableLPE(self, expressions):
+        """Light path expressions (LightPathExpression.h): one extra spectral plane per expression; enable before the first iteration."""
+        arr = (C.c_char_p * max(1, len(expressions)))(*[e.encode() for e in expressions])
+        abi.check(self.lib.prgpu_enable_lpe(self._h, len(expressions), arr))
+
+    def lpe(self, index):
+        out = np.empty(self.width * self.height * 3, dtype=np.float32)
+        abi.check(self.lib.prgpu_download_lpe(self._h, int(index), _f32p(out)))
+        return out.reshape(self.height, self.width, 3)
+
     def pathCost(self):
         """Path vertices traced per pixel so far (persistent pipeline; scheduling statistic)."""
         out = np.empty(self.width * self.height, dtype=np.uint32)
@@ -290,3 +300,13 @@ def image_stats_report(st):
                 ("SNRRef", "%g [%g dB]" % (snr_ref, db(snr_ref))), ("SNRDiff", "%g [%g dB]" % (snr_diff, db(snr_diff))), ("SNT", float(snt)),
                 ("Variance", float(var)), ("VarianceRef", float(var_ref)), ("VarianceDiff", float(var_diff)), ("StdDev", float(np.sqrt(var))),
                 ("StdDevRef", float(np.sqrt(var_ref))), ("StdDevDiff", float(np.sqrt(var_diff)))]
+
+
+def lpe_match(expression, symbols):
+    """LightPathExpression::match on explicit tokens (symbol = scattering type * 3 + event); raises on an invalid expression."""
+    lib = abi.load()
+    arr = (C.c_uint8 * max(1, len(symbols)))(*symbols)
+    rc = lib.prgpu_lpe_match(expression.encode(), arr, len(symbols))
+    if rc < 0:
+        abi.check(rc)
+    return rc == 1

@@ -70,7 +70,7 @@ struct DevEntity {
 };
 
 constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u, FEAT_SHAPE_LIGHTS = 32u, FEAT_TEXTURES = 64u,
-				   FEAT_ROUGH_MATERIALS = 128u, FEAT_ALL = 255u;
+				   FEAT_ROUGH_MATERIALS = 128u, FEAT_LPE = 256u, FEAT_ALL = 511u;
 
 // Area-light data of an analytic entity (one per entity, meaningful for emissive planes and spheres):
 // PlaneEntity::cache (plane.cpp:227-243) and SphereEntity (sphere.cpp:23-31,106-118)
@@ -213,6 +213,7 @@ struct PathState {
 	// shading-point AOV sums (LocalFrameOutputDevice::commitShadingPoints), null when disabled; index = PRGPU_AOV_*
 	float* online_mean;		// AOV_OnlineMean / AOV_OnlineVariance (W*H*3 each), null unless enabled: Welford update per pixel and iteration
 	float* online_variance; // (VarianceEstimator.inl:15-27) at the point where the iteration's value folds into the running mean
+	const struct DevLpe* lpe;			// light path expressions (prgpu_enable_lpe), or null: ONE pointer, so that kernels without them carry no extra arguments
 	uint32_t* cost;			// persistent pipeline: path vertices traced per pixel so far (scheduling statistic, see prgpu_path_cost), or null
 	float* aov[PRGPU_AOV_COUNT];
 	uint32_t aov_mask;
@@ -1249,6 +1250,40 @@ static __device__ __noinline__ void sphere_light_sample(const DevShapeLight& P, 
 __device__ __forceinline__ bool still_reachable(const RayPre& r, float tentry, float limit)
 {
 	return tentry <= limit * 1.000001f + r.eps_t;
+}
+
+// ---- light path expressions: the automaton states of a path, advanced token by token (LPE_Automaton.h:17-33) ----
+constexpr uint32_t LPE_STATES = PRGPU_LPE_MAX_STATES, LPE_TABLE_BYTES = LPE_STATES * 15u + LPE_STATES;
+constexpr uint32_t LPE_SYM_CAMERA = 0u * 3u + 2u, LPE_SYM_EMISSIVE = 1u * 3u + 2u, LPE_SYM_BACKGROUND = 4u * 3u + 2u; // <type, event None>
+constexpr uint32_t LPE_SYM_DIFFUSE_REFLECTION = 3u * 3u + 0u, LPE_SYM_SPECULAR_REFLECTION = 3u * 3u + 1u, LPE_SYM_DIFFUSE_TRANSMISSION = 2u * 3u + 0u,
+				   LPE_SYM_SPECULAR_TRANSMISSION = 2u * 3u + 1u; // LightPathToken(MaterialScatteringType) (LightPathToken.h:45-66)
+struct DevLpe { // lives in device memory (PathState::lpe)
+	uint32_t n;					  // expressions
+	uint32_t* state;			  // per slot: the automaton state of each expression after the path's tokens so far (one byte each)
+	float* iter[PRGPU_LPE_MAX];	  // per expression: this sample's matching fragments (like iter_xyz) ...
+	float* out[PRGPU_LPE_MAX];	  // ... and their running mean over the iterations (like out_xyz)
+	uint8_t tables[PRGPU_LPE_MAX * LPE_TABLE_BYTES]; // per expression next[state * 15 + symbol] (0xFF: the path can no longer match), then accepting[state];
+													 // symbol = scattering type * 3 + event (LightPathToken.h:6-20)
+};
+__device__ __forceinline__ uint32_t lpe_step(const DevLpe& L, uint32_t packed, uint32_t symbol)
+{
+	uint32_t out = 0;
+	for (uint32_t k = 0; k < L.n; ++k) {
+		const uint32_t st = (packed >> (8u * k)) & 0xFFu;
+		const uint32_t nx = st == 0xFFu ? 0xFFu : (uint32_t)L.tables[k * LPE_TABLE_BYTES + st * 15u + symbol];
+		out |= nx << (8u * k);
+	}
+	return out;
+}
+__device__ __forceinline__ uint32_t lpe_accepting(const DevLpe& L, uint32_t packed) // bit k: expression k matches the path as it stands
+{
+	uint32_t mask = 0;
+	for (uint32_t k = 0; k < L.n; ++k) {
+		const uint32_t st = (packed >> (8u * k)) & 0xFFu;
+		if (st != 0xFFu && L.tables[k * LPE_TABLE_BYTES + LPE_STATES * 15u + st])
+			mask |= 1u << k;
+	}
+	return mask;
 }
 
 } // namespace prd

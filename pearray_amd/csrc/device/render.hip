@@ -8,7 +8,7 @@
 //
 // No MFMA: no stage is a dense contraction.  The kernels are latency/bandwidth bound on BVH-node and
 // triangle fetches (64-byte inner and 128-byte leaf records, see DESIGN.md for the bytes-per-ray model).
-// This file is compiled seventeen times (Makefile: -DPR_TU=0..4, -DPR_SUB=0..3) so that the large kernels build in parallel: translation
+// This file is compiled twenty-one times (Makefile: -DPR_TU=0..5, -DPR_SUB=0..3) so that the large kernels build in parallel: translation
 // unit 0 holds the wavefront (lockstep / streaming) kernels, the ray service and the launchers; units (v, s) hold ONE instantiation of the
 // persistent path kernel each (launch_pp_<v>_<s>).  The device functions above the kernels are shared source, not shared objects.
 #ifndef PR_TU
@@ -566,7 +566,9 @@ __device__ __forceinline__ size_t iter_entry(const PathState& ps, uint32_t slot,
 {
 	return (ps.plane_stride ? size_t(ps.iter[slot] - ps.iter_base) * ps.plane_stride : size_t(0)) + size_t(3) * pixel;
 }
-__device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pixel, size_t entry, uint32_t fb, const float xyz[3])
+// lpe_mask: the light path expressions the fragment's path matches (LocalFrameOutputDevice.cpp:99-113: main channel always, every
+// matching expression's plane in addition)
+__device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pixel, size_t entry, uint32_t fb, const float xyz[3], uint32_t lpe_mask = 0u)
 {
 	if (fb) {
 		ps.feedback[pixel] |= fb;
@@ -574,12 +576,19 @@ __device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pix
 		ps.iter_xyz[entry + 0] += xyz[0];
 		ps.iter_xyz[entry + 1] += xyz[1];
 		ps.iter_xyz[entry + 2] += xyz[2];
+		for (uint32_t k = 0; lpe_mask != 0u && k < PRGPU_LPE_MAX; ++k)
+			if (lpe_mask & (1u << k)) {
+				float* plane = ps.lpe->iter[k];
+				plane[3 * pixel + 0] += xyz[0];
+				plane[3 * pixel + 1] += xyz[1];
+				plane[3 * pixel + 2] += xyz[2];
+			}
 	}
 }
 
 // FrameOutputDevice::onEndOfIteration (FrameOutputDevice.cpp:202-221) for one pixel: running mean of the iteration values and, when
 // enabled, the online mean / variance planes (VarianceEstimator::addValue, buffer/VarianceEstimator.inl:15-27; once per pixel and iteration)
-__device__ __forceinline__ void fold_iteration(const PathState& ps, uint32_t pixel, uint32_t iter, const float value[3])
+__device__ __forceinline__ void fold_iteration(const PathState& ps, uint32_t pixel, uint32_t iter, const float value[3], bool with_lpe = false)
 {
 	const float it = (float)(iter + 1), itm1 = (float)iter;
 	for (int c = 0; c < 3; ++c) {
@@ -594,6 +603,13 @@ __device__ __forceinline__ void fold_iteration(const PathState& ps, uint32_t pix
 		}
 		ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + value[c]) / it;
 	}
+	if (with_lpe && ps.lpe) // the expressions' planes average like the main one (persistent kernel variant with FEAT_LPE only)
+		for (uint32_t k = 0; k < ps.lpe->n; ++k) {
+			float* out		  = ps.lpe->out[k];
+			const float* iter_ = ps.lpe->iter[k];
+			for (int c = 0; c < 3; ++c)
+				out[3 * pixel + c] = (out[3 * pixel + c] * itm1 + iter_[3 * pixel + c]) / it;
+		}
 }
 __device__ __forceinline__ float rr_probability(const DevScene& sc, uint32_t L)
 {
@@ -656,7 +672,7 @@ __device__ __forceinline__ float halton(uint32_t index, uint32_t base)
 // Returns false when the camera has no ray for the sample (clipped fisheye, fisheye.cpp:91-94): the sample is counted and its random
 // numbers are spent (RenderTile.cpp:71-131), the slot gets a ray that cannot hit anything and FLAG_NO_RAY, and shade_vertex ends
 // the path without a fragment.
-__device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState& ps, uint32_t slot, uint32_t iter, BlockStats& bs)
+__device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState& ps, uint32_t slot, uint32_t iter, BlockStats& bs, bool with_lpe = false)
 {
 	const prgpu_settings& cfg = sc.cfg;
 	const uint32_t pixel	  = ps.pixel[slot];
@@ -813,6 +829,16 @@ __device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState&
 	if (sc.features & FEAT_SHAPE_LIGHTS)
 		ps.last_pos[slot] = make_float4(0, 0, 0, 0); // TraversalContext::LastPosition starts at the world origin (direct.cpp:55)
 	ps.flags[slot]	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA | (has_ray ? 0u : FLAG_NO_RAY);
+	if (with_lpe && ps.lpe) { // the path starts with its camera token (direct.cpp:67)
+		const DevLpe& L	   = *ps.lpe;
+		L.state[slot]	   = lpe_step(L, 0u, LPE_SYM_CAMERA);
+		for (uint32_t k = 0; k < L.n; ++k) {
+			float* plane		 = L.iter[k];
+			plane[3 * pixel + 0] = 0.0f;
+			plane[3 * pixel + 1] = 0.0f;
+			plane[3 * pixel + 2] = 0.0f;
+		}
+	}
 	{
 		const size_t entry = (ps.plane_stride ? size_t(iter - ps.iter_base) * ps.plane_stride : size_t(0)) + size_t(3) * pixel; // = iter_entry: ps.iter[slot] == iter
 		ps.iter_xyz[entry + 0] = 0.0f;
@@ -1392,6 +1418,23 @@ __device__ __forceinline__ void inf_light_sample(const DevScene& sc, const DevIn
 	}
 }
 
+// The MaterialScatteringType a material reports for the pair (V, L) in tangent space, as a path token symbol: lambert.cpp:41,69 diffuse
+// reflection; conductor.cpp:40,70, mirror.cpp:35,57, roughconductor.cpp:44,108 specular reflection; dielectric.cpp:79-107 and
+// roughdielectric.cpp:198-252 specular reflection / transmission by hemisphere; principled.cpp:511-521,565-575 by hemisphere and
+// roughness < 0.5.
+__device__ __forceinline__ uint32_t scatter_symbol(const prgpu_material& m, V3 Vt, V3 Lt)
+{
+	const bool same = sv_same_hemisphere(Vt, Lt);
+	switch (m.kind) {
+	case PRGPU_MAT_LAMBERT: return LPE_SYM_DIFFUSE_REFLECTION;
+	case PRGPU_MAT_DIELECTRIC:
+	case PRGPU_MAT_ROUGH_DIELECTRIC: return same ? LPE_SYM_SPECULAR_REFLECTION : LPE_SYM_SPECULAR_TRANSMISSION;
+	case PRGPU_MAT_PRINCIPLED:
+		return m.roughness_x < 0.5f ? (same ? LPE_SYM_SPECULAR_REFLECTION : LPE_SYM_SPECULAR_TRANSMISSION) : (same ? LPE_SYM_DIFFUSE_REFLECTION : LPE_SYM_DIFFUSE_TRANSMISSION);
+	default: return LPE_SYM_SPECULAR_REFLECTION; // conductor, mirror, rough conductor
+	}
+}
+
 template <uint32_t FEATS>
 __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState& ps, uint32_t slot, BlockStats& bs, bool& alive, bool& want_shadow,
 											 float4& sh_o, float4& sh_d, float4& sh_xyz)
@@ -1424,6 +1467,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	const float blend	 = 1.0f;
 	const bool power_mis = cfg.mis == PRGPU_MIS_POWER;
 	const Blob hf		 = mono ? hero_only() : blob(1.0f);
+	const bool with_lpe	 = (FEATS & FEAT_LPE) && ps.lpe != nullptr;
+	uint32_t lpe		 = with_lpe ? ps.lpe->state[slot] : 0u; // automaton states after the path's tokens so far
 
 	if (depth == 0) {
 		ps.prim_entity[pixel] = tri == INVALID ? INVALID : sc.tri_entity[tri];
@@ -1433,6 +1478,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
 		float xyz[3];
 		uint32_t fb;
+		const uint32_t m_bg = with_lpe ? lpe_accepting(*ps.lpe, lpe_step(*ps.lpe, lpe, LPE_SYM_BACKGROUND)) : 0u; // ... B (direct.cpp:125, LightPath::createCB)
 		if (depth == 0) { // IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53): one fragment per non-delta infinite light
 			atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
 			bool illuminated = false;
@@ -1445,11 +1491,11 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				float dir_pdf;
 				inf_light_eval(sc, il, ray_d, wl, true, radiance, dir_pdf);
 				fb = fragment_value(sc, blob(1), blob(1), grp_imp, radiance, mono, cie, blend, xyz);
-				apply_fragment(ps, pixel, entry, fb, xyz);
+				apply_fragment(ps, pixel, entry, fb, xyz, m_bg);
 			}
 			if (!illuminated) {
 				fb = fragment_value(sc, blob(1), blob(1), grp_imp, blob(0), mono, cie, blend, xyz);
-				apply_fragment(ps, pixel, entry, fb, xyz);
+				apply_fragment(ps, pixel, entry, fb, xyz, m_bg);
 			}
 		} else if ((FEATS & FEAT_INFINITE_LIGHTS) && sc.n_inf_lights && cfg.direct) {
 			// ---- handleInfLights (direct.cpp:415-456)
@@ -1477,10 +1523,10 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				const Blob mis	  = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
 				fb				  = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
 			}
-			apply_fragment(ps, pixel, entry, fb, xyz);
+			apply_fragment(ps, pixel, entry, fb, xyz, m_bg);
 		} else {
 			fb = fragment_value(sc, hf / (wvl_pdf * bsum(hf)), throughput, grp_imp, blob(0), mono, cie, blend, xyz);
-			apply_fragment(ps, pixel, entry, fb, xyz);
+			apply_fragment(ps, pixel, entry, fb, xyz, m_bg);
 		}
 	} else {
 		const V3 P = ray_o + ray_d * hit4.x;
@@ -1549,7 +1595,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const Blob mis		 = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
 					fb					 = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
 				}
-				apply_fragment(ps, pixel, entry, fb, xyz);
+				apply_fragment(ps, pixel, entry, fb, xyz, with_lpe ? lpe_accepting(*ps.lpe, lpe_step(*ps.lpe, lpe, LPE_SYM_EMISSIVE)) : 0u); // ... E (direct.cpp:387,409)
 			}
 			if (!cfg.emissive_scatter)
 				go_on = false;
@@ -1648,7 +1694,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 							want_shadow = true;
 							sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
 							sh_d		= make_float4(L.x, L.y, L.z, INFINITY); // distance = PR_INF (direct.cpp:329)
-							sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8)));
+							const uint32_t m_nee = with_lpe ? lpe_accepting(*ps.lpe, lpe_step(*ps.lpe, lpe_step(*ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)), LPE_SYM_BACKGROUND)) : 0u; // direct.cpp:338-342
+							sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8) | (m_nee << 16)));
 						} else {
 							apply_fragment(ps, pixel, entry, fb_occ, xyz_occ);
 						}
@@ -1749,7 +1796,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						want_shadow = true;
 						sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
 						sh_d		= make_float4(L.x, L.y, L.z, distance);
-						sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8)));
+						const uint32_t m_nee = with_lpe ? lpe_accepting(*ps.lpe, lpe_step(*ps.lpe, lpe_step(*ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)), LPE_SYM_EMISSIVE)) : 0u; // direct.cpp:338-345
+						sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8) | (m_nee << 16)));
 					} else {
 						apply_fragment(ps, pixel, entry, fb_occ, xyz_occ);
 					}
@@ -1822,6 +1870,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						Lt = -Lt;
 				}
 				const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt));
+				if (with_lpe)
+					lpe = lpe_step(*ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)); // mCameraPath.addToken(sout.Type) (direct.cpp:197)
 				flags	 = sampleDelta ? (flags | FLAG_LAST_DELTA) : (flags & ~FLAG_LAST_DELTA);
 				prev_pdf = path_pdf;
 				path_pdf = path_pdf * (pdf_s * scatProb);
@@ -1852,6 +1902,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						if ((FEATS & FEAT_SHAPE_LIGHTS) && (sc.features & FEAT_SHAPE_LIGHTS))
 							ps.last_pos[slot] = make_float4(P.x, P.y, P.z, 0.0f); // current.LastPosition (direct.cpp:175)
 						ps.flags[slot]		= (flags & ~0xFFu) | nd;
+						if (with_lpe)
+							ps.lpe->state[slot] = lpe;
 						atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
 						atomicAdd(&bs.v[PRGPU_STAT_BOUNCE_RAYS], 1u);
 						if (flags & FLAG_MONO)
@@ -1883,7 +1935,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 	if (i < n_active) {
 		slot = active ? active[i] : slot_base + i;
 		if (sc.features)
-			shade_vertex<FEAT_ALL>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+			shade_vertex<(FEAT_ALL & ~FEAT_LPE)>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz); // light path expressions run in the persistent pipeline only
 		else
 			shade_vertex<0u>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 	}
@@ -2381,7 +2433,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						if (!ps.plane_stride) { // single-tap filter: the sample folds into the running mean right here; with a ring of
 												// planes the launch only fills the planes and k_resolve gathers the taps afterwards
 							const float v[3] = { ps.iter_xyz[3 * pixel], ps.iter_xyz[3 * pixel + 1], ps.iter_xyz[3 * pixel + 2] };
-							fold_iteration(ps, pixel, iter, v);
+							fold_iteration(ps, pixel, iter, v, (FEATS & FEAT_LPE) != 0u);
 						}
 						if (iter + 1 < a.iter_end) {
 							need_pixel = false;
@@ -2410,7 +2462,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				}
 				if (ended && !retired) {
 					ps.iter[slot] = iter;
-					camera_path(sc, ps, slot, iter, sh.bs);
+					camera_path(sc, ps, slot, iter, sh.bs, (FEATS & FEAT_LPE) != 0u);
 					alive = true;
 				}
 				const int n_retired = __popcll(__ballot(retired));
@@ -2632,7 +2684,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 								ps.feedback[pixel] |= fb;
 						} else {
 							const float xyz[3] = { x.x, x.y, x.z };
-							apply_fragment(ps, pixel, entry, fbs & 0xFFu, xyz);
+							apply_fragment(ps, pixel, entry, fbs & 0xFFu, xyz, (FEATS & FEAT_LPE) ? (fbs >> 16) & 0xFu : 0u);
 						}
 					} else {
 						ps.hit[slot] = make_float4(s.best.t, s.best.u, s.best.v, __uint_as_float(s.best.tri));
@@ -3012,10 +3064,10 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 #endif // PR_TU == 0
 
 // ---- persistent path kernel: one translation unit per kernel (feature-mask variant x {3, 2 waves per SIMD} x {plain, instrumented}) ----
-[[maybe_unused]] constexpr uint32_t FEAT_NO_ROUGH = FEAT_ALL & ~FEAT_ROUGH_MATERIALS;
+[[maybe_unused]] constexpr uint32_t FEAT_NO_LPE = FEAT_ALL & ~FEAT_LPE, FEAT_NO_ROUGH = FEAT_NO_LPE & ~FEAT_ROUGH_MATERIALS;
 #define PR_PP_DECL(V, S) void launch_pp_##V##_##S(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st);
 #define PR_PP_DECL4(V) PR_PP_DECL(V, 0) PR_PP_DECL(V, 1) PR_PP_DECL(V, 2) PR_PP_DECL(V, 3)
-PR_PP_DECL4(1) PR_PP_DECL4(2) PR_PP_DECL4(3) PR_PP_DECL4(4)
+PR_PP_DECL4(1) PR_PP_DECL4(2) PR_PP_DECL4(3) PR_PP_DECL4(4) PR_PP_DECL4(5)
 #if PR_TU >= 1
 #ifndef PR_SUB
 #error "compile the persistent-kernel units with -DPR_SUB=0..3"
@@ -3026,8 +3078,10 @@ PR_PP_DECL4(1) PR_PP_DECL4(2) PR_PP_DECL4(3) PR_PP_DECL4(4)
 #define PR_PP_FEATS FEAT_DELTA_MATERIALS
 #elif PR_TU == 3
 #define PR_PP_FEATS FEAT_NO_ROUGH
+#elif PR_TU == 4
+#define PR_PP_FEATS FEAT_NO_LPE
 #else
-#define PR_PP_FEATS FEAT_ALL
+#define PR_PP_FEATS FEAT_ALL // + light path expressions: their state tracking costs the all-features kernel 7 % (C5 135 -> 125 Msamples/s), so it is its own variant
 #endif
 #define PR_PP_CAT2(V, S) launch_pp_##V##_##S
 #define PR_PP_CAT(V, S) PR_PP_CAT2(V, S)
@@ -3103,9 +3157,11 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	// out spheres, AOVs + textures or infinite / shape lights + planes instead changes nothing).  A variant for delta + rough materials
 	// only was measured and dropped: the closures dominate such scenes, 156 vs 154 Msamples/s.
 	typedef void (*LaunchFn)(const DevScene&, const PathState&, const PersistentArgs&, dim3, hipStream_t);
-	static const LaunchFn table[4][4] = { { launch_pp_1_0, launch_pp_1_1, launch_pp_1_2, launch_pp_1_3 }, { launch_pp_2_0, launch_pp_2_1, launch_pp_2_2, launch_pp_2_3 },
-										   { launch_pp_3_0, launch_pp_3_1, launch_pp_3_2, launch_pp_3_3 }, { launch_pp_4_0, launch_pp_4_1, launch_pp_4_2, launch_pp_4_3 } };
-	const int variant = sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3));
+	static const LaunchFn table[5][4] = { { launch_pp_1_0, launch_pp_1_1, launch_pp_1_2, launch_pp_1_3 }, { launch_pp_2_0, launch_pp_2_1, launch_pp_2_2, launch_pp_2_3 },
+										   { launch_pp_3_0, launch_pp_3_1, launch_pp_3_2, launch_pp_3_3 }, { launch_pp_4_0, launch_pp_4_1, launch_pp_4_2, launch_pp_4_3 },
+										   { launch_pp_5_0, launch_pp_5_1, launch_pp_5_2, launch_pp_5_3 } };
+	const int variant = (sc.features & FEAT_LPE) ? 4
+						: (sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3)));
 	table[variant][(occupancy >= 3 ? 0 : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
 }
 

@@ -155,6 +155,18 @@ int prgpu_tonemap(uint32_t mode, float scale, const float* xyz, const float* wei
 	return PRGPU_OK;
 }
 
+// the distinct light path expressions of a channel list, in order of first appearance (their plane indices)
+static std::vector<std::string> distinct_lpe(const prgpu_output_channel* ch, uint32_t n)
+{
+	std::vector<std::string> out;
+	for (uint32_t i = 0; i < n; ++i) {
+		const std::string e(ch[i].lpe, strnlen(ch[i].lpe, sizeof(ch[i].lpe)));
+		if (!e.empty() && ch[i].kind == PRGPU_CHANNEL_SPECTRAL && ch[i].variable == PRGPU_SPECTRAL_OUTPUT && std::find(out.begin(), out.end(), e) == out.end())
+			out.push_back(e);
+	}
+	return out;
+}
+
 int prgpu_outputs_enable(prgpu_scene* s, const prgpu_output_channel* ch, uint32_t n)
 {
 	using prgpu_host::set_last_error;
@@ -162,6 +174,17 @@ int prgpu_outputs_enable(prgpu_scene* s, const prgpu_output_channel* ch, uint32_
 		return set_last_error(PRGPU_EINVAL, "null argument");
 	uint32_t aovs = 0;
 	bool variance = false;
+	{
+		const std::vector<std::string> lpe = distinct_lpe(ch, n);
+		if (!lpe.empty()) {
+			std::vector<const char*> ptr;
+			for (const std::string& e : lpe)
+				ptr.push_back(e.c_str());
+			const int rc = prgpu_enable_lpe(s, (uint32_t)ptr.size(), ptr.data());
+			if (rc != PRGPU_OK)
+				return rc;
+		}
+	}
 	for (uint32_t i = 0; i < n; ++i) {
 		if (ch[i].kind == PRGPU_CHANNEL_3D || ch[i].kind == PRGPU_CHANNEL_1D) {
 			if (ch[i].variable >= PRGPU_AOV_COUNT || prgpu_aov_channels(ch[i].variable) != (ch[i].kind == PRGPU_CHANNEL_3D ? 3u : 1u))
@@ -203,6 +226,7 @@ int prgpu_outputs_save(prgpu_scene* s, const prgpu_output_channel* ch, uint32_t 
 		sample_factor[i] = samples[i] == 0 ? 1.0f : 1.0f / samples[i];
 	std::vector<std::vector<float>> planes; // one per EXR channel
 	std::vector<std::string> names;
+	const std::vector<std::string> lpe = distinct_lpe(ch, n);
 	// ImageWriter writes the spectral channels first, then 3D, 1D and counters (ImageWriter.cpp:79-103,131-247)
 	for (uint32_t pass = 0; pass < 4; ++pass) {
 		const uint32_t want = pass == 0 ? PRGPU_CHANNEL_SPECTRAL : (pass == 1 ? PRGPU_CHANNEL_3D : (pass == 2 ? PRGPU_CHANNEL_1D : PRGPU_CHANNEL_COUNTER));
@@ -213,7 +237,13 @@ int prgpu_outputs_save(prgpu_scene* s, const prgpu_output_channel* ch, uint32_t 
 			const std::string base(c.name, strnlen(c.name, sizeof(c.name)));
 			if (c.kind == PRGPU_CHANNEL_SPECTRAL) {
 				std::vector<float> rgb(np * 3, 0.0f);
-				if (c.variable == PRGPU_SPECTRAL_OUTPUT) {
+				const std::string expr(c.lpe, strnlen(c.lpe, sizeof(c.lpe)));
+				if (c.variable == PRGPU_SPECTRAL_OUTPUT && !expr.empty()) { // the fragments whose light path matches (LocalFrameOutputDevice.cpp:106-112)
+					std::vector<float> plane(np * 3);
+					rc = prgpu_download_lpe(s, (uint32_t)(std::find(lpe.begin(), lpe.end(), expr) - lpe.begin()), plane.data());
+					if (rc == PRGPU_OK)
+						rc = prgpu_tonemap(c.tone, 1.0f, plane.data(), nullptr, rgb.data(), 3, np);
+				} else if (c.variable == PRGPU_SPECTRAL_OUTPUT) {
 					rc = prgpu_tonemap(c.tone, 1.0f, xyz.data(), nullptr, rgb.data(), 3, np);
 				} else { // raw planes (IsRaw, OutputSpecification.cpp:298-301)
 					std::vector<float> mean(np * 3), var(np * 3);

@@ -644,10 +644,16 @@ struct Loader {
 			if (!ty || ty->type != Value::STRING)
 				continue;
 			const std::string type = lower(ty->s);
+			std::string lpe;
 			if (const Value* l = c.get("lpe"))
 				if (l->type == Value::STRING && !l->s.empty()) {
-					warn(where(c) + ": light path expression channels are not provided (skipped)");
-					continue;
+					std::vector<uint8_t> next, accepting;
+					std::string lerr;
+					if (prgpu_host::compile_lpe(l->s, next, accepting, lerr) != PRGPU_OK || l->s.size() >= sizeof(prgpu_output_channel::lpe)) {
+						warn(where(c) + ": invalid or unsupported light path expression '" + l->s + "' (" + lerr + "); the channel is written without it, as in the reference"); // OutputSpecification.cpp:299-302
+					} else {
+						lpe = l->s;
+					}
 				}
 			if (type == "texture" || type == "uvw" || type == "uv" || type == "tex" || type == "displace_id" || type == "displace") {
 				warn(where(c) + ": the '" + type + "' AOV is not provided (skipped)");
@@ -677,7 +683,19 @@ struct Loader {
 			else if (color == "lum" || color == "luminance" || color == "gray")
 				ch.tone = PRGPU_TONE_LUMINANCE;
 			// the colour channel keeps an empty name (R, G, B); every other channel is named after its variable
-			const std::string name = (found->kind == PRGPU_CHANNEL_SPECTRAL && found->variable == PRGPU_SPECTRAL_OUTPUT) ? std::string() : canonical(found->kind, found->variable);
+			std::string name = (found->kind == PRGPU_CHANNEL_SPECTRAL && found->variable == PRGPU_SPECTRAL_OUTPUT) ? std::string() : canonical(found->kind, found->variable);
+			if (!lpe.empty()) {
+				if (!(found->kind == PRGPU_CHANNEL_SPECTRAL && found->variable == PRGPU_SPECTRAL_OUTPUT)) {
+					warn(where(c) + ": light path expressions are provided for colour channels only (channel skipped)");
+					continue;
+				}
+				name += "[" + lpe + "]"; // OutputSpecification.cpp:323-324
+				std::strncpy(ch.lpe, lpe.c_str(), sizeof(ch.lpe) - 1);
+			}
+			if (name.size() >= sizeof(ch.name)) {
+				warn(where(c) + ": channel name too long (skipped)");
+				continue;
+			}
 			std::strncpy(ch.name, name.c_str(), sizeof(ch.name) - 1);
 			out.outputs.push_back(ch);
 		}

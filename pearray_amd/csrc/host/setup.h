@@ -46,4 +46,6 @@ int build_tables(const prgpu_scene_desc* d, HostTables& t, std::string& err);
 // Morton-ordered list of the owned pixels (StreamPipeline.cpp:83-133 walks each tile in Morton order)
 void owned_pixels_morton(uint32_t W, uint32_t H, const prgpu_tile* tiles, uint32_t n_tiles, std::vector<uint32_t>& pixels);
 
+// lpe.cpp: light path expression -> DFA (next[state * 15 + type * 3 + event] = state or 0xFF, accepting[state]; state 0 starts)
+int compile_lpe(const std::string& expr, std::vector<uint8_t>& next, std::vector<uint8_t>& accepting, std::string& err);
 } // namespace prgpu_host

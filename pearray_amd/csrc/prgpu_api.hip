@@ -102,6 +102,7 @@ struct prgpu_scene {
 	uint64_t family_launches[N_FAMILIES] = { 0 };
 	uint64_t rays_closest = 0, rays_any = 0;
 	uint32_t next_iteration = 0;
+	prd::DevLpe lpe_host{}; // host copy of the light path expression block (plane pointers for downloads and the reduce)
 	uint32_t order_tuned_at = 0; // iteration count the pixel order was last tuned at (tune_pixel_order)
 	bool poisoned = false; // a device-side error was reported: further render calls are refused
 	uint64_t pp_launch_samples = 128ull << 20; // persistent mode: camera samples per launch (render calls are cut into bounded launches)
@@ -1522,6 +1523,8 @@ int prgpu_reduce(prgpu_scene* s, prgpu_comm* c, int root)
 	for (uint32_t k = 0; k < PRGPU_AOV_COUNT; ++k) // shading-point AOV sums: plain sums of the owner's samples
 		if (s->ps.aov[k])
 			NCCL_TRY(r.Reduce(s->ps.aov[k], s->ps.aov[k], size_t(s->n_pixels) * prgpu_aov_channels(k), NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+	for (uint32_t k = 0; k < s->lpe_host.n; ++k) // light path expression planes: folded sums of the owner's matching fragments, zero elsewhere
+		NCCL_TRY(r.Reduce(s->lpe_host.out[k], s->lpe_host.out[k], size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
 	NCCL_TRY(r.GroupEnd());
 	return PRGPU_OK;
 }
@@ -1590,6 +1593,103 @@ int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance)
 		HIP_TRY(hipMemcpy(mean, s->ps.online_mean, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
 	if (variance)
 		HIP_TRY(hipMemcpy(variance, s->ps.online_variance, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
+	return PRGPU_OK;
+}
+
+int prgpu_lpe_check(const char* expression)
+{
+	if (!expression)
+		return fail(PRGPU_EINVAL, "null expression");
+	std::vector<uint8_t> next, accepting;
+	std::string err;
+	const int rc = prgpu_host::compile_lpe(expression, next, accepting, err);
+	return rc == PRGPU_OK ? PRGPU_OK : fail(rc, err);
+}
+
+int prgpu_lpe_match(const char* expression, const uint8_t* symbols, uint32_t count)
+{
+	if (!expression || (count && !symbols))
+		return fail(PRGPU_EINVAL, "null argument");
+	std::vector<uint8_t> next, accepting;
+	std::string err;
+	const int rc = prgpu_host::compile_lpe(expression, next, accepting, err);
+	if (rc != PRGPU_OK)
+		return fail(rc, err);
+	uint32_t state = 0;
+	for (uint32_t i = 0; i < count; ++i) {
+		if (symbols[i] >= 15)
+			return fail(PRGPU_EINVAL, "token symbol out of range");
+		state = next[state * 15u + symbols[i]];
+		if (state == 0xFFu)
+			return 0;
+	}
+	return accepting[state] ? 1 : 0;
+}
+
+int prgpu_enable_lpe(prgpu_scene* s, uint32_t n, const char* const* expressions)
+{
+	if (!s || (n && !expressions))
+		return fail(PRGPU_EINVAL, "null argument");
+	if (s->next_iteration != 0)
+		return fail(PRGPU_EINVAL, "light path expressions must be enabled before the first iteration");
+	if (n > PRGPU_LPE_MAX)
+		return fail(PRGPU_EUNSUPPORTED, "at most " + std::to_string(PRGPU_LPE_MAX) + " light path expressions");
+	if (s->ps.lpe)
+		return fail(PRGPU_EINVAL, "light path expressions are already enabled");
+	if (!n)
+		return PRGPU_OK;
+	if (!s->sc.single_tap)
+		return fail(PRGPU_EUNSUPPORTED, "light path expressions need a single-tap pixel filter (block or radius 0)");
+	HIP_TRY(hipSetDevice(s->device));
+	prd::DevLpe host;
+	std::memset(&host, 0, sizeof(host));
+	std::memset(host.tables, 0xFF, sizeof(host.tables));
+	host.n = n;
+	for (uint32_t k = 0; k < n; ++k) {
+		if (!expressions[k])
+			return fail(PRGPU_EINVAL, "null expression");
+		std::vector<uint8_t> next, accepting;
+		std::string err;
+		const int rc = prgpu_host::compile_lpe(expressions[k], next, accepting, err);
+		if (rc != PRGPU_OK)
+			return fail(rc, "'" + std::string(expressions[k]) + "': " + err);
+		uint8_t* table = host.tables + size_t(k) * prd::LPE_TABLE_BYTES;
+		std::copy(next.begin(), next.end(), table);
+		std::fill(table + prd::LPE_STATES * 15u, table + prd::LPE_TABLE_BYTES, 0);
+		std::copy(accepting.begin(), accepting.end(), table + prd::LPE_STATES * 15u);
+	}
+	const size_t ns = size_t(s->n_pixels) + prd::persistent_slot_padding();
+	int rc			= s->alloc(host.state, ns, true);
+	for (uint32_t k = 0; k < n && rc == PRGPU_OK; ++k) {
+		rc = s->alloc(host.iter[k], size_t(s->n_pixels) * 3, true);
+		if (rc == PRGPU_OK)
+			rc = s->alloc(host.out[k], size_t(s->n_pixels) * 3, true);
+	}
+	prd::DevLpe* dev = nullptr;
+	if (rc == PRGPU_OK)
+		rc = s->alloc(dev, 1, false);
+	if (rc != PRGPU_OK)
+		return rc;
+	HIP_TRY(hipMemcpy(dev, &host, sizeof(host), hipMemcpyHostToDevice));
+	s->lpe_host = host;
+	s->ps.lpe	= dev;
+	for (auto& g : s->groups)
+		g.ps.lpe = dev;
+	s->sc.features |= prd::FEAT_LPE;
+	s->mode = prgpu_scene::PERSISTENT; // the planes are folded per pixel by the persistent kernel
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	return PRGPU_OK;
+}
+
+int prgpu_download_lpe(prgpu_scene* s, uint32_t index, float* xyz)
+{
+	if (!s || !xyz)
+		return fail(PRGPU_EINVAL, "null argument");
+	if (!s->ps.lpe || index >= s->lpe_host.n)
+		return fail(PRGPU_EINVAL, "no such light path expression");
+	HIP_TRY(hipSetDevice(s->device));
+	HIP_TRY(hipStreamSynchronize(s->stream));
+	HIP_TRY(hipMemcpy(xyz, s->lpe_host.out[index], size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
 	return PRGPU_OK;
 }
 

@@ -127,6 +127,9 @@ def bind(lib):
     lib.orc_uniform_cone.argtypes = [C.c_float, C.c_float, C.c_float, _F32P]
     lib.orc_inf_light_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, C.c_int, _F32P, _F32P]
     lib.orc_inf_light_sample.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, _F32P, _F32P, _F32P, _F32P]
+    lib.orc_enable_lpe.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p)]
+    lib.orc_download_lpe.argtypes = [C.c_void_p, C.c_uint32, _F32P]
+    lib.orc_lpe_match.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_uint32]
     lib.orc_inf_light_power.restype = None
     lib.orc_inf_light_power.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P]
     return lib
@@ -194,6 +197,15 @@ class OracleScene:
             mask |= 1 << abi.AOV_NAMES.index(n)
         self.lib.orc_enable_aovs.argtypes = [C.c_void_p, C.c_uint32]
         self.lib.orc_enable_aovs(self.h, mask)
+
+    def enable_lpe(self, expressions):
+        arr = (C.c_char_p * max(1, len(expressions)))(*[e.encode() for e in expressions])
+        assert self.lib.orc_enable_lpe(self.h, len(expressions), arr) == 0
+
+    def lpe(self, index):
+        out = np.empty(self.width * self.height * 3, np.float32)
+        assert self.lib.orc_download_lpe(self.h, index, _p(out)) == 0
+        return out.reshape(self.height, self.width, 3)
 
     def enable_variance(self):
         self.lib.orc_enable_variance.argtypes = [C.c_void_p]

@@ -1037,3 +1037,67 @@ def test_small_share_scheduling_does_not_change_the_image(monkeypatch):
     assert not cost0.any()     # the statistic is only kept while slot k renders owned[k]
     assert st["pixel_samples"] < cost.sum() <= st["camera_depth"] + st["background_hits"]     # path length of every sample, summed per pixel
     assert (cost > 0).sum() == sum((x1 - x0) * (y1 - y0) for x0, y0, x1, y1 in tiles)
+
+
+def _lpe_both(sc, expressions, iters=None):
+    iters = sc.spp if iters is None else iters
+    g = backend.RenderContext(sc)
+    g.enableLPE(expressions)
+    o = ob.OracleScene(sc)
+    o.enable_lpe(expressions)
+    g.render(iters)
+    g.waitForFinish()
+    o.render(iters, threads=8)
+    return g, o
+
+
+@pytest.mark.parametrize("name", ["cornell", "glass", "rough", "open_sky"])
+def test_light_path_expression_planes_bit_exact(name):
+    """LPE planes (LocalFrameOutputDevice.cpp:99-113): the device tracks one automaton state per expression and path, the checker matches
+    every fragment's explicit token list with a different algorithm -- the planes agree bit for bit, and so does everything else."""
+    kw = dict(filter=abi.FILTER_BLOCK, filter_radius=0)
+    if name == "cornell":
+        sc, exprs = scene.cornell_box(64, 48, spp=6, **kw), ["CE", "CDE", "CDD+E", "C.*L"]
+    elif name == "glass":
+        sc, exprs = scene.cornell_glassy(64, 48, spp=6, **kw), ["C<T,S>+<R,D>E", "C[DS]*<R,S>[DS]*E", "CD*E", "C.*<TS>.*L"]
+    elif name == "rough":
+        sc, exprs = scene.cornell_rough(64, 48, spp=6, roughness=0.3, vndf=True, **kw), ["CS+E", "C(DS)+D?E", "C<.,D>{1,2}L"]
+    else:
+        sc, exprs = _open_scene(("env_split_rot", "sun", "lamp"), glass=True, filter=abi.FILTER_BLOCK, filter_radius=0), ["CB", "C.+B", "C.*E", "C<T.>+.*L"]
+    g, o = _lpe_both(sc, exprs)
+    assert_parity(g, o, exact=True)
+    some = False
+    for k in range(len(exprs)):
+        a, b = g.lpe(k), o.lpe(k)
+        assert np.array_equal(a, b), (name, exprs[k], float(np.abs(a - b).max()))
+        some = some or a.any()
+    assert some
+    if name == "cornell":
+        assert np.array_equal(g.lpe(3), g.output()[0])
+
+
+def test_lpe_rejections_and_resumed_calls():
+    sc = scene.cornell_box(40, 32, spp=8, filter=abi.FILTER_BLOCK, filter_radius=0)
+    g = backend.RenderContext(sc)
+    with pytest.raises(abi.PrgpuError, match="label"):
+        g.enableLPE(['C<R,D,"wall">E'])
+    with pytest.raises(abi.PrgpuError, match="at most"):
+        g.enableLPE(["CE"] * 5)
+    g.enableLPE(["CDE", "CDD+E"])
+    with pytest.raises(abi.PrgpuError, match="already"):
+        g.enableLPE(["CE"])
+    for n in (3, 1, 4):
+        g.render(n)
+    g.waitForFinish()
+    ref = backend.RenderContext(sc)
+    ref.enableLPE(["CDE", "CDD+E"])
+    ref.render(8)
+    ref.waitForFinish()
+    assert np.array_equal(g.lpe(0), ref.lpe(0)) and np.array_equal(g.lpe(1), ref.lpe(1)) and np.array_equal(g.output()[0], ref.output()[0])
+    multi = backend.RenderContext(scene.cornell_box(40, 32, spp=2, filter=abi.FILTER_GAUSSIAN, filter_radius=2))
+    with pytest.raises(abi.PrgpuError, match="single-tap"):
+        multi.enableLPE(["CE"])
+    late = backend.RenderContext(sc)
+    late.render(1)
+    with pytest.raises(abi.PrgpuError, match="before the first iteration"):
+        late.enableLPE(["CE"])

@@ -1,0 +1,112 @@
+"""Light path expressions: the library's automaton (prgpu_lpe_match, host/lpe.cpp) and the checker's direct matcher (orc_lpe_match) against
+the reference's own known-answer tests (src/tests/lpe.cpp:9-137) and against each other on random expressions and paths; the token stream
+of the `direct` integrator in the checker (C, one token per scattering, E / B tails).  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from pearray_amd import _cabi as abi
+from pearray_amd import backend, scene
+
+# symbol = scattering type * 3 + event (LightPathToken.h:6-20)
+CAM = 0 * 3 + 2
+E_D, E_S, E_N = 1 * 3 + 0, 1 * 3 + 1, 1 * 3 + 2     # emissive tokens as the reference tests build them (event Diffuse / Specular) and as `direct` does (None)
+T_D, T_S = 2 * 3 + 0, 2 * 3 + 1                    # refraction
+R_D, R_S = 3 * 3 + 0, 3 * 3 + 1                    # reflection
+BG = 4 * 3 + 2
+
+# src/tests/lpe.cpp: expression -> [(path, expected)]
+GOLDEN = {
+    "CD*L": [([CAM, R_D, E_D], True), ([CAM, E_D], True), ([CAM, R_S, E_D], False)],
+    "C(DS)+D?E": [([CAM, R_D, T_S, E_D], True), ([CAM, R_D, T_S, R_D, T_S, R_D, E_D], True), ([CAM, R_S, E_D], False), ([CAM, R_S, R_D, E_D], False)],
+    "C[DS]+D?B": [([CAM, R_D, T_S, BG], True), ([CAM, R_D, T_S, R_D, R_D, BG], True), ([CAM, E_S, BG], False)],
+    "C(DS+)+.*L": [([CAM, R_D, T_S, BG], True), ([CAM, R_D, T_S, R_D, R_D, BG], True), ([CAM, R_D, T_S, T_S, R_D, T_S, R_D, R_D, BG], True), ([CAM, E_S, BG], False)],
+}
+
+
+def orc_match(expr, path):
+    lib = ob.load()
+    arr = (C.c_uint8 * max(1, len(path)))(*path)
+    return lib.orc_lpe_match(expr.encode(), arr, len(path))
+
+
+@pytest.mark.parametrize("expr", sorted(GOLDEN))
+def test_reference_known_answers(expr):
+    for path, want in GOLDEN[expr]:
+        assert backend.lpe_match(expr, path) is want, (expr, path)
+        assert orc_match(expr, path) == (1 if want else 0), (expr, path)
+
+
+def test_validity_follows_the_reference_grammar():
+    lib = abi.load()
+    for good in ("CD*L", "C(DS)+D?E", "C[DS]+D?B", "C<R,D>*<T.>{2,3}L", "C.{2}E", "C<L.>", "C(D|S)" if False else "C[DS]", "CD{0,2}(S+[EB])"):
+        assert lib.prgpu_lpe_check(good.encode()) == 0, good
+        assert orc_match(good, [CAM]) in (0, 1)
+    for bad in ("RD*L",            # must start at the camera (src/tests/lpe.cpp:35-39)
+                "C", "", "CD**L"[:0] + "C(", "C(D", "C[", "C[^S]+B", "CD{3,1}E", "CX", "C<Q,D>", "C<R,X>", "CD)"):
+        assert lib.prgpu_lpe_check(bad.encode()) == -1, bad
+        assert orc_match(bad, [CAM]) == -1, bad
+    assert lib.prgpu_lpe_check(b'C<R,D,"wall">E') == -4 and b"label" in lib.prgpu_last_error()      # labels live in the host's registry
+    assert lib.prgpu_lpe_check(b"C" + b"(D?S?)" * 24 + b"E") in (0, -4)                                  # large but legal, or beyond 32 states
+    assert lib.prgpu_lpe_check(b"CD{40}E") == -4 and b"states" in lib.prgpu_last_error()
+
+
+def test_automaton_and_direct_matcher_agree_on_random_expressions():
+    """Two independent implementations (subset-construction DFA in the library, end-position sets in the checker) on random input."""
+    rng = np.random.default_rng(11)
+    atoms = ["D", "S", "E", "L", "B", "R", "T", ".", "<R,D>", "<T,S>", "<.,D>", "<L.>", "<E,.>", "<B.>"]
+    ops = ["", "", "", "*", "+", "?", "{2}", "{1,3}", "{0,2}"]
+
+    def term(depth):
+        r = rng.uniform()
+        if depth < 2 and r < 0.2:
+            return "(" + "".join(term(depth + 1) for _ in range(rng.integers(1, 4))) + ")" + ops[rng.integers(len(ops))]
+        if depth < 2 and r < 0.35:
+            return "[" + "".join(term(depth + 1) for _ in range(rng.integers(1, 4))) + "]" + ops[rng.integers(len(ops))]
+        return atoms[rng.integers(len(atoms))] + ops[rng.integers(len(ops))]
+    symbols = [E_N, BG, T_D, T_S, R_D, R_S, E_D]
+    lib = abi.load()
+    n_checked = n_match = 0
+    for _ in range(300):
+        expr = "C" + "".join(term(0) for _ in range(rng.integers(1, 5)))
+        if lib.prgpu_lpe_check(expr.encode()) != 0:
+            continue        # too many states for the table: the checker has no such limit
+        for _ in range(40):
+            path = [CAM] + [symbols[i] for i in rng.integers(0, len(symbols), rng.integers(0, 9))]
+            a, b = backend.lpe_match(expr, path), orc_match(expr, path)
+            assert b == (1 if a else 0), (expr, path, a, b)
+            n_checked += 1
+            n_match += 1 if a else 0
+    assert n_checked > 5000 and 200 < n_match < n_checked - 200
+
+
+def _box(spp=8, **kw):
+    return scene.cornell_box(48, 40, spp=spp, filter=abi.FILTER_BLOCK, filter_radius=0, **kw)
+
+
+def test_lpe_planes_partition_the_image_in_the_checker():
+    """Every fragment of the Cornell box ends on the lamp: direct light (C E | C D E) and everything with more bounces add up to the
+    whole; an expression nothing matches stays black; 'C.*L' is the image itself."""
+    o = ob.OracleScene(_box())
+    o.enable_lpe(["CE", "CDE", "CDD+E", "C.*L"])
+    o.render(8, threads=8)
+    xyz, _, _ = o.output()
+    seen, direct, indirect, everything = (o.lpe(k) for k in range(4))
+    assert np.array_equal(everything, xyz)
+    o2 = ob.OracleScene(_box())
+    o2.enable_lpe(["C.*B", "CS+E"])          # no background light, no specular surface: nothing matches
+    o2.render(2, threads=8)
+    assert not o2.lpe(0).any() and not o2.lpe(1).any() and o2.output()[0].any()
+    assert seen.sum() > 0 and direct.sum() > 0 and indirect.sum() > 0
+    total = seen.astype(np.float64) + direct + indirect
+    assert np.allclose(total, xyz, rtol=1e-5, atol=1e-6)
+    lamp = seen.sum(axis=-1) > 0
+    assert 0 < lamp.sum() < lamp.size * 0.2          # the lamp is seen directly by few pixels only
+
+
+def test_lpe_needs_a_single_tap_filter_and_no_labels_in_the_library():
+    lib = abi.load()
+    arr = (C.c_char_p * 1)(b"CD*L")
+    assert lib.prgpu_enable_lpe(None, 1, arr) == -1
