@@ -1076,6 +1076,34 @@ def test_light_path_expression_planes_bit_exact(name):
         assert np.array_equal(g.lpe(3), g.output()[0])
 
 
+def test_lpe_planes_shard_over_tiles_and_pass_the_reduce(monkeypatch):
+    """The LPE planes of the ranks' tile shares are zero outside the share and add up to the planes of the unsharded frame; prgpu_reduce
+    carries them (a genuine one-rank RCCL communicator: the sum over one rank is the identity)."""
+    W, H, spp, world = 80, 64, 4, 4
+    kw = dict(filter=abi.FILTER_BLOCK, filter_radius=0)
+    exprs = ["CDE", "CD.+E"]
+    whole = backend.RenderContext(scene.cornell_box(W, H, spp=spp, **kw)); whole.enableLPE(exprs); whole.start(); whole.waitForFinish()
+    acc = [np.zeros_like(whole.lpe(0)), np.zeros_like(whole.lpe(0))]
+    monkeypatch.setenv("PRGPU_COMM_FORCE_RCCL", "1")
+    for rank in range(world):
+        g = backend.RenderContext(scene.cornell_box(W, H, spp=spp, **kw)); g.enableLPE(exprs)
+        tiles = tiling.tiles_for_rank(W, H, rank, world, tile=16)
+        g.setTiles(tiles); g.start(); g.waitForFinish()
+        owned = np.zeros((H, W), dtype=bool)
+        for x0, y0, x1, y1 in tiles:
+            owned[y0:y1, x0:x1] = True
+        before = [g.lpe(0), g.lpe(1)]
+        if rank == 0:
+            comm = backend.Communicator(1, 0)
+            g.reduce(comm); g.waitForFinish(); comm.close()
+        for k in range(2):
+            plane = g.lpe(k)
+            assert np.array_equal(plane, before[k]) and not plane[~owned].any()
+            acc[k] += plane
+    for k in range(2):
+        assert np.array_equal(acc[k], whole.lpe(k)) and acc[k].any()
+
+
 def test_lpe_rejections_and_resumed_calls():
     sc = scene.cornell_box(40, 32, spp=8, filter=abi.FILTER_BLOCK, filter_radius=0)
     g = backend.RenderContext(sc)

@@ -127,21 +127,26 @@ def test_output_blocks_are_parsed_like_the_reference():
       (entity :name 'e' :type 'mesh' :mesh 'q' :materials 'm')
       (output :name 'image'
         (channel :type 'color' :color 'srgb') (channel :type 'n') (channel :type 'ng') (channel :type 'feedback')
-        (channel :type 'color' :color 'srgb' :lpe 'CS*DL') (channel :type 'uv'))
+        (channel :type 'color' :color 'srgb' :lpe 'CS*DL') (channel :type 'uv') (channel :type 'color' :lpe 'C((')
+        (channel :type 'n' :lpe 'CDL') (channel :type 'color' :color 'xyz' :lpe 'C<TD"glass">*L'))
       (output :name 'extra' (channel :type 'RGB' :color 'XYZ') (channel :type 'var') (channel :type 'd') (channel :type 'samples') (channel :type 'nope'))
       (output (channel :type 'color')))"""
     s = scene.PrcScene(source=src)
     ch, n = s.outputs()
     got = [(ch[i].file, ch[i].kind, ch[i].variable, ch[i].tone, ch[i].name.decode()) for i in range(n)]
+    assert [ch[i].lpe.decode() for i in range(n)] == ["", "", "", "", "CS*DL"] + [""] * 6
     A = abi.AOV_NAMES.index
     assert got == [(0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, ""), (0, abi.CHANNEL_3D, A("normal"), 0, "normal"), (0, abi.CHANNEL_3D, A("normal_g"), 0, "normal_geometric"),
                    (0, abi.CHANNEL_COUNTER, 1, 0, "feedback"),
+                   (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, "[CS*DL]"),     # OutputSpecification.cpp:323-324
+                   (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, ""),            # an invalid expression is dropped, the channel stays (:299-302)
+                   (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, ""),             # labels are not provided: same treatment
                    (1, abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, ""), (1, abi.CHANNEL_SPECTRAL, 2, 0, "variance"), (1, abi.CHANNEL_1D, A("depth"), 0, "depth"),
                    (1, abi.CHANNEL_COUNTER, 0, 0, "sample_count")]
     lib = abi.load()
     assert lib.prgpu_prc_output_name(s._h, 0) == b"image" and lib.prgpu_prc_output_name(s._h, 1) == b"extra" and lib.prgpu_prc_output_name(s._h, 2) is None
     w = "\n".join(s.warnings)
-    assert "light path expression" in w and "'uv' AOV" in w and "unknown channel type 'nope'" in w and "no name given" in w
+    assert "invalid or unsupported light path expression 'C(('" in w and "colour channels only" in w and "labelled tokens" in w and "'uv' AOV" in w and "unknown channel type 'nope'" in w and "no name given" in w
 
 
 @pytest.mark.gpu
@@ -177,17 +182,27 @@ def test_output_blocks_end_to_end(tmp_path):
       (mesh :name 'quad' (attribute :type 'p' [-1,0,-1],[1,0,-1],[1,0,1],[-1,0,1]) (faces [0,1,2,3]))
       (entity :name 'floor' :type 'mesh' :mesh 'quad' :materials 'white' :scale 2)
       (entity :name 'lamp' :type 'mesh' :mesh 'quad' :materials 'white' :emission 'lamp' :rotation (euler 180 0 0) :position [0,2,0] :scale 0.3)
-      (output :name 'image' (channel :type 'color' :color 'srgb') (channel :type 'n') (channel :type 'feedback') (channel :type 'depth') (channel :type 'variance')))"""
+      (output :name 'image' (channel :type 'color' :color 'srgb') (channel :type 'n') (channel :type 'feedback') (channel :type 'depth') (channel :type 'variance')
+        (channel :type 'color' :color 'xyz' :lpe 'C.*L') (channel :type 'color' :color 'srgb' :lpe 'CDE') (channel :type 'color' :color 'xyz' :lpe 'CE'))
+      (output :name 'direct' (channel :type 'color' :color 'xyz' :lpe 'CDE')))"""
     s = scene.PrcScene(source=src)
     g = backend.RenderContext(s)
     g.enableOutputs(s)
     g.start(); g.waitForFinish()
     paths = g.saveOutputs(s, str(tmp_path))
-    assert [os.path.basename(p) for p in paths] == ["image.exr"]
+    assert [os.path.basename(p) for p in paths] == ["image.exr", "direct.exr"]
     img = read_exr_uncompressed(paths[0])
-    assert sorted(img) == sorted(["R", "G", "B", "variance.R", "variance.G", "variance.B", "normal.x", "normal.y", "normal.z", "depth", "feedback"])
+    lpe_names = ["[%s].%s" % (e, c) for e in ("C.*L", "CDE", "CE") for c in "RGB"]
+    assert sorted(img) == sorted(["R", "G", "B", "variance.R", "variance.G", "variance.B", "normal.x", "normal.y", "normal.z", "depth", "feedback"] + lpe_names)
     xyz, smp, fb = g.output()
     rgb = backend.tonemap(xyz)
+    direct = read_exr_uncompressed(paths[1])
+    assert sorted(direct) == sorted("[CDE]." + c for c in "RGB")              # the three distinct expressions are planes 0, 1, 2 in order of appearance
+    for k, c in enumerate("RGB"):
+        assert np.array_equal(img["[C.*L]." + c], xyz[..., k])               # every light path ('.' = any scattering, LPE_RegState.h:59-60): the frame itself
+        assert np.array_equal(img["[CDE]." + c], backend.tonemap(g.lpe(1))[..., k]) and np.array_equal(direct["[CDE]." + c], g.lpe(1)[..., k])
+        assert np.array_equal(img["[CE]." + c], g.lpe(2)[..., k])
+    assert g.lpe(1)[..., 1].max() > 0 and g.lpe(2)[..., 1].sum() >= 0 and (g.lpe(1)[..., 1] <= xyz[..., 1] + 1e-6).all()
     for k, c in enumerate("RGB"):
         assert np.array_equal(img[c], rgb[..., k])
         assert np.array_equal(img["variance." + c], g.variance()[1][..., k])
