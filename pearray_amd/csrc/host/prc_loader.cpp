@@ -491,6 +491,9 @@ struct Loader {
 		const std::string mis		= lower(get_string(g, "mis", "balance"));
 		settings.mis				= mis == "power" ? PRGPU_MIS_POWER : PRGPU_MIS_BALANCE;
 		settings.emissive_scatter	= get_bool(g, "emissive_scatter", true) ? 1 : 0;
+		settings.nee				= get_bool(g, "nee", true) ? 1 : 0; // direct.cpp:512
+		if (!get_bool(g, "direct", true))					  // direct.cpp:513: hits of emitters would not count and NEE would lose its MIS partner
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": ':direct false' is not supported");
 		have_integrator				= true;
 	}
 	void add_light(const Group& g) // SceneLoader.cpp:558-600, environment.cpp:152-205, distant.cpp:112-121, sun.cpp:250-267, sky.cpp:180-198

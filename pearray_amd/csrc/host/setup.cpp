@@ -874,7 +874,7 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		return bad("unknown sampler / mapper / filter / mis selector");
 	if (!c.aa_samples || !c.lens_samples || !c.time_samples || !c.spectral_samples)
 		return bad("sample counts must be positive");
-	if (!(c.spectral_end > c.spectral_start))
+	if (!(c.spectral_end > c.spectral_start) && !(c.spectral_mono && c.spectral_end == c.spectral_start)) // `:spectral_domain 520` is [520, 520] + mono (SceneLoader.cpp:120-138)
 		return bad("spectral domain is empty");
 	if (!c.spectral_mono && (c.mapper == PRGPU_MAPPER_CIE || c.mapper == PRGPU_MAPPER_CIE_Y) && !(c.spectral_start >= prd::CIE_START && c.spectral_end <= prd::CIE_END))
 		return bad("the cie spectral mapper needs a spectral domain inside the CIE domain (cie.cpp:93-102)");
