@@ -431,9 +431,10 @@ int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance); /* ei
  * over the iterations like it.  A path is the token sequence the `direct` integrator builds (direct.cpp:67,125,197,338-351,387,409):
  * C, one <type, event> token per scattering (the material's MaterialScatteringType), then E (emissive surface) or B (background /
  * infinite light); next-event fragments carry the evaluated scattering type before their E / B.  Grammar and token classes as in
- * LPE_Parser.cpp / LPE_RegState.h: C first, then D S E L B R T . <T,E>, groups ( ), unions [ ], and * + ? {n} {n,m}; labelled tokens
- * (<T,E,"label">: material labels live in the host's registry) and expressions that need more than PRGPU_LPE_MAX_STATES automaton
- * states are PRGPU_EUNSUPPORTED.  Enable before the first iteration; needs a single-tap pixel filter and selects the persistent
+ * LPE_Parser.cpp / LPE_RegState.h: C first, then D S E L B R T . <T,E>, groups ( ), unions [ ], and * + ? {n} {n,m}.  Labelled tokens (<T,E,"label">) are
+ * parsed and match nothing: a labelled token only matches path tokens carrying that label (LPE_Automaton.cpp:92-110) and the `direct`
+ * integrator builds all its tokens with label 0.  Expressions that need more than PRGPU_LPE_MAX_STATES automaton states are
+ * PRGPU_EUNSUPPORTED.  Enable before the first iteration; needs a single-tap pixel filter and selects the persistent
  * pipeline.  prgpu_lpe_check only parses (0 = valid). */
 #define PRGPU_LPE_MAX 4
 #define PRGPU_LPE_MAX_STATES 32

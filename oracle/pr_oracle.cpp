@@ -867,6 +867,7 @@ struct BvhNode {
 struct LpeNode {
 	enum Kind { TOKEN, CONCAT, UNION, REPEAT } kind = TOKEN;
 	char type = '.', event = '.';
+	bool labelled = false;	 // TOKEN with a label: never matches the label-0 tokens of this path
 	uint32_t lo = 1, hi = 1; // REPEAT; hi == 0: unbounded
 	std::vector<LpeNode> kids;
 };
@@ -973,10 +974,20 @@ struct LpeParser {
 			if (!(e == 'D' || e == 'S' || e == '.'))
 				ok = false;
 			++pos;
-			if (cur() == '"' || cur() == ',')
-				ok = false; // labels: not supported
+			bool labelled = false;
+			if (cur() == '"' || cur() == ',') { // LPE_Parser.cpp:233-238
+				if (cur() == ',')
+					++pos;
+				accept('"');
+				while (ok && pos < s.size() && cur() != '"')
+					++pos;
+				accept('"');
+				labelled = true;
+			}
 			accept('>');
-			return op(token(t, e));
+			LpeNode tk = token(t, e);
+			tk.labelled = labelled; // the path tokens of `direct` carry label 0 (LightPathToken.h:38): a labelled token never matches them (LPE_Automaton.cpp:92-110)
+			return op(tk);
 		}
 		ok = false;
 		return LpeNode();
@@ -1004,6 +1015,8 @@ struct LpeParser {
 };
 inline bool lpe_token_matches(const LpeNode& n, uint8_t symbol)
 {
+	if (n.labelled)
+		return false;
 	const int t = symbol / 3, e = symbol % 3; // ScatteringType Camera, Emissive, Refraction, Reflection, Background; ScatteringEvent Diffuse, Specular, None
 	bool mt;
 	switch (n.type) {

@@ -9,7 +9,8 @@
 //     op      := '*' | '+' | '?' | '{' n '}' | '{' n ',' m '}'
 // Token meaning (LPE_RegState.h:39-79): type C camera, E emissive, B background, L emissive or background, R reflection, T refraction,
 // '.' reflection or refraction; event D diffuse, S specular, '.' any (including the "none" of camera / light tokens).  D and S alone are
-// <.,D> and <.,S>.  Labels are a host-side registry of material names the backend does not carry: a labelled token is PRGPU_EUNSUPPORTED.
+// <.,D> and <.,S>.  A labelled token matches only path tokens with that label; the `direct` integrator never labels its tokens, so a
+// labelled token is parsed and matches nothing (as in the reference for this path).
 // A path matches when the automaton, fed every token from the camera on, ends in an accepting state (LPE_Automaton.h:17-33).
 #include <algorithm>
 #include <cctype>
@@ -117,9 +118,14 @@ struct Parser {
 					++pos;
 				if (!accept('"'))
 					return nullptr;
-				unsupported = 1;
-				fail("labelled tokens are not supported by this backend");
-				return nullptr;
+				if (!accept('>'))
+					return nullptr;
+				// A labelled token only matches path tokens that carry the same label (LPE_Automaton.cpp:92-110); the `direct` integrator
+				// builds every token with label index 0 (LightPathToken.h:38,45; no caller passes one), so on this path it matches nothing.
+				std::unique_ptr<Node> dead = token_node(t, e);
+				if (dead)
+					dead->symbols = 0;
+				return dead;
 			}
 			if (!accept('>'))
 				return nullptr;
@@ -336,7 +342,7 @@ void closure(const Nfa& a, std::set<int>& st)
 } // namespace
 
 // DFA of `expr`: next[state * 15 + symbol] = following state or 0xFF (the path can no longer match), accepting[state]; state 0 is the
-// start.  At most PRGPU_LPE_MAX_STATES states.  Returns PRGPU_OK, PRGPU_EINVAL (syntax) or PRGPU_EUNSUPPORTED (labels, too many states).
+// start.  At most PRGPU_LPE_MAX_STATES states.  Returns PRGPU_OK, PRGPU_EINVAL (syntax) or PRGPU_EUNSUPPORTED (too many states).
 int compile_lpe(const std::string& expr, std::vector<uint8_t>& next, std::vector<uint8_t>& accepting, std::string& err)
 {
 	Parser p(expr);

@@ -1057,7 +1057,7 @@ def test_light_path_expression_planes_bit_exact(name):
     every fragment's explicit token list with a different algorithm -- the planes agree bit for bit, and so does everything else."""
     kw = dict(filter=abi.FILTER_BLOCK, filter_radius=0)
     if name == "cornell":
-        sc, exprs = scene.cornell_box(64, 48, spp=6, **kw), ["CE", "CDE", "CDD+E", "C.*L"]
+        sc, exprs = scene.cornell_box(64, 48, spp=6, **kw), ["CE", "C[<RD\"wall\">D]E", "CDD+E", "C.*L"]   # the labelled alternative is dead: plane 1 == CDE
     elif name == "glass":
         sc, exprs = scene.cornell_glassy(64, 48, spp=6, **kw), ["C<T,S>+<R,D>E", "C[DS]*<R,S>[DS]*E", "CD*E", "C.*<TS>.*L"]
     elif name == "rough":
@@ -1107,8 +1107,8 @@ def test_lpe_planes_shard_over_tiles_and_pass_the_reduce(monkeypatch):
 def test_lpe_rejections_and_resumed_calls():
     sc = scene.cornell_box(40, 32, spp=8, filter=abi.FILTER_BLOCK, filter_radius=0)
     g = backend.RenderContext(sc)
-    with pytest.raises(abi.PrgpuError, match="label"):
-        g.enableLPE(['C<R,D,"wall">E'])
+    with pytest.raises(abi.PrgpuError, match="syntax"):
+        g.enableLPE(['C<R,D,"wall>E'])
     with pytest.raises(abi.PrgpuError, match="at most"):
         g.enableLPE(["CE"] * 5)
     g.enableLPE(["CDE", "CDD+E"])

@@ -48,7 +48,9 @@ def test_validity_follows_the_reference_grammar():
                 "C", "", "CD**L"[:0] + "C(", "C(D", "C[", "C[^S]+B", "CD{3,1}E", "CX", "C<Q,D>", "C<R,X>", "CD)"):
         assert lib.prgpu_lpe_check(bad.encode()) == -1, bad
         assert orc_match(bad, [CAM]) == -1, bad
-    assert lib.prgpu_lpe_check(b'C<R,D,"wall">E') == -4 and b"label" in lib.prgpu_last_error()      # labels live in the host's registry
+    for labelled in ('C<R,D,"wall">E', 'C<TS"glass">*L', 'C[<RD,"a">D]+E'):                         # LPE_Parser.cpp:233-238: both label spellings
+        assert lib.prgpu_lpe_check(labelled.encode()) == 0 and orc_match(labelled, [CAM]) == 0
+    assert lib.prgpu_lpe_check(b'C<R,D,"wall>E') == -1
     assert lib.prgpu_lpe_check(b"C" + b"(D?S?)" * 24 + b"E") in (0, -4)                                  # large but legal, or beyond 32 states
     assert lib.prgpu_lpe_check(b"CD{40}E") == -4 and b"states" in lib.prgpu_last_error()
 

@@ -134,19 +134,19 @@ def test_output_blocks_are_parsed_like_the_reference():
     s = scene.PrcScene(source=src)
     ch, n = s.outputs()
     got = [(ch[i].file, ch[i].kind, ch[i].variable, ch[i].tone, ch[i].name.decode()) for i in range(n)]
-    assert [ch[i].lpe.decode() for i in range(n)] == ["", "", "", "", "CS*DL"] + [""] * 6
+    assert [ch[i].lpe.decode() for i in range(n)] == ["", "", "", "", "CS*DL", "", 'C<TD"glass">*L'] + [""] * 4
     A = abi.AOV_NAMES.index
     assert got == [(0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, ""), (0, abi.CHANNEL_3D, A("normal"), 0, "normal"), (0, abi.CHANNEL_3D, A("normal_g"), 0, "normal_geometric"),
                    (0, abi.CHANNEL_COUNTER, 1, 0, "feedback"),
                    (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, "[CS*DL]"),     # OutputSpecification.cpp:323-324
                    (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, ""),            # an invalid expression is dropped, the channel stays (:299-302)
-                   (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, ""),             # labels are not provided: same treatment
+                   (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, '[C<TD"glass">*L]'), # a labelled token is legal (and matches nothing on this path)
                    (1, abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, ""), (1, abi.CHANNEL_SPECTRAL, 2, 0, "variance"), (1, abi.CHANNEL_1D, A("depth"), 0, "depth"),
                    (1, abi.CHANNEL_COUNTER, 0, 0, "sample_count")]
     lib = abi.load()
     assert lib.prgpu_prc_output_name(s._h, 0) == b"image" and lib.prgpu_prc_output_name(s._h, 1) == b"extra" and lib.prgpu_prc_output_name(s._h, 2) is None
     w = "\n".join(s.warnings)
-    assert "invalid or unsupported light path expression 'C(('" in w and "colour channels only" in w and "labelled tokens" in w and "'uv' AOV" in w and "unknown channel type 'nope'" in w and "no name given" in w
+    assert "invalid or unsupported light path expression 'C(('" in w and "colour channels only" in w and "'uv' AOV" in w and "unknown channel type 'nope'" in w and "no name given" in w
 
 
 @pytest.mark.gpu
