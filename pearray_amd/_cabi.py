@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libprgpu.so")
+LIB_PATH = os.environ.get("PRGPU_LIBRARY") or os.path.join(_HERE, "csrc", "libprgpu.so")   # PRGPU_LIBRARY: an A/B build of the same ABI (development)
 
 PRGPU_API_VERSION = 7
 INVALID_ID = 0xFFFFFFFF

@@ -38,6 +38,7 @@ struct PersistentGeometry {
 };
 PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, uint32_t max_slots_per_block);
 uint32_t persistent_slot_padding(); // per-slot arrays need n_pixels + this many entries
+uint32_t persistent_block_threads(); // 256 or 768 (PR_PP_BLOCK)
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
 							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int refill_min, int both_below, int occupancy, int shader_wave, int shade_help,
 							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st);

@@ -33,7 +33,11 @@ enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CN
 // record per step and refill idle lanes when too few are active, so a few long rays do not hold 63 idle lanes.
 // The traversal stack lives in LDS (STACK_LDS entries per lane, bank-conflict free layout [entry][lane]); the
 // rare deeper stacks spill their oldest entries to a per-thread slab in HBM.
-constexpr int TRAV_BLOCK	= 256;
+#ifndef PR_PP_BLOCK
+#define PR_PP_BLOCK 256 // threads of a persistent-kernel block: 256 (three blocks per CU) or 768 (one block per CU: its twelve waves share one set of queues)
+#endif
+constexpr int PP_BLOCK		= PR_PP_BLOCK;
+constexpr int TRAV_BLOCK	= PR_TU >= 1 ? PP_BLOCK : 256; // the persistent-kernel units hold nothing but that kernel
 constexpr int STACK_LDS		= 16;
 constexpr int STACK_SPILL	= 64;  // additional entries per thread in global memory
 constexpr bool ANY_SORTED	= false; // near-to-far order for occlusion rays measured slightly slower than unsorted (fewer ALU ops win)
@@ -2050,7 +2054,7 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 #ifndef PR_SPLIT
 #define PR_SPLIT 0
 #endif
-constexpr int PP_SLOTS_MAX		= PR_SPLIT ? 512 : 1024; // the task queue's LDS comes out of the slot rings
+constexpr int PP_SLOTS_MAX		= PR_SPLIT ? 512 : (PP_BLOCK == 768 ? 2048 : 1024); // the task queue's LDS comes out of the slot rings
 constexpr uint32_t SPLIT_Q		= 1024;					 // ring of leaf tasks (owner lane | leaf unit << 8)
 constexpr uint32_t PP_EMPTY		= 0xFFFFFFFFu;
 constexpr uint32_t PP_ANY		= 0x80000000u; // ray entry: the slot's shadow ray (else its path ray)
@@ -2316,7 +2320,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	unsigned long long t_shade = 0, t_idle = 0;
 	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
 
-	const bool shader = a.shader_wave != 0u && (threadIdx.x >> 6) == TRAV_BLOCK / 64 - 1;
+	const bool shader = a.shader_wave != 0u && ((threadIdx.x >> 6) & 3u) == 3u; // one wave in four
 	const uint32_t shade_full = a.shader_wave != 0u ? a.shade_help : a.shade_min;
 #if PR_SPLIT
 	// test up to 64 queued leaves with this wave (whatever rays its own lanes hold); false when nothing could be claimed
@@ -3120,6 +3124,7 @@ PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, ui
 	return g;
 }
 uint32_t persistent_slot_padding() { return PP_SLOTS_MAX; }
+uint32_t persistent_block_threads() { return PP_BLOCK; }
 
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
 							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int refill_min, int both_below, int occupancy, int shader_wave, int shade_help,
@@ -3165,7 +3170,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	table[variant][(occupancy >= 3 ? 0 : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
 }
 
-size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * TRAV_BLOCK * STACK_SPILL; }
+size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * std::max(TRAV_BLOCK, PP_BLOCK) * STACK_SPILL; }
 #endif // PR_TU == 0
 
 } // namespace prd

@@ -538,7 +538,9 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		if (rc != PRGPU_OK)
 			return rc;
 		{ // persistent path kernel: its own grid (measured best: 3 blocks per CU at 3 waves per SIMD, refill below 48 lanes)
-			uint32_t pp_blocks_per_cu = 3;
+			uint32_t pp_blocks_per_cu = 768u / prd::persistent_block_threads(); // twelve waves per CU either way
+			if (!getenv("PRGPU_PP_SLOTS"))
+				s->pp_slots = 512u * (prd::persistent_block_threads() / 256u);
 			if (const char* env = getenv("PRGPU_PP_BLOCKS_PER_CU"))
 				pp_blocks_per_cu = (uint32_t)std::min(8, std::max(1, atoi(env)));
 			s->ws_pp.max_blocks	  = (uint32_t)std::max(1, prop.multiProcessorCount) * pp_blocks_per_cu;
@@ -1148,11 +1150,12 @@ int prgpu_sync(prgpu_scene* s)
 			return rc;
 	}
 	if (const char* path = s->instrument && s->mode == prgpu_scene::PERSISTENT ? getenv("PRGPU_DUMP_BLOCK_LIFE") : nullptr) { // diagnostics: one line per block of the last instrumented launch
-		std::vector<uint2> rows(size_t(s->ws_pp.max_blocks) * 256u);
+		const size_t bt = prd::persistent_block_threads();
+		std::vector<uint2> rows(size_t(s->ws_pp.max_blocks) * bt);
 		HIP_TRY(hipMemcpy(rows.data(), s->ws_pp.spill, rows.size() * sizeof(uint2), hipMemcpyDeviceToHost));
 		if (FILE* f = std::fopen(path, "w")) {
 			for (uint32_t b = 0; b < s->ws_pp.max_blocks; ++b)
-				std::fprintf(f, "%u %u %u\n", b, rows[size_t(b) * 256u].x, rows[size_t(b) * 256u].y);
+				std::fprintf(f, "%u %u %u\n", b, rows[size_t(b) * bt].x, rows[size_t(b) * bt].y);
 			std::fclose(f);
 		}
 	}
