@@ -278,7 +278,8 @@ Frag build(const Node& n, Nfa& a)
 	switch (n.kind) {
 	case Node::TOKEN: {
 		const int i = a.add(), o = a.add();
-		a.adj[i].push_back({ o, n.symbols });
+		if (n.symbols != 0) // an empty symbol set (labelled token) is a dead end, not an epsilon edge
+			a.adj[i].push_back({ o, n.symbols });
 		return { i, o };
 	}
 	case Node::CONCAT: {

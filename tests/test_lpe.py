@@ -51,6 +51,12 @@ def test_validity_follows_the_reference_grammar():
     for labelled in ('C<R,D,"wall">E', 'C<TS"glass">*L', 'C[<RD,"a">D]+E'):                         # LPE_Parser.cpp:233-238: both label spellings
         assert lib.prgpu_lpe_check(labelled.encode()) == 0 and orc_match(labelled, [CAM]) == 0
     assert lib.prgpu_lpe_check(b'C<R,D,"wall>E') == -1
+    RD, EMI = R_D, E_N                                                                              # a labelled token is a dead end, not an epsilon
+    for expr, tokens, want in (('C<RD"wall">E', [CAM, EMI], 0), ('C<RD"wall">E', [CAM, RD, EMI], 0), ('C[<RD"wall">D]E', [CAM, RD, EMI], 1),
+                               ('C[<RD"wall">D]E', [CAM, EMI], 0), ('C<RD"wall">*E', [CAM, EMI], 1), ('C<RD"wall">?DE', [CAM, RD, EMI], 1)):
+        arr = (C.c_uint8 * len(tokens))(*tokens)
+        assert lib.prgpu_lpe_match(expr.encode(), arr, len(tokens)) == want, (expr, tokens)
+        assert orc_match(expr, tokens) == want, (expr, tokens)
     assert lib.prgpu_lpe_check(b"C" + b"(D?S?)" * 24 + b"E") in (0, -4)                                  # large but legal, or beyond 32 states
     assert lib.prgpu_lpe_check(b"CD{40}E") == -4 and b"states" in lib.prgpu_last_error()
 
@@ -58,7 +64,7 @@ def test_validity_follows_the_reference_grammar():
 def test_automaton_and_direct_matcher_agree_on_random_expressions():
     """Two independent implementations (subset-construction DFA in the library, end-position sets in the checker) on random input."""
     rng = np.random.default_rng(11)
-    atoms = ["D", "S", "E", "L", "B", "R", "T", ".", "<R,D>", "<T,S>", "<.,D>", "<L.>", "<E,.>", "<B.>"]
+    atoms = ["D", "S", "E", "L", "B", "R", "T", ".", "<R,D>", "<T,S>", "<.,D>", "<L.>", "<E,.>", "<B.>", '<R,D,"x">', '<TS"y">']   # labelled tokens: dead ends on this path
     ops = ["", "", "", "*", "+", "?", "{2}", "{1,3}", "{0,2}"]
 
     def term(depth):
