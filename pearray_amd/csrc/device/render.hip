@@ -2749,7 +2749,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 // Two register budgets of the same kernel: 2 waves per SIMD (no spills) and 3 waves per SIMD (the compiler spills a few shading
 // temporaries to scratch); which one is faster is a latency-hiding question answered by measurement (PRGPU_PP_OCCUPANCY).
 template <bool COUNT, uint32_t FEATS>
-__global__ void __launch_bounds__(TRAV_BLOCK) k_path_persistent(DevScene sc, PathState ps, PersistentArgs a)
+__global__ void __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) k_path_persistent(DevScene sc, PathState ps, PersistentArgs a)
 {
 	path_persistent<COUNT, FEATS>(sc, ps, a);
 }
