@@ -9,7 +9,8 @@
 // walk Scene -- it hands the SAME scene file the host is loading to the library's own loader (prgpu_prc_load_file), which produces
 // the flat prgpu_scene_desc, and supplies what only the host can compute: the SkyModel tables of `sky` lights (pr_lib_skysun).
 // How the frame comes back: results bypass the per-fragment queue (RenderTileSession::pushSpectralFragment is a per-sample virtual
-// call); at onEnd() the XYZ / sample-count / feedback planes are downloaded into the host's FrameOutputDevice buffers.
+// call); at onEnd() the XYZ / sample-count / feedback planes, the shading-point AOVs, the online mean / variance and the
+// light path expression planes are downloaded into the host's FrameOutputDevice buffers.
 #include "Environment.h"
 #include "Logger.h"
 #include "SceneLoadContext.h"
@@ -128,6 +129,25 @@ public:
 			auto feedback = frame->data().getInternalChannel_Counter(AOV_Feedback);
 			if (prgpu_download(mScene, xyz ? xyz->ptr() : nullptr, samples ? samples->ptr() : nullptr, feedback ? feedback->ptr() : nullptr) != PRGPU_OK)
 				PR_LOG(L_ERROR) << "[gpu_direct] " << prgpu_last_error() << std::endl;
+			// the planes the (output ...) blocks asked for, where the host's frame holds the same channel (OutputSpecification::setup)
+			static const std::pair<AOV3D, uint32> map3d[] = { { AOV_Position, PRGPU_AOV_POSITION }, { AOV_Normal, PRGPU_AOV_NORMAL }, { AOV_NormalG, PRGPU_AOV_NORMAL_G },
+															   { AOV_Tangent, PRGPU_AOV_TANGENT }, { AOV_Bitangent, PRGPU_AOV_BITANGENT }, { AOV_View, PRGPU_AOV_VIEW } };
+			static const std::pair<AOV1D, uint32> map1d[] = { { AOV_EntityID, PRGPU_AOV_ENTITY_ID }, { AOV_MaterialID, PRGPU_AOV_MATERIAL_ID },
+															   { AOV_EmissionID, PRGPU_AOV_EMISSION_ID }, { AOV_Depth, PRGPU_AOV_DEPTH } };
+			for (const auto& m : map3d)
+				if (auto plane = frame->data().getInternalChannel_3D(m.first))
+					(void)prgpu_download_aov(mScene, m.second, plane->ptr()); // EINVAL when the plane was not enabled on the device: left as it is
+			for (const auto& m : map1d)
+				if (auto plane = frame->data().getInternalChannel_1D(m.first))
+					(void)prgpu_download_aov(mScene, m.second, plane->ptr());
+			auto mean = frame->data().getInternalChannel_Spectral(AOV_OnlineMean), variance = frame->data().getInternalChannel_Spectral(AOV_OnlineVariance);
+			if (mean || variance)
+				(void)prgpu_download_variance(mScene, mean ? mean->ptr() : nullptr, variance ? variance->ptr() : nullptr);
+			// light path expression planes: the i-th LPE colour channel of the frame is the i-th distinct expression of the file's
+			// (channel :type 'color' :lpe ...) list, the order prgpu_outputs_enable enabled them in (FrameContainer.h:78-86,111)
+			for (size_t i = 0; i < frame->data().getLPEChannelCount_Spectral(AOV_Output) && i < PRGPU_LPE_MAX; ++i)
+				if (auto plane = frame->data().getLPEChannel_Spectral(AOV_Output, i))
+					(void)prgpu_download_lpe(mScene, (uint32)i, plane->ptr());
 		}
 	}
 
