@@ -22,6 +22,18 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert getattr(lib, name) is not None
 
 
+def test_the_pearray_side_adapter_and_the_docs_only_use_declared_entry_points():
+    """integration/pr_pl_int_gpu_direct.cpp cannot be compiled here (PearRay's headers, Eigen); at least every prgpu_* call in it, and in
+    INTEGRATION.md's host loops, must be an entry point (or type / constant) that include/prgpu.h declares."""
+    header = open(os.path.join(ROOT, "include", "prgpu.h")).read()
+    for rel in (os.path.join("integration", "pr_pl_int_gpu_direct.cpp"), "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, rel)).read()
+        for name in set(re.findall(r"\b(prgpu_[a-z0-9_]+)\s*\(", text)):
+            assert name in abi.SYMBOLS or name == "prgpu_init", (rel, name)   # prgpu_init: SURVEY's proposed name, mentioned as replaced
+        for name in set(re.findall(r"\b(PRGPU_[A-Z0-9_]+)\b", text)):
+            assert re.search(r"\b%s\b" % name, header) or name.startswith(("PRGPU_PP_", "PRGPU_MODE", "PRGPU_COMM_", "PRGPU_TRACE_", "PRGPU_LIBRARY", "PRGPU_DUMP", "PRGPU_BLOCKS", "PRGPU_GROUPS")), (rel, name)
+
+
 def test_struct_layouts_match_the_header(tmp_path):
     """sizeof/offsetof of every ABI struct as seen by a C compiler equal the ctypes mirror."""
     import subprocess
