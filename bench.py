@@ -180,7 +180,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--triangles", type=int, default=NTRI)
