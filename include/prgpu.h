@@ -144,8 +144,16 @@ typedef struct prgpu_emission {
  * SPHERE (src/plugins/main/entities/sphere.cpp): an Embree RTC_GEOMETRY_TYPE_SPHERE_POINT at M * (0,0,0) with radius
  * `radius` * mean column norm of the linear part (sphere.cpp:77-92).  Described as ONE placeholder triangle (its three indices are
  * ignored) so that the per-triangle arrays stay uniform; primitive id 0; N = normalize(P - centre), Tangent::frame (sphere.cpp:118-129).
- * Emissive spheres are not supported yet. */
-enum { PRGPU_ENTITY_MESH = 0, PRGPU_ENTITY_PLANE = 1, PRGPU_ENTITY_SPHERE = 2 };
+ * Emissive spheres are not supported yet.
+ * QUADRIC (src/plugins/main/entities/quadric.cpp; `quadric`, `cone`, `cylinder`): the implicit surface
+ * A x^2 + B y^2 + C z^2 + D xy + E xz + F yz + G x + H y + I z + J = 0 inside a local box, an Embree user geometry with its own
+ * intersect / occluded callbacks (quadric.cpp:131-248; geometry/Quadric.h).  `params` is the offset of 16 floats in
+ * prgpu_scene_desc::spectral_tables: A..J, box min xyz, box max xyz (the library grows the box by 1e-4 as quadric.cpp:33 does).
+ * Described as ONE placeholder triangle whose three indices name the same vertex (never hit); primitive id 0;
+ * N = normalMatrix * normalize(gradient(invTransform * P)), Tangent::frame, uv = 0 (quadric.cpp:95-108).  The occlusion callback of
+ * the reference tests the UNBOUNDED surface from the box's entry on (no clip to the box's exit or the ray's extent): kept.
+ * Emissive quadrics are rejected (the reference's sampleParameterPoint is a stub with pdf 0).  Persistent pipeline only. */
+enum { PRGPU_ENTITY_MESH = 0, PRGPU_ENTITY_PLANE = 1, PRGPU_ENTITY_SPHERE = 2, PRGPU_ENTITY_QUADRIC = 3 };
 typedef struct prgpu_entity {
 	uint32_t first_tri;
 	uint32_t n_tris;
@@ -155,7 +163,7 @@ typedef struct prgpu_entity {
 	float    radius;       /* SPHERE: local radius (`:radius`, default 1) */
 	uint32_t has_uvs;      /* MESH: 1: the mesh has texture coordinates (MeshEntity<HasUV>, mesh.cpp:205-228): interpolated uv, and with
 	                          has_normals the tangent frame of Face::tangentFromUV (geometry/Face.h:80-98) */
-	uint32_t reserved;
+	uint32_t params;       /* QUADRIC: offset of its 16 floats in spectral_tables (0 otherwise) */
 	float    transform[16];
 } prgpu_entity;
 

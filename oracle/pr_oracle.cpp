@@ -1098,6 +1098,15 @@ struct Scene {
 		float pdf_cache = 0;   // sphere: 1 / worldSurfaceArea
 	};
 	std::vector<ShapeLight> shape_light; // per entity
+	// QUADRIC entities (entities/quadric.cpp): coefficients, the local box grown by BBOX_EPS, the world box of its corners, invTransform
+	struct Quadric {
+		float p[10];
+		V3 lo, hi, wlo, whi;
+		float inv[12];
+		uint32_t tri, entity;
+	};
+	std::vector<Quadric> quadrics;
+	std::vector<uint32_t> quadric_of;	   // entity -> index into quadrics
 	std::vector<V3> sphere_c;			   // SPHERE entities: world centre (transform * 0) ...
 	std::vector<float> sphere_r;		   // ... and world radius (sphere.cpp:77-92)
 	float eps_t = 0;					   // slab-test slack, 8e-6 * max |coordinate| (world vertices, camera origin)
@@ -1791,6 +1800,116 @@ inline bool sphere_hit(const RayPre& r, V3 c, float radius, float tmin, float li
 	return false;
 }
 inline bool prim_is_sphere(const Scene& s, uint32_t tri) { return s.entities[s.tri_entity[tri]].kind == PRGPU_ENTITY_SPHERE; }
+
+// ---- quadric entities: Embree user geometry with the entity's own callbacks (entities/quadric.cpp:116-248) --------------------------
+// Quadric::intersect (geometry/Quadric.h:27-70)
+inline bool quadric_intersect(const float* q, V3 origin, V3 direction, float& t)
+{
+	constexpr float INT_EPS = 1e-6f;
+	const float A = q[0], B = q[1], C = q[2], D = q[3], E = q[4], F = q[5], G = q[6], H = q[7], I = q[8], J = q[9];
+	const float a = ((((A * direction.x * direction.x + B * direction.y * direction.y) + C * direction.z * direction.z) + D * direction.x * direction.y) + E * direction.x * direction.z)
+					+ F * direction.y * direction.z;
+	const float b = ((((((((2 * A * origin.x * direction.x + 2 * B * origin.y * direction.y) + 2 * C * origin.z * direction.z) + D * (origin.x * direction.y + origin.y * direction.x))
+						 + E * (origin.x * direction.z + origin.z * direction.x))
+						+ F * (origin.y * direction.z + origin.z * direction.y))
+					   + G * direction.x)
+					  + H * direction.y)
+					 + I * direction.z);
+	const float c = ((((((((A * origin.x * origin.x + B * origin.y * origin.y) + C * origin.z * origin.z) + D * origin.x * origin.y) + E * origin.x * origin.z) + F * origin.y * origin.z)
+					   + G * origin.x)
+					  + H * origin.y)
+					 + I * origin.z)
+					+ J;
+	const bool linear = std::fabs(a) <= PR_EPS;
+	const float lin	  = -c / b;
+	float discrim	  = b * b - 4 * a * c;
+	const bool invalid = discrim < 0;
+	discrim			   = std::sqrt(discrim);
+	const float qu1 = (-b - discrim) / (2 * a), qu2 = (-b + discrim) / (2 * a);
+	const bool behind = qu1 <= INT_EPS;
+	const float qu	  = behind ? qu2 : qu1;
+	t				  = linear ? lin : (invalid ? PR_INF_F : qu);
+	return t < PR_INF_F && (t >= INT_EPS);
+}
+// Quadric::normal (Quadric.h:115-121) = gradient(...).normalized()
+inline V3 quadric_normal(const float* q, V3 x)
+{
+	return normalized(v3(((2 * q[0] * x.x + q[3] * x.y) + q[4] * x.z) + q[6], ((q[3] * x.x + 2 * q[1] * x.y) + q[5] * x.z) + q[7], ((q[4] * x.x + q[5] * x.y) + 2 * q[2] * x.z) + q[8]));
+}
+// BoundingBox::intersectsRange (geometry/BoundingBox.cpp:50-70) of Ray(origin, direction): MinT = PR_EPSILON, MaxT = inf (Ray.h:25-26)
+struct BoxRange {
+	float entry, exit;
+};
+inline BoxRange box_range(V3 lower, V3 upper, V3 origin, V3 direction)
+{
+	const V3 inv  = v3(1.0f / direction.x, 1.0f / direction.y, 1.0f / direction.z);
+	const V3 vmin = v3(inv.x * (lower.x - origin.x), inv.y * (lower.y - origin.y), inv.z * (lower.z - origin.z));
+	const V3 vmax = v3(inv.x * (upper.x - origin.x), inv.y * (upper.y - origin.y), inv.z * (upper.z - origin.z));
+	BoxRange r;
+	r.entry = std::min(vmin.x, vmax.x);
+	r.exit	= std::max(vmin.x, vmax.x);
+	r.entry = std::max(std::min(vmin.y, vmax.y), r.entry);
+	r.exit	= std::min(std::max(vmin.y, vmax.y), r.exit);
+	r.entry = std::max(std::min(vmin.z, vmax.z), r.entry);
+	r.exit	= std::min(std::max(vmin.z, vmax.z), r.exit);
+	r.entry = std::max(PR_EPS, r.entry);
+	r.exit	= std::min(PR_INF_F, r.exit);
+	return r;
+}
+// What Embree does before it calls a user primitive's callback: the ray's extent must overlap the primitive's bounds (userBoundsFunc,
+// quadric.cpp:116-128).  Embree is not in the tree; restated as the plain segment / box overlap.
+inline bool quadric_bounds_overlap(const Scene::Quadric& Q, V3 o, V3 d, float tnear, float tfar)
+{
+	const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z }, lo[3] = { Q.wlo.x, Q.wlo.y, Q.wlo.z }, hi[3] = { Q.whi.x, Q.whi.y, Q.whi.z };
+	float t0 = tnear, t1 = tfar;
+	for (int k = 0; k < 3; ++k) {
+		if (dd[k] == 0.0f) {
+			if (oo[k] < lo[k] || oo[k] > hi[k])
+				return false;
+			continue;
+		}
+		const float a = (lo[k] - oo[k]) / dd[k], b = (hi[k] - oo[k]) / dd[k];
+		t0 = std::fmax(t0, std::fmin(a, b));
+		t1 = std::fmin(t1, std::fmax(a, b));
+	}
+	return t0 <= t1;
+}
+inline V3 affine_point(const float* m, V3 p) { return v3(((m[0] * p.x + m[1] * p.y) + m[2] * p.z) + m[3], ((m[4] * p.x + m[5] * p.y) + m[6] * p.z) + m[7], ((m[8] * p.x + m[9] * p.y) + m[10] * p.z) + m[11]); }
+inline V3 affine_vector(const float* m, V3 p) { return v3((m[0] * p.x + m[1] * p.y) + m[2] * p.z, (m[4] * p.x + m[5] * p.y) + m[6] * p.z, (m[8] * p.x + m[9] * p.y) + m[10] * p.z); }
+// userIntersectFuncN (quadric.cpp:131-190) for one ray: ray_tfar shrinks to the LOCAL parameter of the hit (:185)
+inline void quadric_intersect_callback(const Scene& s, const Scene::Quadric& Q, V3 ray_org, V3 ray_dir, float ray_tnear, Hit& best)
+{
+	if (!quadric_bounds_overlap(Q, ray_org, ray_dir, ray_tnear, best.t))
+		return;
+	const V3 local_org = affine_point(Q.inv, ray_org), local_dir = affine_vector(Q.inv, ray_dir);
+	BoxRange range = box_range(Q.lo, Q.hi, local_org, local_dir);
+	if (range.entry < 0)
+		range.entry = 0;
+	float t;
+	if (!quadric_intersect(Q.p, local_org + local_dir * range.entry, local_dir, t))
+		return;
+	t += range.entry;
+	if (t > range.exit)
+		return;
+	const V3 dt2		 = affine_vector(s.entities[Q.entity].transform, local_dir * t); // Ray::transformDistance (Ray.h:93-100)
+	const float global_t = std::sqrt((dt2.x * dt2.x + dt2.y * dt2.y) + dt2.z * dt2.z);
+	if (global_t >= ray_tnear && global_t <= best.t) {
+		if (t < best.t || (t == best.t && Q.tri < best.tri)) // several geometries at one distance: this restatement's tie rule
+			best = Hit{ t, 0.0f, 0.0f, Q.tri };
+	}
+}
+// userOccludedFuncN (quadric.cpp:193-231): the UNBOUNDED surface from the box's entry on -- no clip to the exit, none to the ray's extent
+inline bool quadric_occluded_callback(const Scene::Quadric& Q, V3 ray_org, V3 ray_dir, float ray_tnear, float ray_tfar)
+{
+	if (!quadric_bounds_overlap(Q, ray_org, ray_dir, ray_tnear, ray_tfar))
+		return false;
+	const V3 local_org = affine_point(Q.inv, ray_org), local_dir = affine_vector(Q.inv, ray_dir);
+	BoxRange range = box_range(Q.lo, Q.hi, local_org, local_dir);
+	if (range.entry < 0)
+		range.entry = 0;
+	float t;
+	return quadric_intersect(Q.p, local_org + local_dir * range.entry, local_dir, t);
+}
 // closest hit: tmin < t <= tmax; equal t -> lower global triangle index wins (documented tie rule)
 inline void test_tri_closest(const Scene& s, const RayPre& r, uint32_t tri, float tmin, Hit& best)
 {
@@ -1819,6 +1938,8 @@ Hit trace_closest(Scene& s, V3 o, V3 d, float tmin, float tmax, bool brute, bool
 	if (brute) {
 		for (uint32_t t = 0; t < s.d.n_triangles; ++t)
 			test_tri_closest(s, r, t, tmin, best);
+		for (const Scene::Quadric& Q : s.quadrics)
+			quadric_intersect_callback(s, Q, o, d, tmin, best);
 		return best;
 	}
 	uint32_t stack[128];
@@ -1853,6 +1974,8 @@ Hit trace_closest(Scene& s, V3 o, V3 d, float tmin, float tmax, bool brute, bool
 				stack[sp++] = n.left + 1;
 		}
 	}
+	for (const Scene::Quadric& Q : s.quadrics) // user geometries: Embree would reach them through the same BVH; the closest hit is order independent
+		quadric_intersect_callback(s, Q, o, d, tmin, best);
 	if (count) {
 		s.cnt_nodes += nn;
 		s.cnt_tris += nt;
@@ -1874,6 +1997,9 @@ bool trace_any(Scene& s, V3 o, V3 d, float tmin, float distance, bool brute)
 			return false;
 		return t > tmin && t <= tmax;
 	};
+	for (const Scene::Quadric& Q : s.quadrics)
+		if (quadric_occluded_callback(Q, o, d, tmin, tmax))
+			return true;
 	if (brute) {
 		for (uint32_t t = 0; t < s.d.n_triangles; ++t)
 			if (test(t))
@@ -1925,6 +2051,18 @@ void geometry_point(const Scene& s, uint32_t tri, float u, float v, V3 P, GeomPo
 	if (E.kind == PRGPU_ENTITY_SPHERE) { // SphereEntity::provideGeometryPoint (sphere.cpp:118-129): normal from the queried position
 		g.N = normalized(P - s.sphere_c[e]);
 		frame_duff(g.N, g.Nx, g.Ny); // Tangent::frame = unnormalized_frame + normalize
+		g.Nx	   = normalized(g.Nx);
+		g.Ny	   = normalized(g.Ny);
+		g.entity   = e;
+		g.prim	   = 0;
+		g.material = s.tri_material[tri];
+		g.emission = E.emission;
+		return;
+	}
+	if (E.kind == PRGPU_ENTITY_QUADRIC) { // QuadricEntity::provideGeometryPoint (quadric.cpp:95-108)
+		const Scene::Quadric& Q = s.quadrics[s.quadric_of[e]];
+		g.N = mat3_mul(s.nmat[e].data(), quadric_normal(Q.p, affine_point(Q.inv, P)));
+		frame_duff(g.N, g.Nx, g.Ny); // Tangent::frame
 		g.Nx	   = normalized(g.Nx);
 		g.Ny	   = normalized(g.Ny);
 		g.entity   = e;
@@ -3906,8 +4044,10 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 			return fail("entity wants normals but none given");
 		if (E.has_uvs && s.uvs.empty())
 			return fail("entity wants texture coordinates but none given");
-		if (E.kind > PRGPU_ENTITY_SPHERE || (E.kind == PRGPU_ENTITY_PLANE && E.n_tris != 2))
+		if (E.kind > PRGPU_ENTITY_QUADRIC || (E.kind == PRGPU_ENTITY_PLANE && E.n_tris != 2))
 			return fail("bad plane entity");
+		if (E.kind == PRGPU_ENTITY_QUADRIC && (E.n_tris != 1 || uint64_t(E.params) + 16u > d->n_spectral_table_values || E.emission != INVALID))
+			return fail("bad quadric entity");
 		if (E.kind == PRGPU_ENTITY_SPHERE && (E.n_tris != 1 || !(E.radius > 0)))
 			return fail("bad sphere entity");
 		for (uint32_t t = 0; t < E.n_tris; ++t)
@@ -4037,11 +4177,44 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 		s.wv[3 * E.first_tri + 1] = s.sphere_c[e] + v3(rr, rr, rr);
 		s.wv[3 * E.first_tri + 2] = s.sphere_c[e];
 	}
+	s.quadrics.clear();
+	s.quadric_of.assign(d->n_entities, 0u);
+	for (uint32_t e = 0; e < d->n_entities; ++e) {
+		const prgpu_entity& E = s.entities[e];
+		if (E.kind != PRGPU_ENTITY_QUADRIC)
+			continue;
+		Scene::Quadric Q;
+		const float* q = d->spectral_tables + E.params;
+		for (int k = 0; k < 10; ++k)
+			Q.p[k] = q[k];
+		constexpr float BBOX_EPS = 1e-4f; // quadric.cpp:22,33
+		Q.lo = v3(q[10] - BBOX_EPS, q[11] - BBOX_EPS, q[12] - BBOX_EPS);
+		Q.hi = v3(q[13] + BBOX_EPS, q[14] + BBOX_EPS, q[15] + BBOX_EPS);
+		affine_inverse(E.transform, Q.inv);
+		Q.wlo = v3(PR_INF_F, PR_INF_F, PR_INF_F);
+		Q.whi = v3(-PR_INF_F, -PR_INF_F, -PR_INF_F);
+		for (int corner = 0; corner < 8; ++corner) {
+			const V3 w = affine_point(E.transform, v3((corner & 1) ? Q.hi.x : Q.lo.x, (corner & 2) ? Q.hi.y : Q.lo.y, (corner & 4) ? Q.hi.z : Q.lo.z));
+			Q.wlo	   = v3(std::min(Q.wlo.x, w.x), std::min(Q.wlo.y, w.y), std::min(Q.wlo.z, w.z));
+			Q.whi	   = v3(std::max(Q.whi.x, w.x), std::max(Q.whi.y, w.y), std::max(Q.whi.z, w.z));
+		}
+		Q.tri			= E.first_tri;
+		Q.entity		= e;
+		s.quadric_of[e] = (uint32_t)s.quadrics.size();
+		s.quadrics.push_back(Q);
+	}
 	{ // origin-centred bounding sphere of the world-space bounding box (Scene.cpp:107-118, Sphere::combine)
 		V3 lo = v3(PR_INF_F, PR_INF_F, PR_INF_F), hi = v3(-PR_INF_F, -PR_INF_F, -PR_INF_F);
-		for (const V3& p : s.wv) {
+		for (size_t i = 0; i < s.wv.size(); ++i) {
+			if (s.entities[s.tri_entity[i / 3]].kind == PRGPU_ENTITY_QUADRIC)
+				continue; // the placeholder point is not part of the entity's box
+			const V3& p = s.wv[i];
 			lo = v3(std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z));
 			hi = v3(std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z));
+		}
+		for (const Scene::Quadric& Q : s.quadrics) {
+			lo = v3(std::min(lo.x, Q.wlo.x), std::min(lo.y, Q.wlo.y), std::min(lo.z, Q.wlo.z));
+			hi = v3(std::max(hi.x, Q.whi.x), std::max(hi.y, Q.whi.y), std::max(hi.z, Q.whi.z));
 		}
 		float r2 = 0;
 		const float fu = dot(hi, hi), fl = dot(lo, lo);
@@ -4539,6 +4712,38 @@ void orc_lambert_sample(orc_scene* h, uint32_t material, const float wvl[4], con
 	if (std::signbit(v[2]) != std::signbit(L.z))
 		L = -L;
 	l[0] = L.x; l[1] = L.y; l[2] = L.z;
+}
+
+// ---- quadric KAT exports (tests/quadric.cpp of the reference) -------------------------------------------------------------
+int orc_quadric_intersect(const float q[10], const float o[3], const float d[3], float* t)
+{
+	float tt = 0;
+	const bool hit = quadric_intersect(q, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), tt);
+	*t = tt;
+	return hit ? 1 : 0;
+}
+void orc_quadric_normal(const float q[10], const float x[3], float n[3])
+{
+	const V3 r = quadric_normal(q, v3(x[0], x[1], x[2]));
+	n[0] = r.x, n[1] = r.y, n[2] = r.z;
+}
+// one ray against the scene's quadric callbacks only: closest (returns the entity or INVALID, *t the distance) and occlusion
+uint32_t orc_quadric_closest(orc_scene* h, const float o[3], const float d[3], float tmin, float tmax, float* t)
+{
+	Scene& s = h->s;
+	Hit best{ tmax, 0, 0, INVALID };
+	for (const Scene::Quadric& Q : s.quadrics)
+		quadric_intersect_callback(s, Q, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), tmin, best);
+	*t = best.t;
+	return best.tri == INVALID ? INVALID : s.tri_entity[best.tri];
+}
+int orc_quadric_occluded(orc_scene* h, const float o[3], const float d[3], float tmin, float tmax)
+{
+	Scene& s = h->s;
+	for (const Scene::Quadric& Q : s.quadrics)
+		if (quadric_occluded_callback(Q, v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]), tmin, tmax))
+			return 1;
+	return 0;
 }
 
 // ---- rough material KAT exports (tests/microfacets.cpp, tests/materials.cpp of the reference) --------------------------

@@ -103,6 +103,10 @@ void     orc_lambert_sample(orc_scene* s, uint32_t material, const float wvl[4],
 
 /* GGX microfacet closures (base/math/Microfacet.h, RoughDistribution.h, MicrofacetReflection.h) and the rough materials built on
  * them (roughconductor.cpp, roughdielectric.cpp); KATs of the reference's tests/microfacets.cpp and tests/materials.cpp. */
+int      orc_quadric_intersect(const float q[10], const float o[3], const float d[3], float* t);   /* Quadric::intersect */
+void     orc_quadric_normal(const float q[10], const float x[3], float n[3]);                       /* Quadric::normal */
+uint32_t orc_quadric_closest(orc_scene* s, const float o[3], const float d[3], float tmin, float tmax, float* t); /* the intersect callbacks only */
+int      orc_quadric_occluded(orc_scene* s, const float o[3], const float d[3], float tmin, float tmax);          /* the occluded callbacks only */
 float    orc_ndf_ggx(const float h[3], float rx, float ry, int aniso);
 float    orc_pdf_ggx(const float h[3], float rx, float ry, int aniso);
 float    orc_mf_reflection(int what /*0 eval, 1 evalConductor, 2 pdf*/, float m1, float m2, int aniso, int vndf, const float w_in[3],

@@ -18,7 +18,7 @@ MAT_LAMBERT, MAT_DIELECTRIC, MAT_CONDUCTOR, MAT_ROUGH_CONDUCTOR, MAT_ROUGH_DIELE
 MATF_ANISOTROPIC, MATF_NO_VNDF, MATF_HAS_TRANSMISSION = 1, 2, 4
 PRINCIPLED_PARAMS = ("diffuse_transmission", "specular_transmission", "specular_tint", "anisotropic", "flatness", "metallic", "sheen",
                      "sheen_tint", "clearcoat", "clearcoat_gloss")
-ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE = 0, 1, 2
+ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE, ENTITY_QUADRIC = 0, 1, 2, 3
 LIGHT_ENVIRONMENT, LIGHT_DISTANT, LIGHT_SKY, LIGHT_SUN, LIGHT_CIE_SKY = 0, 1, 2, 3, 4
 SKYF_EXTEND, SKYF_COMPENSATION, SKYF_CLOUDY = 1, 2, 8
 SKY_BANDS = 11
@@ -55,7 +55,7 @@ class Emission(C.Structure):
 
 class Entity(C.Structure):
     _fields_ = [("first_tri", C.c_uint32), ("n_tris", C.c_uint32), ("emission", C.c_uint32),
-                ("has_normals", C.c_uint32), ("kind", C.c_uint32), ("radius", C.c_float), ("has_uvs", C.c_uint32), ("reserved", C.c_uint32), ("transform", C.c_float * 16)]
+                ("has_normals", C.c_uint32), ("kind", C.c_uint32), ("radius", C.c_float), ("has_uvs", C.c_uint32), ("params", C.c_uint32), ("transform", C.c_float * 16)]
 
 
 class Light(C.Structure):

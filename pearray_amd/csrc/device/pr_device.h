@@ -67,10 +67,23 @@ struct DevEntity {
 	uint32_t light_id, kind; // kind: PRGPU_ENTITY_*
 	float sphere_r;			 // SPHERE: world radius (sphere.cpp:77-92); the centre is the translation (m[3], m[7], m[11])
 	uint32_t has_uvs;		 // MESH: texture coordinates present (interpolated uv, UV-derived tangent frame)
+	uint32_t quadric;		 // QUADRIC: index into DevScene::quadrics
 };
 
 constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u, FEAT_SHAPE_LIGHTS = 32u, FEAT_TEXTURES = 64u,
-				   FEAT_ROUGH_MATERIALS = 128u, FEAT_LPE = 256u, FEAT_ALL = 511u;
+				   FEAT_ROUGH_MATERIALS = 128u, FEAT_LPE = 256u, FEAT_QUADRICS = 512u, FEAT_ALL = 1023u;
+
+// QuadricEntity (src/plugins/main/entities/quadric.cpp; `quadric`, `cone`, `cylinder`): an implicit surface inside a local box.  Embree
+// sees a user geometry: one primitive with the world box as bounds and the entity's own intersect / occluded callbacks.  Here the few
+// quadrics of a scene are tested once per ray, before the BVH walk (whose placeholder triangle for the entity is degenerate and never hit).
+struct DevQuadric {
+	float p[10];		 // A x^2 + B y^2 + C z^2 + D xy + E xz + F yz + G x + H y + I z + J = 0 (Quadric.h:10-12)
+	float lo[3], hi[3];	 // local box, already grown by BBOX_EPS (quadric.cpp:22,33)
+	float wlo[3], whi[3]; // world box of the eight transformed corners (the bounds callback, quadric.cpp:116-128)
+	float inv[12];		 // invTransform, 3 rows of 4
+	uint32_t tri;		 // the entity's placeholder triangle: the primitive id hits report
+	uint32_t entity;
+};
 
 // Area-light data of an analytic entity (one per entity, meaningful for emissive planes and spheres):
 // PlaneEntity::cache (plane.cpp:227-243) and SphereEntity (sphere.cpp:23-31,106-118)
@@ -156,6 +169,8 @@ struct DevScene {
 	uint32_t n_lights; // area lights; the infinite lights follow them in light_cdf
 	const DevInfLight* inf_lights;
 	const DevShapeLight* shape_lights; // per entity, or null when no plane / sphere emits
+	const DevQuadric* quadrics;		   // quadric entities, or null
+	uint32_t n_quadrics;
 	uint32_t n_inf_lights;
 	const float* sky_cdf; // Distribution2D tables of the SKY lights (DevInfLight::dist_offset), or null
 	float scene_radius; // origin-centred bounding sphere (Scene.cpp:107-118)
@@ -778,6 +793,94 @@ __device__ __forceinline__ bool sphere_hit(const RayPre& r, V3 c, float radius, 
 	}
 	return false;
 }
+// ---- quadric entities (quadric.cpp:131-248, geometry/Quadric.h, BoundingBox::intersectsRange) ---------------------------------------
+// std::min / std::max as the reference's libstdc++ evaluates them (NaN from 0 * inf on axis-parallel rays propagates the same way)
+__device__ __forceinline__ float std_min(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float std_max(float a, float b) { return a < b ? b : a; }
+// Quadric::intersect (Quadric.h:27-70): nearest root beyond INT_EPS of a t^2 + b t + c = 0, the far one when the near one lies behind
+__device__ __forceinline__ bool quadric_roots(const float* p, V3 o, V3 d, float& t)
+{
+	const float INT_EPS = 1e-6f;
+	const float A = p[0], B = p[1], C = p[2], D = p[3], E = p[4], F = p[5], G = p[6], H = p[7], I = p[8], J = p[9];
+	const float a = ((((A * d.x * d.x + B * d.y * d.y) + C * d.z * d.z) + D * d.x * d.y) + E * d.x * d.z) + F * d.y * d.z;
+	const float b = ((((((((2 * A * o.x * d.x + 2 * B * o.y * d.y) + 2 * C * o.z * d.z) + D * (o.x * d.y + o.y * d.x)) + E * (o.x * d.z + o.z * d.x)) + F * (o.y * d.z + o.z * d.y))
+					   + G * d.x) + H * d.y) + I * d.z);
+	const float c = ((((((((A * o.x * o.x + B * o.y * o.y) + C * o.z * o.z) + D * o.x * o.y) + E * o.x * o.z) + F * o.y * o.z) + G * o.x) + H * o.y) + I * o.z) + J;
+	const bool linear	= fabsf(a) <= 1.1920929e-07f; // PR_EPSILON
+	const float lin		= -c / b;
+	const float discrim = b * b - 4 * a * c;
+	const bool invalid	= discrim < 0;
+	const float root	= sqrtf(discrim);
+	const float qu1 = (-b - root) / (2 * a), qu2 = (-b + root) / (2 * a);
+	const bool behind = qu1 <= INT_EPS;
+	const float qu	  = behind ? qu2 : qu1;
+	t				  = linear ? lin : (invalid ? INFINITY : qu);
+	return t < INFINITY && t >= INT_EPS;
+}
+// robust segment / box overlap for the bounds Embree culls user primitives with (axis-parallel rays: origin inside the slab)
+__device__ __forceinline__ bool quadric_bounds_hit(const DevQuadric& q, V3 o, V3 d, float tmin, float tmax)
+{
+	float t0 = tmin, t1 = tmax;
+	const float oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+	for (int k = 0; k < 3; ++k) {
+		if (dd[k] == 0.0f) {
+			if (oo[k] < q.wlo[k] || oo[k] > q.whi[k])
+				return false;
+			continue;
+		}
+		const float a = (q.wlo[k] - oo[k]) / dd[k], b = (q.whi[k] - oo[k]) / dd[k];
+		t0 = fmaxf(t0, fminf(a, b));
+		t1 = fminf(t1, fmaxf(a, b));
+	}
+	return t0 <= t1;
+}
+// userIntersectFuncN / userOccludedFuncN (quadric.cpp:131-248) for one ray.  closest: the hit distance when the surface is met inside
+// the local box and inside [tmin, tmax]; any: whether the ray is reported occluded -- the reference's occlusion callback neither clips
+// the root to the box's exit nor to the ray's extent, which is kept (a quadric shadows whatever lies behind its box along the ray).
+__device__ __forceinline__ bool quadric_hit(const DevQuadric& q, const float* m /* the entity's transform rows */, V3 o, V3 d, float tmin, float tmax, bool any, float& t_hit)
+{
+	if (!quadric_bounds_hit(q, o, d, tmin, tmax))
+		return false;
+	const V3 lo_ = v3(((q.inv[0] * o.x + q.inv[1] * o.y) + q.inv[2] * o.z) + q.inv[3], ((q.inv[4] * o.x + q.inv[5] * o.y) + q.inv[6] * o.z) + q.inv[7],
+					  ((q.inv[8] * o.x + q.inv[9] * o.y) + q.inv[10] * o.z) + q.inv[11]);
+	const V3 ld	 = v3((q.inv[0] * d.x + q.inv[1] * d.y) + q.inv[2] * d.z, (q.inv[4] * d.x + q.inv[5] * d.y) + q.inv[6] * d.z, (q.inv[8] * d.x + q.inv[9] * d.y) + q.inv[10] * d.z);
+	// BoundingBox::intersectsRange of Ray(local_org, local_dir): MinT = PR_EPSILON, MaxT = inf (Ray.h:25-26, BoundingBox.cpp:50-70)
+	const float ix = 1.0f / ld.x, iy = 1.0f / ld.y, iz = 1.0f / ld.z;
+	const float ax = ix * (q.lo[0] - lo_.x), bx = ix * (q.hi[0] - lo_.x);
+	const float ay = iy * (q.lo[1] - lo_.y), by = iy * (q.hi[1] - lo_.y);
+	const float az = iz * (q.lo[2] - lo_.z), bz = iz * (q.hi[2] - lo_.z);
+	float entry = std_min(ax, bx), exit_ = std_max(ax, bx);
+	entry = std_max(std_min(ay, by), entry);
+	exit_ = std_min(std_max(ay, by), exit_);
+	entry = std_max(std_min(az, bz), entry);
+	exit_ = std_min(std_max(az, bz), exit_);
+	entry = std_max(1.1920929e-07f, entry);
+	exit_ = std_min(INFINITY, exit_);
+	if (entry < 0)
+		entry = 0;
+	float t;
+	if (!quadric_roots(q.p, lo_ + ld * entry, ld, t))
+		return false;
+	if (any)
+		return true;
+	t += entry;
+	if (t > exit_)
+		return false;
+	// Ray::transformDistance (Ray.h:93-100): the length of the displacement back in world space, compared with the ray's extent;
+	// the distance STORED is the local parameter (quadric.cpp:185) -- the same number for an affine map, up to rounding
+	const V3 dt		= ld * t;
+	const V3 w		= v3((m[0] * dt.x + m[1] * dt.y) + m[2] * dt.z, (m[4] * dt.x + m[5] * dt.y) + m[6] * dt.z, (m[8] * dt.x + m[9] * dt.y) + m[10] * dt.z);
+	const float gt	= sqrtf((w.x * w.x + w.y * w.y) + w.z * w.z);
+	if (!(gt >= tmin && gt <= tmax))
+		return false;
+	t_hit = t;
+	return true;
+}
+__device__ __forceinline__ V3 quadric_gradient(const float* p, V3 x)
+{
+	return v3(((2 * p[0] * x.x + p[3] * x.y) + p[4] * x.z) + p[6], ((p[3] * x.x + 2 * p[1] * x.y) + p[5] * x.z) + p[7], ((p[4] * x.x + p[5] * x.y) + 2 * p[2] * x.z) + p[8]);
+}
+
 // slab test against a padded box; entry <= limit keeps equal-t ties reachable
 __device__ __forceinline__ bool box_hit(const RayPre& r, const float* lo, const float* hi, float tmin, float limit, float& tentry)
 {
@@ -1265,8 +1368,11 @@ struct DevLpe { // lives in device memory (PathState::lpe)
 	uint8_t tables[PRGPU_LPE_MAX * LPE_TABLE_BYTES]; // per expression next[state * 15 + symbol] (0xFF: the path can no longer match), then accepting[state];
 													 // symbol = scattering type * 3 + event (LightPathToken.h:6-20)
 };
-__device__ __forceinline__ uint32_t lpe_step(const DevLpe& L, uint32_t packed, uint32_t symbol)
+// (pointer, not reference: a reference parameter is `dereferenceable` to the optimiser, which may then hoist the table loads above the
+// caller's null check -- the top kernel variant also runs scenes without expressions, PathState::lpe == nullptr)
+__device__ __forceinline__ uint32_t lpe_step(const DevLpe* Lp, uint32_t packed, uint32_t symbol)
 {
+	const DevLpe& L = *Lp;
 	uint32_t out = 0;
 	for (uint32_t k = 0; k < L.n; ++k) {
 		const uint32_t st = (packed >> (8u * k)) & 0xFFu;
@@ -1275,8 +1381,9 @@ __device__ __forceinline__ uint32_t lpe_step(const DevLpe& L, uint32_t packed, u
 	}
 	return out;
 }
-__device__ __forceinline__ uint32_t lpe_accepting(const DevLpe& L, uint32_t packed) // bit k: expression k matches the path as it stands
+__device__ __forceinline__ uint32_t lpe_accepting(const DevLpe* Lp, uint32_t packed) // bit k: expression k matches the path as it stands
 {
+	const DevLpe& L = *Lp;
 	uint32_t mask = 0;
 	for (uint32_t k = 0; k < L.n; ++k) {
 		const uint32_t st = (packed >> (8u * k)) & 0xFFu;

@@ -446,6 +446,21 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 		g.uv[0] = g.uv[1] = 0.0f; // Spherical::uv_from_normal is not built (validate rejects textured materials on spheres)
 		return;
 	}
+	if ((FEATS & FEAT_QUADRICS) && E.kind == PRGPU_ENTITY_QUADRIC) { // QuadricEntity::provideGeometryPoint (quadric.cpp:95-108)
+		const DevQuadric& Q = sc.quadrics[E.quadric];
+		const V3 L = v3(((Q.inv[0] * P.x + Q.inv[1] * P.y) + Q.inv[2] * P.z) + Q.inv[3], ((Q.inv[4] * P.x + Q.inv[5] * P.y) + Q.inv[6] * P.z) + Q.inv[7],
+						((Q.inv[8] * P.x + Q.inv[9] * P.y) + Q.inv[10] * P.z) + Q.inv[11]);
+		g.N = mat3_mul(E.nm, normalized(quadric_gradient(Q.p, L))); // not normalised again (as there)
+		frame_duff(g.N, g.Nx, g.Ny);
+		g.Nx	   = normalized(g.Nx);
+		g.Ny	   = normalized(g.Ny);
+		g.entity   = e;
+		g.prim	   = 0;
+		g.material = sc.tri_material[tri];
+		g.emission = E.emission;
+		g.uv[0] = g.uv[1] = 0.0f; // the callbacks report u = v = 0 (quadric.cpp:158-159)
+		return;
+	}
 	if ((FEATS & FEAT_PLANES) && E.kind == PRGPU_ENTITY_PLANE) { // PlaneEntity::provideGeometryPoint + cache() (plane.cpp:206-238)
 		const uint32_t t0 = E.first_tri; // (v0, v1, v3): x = v3 - v0, y = v1 - v0
 		const V3 v0 = load3(sc.positions, sc.indices[3 * t0]), v1 = load3(sc.positions, sc.indices[3 * t0 + 1]), v3p = load3(sc.positions, sc.indices[3 * t0 + 2]);
@@ -835,7 +850,7 @@ __device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState&
 	ps.flags[slot]	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA | (has_ray ? 0u : FLAG_NO_RAY);
 	if (with_lpe && ps.lpe) { // the path starts with its camera token (direct.cpp:67)
 		const DevLpe& L	   = *ps.lpe;
-		L.state[slot]	   = lpe_step(L, 0u, LPE_SYM_CAMERA);
+		L.state[slot]	   = lpe_step(ps.lpe, 0u, LPE_SYM_CAMERA);
 		for (uint32_t k = 0; k < L.n; ++k) {
 			float* plane		 = L.iter[k];
 			plane[3 * pixel + 0] = 0.0f;
@@ -1482,7 +1497,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
 		float xyz[3];
 		uint32_t fb;
-		const uint32_t m_bg = with_lpe ? lpe_accepting(*ps.lpe, lpe_step(*ps.lpe, lpe, LPE_SYM_BACKGROUND)) : 0u; // ... B (direct.cpp:125, LightPath::createCB)
+		const uint32_t m_bg = with_lpe ? lpe_accepting(ps.lpe, lpe_step(ps.lpe, lpe, LPE_SYM_BACKGROUND)) : 0u; // ... B (direct.cpp:125, LightPath::createCB)
 		if (depth == 0) { // IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53): one fragment per non-delta infinite light
 			atomicAdd(&bs.v[PRGPU_STAT_CAMERA_DEPTH], 1u);
 			bool illuminated = false;
@@ -1599,7 +1614,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const Blob mis		 = (hf * p0) / ((power_mis ? wvl_pdf * wvl_pdf : wvl_pdf) * denom);
 					fb					 = fragment_value(sc, mis, throughput, grp_imp, radiance, mono, cie, blend, xyz);
 				}
-				apply_fragment(ps, pixel, entry, fb, xyz, with_lpe ? lpe_accepting(*ps.lpe, lpe_step(*ps.lpe, lpe, LPE_SYM_EMISSIVE)) : 0u); // ... E (direct.cpp:387,409)
+				apply_fragment(ps, pixel, entry, fb, xyz, with_lpe ? lpe_accepting(ps.lpe, lpe_step(ps.lpe, lpe, LPE_SYM_EMISSIVE)) : 0u); // ... E (direct.cpp:387,409)
 			}
 			if (!cfg.emissive_scatter)
 				go_on = false;
@@ -1698,7 +1713,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 							want_shadow = true;
 							sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
 							sh_d		= make_float4(L.x, L.y, L.z, INFINITY); // distance = PR_INF (direct.cpp:329)
-							const uint32_t m_nee = with_lpe ? lpe_accepting(*ps.lpe, lpe_step(*ps.lpe, lpe_step(*ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)), LPE_SYM_BACKGROUND)) : 0u; // direct.cpp:338-342
+							const uint32_t m_nee = with_lpe ? lpe_accepting(ps.lpe, lpe_step(ps.lpe, lpe_step(ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)), LPE_SYM_BACKGROUND)) : 0u; // direct.cpp:338-342
 							sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8) | (m_nee << 16)));
 						} else {
 							apply_fragment(ps, pixel, entry, fb_occ, xyz_occ);
@@ -1800,7 +1815,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 						want_shadow = true;
 						sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
 						sh_d		= make_float4(L.x, L.y, L.z, distance);
-						const uint32_t m_nee = with_lpe ? lpe_accepting(*ps.lpe, lpe_step(*ps.lpe, lpe_step(*ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)), LPE_SYM_EMISSIVE)) : 0u; // direct.cpp:338-345
+						const uint32_t m_nee = with_lpe ? lpe_accepting(ps.lpe, lpe_step(ps.lpe, lpe_step(ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)), LPE_SYM_EMISSIVE)) : 0u; // direct.cpp:338-345
 						sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8) | (m_nee << 16)));
 					} else {
 						apply_fragment(ps, pixel, entry, fb_occ, xyz_occ);
@@ -1875,7 +1890,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				}
 				const V3 L = normalized(from_tangent_space(N, gp.Nx, gp.Ny, Lt));
 				if (with_lpe)
-					lpe = lpe_step(*ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)); // mCameraPath.addToken(sout.Type) (direct.cpp:197)
+					lpe = lpe_step(ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)); // mCameraPath.addToken(sout.Type) (direct.cpp:197)
 				flags	 = sampleDelta ? (flags | FLAG_LAST_DELTA) : (flags & ~FLAG_LAST_DELTA);
 				prev_pdf = path_pdf;
 				path_pdf = path_pdf * (pdf_s * scatProb);
@@ -1939,7 +1954,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 	if (i < n_active) {
 		slot = active ? active[i] : slot_base + i;
 		if (sc.features)
-			shade_vertex<(FEAT_ALL & ~FEAT_LPE)>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz); // light path expressions run in the persistent pipeline only
+			shade_vertex<(FEAT_ALL & ~(FEAT_LPE | FEAT_QUADRICS))>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz); // light path expressions and quadric entities run in the persistent pipeline only
 		else
 			shade_vertex<0u>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 	}
@@ -2521,6 +2536,22 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				trav_begin(s, st, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, any ? rd.w - 0.001f : rd.w, sc.eps_t); // tfar rule: Scene.cpp:275
 				s.any	= any;
 				has_ray = true;
+				if (FEATS & FEAT_QUADRICS) { // the scene's quadric entities, once per ray: a hit bounds the BVH walk, an occluded shadow ray skips it
+					for (uint32_t k = 0; k < sc.n_quadrics; ++k) {
+						const DevQuadric& Q = sc.quadrics[k];
+						float tq;
+						if (quadric_hit(Q, sc.entities[Q.entity].m, s.r.o, s.r.d, s.tmin, s.best.t, any, tq)) {
+							if (any) { // occluded: nothing in the BVH is reachable any more, the root step ends the ray (REC_EMPTY must not
+									   // enter the step loop: it carries the leaf bit)
+								s.best.tri = Q.tri;
+								s.best.t   = -INFINITY;
+								break;
+							}
+							if (tq < s.best.t || (tq == s.best.t && Q.tri < s.best.tri))
+								s.best = Hit{ tq, 0.0f, 0.0f, Q.tri };
+						}
+					}
+				}
 #if PR_SPLIT
 				sh.lane_entry[threadIdx.x] = my_entry;
 				__hip_atomic_store(&sh.best[threadIdx.x], ((unsigned long long)__float_as_uint(s.best.t) << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -3068,7 +3099,7 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 #endif // PR_TU == 0
 
 // ---- persistent path kernel: one translation unit per kernel (feature-mask variant x {3, 2 waves per SIMD} x {plain, instrumented}) ----
-[[maybe_unused]] constexpr uint32_t FEAT_NO_LPE = FEAT_ALL & ~FEAT_LPE, FEAT_NO_ROUGH = FEAT_NO_LPE & ~FEAT_ROUGH_MATERIALS;
+[[maybe_unused]] constexpr uint32_t FEAT_NO_LPE = FEAT_ALL & ~(FEAT_LPE | FEAT_QUADRICS), FEAT_NO_ROUGH = FEAT_NO_LPE & ~FEAT_ROUGH_MATERIALS; // quadric entities ride in the top variant
 #define PR_PP_DECL(V, S) void launch_pp_##V##_##S(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st);
 #define PR_PP_DECL4(V) PR_PP_DECL(V, 0) PR_PP_DECL(V, 1) PR_PP_DECL(V, 2) PR_PP_DECL(V, 3)
 PR_PP_DECL4(1) PR_PP_DECL4(2) PR_PP_DECL4(3) PR_PP_DECL4(4) PR_PP_DECL4(5)
@@ -3165,7 +3196,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	static const LaunchFn table[5][4] = { { launch_pp_1_0, launch_pp_1_1, launch_pp_1_2, launch_pp_1_3 }, { launch_pp_2_0, launch_pp_2_1, launch_pp_2_2, launch_pp_2_3 },
 										   { launch_pp_3_0, launch_pp_3_1, launch_pp_3_2, launch_pp_3_3 }, { launch_pp_4_0, launch_pp_4_1, launch_pp_4_2, launch_pp_4_3 },
 										   { launch_pp_5_0, launch_pp_5_1, launch_pp_5_2, launch_pp_5_3 } };
-	const int variant = (sc.features & FEAT_LPE) ? 4
+	const int variant = (sc.features & (FEAT_LPE | FEAT_QUADRICS)) ? 4
 						: (sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3)));
 	table[variant][(occupancy >= 3 ? 0 : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
 }

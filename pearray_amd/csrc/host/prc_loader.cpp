@@ -1076,8 +1076,78 @@ struct Loader {
 			out.entities.push_back(e);
 			return;
 		}
+		if (type == "quadric" || type == "cone" || type == "cylinder") { // QuadricEntityPlugin::create (quadric.cpp:252-316)
+			note_visibility_flags(g);
+			prgpu_entity e;
+			std::memset(&e, 0, sizeof(e));
+			e.first_tri = (uint32_t)(out.indices.size() / 3);
+			e.n_tris	= 1;
+			e.emission	= PRGPU_INVALID_ID;
+			if (g.get("emission"))
+				fail(PRGPU_EUNSUPPORTED, where(g) + ": emissive " + type + " entities are not supported (the reference's sampler for them is a stub with pdf 0)");
+			float q[16] = { 0 };
+			if (type == "quadric") {
+				const Value* pv = g.get("parameters");
+				std::vector<float> qp;
+				if (pv && pv->type == Value::GROUP && pv->g->is_array && pv->g->all_numbers())
+					for (size_t i = 0; i < pv->g->anonymous_count(); ++i)
+						qp.push_back((float)pv->g->at(i).number());
+				if (qp.size() == 3 || qp.size() == 4) {
+					q[0] = qp[0], q[1] = qp[1], q[2] = qp[2];
+					q[9] = qp.size() == 4 ? qp[3] : 0.0f;
+				} else if (qp.size() == 10) {
+					std::copy(qp.begin(), qp.end(), q);
+				} else {
+					fail(PRGPU_EINVAL, where(g) + ": invalid quadric parameters given (3, 4 or 10 numbers)"); // quadric.cpp:308-310
+				}
+				float lo[3] = { -1, -1, -1 }, hi[3] = { 1, 1, 1 };
+				(void)get_vec3(g, "min", lo);
+				(void)get_vec3(g, "max", hi);
+				for (int k = 0; k < 3; ++k) {
+					q[10 + k] = lo[k];
+					q[13 + k] = hi[k];
+				}
+			} else {
+				const float radius = (float)get_number(g, "radius", 1.0), height = (float)get_number(g, "height", 1.0);
+				const bool center  = get_bool(g, "center_on", true);
+				if (!(radius > 0) || !(height > 0))
+					fail(PRGPU_EINVAL, where(g) + ": " + type + " :radius and :height must be positive");
+				const float a2 = 1 / (radius * radius);
+				q[0] = q[1] = a2;
+				if (type == "cylinder") {
+					q[9] = -1.0f;
+				} else {
+					q[2] = -(1 / (height * height));
+					if (center) {
+						q[8] = 1 / height;
+						q[9] = -0.25f;
+					}
+				}
+				q[10] = q[11] = -radius;
+				q[13] = q[14] = radius;
+				q[12] = center ? -height / 2 : 0.0f;
+				q[15] = center ? height / 2 : height;
+			}
+			e.kind	 = PRGPU_ENTITY_QUADRIC;
+			e.params = (uint32_t)out.tables.size();
+			out.tables.insert(out.tables.end(), q, q + 16);
+			transform_of(g, e.transform);
+			const Value* mv = g.get("material");
+			uint32_t mat	= PRGPU_INVALID_ID;
+			if (mv && mv->type == Value::STRING) {
+				const auto it = material_ids.find(mv->s);
+				mat			  = it == material_ids.end() ? PRGPU_INVALID_ID : it->second;
+			}
+			const uint32_t base = (uint32_t)(out.positions.size() / 3);
+			out.positions.insert(out.positions.end(), 9, 0.0f); // placeholder triangle: one point, never hit
+			for (uint32_t i = 0; i < 3; ++i)
+				out.indices.push_back(base + i);
+			out.tri_material.push_back(mat);
+			out.entities.push_back(e);
+			return;
+		}
 		if (type != "mesh")
-			fail(PRGPU_EUNSUPPORTED, where(g) + ": entity type '" + type + "' is not supported (mesh, plane and sphere are; tessellate other primitives)");
+			fail(PRGPU_EUNSUPPORTED, where(g) + ": entity type '" + type + "' is not supported (mesh, plane, sphere, quadric, cone and cylinder are; tessellate other primitives)");
 		note_visibility_flags(g);
 		const auto mit = meshes.find(get_string(g, "mesh", ""));
 		if (mit == meshes.end())

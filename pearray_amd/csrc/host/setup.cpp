@@ -280,6 +280,7 @@ void cie_xyz(float wl, float xyz[3])
 void entity_tables(const prgpu_scene_desc* d, HostTables& t)
 {
 	t.entities.resize(d->n_entities);
+	t.quadrics.clear();
 	t.tri_entity.resize(d->n_triangles);
 	for (uint32_t e = 0; e < d->n_entities; ++e) {
 		const prgpu_entity& src = d->entities[e];
@@ -300,6 +301,39 @@ void entity_tables(const prgpu_scene_desc* d, HostTables& t)
 		E.kind		  = src.kind;
 		E.has_uvs	  = (src.has_uvs && d->uvs && src.kind == PRGPU_ENTITY_MESH) ? 1u : 0u;
 		E.sphere_r	  = 0.0f;
+		E.quadric	  = 0u;
+		if (src.kind == PRGPU_ENTITY_QUADRIC) { // QuadricEntity (quadric.cpp:28-38): local box grown by BBOX_EPS, world box of its corners
+			prd::DevQuadric Q;
+			std::memset(&Q, 0, sizeof(Q));
+			const float* q = d->spectral_tables + src.params;
+			for (int k = 0; k < 10; ++k)
+				Q.p[k] = q[k];
+			for (int r = 0; r < 3; ++r) {
+				Q.lo[r] = q[10 + r] - 1e-4f;
+				Q.hi[r] = q[13 + r] + 1e-4f;
+			}
+			for (int r = 0; r < 3; ++r) { // Transformf::inverse: linear^-1 = nm^T, translation = -linear^-1 * t
+				for (int c2 = 0; c2 < 3; ++c2)
+					Q.inv[4 * r + c2] = E.nm[3 * c2 + r];
+				Q.inv[4 * r + 3] = -((Q.inv[4 * r] * m[3] + Q.inv[4 * r + 1] * m[7]) + Q.inv[4 * r + 2] * m[11]);
+			}
+			for (int r = 0; r < 3; ++r) {
+				Q.wlo[r] = INFINITY;
+				Q.whi[r] = -INFINITY;
+			}
+			for (int corner = 0; corner < 8; ++corner) {
+				const float c[3] = { (corner & 1) ? Q.hi[0] : Q.lo[0], (corner & 2) ? Q.hi[1] : Q.lo[1], (corner & 4) ? Q.hi[2] : Q.lo[2] };
+				for (int r = 0; r < 3; ++r) {
+					const float w = ((m[4 * r] * c[0] + m[4 * r + 1] * c[1]) + m[4 * r + 2] * c[2]) + m[4 * r + 3];
+					Q.wlo[r]	  = std::min(Q.wlo[r], w);
+					Q.whi[r]	  = std::max(Q.whi[r], w);
+				}
+			}
+			Q.tri	  = src.first_tri;
+			Q.entity  = e;
+			E.quadric = (uint32_t)t.quadrics.size();
+			t.quadrics.push_back(Q);
+		}
 		if (src.kind == PRGPU_ENTITY_SPHERE) { // sphere.cpp:77-92: radius * mean column norm of the linear part
 			auto col_norm = [&](int j) { return std::sqrt((m[j] * m[j] + m[4 + j] * m[4 + j]) + m[8 + j] * m[8 + j]); };
 			E.sphere_r	  = src.radius * (((col_norm(0) + col_norm(1)) + col_norm(2)) / 3.0f);
@@ -526,6 +560,8 @@ void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 {
 	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (uint32_t tri = 0; tri < d->n_triangles; ++tri) {
+		if (t.entities[t.tri_entity[tri]].kind == PRGPU_ENTITY_QUADRIC)
+			continue; // the placeholder point is not part of the entity's box
 		for (int k = 0; k < 3; ++k) {
 			float w[3];
 			world_vertex(d, t, tri, k, w);
@@ -535,6 +571,11 @@ void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 			}
 		}
 	}
+	for (const prd::DevQuadric& Q : t.quadrics) // an entity's world box is what the scene's bounds combine (Scene.cpp:107-118)
+		for (int r = 0; r < 3; ++r) {
+			lo[r] = std::min(lo[r], Q.wlo[r]);
+			hi[r] = std::max(hi[r], Q.whi[r]);
+		}
 	const float fu = (hi[0] * hi[0] + hi[1] * hi[1]) + hi[2] * hi[2], fl = (lo[0] * lo[0] + lo[1] * lo[1]) + lo[2] * lo[2];
 	float radius = fu > 0 ? std::sqrt(fu) : 0.0f;
 	if (fl > radius * radius)
@@ -913,8 +954,23 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 			return bad("material index out of range");
 	for (uint32_t e = 0; e < d->n_entities; ++e) {
 		const prgpu_entity& E = d->entities[e];
-		if (E.kind > PRGPU_ENTITY_SPHERE)
+		if (E.kind > PRGPU_ENTITY_QUADRIC)
 			return bad("unknown entity kind");
+		if (E.kind == PRGPU_ENTITY_QUADRIC) {
+			if (E.n_tris != 1 || uint64_t(E.params) + 16u > d->n_spectral_table_values)
+				return bad("a quadric entity is one placeholder triangle and 16 floats (A..J, box min, box max) in spectral_tables");
+			const float* q = d->spectral_tables + E.params;
+			for (int k = 0; k < 16; ++k)
+				if (!std::isfinite(q[k]))
+					return bad("quadric parameters must be finite");
+			if (!(q[10] <= q[13] && q[11] <= q[14] && q[12] <= q[15]))
+				return bad("quadric box: min must not exceed max");
+			const uint32_t* ix = d->indices + 3 * size_t(E.first_tri);
+			if (ix[0] != ix[1] && std::memcmp(d->positions + 3 * size_t(ix[0]), d->positions + 3 * size_t(ix[1]), 12) != 0)
+				return bad("the placeholder triangle of a quadric entity must be degenerate (one point)");
+			if (E.emission != PRGPU_INVALID_ID)
+				return bad("emissive quadric entities are not supported (the reference's sampler for them is a stub with pdf 0)", PRGPU_EUNSUPPORTED);
+		}
 		if (E.kind == PRGPU_ENTITY_SPHERE && (E.n_tris != 1 || !(E.radius > 0)))
 			return bad("a sphere entity is one placeholder triangle and a positive radius");
 		if (E.kind == PRGPU_ENTITY_PLANE && E.n_tris != 2)

@@ -23,6 +23,7 @@ struct HostTables {
 	std::vector<prd::DevInfLight> inf_lights;
 	std::vector<float> sky_cdf; // Distribution2D tables of the SKY lights (DevInfLight::dist_offset)
 	std::vector<prd::DevShapeLight> shape_lights; // per entity; empty when no plane / sphere emits
+	std::vector<prd::DevQuadric> quadrics;		  // quadric entities
 	float scene_radius = 0.0f;
 	std::vector<float> wl_cdf;
 	float wl_u_offset = 0.0f, wl_u_scale = 1.0f; // cie mapper: truncation window inside the CDF (CIE.h:124-134)

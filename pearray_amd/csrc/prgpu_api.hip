@@ -355,7 +355,13 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.shape_lights	 = nullptr;
 	if (!t.shape_lights.empty())
 		UP(sc.shape_lights, t.shape_lights);
+	sc.quadrics	  = nullptr;
+	sc.n_quadrics = (uint32_t)t.quadrics.size();
+	if (!t.quadrics.empty())
+		UP(sc.quadrics, t.quadrics);
 	sc.features		 = d->n_lights ? prd::FEAT_INFINITE_LIGHTS : 0u;
+	if (!t.quadrics.empty())
+		sc.features |= prd::FEAT_QUADRICS;
 	if (!t.shape_lights.empty())
 		sc.features |= prd::FEAT_SHAPE_LIGHTS;
 	for (uint32_t i = 0; i < d->n_spectra; ++i)
@@ -489,6 +495,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		else
 			return fail(PRGPU_EINVAL, "PRGPU_MODE must be lockstep, streaming or persistent");
 	}
+	if ((s->sc.features & prd::FEAT_QUADRICS) && s->mode != prgpu_scene::PERSISTENT)
+		return fail(PRGPU_EUNSUPPORTED, "quadric entities are traced by the persistent pipeline only");
 	if (const char* env = getenv("PRGPU_PP_SLOTS"))
 		s->pp_slots = (uint32_t)std::max(256, atoi(env));
 	if (const char* env = getenv("PRGPU_PP_OCCUPANCY"))
@@ -1277,6 +1285,8 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 		return fail(PRGPU_EINVAL, "null argument");
 	if (n == 0)
 		return PRGPU_OK;
+	if (s->sc.features & prd::FEAT_QUADRICS)
+		return fail(PRGPU_EUNSUPPORTED, "the ray service does not trace quadric entities");
 	HIP_TRY(hipSetDevice(s->device));
 	float *d_org = nullptr, *d_dir = nullptr, *d_tmin = nullptr, *d_tmax = nullptr, *d_u = nullptr, *d_v = nullptr, *d_t = nullptr;
 	uint32_t *d_e = nullptr, *d_p = nullptr;
@@ -1338,6 +1348,8 @@ int prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* d
 		return fail(PRGPU_EINVAL, "null argument");
 	if (n == 0)
 		return PRGPU_OK;
+	if (s->sc.features & prd::FEAT_QUADRICS)
+		return fail(PRGPU_EUNSUPPORTED, "the ray service does not trace quadric entities");
 	HIP_TRY(hipSetDevice(s->device));
 	float *d_org = nullptr, *d_dir = nullptr, *d_tmin = nullptr, *d_dist = nullptr;
 	uint8_t* d_occ = nullptr;

@@ -297,6 +297,35 @@ class SceneBuilder:
         self.entities[e].radius = float(radius)
         return e
 
+    def add_quadric(self, material, parameters, box_min=(-1, -1, -1), box_max=(1, 1, 1), transform=IDENTITY):
+        """(entity :type 'quadric' :parameters [A..J] :min :max), quadric.cpp:296-313: 3, 4 or 10 coefficients"""
+        q = [float(v) for v in parameters]
+        if len(q) == 3:
+            q = q + [0.0] * 7
+        elif len(q) == 4:
+            q = q[:3] + [0.0] * 6 + q[3:]
+        assert len(q) == 10, "3, 4 or 10 quadric parameters"
+        e = self.add_mesh([[0, 0, 0], [0, 0, 0], [0, 0, 0]], [[0, 1, 2]], material, transform=transform)   # placeholder: degenerate, never hit
+        self.entities[e].kind = abi.ENTITY_QUADRIC
+        self.entities[e].params = len(self.tables)
+        self.tables.extend(float(np.float32(v)) for v in q + list(box_min) + list(box_max))
+        return e
+
+    def add_cylinder(self, material, radius=1.0, height=1.0, center_on=True, transform=IDENTITY):
+        """(entity :type 'cylinder'), quadric.cpp:255-272"""
+        r, h = np.float32(radius), np.float32(height)
+        a2 = np.float32(1) / (r * r)
+        z0, z1 = (-h / np.float32(2), h / np.float32(2)) if center_on else (np.float32(0), h)
+        return self.add_quadric(material, [a2, a2, 0, 0, 0, 0, 0, 0, 0, -1], (-r, -r, z0), (r, r, z1), transform)
+
+    def add_cone(self, material, radius=1.0, height=1.0, center_on=True, transform=IDENTITY):
+        """(entity :type 'cone'), quadric.cpp:273-294"""
+        r, h = np.float32(radius), np.float32(height)
+        a2, h2 = np.float32(1) / (r * r), np.float32(1) / (h * h)
+        if center_on:
+            return self.add_quadric(material, [a2, a2, -h2, 0, 0, 0, 0, 0, np.float32(1) / h, -0.25], (-r, -r, -h / np.float32(2)), (r, r, h / np.float32(2)), transform)
+        return self.add_quadric(material, [a2, a2, -h2, 0, 0, 0, 0, 0, 0, 0], (-r, -r, 0), (r, r, h), transform)
+
     def set_camera(self, transform, width=1.0, height=1.0, near=1e-6, far=float("inf"), local_direction=(0, 0, 1),
                    local_right=(1, 0, 0), local_up=(0, 1, 0), fstop=0.0, aperture_radius=0.05, ortho=False):
         c = self.camera
@@ -460,10 +489,15 @@ def save_scene_npz(path, desc, drop_sky_tables=True):
             if sp.kind in (abi.SPEC_TABLE, abi.SPEC_SELLMEIER):
                 sp.table_offset = shift(sp.table_offset)
         tables = tables[keep]
+    entities = [abi.Entity.from_buffer_copy(C.string_at(C.addressof(desc.entities[i]), C.sizeof(abi.Entity))) for i in range(desc.n_entities)]
+    if drop_sky_tables:
+        for en in entities:
+            if en.kind == abi.ENTITY_QUADRIC:
+                en.params = shift(en.params)
     out["tables"] = tables
     for name, count, cls in _STRUCT_ARRAYS:
         n = getattr(desc, count)
-        src = lights if name == "lights" else (spectra if name == "spectra" else [getattr(desc, name)[i] for i in range(n)])
+        src = lights if name == "lights" else (spectra if name == "spectra" else (entities if name == "entities" else [getattr(desc, name)[i] for i in range(n)]))
         out[name] = np.frombuffer(b"".join(C.string_at(C.addressof(x), C.sizeof(cls)) for x in src), dtype=np.uint8).copy()
     np.savez_compressed(path, **out)
 

@@ -104,6 +104,11 @@ def bind(lib):
     lib.orc_normal_matrix.argtypes = [_F32P, _F32P, _F32P]
     lib.orc_lambert_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _F32P, _F32P, _F32P]
     lib.orc_lambert_sample.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, C.c_float, C.c_float, _F32P, _F32P, _F32P]
+    lib.orc_quadric_intersect.argtypes = [_F32P, _F32P, _F32P, _F32P]
+    lib.orc_quadric_normal.argtypes = [_F32P, _F32P, _F32P]
+    lib.orc_quadric_closest.restype = C.c_uint32
+    lib.orc_quadric_closest.argtypes = [C.c_void_p, _F32P, _F32P, C.c_float, C.c_float, _F32P]
+    lib.orc_quadric_occluded.argtypes = [C.c_void_p, _F32P, _F32P, C.c_float, C.c_float]
     lib.orc_ndf_ggx.restype = lib.orc_pdf_ggx.restype = lib.orc_mf_reflection.restype = C.c_float
     lib.orc_ndf_ggx.argtypes = lib.orc_pdf_ggx.argtypes = [_F32P, C.c_float, C.c_float, C.c_int]
     lib.orc_mf_reflection.argtypes = [C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _F32P, _F32P, C.c_float, C.c_float]

@@ -117,7 +117,7 @@ def test_defaults_follow_the_reference():
 
 
 @pytest.mark.parametrize("block,code,needle", [
-    ("(entity :name 's' :type 'cone' :radius 1)", -4, "entity type 'cone'"),
+    ("(entity :name 's' :type 'subdiv' :mesh 'm')", -4, "entity type 'subdiv'"),
     ("(entity :name 's' :type 'sphere' :emission 'nope')", -1, "unknown emission"),
     ("(material :name 'g' :type 'glass' :roughness 'tex')", -4, "must be a number"),
     ("(material :name 'g' :type 'ward')", -4, "material type 'ward'"),
@@ -212,7 +212,7 @@ def test_every_reference_example_either_loads_or_names_what_is_missing():
             msg = lib.prgpu_prc_last_error().decode()
             assert "not supported" in msg or "not available" in msg or "needs the table" in msg, name
             refused.append(name)
-    assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and "complex.prc" in loaded and "material_array.prc" in loaded and "sky.prc" in loaded and "skylens.prc" in loaded and len(loaded) >= 16
+    assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and "complex.prc" in loaded and "material_array.prc" in loaded and "sky.prc" in loaded and "skylens.prc" in loaded and "box.prc" in loaded and "quadric_showcase.prc" in loaded and len(loaded) >= 18
 
 
 def test_obj_embed_semantics(tmp_path):

@@ -1,4 +1,4 @@
-"""Every reference example the loader accepts (15 of examples/*.prc next to complex.prc = BASELINE config C5, which has its own fixture and tests; `vcm` / `ao` integrators replaced by `direct`), reduced to array
+"""Every reference example the loader accepts (17 of examples/*.prc next to complex.prc = BASELINE config C5, which has its own fixture and tests; `vcm` / `ao` integrators replaced by `direct`), reduced to array
 fixtures by tools/make_example_fixtures.py (the reference's files do not travel to the GPU box): the HIP path renders each one and is
 compared with the checker -- hit ids, sample / feedback planes and statistics exact, XYZ bit for bit where the pixel filter has a single
 live tap.  CPU: the fixtures are current (equal to a fresh conversion where the reference checkout exists) and the checker renders them."""
@@ -37,7 +37,7 @@ def single_tap(sc):
 
 
 def test_there_is_a_fixture_for_every_example_the_loader_accepts():
-    assert len(FIXTURES) == 15 and "cornellbox" in NAMES and "material_showcase" in NAMES and "skylens" in NAMES
+    assert len(FIXTURES) == 17 and "cornellbox" in NAMES and "material_showcase" in NAMES and "skylens" in NAMES
     if not os.path.isdir(REF_EXAMPLES):
         pytest.skip("reference checkout not present")
     import sys
