@@ -66,8 +66,9 @@ struct DevEntity {
 	float vol_scale, world_area;
 	uint32_t light_id, kind; // kind: PRGPU_ENTITY_*
 	float sphere_r;			 // SPHERE: world radius (sphere.cpp:77-92); the centre is the translation (m[3], m[7], m[11])
-	uint32_t has_uvs;		 // MESH: texture coordinates present (interpolated uv, UV-derived tangent frame)
-	uint32_t quadric;		 // QUADRIC: index into DevScene::quadrics
+	uint32_t has_uvs;		 // MESH: texture coordinates present (interpolated uv, UV-derived tangent frame); QUADRIC: index into DevScene::quadrics
+							 // (no field of its own: the record's size and the argument block's layout feed the register allocation of every variant --
+							 // one more word here cost the C5 kernel 29 more spilled registers and 2 %)
 };
 
 constexpr uint32_t FEAT_DELTA_MATERIALS = 1u, FEAT_INFINITE_LIGHTS = 2u, FEAT_PLANES = 4u, FEAT_SPHERES = 8u, FEAT_AOVS = 16u, FEAT_SHAPE_LIGHTS = 32u, FEAT_TEXTURES = 64u,
@@ -169,8 +170,6 @@ struct DevScene {
 	uint32_t n_lights; // area lights; the infinite lights follow them in light_cdf
 	const DevInfLight* inf_lights;
 	const DevShapeLight* shape_lights; // per entity, or null when no plane / sphere emits
-	const DevQuadric* quadrics;		   // quadric entities, or null
-	uint32_t n_quadrics;
 	uint32_t n_inf_lights;
 	const float* sky_cdf; // Distribution2D tables of the SKY lights (DevInfLight::dist_offset), or null
 	float scene_radius; // origin-centred bounding sphere (Scene.cpp:107-118)
@@ -191,6 +190,8 @@ struct DevScene {
 	uint32_t single_tap; // filter has exactly one weight > eps (the centre): splat is per-pixel
 	float centre_weight;
 	float eps_t; // slab-test slack: 8e-6 * max |coordinate| over world vertices and the camera origin
+	const DevQuadric* quadrics; // quadric entities, or null (last: see DevEntity::has_uvs)
+	uint32_t n_quadrics;
 };
 
 // Per-path state, SoA, indexed by slot (= position of the pixel in the Morton-ordered owned list).

@@ -447,7 +447,7 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 		return;
 	}
 	if ((FEATS & FEAT_QUADRICS) && E.kind == PRGPU_ENTITY_QUADRIC) { // QuadricEntity::provideGeometryPoint (quadric.cpp:95-108)
-		const DevQuadric& Q = sc.quadrics[E.quadric];
+		const DevQuadric& Q = sc.quadrics[E.has_uvs];
 		const V3 L = v3(((Q.inv[0] * P.x + Q.inv[1] * P.y) + Q.inv[2] * P.z) + Q.inv[3], ((Q.inv[4] * P.x + Q.inv[5] * P.y) + Q.inv[6] * P.z) + Q.inv[7],
 						((Q.inv[8] * P.x + Q.inv[9] * P.y) + Q.inv[10] * P.z) + Q.inv[11]);
 		g.N = mat3_mul(E.nm, normalized(quadric_gradient(Q.p, L))); // not normalised again (as there)

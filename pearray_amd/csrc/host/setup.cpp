@@ -301,7 +301,6 @@ void entity_tables(const prgpu_scene_desc* d, HostTables& t)
 		E.kind		  = src.kind;
 		E.has_uvs	  = (src.has_uvs && d->uvs && src.kind == PRGPU_ENTITY_MESH) ? 1u : 0u;
 		E.sphere_r	  = 0.0f;
-		E.quadric	  = 0u;
 		if (src.kind == PRGPU_ENTITY_QUADRIC) { // QuadricEntity (quadric.cpp:28-38): local box grown by BBOX_EPS, world box of its corners
 			prd::DevQuadric Q;
 			std::memset(&Q, 0, sizeof(Q));
@@ -331,7 +330,7 @@ void entity_tables(const prgpu_scene_desc* d, HostTables& t)
 			}
 			Q.tri	  = src.first_tri;
 			Q.entity  = e;
-			E.quadric = (uint32_t)t.quadrics.size();
+			E.has_uvs = (uint32_t)t.quadrics.size(); // QUADRIC: the index of its record
 			t.quadrics.push_back(Q);
 		}
 		if (src.kind == PRGPU_ENTITY_SPHERE) { // sphere.cpp:77-92: radius * mean column norm of the linear part
