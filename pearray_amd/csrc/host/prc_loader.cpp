@@ -367,8 +367,126 @@ struct Loader {
 			}
 			return spectrum_sellmeier(b, c, (int)(n / 2));
 		}
-		fail(PRGPU_EUNSUPPORTED, "spectral expression " + where(e) + " is not supported (number, refl, illum, illuminant, spectrum, smul, lookup_index, checkerboard are)");
+		if (id == "spd") // SPDFilePlugin::create (node/SPDFileNode.cpp:20-91): an equidistant spectrum from a CSV file
+			return spectrum_spd_file(e);
+		fail(PRGPU_EUNSUPPORTED, "spectral expression " + where(e) + " is not supported (number, refl, illum, illuminant, spectrum, spd, smul, lookup_index, checkerboard are)");
 	}
+	// CSV::read (base/container/CSV.cpp:52-163): ',' or ';' separate, empty tokens are skipped, a first row with a non-number is the
+	// header, rows with another token count are dropped, tokens that are not numbers count as 0
+	static bool read_csv(const std::string& path, std::vector<float>& data, size_t& columns)
+	{
+		std::ifstream f(path);
+		if (!f)
+			return false;
+		auto split = [](const std::string& line, std::vector<std::string>& tokens, size_t limit) {
+			tokens.clear();
+			std::string token;
+			for (const char c : line) {
+				if (c == ',' || c == ';') {
+					if (!token.empty())
+						tokens.push_back(token);
+					token.clear();
+				} else {
+					token += c;
+				}
+				if (limit && tokens.size() == limit)
+					return;
+			}
+			if (!token.empty())
+				tokens.push_back(token);
+		};
+		auto number = [](const std::string& t, float& v) { // std::stof in the "C" locale: leading blanks, the longest valid prefix
+			char* end = nullptr;
+			errno	  = 0;
+			const float r = std::strtof(t.c_str(), &end);
+			if (end == t.c_str())
+				return false;
+			v = (errno == ERANGE && !std::isfinite(r)) ? 0.0f : r; // out of range: silently 0 (CSV.cpp:143-146)
+			return true;
+		};
+		std::string line;
+		std::getline(f, line);
+		if (!line.empty() && line.back() == '\r')
+			line.pop_back();
+		std::vector<std::string> tokens;
+		split(line, tokens, 0);
+		columns = tokens.size();
+		if (columns == 0)
+			return false;
+		data.clear();
+		bool header = false;
+		for (const std::string& t : tokens) {
+			float v;
+			if (!number(t, v))
+				header = true;
+		}
+		if (!header)
+			for (const std::string& t : tokens) {
+				float v = 0;
+				(void)number(t, v);
+				data.push_back(v);
+			}
+		while (std::getline(f, line)) {
+			if (!line.empty() && line.back() == '\r')
+				line.pop_back();
+			split(line, tokens, columns);
+			if (tokens.size() != columns)
+				continue; // malformed line: skipped
+			for (const std::string& t : tokens) {
+				float v = 0;
+				if (!number(t, v))
+					v = 0.0f;
+				data.push_back(v);
+			}
+		}
+		return true;
+	}
+	uint32_t spectrum_spd_file(const Group& e)
+	{
+		std::string file = get_string(e, "file", "");
+		if (file.empty() && e.anonymous_count() > 0 && e.at(0).type == Value::STRING)
+			file = e.at(0).s;
+		if (file.empty())
+			fail(PRGPU_EINVAL, where(e) + ": no file given for spd");
+		std::string path = file;
+		if (path[0] != '/' && !current_dir.empty())
+			path = current_dir + "/" + path;
+		std::vector<float> data;
+		size_t columns = 0;
+		if (!read_csv(path, data, columns))
+			fail(PRGPU_EIO, where(e) + ": spd file '" + path + "' is not valid");
+		const size_t rows = data.size() / columns;
+		if (columns <= 1 || rows < 2)
+			fail(PRGPU_EINVAL, where(e) + ": spd file '" + file + "' has not enough data");
+		const float delta = data[columns] - data[0], start = data[0], end = data[(rows - 1) * columns];
+		if (delta <= 1.1920929e-07f)
+			fail(PRGPU_EINVAL, where(e) + ": spd file '" + file + "' has invalid wavelengths");
+		size_t column = 1;
+		if (const Value* v = e.get("column"))
+			if (v->is_number())
+				column = (size_t)v->number();
+		if (e.anonymous_count() > 1 && e.at(1).is_number())
+			column = (size_t)e.at(1).number();
+		if (column >= columns) // the reference clamps to columnCount and then reads past the row (SPDFileNode.cpp:66,82): refused here
+			fail(PRGPU_EINVAL, where(e) + ": spd column " + std::to_string(column) + " does not exist in '" + file + "'");
+		float norm = 1.0f;
+		if (const Value* v = e.get("percentage"))
+			if (v->type == Value::BOOL)
+				norm = v->b ? (1 / 100.0f) : 1.0f;
+		if (e.anonymous_count() > 2 && e.at(2).type == Value::BOOL)
+			norm = e.at(2).b ? (1 / 100.0f) : 1.0f;
+		std::vector<float> values(rows);
+		bool uneven = false;
+		for (size_t i = 0; i < rows; ++i) {
+			if (std::fabs(data[i * columns] - (i * delta + start)) > 1.1920929e-07f)
+				uneven = true;
+			values[i] = data[i * columns + column] * norm; // spectrum_table clamps at zero like SPDFileNode.cpp:82
+		}
+		if (uneven)
+			warn(where(e) + ": spd file '" + file + "' has non equidistant data (read as equidistant, as in the reference)");
+		return spectrum_table(start, end, values.data(), rows);
+	}
+	std::string current_dir; // directory of the file being loaded (relative file names of spd nodes)
 	float string_default = 1.0f; // default of the parameter being parsed (for strings naming unknown nodes)
 	uint32_t spectral_param(const Group& g, std::initializer_list<const char*> keys, float def)
 	{
@@ -1630,6 +1748,7 @@ struct Loader {
 	}
 	void dispatch(const Group& b, const std::string& dir) // SceneLoader.cpp:162-198
 	{
+		current_dir = dir;
 		const std::string& id = b.id;
 		if (id == "include")
 			add_include(b, dir);

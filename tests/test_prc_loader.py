@@ -516,3 +516,45 @@ def test_mitsuba_serialized_embed_semantics(tmp_path, version, double, with_norm
     (tmp_path / "bad.serialized").write_bytes(b"\x00\x00\x04\x00" + b"\0" * 16)
     with pytest.raises(abi.PrgpuError, match="not a valid Mitsuba"):
         scene.PrcScene(source=EMBED % ("mts", str(tmp_path / "bad.serialized"), ""))
+
+
+def _spd_scene(tmp_path, csv_text, expr="(spd 'data.csv')"):
+    (tmp_path / "data.csv").write_text(csv_text)
+    src = "(scene (camera :name 'c' :type 'standard') (emission :name 'e' :type 'standard' :radiance %s) (material :name 'm' :type 'diffuse'))" % expr
+    s = scene.PrcScene(source=src, include_dir=str(tmp_path))
+    sp = s.desc.spectra[s.desc.emissions[0].radiance]
+    values = [s.desc.spectral_tables[sp.table_offset + i] for i in range(sp.table_count)]
+    return s, sp, values
+
+
+def test_spd_file_node_reads_csv_like_the_reference(tmp_path):
+    """SPDFilePlugin::create (node/SPDFileNode.cpp:20-91) over CSV::read (base/container/CSV.cpp:52-163; its behaviours as exercised by
+    src/tests/csv.cpp: header detection, ',' and ';', empty tokens skipped, invalid numbers -> 0, short lines dropped)."""
+    s, sp, v = _spd_scene(tmp_path, "Wavelength;Rel.Power\n400;1.5\n410;2.5\n420;-3\n430;4e2\n")
+    assert (sp.kind, sp.table_count, sp.wl_start, sp.wl_end) == (abi.SPEC_TABLE, 4, 400.0, 430.0) and v == [1.5, 2.5, 0.0, 400.0]   # clamped at zero (:82)
+    _, sp, v = _spd_scene(tmp_path, "400, 1, 10\n500, 2, 20,\n600,, 3, 30\n700, x, 40\n", "(spd 'data.csv' 2 true)")       # no header; column 2 in percent
+    assert (sp.table_count, sp.wl_start, sp.wl_end) == (4, 400.0, 700.0) and np.allclose(v, [0.1, 0.2, 0.3, 0.4])
+    _, sp, v = _spd_scene(tmp_path, "400, 1, 10\n500, 2, 20,\n600,, 3, 30\n700, x, 40\n")                                    # "x" is not a number: 0
+    assert v == [1.0, 2.0, 3.0, 0.0]
+    _, sp, v = _spd_scene(tmp_path, "l,p\n400,1\n450\n500,2\n600,3,9\n", "(spd :file 'data.csv' :column 1 :percentage false)")  # the short line is dropped; extra tokens ignored
+    assert (sp.table_count, sp.wl_start, sp.wl_end) == (3, 400.0, 600.0) and v == [1.0, 2.0, 3.0]
+    s, sp, v = _spd_scene(tmp_path, "400,1\n500,2\n650,3\n")
+    assert any("non equidistant" in w for w in s.warnings) and (sp.wl_start, sp.wl_end) == (400.0, 650.0)
+    for text, expr, needle in (("400,1\n", "(spd 'data.csv')", "not enough data"), ("400\n500\n", "(spd 'data.csv')", "not enough data"),
+                               ("500,1\n400,2\n", "(spd 'data.csv')", "invalid wavelengths"), ("400,1\n500,2\n", "(spd 'data.csv' 2)", "column 2"),
+                               ("400,1\n500,2\n", "(spd 'missing.csv')", "not valid"), ("400,1\n500,2\n", "(spd)", "no file")):
+        with pytest.raises(abi.PrgpuError, match=needle):
+            _spd_scene(tmp_path, text, expr)
+
+
+def test_reference_uv_light_spectrum_loads():
+    path = os.path.join(REF_EXAMPLES, "UVLight.csv") if "REF_EXAMPLES" in globals() else "/root/reference/examples/UVLight.csv"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    src = "(scene (camera :name 'c' :type 'standard') (emission :name 'e' :type 'standard' :radiance (smul (spd 'UVLight.csv') 100)) (material :name 'm' :type 'diffuse'))"
+    s = scene.PrcScene(source=src, include_dir=os.path.dirname(path))            # cornellbox_fluorescent.prc:56
+    mul = s.desc.spectra[s.desc.emissions[0].radiance]
+    assert mul.kind == abi.SPEC_MUL
+    sp = s.desc.spectra[mul.lhs] if s.desc.spectra[mul.lhs].kind == abi.SPEC_TABLE else s.desc.spectra[mul.rhs]
+    v = np.array([s.desc.spectral_tables[sp.table_offset + i] for i in range(sp.table_count)])
+    assert (sp.table_count, sp.wl_start, sp.wl_end) == (111, 300.0, 410.0) and v.max() > 0 and (v >= 0).all() and 340 < 300 + v.argmax() < 380
