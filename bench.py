@@ -241,7 +241,17 @@ def main():
             box = [raw]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        comm = backend.Communicator(world, rank, device=local, exchange=exchange)
+        try:
+            comm = backend.Communicator(world, rank, device=local, exchange=exchange)
+        except Exception as e:  # noqa: BLE001 -- keep the bench line: fall back to the torch.distributed reduce on every rank
+            sys.stderr.write("[bench] rank %d: prgpu_comm_create failed (%s); falling back to torch.distributed.reduce\n" % (rank, e))
+            comm = None
+        if world > 1:           # all ranks take the same branch
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
 
     def reduce_frame():
         if comm is not None:
@@ -276,6 +286,7 @@ def main():
                                "sobol %d-spp schedule, hero wavelengths (spd CMIS), %d iterations timed"
                                % (args.triangles - 32, args.triangles, width, height, SPP, args.steps),
                    "samples_per_step": int(samples / args.steps), "parallelism": "tiles%d" % world,
+                   "collective": "none (one rank)" if world == 1 else ("prgpu_reduce (RCCL from libprgpu)" if comm is not None else "torch.distributed.reduce"),
                    "mrays_per_s": round(rays / dt / 1e6, 2), "mean_path_depth": round(depth / max(samples, 1), 3),
                    "scene_create_s": round(t_create, 3)},
     }
