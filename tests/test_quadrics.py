@@ -218,6 +218,14 @@ def test_gpu_quadric_scene_is_bit_exact_and_shards_over_tiles():
         h = backend.RenderContext(s); h.setTiles(tiling.tiles_for_rank(96, 72, rank, 2, tile=16)); h.render(8); h.waitForFinish()
         acc += h.output()[0]
     assert np.array_equal(acc, gx)
+    # light path expressions live in the same kernel variant: planes of paths over quadric surfaces
+    exprs = ["CDE", "C<T.>+.*L", "C.*<RS>.*L"]
+    gl = backend.RenderContext(s); gl.enableLPE(exprs); gl.render(8); gl.waitForFinish()
+    ol = ob.OracleScene(s); ol.enable_lpe(exprs); ol.render(8, threads=16)
+    assert np.array_equal(gl.output()[0], gx)
+    for k in range(len(exprs)):
+        assert np.array_equal(gl.lpe(k), ol.lpe(k)), exprs[k]
+    assert gl.lpe(1).any() and gl.lpe(2).any()                       # through the glass ellipsoid, off the metal cylinder
     # the other pipelines and the ray service say what they do not do
     with pytest.raises(abi.PrgpuError, match="ray service"):
         g.traceRays(np.zeros((1, 3), np.float32), np.array([[0, 0, 1]], np.float32), np.full(1, 1e-4, np.float32), np.full(1, np.inf, np.float32))
