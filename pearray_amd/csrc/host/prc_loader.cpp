@@ -27,6 +27,7 @@
 
 #include "../../../include/prgpu.h"
 #include "../tables/pr_tables.inl"
+#include "../tables/pr_illuminants.inl"
 #include <zlib.h>
 
 #include "datalisp.h"
@@ -294,7 +295,19 @@ struct Loader {
 				return spectrum_table(300.0f, 830.0f, PR_D65, 107);
 			if (name == "e")
 				return spectrum_const(1.0f);
-			fail(PRGPU_EUNSUPPORTED, where(e) + ": illuminant '" + name + "' is not available (D65 and E are)");
+			static const struct {
+				const char* name;
+				const float* data;
+			} wide[] = { { "a", PR_ILL_A }, { "c", PR_ILL_C }, { "d50", PR_ILL_D50 }, { "d55", PR_ILL_D55 }, { "d75", PR_ILL_D75 } },
+			  fluorescent[] = { { "f1", PR_ILL_F1 }, { "f2", PR_ILL_F2 }, { "f3", PR_ILL_F3 }, { "f4", PR_ILL_F4 }, { "f5", PR_ILL_F5 }, { "f6", PR_ILL_F6 },
+								{ "f7", PR_ILL_F7 }, { "f8", PR_ILL_F8 }, { "f9", PR_ILL_F9 }, { "f10", PR_ILL_F10 }, { "f11", PR_ILL_F11 }, { "f12", PR_ILL_F12 } };
+			for (const auto& w : wide) // CIE_SampleCount samples over [300, 830] nm (IlluminantData.inl:4-6)
+				if (name == w.name)
+					return spectrum_table(300.0f, 830.0f, w.data, 107);
+			for (const auto& f : fluorescent) // CIE_F_SampleCount samples over [380, 780] nm (:8-10)
+				if (name == f.name)
+					return spectrum_table(380.0f, 780.0f, f.data, 81);
+			fail(PRGPU_EINVAL, where(e) + ": unknown illuminant '" + name + "'");
 		}
 		if (id == "spectrum") { // SpectralConstNode.cpp:12-33
 			const float start = (float)get_number(e, "start", 0.0), end = (float)get_number(e, "end", 0.0);
