@@ -5,7 +5,7 @@
 namespace prd {
 // gstats: PRGPU_STAT_COUNT statistics, then inner/leaf record counters of closest and any-hit traversal, then wave-iteration
 // counters, then the persistent kernel's shading passes / shaded vertices / time split
-constexpr int N_DEVICE_COUNTERS = PRGPU_STAT_COUNT + 11;
+constexpr int N_DEVICE_COUNTERS = PRGPU_STAT_COUNT + 16; // ... + diagnostics (PRGPU_DEBUG_COUNTERS): leaf-step / inner-step ticks, shader cycles, refill ticks, ray-end ticks
 
 // Scratch of one persistent traversal launch: queue head (u32) and the per-thread stack spill slab.
 // Launches that may run concurrently need separate workspaces.
@@ -14,6 +14,11 @@ struct TraceWorkspace {
 	uint2* spill		 = nullptr; // max_blocks * 256 * STACK_SPILL entries
 	uint32_t max_blocks	 = 0;		// persistent grid size (blocks)
 	int refill_below	 = 44;		// refill a wave from the queue when fewer lanes than this are active
+	// persistent path kernel, resident pixels: per-block pixel lists and state words (bl_entries each), per-slot list index
+	uint32_t* bl_list	 = nullptr;
+	uint32_t* bl_word	 = nullptr;
+	uint32_t* slot_unit	 = nullptr;
+	size_t bl_entries	 = 0;
 };
 size_t trace_workspace_spill_entries(uint32_t max_blocks);
 

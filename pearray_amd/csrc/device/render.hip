@@ -26,7 +26,7 @@ struct Hit {
 };
 
 // indices into the extra device counters after the 11 statistics
-enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES, CNT_SHADE_TICKS, CNT_IDLE_TICKS, CNT_TOTAL_TICKS };
+enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES, CNT_SHADE_TICKS, CNT_IDLE_TICKS, CNT_TOTAL_TICKS, CNT_LEAF_TICKS, CNT_INNER_TICKS, CNT_TOTAL_CYCLES, CNT_REFILL_TICKS, CNT_FIN_TICKS };
 
 // ---- traversal ------------------------------------------------------------------------------------------------
 // Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one
@@ -38,7 +38,15 @@ enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CN
 #endif
 constexpr int PP_BLOCK		= PR_PP_BLOCK;
 constexpr int TRAV_BLOCK	= PR_TU >= 1 ? PP_BLOCK : 256; // the persistent-kernel units hold nothing but that kernel
-constexpr int STACK_LDS		= 16;
+// PR_SPLIT = 1: the persistent path kernel hands leaf tests to whole waves through wave-private task rings (see path_persistent);
+// its traversal stack then only holds inner nodes (PR_WS_STACK entries per lane in LDS: with 8 the C4 scene spills all the time, 15.7 vs 13.6 ms)
+#ifndef PR_SPLIT
+#define PR_SPLIT 0
+#endif
+#ifndef PR_WS_STACK
+#define PR_WS_STACK 16
+#endif
+constexpr int STACK_LDS		= (PR_TU >= 1 && PR_SPLIT) ? PR_WS_STACK : 16;
 constexpr int STACK_SPILL	= 64;  // additional entries per thread in global memory
 constexpr bool ANY_SORTED	= false; // near-to-far order for occlusion rays measured slightly slower than unsorted (fewer ALU ops win)
 
@@ -2060,21 +2068,30 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 // the pixel has all its samples the slot takes the next unrendered pixel from a global counter.  There is no grid-wide
 // barrier, no host round trip and no drain phase between path vertices; blocks never wait for each other, waves only
 // ever wait for waves of their own block (which are resident by construction).
-// PR_SPLIT = 1 compiles the split traversal into the persistent kernel: leaf tests through an LDS task queue instead of one kind of record
-// per wave step.  Bit-identical (all GPU tests pass with it), 28 % fewer wave steps on C4 (14.3 M vs 19.9 M per iteration, lane utilisation
-// 0.83 vs 0.58), but each step carries the queue bookkeeping, finished rays wait for their last batch, and u, v need one more test of the
-// winning triangle: 14.8 ms per iteration against 13.45 -- so it stays off.  In the leaner ray-service kernel the same scheme wins 17 %
-// (k_service_closest_split, profiles/r02_trace_split_prototype.log).  Next steps that could turn it: a second result slot per lane so
-// that a lane starts its next ray while the last leaves of the previous one are tested, and u, v published by the winning leaf lane.
-#ifndef PR_SPLIT
-#define PR_SPLIT 0
+// Split traversal (PR_SPLIT, default): inner nodes and leaves are different kinds of work -- a 64-byte record and four slab tests against a
+// 128-byte record and up to three watertight triangle tests -- and a wave that steps one kind per step (the majority's, see
+// trace_persistent) leaves 42 % of its lanes idle on the C4 scene.  Here a lane never steps a leaf itself: the inner step turns every hit
+// leaf child into a TASK (leaf record, owner lane) in a ring that belongs to the wave alone -- plain LDS writes at positions from a
+// ballot prefix sum, head and tail live in scalar registers, no atomics and no other wave involved -- and goes on with the inner nodes on
+// its stack.  Whenever 64 tasks wait (or nothing else can move) the wave runs a leaf step at full lane fill: lane j tests task j's
+// triangles with the owner's ray constants (fetched from the owner lane's registers with ds_bpermute) and merges its best hit into the
+// owner's 64-bit key (order-preserving t bits << 32 | triangle id) with one LDS minimum, which IS the rule "closer, or equally close with
+// the smaller id" of the sequential test; the lane whose candidate won publishes u, v.  A ray is finished when its stack is empty and the
+// ring's head has passed its last task.  Tasks left behind by a ray that ended early (an occluded shadow ray) are tested against whatever
+// ray the owner lane holds by then: a triangle that passes the test for that ray IS a hit of that ray, so a stale task can only confirm
+// the result.  (Round 2's version of this went through one block-wide queue with LDS atomics in every step, let finished rays wait for
+// other waves' batches and re-tested the winning triangle for u, v: 28 % fewer steps but 10 % slower; profiles/r02_split_traversal_persistent.log.)
+#ifndef PR_PP_SLOTS_MAX
+#define PR_PP_SLOTS_MAX (PP_BLOCK == 768 ? 2048 : (PR_SPLIT ? 512 : 1024)) // the split traversal's rings and keys come out of the slot rings
 #endif
-constexpr int PP_SLOTS_MAX		= PR_SPLIT ? 512 : (PP_BLOCK == 768 ? 2048 : 1024); // the task queue's LDS comes out of the slot rings
-constexpr uint32_t SPLIT_Q		= 1024;					 // ring of leaf tasks (owner lane | leaf unit << 8)
+constexpr int PP_SLOTS_MAX		= PR_PP_SLOTS_MAX;
+constexpr uint32_t WS_RING		= 256;					 // tasks per wave: fewer than 64 wait when an inner step adds some (a step that would overflow the ring is retried, see trav_inner_ws)
 constexpr uint32_t PP_EMPTY		= 0xFFFFFFFFu;
 constexpr uint32_t PP_ANY		= 0x80000000u; // ray entry: the slot's shadow ray (else its path ray)
 constexpr uint32_t PP_REGEN		= 0x80000000u; // shade entry: the slot's path has ended (else: shade the vertex at ps.hit)
 constexpr uint32_t PP_DEAD		= 0x100u;	   // pending word: no bounce ray follows the rays in flight
+constexpr uint32_t PP_VISIBLE	= 0x200u;	   // pending word: the slot's shadow ray reached the light (set by the ray's last step)
+constexpr uint32_t PP_SHADOW	= 0x400u;	   // pending word: the vertex queued a shadow ray, its NEE fragment waits in ps.sh_xyz
 constexpr unsigned long long PP_IDLE_LIMIT_TICKS = 30ull * 100000000ull; // safety net: a wave that has seen no work for 30 s of wall clock (100 MHz ticks) gives up and flags an error
 
 // NQ shade queues, one per material class (HitStream::setup / getNextGroup, trace/HitStream.cpp:57-118, sort hits into runs of equal
@@ -2087,13 +2104,12 @@ struct PPShared {
 	uint32_t q_shade[NQ][PP_SLOTS_MAX];
 	uint32_t pending[PP_SLOTS_MAX];
 #if PR_SPLIT
-	unsigned long long best[TRAV_BLOCK]; // per lane: (t bits << 32) | triangle id of its ray's best hit, merged by the leaf waves with one 64-bit minimum
-	uint32_t leaf_pending[TRAV_BLOCK];	 // leaf tasks of the lane's ray not yet merged
-	uint32_t lane_entry[TRAV_BLOCK];	 // the ray a lane holds (slot | PP_ANY), for the wave that tests its leaves
-	uint32_t q_leaf[SPLIT_Q];
-	uint32_t leaf_head, leaf_tail;
+	uint32_t ws_task[TRAV_BLOCK / 64][WS_RING]; // per wave: leaf tasks (leaf unit << 6 | owner lane)
+	unsigned long long ws_key[TRAV_BLOCK];		// per lane: its ray's best hit so far, (ordered t bits << 32) | triangle id
+	float2 ws_uv[TRAV_BLOCK];					// ... and that hit's barycentrics
 #endif
 	uint32_t ray_head, ray_tail, shade_head[NQ], shade_tail[NQ];
+	uint32_t n_list, unit_next, exhausted, n_frozen; // resident pixels: the block's pixel list and its round-robin stream of (pixel, sample) units
 	uint32_t live; // slots that still own, or may still acquire, a pixel
 	uint32_t error;
 	BlockStats bs;
@@ -2102,12 +2118,20 @@ struct PPShared {
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t wave_bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// ---- split traversal: leaf tests handed to whole waves through an LDS task queue (see path_persistent) ----
-// inner step of the split traversal: hit children that are leaves become tasks at once (they never enter the stack), the inner ones
-// are sorted and pushed as in trav_inner_rec.  Returns nothing; *n_tasks = leaves queued by this lane.
+// ---- split traversal (see above) ----
+// order-preserving map of a float to an unsigned key (negative values below positive ones), and back
+__device__ __forceinline__ uint32_t float_key(float f)
+{
+	const uint32_t b = __float_as_uint(f);
+	return b ^ ((b & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu)); }
+// Inner step of the split traversal: the four slab tests of trav_inner_rec; hit children that are leaves become tasks of the wave's ring
+// (they never enter the stack), hit inner children are sorted and pushed as there.  `active`: the lane holds a ray at an inner record (all
+// lanes of the wave take part in the ring bookkeeping).  ws_tail is wave-uniform; my_last becomes the ring position behind the lane's last task.
 template <typename STK>
-__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, uint32_t* q, uint32_t* q_tail,
-												 uint32_t* pending_own, uint32_t tid, bool active, const uint32_t* q_head, uint32_t* overflow)
+__device__ __forceinline__ void trav_inner_ws(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool active, uint32_t* ring,
+											  uint32_t ws_head, uint32_t& ws_tail, uint32_t& my_last, uint32_t lane, bool& overflow)
 {
 	float t[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
 	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
@@ -2128,10 +2152,10 @@ __device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4&
 			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
 			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
 			t[k]		   = t0;
-			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY;
+			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY; // acceptance rule of box_hit
 		}
 	}
-	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts through three ballots)
+	// leaves -> tasks: ring positions from a prefix sum over the lanes' counts (three ballots: a lane queues at most four)
 	bool lf[4];
 	uint32_t cnt = 0;
 #pragma unroll
@@ -2140,24 +2164,24 @@ __device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4&
 		cnt += lf[k] ? 1u : 0u;
 	}
 	{
-		const uint32_t lane			   = tid & 63u;
 		const unsigned long long below = (1ull << lane) - 1ull;
 		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
 		const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
 		if (total != 0u) {
-			uint32_t base = 0;
-			if (lane == 0)
-				base = __hip_atomic_fetch_add(q_tail, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			base = wave_bcast0(base);
-			if (lane == 0 && base + total - lds_load(q_head) > SPLIT_Q) // cannot happen while callers keep the ring below a quarter full and a
-				__hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // step adds at most 256 per wave; loud if it does
-			uint32_t pos = base + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
-			if (cnt)
-				__hip_atomic_fetch_add(pending_own, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (ws_tail - ws_head + total <= WS_RING) {
+				uint32_t pos = ws_tail + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
 #pragma unroll
-			for (int k = 0; k < 4; ++k)
-				if (lf[k])
-					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], ((c[k] & ~REC_LEAF_BIT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				for (int k = 0; k < 4; ++k)
+					if (lf[k])
+						ring[(pos++) & (WS_RING - 1u)] = ((c[k] & ~REC_LEAF_BIT) << 6) | lane;
+				if (cnt)
+					my_last = pos;
+				ws_tail += total;
+			} else {
+				overflow = true; // (wave-uniform)
+				if (cnt)
+					active = false; // no room for this step's tasks (> 192 of them: hardly ever): the lanes that have some stay where they are; the caller runs a leaf step next, which empties the ring
+			}
 		}
 	}
 	if (!active)
@@ -2273,10 +2297,19 @@ struct PersistentArgs {
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
 	uint32_t sort_rays;	  // 1: a shading pass queues its rays ordered by direction octant
 	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
-	int fin_batch;		  // split traversal: finished rays are written out once this many of a wave's lanes hold one
+	uint32_t ws_min_tasks; // split traversal: a leaf step also runs with this many tasks (< 64) ...
+	int ws_wait;		   // ... when this many of the wave's rays have nothing left but tasks
 	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
+	// resident pixels (see path_persistent): per block `bl_cap` list entries (pixel) and state words (samples done | samples handed out << 16),
+	// and per slot the list entry of the pixel it renders
+	uint32_t resident;
+	uint32_t bl_cap;
+	uint32_t* bl_list;
+	uint32_t* bl_word;
+	uint32_t* slot_unit;
 	unsigned long long* gstats;
 };
+constexpr uint32_t BL_UNWRITTEN = 0xFFFFFFFEu, BL_HOLE = 0xFFFFFFFFu; // list entry reserved but not yet written / reserved when the frame had no pixel left
 
 template <bool COUNT, uint32_t FEATS>
 __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathState& ps, const PersistentArgs& a)
@@ -2307,15 +2340,15 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			sh.shade_head[q] = sh.shade_tail[q] = 0;
 		sh.live					  = block_slots;
 		sh.error				  = 0;
-#if PR_SPLIT
-		sh.leaf_head = sh.leaf_tail = 0;
-#endif
+		sh.n_list = sh.unit_next = sh.exhausted = sh.n_frozen = 0;
 	}
-#if PR_SPLIT
-	for (uint32_t i = threadIdx.x; i < SPLIT_Q; i += TRAV_BLOCK)
-		sh.q_leaf[i] = PP_EMPTY;
-	sh.leaf_pending[threadIdx.x] = 0;
-#endif
+	uint32_t* const bl_list = a.bl_list + size_t(blockIdx.x) * a.bl_cap;
+	uint32_t* const bl_word = a.bl_word + size_t(blockIdx.x) * a.bl_cap;
+	if (a.resident)
+		for (uint32_t i = threadIdx.x; i < a.bl_cap; i += TRAV_BLOCK) {
+			bl_list[i] = BL_UNWRITTEN;
+			bl_word[i] = 0u;
+		}
 	stats_init(sh.bs);
 	__syncthreads();
 
@@ -2332,38 +2365,56 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	uint32_t spins	  = 0;
 	unsigned long long t_idle_since = 0;
 	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, wleaf = 0, sbatches = 0, slanes = 0;
-	unsigned long long t_shade = 0, t_idle = 0;
+	unsigned long long t_shade = 0, t_idle = 0, t_leaf = 0, t_inner = 0, t_refill = 0, t_fin = 0;
 	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
+	const unsigned long long c_start = COUNT ? (unsigned long long)clock64() : 0ull;
 
 	const bool shader = a.shader_wave != 0u && ((threadIdx.x >> 6) & 3u) == 3u; // one wave in four
 	const uint32_t shade_full = a.shader_wave != 0u ? a.shade_help : a.shade_min;
 #if PR_SPLIT
-	// test up to 64 queued leaves with this wave (whatever rays its own lanes hold); false when nothing could be claimed
-	auto leaf_batch = [&]() -> bool {
-		uint32_t first;
-		const uint32_t nt = ring_claim(&sh.leaf_head, &sh.leaf_tail, 64u, first);
-		if (nt == 0u)
-			return false;
-		if (lane < nt) {
-			const uint32_t task	 = ring_take(sh.q_leaf, SPLIT_Q - 1u, first + lane);
-			const uint32_t owner = task & 0xFFu, unit = task >> 8;
-			const uint32_t entry = sh.lane_entry[owner];
-			const bool any		 = (entry & PP_ANY) != 0;
-			const uint32_t slot	 = slot0 + (entry & ~PP_ANY);
-			const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + unit);
+	uint32_t* const ring = sh.ws_task[threadIdx.x >> 6];
+	uint32_t ws_head = 0, ws_tail = 0; // wave-uniform ring positions (free running)
+	uint32_t my_last = 0;			   // ring position behind the last task of the lane's ray
+	bool ws_overflow = false;		   // the last inner step found the ring too full for its tasks
+	// leaf step: the wave's first (up to) 64 tasks, one per lane, at full lane fill
+	auto leaf_step = [&]() {
+		const uint32_t n  = min(64u, ws_tail - ws_head);
+		const bool mine	  = lane < n;
+		uint32_t task	  = lane;
+		if (mine)
+			task = ring[(ws_head + lane) & (WS_RING - 1u)];
+		ws_head += n;
+		const uint32_t owner = task & 63u;
+		const int sel		 = (int)(owner << 2);
+		// the owner's ray constants, straight from its registers
+		auto fetch = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(v))); };
+		RayPre r;
+		r.o		= v3(fetch(s.r.o.x), fetch(s.r.o.y), fetch(s.r.o.z));
+		r.Sx	= fetch(s.r.Sx);
+		r.Sy	= fetch(s.r.Sy);
+		r.Sz	= fetch(s.r.Sz);
+		const float tmin = fetch(s.tmin);
+		const int kk	 = __builtin_amdgcn_ds_bpermute(sel, s.r.kx | (s.r.ky << 2) | (s.r.kz << 4) | (s.any ? 64 : 0) | (has_ray ? 128 : 0));
+		r.kx			 = kk & 3;
+		r.ky			 = (kk >> 2) & 3;
+		r.kz			 = (kk >> 4) & 3;
+		float limit		 = 0.0f;
+		if (FEATS & FEAT_SPHERES) {
+			r.d	  = v3(fetch(s.r.d.x), fetch(s.r.d.y), fetch(s.r.d.z));
+			limit = fetch(s.best.t);
+		}
+		unsigned long long cand = ~0ull;
+		float bu = 0.0f, bv = 0.0f;
+		if (mine && (kk & 128)) {
+			const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (task >> 6));
 			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
-			const float4 ro = any ? ps.sh_o[slot] : ps.ray_o[slot], rd = any ? ps.sh_d[slot] : ps.ray_d[slot];
-			const RayPre r	 = ray_prepare(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), sc.eps_t);
-			const float tmin = ro.w;
-			const float limit = __uint_as_float((uint32_t)(__hip_atomic_load(&sh.best[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
 			const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
 								  q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w };
-			const uint32_t count   = __float_as_uint(f[30]);
-			unsigned long long key = ~0ull;
+			const uint32_t count = __float_as_uint(f[30]);
 #pragma unroll
 			for (int k = 0; k < 3; ++k) {
 				if ((uint32_t)k < count) {
-					float tt, uu, vv;
+					float tt, uu = 0.0f, vv = 0.0f;
 					const uint32_t prim = __float_as_uint(f[10 * k + 9]);
 					bool hit;
 					if ((FEATS & FEAT_SPHERES) && (prim & PRIM_SPHERE_BIT))
@@ -2372,20 +2423,37 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						hit = woop(r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]), v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), tt, uu, vv)
 							  && tt > tmin;
 					if (hit) {
-						const unsigned long long cand = ((unsigned long long)__float_as_uint(tt) << 32) | (prim & ~PRIM_SPHERE_BIT);
-						key							  = cand < key ? cand : key;
+						const unsigned long long c2 = ((unsigned long long)float_key(tt) << 32) | (prim & ~PRIM_SPHERE_BIT);
+						if (c2 < cand) {
+							cand = c2;
+							bu	 = uu;
+							bv	 = vv;
+						}
 					}
 				}
 			}
 			if (COUNT) {
-				cl_c += any ? 0 : 1;
-				cl_a += any ? 1 : 0;
+				cl_c += (kk & 64) ? 0 : 1;
+				cl_a += (kk & 64) ? 1 : 0;
 			}
-			if (key != ~0ull)
-				__hip_atomic_fetch_min(&sh.best[owner], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			__hip_atomic_fetch_sub(&sh.leaf_pending[owner], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		return true;
+		const uint32_t otid = (threadIdx.x & ~63u) | owner;
+		if (cand != ~0ull)
+			__hip_atomic_fetch_min(&sh.ws_key[otid], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		if (cand != ~0ull && __hip_atomic_load(&sh.ws_key[otid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == cand)
+			sh.ws_uv[otid] = make_float2(bu, bv); // the candidate that won publishes its barycentrics
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		if (has_ray) { // every ray of the wave sees its hit distance shrink
+			const unsigned long long k = __hip_atomic_load(&sh.ws_key[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			s.best.t				   = key_float((uint32_t)(k >> 32));
+			s.best.tri				   = (uint32_t)k;
+			if (s.any && s.best.tri != INVALID) { // occluded: done (its remaining tasks can only confirm that)
+				st.reset();
+				s.cur	= REC_EMPTY;
+				my_last = ws_head;
+			}
+		}
 	};
 #endif
 	for (;;) {
@@ -2429,6 +2497,20 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					regen			 = (e & PP_REGEN) != 0;
 				}
 				const uint32_t slot = slot0 + slot_l;
+				if (mine) { // the NEE fragment of the slot's previous vertex, now that its shadow ray has reported (see the end of the ray loop)
+					const uint32_t pw = lds_load(&sh.pending[slot_l]);
+					if (pw & PP_SHADOW) {
+						const float4 x		 = ps.sh_xyz[slot];
+						const uint32_t fbs	 = __float_as_uint(x.w);
+						const uint32_t pixel = ps.pixel[slot];
+						if (pw & PP_VISIBLE) {
+							const float xyz[3] = { x.x, x.y, x.z };
+							apply_fragment(ps, pixel, iter_entry(ps, slot, pixel), fbs & 0xFFu, xyz, (FEATS & FEAT_LPE) ? (fbs >> 16) & 0xFu : 0u);
+						} else if ((fbs >> 8) & 0xFFu) {
+							ps.feedback[pixel] |= (fbs >> 8) & 0xFFu;
+						}
+					}
+				}
 				bool alive = false, want_shadow = false;
 				float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
 				if (NQ > 1 && cls == 1) { // wave-uniform: the body with the rough / principled closures
@@ -2455,13 +2537,110 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 							fold_iteration(ps, pixel, iter, v, (FEATS & FEAT_LPE) != 0u);
 						}
 						if (iter + 1 < a.iter_end) {
-							need_pixel = false;
-							iter	   = iter + 1;
+							if (!a.resident) { // the pixel's next sample follows in this slot
+								need_pixel = false;
+								iter	   = iter + 1;
+							} else { // ... only if the block's unit stream has already passed it over (see below)
+								const uint32_t old = __hip_atomic_fetch_add(&bl_word[a.slot_unit[slot]], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+								if ((old >> 16) >= (old & 0xFFFFu) + 1u) {
+									need_pixel = false;
+									iter	   = iter + 1;
+								}
+							}
 						}
 					}
 				}
 				bool retired = false;
-				{
+				if (a.resident) {
+					// Resident pixels (RenderContext::getNextTile hands a tile to whichever thread is free, iteration after iteration,
+					// RenderContext.cpp:234-271; here the unit is a pixel sample).  A slot that keeps its pixel for every sample of the launch
+					// leaves the slots that finish early idle until the launch ends -- half a chain of samples per launch (5 % of the C4 frame,
+					// 19 % of a quarter share).  Instead a pixel stays with the BLOCK: during the launch's first iteration blocks take pixels from
+					// the global counter as their slots fall free (so a block's list is as long as the block is fast) and append them to their
+					// list; afterwards the block deals its list round-robin, one (pixel, sample) unit per free slot.  The pixel's planes (RNG state,
+					// sums, running mean) are only ever touched by waves of one block, i.e. one CU: no cross-XCD coherence is involved.  A unit whose
+					// predecessor sample is still running is delegated to the slot running it (the state word counts samples done and samples
+					// handed out; one atomic on either side decides), so nothing ever waits.
+					if (wave_bcast0(lds_load(&sh.exhausted)) == 0u) { // first iteration: new pixels
+						const unsigned long long m = __ballot(need_pixel);
+						if (m != 0ull) {
+							const uint32_t n	= (uint32_t)__popcll(m);
+							const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+							const int leader	= __ffsll((long long)m) - 1;
+							uint32_t pos		= 0;
+							if ((int)lane == leader)
+								pos = __hip_atomic_fetch_add(&sh.n_list, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							pos = __shfl(pos, leader, 64);
+							const uint32_t n_fit = pos >= a.bl_cap ? 0u : min(n, a.bl_cap - pos);
+							uint32_t idx		 = a.n_owned;
+							if (n_fit != 0u) {
+								// the list positions are reserved BEFORE the pixels are claimed: whoever sees the counter exhausted also sees every
+								// reservation that can still receive a pixel
+								__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+								if ((int)lane == leader)
+									idx = atomicAdd(a.next_pixel, n_fit);
+								idx = __shfl(idx, leader, 64);
+							}
+							if ((n_fit < n || idx + n_fit >= a.n_owned) && (int)lane == leader)
+								__hip_atomic_store(&sh.exhausted, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+							if (need_pixel && rank < n_fit) {
+								const uint32_t i = idx + rank;
+								uint32_t entry	 = BL_HOLE;
+								if (i < a.n_owned) {
+									entry				= a.owned[i];
+									ps.pixel[slot]		= entry;
+									a.slot_unit[slot]	= pos + rank;
+									iter				= a.iter_begin;
+									need_pixel			= false;
+								}
+								__hip_atomic_store(&bl_list[pos + rank], entry, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+							}
+						}
+					}
+					const uint32_t rounds = a.iter_end - a.iter_begin - 1u; // units per list entry
+					while (__any(need_pixel)) { // later iterations: the block's own list, round-robin
+						uint32_t nf = lds_load(&sh.n_frozen);
+						if (nf == 0u) { // the list is complete (every reservation that can hold a pixel has been made): its length is fixed once
+							if (lane == 0) {
+								uint32_t expect = 0u;
+								(void)__hip_atomic_compare_exchange_strong(&sh.n_frozen, &expect, min(lds_load(&sh.n_list), a.bl_cap) + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+																		   __HIP_MEMORY_SCOPE_WORKGROUP);
+							}
+							nf = lds_load(&sh.n_frozen);
+						}
+						const uint32_t N		   = wave_bcast0(nf) - 1u;
+						const unsigned long long total = (unsigned long long)N * rounds;
+						const unsigned long long m = __ballot(need_pixel);
+						const uint32_t rank		   = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+						const int leader		   = __ffsll((long long)m) - 1;
+						uint32_t u0				   = 0;
+						if ((int)lane == leader)
+							u0 = __hip_atomic_fetch_add(&sh.unit_next, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						u0 = __shfl(u0, leader, 64);
+						if (need_pixel) {
+							const uint32_t u = u0 + rank;
+							if (u >= total) {
+								retired	   = true;
+								need_pixel = false;
+							} else {
+								const uint32_t k = u % N;
+								uint32_t p;
+								while ((p = __hip_atomic_load(&bl_list[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == BL_UNWRITTEN)
+									__builtin_amdgcn_s_sleep(1); // reserved by a wave of this block that is a few instructions away from writing it
+								if (p != BL_HOLE) {
+									const uint32_t old = __hip_atomic_fetch_add(&bl_word[k], 1u << 16, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+									const uint32_t r   = (old >> 16) + 1u; // the pixel's r-th sample of this launch (0-based)
+									if ((old & 0xFFFFu) >= r) {			   // its predecessor is done: run it here; else the slot running the predecessor goes on with it
+										ps.pixel[slot]	  = p;
+										a.slot_unit[slot] = k;
+										iter			  = a.iter_begin + r;
+										need_pixel		  = false;
+									}
+								}
+							}
+						}
+					}
+				} else {
 					uint32_t idx;
 					if (a.direct_map)
 						idx = need_pixel && ps.pixel[slot] == INVALID ? slot : a.n_owned; // the slot's one and only pixel, then retirement
@@ -2493,7 +2672,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						ps.sh_d[slot]	= sh_d;
 						ps.sh_xyz[slot] = sh_xyz;
 					}
-					__hip_atomic_store(&sh.pending[slot_l], (alive ? 1u : 0u) + (want_shadow ? 1u : 0u) + (alive ? 0u : PP_DEAD), __ATOMIC_RELAXED,
+					__hip_atomic_store(&sh.pending[slot_l], (alive ? 1u : 0u) + (want_shadow ? 1u + PP_SHADOW : 0u) + (alive ? 0u : PP_DEAD), __ATOMIC_RELAXED,
 									   __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 				if (a.sort_rays) { // "sorted ray queues": order the wave's new rays by direction octant (measured: see DESIGN.md)
@@ -2525,6 +2704,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		// with a handful of lanes (a wave step costs the same with 3 lanes as with 64).
 		const unsigned long long idle = __ballot(!has_ray);
 		if (!shader && idle != 0ull && n_queued > 0u && (n_queued >= a.refill_min || threadIdx.x < 64u)) {
+			const unsigned long long t0r = COUNT ? wall_clock64() : 0ull;
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(idle), first);
 			const uint32_t r = __popcll(idle & ((1ull << lane) - 1ull));
@@ -2553,10 +2733,15 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					}
 				}
 #if PR_SPLIT
-				sh.lane_entry[threadIdx.x] = my_entry;
-				__hip_atomic_store(&sh.best[threadIdx.x], ((unsigned long long)__float_as_uint(s.best.t) << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if ((FEATS & FEAT_QUADRICS) && any && s.best.tri != INVALID)
+					s.cur = REC_EMPTY; // occluded by a quadric: finished as it stands
+				__hip_atomic_store(&sh.ws_key[threadIdx.x], ((unsigned long long)float_key(s.best.t) << 32) | s.best.tri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				sh.ws_uv[threadIdx.x] = make_float2(0.0f, 0.0f);
+				my_last				  = ws_head; // no task of its own yet
 #endif
 			}
+			if (COUNT)
+				t_refill += wall_clock64() - t0r;
 		}
 		if (!__any(has_ray)) {
 			// nothing to trace and not enough to shade: other waves of the block hold the work, or the block is done
@@ -2582,40 +2767,26 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		spins = 0;
 		for (;;) {
 #if PR_SPLIT
-			// Split traversal: a lane that reaches a leaf queues (lane, leaf record) and goes on with its stack; whenever 64 tasks wait,
-			// the next wave that comes by tests 64 leaves at full lane fill and merges each hit into the owner's best hit with one 64-bit
-			// LDS minimum over (t, triangle id) -- the rule "closer, or equally close with the smaller id" of the sequential test.  Inner
-			// steps therefore run for every ray of the wave (no vote between record kinds: lane utilisation 0.58 -> 0.8), at the price
-			// of seeing the best t one batch late (+2 % inner, +6 % leaf records on C4).  A ray is finished when its stack is empty
-			// and none of its tasks is outstanding.
-			// the step's LDS reads in one go (one wait): queue fill, the lane's outstanding tasks, then its merged best hit.  LDS executes a
-			// wave's instructions in order and a leaf lane merges before it counts down, so "no task outstanding" implies a final key
-			const uint32_t l_tail = lds_load(&sh.leaf_tail), l_head = lds_load(&sh.leaf_head);
-			const uint32_t my_pending = lds_load(&sh.leaf_pending[threadIdx.x]);
-			asm volatile("" ::: "memory");
-			const unsigned long long key = __hip_atomic_load(&sh.best[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			const uint32_t n_tasks		 = wave_bcast0(l_tail - l_head);
-			const bool can_inner		 = __any(has_ray && s.cur != REC_EMPTY);
-			bool fin					 = has_ray && s.cur == REC_EMPTY && my_pending == 0u; // the lane has not stepped since: nothing new is outstanding
+			// split traversal (see the top of this section): inner steps for every ray that has an inner node, a leaf step whenever a
+			// wave-full of tasks waits -- or earlier, when nothing else can move or many finished stacks wait for their last tasks
+			const uint32_t n_tasks			 = ws_tail - ws_head;
+			const bool at_inner				 = has_ray && s.cur != REC_EMPTY; // always an inner record: leaves never stay in s.cur
+			const unsigned long long m_inner = __ballot(at_inner);
+			const int n_wait				 = __popcll(__ballot(has_ray && s.cur == REC_EMPTY && (int32_t)(ws_head - my_last) < 0));
 			if (COUNT && lane == 0)
 				++witers;
-			if (n_tasks >= 64u || (n_tasks > 0u && !can_inner)) {
-				leaf_batch();
+			if (n_tasks >= 64u || (n_tasks > 0u && (ws_overflow || m_inner == 0ull || (n_tasks >= a.ws_min_tasks && n_wait >= a.ws_wait)))) {
+				ws_overflow = false;
+				const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
+				leaf_step();
 				if (COUNT && lane == 0)
 					++wleaf;
-			} else if (can_inner) {
-				// (room for this step's tasks -- at most 4 per lane -- is certain: fewer than 64 wait, and the other three waves add at most 768)
-				bool act  = has_ray && s.cur != REC_EMPTY; // always an inner record: leaves never stay in s.cur
+				if (COUNT)
+					t_leaf += wall_clock64() - t0;
+			} else if (m_inner != 0ull) {
+				const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
 				float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
-				if (act) {
-					s.best.t = __uint_as_float((uint32_t)(key >> 32));
-					if (s.any && (uint32_t)key != INVALID) { // occluded: done (tasks still in flight only confirm it)
-						st.reset();
-						s.cur = REC_EMPTY;
-						act	  = false;
-					}
-				}
-				if (act) {
+				if (at_inner) {
 					if (COUNT) {
 						cn_c += s.any ? 0 : 1;
 						cn_a += s.any ? 1 : 0;
@@ -2626,36 +2797,17 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					q2 = rec[2];
 					q3 = rec[3];
 				}
-				trav_inner_split(s, st, q0, q1, q2, q3, sh.q_leaf, &sh.leaf_tail, &sh.leaf_pending[threadIdx.x], threadIdx.x, act, &sh.leaf_head, &sh.error);
-			} else {
-				const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
-				__builtin_amdgcn_s_sleep(1); // every ray of the wave waits for tasks another wave is testing
+				trav_inner_ws(s, st, q0, q1, q2, q3, at_inner, ring, ws_head, ws_tail, my_last, lane, ws_overflow);
 				if (COUNT)
-					t_idle += wall_clock64() - t0;
+					t_inner += wall_clock64() - t0;
 			}
-			// finished rays wait for company: their results cost two dependent fetches (the winning triangle's leaf slot), paid once
-			// for a batch instead of in every step -- unless the wave is short of rays anyway
-			{
-				const int n_done = __popcll(__ballot(fin));
-				const int n_busy = __popcll(__ballot(has_ray && !fin));
-				if (!(n_done >= a.fin_batch || n_busy < a.refill_below))
-					fin = false;
-			}
-			if (fin) { // the ray's result: t and the triangle from the merged key, u and v from one more test of that triangle
-				s.best.tri					 = (uint32_t)key;
-				s.best.t					 = __uint_as_float((uint32_t)(key >> 32));
+			const bool fin = has_ray && s.cur == REC_EMPTY && (int32_t)(ws_head - my_last) >= 0;
+			if (fin && !s.any) { // (t, triangle) were refreshed by the leaf step that tested the ray's last task; the winner left u, v
 				s.best.u = s.best.v = 0.0f;
-				if (!s.any && s.best.tri != INVALID) {
-					const uint32_t where = sc.tri_slot[s.best.tri];
-					const float* f		 = reinterpret_cast<const float*>(sc.recs + (where >> 2)) + 10u * (where & 3u);
-					if (!((FEATS & FEAT_SPHERES) && (__float_as_uint(f[9]) & PRIM_SPHERE_BIT))) {
-						// the test's ray constants are rebuilt here rather than carried through the stepping loop (9 registers)
-						const uint32_t fslot = slot0 + (my_entry & ~PP_ANY);
-						const float4 fo = ps.ray_o[fslot], fd = ps.ray_d[fslot];
-						const RayPre fr = ray_prepare(v3(fo.x, fo.y, fo.z), v3(fd.x, fd.y, fd.z), sc.eps_t);
-						float tt;
-						(void)woop(fr, v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), v3(f[6], f[7], f[8]), tt, s.best.u, s.best.v);
-					}
+				if (s.best.tri != INVALID) {
+					const float2 uv = sh.ws_uv[threadIdx.x];
+					s.best.u		= uv.x;
+					s.best.v		= uv.y;
 				}
 			}
 #else
@@ -2679,9 +2831,22 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			// leaves -- a ray parks the leaf it reaches and goes on with inner nodes: lane utilisation 0.58 -> 0.63, but 3-4 % more
 			// records from the delayed shrinking of best.t, 1.5 % slower; 8-wide quantised nodes: 23 % fewer inner records, 2.5x the
 			// instructions per step, 13 % slower.)
+			const unsigned long long t0s = COUNT ? wall_clock64() : 0ull;
 			if (go_inner || go_leaf) {
 				const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
 				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3]; // an inner record, or the first half of a leaf
+#ifdef PR_EXPERIMENT_EXTRA_LOAD
+				{ // EXPERIMENT: PR_EXPERIMENT_EXTRA_LOAD more lane-loads of the same line per step (is the step bound by lane-loads?)
+					const float4* r2 = rec;
+					asm volatile("" : "+v"(r2));
+					for (int e = 0; e < PR_EXPERIMENT_EXTRA_LOAD; ++e) {
+						const float4 qx = r2[e & 3];
+						asm volatile("" : "+v"(r2));
+						if (qx.x == 1.2345e-30f && qx.y == 5.4321e-30f)
+							s.tmin += 1.0f;
+					}
+				}
+#endif
 				if (go_inner) {
 					if (COUNT) {
 						cn_c += s.any ? 0 : 1;
@@ -2697,10 +2862,17 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					trav_leaf_rec<MODE_MIXED, (FEATS & FEAT_SPHERES) != 0>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
 				}
 			}
+			if (COUNT) {
+				if (do_inner)
+					t_inner += wall_clock64() - t0s;
+				else
+					t_leaf += wall_clock64() - t0s;
+			}
 #endif
 #if !PR_SPLIT
 			const bool fin = has_ray && s.cur == REC_EMPTY;
 #endif
+			const unsigned long long t0f = COUNT ? wall_clock64() : 0ull;
 			if (__any(fin)) {
 				bool last	   = false;
 				uint32_t entry = 0;
@@ -2708,24 +2880,19 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				if (fin) {
 					const uint32_t slot_l = my_entry & ~PP_ANY;
 					const uint32_t slot	  = slot0 + slot_l;
-					if (s.any) { // the pending NEE fragment (direct.cpp:329-351)
-						const float4 x		 = ps.sh_xyz[slot];
-						const uint32_t fbs	 = __float_as_uint(x.w);
-						const uint32_t pixel = ps.pixel[slot];
-						const size_t entry	 = iter_entry(ps, slot, pixel);
-						if (s.best.tri != INVALID) {
-							const uint32_t fb = (fbs >> 8) & 0xFFu;
-							if (fb)
-								ps.feedback[pixel] |= fb;
-						} else {
-							const float xyz[3] = { x.x, x.y, x.z };
-							apply_fragment(ps, pixel, entry, fbs & 0xFFu, xyz, (FEATS & FEAT_LPE) ? (fbs >> 16) & 0xFu : 0u);
-						}
+					// A shadow ray only reports whether it reached the light: one flag in the slot's pending word.  Its fragment (direct.cpp:329-351)
+					// is applied by the shading pass that takes the slot next -- same order (NEE of vertex k before anything of vertex k + 1),
+					// but the two dependent global round trips (fragment record, then the pixel's sums) no longer stall a wave full of rays
+					// in flight every time one of its shadow rays ends (a third of all rays; ~ 20 % of the traversal loop's time on C4).
+					uint32_t add = 0xFFFFFFFFu; // -1
+					if (s.any) {
+						if (s.best.tri == INVALID)
+							add += PP_VISIBLE;
 					} else {
 						ps.hit[slot] = make_float4(s.best.t, s.best.u, s.best.v, __uint_as_float(s.best.tri));
 					}
-					// release: the hit / fragment is visible to the wave that shades the slot next
-					const uint32_t old = __hip_atomic_fetch_sub(&sh.pending[slot_l], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+					// release: the hit is visible to the wave that shades the slot next
+					const uint32_t old = __hip_atomic_fetch_add(&sh.pending[slot_l], add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
 					last			   = (old & 0xFFu) == 1u;
 					entry			   = slot_l | ((old & PP_DEAD) ? PP_REGEN : 0u);
 					if (NQ > 1 && last && !(old & PP_DEAD)) { // class of the material the slot's path ray hit (the shadow ray may finish last)
@@ -2736,6 +2903,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				}
 				for (int q = 0; q < NQ; ++q)
 					ring_push(sh.q_shade[q], SHADE_MASK, &sh.shade_tail[q], last && qcls == q, entry);
+				if (COUNT)
+					t_fin += wall_clock64() - t0f;
 			}
 			const int active = __popcll(__ballot(has_ray));
 			if (active == 0)
@@ -2771,6 +2940,11 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			atomicAdd(&a.gstats[CNT_SHADE_TICKS], t_shade);
 			atomicAdd(&a.gstats[CNT_IDLE_TICKS], t_idle);
 			atomicAdd(&a.gstats[CNT_TOTAL_TICKS], wall_clock64() - t_start);
+			atomicAdd(&a.gstats[CNT_LEAF_TICKS], t_leaf);
+			atomicAdd(&a.gstats[CNT_INNER_TICKS], t_inner);
+			atomicAdd(&a.gstats[CNT_REFILL_TICKS], t_refill);
+			atomicAdd(&a.gstats[CNT_FIN_TICKS], t_fin);
+			atomicAdd(&a.gstats[CNT_TOTAL_CYCLES], (unsigned long long)clock64() - c_start);
 		}
 		if (threadIdx.x == 0) // diagnostics (PRGPU_DUMP_BLOCK_LIFE): the block's lifetime and vertex count, in its own first spill entry (no longer needed)
 			a.spill[blockIdx.x * TRAV_BLOCK] = make_uint2((uint32_t)(wall_clock64() - t_start), sh.bs.v[PRGPU_STAT_CAMERA_DEPTH] + sh.bs.v[PRGPU_STAT_BACKGROUND_HITS]);
@@ -2821,6 +2995,91 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uin
 // 64-bit LDS minimum over (t, triangle id) -- exactly the reference's rule "closer, or equally close with the smaller id".  A ray is
 // finished when its stack is empty and none of its tasks is outstanding; u, v come from one more test of the winning triangle
 // (found through tri_slot: triangle -> leaf unit and slot).  Inner steps see the best t one batch late (more records visited).
+constexpr uint32_t SPLIT_Q = 1024; // ring of leaf tasks (owner lane | leaf unit << 8)
+// ---- split traversal: leaf tests handed to whole waves through an LDS task queue (ray service, k_service_closest_split: one block-wide queue) ----
+// inner step of the split traversal: hit children that are leaves become tasks at once (they never enter the stack), the inner ones
+// are sorted and pushed as in trav_inner_rec.  Returns nothing; *n_tasks = leaves queued by this lane.
+template <typename STK>
+__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, uint32_t* q, uint32_t* q_tail,
+												 uint32_t* pending_own, uint32_t tid, bool active, const uint32_t* q_head, uint32_t* overflow)
+{
+	float t[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
+	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
+	bool h[4] = { false, false, false, false };
+	if (active) {
+		const uint32_t eb = __float_as_uint(q0.w);
+		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
+		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
+		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
+		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
+		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const float axk = __fmaf_rn(PR_UB(wnx, k), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn(PR_UB(wfx, k), sx, dx) * s.r.inv_d.x;
+			const float ayk = __fmaf_rn(PR_UB(wny, k), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn(PR_UB(wfy, k), sy, dy) * s.r.inv_d.y;
+			const float azk = __fmaf_rn(PR_UB(wnz, k), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn(PR_UB(wfz, k), sz, dz) * s.r.inv_d.z;
+			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
+			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
+			t[k]		   = t0;
+			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY;
+		}
+	}
+	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts through three ballots)
+	bool lf[4];
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		lf[k] = h[k] && (c[k] & REC_LEAF_BIT) != 0u;
+		cnt += lf[k] ? 1u : 0u;
+	}
+	{
+		const uint32_t lane			   = tid & 63u;
+		const unsigned long long below = (1ull << lane) - 1ull;
+		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
+		const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
+		if (total != 0u) {
+			uint32_t base = 0;
+			if (lane == 0)
+				base = __hip_atomic_fetch_add(q_tail, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			base = wave_bcast0(base);
+			if (lane == 0 && base + total - lds_load(q_head) > SPLIT_Q) // cannot happen while callers keep the ring below a quarter full and a
+				__hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // step adds at most 256 per wave; loud if it does
+			uint32_t pos = base + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+			if (cnt)
+				__hip_atomic_fetch_add(pending_own, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				if (lf[k])
+					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], ((c[k] & ~REC_LEAF_BIT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+	}
+	if (!active)
+		return;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const bool in = h[k] && !lf[k];
+		t[k]		  = in ? t[k] : INFINITY;
+		c[k]		  = in ? c[k] : REC_EMPTY;
+	}
+#define PR_CSWAP(a, b)                                          \
+	{                                                           \
+		const bool sw	  = t[b] < t[a];                        \
+		const float ta = t[a], tb = t[b];                       \
+		const uint32_t ca = c[a], cb = c[b];                    \
+		t[a] = sw ? tb : ta; t[b] = sw ? ta : tb;               \
+		c[a] = sw ? cb : ca; c[b] = sw ? ca : cb;               \
+	}
+	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+#undef PR_CSWAP
+	st.reserve(3);
+	st.push_if(c[3] != REC_EMPTY, c[3], t[3]);
+	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
+	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
+	s.cur = c[0];
+	trav_pop<MODE_CLOSEST>(s, st);
+}
+
 constexpr bool COUNT_SPLIT_STEPS = true;
 struct SplitShared {
 	uint2 stack[STACK_LDS * TRAV_BLOCK];
@@ -3184,7 +3443,20 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.leaf_bias		  = getenv("PRGPU_PP_LEAF_BIAS") ? std::max(1, atoi(getenv("PRGPU_PP_LEAF_BIAS"))) : 100;
 	a.gstats		  = gstats;
 	a.direct_map	  = all_in_flight ? 1u : 0u;
-	a.fin_batch		  = getenv("PRGPU_PP_FIN_BATCH") ? std::min(64, std::max(1, atoi(getenv("PRGPU_PP_FIN_BATCH")))) : 16;
+	// resident pixels: more pixels than slots and more than one sample per pixel in this launch (PRGPU_PP_RESIDENT=0: a pixel keeps its slot)
+	static const bool resident_ok = !(getenv("PRGPU_PP_RESIDENT") && atoi(getenv("PRGPU_PP_RESIDENT")) == 0);
+	a.bl_cap		  = (uint32_t)std::min<uint64_t>(n_owned, 2ull * ((n_owned + g.n_blocks - 1) / g.n_blocks) + 1024ull);
+	a.bl_list		  = ws.bl_list;
+	a.bl_word		  = ws.bl_word;
+	a.slot_unit		  = ws.slot_unit;
+	a.resident		  = resident_ok && !all_in_flight && iter_end - iter_begin >= 2u && iter_end - iter_begin < 65536u && ws.bl_list != nullptr
+						&& uint64_t(a.bl_cap) * g.n_blocks <= ws.bl_entries && uint64_t(a.bl_cap) * (iter_end - iter_begin) < (1ull << 31)
+					  ? 1u
+					  : 0u;
+	if (!a.resident)
+		a.bl_cap = 0;
+	a.ws_min_tasks	  = getenv("PRGPU_PP_WS_MIN") ? (uint32_t)std::min(64, std::max(1, atoi(getenv("PRGPU_PP_WS_MIN")))) : 32u;
+	a.ws_wait		  = getenv("PRGPU_PP_WS_WAIT") ? std::min(65, std::max(1, atoi(getenv("PRGPU_PP_WS_WAIT")))) : 16;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks);
 	// smallest compiled variant that covers the scene's features: lean (Lambert / mesh / area lights), + smooth delta materials,

@@ -552,10 +552,17 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 			if (const char* env = getenv("PRGPU_PP_BLOCKS_PER_CU"))
 				pp_blocks_per_cu = (uint32_t)std::min(8, std::max(1, atoi(env)));
 			s->ws_pp.max_blocks	  = (uint32_t)std::max(1, prop.multiProcessorCount) * pp_blocks_per_cu;
+			if (const char* env = getenv("PRGPU_PP_MAX_BLOCKS")) // tests: a small grid, so that a small film has more pixels than path slots
+				s->ws_pp.max_blocks = (uint32_t)std::min<int64_t>(s->ws_pp.max_blocks, std::max(1, atoi(env)));
 			s->ws_pp.refill_below = 48;
 			if (const char* env = getenv("PRGPU_PP_REFILL"))
 				s->ws_pp.refill_below = std::min(64, std::max(1, atoi(env)));
 			AL(s->ws_pp.spill, prd::trace_workspace_spill_entries(s->ws_pp.max_blocks), false);
+			// resident pixels (launch_path_persistent): room for every block to list twice its fair share of the frame
+			s->ws_pp.bl_entries = 2 * size_t(np) + size_t(s->ws_pp.max_blocks) * 1026u;
+			AL(s->ws_pp.bl_list, s->ws_pp.bl_entries, false);
+			AL(s->ws_pp.bl_word, s->ws_pp.bl_entries, false);
+			AL(s->ws_pp.slot_unit, ns, false);
 		}
 		if (rc != PRGPU_OK)
 			return rc;
@@ -831,7 +838,7 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	// watchdog is never near a legitimate wait.  Per-pixel state lives in the planes, so consecutive launches continue exactly
 	// where the previous one stopped (identical results for any chunking).
 	const uint64_t per_iter = std::max<uint64_t>(1, s->n_slots);
-	uint32_t chunk			= (uint32_t)std::min<uint64_t>(1u << 20, std::max<uint64_t>(s->pp_launch_min_iters, s->pp_launch_samples / per_iter));
+	uint32_t chunk			= (uint32_t)std::min<uint64_t>(1u << 15, std::max<uint64_t>(s->pp_launch_min_iters, s->pp_launch_samples / per_iter));
 	// A small tile share (every owned pixel in flight at once, no slot ever takes a second pixel) is bound by the LATENCY of a pixel's
 	// chain of samples, not by throughput: there the block's last wave only shades (batches of any size, the moment a vertex waits)
 	// and the other three only trace, so that no ray in flight is parked behind a shading pass (1/8 of the C4 frame: 2.62 -> 2.30 ms
@@ -1238,6 +1245,13 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 	out->shade_ticks		= host[PRGPU_STAT_COUNT + 8];
 	out->idle_ticks			= host[PRGPU_STAT_COUNT + 9];
 	out->total_ticks		= host[PRGPU_STAT_COUNT + 10];
+	if (getenv("PRGPU_DEBUG_COUNTERS")) // development: split-traversal time split and the shader clock (cycles per 100 MHz tick)
+		if (host[PRGPU_STAT_COUNT + 10]) {
+			const double T = double(host[PRGPU_STAT_COUNT + 10]);
+			fprintf(stderr, "[prgpu] wave time: shading %.1f %%, idle %.1f %%, leaf steps %.1f %%, inner steps %.1f %%, refill %.1f %%, ray ends %.1f %%; shader clock %.0f MHz\n",
+					100 * host[PRGPU_STAT_COUNT + 8] / T, 100 * host[PRGPU_STAT_COUNT + 9] / T, 100 * host[PRGPU_STAT_COUNT + 11] / T, 100 * host[PRGPU_STAT_COUNT + 12] / T,
+					100 * host[PRGPU_STAT_COUNT + 14] / T, 100 * host[PRGPU_STAT_COUNT + 15] / T, 100.0 * double(host[PRGPU_STAT_COUNT + 13]) / T);
+		}
 	return PRGPU_OK;
 }
 

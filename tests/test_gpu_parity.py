@@ -332,6 +332,38 @@ def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypat
         assert ref[2] == out[2], env
 
 
+@pytest.mark.parametrize("blocks,slots", [(4, 256), (7, 512), (16, 256), (40, 256), (64, 512)])
+def test_resident_pixel_scheduling_of_the_persistent_kernel_is_bit_exact(monkeypatch, blocks, slots):
+    """More pixels than path slots and several samples per launch: pixels stay with a BLOCK, which deals (pixel, sample) units round-robin
+    to its free slots (a unit whose predecessor still runs is delegated to the slot running it).  Grid sizes from 'every block lists
+    5000 pixels' down to 'hardly more pixels than slots' (delegation on nearly every unit); results equal the oracle's bit for bit, and
+    those of the pixel-keeps-its-slot scheme (PRGPU_PP_RESIDENT=0 is read once per process, so that scheme is covered by the oracle)."""
+    monkeypatch.setenv("PRGPU_MODE", "persistent")
+    monkeypatch.setenv("PRGPU_PP_MAX_BLOCKS", str(blocks))
+    monkeypatch.setenv("PRGPU_PP_SLOTS", str(slots))
+    sc = scene.cornell_soup(160, 128, spp=7, n_triangles=5_000)
+    g, o = render_both(sc, iters=7)
+    assert_parity(g, o, exact=True)
+    # a second call continues the pixels' streams (launches of 3 + 2 + 1 iterations)
+    g2 = backend.RenderContext(sc)
+    for n in (3, 2, 1, 1):
+        g2.render(n)
+    g2.waitForFinish()
+    for a, b in zip(g.output(), g2.output()):
+        assert np.array_equal(a, b)
+    assert g.statistics() == g2.statistics()
+
+
+def test_resident_pixel_scheduling_with_a_multi_tap_filter_and_glass(monkeypatch):
+    monkeypatch.setenv("PRGPU_MODE", "persistent")
+    monkeypatch.setenv("PRGPU_PP_MAX_BLOCKS", "9")
+    monkeypatch.setenv("PRGPU_PP_SLOTS", "256")
+    g, o = render_both(scene.cornell_glassy(96, 80, spp=6, filter=abi.FILTER_GAUSSIAN, filter_radius=2), iters=6)
+    assert assert_parity(g, o, exact=False) <= 1e-5
+    g, o = render_both(scene.cornell_rough(96, 80, spp=6), iters=6)
+    assert_parity(g, o, exact=True)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("flt,r", [(abi.FILTER_MITCHELL, 1), (abi.FILTER_GAUSSIAN, 2)])
 def test_bound_framebuffer_receives_every_plane_in_every_pipeline(monkeypatch, mode, flt, r):

@@ -13,7 +13,7 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 sc = scene.cornell_soup(W, H, spp=1024, n_triangles=1_000_000)
 ctx = backend.RenderContext(sc)
 if world > 1:
-    ctx.setTiles(tiling.tiles_for_rank(W, H, 0, world))
+    ctx.setTiles(tiling.tiles_for_rank(W, H, 0, world, tile=64 if world <= 2 else 16))
 ctx.render(8); ctx.waitForFinish()
 ctx.setInstrumentation(True); ctx.render(iters); ctx.waitForFinish()
 rows = np.loadtxt(out, dtype=np.int64)
@@ -21,6 +21,7 @@ life = rows[:, 1] / 1e5 / iters     # ms per iteration
 work = rows[:, 2] / iters           # path vertices per iteration
 q = np.percentile(life, [0, 5, 25, 50, 75, 95, 100])
 print("share 1/%d, %d iterations: block lifetime ms/iteration min %.3f p5 %.3f p25 %.3f median %.3f p75 %.3f p95 %.3f max %.3f, mean %.3f" % ((world, iters) + tuple(q) + (life.mean(),)))
+print("launch: last block ends after %.3f ms; blocks idle at the end of the launch for %.1f %% of the grid's time (1 - mean / max lifetime)" % (rows[:, 1].max() / 1e5, 100 * (1 - life.mean() / life.max())))
 print("vertices per block and iteration: min %.0f median %.0f max %.0f; correlation(lifetime, vertices) = %.3f" % (work.min(), np.median(work), work.max(), np.corrcoef(life, work)[0, 1]))
 for k in range(8):  # by XCD (block index mod 8)
     print("  blocks with index %% 8 == %d: mean lifetime %.3f, mean vertices %.0f" % (k, life[k::8].mean(), work[k::8].mean()))
