@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define PRGPU_API_VERSION 7
+#define PRGPU_API_VERSION 8
 #define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
 
 enum {
@@ -511,13 +511,13 @@ int prgpu_write_exr(const char* path, uint32_t width, uint32_t height, uint32_t 
  * (spectral_mapper), (integrator :type 'direct'), (camera :type 'standard'), (material :type 'diffuse'), (emission :type 'standard'),
  * spectral expressions number / (refl r g b) / (illum r g b) / (illuminant "D65") / (spectrum :start :end v...) / (smul a b),
  * inline (mesh (attribute :type 'p'|'n' ...) (faces ...) (materials ...)), (entity :type 'mesh' ...), (include "file"),
- * (light :type 'env'|'distant'|'sun'|'sky') -- the sky with a host-supplied table (prgpu_prc_sky).
+ * (light :type 'env'|'distant'|'sun'|'sky') -- the sky's Hosek-Wilkie table is built by the loader (prgpu_sky_table).
  * Constructs this backend cannot render fail with PRGPU_EUNSUPPORTED and a message naming the block; output blocks are skipped
  * with a warning.  The returned object owns every array the description points to. */
 typedef struct prgpu_prc prgpu_prc;
-/* The table a (light :type 'sky') evaluates: SkyModel::mData (src/skysun/skysun/SkyModel.cpp:17-60), which PearRay fills from the
- * Hosek-Wilkie dataset while it loads the scene.  The dataset stays with the host (pr_lib_skysun); the loader takes the finished table.
- * A sky light without a matching entry fails with PRGPU_EUNSUPPORTED and a message that names what is needed. */
+/* The table a (light :type 'sky') evaluates: SkyModel::mData (src/skysun/skysun/SkyModel.cpp:15-56), filled from the Hosek-Wilkie
+ * sky-dome model while the scene loads.  The loader builds it itself (prgpu_sky_table below); a host that already holds the finished
+ * table of its own SkyModel may pass it in instead, per light name. */
 typedef struct prgpu_prc_sky {
 	const char*  light_name;       /* :name of the light this table belongs to; NULL = any sky light */
 	const float* table;            /* elevation_count * azimuth_count * 11 floats, [elevation][azimuth][band] */
@@ -528,7 +528,7 @@ typedef struct prgpu_prc_options {
 	uint32_t aa_samples;    /* 0: keep the aa sampler's :sample_count */
 	uint32_t force_direct;  /* 1: accept any (integrator :type ...) and render it with `direct` at default parameters */
 	uint64_t seed;          /* 0: RenderSettings default (42) */
-	uint32_t n_skies;       /* host-supplied sky tables (may be 0) */
+	uint32_t n_skies;       /* host-supplied sky tables (may be 0: the loader builds them) */
 	uint32_t reserved;
 	const prgpu_prc_sky* skies;
 } prgpu_prc_options;
@@ -540,10 +540,23 @@ void  prgpu_sun_position(int year, int month, int day, int hour, int minute, flo
 /* Sun radiance through the atmosphere [W / (m^2 nm sr)] at `wavelength` nm for the zenith angle `theta` and a turbidity:
  * computeSunRadiance, src/skysun/skysun/SunRadiance.cpp:76-118 (the loader tabulates it for `sun` lights, sun.cpp:42-46,166-170). */
 float prgpu_sun_radiance(float wavelength, float theta, float turbidity);
+/* SkyModel::SkyModel (src/skysun/skysun/SkyModel.cpp:15-56) over the spectral Hosek-Wilkie model (src/skysun/skysun/model/
+ * ArHosekSkyModel.cpp:130-401,520-565): table[elevation][azimuth][band] (elevation_count * azimuth_count * 11 floats, elevation rows
+ * 0 .. pi/2, azimuth columns 0 .. 2 pi) for the sun at (sun_elevation, sun_azimuth) as computeSunEA returns them, a turbidity in
+ * [1, 10] and the ground albedo at the band wavelengths 320 + 40 k nm.  Host only (no device involved); ~0.1 s for 512 x 256. */
+typedef struct prgpu_sky_params {
+	float sun_elevation, sun_azimuth; /* computeSunEA (SunLocation.cpp:102-124) of the light's parameters */
+	float turbidity;                  /* `turbidity` (default 3) */
+	float albedo[PRGPU_SKY_BANDS];    /* `albedo` (default 0.15) evaluated at 320 + 40 k nm (SkyModel.cpp:28-34) */
+} prgpu_sky_params;
+int prgpu_sky_table(float sun_elevation, float sun_azimuth, float turbidity, const float albedo[PRGPU_SKY_BANDS], uint32_t azimuth_count,
+                    uint32_t elevation_count, float* table);
 int prgpu_prc_load_file(const char* path, const prgpu_prc_options* options, prgpu_prc** out);
 int prgpu_prc_load_string(const char* source, const char* include_dir, const prgpu_prc_options* options, prgpu_prc** out);
 const prgpu_scene_desc* prgpu_prc_desc(const prgpu_prc* scene);
 const char* prgpu_prc_warnings(const prgpu_prc* scene); /* newline separated */
+/* What the SkyModel of light `light` (a PRGPU_LIGHT_SKY of the loaded scene) was built from; PRGPU_EINVAL for any other light. */
+int prgpu_prc_sky_info(const prgpu_prc* scene, uint32_t light, prgpu_sky_params* out);
 /* The scene's (output ...) blocks: their channels (all files, in file order) and the :name of file k (NULL beyond the last). */
 const prgpu_output_channel* prgpu_prc_outputs(const prgpu_prc* scene, uint32_t* n_channels);
 const char* prgpu_prc_output_name(const prgpu_prc* scene, uint32_t file);

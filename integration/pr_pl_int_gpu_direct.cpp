@@ -7,7 +7,7 @@
 //
 // How the scene crosses: core interfaces (IEntity, IMaterial) do not expose triangles or closure parameters, so the adapter does not
 // walk Scene -- it hands the SAME scene file the host is loading to the library's own loader (prgpu_prc_load_file), which produces
-// the flat prgpu_scene_desc, and supplies what only the host can compute: the SkyModel tables of `sky` lights (pr_lib_skysun).
+// the flat prgpu_scene_desc, the Hosek-Wilkie tables of `sky` lights included (prgpu_sky_table: SkyModel.cpp:15-56 restated).
 // How the frame comes back: results bypass the per-fragment queue (RenderTileSession::pushSpectralFragment is a per-sample virtual
 // call); at onEnd() the XYZ / sample-count / feedback planes, the shading-point AOVs, the online mean / variance and the
 // light path expression planes are downloaded into the host's FrameOutputDevice buffers.
@@ -23,42 +23,26 @@
 #include "renderer/RenderContext.h"
 #include "renderer/RenderTile.h"
 #include "renderer/RenderTileSession.h"
-#include "skysun/SkyModel.h"
-#include "skysun/SunLocation.h"
 
 #include <prgpu.h>
 
 #include <atomic>
-#include <map>
 
 namespace PR {
 struct GpuDirectSetup {
 	std::filesystem::path SceneFile;						// the .prc being loaded (SceneLoadContext::currentFile)
 	prgpu_settings Integrator;								// `direct` parameters (direct.cpp:500-515)
-	std::map<std::string, std::vector<float>> SkyTables;	// SkyModel::mData per sky light, [elevation][azimuth][band]
-	std::map<std::string, std::pair<uint32, uint32>> SkyResolution;
 };
 
-// flatten(ctx): everything the device needs, from the scene FILE plus the host-side tables
+// flatten(ctx): everything the device needs, from the scene FILE
 static prgpu_prc* flatten(const GpuDirectSetup& setup, const RenderSettings& rs)
 {
-	std::vector<prgpu_prc_sky> skies;
-	for (const auto& kv : setup.SkyTables) {
-		prgpu_prc_sky s;
-		s.light_name	  = kv.first.c_str();
-		s.table			  = kv.second.data();
-		s.azimuth_count	  = setup.SkyResolution.at(kv.first).first;
-		s.elevation_count = setup.SkyResolution.at(kv.first).second;
-		skies.push_back(s);
-	}
 	prgpu_prc_options opt;
 	std::memset(&opt, 0, sizeof(opt));
 	opt.width		 = rs.filmWidth; // the host's settings win over the file (command line overrides)
 	opt.height		 = rs.filmHeight;
 	opt.seed		 = rs.seed;
 	opt.force_direct = 1; // the file says (integrator :type 'gpu_direct'); render it with the direct path
-	opt.n_skies		 = (uint32)skies.size();
-	opt.skies		 = skies.data();
 	prgpu_prc* file	 = nullptr;
 	if (prgpu_prc_load_file(setup.SceneFile.generic_string().c_str(), &opt, &file) != PRGPU_OK) {
 		PR_LOG(L_ERROR) << "[gpu_direct] " << prgpu_prc_last_error() << std::endl;
@@ -208,22 +192,6 @@ public:
 		setup.Integrator.nee				= p.getBool("nee", true);
 		setup.Integrator.direct				= p.getBool("direct", true);
 		setup.Integrator.emissive_scatter	= p.getBool("emissive_scatter", true);
-		// `sky` lights: the integrator block may name them with their parameters (:sky_lights ['sky']); the table is the host's
-		// SkyModel evaluated exactly as sky.cpp:195 does.  A scene without sky lights needs nothing here.
-		for (const std::string& name : p.getStringArray("sky_lights")) {
-			SceneLoadContext light_ctx(ctx.environment(), ctx.currentFile());
-			light_ctx.parameters() = ctx.environment()->lightParameters(name); // the (light :name ...) block's parameter group
-			const ElevationAzimuth sunEA = computeSunEA(light_ctx.parameters());
-			const SkyModel model(light_ctx.lookupSpectralNode("albedo", 0.15f), sunEA, light_ctx.parameters());
-			std::vector<float> table(model.elevationCount() * model.azimuthCount() * AR_SPECTRAL_BANDS);
-			for (size_t el = 0; el < model.elevationCount(); ++el)
-				for (size_t az = 0; az < model.azimuthCount(); ++az)
-					for (size_t b = 0; b < AR_SPECTRAL_BANDS; ++b)
-						table[(el * model.azimuthCount() + az) * AR_SPECTRAL_BANDS + b] = model.radiance((int)b,
-							ElevationAzimuth{ ELEVATION_RANGE * (el + 0.5f) / model.elevationCount(), AZIMUTH_RANGE * (az + 0.5f) / model.azimuthCount() });
-			setup.SkyTables[name]	  = std::move(table);
-			setup.SkyResolution[name] = { (uint32)model.azimuthCount(), (uint32)model.elevationCount() };
-		}
 		return std::make_shared<IntGpuDirectFactory>(setup);
 	}
 

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRGPU_LIBRARY") or os.path.join(_HERE, "csrc", "libprgpu.so")   # PRGPU_LIBRARY: an A/B build of the same ABI (development)
 
-PRGPU_API_VERSION = 7
+PRGPU_API_VERSION = 8
 INVALID_ID = 0xFFFFFFFF
 COMM_ID_BYTES = 128
 
@@ -147,6 +147,10 @@ def default_settings(width, height):
 
 
 # Entry points declared by include/prgpu.h: name -> (restype, argtypes)
+class SkyParams(C.Structure):  # prgpu_sky_params
+    _fields_ = [("sun_elevation", C.c_float), ("sun_azimuth", C.c_float), ("turbidity", C.c_float), ("albedo", C.c_float * 11)]
+
+
 _VP, _U32P, _F32P, _U8P, _U64P = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)
 SYMBOLS = {
     "prgpu_last_error": (C.c_char_p, []),
@@ -196,6 +200,8 @@ SYMBOLS = {
     "prgpu_write_exr": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(_F32P), _U32P]),
     "prgpu_sun_position": (None, [C.c_int] * 5 + [C.c_float] * 4 + [_F32P, _F32P]),
     "prgpu_sun_radiance": (C.c_float, [C.c_float] * 3),
+    "prgpu_sky_table": (C.c_int, [C.c_float, C.c_float, C.c_float, _F32P, C.c_uint32, C.c_uint32, _F32P]),
+    "prgpu_prc_sky_info": (C.c_int, [_VP, C.c_uint32, C.POINTER(SkyParams)]),
     "prgpu_prc_load_file": (C.c_int, [C.c_char_p, C.POINTER(PrcOptions), C.POINTER(_VP)]),
     "prgpu_prc_load_string": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(PrcOptions), C.POINTER(_VP)]),
     "prgpu_prc_desc": (C.POINTER(SceneDesc), [_VP]),

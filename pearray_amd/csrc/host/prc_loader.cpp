@@ -44,6 +44,7 @@ struct prgpu_prc {
 	std::vector<prgpu_emission> emissions;
 	std::vector<prgpu_spectrum> spectra;
 	std::vector<prgpu_light> lights;
+	std::vector<prgpu_sky_params> sky_params; // per light (sky lights only: what SkyModel was built from)
 	std::vector<prgpu_output_channel> outputs;
 	std::vector<std::string> output_names;
 	prgpu_scene_desc desc;
@@ -501,6 +502,37 @@ struct Loader {
 	}
 	std::string current_dir; // directory of the file being loaded (relative file names of spd nodes)
 	float string_default = 1.0f; // default of the parameter being parsed (for strings naming unknown nodes)
+	// FloatSpectralNode::eval of a loaded node at one wavelength (what SkyModel asks of the ground albedo, SkyModel.cpp:30-34): the
+	// arithmetic of spectrum_leaf / spectrum_eval on the device
+	float eval_spectrum_at(uint32_t id, float wl) const
+	{
+		auto leaf = [&](const prgpu_spectrum& n) -> float {
+			switch (n.kind) {
+			case PRGPU_SPEC_CONST: return n.p[0];
+			case PRGPU_SPEC_PARAMETRIC:
+			case PRGPU_SPEC_PARAMETRIC_SCALED: {
+				const float x = (n.p[0] * wl + n.p[1]) * wl + n.p[2];
+				const float v = (0.5f * x) * (1.0f / std::sqrt(x * x + 1.0f)) + 0.5f;
+				return n.kind == PRGPU_SPEC_PARAMETRIC ? v : v * n.p[3];
+			}
+			case PRGPU_SPEC_TABLE: {
+				const float delta = (n.wl_end - n.wl_start) / (n.table_count - 1);
+				const float af	  = std::max(0.0f, (wl - n.wl_start) / delta);
+				const int index	  = (int)std::min<float>(float(n.table_count - 2), af);
+				const float t	  = std::min<float>(float(n.table_count - 1), af) - index;
+				const float* data = out.tables.data() + n.table_offset;
+				return data[index] * (1 - t) + data[index + 1] * t;
+			}
+			default: return 0.0f;
+			}
+		};
+		if (id >= out.spectra.size())
+			return 0.0f;
+		const prgpu_spectrum& n = out.spectra[id];
+		if (n.kind == PRGPU_SPEC_MUL && n.lhs < out.spectra.size() && n.rhs < out.spectra.size())
+			return leaf(out.spectra[n.lhs]) * leaf(out.spectra[n.rhs]);
+		return leaf(n);
+	}
 	uint32_t spectral_param(const Group& g, std::initializer_list<const char*> keys, float def)
 	{
 		string_default = def;
@@ -697,20 +729,45 @@ struct Loader {
 					sky = &opt.skies[i];
 					break;
 				}
-			if (!sky || !sky->table)
-				fail(PRGPU_EUNSUPPORTED, where(g) + ": light type 'sky' needs the table of PearRay's SkyModel (Hosek-Wilkie evaluation, src/skysun): "
-												  "supply it through prgpu_prc_options::skies for light '" + name + "'");
 			const uint32_t azc = (uint32_t)get_number(g, "azimuth_resolution", 512), elc = (uint32_t)get_number(g, "elevation_resolution", 256);
-			if (azc != sky->azimuth_count || elc != sky->elevation_count)
-				fail(PRGPU_EINVAL, where(g) + ": the supplied sky table is " + std::to_string(sky->azimuth_count) + " x " + std::to_string(sky->elevation_count)
-										+ " but the light asks for " + std::to_string(azc) + " x " + std::to_string(elc));
+			if (azc == 0 || elc == 0 || uint64_t(azc) * elc > (1ull << 26))
+				fail(PRGPU_EINVAL, where(g) + ": sky resolution out of range");
+			// SkyLightFactory::create (sky.cpp:180-198) -> SkyModel (SkyModel.cpp:15-56): ground albedo (default 0.15) at the eleven band
+			// wavelengths, the sun position, the turbidity (default 3)
+			prgpu_sky_params sp;
+			std::memset(&sp, 0, sizeof(sp));
+			sun_position(g, sp.sun_elevation, sp.sun_azimuth);
+			sp.turbidity = (float)get_number(g, "turbidity", 3.0);
+			{ // the albedo is only evaluated here: nodes its expression created do not stay in the scene
+				const size_t n_spectra = out.spectra.size(), n_tables = out.tables.size();
+				const uint32_t alb	   = spectral_param(g, { "albedo" }, 0.15f);
+				for (int k = 0; k < PRGPU_SKY_BANDS; ++k)
+					sp.albedo[k] = eval_spectrum_at(alb, 320.0f + k * 40.0f);
+				out.spectra.resize(n_spectra);
+				out.tables.resize(n_tables);
+			}
+			std::vector<float> own;
+			const float* table = sky ? sky->table : nullptr;
+			if (table) {
+				if (azc != sky->azimuth_count || elc != sky->elevation_count)
+					fail(PRGPU_EINVAL, where(g) + ": the supplied sky table is " + std::to_string(sky->azimuth_count) + " x " + std::to_string(sky->elevation_count)
+											+ " but the light asks for " + std::to_string(azc) + " x " + std::to_string(elc));
+			} else { // no table from the host: build it here
+				own.resize(size_t(azc) * elc * PRGPU_SKY_BANDS);
+				if (prgpu_sky_table(sp.sun_elevation, sp.sun_azimuth, sp.turbidity, sp.albedo, azc, elc, own.data()) != PRGPU_OK)
+					fail(PRGPU_EINVAL, where(g) + ": the sky model covers turbidities 1 ... 10");
+				table = own.data();
+			}
+			if (out.sky_params.size() < out.lights.size() + 1)
+				out.sky_params.resize(out.lights.size() + 1);
+			out.sky_params[out.lights.size()] = sp;
 			l.kind			  = PRGPU_LIGHT_SKY;
 			l.radiance		  = PRGPU_INVALID_ID;
 			l.flags			  = (get_bool(g, "extend", true) ? PRGPU_SKYF_EXTEND : 0u) | (get_bool(g, "compensation", false) ? PRGPU_SKYF_COMPENSATION : 0u);
 			l.table_offset	  = (uint32_t)out.tables.size();
 			l.azimuth_count	  = azc;
 			l.elevation_count = elc;
-			out.tables.insert(out.tables.end(), sky->table, sky->table + size_t(azc) * elc * PRGPU_SKY_BANDS);
+			out.tables.insert(out.tables.end(), table, table + size_t(azc) * elc * PRGPU_SKY_BANDS);
 		} else if (type == "uniform_sky" || type == "cloudy_sky") { // CIESkyLightFactory::create, cie_sky.cpp:134-160
 			l.kind	= PRGPU_LIGHT_CIE_SKY;
 			l.flags = type == "cloudy_sky" ? PRGPU_SKYF_CLOUDY : 0u;
@@ -1956,6 +2013,13 @@ int prgpu_prc_load_file(const char* path, const prgpu_prc_options* opt, prgpu_pr
 
 const prgpu_scene_desc* prgpu_prc_desc(const prgpu_prc* p) { return p ? &p->desc : nullptr; }
 const char* prgpu_prc_warnings(const prgpu_prc* p) { return p ? p->warnings.c_str() : ""; }
+int prgpu_prc_sky_info(const prgpu_prc* p, uint32_t light, prgpu_sky_params* out)
+{
+	if (!p || !out || light >= p->lights.size() || p->lights[light].kind != PRGPU_LIGHT_SKY || light >= p->sky_params.size())
+		return PRGPU_EINVAL;
+	*out = p->sky_params[light];
+	return PRGPU_OK;
+}
 const prgpu_output_channel* prgpu_prc_outputs(const prgpu_prc* scene, uint32_t* n_channels)
 {
 	if (n_channels)

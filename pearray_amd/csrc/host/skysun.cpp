@@ -6,12 +6,17 @@
 //   * the sun's spectral radiance through the atmosphere -- computeSunRadiance, src/skysun/skysun/SunRadiance.cpp:76-118 (Preetham,
 //     Shirley, Smits: "A Practical Analytic Model for Daylight", SIGGRAPH 1999, appendix 1; absorption spectra and the solar
 //     spectrum tabulated from Iqbal, "An Introduction to Solar Radiation", 1983 -- published physical data, like the CIE tables).
-// The SKY table (Hosek-Wilkie, 514 KB of fitted coefficients) is NOT reproduced: the host supplies it (prgpu_prc_options::skies).
+//   * the sky table a (light :type 'sky') evaluates -- SkyModel::SkyModel, src/skysun/skysun/SkyModel.cpp:15-56, over the spectral
+//     Hosek-Wilkie sky-dome model (src/skysun/skysun/model/ArHosekSkyModel.cpp:130-401,520-565; L. Hosek, A. Wilkie: "An Analytic Model
+//     for Full Spectral Sky-Dome Radiance", SIGGRAPH 2012): prgpu_sky_table below.  The model's fitted coefficients (published data,
+//     tables/pr_hosek.inl, extracted by tools/extract_hosek.py) are the only thing taken over; the evaluation is restated here and pinned
+//     by a test driver compiled from the reference's own ArHosekSkyModel.cpp (ref_hosek_driver of the checker -> tests/golden/ref_hosek.json).
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
 
 #include "../../../include/prgpu.h"
+#include "../tables/pr_hosek.inl"
 
 namespace {
 
@@ -58,6 +63,71 @@ float ordered_lookup(const float* amp, const float* wvl, int count, float wavele
 	const int index = std::max(0, std::min(first - 1, count - 2));
 	const float t	= std::max(0.0f, std::min(1.0f, (wavelength - wvl[index]) / (wvl[index + 1] - wvl[index])));
 	return amp[index] * (1 - t) + amp[index + 1] * t;
+}
+
+// ---- Hosek-Wilkie sky dome, spectral variant ----
+// The fit stores, per band, albedo (0 | 1) and integer turbidity (1..10), six control points of a quintic Bezier curve over
+// x = cbrt(solar elevation / (pi / 2)): nine coefficients of the radiance distribution and one mean radiance.  A state for given
+// (elevation, turbidity, albedo) blends the curves of the two neighbouring turbidities and the two albedos
+// (ArHosekSkyModel_CookConfiguration / _CookRadianceConfiguration, ArHosekSkyModel.cpp:130-281).  Evaluation order follows the model
+// code term by term, so that the doubles agree with a build of it.
+inline double hosek_quintic(const double* m, int stride, double x)
+{
+	return std::pow(1.0 - x, 5.0) * m[0] + 5.0 * std::pow(1.0 - x, 4.0) * x * m[stride] + 10.0 * std::pow(1.0 - x, 3.0) * std::pow(x, 2.0) * m[2 * stride]
+		   + 10.0 * std::pow(1.0 - x, 2.0) * std::pow(x, 3.0) * m[3 * stride] + 5.0 * (1.0 - x) * std::pow(x, 4.0) * m[4 * stride] + std::pow(x, 5.0) * m[5 * stride];
+}
+struct HosekBand {
+	double config[9];
+	double radiance;
+};
+HosekBand hosek_band(int band, double solar_elevation, double turbidity, double albedo)
+{
+	HosekBand b;
+	const int it	 = (int)turbidity;
+	const double rem = turbidity - (double)it;
+	const double x	 = std::pow(solar_elevation / (PI_D / 2.0), 1.0 / 3.0);
+	const double* C	 = PR_HOSEK_CONFIG[band];
+	const double* R	 = PR_HOSEK_RADIANCE[band];
+	// albedo 0 / 1 at the lower turbidity, then (unless the turbidity is 10) at the higher one
+	for (int i = 0; i < 9; ++i)
+		b.config[i] = (1.0 - albedo) * (1.0 - rem) * hosek_quintic(C + 9 * 6 * (it - 1) + i, 9, x);
+	for (int i = 0; i < 9; ++i)
+		b.config[i] += albedo * (1.0 - rem) * hosek_quintic(C + 9 * 6 * 10 + 9 * 6 * (it - 1) + i, 9, x);
+	b.radiance = (1.0 - albedo) * (1.0 - rem) * hosek_quintic(R + 6 * (it - 1), 1, x);
+	b.radiance += albedo * (1.0 - rem) * hosek_quintic(R + 6 * 10 + 6 * (it - 1), 1, x);
+	if (it != 10) {
+		for (int i = 0; i < 9; ++i)
+			b.config[i] += (1.0 - albedo) * rem * hosek_quintic(C + 9 * 6 * it + i, 9, x);
+		for (int i = 0; i < 9; ++i)
+			b.config[i] += albedo * rem * hosek_quintic(C + 9 * 6 * 10 + 9 * 6 * it + i, 9, x);
+		b.radiance += (1.0 - albedo) * rem * hosek_quintic(R + 6 * it, 1, x);
+		b.radiance += albedo * rem * hosek_quintic(R + 6 * 10 + 6 * it, 1, x);
+	}
+	return b;
+}
+// ArHosekSkyModel_GetRadianceInternal (ArHosekSkyModel.cpp:283-297): theta = zenith angle of the view direction, gamma = angle to the sun
+inline double hosek_distribution(const double* c, double theta, double gamma)
+{
+	const double expM	= std::exp(c[4] * gamma);
+	const double rayM	= std::cos(gamma) * std::cos(gamma);
+	const double mieM	= (1.0 + std::cos(gamma) * std::cos(gamma)) / std::pow((1.0 + c[8] * c[8] - 2.0 * c[8] * std::cos(gamma)), 1.5);
+	const double zenith = std::sqrt(std::cos(theta));
+	return (1.0 + c[0] * std::exp(c[1] / (std::cos(theta) + 0.01))) * (c[2] + c[3] * expM + c[5] * rayM + c[6] * mieM + c[7] * zenith);
+}
+// arhosekskymodel_radiance (ArHosekSkyModel.cpp:520-565) for a state of eleven bands
+double hosek_radiance(const HosekBand* bands, double theta, double gamma, double wavelength)
+{
+	const int low = (int)((wavelength - 320.0) / 40.0);
+	if (low < 0 || low >= 11)
+		return 0.0;
+	const double interp = std::fmod((wavelength - 320.0) / 40.0, 1.0);
+	const double val_low = hosek_distribution(bands[low].config, theta, gamma) * bands[low].radiance;
+	if (interp < 1e-6)
+		return val_low;
+	double result = (1.0 - interp) * val_low;
+	if (low + 1 < 11)
+		result += interp * hosek_distribution(bands[low + 1].config, theta, gamma) * bands[low + 1].radiance;
+	return result;
 }
 
 } // namespace
@@ -126,6 +196,42 @@ void prgpu_sun_position(int year, int month, int day, int hour, int minute, floa
 	if (azimuth)
 		*azimuth = (float)az;
 	(void)PI_D;
+}
+
+// SkyModel::SkyModel (src/skysun/skysun/SkyModel.cpp:15-56): table[elevation y][azimuth x][band k] = max(0, radiance) of the Hosek-Wilkie
+// model for the sun at (sun_elevation, sun_azimuth), with the ground albedo evaluated at the band's wavelength.  Float / double steps as
+// there: the angles are floats (sinf, cosf, acosf), the model runs in double, the band is asked for at its wavelength + 0.005 nm ("make
+// sure the correct bin is chosen": the model then blends 1.25e-4 of the next band in, kept), and the model's `solar_elevation` is
+// handed pi / 2 - sunEA.Elevation as the constructor does.
+int prgpu_sky_table(float sun_elevation, float sun_azimuth, float turbidity, const float albedo[PRGPU_SKY_BANDS], uint32_t azimuth_count,
+					uint32_t elevation_count, float* table)
+{
+	if (!albedo || !table || azimuth_count == 0 || elevation_count == 0)
+		return PRGPU_EINVAL;
+	if (!(turbidity >= 1.0f && turbidity <= 10.0f)) // the fit covers turbidities 1 .. 10 (the model code indexes outside its tables beyond)
+		return PRGPU_EINVAL;
+	const float PI_2F			= 1.57079632679489661923f;
+	const float ELEVATION_RANGE = PI_F * 0.5f, AZIMUTH_RANGE = PI_F * 2;
+	const float solar_elevation = PI_2F - sun_elevation;
+	const float sun_se = std::sin(solar_elevation), sun_ce = std::cos(solar_elevation);
+	for (uint32_t k = 0; k < PRGPU_SKY_BANDS; ++k) {
+		const float wavelength = 320.0f + k * 40.0f;
+		HosekBand bands[PRGPU_SKY_BANDS]; // arhosekskymodelstate_alloc_init: one state per band's albedo
+		for (int b = 0; b < PRGPU_SKY_BANDS; ++b)
+			bands[b] = hosek_band(b, (double)solar_elevation, (double)turbidity, (double)albedo[k]);
+		for (uint32_t y = 0; y < elevation_count; ++y) {
+			const float theta = PI_2F - std::max(0.001f, ELEVATION_RANGE * y / (float)elevation_count);
+			const float st = std::sin(theta), ct = std::cos(theta);
+			for (uint32_t x = 0; x < azimuth_count; ++x) {
+				const float azimuth	 = AZIMUTH_RANGE * x / (float)azimuth_count;
+				const float cosGamma = ct * sun_ce + st * sun_se * std::cos(azimuth - sun_azimuth);
+				const float gamma	 = std::acos(std::min(1.0f, std::max(-1.0f, cosGamma)));
+				const float radiance = (float)hosek_radiance(bands, theta, gamma, wavelength + 0.005f);
+				table[(size_t(y) * azimuth_count + x) * PRGPU_SKY_BANDS + k] = std::max(0.0f, radiance);
+			}
+		}
+	}
+	return PRGPU_OK;
 }
 
 } // extern "C"

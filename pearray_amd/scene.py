@@ -442,6 +442,16 @@ class PrcScene:
         self.desc = lib.prgpu_prc_desc(h).contents
         self.warnings = [w for w in lib.prgpu_prc_warnings(h).decode().split("\n") if w]
 
+    def sky_params(self):
+        """{light index: (sun elevation, sun azimuth, turbidity, albedo[11])} of the scene's sky lights (what their SkyModel was built from)."""
+        out = {}
+        for i in range(self.desc.n_lights):
+            if self.desc.lights[i].kind == abi.LIGHT_SKY:
+                sp = abi.SkyParams()
+                abi.check(self._lib.prgpu_prc_sky_info(self._h, i, C.byref(sp)))
+                out[i] = (sp.sun_elevation, sp.sun_azimuth, sp.turbidity, [float(a) for a in sp.albedo])
+        return out
+
     def outputs(self):
         """(channel array, count) of the scene's (output ...) blocks (OutputSpecification.cpp:254-365)."""
         n = C.c_uint32()
@@ -465,9 +475,20 @@ _STRUCT_ARRAYS = (("entities", "n_entities", abi.Entity), ("materials", "n_mater
                   ("spectra", "n_spectra", abi.Spectrum), ("lights", "n_lights", abi.Light))
 
 
-def save_scene_npz(path, desc, drop_sky_tables=True):
-    """Write a scene description (from SceneBuilder or the .prc loader) as a compressed .npz.  The tables of SKY lights -- host
-    supplied, 5.8 MB each at the default resolution -- are left out by default and given again to load_scene_npz."""
+def hosek_sky_table(sun_elevation, sun_azimuth, turbidity=3.0, albedo=0.15, elevation_count=256, azimuth_count=512):
+    """SkyModel::mData (src/skysun/skysun/SkyModel.cpp:15-56) through prgpu_sky_table: float32 [elevation, azimuth, 11]."""
+    alb = (C.c_float * abi.SKY_BANDS)(*([albedo] * abi.SKY_BANDS if np.isscalar(albedo) else list(albedo)))
+    t = np.zeros((elevation_count, azimuth_count, abi.SKY_BANDS), dtype=np.float32)
+    rc = abi.load().prgpu_sky_table(sun_elevation, sun_azimuth, turbidity, alb, azimuth_count, elevation_count, t.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc != 0:
+        raise abi.PrgpuError("prgpu_sky_table: error %d (turbidity must lie in 1 ... 10)" % rc)
+    return t
+
+
+def save_scene_npz(path, desc, drop_sky_tables=True, sky_params=None):
+    """Write a scene description (from SceneBuilder or the .prc loader) as a compressed .npz.  The tables of SKY lights -- 5.8 MB each at
+    the default resolution -- are left out by default; `sky_params` ({light index: (elevation, azimuth, turbidity, albedo[11])}, e.g.
+    PrcScene.sky_params()) is stored instead, and ArrayScene rebuilds the tables from it (prgpu_sky_table)."""
     def arr(ptr, n, dt):
         return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dt).copy() if n and ptr else np.zeros(0, dt)
     out = {"positions": arr(desc.positions, 3 * desc.n_vertices, np.float32), "normals": arr(desc.normals, 3 * desc.n_vertices, np.float32),
@@ -495,6 +516,8 @@ def save_scene_npz(path, desc, drop_sky_tables=True):
             if en.kind == abi.ENTITY_QUADRIC:
                 en.params = shift(en.params)
     out["tables"] = tables
+    if sky_params:
+        out["sky_params"] = np.array([[i, el, az, tu] + list(al) for i, (el, az, tu, al) in sorted(sky_params.items())], dtype=np.float32)
     for name, count, cls in _STRUCT_ARRAYS:
         n = getattr(desc, count)
         src = lights if name == "lights" else (spectra if name == "spectra" else (entities if name == "entities" else [getattr(desc, name)[i] for i in range(n)]))
@@ -508,7 +531,7 @@ class ArrayScene:
     def __init__(self, path, sky_tables=None):
         z = np.load(path)
         # v6 caches load unchanged: prgpu_light kept its size, and the v6 prgpu_camera is a prefix of the v7 one (the new fields are zero)
-        assert int(z["api_version"][0]) in (6, abi.PRGPU_API_VERSION), "scene cache written for another ABI version"
+        assert int(z["api_version"][0]) in (6, 7, abi.PRGPU_API_VERSION), "scene cache written for another ABI version"  # the structs kept their layout
         self.positions, self.indices, self.tri_material = z["positions"], z["indices"], z["tri_material"]
         self.normals = z["normals"] if len(z["normals"]) else None
         self.uvs = z["uvs"] if len(z["uvs"]) else None
@@ -521,10 +544,15 @@ class ArrayScene:
             self._structs[name + "_n"] = n
         offset = len(tables[0])
         skies = list(sky_tables or [])
+        params = {int(r[0]): r[1:] for r in z["sky_params"]} if "sky_params" in z.files else {}
         for i in range(self._structs["lights_n"]):
             l = self._structs["lights"][i]
             if l.kind == abi.LIGHT_SKY:
-                t = np.ascontiguousarray(skies.pop(0), dtype=np.float32)
+                if skies:
+                    t = np.ascontiguousarray(skies.pop(0), dtype=np.float32)
+                else:  # the Hosek-Wilkie table of the light's SkyModel, rebuilt from the stored parameters
+                    el, az, tu = (float(v) for v in params[i][:3])
+                    t = hosek_sky_table(el, az, tu, [float(a) for a in params[i][3:]], l.elevation_count, l.azimuth_count)
                 assert t.shape == (l.elevation_count, l.azimuth_count, abi.SKY_BANDS), "sky table shape %s" % (t.shape,)
                 l.table_offset = offset
                 tables.append(t.reshape(-1))
@@ -554,22 +582,6 @@ class ArrayScene:
 
 for _p in ("settings", "width", "height", "spp"):
     setattr(ArrayScene, _p, getattr(SceneData, _p))
-
-
-def synthetic_sky_table(elevation_count=256, azimuth_count=512, sun_elevation=0.6, sun_azimuth=3.7, turbidity=3.0):
-    """A stand-in for SkyModel::mData where the Hosek-Wilkie evaluation is not available (tests, bench): a smooth clear-sky shaped
-    table -- horizon brightening, a circumsolar lobe, bluer towards the zenith -- in W / (m^2 nm sr)-like magnitudes.  NOT the
-    Hosek-Wilkie model; images rendered with it are not comparable with PearRay's, the code path and its cost are the same."""
-    el = (np.arange(elevation_count) / elevation_count * (np.pi / 2)).astype(np.float64)
-    az = (np.arange(azimuth_count) / azimuth_count * (2 * np.pi)).astype(np.float64)
-    E, A = np.meshgrid(el, az, indexing="ij")
-    cosg = np.clip(np.sin(E) * np.sin(sun_elevation) + np.cos(E) * np.cos(sun_elevation) * np.cos(A - sun_azimuth), -1, 1)
-    gamma = np.arccos(cosg)
-    lum = (1 + 0.6 * np.exp(-3.0 * np.sin(E))) * (0.25 + 5.0 * np.exp(-3.0 * gamma) + 0.4 * cosg ** 2) * (0.04 * turbidity + 0.03)
-    wl = 320.0 + 40.0 * np.arange(abi.SKY_BANDS)
-    blue = (550.0 / wl) ** (2.0 + 1.5 * np.sin(E)[..., None])          # Rayleigh-like tilt, stronger towards the zenith
-    band = np.exp(-0.5 * ((wl - 480.0) / 220.0) ** 2)                  # roll-off towards UV / IR
-    return (lum[..., None] * blue * band[None, None, :]).astype(np.float32)
 
 
 def load_prc(path, **overrides):

@@ -727,10 +727,10 @@ def test_c5_class_scene_sky_sun_principled_glass_spheres_in_every_pipeline(monke
 
 
 def _complex_c5(width, height, spp):
-    """BASELINE config C5: the scene of examples/complex.prc (fixture written by tools/make_c5_fixture.py) with a synthetic table in
-    place of the Hosek-Wilkie sky, which stays with the host."""
+    """BASELINE config C5: the scene of examples/complex.prc (fixture written by tools/make_c5_fixture.py); the sky light's Hosek-Wilkie
+    table is rebuilt from the parameters the fixture stores (prgpu_sky_table)."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scenes", "complex_c5.npz")
-    sc = scene.ArrayScene(path, sky_tables=[scene.synthetic_sky_table()])
+    sc = scene.ArrayScene(path)
     sc.desc.settings.width, sc.desc.settings.height, sc.desc.settings.aa_samples = width, height, spp
     return sc
 

@@ -182,13 +182,12 @@ def test_uniform_cie_sky_over_a_floor_is_close_to_a_constant_environment():
 
 @pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference examples not present")
 def test_reference_examples_with_spherical_and_fisheye_cameras_load():
-    sky = scene.synthetic_sky_table()
     p = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "sky.prc"))
     cam = p.desc.camera
     assert cam.kind == abi.CAMERA_SPHERICAL and abs(cam.theta_start + 1.570796) < 1e-6 and abs(cam.theta_end - np.pi / 2) < 1e-6
     kinds = sorted(p.desc.lights[i].kind for i in range(p.desc.n_lights))
     assert kinds == [abi.LIGHT_SUN, abi.LIGHT_CIE_SKY] and any(p.desc.lights[i].flags & abi.SKYF_CLOUDY for i in range(p.desc.n_lights))
-    q = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "skylens.prc"), skies={"sky": sky})
+    q = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "skylens.prc"))
     cam = q.desc.camera
     assert cam.kind == abi.CAMERA_FISHEYE and cam.clip_range == 1 and cam.fisheye_map == abi.FISHEYE_CIRCULAR
     assert abs(cam.fov - np.float32(180.0) * (np.float32(np.pi) / np.float32(180.0))) < 1e-6

@@ -121,7 +121,7 @@ def test_defaults_follow_the_reference():
     ("(entity :name 's' :type 'sphere' :emission 'nope')", -1, "unknown emission"),
     ("(material :name 'g' :type 'glass' :roughness 'tex')", -4, "must be a number"),
     ("(material :name 'g' :type 'ward')", -4, "material type 'ward'"),
-    ("(light :name 'sky' :type 'sky')", -4, "needs the table"),
+    ("(light :name 'sky' :type 'sky' :turbidity 0.5)", -1, "turbidities 1"),
     ("(light :name 'l' :type 'spot')", -4, "light type 'spot'"),
     ("(integrator :type 'vcm')", -4, "integrator 'vcm'"),
     ("(sampler :type 'blue_noise')", -4, "sampler type 'blue_noise'"),
@@ -210,7 +210,7 @@ def test_every_reference_example_either_loads_or_names_what_is_missing():
         else:
             assert rc == -4, (name, rc, lib.prgpu_prc_last_error())   # valid DataLisp, unsupported feature -- never a syntax error
             msg = lib.prgpu_prc_last_error().decode()
-            assert "not supported" in msg or "not available" in msg or "needs the table" in msg, name
+            assert "not supported" in msg or "not available" in msg, name
             refused.append(name)
     assert "cornellbox.prc" in loaded and "area_lit_spheres.prc" in loaded and "complex.prc" in loaded and "material_array.prc" in loaded and "sky.prc" in loaded and "skylens.prc" in loaded and "box.prc" in loaded and "quadric_showcase.prc" in loaded and len(loaded) >= 18
 
@@ -305,8 +305,8 @@ def test_sun_and_sky_lights_match_scene_builder():
                      "(light :name 'sky' :type 'sky' :elevation_resolution 4 :azimuth_resolution 8 :extend false :rotation (euler 90 0 0))"
                      "(light :name 'dot' :type 'sun' :radius 0 :theta 0.4 :phi -1.0)")
     table = np.arange(4 * 8 * 11, dtype=np.float32).reshape(4, 8, 11) / 100
-    with pytest.raises(abi.PrgpuError, match="needs the table"):
-        scene.PrcScene(source=src)
+    own = scene.PrcScene(source=src)   # without a host table the loader builds the light's SkyModel itself (tests/test_hosek_sky.py)
+    assert own.desc.lights[1].kind == abi.LIGHT_SKY and list(own.sky_params()) == [1]
     with pytest.raises(abi.PrgpuError, match="8 x 4"):
         scene.PrcScene(source=src, skies={"sky": np.zeros((5, 8, 11), np.float32)})
     s = scene.PrcScene(source=src, skies={"other": np.zeros((4, 8, 11), np.float32), "sky": table})
@@ -410,13 +410,16 @@ def test_scene_cache_round_trips_a_description_and_drops_sky_tables(tmp_path):
 def test_c5_fixture_is_the_reference_scene():
     """tests/golden/scenes/complex_c5.npz (tools/make_c5_fixture.py) against a fresh load of examples/complex.prc."""
     path = os.path.join(HERE, "golden", "scenes", "complex_c5.npz")
-    table = scene.synthetic_sky_table(256, 512)
-    assert table.shape == (256, 512, 11) and np.isfinite(table).all() and table.min() >= 0
-    fx = scene.ArrayScene(path, sky_tables=[table])
+    fx = scene.ArrayScene(path)   # the sky table is rebuilt from the stored sun position, turbidity and ground albedo
     assert (fx.desc.n_triangles, fx.desc.n_entities, fx.desc.n_materials, fx.desc.n_lights) == (304046, 68, 6, 2)
+    sky = [fx.desc.lights[i] for i in range(fx.desc.n_lights) if fx.desc.lights[i].kind == abi.LIGHT_SKY][0]
+    table = fx.tables[sky.table_offset:sky.table_offset + 256 * 512 * 11]
+    assert np.isfinite(table).all() and table.min() >= 0 and 0.1 < table.max() < 1.0   # W / (m^2 sr nm): the circumsolar peak of a clear sky
     if not os.path.isdir(REF_EXAMPLES):
         return
-    ref = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "complex.prc"), skies={"sky": table})
+    ref = scene.PrcScene(path=os.path.join(REF_EXAMPLES, "complex.prc"))   # loads as shipped: no host-supplied table
+    rsky = [ref.desc.lights[i] for i in range(ref.desc.n_lights) if ref.desc.lights[i].kind == abi.LIGHT_SKY][0]
+    assert np.array_equal(arr(ref.desc.spectral_tables, ref.desc.n_spectral_table_values, np.float32)[rsky.table_offset:rsky.table_offset + 256 * 512 * 11], table)
     for f in ("n_vertices", "n_triangles", "n_entities", "n_materials", "n_spectra", "n_lights"):
         assert getattr(fx.desc, f) == getattr(ref.desc, f), f
     assert np.array_equal(arr(fx.desc.positions, 3 * fx.desc.n_vertices, np.float32), arr(ref.desc.positions, 3 * ref.desc.n_vertices, np.float32))

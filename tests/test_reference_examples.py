@@ -18,17 +18,8 @@ NAMES = [os.path.basename(f)[:-4] for f in FIXTURES]
 REF_EXAMPLES = "/root/reference/examples"
 
 
-def sky_tables_for(path):
-    """One synthetic table per SKY light, of the size the light asks for (the Hosek-Wilkie evaluation stays with the host)."""
-    z = np.load(path)
-    raw = z["lights"].tobytes()
-    n = len(raw) // abi.C.sizeof(abi.Light)
-    lights = (abi.Light * max(1, n)).from_buffer_copy(raw.ljust(abi.C.sizeof(abi.Light) * max(1, n), b"\0"))
-    return [scene.synthetic_sky_table(lights[i].elevation_count, lights[i].azimuth_count) for i in range(n) if lights[i].kind == abi.LIGHT_SKY]
-
-
 def load(path):
-    return scene.ArrayScene(path, sky_tables=sky_tables_for(path))
+    return scene.ArrayScene(path)   # sky lights: the Hosek-Wilkie tables are rebuilt from the stored parameters (prgpu_sky_table)
 
 
 def single_tap(sc):
@@ -56,7 +47,7 @@ def test_there_is_a_fixture_for_every_example_the_loader_accepts():
         import tempfile
         with tempfile.TemporaryDirectory() as d:          # the committed fixture is what the loader produces today
             p = os.path.join(d, "x.npz")
-            scene.save_scene_npz(p, s.desc)
+            scene.save_scene_npz(p, s.desc, sky_params=s.sky_params())
             a, b = np.load(p), np.load(os.path.join(HERE, "golden", "scenes", "examples", name[:-4] + ".npz"))
             assert sorted(a.files) == sorted(b.files), name
             for k in a.files:

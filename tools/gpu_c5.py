@@ -1,5 +1,5 @@
-"""BASELINE config C5 on one GPU: examples/complex.prc (fixture tests/golden/scenes/complex_c5.npz; synthetic table in place of the
-Hosek-Wilkie sky) at 1920x1080 -- one full-resolution iteration checked against the CPU oracle, then timed, with the kernel's
+"""BASELINE config C5 on one GPU: examples/complex.prc (fixture tests/golden/scenes/complex_c5.npz; the Hosek-Wilkie sky table rebuilt from the
+stored parameters) at 1920x1080 -- one full-resolution iteration checked against the CPU oracle, then timed, with the kernel's
 time split (traversal / shading) from the instrumented variant.  usage: python tools/gpu_c5.py [iterations]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ from pearray_amd import backend, scene
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 W, H = (int(os.environ.get("C5_W", 1920)), int(os.environ.get("C5_H", 1080)))
-sc = scene.ArrayScene(os.path.join(ROOT, "tests", "golden", "scenes", "complex_c5.npz"), sky_tables=[scene.synthetic_sky_table()])
+sc = scene.ArrayScene(os.path.join(ROOT, "tests", "golden", "scenes", "complex_c5.npz"))
 sc.desc.settings.width, sc.desc.settings.height = W, H
 t = time.time(); ctx = backend.RenderContext(sc); t_create = time.time() - t
 if os.environ.get("C5_CHECK", "1") != "0":

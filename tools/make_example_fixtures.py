@@ -1,14 +1,11 @@
 #!/usr/bin/env python3
 """Reduce every reference example the loader accepts (examples/*.prc; other integrators replaced by `direct`) to the arrays the backend
-consumes: tests/golden/scenes/examples/<name>.npz (inputs only: geometry, materials, spectra, camera, settings, lights WITHOUT sky
-tables, which are host supplied) at a reduced film.  Run where /root/reference exists; the GPU box only sees the .npz files.
+consumes: tests/golden/scenes/examples/<name>.npz (inputs only: geometry, materials, spectra, camera, settings, lights; a sky light's
+5.8 MB Hosek-Wilkie table is stored as the parameters it is built from) at a reduced film.  Run where /root/reference exists; the GPU box only sees the .npz files.
 tests/test_reference_examples.py renders them on the GPU against the checker."""
 import glob
 import os
-import re
 import sys
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,17 +16,7 @@ FILM = (96, 64, 4)       # width, height, aa samples
 
 
 def load(path):
-    """The loader names the table size a sky light asks for; supply a placeholder of that size (dropped again by save_scene_npz)."""
-    shape = (256, 512)
-    for _ in range(3):
-        try:
-            return scene.PrcScene(path=path, skies={"sky": np.zeros(shape + (abi.SKY_BANDS,), dtype=np.float32)}, force_direct=True,
-                                  width=FILM[0], height=FILM[1], spp=FILM[2])
-        except abi.PrgpuError as e:
-            m = re.search(r"asks for (\d+) x (\d+)", str(e))
-            if not m:
-                raise
-            shape = (int(m.group(2)), int(m.group(1)))
+    return scene.PrcScene(path=path, force_direct=True, width=FILM[0], height=FILM[1], spp=FILM[2])
 
 
 if __name__ == "__main__":
@@ -46,5 +33,5 @@ if __name__ == "__main__":
             print("skip  %-28s %s" % (name, str(e)[:110]))
             continue
         dst = os.path.join(dst_dir, name[:-4] + ".npz")
-        scene.save_scene_npz(dst, s.desc)
+        scene.save_scene_npz(dst, s.desc, sky_params=s.sky_params())
         print("wrote %-28s %7d triangles, %d infinite lights, %.2f MB" % (name, s.desc.n_triangles, s.desc.n_lights, os.path.getsize(dst) / 1e6))

@@ -7,7 +7,7 @@ from pearray_amd import backend, scene
 
 name, iters = sys.argv[1], int(sys.argv[2])
 if name == "c5":
-    sc = scene.ArrayScene(os.path.join(ROOT, "tests", "golden", "scenes", "complex_c5.npz"), sky_tables=[scene.synthetic_sky_table()])
+    sc = scene.ArrayScene(os.path.join(ROOT, "tests", "golden", "scenes", "complex_c5.npz"))
 elif name == "rough":
     sc = scene.cornell_rough(1024, 1024, spp=256, roughness=0.2, vndf=True)
 elif name == "metal_all":
