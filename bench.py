@@ -65,7 +65,7 @@ def host_cpu_share():
     return n, (os.cpu_count() or 1), quota
 
 
-def cpu_baseline(scene_desc, iters=4, tile=32):
+def cpu_baseline(scene_desc, iters=4, tile=32, what="the same 1M-triangle scene"):
     """CPU checker ("port") on the host cores: `iters` full-frame iterations of the SAME workload, handed to the worker threads as
     `tile` x `tile`-pixel Z-order tiles so that every hardware thread has work (the reference's 8 x 8 grid feeds at most 64)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -84,9 +84,9 @@ def cpu_baseline(scene_desc, iters=4, tile=32):
     st = o.statistics()
     return {"value": round(st["pixel_samples"] / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "threads_busy": min(cores, tx * ty),
             "host_threads": host_threads, "cgroup_cpu_quota": quota, "kind": "port", "build": how,
-            "sample": "%d iteration(s) of the full %dx%d frame of the same 1M-triangle scene (%d samples, %.1f s render, %.1f s SAH BVH build excluded), "
+            "sample": "%d iteration(s) of the full %dx%d frame of %s (%d samples, %.1f s render, %.1f s SAH BVH build excluded), "
                       "%d tiles of %dx%d pixels for %d threads; CPU restatement, not Embree"
-                      % (iters, scene_desc.width, scene_desc.height, st["pixel_samples"], dt, t_build, tx * ty, tile, tile, cores)}
+                      % (iters, scene_desc.width, scene_desc.height, what, st["pixel_samples"], dt, t_build, tx * ty, tile, tile, cores)}
 
 
 def kernel_source_sha16():
@@ -123,7 +123,7 @@ def pmc_traffic(kernel_signature):
     return None, None, reason or "no profiles/r*_pmc_summary.json"
 
 
-def roofline(ctx, rank, iters=8):
+def roofline(ctx, rank, iters=8, variant="0u"):
     """Roofline of the dominant kernel, measured live on this rank: HIP events on the launch stream around every launch
     (pass 1), node/triangle record counters of the instrumented kernel variant (pass 2; same pixels, statistically identical
     iterations).  Algorithmic bytes = rays x (32 B ray + 16 B result) + 64 B x inner + 128 B x leaf BVH records fetched."""
@@ -146,7 +146,7 @@ def roofline(ctx, rank, iters=8):
     persistent = fam["path"][1] > 0
     if persistent:
         # one launch = `iters` iterations of everything: closest-hit and occlusion traversal + shading, fused
-        kernel, substr = "k_path_persistent_occ3", "k_path_persistent_occ3<false,0u>"  # the lean instantiation the C4 scene runs
+        kernel, substr = "k_path_persistent_occ3", "k_path_persistent_occ3<false,%s>" % variant  # the instantiation the scene's features select
         ms, n = fam["path"]
         alg_bytes = (bytes_closest + bytes_any) / n          # per launch
         iters_per_launch = iters / n
@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--width", type=int, default=W)
     ap.add_argument("--height", type=int, default=H)
     ap.add_argument("--triangles", type=int, default=NTRI)
+    ap.add_argument("--workload", choices=("c4", "c5"), default="c4",
+                    help="c4 (default, the BASELINE headline): 1M-triangle Cornell box; c5: examples/complex.prc (sky + sun, glass, rough conductor, "
+                         "principled, spheres) from its committed array fixture, sobol 4096-spp schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="skip roofline/cpu passes (for rocprofv3 runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -207,11 +210,22 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if args.steps + args.warmup > SPP:
-        raise SystemExit("steps + warmup exceed the %d-spp schedule" % SPP)
-
     width, height = args.width, args.height
-    sc = scene.cornell_soup(width, height, spp=SPP, n_triangles=args.triangles)
+    if args.workload == "c5":
+        sc = scene.ArrayScene(os.path.join(ROOT, "tests", "golden", "scenes", "complex_c5.npz"))   # the sky table is rebuilt on load (prgpu_sky_table)
+        sc.desc.settings.width, sc.desc.settings.height = width, height
+        spp = sc.desc.settings.aa_samples
+        workload = ("C5: examples/complex.prc (%d triangles + 4 spheres, sky + sun, glass / rough conductor / principled materials), %dx%d, `direct` "
+                    "integrator, sobol %d-spp schedule, hero wavelengths (spd CMIS), %d iterations timed" % (sc.desc.n_triangles, width, height, spp, args.steps))
+        variant, what = "255u", "the same scene (complex.prc)"
+    else:
+        spp = SPP
+        sc = scene.cornell_soup(width, height, spp=SPP, n_triangles=args.triangles)
+        workload = ("C4: Cornell box + %d-triangle soup (%d triangles), %dx%d, `direct` integrator (NEE+MIS+RR, depth 64), "
+                    "sobol %d-spp schedule, hero wavelengths (spd CMIS), %d iterations timed" % (args.triangles - 32, args.triangles, width, height, SPP, args.steps))
+        variant, what = "0u", "the same 1M-triangle scene"
+    if args.steps + args.warmup + 16 > spp:
+        raise SystemExit("steps + warmup (+ 16 roofline iterations) exceed the %d-spp schedule" % spp)
     t0 = time.time()
     ctx = backend.RenderContext(sc, device=local)
     t_create = time.time() - t0
@@ -282,9 +296,7 @@ def main():
         "metric": "Msamples/s", "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C4: Cornell box + %d-triangle soup (%d triangles), %dx%d, `direct` integrator (NEE+MIS+RR, depth 64), "
-                               "sobol %d-spp schedule, hero wavelengths (spd CMIS), %d iterations timed"
-                               % (args.triangles - 32, args.triangles, width, height, SPP, args.steps),
+        "config": {"workload": workload,
                    "samples_per_step": int(samples / args.steps), "parallelism": "tiles%d" % world,
                    "collective": "none (one rank)" if world == 1 else ("prgpu_reduce (RCCL from libprgpu)" if comm is not None else "torch.distributed.reduce"),
                    "mrays_per_s": round(rays / dt / 1e6, 2), "mean_path_depth": round(depth / max(samples, 1), 3),
@@ -300,9 +312,9 @@ def main():
         out["frame_check"] = {"xyz_equal": bool(np.array_equal(xyz.cpu().numpy(), rxyz)), "samples_equal": bool(np.array_equal(smp.cpu().numpy(), rsmp))}
         ref.close()
     if not args.profile_only:
-        out["roofline"] = roofline(ctx, rank)
+        out["roofline"] = roofline(ctx, rank, variant=variant)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sc)
+            out["cpu_baseline"] = cpu_baseline(sc, what=what)
         if rank != 0:
             out.pop("roofline", None)
 

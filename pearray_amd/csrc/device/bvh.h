@@ -12,6 +12,7 @@ struct BvhBuildInput {
 	const uint32_t* indices;	// device
 	const uint32_t* tri_entity; // device
 	const DevEntity* entities;	// device
+	const uint8_t* tri_class = nullptr; // device, or null: per-triangle material class, copied into the leaf records (float 31: one byte per slot)
 };
 struct BvhBuildOutput {
 	Rec64* recs = nullptr; // device, addressed in 64-byte units: n_inner inner records (one unit each, unit 0 is the root), then from

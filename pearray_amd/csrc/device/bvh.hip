@@ -373,9 +373,10 @@ __global__ void k_emit_inner(int n, const float4* __restrict__ wv, const uint32_
 	write_inner_q(recs + inner_idx[i], ch, nc);
 }
 
-// leaf record: triangle k occupies floats [10k, 10k+10): v0, v1, v2, original triangle index; float 30 = count
+// leaf record: triangle k occupies floats [10k, 10k+10): v0, v1, v2, original triangle index; float 30 = count, float 31 = material classes
 __global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const uint32_t* __restrict__ leaf_flag,
-							  const uint32_t* __restrict__ leaf_count, const uint32_t* __restrict__ leaf_idx, uint32_t leaf_unit0, Rec64* __restrict__ recs)
+							  const uint32_t* __restrict__ leaf_count, const uint32_t* __restrict__ leaf_idx, uint32_t leaf_unit0, Rec64* __restrict__ recs,
+							  const uint8_t* __restrict__ tri_class)
 {
 	const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
 	if (pos >= n || !leaf_flag[pos])
@@ -384,8 +385,10 @@ __global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const u
 	float f[32];
 	for (int k = 0; k < 32; ++k)
 		f[k] = 0.0f;
+	uint32_t classes = 0u;
 	for (uint32_t k = 0; k < cnt; ++k) {
 		const uint32_t t = sorted_tri[pos + k];
+		classes |= (tri_class ? (uint32_t)tri_class[t] : 0u) << (8u * k);
 		if (wv[3 * t].w != 0.0f) { // analytic sphere: centre, radius
 			const float4 c = wv[3 * t + 2];
 			f[10 * k]	   = c.x;
@@ -404,13 +407,14 @@ __global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const u
 		f[10 * k + 9] = __uint_as_float(t);
 	}
 	f[30]		= __uint_as_float(cnt);
+	f[31]		= __uint_as_float(classes); // material class of the triangle in slot k in byte k (the persistent kernel's shade queues bin by it)
 	float4* dst = reinterpret_cast<float4*>(recs + leaf_unit0 + 2u * leaf_idx[pos]);
 	for (int q = 0; q < 8; ++q)
 		dst[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
 }
 
 // tiny scenes (n <= 3): one inner record whose only child is the single leaf
-__global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, Rec64* __restrict__ recs)
+__global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, Rec64* __restrict__ recs, const uint8_t* __restrict__ tri_class)
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0)
 		return;
@@ -418,9 +422,11 @@ __global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const ui
 	float leaf[32];
 	for (int k = 0; k < 32; ++k)
 		leaf[k] = 0.0f;
+	uint32_t classes = 0u;
 	for (uint32_t i = 0; i < n; ++i) {
 		float a[3], b[3];
 		const uint32_t t = sorted_tri[i];
+		classes |= (tri_class ? (uint32_t)tri_class[t] : 0u) << (8u * i);
 		tri_box(wv, t, a, b);
 		for (int k = 0; k < 3; ++k) {
 			lo[k] = fminf(lo[k], a[k]);
@@ -444,6 +450,7 @@ __global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const ui
 		leaf[10 * i + 9] = __uint_as_float(t);
 	}
 	leaf[30] = __uint_as_float(n);
+	leaf[31] = __uint_as_float(classes);
 	pad_box(lo, hi);
 	// unit 0: the root inner record with one child; units 2..3: the leaf
 	ChildRef only;
@@ -509,7 +516,7 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 		HIPC(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
 		if (n <= 3) {
 			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * 4));
-			hipLaunchKernelGGL(k_tiny_scene, dim3(1), dim3(64), 0, stream, n, wv, vals_sorted, out.recs);
+			hipLaunchKernelGGL(k_tiny_scene, dim3(1), dim3(64), 0, stream, n, wv, vals_sorted, out.recs, in.tri_class);
 			out.n_inner	   = 1;
 			out.n_leaf	   = 1;
 			out.leaf_unit0 = 2;
@@ -552,7 +559,7 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * (size_t(out.leaf_unit0) + 2 * size_t(out.n_leaf))));
 			hipLaunchKernelGGL(k_emit_inner, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes,
 							   inner_flag, inner_idx, leaf_idx, out.leaf_unit0, out.recs);
-			hipLaunchKernelGGL(k_emit_leaves, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, leaf_flag, leaf_cnt, leaf_idx, out.leaf_unit0, out.recs);
+			hipLaunchKernelGGL(k_emit_leaves, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, leaf_flag, leaf_cnt, leaf_idx, out.leaf_unit0, out.recs, in.tri_class);
 		}
 		HIPC(hipGetLastError());
 		HIPC(hipStreamSynchronize(stream));

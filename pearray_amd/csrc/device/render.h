@@ -5,7 +5,7 @@
 namespace prd {
 // gstats: PRGPU_STAT_COUNT statistics, then inner/leaf record counters of closest and any-hit traversal, then wave-iteration
 // counters, then the persistent kernel's shading passes / shaded vertices / time split
-constexpr int N_DEVICE_COUNTERS = PRGPU_STAT_COUNT + 16; // ... + diagnostics (PRGPU_DEBUG_COUNTERS): leaf-step / inner-step ticks, shader cycles, refill ticks, ray-end ticks
+constexpr int N_DEVICE_COUNTERS = PRGPU_STAT_COUNT + 18; // ... + diagnostics (PRGPU_DEBUG_COUNTERS): leaf-step / inner-step ticks, shader cycles, refill ticks, ray-end ticks
 
 // Scratch of one persistent traversal launch: queue head (u32) and the per-thread stack spill slab.
 // Launches that may run concurrently need separate workspaces.

@@ -26,7 +26,7 @@ struct Hit {
 };
 
 // indices into the extra device counters after the 11 statistics
-enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES, CNT_SHADE_TICKS, CNT_IDLE_TICKS, CNT_TOTAL_TICKS, CNT_LEAF_TICKS, CNT_INNER_TICKS, CNT_TOTAL_CYCLES, CNT_REFILL_TICKS, CNT_FIN_TICKS };
+enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES, CNT_SHADE_TICKS, CNT_IDLE_TICKS, CNT_TOTAL_TICKS, CNT_LEAF_TICKS, CNT_INNER_TICKS, CNT_TOTAL_CYCLES, CNT_REFILL_TICKS, CNT_FIN_TICKS, CNT_CAMERA_TICKS, CNT_VERTEX_TICKS };
 
 // ---- traversal ------------------------------------------------------------------------------------------------
 // Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one
@@ -38,15 +38,7 @@ enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CN
 #endif
 constexpr int PP_BLOCK		= PR_PP_BLOCK;
 constexpr int TRAV_BLOCK	= PR_TU >= 1 ? PP_BLOCK : 256; // the persistent-kernel units hold nothing but that kernel
-// PR_SPLIT = 1: the persistent path kernel hands leaf tests to whole waves through wave-private task rings (see path_persistent);
-// its traversal stack then only holds inner nodes (PR_WS_STACK entries per lane in LDS: with 8 the C4 scene spills all the time, 15.7 vs 13.6 ms)
-#ifndef PR_SPLIT
-#define PR_SPLIT 0
-#endif
-#ifndef PR_WS_STACK
-#define PR_WS_STACK 16
-#endif
-constexpr int STACK_LDS		= (PR_TU >= 1 && PR_SPLIT) ? PR_WS_STACK : 16;
+constexpr int STACK_LDS		= 16;
 constexpr int STACK_SPILL	= 64;  // additional entries per thread in global memory
 constexpr bool ANY_SORTED	= false; // near-to-far order for occlusion rays measured slightly slower than unsorted (fewer ALU ops win)
 
@@ -94,6 +86,7 @@ struct Trav {
 	Hit best;	  // closest: running best (t starts at tmax); any: t = tmax, tri != INVALID once occluded
 	uint32_t cur; // current record ref, REC_EMPTY when the ray is finished
 	bool any;	  // MODE_MIXED only: this lane's ray is an occlusion ray
+	uint32_t cls; // material class of the best hit's triangle (leaf record, float 31); tracked only where the caller asks for it
 };
 
 // traversal flavour: closest hit, occlusion (any hit), or a per-lane mix of both in one wave (persistent path kernel)
@@ -107,6 +100,7 @@ __device__ __forceinline__ void trav_begin(Trav& s, STK& st, V3 o, V3 d, float t
 	s.best = Hit{ tmax, 0.0f, 0.0f, INVALID };
 	s.cur  = 0u; // root
 	s.any  = false;
+	s.cls  = 0u;
 	st.reset();
 }
 
@@ -207,7 +201,7 @@ __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& s
 
 // Leaf step: fetch the leaf record (<= 3 triangles) and run the watertight test on each.
 // SPH: the leaf may hold analytic spheres (scenes with sphere entities); compiled out of the lean persistent kernel
-template <int M, bool SPH>
+template <int M, bool SPH, bool CLS = false>
 __device__ __forceinline__ void leaf_test(Trav& s, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4, const float4& q5,
 										  const float4& q6, const float4& q7)
 {
@@ -236,17 +230,19 @@ __device__ __forceinline__ void leaf_test(Trav& s, const float4& q0, const float
 						s.best.tri = tri;
 				} else if (t < s.best.t || (t == s.best.t && tri < s.best.tri)) {
 					s.best = Hit{ t, u, v, tri };
+					if (CLS)
+						s.cls = (__float_as_uint(f[31]) >> (8 * k)) & 0xFFu;
 				}
 			}
 		}
 	}
 }
-template <int M, bool SPH, typename STK>
+template <int M, bool SPH, bool CLS = false, typename STK>
 __device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
 											  const float4& q5, const float4& q6, const float4& q7)
 {
 	const bool ANY = M == MODE_ANY || (M == MODE_MIXED && s.any);
-	leaf_test<M, SPH>(s, q0, q1, q2, q3, q4, q5, q6, q7);
+	leaf_test<M, SPH, CLS>(s, q0, q1, q2, q3, q4, q5, q6, q7);
 	s.cur = REC_EMPTY;
 	if (ANY && s.best.tri != INVALID) { // occluded: done
 		st.reset();
@@ -699,7 +695,12 @@ __device__ __forceinline__ float halton(uint32_t index, uint32_t base)
 // Returns false when the camera has no ray for the sample (clipped fisheye, fisheye.cpp:91-94): the sample is counted and its random
 // numbers are spent (RenderTile.cpp:71-131), the slot gets a ray that cannot hit anything and FLAG_NO_RAY, and shade_vertex ends
 // the path without a fragment.
-__device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState& ps, uint32_t slot, uint32_t iter, BlockStats& bs, bool with_lpe = false)
+// wl: the wavelength distribution's CDF and its guide table when the caller keeps copies close by (LDS), else null
+struct WlTable {
+	const float* cdf	  = nullptr;
+	const uint16_t* guide = nullptr;
+};
+__device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState& ps, uint32_t slot, uint32_t iter, BlockStats& bs, bool with_lpe = false, WlTable wlt = WlTable())
 {
 	const prgpu_settings& cfg = sc.cfg;
 	const uint32_t pixel	  = ps.pixel[slot];
@@ -743,7 +744,8 @@ __device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState&
 		const float span = cfg.spectral_end - cfg.spectral_start;
 		for (int k = 0; k < 4; ++k) {
 			float pdf;
-			const float v = distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, rng_float(rnd), pdf);
+			const float u = rng_float(rnd);
+			const float v = wlt.guide ? distribution_sample_continuous_guided(wlt.cdf, sc.wl_cdf_size, wlt.guide, u, pdf) : distribution_sample_continuous(sc.wl_cdf, sc.wl_cdf_size, u, pdf);
 			wl.v[k]		  = v * span + cfg.spectral_start;
 			wl_pdf.v[k]	  = pdf;
 		}
@@ -2068,29 +2070,16 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 // the pixel has all its samples the slot takes the next unrendered pixel from a global counter.  There is no grid-wide
 // barrier, no host round trip and no drain phase between path vertices; blocks never wait for each other, waves only
 // ever wait for waves of their own block (which are resident by construction).
-// Split traversal (PR_SPLIT, default): inner nodes and leaves are different kinds of work -- a 64-byte record and four slab tests against a
-// 128-byte record and up to three watertight triangle tests -- and a wave that steps one kind per step (the majority's, see
-// trace_persistent) leaves 42 % of its lanes idle on the C4 scene.  Here a lane never steps a leaf itself: the inner step turns every hit
-// leaf child into a TASK (leaf record, owner lane) in a ring that belongs to the wave alone -- plain LDS writes at positions from a
-// ballot prefix sum, head and tail live in scalar registers, no atomics and no other wave involved -- and goes on with the inner nodes on
-// its stack.  Whenever 64 tasks wait (or nothing else can move) the wave runs a leaf step at full lane fill: lane j tests task j's
-// triangles with the owner's ray constants (fetched from the owner lane's registers with ds_bpermute) and merges its best hit into the
-// owner's 64-bit key (order-preserving t bits << 32 | triangle id) with one LDS minimum, which IS the rule "closer, or equally close with
-// the smaller id" of the sequential test; the lane whose candidate won publishes u, v.  A ray is finished when its stack is empty and the
-// ring's head has passed its last task.  Tasks left behind by a ray that ended early (an occluded shadow ray) are tested against whatever
-// ray the owner lane holds by then: a triangle that passes the test for that ray IS a hit of that ray, so a stale task can only confirm
-// the result.  (Round 2's version of this went through one block-wide queue with LDS atomics in every step, let finished rays wait for
-// other waves' batches and re-tested the winning triangle for u, v: 28 % fewer steps but 10 % slower; profiles/r02_split_traversal_persistent.log.)
 #ifndef PR_PP_SLOTS_MAX
-#define PR_PP_SLOTS_MAX (PP_BLOCK == 768 ? 2048 : (PR_SPLIT ? 512 : 1024)) // the split traversal's rings and keys come out of the slot rings
+#define PR_PP_SLOTS_MAX (PP_BLOCK == 768 ? 1536 : 512) // slots per block; more than 512 per 256 lanes was never faster (C5: 13.7 ms at 512, 15.8 at 768, 17.1 at 1024)
 #endif
 constexpr int PP_SLOTS_MAX		= PR_PP_SLOTS_MAX;
-constexpr uint32_t WS_RING		= 256;					 // tasks per wave: fewer than 64 wait when an inner step adds some (a step that would overflow the ring is retried, see trav_inner_ws)
+constexpr uint32_t WL_LDS		= 448;					 // entries of the wavelength CDF kept in LDS (the spd mapper has 441; larger tables stay in global memory)
 constexpr uint32_t PP_EMPTY		= 0xFFFFFFFFu;
 constexpr uint32_t PP_ANY		= 0x80000000u; // ray entry: the slot's shadow ray (else its path ray)
-constexpr uint32_t PP_REGEN		= 0x80000000u; // shade entry: the slot's path has ended (else: shade the vertex at ps.hit)
 constexpr uint32_t PP_DEAD		= 0x100u;	   // pending word: no bounce ray follows the rays in flight
 constexpr uint32_t PP_VISIBLE	= 0x200u;	   // pending word: the slot's shadow ray reached the light (set by the ray's last step)
+constexpr uint32_t PP_CLS_SHIFT	= 12u;		   // pending word, two bits: material class of the path ray's hit (set by that ray's last step)
 constexpr uint32_t PP_SHADOW	= 0x400u;	   // pending word: the vertex queued a shadow ray, its NEE fragment waits in ps.sh_xyz
 constexpr unsigned long long PP_IDLE_LIMIT_TICKS = 30ull * 100000000ull; // safety net: a wave that has seen no work for 30 s of wall clock (100 MHz ticks) gives up and flags an error
 
@@ -2101,14 +2090,11 @@ template <int NQ>
 struct PPShared {
 	uint2 stack[STACK_LDS * TRAV_BLOCK];
 	uint32_t q_ray[2 * PP_SLOTS_MAX]; // a slot has at most two rays queued or in flight
-	uint32_t q_shade[NQ][PP_SLOTS_MAX];
+	uint32_t q_shade[NQ + 1][PP_SLOTS_MAX]; // ... and, last, the queue of slots whose path has ended (fold, next sample, camera ray)
 	uint32_t pending[PP_SLOTS_MAX];
-#if PR_SPLIT
-	uint32_t ws_task[TRAV_BLOCK / 64][WS_RING]; // per wave: leaf tasks (leaf unit << 6 | owner lane)
-	unsigned long long ws_key[TRAV_BLOCK];		// per lane: its ray's best hit so far, (ordered t bits << 32) | triangle id
-	float2 ws_uv[TRAV_BLOCK];					// ... and that hit's barycentrics
-#endif
-	uint32_t ray_head, ray_tail, shade_head[NQ], shade_tail[NQ];
+	uint32_t ray_head, ray_tail, shade_head[NQ + 1], shade_tail[NQ + 1];
+	float wl_cdf[WL_LDS];		   // the wavelength distribution (camera_path searches it four times per sample) ...
+	uint16_t wl_guide[CDF_GUIDE_BUCKETS + 2]; // ... and its guide table (distribution_sample_continuous_guided)
 	uint32_t n_list, unit_next, exhausted, n_frozen; // resident pixels: the block's pixel list and its round-robin stream of (pixel, sample) units
 	uint32_t live; // slots that still own, or may still acquire, a pixel
 	uint32_t error;
@@ -2117,98 +2103,6 @@ struct PPShared {
 
 __device__ __forceinline__ uint32_t lds_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t wave_bcast0(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-// ---- split traversal (see above) ----
-// order-preserving map of a float to an unsigned key (negative values below positive ones), and back
-__device__ __forceinline__ uint32_t float_key(float f)
-{
-	const uint32_t b = __float_as_uint(f);
-	return b ^ ((b & 0x80000000u) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float key_float(uint32_t k) { return __uint_as_float(k ^ ((k & 0x80000000u) ? 0x80000000u : 0xFFFFFFFFu)); }
-// Inner step of the split traversal: the four slab tests of trav_inner_rec; hit children that are leaves become tasks of the wave's ring
-// (they never enter the stack), hit inner children are sorted and pushed as there.  `active`: the lane holds a ray at an inner record (all
-// lanes of the wave take part in the ring bookkeeping).  ws_tail is wave-uniform; my_last becomes the ring position behind the lane's last task.
-template <typename STK>
-__device__ __forceinline__ void trav_inner_ws(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool active, uint32_t* ring,
-											  uint32_t ws_head, uint32_t& ws_tail, uint32_t& my_last, uint32_t lane, bool& overflow)
-{
-	float t[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
-	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
-	bool h[4] = { false, false, false, false };
-	if (active) {
-		const uint32_t eb = __float_as_uint(q0.w);
-		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
-		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
-		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
-		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
-		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
-		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const float axk = __fmaf_rn(PR_UB(wnx, k), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn(PR_UB(wfx, k), sx, dx) * s.r.inv_d.x;
-			const float ayk = __fmaf_rn(PR_UB(wny, k), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn(PR_UB(wfy, k), sy, dy) * s.r.inv_d.y;
-			const float azk = __fmaf_rn(PR_UB(wnz, k), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn(PR_UB(wfz, k), sz, dz) * s.r.inv_d.z;
-			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
-			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
-			t[k]		   = t0;
-			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY; // acceptance rule of box_hit
-		}
-	}
-	// leaves -> tasks: ring positions from a prefix sum over the lanes' counts (three ballots: a lane queues at most four)
-	bool lf[4];
-	uint32_t cnt = 0;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		lf[k] = h[k] && (c[k] & REC_LEAF_BIT) != 0u;
-		cnt += lf[k] ? 1u : 0u;
-	}
-	{
-		const unsigned long long below = (1ull << lane) - 1ull;
-		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
-		const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
-		if (total != 0u) {
-			if (ws_tail - ws_head + total <= WS_RING) {
-				uint32_t pos = ws_tail + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
-#pragma unroll
-				for (int k = 0; k < 4; ++k)
-					if (lf[k])
-						ring[(pos++) & (WS_RING - 1u)] = ((c[k] & ~REC_LEAF_BIT) << 6) | lane;
-				if (cnt)
-					my_last = pos;
-				ws_tail += total;
-			} else {
-				overflow = true; // (wave-uniform)
-				if (cnt)
-					active = false; // no room for this step's tasks (> 192 of them: hardly ever): the lanes that have some stay where they are; the caller runs a leaf step next, which empties the ring
-			}
-		}
-	}
-	if (!active)
-		return;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const bool in = h[k] && !lf[k];
-		t[k]		  = in ? t[k] : INFINITY;
-		c[k]		  = in ? c[k] : REC_EMPTY;
-	}
-#define PR_CSWAP(a, b)                                          \
-	{                                                           \
-		const bool sw	  = t[b] < t[a];                        \
-		const float ta = t[a], tb = t[b];                       \
-		const uint32_t ca = c[a], cb = c[b];                    \
-		t[a] = sw ? tb : ta; t[b] = sw ? ta : tb;               \
-		c[a] = sw ? cb : ca; c[b] = sw ? ca : cb;               \
-	}
-	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
-#undef PR_CSWAP
-	st.reserve(3);
-	st.push_if(c[3] != REC_EMPTY, c[3], t[3]);
-	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
-	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
-	s.cur = c[0];
-	trav_pop<MODE_CLOSEST>(s, st);
-}
 
 // append the value of every lane with `pred` to a ring queue: one LDS atomic per wave; the entry becomes visible to the
 // poppers when it is written (release: the slot's state in global memory is visible before the entry is)
@@ -2297,8 +2191,6 @@ struct PersistentArgs {
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
 	uint32_t sort_rays;	  // 1: a shading pass queues its rays ordered by direction octant
 	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
-	uint32_t ws_min_tasks; // split traversal: a leaf step also runs with this many tasks (< 64) ...
-	int ws_wait;		   // ... when this many of the wave's rays have nothing left but tasks
 	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
 	// resident pixels (see path_persistent): per block `bl_cap` list entries (pixel) and state words (samples done | samples handed out << 16),
 	// and per slot the list entry of the pixel it renders
@@ -2316,6 +2208,11 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 {
 	// material classes: 0 = everything but the rough / principled closures, 1 = those (only kernels that contain them have the queue)
 	constexpr int NQ = (FEATS & FEAT_ROUGH_MATERIALS) ? 2 : 1;
+	// ... plus the queue of ended paths.  A path's end (fold the sample, take the next unit of work, generate the camera ray: four
+	// binary searches of the wavelength distribution among other things) used to be handled inside the vertex pass that found it, i.e.
+	// in EVERY pass for the quarter of its lanes whose path had just ended -- 7 % of the kernel's time on C4, 9 % on C5, at a quarter of
+	// the lanes.  In a queue of its own it runs at full lane fill.
+	constexpr int QR = NQ;
 	constexpr uint32_t FEATS_PLAIN = FEATS & ~FEAT_ROUGH_MATERIALS;
 	__shared__ PPShared<NQ> sh;
 	constexpr uint32_t RAY_MASK = 2 * PP_SLOTS_MAX - 1, SHADE_MASK = PP_SLOTS_MAX - 1;
@@ -2325,8 +2222,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	for (uint32_t i = threadIdx.x; i < 2 * PP_SLOTS_MAX; i += TRAV_BLOCK)
 		sh.q_ray[i] = PP_EMPTY;
 	for (uint32_t i = threadIdx.x; i < PP_SLOTS_MAX; i += TRAV_BLOCK) {
-		sh.q_shade[0][i] = i < block_slots ? (i | PP_REGEN) : PP_EMPTY; // every slot starts by acquiring a pixel
-		for (int q = 1; q < NQ; ++q)
+		sh.q_shade[QR][i] = i < block_slots ? i : PP_EMPTY; // every slot starts by acquiring a pixel
+		for (int q = 0; q < NQ; ++q)
 			sh.q_shade[q][i] = PP_EMPTY;
 		sh.pending[i] = 0;
 		if (i < block_slots)
@@ -2334,10 +2231,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	}
 	if (threadIdx.x == 0) {
 		sh.ray_head = sh.ray_tail = 0;
-		sh.shade_head[0]		  = 0;
-		sh.shade_tail[0]		  = block_slots;
-		for (int q = 1; q < NQ; ++q)
+		for (int q = 0; q < NQ; ++q)
 			sh.shade_head[q] = sh.shade_tail[q] = 0;
+		sh.shade_head[QR] = 0;
+		sh.shade_tail[QR] = block_slots;
 		sh.live					  = block_slots;
 		sh.error				  = 0;
 		sh.n_list = sh.unit_next = sh.exhausted = sh.n_frozen = 0;
@@ -2349,8 +2246,34 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			bl_list[i] = BL_UNWRITTEN;
 			bl_word[i] = 0u;
 		}
+	const bool wl_in_lds = sc.wl_cdf_size >= 2u && sc.wl_cdf_size <= WL_LDS && sc.cfg.mapper == PRGPU_MAPPER_SPD_CMIS;
+	if (wl_in_lds)
+		for (uint32_t i = threadIdx.x; i < sc.wl_cdf_size; i += TRAV_BLOCK)
+			sh.wl_cdf[i] = sc.wl_cdf[i];
 	stats_init(sh.bs);
 	__syncthreads();
+	if (wl_in_lds) { // guide[b] = number of entries <= b / 256
+		for (uint32_t b = threadIdx.x; b <= CDF_GUIDE_BUCKETS; b += TRAV_BLOCK) {
+			const float x = (float)b / (float)CDF_GUIDE_BUCKETS;
+			int first = 0, len = (int)sc.wl_cdf_size;
+			while (len > 0) {
+				const int half = len / 2, middle = first + half;
+				if (sh.wl_cdf[middle] <= x) {
+					first = middle + 1;
+					len -= half + 1;
+				} else {
+					len = half;
+				}
+			}
+			sh.wl_guide[b] = (uint16_t)first;
+		}
+		__syncthreads();
+	}
+	WlTable wlt;
+	if (wl_in_lds) {
+		wlt.cdf	  = sh.wl_cdf;
+		wlt.guide = sh.wl_guide;
+	}
 
 	Stack st;
 	st.lds			= sh.stack + threadIdx.x;
@@ -2365,103 +2288,18 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	uint32_t spins	  = 0;
 	unsigned long long t_idle_since = 0;
 	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, wleaf = 0, sbatches = 0, slanes = 0;
-	unsigned long long t_shade = 0, t_idle = 0, t_leaf = 0, t_inner = 0, t_refill = 0, t_fin = 0;
+	unsigned long long t_shade = 0, t_idle = 0, t_leaf = 0, t_inner = 0, t_refill = 0, t_fin = 0, t_cam = 0, t_vert = 0;
 	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
 	const unsigned long long c_start = COUNT ? (unsigned long long)clock64() : 0ull;
 
 	const bool shader = a.shader_wave != 0u && ((threadIdx.x >> 6) & 3u) == 3u; // one wave in four
 	const uint32_t shade_full = a.shader_wave != 0u ? a.shade_help : a.shade_min;
-#if PR_SPLIT
-	uint32_t* const ring = sh.ws_task[threadIdx.x >> 6];
-	uint32_t ws_head = 0, ws_tail = 0; // wave-uniform ring positions (free running)
-	uint32_t my_last = 0;			   // ring position behind the last task of the lane's ray
-	bool ws_overflow = false;		   // the last inner step found the ring too full for its tasks
-	// leaf step: the wave's first (up to) 64 tasks, one per lane, at full lane fill
-	auto leaf_step = [&]() {
-		const uint32_t n  = min(64u, ws_tail - ws_head);
-		const bool mine	  = lane < n;
-		uint32_t task	  = lane;
-		if (mine)
-			task = ring[(ws_head + lane) & (WS_RING - 1u)];
-		ws_head += n;
-		const uint32_t owner = task & 63u;
-		const int sel		 = (int)(owner << 2);
-		// the owner's ray constants, straight from its registers
-		auto fetch = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(v))); };
-		RayPre r;
-		r.o		= v3(fetch(s.r.o.x), fetch(s.r.o.y), fetch(s.r.o.z));
-		r.Sx	= fetch(s.r.Sx);
-		r.Sy	= fetch(s.r.Sy);
-		r.Sz	= fetch(s.r.Sz);
-		const float tmin = fetch(s.tmin);
-		const int kk	 = __builtin_amdgcn_ds_bpermute(sel, s.r.kx | (s.r.ky << 2) | (s.r.kz << 4) | (s.any ? 64 : 0) | (has_ray ? 128 : 0));
-		r.kx			 = kk & 3;
-		r.ky			 = (kk >> 2) & 3;
-		r.kz			 = (kk >> 4) & 3;
-		float limit		 = 0.0f;
-		if (FEATS & FEAT_SPHERES) {
-			r.d	  = v3(fetch(s.r.d.x), fetch(s.r.d.y), fetch(s.r.d.z));
-			limit = fetch(s.best.t);
-		}
-		unsigned long long cand = ~0ull;
-		float bu = 0.0f, bv = 0.0f;
-		if (mine && (kk & 128)) {
-			const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (task >> 6));
-			const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
-			const float f[32] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
-								  q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, q6.x, q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w };
-			const uint32_t count = __float_as_uint(f[30]);
-#pragma unroll
-			for (int k = 0; k < 3; ++k) {
-				if ((uint32_t)k < count) {
-					float tt, uu = 0.0f, vv = 0.0f;
-					const uint32_t prim = __float_as_uint(f[10 * k + 9]);
-					bool hit;
-					if ((FEATS & FEAT_SPHERES) && (prim & PRIM_SPHERE_BIT))
-						hit = sphere_hit(r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), f[10 * k + 3], tmin, limit, tt);
-					else
-						hit = woop(r, v3(f[10 * k], f[10 * k + 1], f[10 * k + 2]), v3(f[10 * k + 3], f[10 * k + 4], f[10 * k + 5]), v3(f[10 * k + 6], f[10 * k + 7], f[10 * k + 8]), tt, uu, vv)
-							  && tt > tmin;
-					if (hit) {
-						const unsigned long long c2 = ((unsigned long long)float_key(tt) << 32) | (prim & ~PRIM_SPHERE_BIT);
-						if (c2 < cand) {
-							cand = c2;
-							bu	 = uu;
-							bv	 = vv;
-						}
-					}
-				}
-			}
-			if (COUNT) {
-				cl_c += (kk & 64) ? 0 : 1;
-				cl_a += (kk & 64) ? 1 : 0;
-			}
-		}
-		const uint32_t otid = (threadIdx.x & ~63u) | owner;
-		if (cand != ~0ull)
-			__hip_atomic_fetch_min(&sh.ws_key[otid], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		if (cand != ~0ull && __hip_atomic_load(&sh.ws_key[otid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == cand)
-			sh.ws_uv[otid] = make_float2(bu, bv); // the candidate that won publishes its barycentrics
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		if (has_ray) { // every ray of the wave sees its hit distance shrink
-			const unsigned long long k = __hip_atomic_load(&sh.ws_key[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			s.best.t				   = key_float((uint32_t)(k >> 32));
-			s.best.tri				   = (uint32_t)k;
-			if (s.any && s.best.tri != INVALID) { // occluded: done (its remaining tasks can only confirm that)
-				st.reset();
-				s.cur	= REC_EMPTY;
-				my_last = ws_head;
-			}
-		}
-	};
-#endif
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
 		// the fullest class queue decides: a pass shades one class
 		uint32_t n_shade = wave_bcast0(lds_load(&sh.shade_tail[0]) - lds_load(&sh.shade_head[0]));
 		int cls			 = 0;
-		for (int q = 1; q < NQ; ++q) {
+		for (int q = 1; q < NQ + 1; ++q) {
 			const uint32_t nq = wave_bcast0(lds_load(&sh.shade_tail[q]) - lds_load(&sh.shade_head[q]));
 			if (nq > n_shade) {
 				n_shade = nq;
@@ -2490,12 +2328,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				}
 				const bool mine	  = lane < n;
 				uint32_t slot_l	  = 0;
-				bool regen		  = false;
-				if (mine) {
-					const uint32_t e = ring_take(sh.q_shade[cls], SHADE_MASK, first + lane);
-					slot_l			 = e & ~PP_REGEN;
-					regen			 = (e & PP_REGEN) != 0;
-				}
+				const bool regen_pass = cls == QR; // wave-uniform: a pass of ended paths, or a pass of vertices
+				const bool regen	  = regen_pass;
+				if (mine)
+					slot_l = ring_take(sh.q_shade[cls], SHADE_MASK, first + lane);
 				const uint32_t slot = slot0 + slot_l;
 				if (mine) { // the NEE fragment of the slot's previous vertex, now that its shadow ray has reported (see the end of the ray loop)
 					const uint32_t pw = lds_load(&sh.pending[slot_l]);
@@ -2513,15 +2349,20 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				}
 				bool alive = false, want_shadow = false;
 				float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
-				if (NQ > 1 && cls == 1) { // wave-uniform: the body with the rough / principled closures
-					if (mine && !regen)
+				const unsigned long long t0v = COUNT ? wall_clock64() : 0ull;
+				if (regen_pass) {
+				} else if (NQ > 1 && cls == 1) { // wave-uniform: the body with the rough / principled closures
+					if (mine)
 						shade_vertex<FEATS>(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 				} else {
-					if (mine && !regen)
+					if (mine)
 						shade_vertex<FEATS_PLAIN>(sc, ps, slot, sh.bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 				}
+				if (COUNT)
+					t_vert += wall_clock64() - t0v;
 				// the path ended: fold the sample, then the pixel's next sample or the next pixel
-				const bool ended = mine && (regen || (!alive && !want_shadow));
+				const bool to_regen = !regen_pass && mine && !alive && !want_shadow; // the vertex ended the path and nothing is in flight: queue its end
+				const bool ended	= mine && regen;
 				bool need_pixel	 = false;
 				uint32_t iter	 = 0;
 				if (ended) {
@@ -2658,11 +2499,14 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						}
 					}
 				}
+				const unsigned long long t0c = COUNT ? wall_clock64() : 0ull;
 				if (ended && !retired) {
 					ps.iter[slot] = iter;
-					camera_path(sc, ps, slot, iter, sh.bs, (FEATS & FEAT_LPE) != 0u);
+					camera_path(sc, ps, slot, iter, sh.bs, (FEATS & FEAT_LPE) != 0u, wlt);
 					alive = true;
 				}
+				if (COUNT)
+					t_cam += wall_clock64() - t0c;
 				const int n_retired = __popcll(__ballot(retired));
 				if (n_retired && lane == 0)
 					__hip_atomic_fetch_sub(&sh.live, (uint32_t)n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2675,6 +2519,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					__hip_atomic_store(&sh.pending[slot_l], (alive ? 1u : 0u) + (want_shadow ? 1u + PP_SHADOW : 0u) + (alive ? 0u : PP_DEAD), __ATOMIC_RELAXED,
 									   __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
+				ring_push(sh.q_shade[QR], SHADE_MASK, &sh.shade_tail[QR], to_regen, slot_l);
 				if (a.sort_rays) { // "sorted ray queues": order the wave's new rays by direction octant (measured: see DESIGN.md)
 					const float4 bd = alive ? ps.ray_d[slot] : make_float4(0, 0, 0, 0);
 					ring_push_sorted(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY, direction_octant(sh_d.x, sh_d.y, sh_d.z));
@@ -2727,18 +2572,14 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 								s.best.t   = -INFINITY;
 								break;
 							}
-							if (tq < s.best.t || (tq == s.best.t && Q.tri < s.best.tri))
+							if (tq < s.best.t || (tq == s.best.t && Q.tri < s.best.tri)) {
 								s.best = Hit{ tq, 0.0f, 0.0f, Q.tri };
+								if (NQ > 1)
+									s.cls = sc.tri_class[Q.tri];
+							}
 						}
 					}
 				}
-#if PR_SPLIT
-				if ((FEATS & FEAT_QUADRICS) && any && s.best.tri != INVALID)
-					s.cur = REC_EMPTY; // occluded by a quadric: finished as it stands
-				__hip_atomic_store(&sh.ws_key[threadIdx.x], ((unsigned long long)float_key(s.best.t) << 32) | s.best.tri, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				sh.ws_uv[threadIdx.x] = make_float2(0.0f, 0.0f);
-				my_last				  = ws_head; // no task of its own yet
-#endif
 			}
 			if (COUNT)
 				t_refill += wall_clock64() - t0r;
@@ -2766,51 +2607,6 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		}
 		spins = 0;
 		for (;;) {
-#if PR_SPLIT
-			// split traversal (see the top of this section): inner steps for every ray that has an inner node, a leaf step whenever a
-			// wave-full of tasks waits -- or earlier, when nothing else can move or many finished stacks wait for their last tasks
-			const uint32_t n_tasks			 = ws_tail - ws_head;
-			const bool at_inner				 = has_ray && s.cur != REC_EMPTY; // always an inner record: leaves never stay in s.cur
-			const unsigned long long m_inner = __ballot(at_inner);
-			const int n_wait				 = __popcll(__ballot(has_ray && s.cur == REC_EMPTY && (int32_t)(ws_head - my_last) < 0));
-			if (COUNT && lane == 0)
-				++witers;
-			if (n_tasks >= 64u || (n_tasks > 0u && (ws_overflow || m_inner == 0ull || (n_tasks >= a.ws_min_tasks && n_wait >= a.ws_wait)))) {
-				ws_overflow = false;
-				const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
-				leaf_step();
-				if (COUNT && lane == 0)
-					++wleaf;
-				if (COUNT)
-					t_leaf += wall_clock64() - t0;
-			} else if (m_inner != 0ull) {
-				const unsigned long long t0 = COUNT ? wall_clock64() : 0ull;
-				float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
-				if (at_inner) {
-					if (COUNT) {
-						cn_c += s.any ? 0 : 1;
-						cn_a += s.any ? 1 : 0;
-					}
-					const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + s.cur);
-					q0 = rec[0];
-					q1 = rec[1];
-					q2 = rec[2];
-					q3 = rec[3];
-				}
-				trav_inner_ws(s, st, q0, q1, q2, q3, at_inner, ring, ws_head, ws_tail, my_last, lane, ws_overflow);
-				if (COUNT)
-					t_inner += wall_clock64() - t0;
-			}
-			const bool fin = has_ray && s.cur == REC_EMPTY && (int32_t)(ws_head - my_last) >= 0;
-			if (fin && !s.any) { // (t, triangle) were refreshed by the leaf step that tested the ray's last task; the winner left u, v
-				s.best.u = s.best.v = 0.0f;
-				if (s.best.tri != INVALID) {
-					const float2 uv = sh.ws_uv[threadIdx.x];
-					s.best.u		= uv.x;
-					s.best.v		= uv.y;
-				}
-			}
-#else
 			// one kind of record per wave step (see trace_persistent)
 			const bool at_leaf	= has_ray && (s.cur & REC_LEAF_BIT) != 0;
 			const bool at_inner = has_ray && !at_leaf;
@@ -2859,7 +2655,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						cl_c += s.any ? 0 : 1;
 						cl_a += s.any ? 1 : 0;
 					}
-					trav_leaf_rec<MODE_MIXED, (FEATS & FEAT_SPHERES) != 0>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
+					trav_leaf_rec<MODE_MIXED, (FEATS & FEAT_SPHERES) != 0, (NQ > 1)>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
 				}
 			}
 			if (COUNT) {
@@ -2868,10 +2664,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				else
 					t_leaf += wall_clock64() - t0s;
 			}
-#endif
-#if !PR_SPLIT
 			const bool fin = has_ray && s.cur == REC_EMPTY;
-#endif
 			const unsigned long long t0f = COUNT ? wall_clock64() : 0ull;
 			if (__any(fin)) {
 				bool last	   = false;
@@ -2890,18 +2683,20 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 							add += PP_VISIBLE;
 					} else {
 						ps.hit[slot] = make_float4(s.best.t, s.best.u, s.best.v, __uint_as_float(s.best.tri));
+						if (NQ > 1) // the class of the material it hit travels in the pending word (the leaf record carried it: no lookup here)
+							add += (s.cls & 3u) << PP_CLS_SHIFT;
 					}
 					// release: the hit is visible to the wave that shades the slot next
 					const uint32_t old = __hip_atomic_fetch_add(&sh.pending[slot_l], add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
 					last			   = (old & 0xFFu) == 1u;
-					entry			   = slot_l | ((old & PP_DEAD) ? PP_REGEN : 0u);
-					if (NQ > 1 && last && !(old & PP_DEAD)) { // class of the material the slot's path ray hit (the shadow ray may finish last)
-						const uint32_t tri = s.any ? __float_as_uint(ps.hit[slot].w) : s.best.tri;
-						qcls			   = tri == INVALID ? 0 : (int)sc.tri_class[tri];
-					}
+					entry			   = slot_l;
+					if (last && (old & PP_DEAD))
+						qcls = QR; // no bounce ray followed: the path has ended
+					if (NQ > 1 && last && !(old & PP_DEAD)) // class of the material the slot's path ray hit (the shadow ray may finish last)
+						qcls = s.any ? (int)((old >> PP_CLS_SHIFT) & 3u) : (int)(s.cls & 3u);
 					has_ray = false;
 				}
-				for (int q = 0; q < NQ; ++q)
+				for (int q = 0; q < NQ + 1; ++q)
 					ring_push(sh.q_shade[q], SHADE_MASK, &sh.shade_tail[q], last && qcls == q, entry);
 				if (COUNT)
 					t_fin += wall_clock64() - t0f;
@@ -2911,7 +2706,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				break;
 			if (active < a.refill_below) { // under-occupied: leave if there is anything to refill from or to shade
 				uint32_t nsh = lds_load(&sh.shade_tail[0]) - lds_load(&sh.shade_head[0]);
-				for (int q = 1; q < NQ; ++q)
+				for (int q = 1; q < NQ + 1; ++q)
 					nsh = max(nsh, lds_load(&sh.shade_tail[q]) - lds_load(&sh.shade_head[q]));
 				const uint32_t nq = lds_load(&sh.ray_tail) - lds_load(&sh.ray_head);
 				if (wave_bcast0(((nq > 0u && (nq >= a.refill_min || threadIdx.x < 64u)) || nsh >= shade_full || (a.shader_wave == 0u && nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
@@ -2944,6 +2739,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			atomicAdd(&a.gstats[CNT_INNER_TICKS], t_inner);
 			atomicAdd(&a.gstats[CNT_REFILL_TICKS], t_refill);
 			atomicAdd(&a.gstats[CNT_FIN_TICKS], t_fin);
+			atomicAdd(&a.gstats[CNT_CAMERA_TICKS], t_cam);
+			atomicAdd(&a.gstats[CNT_VERTEX_TICKS], t_vert);
 			atomicAdd(&a.gstats[CNT_TOTAL_CYCLES], (unsigned long long)clock64() - c_start);
 		}
 		if (threadIdx.x == 0) // diagnostics (PRGPU_DUMP_BLOCK_LIFE): the block's lifetime and vertex count, in its own first spill entry (no longer needed)
@@ -3444,7 +3241,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.gstats		  = gstats;
 	a.direct_map	  = all_in_flight ? 1u : 0u;
 	// resident pixels: more pixels than slots and more than one sample per pixel in this launch (PRGPU_PP_RESIDENT=0: a pixel keeps its slot)
-	static const bool resident_ok = !(getenv("PRGPU_PP_RESIDENT") && atoi(getenv("PRGPU_PP_RESIDENT")) == 0);
+	const bool resident_ok = !(getenv("PRGPU_PP_RESIDENT") && atoi(getenv("PRGPU_PP_RESIDENT")) == 0);
 	a.bl_cap		  = (uint32_t)std::min<uint64_t>(n_owned, 2ull * ((n_owned + g.n_blocks - 1) / g.n_blocks) + 1024ull);
 	a.bl_list		  = ws.bl_list;
 	a.bl_word		  = ws.bl_word;
@@ -3455,8 +3252,6 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 					  : 0u;
 	if (!a.resident)
 		a.bl_cap = 0;
-	a.ws_min_tasks	  = getenv("PRGPU_PP_WS_MIN") ? (uint32_t)std::min(64, std::max(1, atoi(getenv("PRGPU_PP_WS_MIN")))) : 32u;
-	a.ws_wait		  = getenv("PRGPU_PP_WS_WAIT") ? std::min(65, std::max(1, atoi(getenv("PRGPU_PP_WS_WAIT")))) : 16;
 	(void)hipMemsetAsync(next_pixel, 0, sizeof(uint32_t), st);
 	const dim3 grid(g.n_blocks);
 	// smallest compiled variant that covers the scene's features: lean (Lambert / mesh / area lights), + smooth delta materials,

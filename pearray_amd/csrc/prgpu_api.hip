@@ -406,7 +406,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.n_tris		 = d->n_triangles;
 
 	// device LBVH
-	prd::BvhBuildInput bin{ d->n_triangles, d->n_entities, sc.positions, sc.indices, sc.tri_entity, sc.entities };
+	prd::BvhBuildInput bin{ d->n_triangles, d->n_entities, sc.positions, sc.indices, sc.tri_entity, sc.entities, sc.tri_class };
 	prd::BvhBuildOutput bout;
 	if (!prd::build_lbvh(bin, bout, s->stream, err))
 		return fail(PRGPU_EDEVICE, "LBVH build failed: " + err);
@@ -1248,9 +1248,10 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 	if (getenv("PRGPU_DEBUG_COUNTERS")) // development: split-traversal time split and the shader clock (cycles per 100 MHz tick)
 		if (host[PRGPU_STAT_COUNT + 10]) {
 			const double T = double(host[PRGPU_STAT_COUNT + 10]);
-			fprintf(stderr, "[prgpu] wave time: shading %.1f %%, idle %.1f %%, leaf steps %.1f %%, inner steps %.1f %%, refill %.1f %%, ray ends %.1f %%; shader clock %.0f MHz\n",
+			fprintf(stderr, "[prgpu] wave time: shading %.1f %%, idle %.1f %%, leaf steps %.1f %%, inner steps %.1f %%, refill %.1f %%, ray ends %.1f %%; of the shading: vertices %.1f %%, camera paths %.1f %%; shader clock %.0f MHz\n",
 					100 * host[PRGPU_STAT_COUNT + 8] / T, 100 * host[PRGPU_STAT_COUNT + 9] / T, 100 * host[PRGPU_STAT_COUNT + 11] / T, 100 * host[PRGPU_STAT_COUNT + 12] / T,
-					100 * host[PRGPU_STAT_COUNT + 14] / T, 100 * host[PRGPU_STAT_COUNT + 15] / T, 100.0 * double(host[PRGPU_STAT_COUNT + 13]) / T);
+					100 * host[PRGPU_STAT_COUNT + 14] / T, 100 * host[PRGPU_STAT_COUNT + 15] / T, 100 * host[PRGPU_STAT_COUNT + 17] / T, 100 * host[PRGPU_STAT_COUNT + 16] / T,
+					100.0 * double(host[PRGPU_STAT_COUNT + 13]) / T);
 		}
 	return PRGPU_OK;
 }

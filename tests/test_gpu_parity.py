@@ -162,8 +162,11 @@ def test_ray_service_hit_ids_exact_cornell():
     assert np.array_equal(g.traceShadowRays(org, d, 1e-4, dist), o.trace_any(org, d, 1e-4, dist))
 
 
-def test_ray_service_hit_ids_exact_soup_vs_brute_force():
-    """Device LBVH vs the oracle's exhaustive test (no BVH on the checking side at all)."""
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_ray_service_hit_ids_exact_soup_vs_brute_force(monkeypatch, split):
+    """Device LBVH vs the oracle's exhaustive test (no BVH on the checking side at all); both traversal kernels of the service
+    (PRGPU_TRACE_SPLIT=0: one kind of record per wave step; default: leaf tests through a task queue)."""
+    monkeypatch.setenv("PRGPU_TRACE_SPLIT", split)
     sc = scene.cornell_soup(8, 8, spp=1, n_triangles=30_032)
     g, o = backend.RenderContext(sc), ob.OracleScene(sc)
     rng = np.random.default_rng(12)
@@ -321,7 +324,9 @@ def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypat
     ref = _render_mode(monkeypatch, "lockstep", sc, [4])
     for env in (dict(PRGPU_PP_SLOTS="256", PRGPU_PP_OCCUPANCY="2"), dict(PRGPU_PP_SLOTS="1024", PRGPU_PP_SHADE_PARTIAL="1"),
                 dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_PARTIAL_ACT="4"),
-                dict(PRGPU_PP_BOTH="65", PRGPU_PP_REFILL_MIN="16"), dict(PRGPU_PP_BOTH="20")):
+                dict(PRGPU_PP_BOTH="65", PRGPU_PP_REFILL_MIN="16"), dict(PRGPU_PP_BOTH="20"), dict(PRGPU_PP_SORT="1"), dict(PRGPU_PP_SHADER="1"),
+                dict(PRGPU_PP_SHADER="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"), dict(PRGPU_PP_RESIDENT="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"),
+                dict(PRGPU_PP_LEAF_BIAS="160")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         out = _render_mode(monkeypatch, "persistent", sc, [4])
@@ -337,7 +342,7 @@ def test_resident_pixel_scheduling_of_the_persistent_kernel_is_bit_exact(monkeyp
     """More pixels than path slots and several samples per launch: pixels stay with a BLOCK, which deals (pixel, sample) units round-robin
     to its free slots (a unit whose predecessor still runs is delegated to the slot running it).  Grid sizes from 'every block lists
     5000 pixels' down to 'hardly more pixels than slots' (delegation on nearly every unit); results equal the oracle's bit for bit, and
-    those of the pixel-keeps-its-slot scheme (PRGPU_PP_RESIDENT=0 is read once per process, so that scheme is covered by the oracle)."""
+    those of the pixel-keeps-its-slot scheme (PRGPU_PP_RESIDENT=0, in the knob test below)."""
     monkeypatch.setenv("PRGPU_MODE", "persistent")
     monkeypatch.setenv("PRGPU_PP_MAX_BLOCKS", str(blocks))
     monkeypatch.setenv("PRGPU_PP_SLOTS", str(slots))
@@ -733,6 +738,28 @@ def _complex_c5(width, height, spp):
     sc = scene.ArrayScene(path)
     sc.desc.settings.width, sc.desc.settings.height, sc.desc.settings.aa_samples = width, height, spp
     return sc
+
+
+def test_c4_full_resolution_one_iteration_bit_exact():
+    """BASELINE config C4 at its full size: 1920 x 1080, 1 M triangles -- one whole iteration (2.07 M paths) against the checker:
+    primary hit ids, sample and feedback planes, the eleven statistics and every pixel's XYZ, bit for bit."""
+    sc = scene.cornell_soup(1920, 1080, spp=1024, n_triangles=1_000_000)
+    g, o = render_both(sc, iters=1, threads=16)
+    assert_parity(g, o, exact=True)
+    assert g.statistics()["pixel_samples"] == 1920 * 1080
+    g.render(3)   # ... and the persistent kernel's multi-iteration launch (resident pixels) against three more checker iterations
+    g.waitForFinish()
+    o.render(3, threads=16)
+    assert_parity(g, o, exact=True)
+
+
+def test_c5_full_resolution_one_iteration_bit_exact():
+    """BASELINE config C5 at its full size: examples/complex.prc as shipped (its sky light's Hosek-Wilkie table built by the library),
+    1920 x 1080 -- two whole iterations against the checker, bit for bit."""
+    sc = _complex_c5(1920, 1080, 4096)
+    g, o = render_both(sc, iters=2, threads=16)
+    assert_parity(g, o, exact=True)
+    assert g.statistics()["pixel_samples"] == 2 * 1920 * 1080
 
 
 def test_c5_complex_prc_scene_bit_exact():

@@ -1,4 +1,4 @@
-"""Instrumented persistent-kernel counters for a tile share of the C4 frame: records per ray, wave steps, lane utilisation, time split.
+"""Instrumented persistent-kernel counters for a tile share of the C4 (or C5) frame: records per ray, wave steps, lane utilisation, time split.
 usage: python tools/gpu_counters.py [world] [iterations] [scene: c4|c5]   (GPU box; env knobs apply)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,9 +9,8 @@ world = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 which = sys.argv[3] if len(sys.argv) > 3 else "c4"
 if which == "c5":
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-    from c5_scene import c5_scene
-    sc = c5_scene(W, H)
+    sc = scene.ArrayScene(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "scenes", "complex_c5.npz"))
+    sc.desc.settings.width, sc.desc.settings.height = W, H
 else:
     sc = scene.cornell_soup(W, H, spp=1024, n_triangles=1_000_000)
 ctx = backend.RenderContext(sc)
