@@ -2191,6 +2191,7 @@ struct PersistentArgs {
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
 	uint32_t sort_rays;	  // 1: a shading pass queues its rays ordered by direction octant
 	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
+	int fin_batch;		  // finished rays of a wave are written out once this many lanes hold one (or the wave is under-occupied); 1: at once
 	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
 	// resident pixels (see path_persistent): per block `bl_cap` list entries (pixel) and state words (samples done | samples handed out << 16),
 	// and per slot the list entry of the pixel it renders
@@ -2608,8 +2609,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		spins = 0;
 		for (;;) {
 			// one kind of record per wave step (see trace_persistent)
-			const bool at_leaf	= has_ray && (s.cur & REC_LEAF_BIT) != 0;
-			const bool at_inner = has_ray && !at_leaf;
+			const bool at_leaf	= has_ray && s.cur != REC_EMPTY && (s.cur & REC_LEAF_BIT) != 0; // (a finished ray waits for its write-out, below)
+			const bool at_inner = has_ray && (s.cur & REC_LEAF_BIT) == 0;
 			const int n_leaf	= __popcll(__ballot(at_leaf));
 			const int n_inner	= __popcll(__ballot(at_inner));
 			if (COUNT && lane == 0)
@@ -2664,7 +2665,17 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				else
 					t_leaf += wall_clock64() - t0s;
 			}
-			const bool fin = has_ray && s.cur == REC_EMPTY;
+			// Finished rays are written out in batches: the write-out releases the hit to the block (it waits for the wave's global stores,
+			// about a microsecond during which none of the wave's rays moves), and a finished lane has nothing to do anyway until the wave
+			// refills -- so wait until `fin_batch` lanes are done, or until the wave is short of running rays and wants new ones.
+			const bool done = has_ray && s.cur == REC_EMPTY;
+			bool fin		= done;
+			if (a.fin_batch > 1) {
+				const int n_done = __popcll(__ballot(done));
+				const int n_run	 = __popcll(__ballot(has_ray && !done));
+				if (n_done < a.fin_batch && n_run >= a.refill_below)
+					fin = false;
+			}
 			const unsigned long long t0f = COUNT ? wall_clock64() : 0ull;
 			if (__any(fin)) {
 				bool last	   = false;
@@ -3240,6 +3251,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.leaf_bias		  = getenv("PRGPU_PP_LEAF_BIAS") ? std::max(1, atoi(getenv("PRGPU_PP_LEAF_BIAS"))) : 100;
 	a.gstats		  = gstats;
 	a.direct_map	  = all_in_flight ? 1u : 0u;
+	a.fin_batch		  = getenv("PRGPU_PP_FIN_BATCH") ? std::min(64, std::max(1, atoi(getenv("PRGPU_PP_FIN_BATCH")))) : 16;
 	// resident pixels: more pixels than slots and more than one sample per pixel in this launch (PRGPU_PP_RESIDENT=0: a pixel keeps its slot)
 	const bool resident_ok = !(getenv("PRGPU_PP_RESIDENT") && atoi(getenv("PRGPU_PP_RESIDENT")) == 0);
 	a.bl_cap		  = (uint32_t)std::min<uint64_t>(n_owned, 2ull * ((n_owned + g.n_blocks - 1) / g.n_blocks) + 1024ull);
