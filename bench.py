@@ -255,11 +255,19 @@ def main():
             box = [raw]
             dist.broadcast_object_list(box, src=0)
             return box[0]
+        # every rank probes RCCL on its own and the ranks agree BEFORE any call in which one of them could fail while the others block
+        usable = 1 if backend.rccl_available() else 0
+        if world > 1:
+            flag = torch.tensor([usable], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            usable = int(flag.item())
         try:
-            comm = backend.Communicator(world, rank, device=local, exchange=exchange)
+            comm = backend.Communicator(world, rank, device=local, exchange=exchange) if usable else None
         except Exception as e:  # noqa: BLE001 -- keep the bench line: fall back to the torch.distributed reduce on every rank
             sys.stderr.write("[bench] rank %d: prgpu_comm_create failed (%s); falling back to torch.distributed.reduce\n" % (rank, e))
             comm = None
+        if not usable:
+            sys.stderr.write("[bench] rank %d: RCCL is not reachable through libprgpu on every rank; falling back to torch.distributed.reduce\n" % rank)
         if world > 1:           # all ranks take the same branch
             ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)

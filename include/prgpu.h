@@ -412,7 +412,10 @@ int  prgpu_comm_create(const uint8_t id[PRGPU_COMM_ID_BYTES], int n_ranks, int r
 void prgpu_comm_destroy(prgpu_comm* comm);
 int  prgpu_comm_size(const prgpu_comm* comm);   /* n_ranks, or PRGPU_EINVAL */
 /* Asynchronous on the scene's stream (after the render calls queued there); prgpu_sync / prgpu_download wait for it.  In place:
- * on `root` the planes hold the sums afterwards, on the other ranks they are unchanged. */
+ * on `root` the planes hold the sums afterwards, on the other ranks they are unchanged.  ONE reduce per frame: with more than one
+ * rank a second call on the same scene object returns PRGPU_EINVAL (the root's copies of the other ranks' pixels already hold their
+ * totals, a second sum would add them again) -- except when the first one ran before anything was rendered (all planes zero:
+ * warming the communicator up). */
 int  prgpu_reduce(prgpu_scene* s, prgpu_comm* comm, int root);
 
 /* -- shading-point AOVs and image files ------------------------------------------------------

@@ -208,12 +208,22 @@ class Communicator:
         self._h = C.c_void_p()
         ident = None
         if n_ranks > 1 or os.environ.get("PRGPU_COMM_FORCE_RCCL", "0") not in ("", "0"):
-            raw = None
+            if n_ranks > 1 and exchange is None:
+                raise ValueError("Communicator: n_ranks > 1 needs an `exchange` callable that ships rank 0's %d-byte id to every rank" % abi.COMM_ID_BYTES)
+            raw, err = None, None
             if rank == 0:
                 buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
-                abi.check(self.lib.prgpu_comm_unique_id(buf))
-                raw = bytes(buf)
+                try:
+                    abi.check(self.lib.prgpu_comm_unique_id(buf))
+                    raw = bytes(buf)
+                except Exception as e:  # noqa: BLE001 -- the other ranks are waiting in the exchange: send them a sentinel first
+                    err = e
             raw = exchange(raw) if exchange is not None else raw
+            if err is not None:
+                raise err
+            if not isinstance(raw, (bytes, bytearray)) or len(raw) != abi.COMM_ID_BYTES:
+                raise ValueError("Communicator: the exchange delivered %r instead of rank 0's %d-byte id (rank 0 could not create one?)"
+                                 % (type(raw).__name__ if raw is not None else None, abi.COMM_ID_BYTES))
             ident = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(raw)
         abi.check(self.lib.prgpu_comm_create(ident, int(n_ranks), int(rank), int(device), C.byref(self._h)))
 
@@ -231,6 +241,13 @@ class Communicator:
             self.close()
         except Exception:
             pass
+
+
+def rccl_available():
+    """True if this process can reach RCCL through the library (dlopen + ncclGetUniqueId): a rank-symmetric probe to run -- and agree
+    on across the ranks -- BEFORE the first call in which one rank could fail while its peers block (id broadcast, ncclCommInitRank)."""
+    buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
+    return abi.load().prgpu_comm_unique_id(buf) == 0
 
 
 def write_exr(path, channels):

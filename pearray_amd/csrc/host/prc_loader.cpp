@@ -1677,6 +1677,8 @@ struct Loader {
 		if (shape >= count)
 			fail(PRGPU_EINVAL, path + ": cannot access shape " + std::to_string(shape) + ", the file contains " + std::to_string(count));
 		const size_t osz = version >= 4 ? 8 : 4;
+		if (uint64_t(count) * osz + 4 > file.size()) // the offset dictionary at the end of the file must fit into it
+			fail(PRGPU_EINVAL, path + ": the shape count " + std::to_string(count) + " does not fit the file");
 		auto offset_of = [&](uint32_t k) {
 			uint64_t o = 0;
 			rd(file.size() - 4 - osz * (count - k), &o, osz);
@@ -1730,6 +1732,19 @@ struct Loader {
 		take(&n_tris, 8);
 		if (n_vertices == 0 || n_tris == 0 || n_vertices > 0xFFFFFFFFull || n_tris > 0x7FFFFFFFull)
 			fail(PRGPU_EINVAL, path + ": no valid mesh in shape " + std::to_string(shape));
+		{ // the counts are from the file: check them against the inflated stream before anything is sized by them
+			const uint64_t elem = (flags & MF_DOUBLE) ? 8 : 4;
+			uint64_t need		= n_vertices * 3 * elem + n_tris * 3 * 4;
+			if (flags & MF_VERTEXNORMALS)
+				need += n_vertices * 3 * elem;
+			if (flags & MF_TEXCOORDS)
+				need += n_vertices * 2 * elem;
+			if (flags & MF_VERTEXCOLORS)
+				need += n_vertices * 3 * elem;
+			if (need > data.size() - pos)
+				fail(PRGPU_EINVAL, path + ": shape " + std::to_string(shape) + " announces " + std::to_string(n_vertices) + " vertices and " + std::to_string(n_tris)
+										+ " triangles but its stream holds " + std::to_string(data.size() - pos) + " bytes");
+		}
 		auto floats = [&](std::vector<float>& dst, size_t n) {
 			dst.resize(n);
 			if (flags & MF_DOUBLE) {

@@ -105,6 +105,7 @@ struct prgpu_scene {
 	prd::DevLpe lpe_host{}; // host copy of the light path expression block (plane pointers for downloads and the reduce)
 	uint32_t order_tuned_at = 0; // iteration count the pixel order was last tuned at (tune_pixel_order)
 	bool poisoned = false; // a device-side error was reported: further render calls are refused
+	uint32_t reduced_at = 0xFFFFFFFFu; // iteration count at which prgpu_reduce summed the ranks' frames in place (0xFFFFFFFF: not yet)
 	uint64_t pp_launch_samples = 128ull << 20; // persistent mode: camera samples per launch (render calls are cut into bounded launches)
 	uint32_t pp_launch_min_iters = 8;
 
@@ -383,7 +384,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		else if (d->entities[e].kind == PRGPU_ENTITY_SPHERE)
 			sc.features |= prd::FEAT_SPHERES;
 	if (const char* env = getenv("PRGPU_FORCE_FEATURES")) // measurement aid: run a scene with a larger kernel variant than it needs (same results)
-		sc.features |= (uint32_t)strtoul(env, nullptr, 0) & prd::FEAT_ALL;
+		sc.features |= (uint32_t)strtoul(env, nullptr, 0) & prd::FEAT_ALL & ~(prd::FEAT_LPE | prd::FEAT_QUADRICS); // (those two need data the scene does not have)
 	sc.scene_radius	 = t.scene_radius;
 	sc.wl_cdf_size	 = (uint32_t)t.wl_cdf.size();
 	sc.wl_u_offset	 = t.wl_u_offset;
@@ -1534,6 +1535,15 @@ int prgpu_reduce(prgpu_scene* s, prgpu_comm* c, int root)
 		return fail(PRGPU_EINVAL, "null argument");
 	if (root < 0 || root >= c->n_ranks)
 		return fail(PRGPU_EINVAL, "root must be a rank of the communicator");
+	// The reduce sums IN PLACE into the root's planes: afterwards the root's copies of the other ranks' pixels hold their totals, and a
+	// second reduce after more rendering would add the new totals on top.  One reduce per frame -- except before anything was rendered
+	// (all planes zero: warming the communicator up), which may be repeated.
+	if (c->n_ranks > 1) {
+		if (s->reduced_at != 0xFFFFFFFFu && s->reduced_at != 0u)
+			return fail(PRGPU_EINVAL, "prgpu_reduce: this scene's frame has already been reduced (after " + std::to_string(s->reduced_at)
+										  + " iterations); the in-place sum cannot be repeated -- create the scene again for another frame");
+		s->reduced_at = s->next_iteration;
+	}
 	if (!c->nccl)
 		return PRGPU_OK; // one rank: the frame is already complete
 	if (c->device != s->device)

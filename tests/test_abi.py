@@ -108,6 +108,15 @@ def test_scene_create_fails_loudly_without_device():
     assert rc == -2 and not h.value and b"no CPU fallback" in lib.prgpu_last_error()
 
 
+def test_communicator_argument_errors_are_clear():
+    """Advisor finding: n_ranks > 1 without a way to ship rank 0's id used to end in an opaque TypeError."""
+    from pearray_amd import backend
+    with pytest.raises(ValueError, match="exchange"):
+        backend.Communicator(2, 1)
+    with pytest.raises(ValueError, match="instead of rank 0's"):
+        backend.Communicator(2, 1, exchange=lambda raw: None)   # rank 0 could not create an id and sent the sentinel
+
+
 def test_product_never_imports_the_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "pearray_amd")):
         for f in files:

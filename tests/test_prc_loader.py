@@ -519,6 +519,15 @@ def test_mitsuba_serialized_embed_semantics(tmp_path, version, double, with_norm
     (tmp_path / "bad.serialized").write_bytes(b"\x00\x00\x04\x00" + b"\0" * 16)
     with pytest.raises(abi.PrgpuError, match="not a valid Mitsuba"):
         scene.PrcScene(source=EMBED % ("mts", str(tmp_path / "bad.serialized"), ""))
+    # counts taken from the file are checked against the stream before anything is sized by them (a hostile file must not ask for 48 GB)
+    raw = struct.pack("<I", 0x1000) + (b"x\0" if version >= 4 else b"") + struct.pack("<QQ", 0xFFFFFFFF, 1) + b"\0" * 64
+    huge = struct.pack("<HH", 0x041C, version) + zlib.compress(raw) + struct.pack("<Q" if version >= 4 else "<I", 0) + struct.pack("<I", 1)
+    (tmp_path / "huge.serialized").write_bytes(huge)
+    with pytest.raises(abi.PrgpuError, match="announces 4294967295 vertices"):
+        scene.PrcScene(source=EMBED % ("mts", str(tmp_path / "huge.serialized"), ""))
+    (tmp_path / "count.serialized").write_bytes(blob[:-4] + struct.pack("<I", 0x7FFFFFFF))   # a shape count the file cannot hold
+    with pytest.raises(abi.PrgpuError, match="does not fit the file"):
+        scene.PrcScene(source=EMBED % ("mts", str(tmp_path / "count.serialized"), ""))
 
 
 def _spd_scene(tmp_path, csv_text, expr="(spd 'data.csv')"):
