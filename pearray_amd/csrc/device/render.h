@@ -48,6 +48,10 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int refill_min, int both_below, int occupancy, int shader_wave, int shade_help,
 							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st);
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st);
+// lockstep pipeline, PRGPU_SORT_RAYS=1 (experiment): the active list ordered by (Morton code of the ray origin, direction octant)
+size_t sort_active_temp_bytes(uint32_t n_max);
+void launch_sort_active(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n, uint32_t* keys_in, uint32_t* keys_out, uint32_t* active_out,
+						void* temp, size_t temp_bytes, hipStream_t st);
 void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
 							uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, unsigned long long* gstats,
 							hipStream_t st);

@@ -17,6 +17,9 @@
 #include "render.h"
 
 #include <algorithm>
+#if PR_TU == 0
+#include <hipcub/hipcub.hpp>
+#endif
 
 namespace prd {
 
@@ -2120,31 +2123,6 @@ __device__ __forceinline__ void ring_push(uint32_t* q, uint32_t cap_mask, uint32
 	if (pred)
 		__hip_atomic_store(&q[(base + __popcll(mask & ((1ull << lane) - 1ull))) & cap_mask], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// the same, with the wave's entries ordered by a 3-bit key (the direction octant of the ray): rays that are handed out together then
-// share the near/far child order.  Counting sort inside the wave: eight ballots.
-__device__ __forceinline__ void ring_push_sorted(uint32_t* q, uint32_t cap_mask, uint32_t* tail, bool pred, uint32_t value, uint32_t key)
-{
-	const unsigned long long mask = __ballot(pred);
-	if (mask == 0ull)
-		return;
-	const uint32_t lane = threadIdx.x & 63u;
-	uint32_t base		= 0;
-	const int leader	= __ffsll((long long)mask) - 1;
-	if ((int)lane == leader)
-		base = __hip_atomic_fetch_add(tail, (uint32_t)__popcll(mask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-	base = __shfl(base, leader, 64);
-	uint32_t before = 0, rank = 0;
-#pragma unroll
-	for (uint32_t k = 0; k < 8; ++k) {
-		const unsigned long long mk = __ballot(pred && key == k);
-		if (key == k)
-			rank = before + __popcll(mk & ((1ull << lane) - 1ull));
-		before += (uint32_t)__popcll(mk);
-	}
-	if (pred)
-		__hip_atomic_store(&q[(base + rank) & cap_mask], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ uint32_t direction_octant(float x, float y, float z) { return (x < 0.0f ? 1u : 0u) | (y < 0.0f ? 2u : 0u) | (z < 0.0f ? 4u : 0u); }
 // claim up to `want` entries; returns how many (wave-uniform) and the ring position of the first one
 __device__ __forceinline__ uint32_t ring_claim(uint32_t* head, const uint32_t* tail, uint32_t want, uint32_t& first)
 {
@@ -2189,7 +2167,6 @@ struct PersistentArgs {
 	uint32_t refill_min; // waves other than the block's first one refill only when at least this many rays are queued
 	uint32_t shader_wave; // 1: the block's last wave only shades (any batch size, never holds rays); the others trace and help
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
-	uint32_t sort_rays;	  // 1: a shading pass queues its rays ordered by direction octant
 	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
 	int fin_batch;		  // finished rays of a wave are written out once this many lanes hold one (or the wave is under-occupied); 1: at once
 	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
@@ -2293,7 +2270,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
 	const unsigned long long c_start = COUNT ? (unsigned long long)clock64() : 0ull;
 
-	const bool shader = a.shader_wave != 0u && ((threadIdx.x >> 6) & 3u) == 3u; // one wave in four
+	const uint32_t shader_idx = 3u; // one wave in four (rotating it with the block's dispatch layer, so that the shading waves of the blocks that
+									// share a CU sit on different SIMDs, changes nothing: 2.38 - 2.43 ms per iteration at 1/8 of the C4 frame either way)
+	const bool shader		  = a.shader_wave != 0u && ((threadIdx.x >> 6) & 3u) == shader_idx;
+	const bool first_tracer	  = (threadIdx.x >> 6) == ((a.shader_wave != 0u && shader_idx == 0u) ? 1u : 0u); // the wave that takes a thin supply of rays
 	const uint32_t shade_full = a.shader_wave != 0u ? a.shade_help : a.shade_min;
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
@@ -2521,14 +2501,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 									   __HIP_MEMORY_SCOPE_WORKGROUP);
 				}
 				ring_push(sh.q_shade[QR], SHADE_MASK, &sh.shade_tail[QR], to_regen, slot_l);
-				if (a.sort_rays) { // "sorted ray queues": order the wave's new rays by direction octant (measured: see DESIGN.md)
-					const float4 bd = alive ? ps.ray_d[slot] : make_float4(0, 0, 0, 0);
-					ring_push_sorted(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY, direction_octant(sh_d.x, sh_d.y, sh_d.z));
-					ring_push_sorted(sh.q_ray, RAY_MASK, &sh.ray_tail, alive, slot_l, direction_octant(bd.x, bd.y, bd.z));
-				} else {
-					ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY);
-					ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, alive, slot_l);
-				}
+				ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, want_shadow, slot_l | PP_ANY);
+				ring_push(sh.q_ray, RAY_MASK, &sh.ray_tail, alive, slot_l);
 				{ // rays in flight were parked during the pass: rebuild their traversal constants (same values) rather than
 				  // holding them in registers across the shading code
 					const uint32_t pslot = slot0 + (has_ray ? (my_entry & ~PP_ANY) : 0u);
@@ -2549,7 +2523,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		// wait for at least `refill_min`, so that a thin supply of rays fills a few waves instead of keeping every wave stepping
 		// with a handful of lanes (a wave step costs the same with 3 lanes as with 64).
 		const unsigned long long idle = __ballot(!has_ray);
-		if (!shader && idle != 0ull && n_queued > 0u && (n_queued >= a.refill_min || threadIdx.x < 64u)) {
+		if (!shader && idle != 0ull && n_queued > 0u && (n_queued >= a.refill_min || first_tracer)) {
 			const unsigned long long t0r = COUNT ? wall_clock64() : 0ull;
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(idle), first);
@@ -2720,7 +2694,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				for (int q = 1; q < NQ + 1; ++q)
 					nsh = max(nsh, lds_load(&sh.shade_tail[q]) - lds_load(&sh.shade_head[q]));
 				const uint32_t nq = lds_load(&sh.ray_tail) - lds_load(&sh.ray_head);
-				if (wave_bcast0(((nq > 0u && (nq >= a.refill_min || threadIdx.x < 64u)) || nsh >= shade_full || (a.shader_wave == 0u && nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
+				if (wave_bcast0(((nq > 0u && (nq >= a.refill_min || first_tracer)) || nsh >= shade_full || (a.shader_wave == 0u && nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
 					break;
 			}
 		}
@@ -3089,6 +3063,47 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_any(DevScene sc, uint32_
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------
+// ---- sorted ray queue of the lockstep pipeline (experiment, PRGPU_SORT_RAYS=1; HitStream::setup + radixSort, trace/HitStream.cpp:57-86,
+// base/container/RadixSort.h:12-43, sort a stream by a key before it is processed): the active list of a path depth is ordered by
+// key = Morton27(ray origin on a 512^3 grid over the scene's bounding cube) << 3 | direction octant, so that neighbouring lanes walk
+// neighbouring parts of the tree.  Per-pixel results do not depend on the order of the list.
+__device__ __forceinline__ uint32_t spread9(uint32_t v) // 9 bits -> every third bit
+{
+	v &= 0x1FFu;
+	v = (v | (v << 16)) & 0x030000FFu;
+	v = (v | (v << 8)) & 0x0300F00Fu;
+	v = (v | (v << 4)) & 0x030C30C3u;
+	v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+__global__ void __launch_bounds__(256) k_ray_sort_keys(PathState ps, const uint32_t* __restrict__ active, uint32_t n, float radius, uint32_t* __restrict__ keys)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n)
+		return;
+	const uint32_t slot = active[i];
+	const float4 o = ps.ray_o[slot], d = ps.ray_d[slot];
+	const float inv = radius > 0.0f ? 256.0f / radius : 0.0f; // (o + R) / (2 R) * 512
+	const uint32_t qx = (uint32_t)fminf(fmaxf((o.x + radius) * inv, 0.0f), 511.0f), qy = (uint32_t)fminf(fmaxf((o.y + radius) * inv, 0.0f), 511.0f),
+				   qz = (uint32_t)fminf(fmaxf((o.z + radius) * inv, 0.0f), 511.0f);
+	const uint32_t morton = (spread9(qx) << 2) | (spread9(qy) << 1) | spread9(qz);
+	keys[i] = (morton << 3) | (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+}
+size_t sort_active_temp_bytes(uint32_t n_max)
+{
+	size_t bytes = 0;
+	(void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_max, 0, 30);
+	return bytes;
+}
+void launch_sort_active(const DevScene& sc, const PathState& ps, const uint32_t* active, uint32_t n, uint32_t* keys_in, uint32_t* keys_out, uint32_t* active_out,
+						void* temp, size_t temp_bytes, hipStream_t st)
+{
+	if (!n)
+		return;
+	hipLaunchKernelGGL(k_ray_sort_keys, dim3((n + 255) / 256), dim3(256), 0, st, ps, active, n, sc.scene_radius, keys_in);
+	(void)hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, active, active_out, (int)n, 0, 30, st);
+}
+
 static inline dim3 grid_for(uint32_t n, uint32_t block = 256) { return dim3((n + block - 1) / block); }
 
 void launch_raygen(const DevScene& sc, const PathState& ps, uint32_t slot_base, uint32_t n_slots, uint32_t iter, unsigned long long* gstats, hipStream_t st)
@@ -3247,7 +3262,6 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.both_below	  = std::min(65, std::max(0, both_below));
 	a.shader_wave	  = shader_wave ? 1u : 0u;
 	a.shade_help	  = (uint32_t)std::max(64, shade_help);
-	a.sort_rays		  = getenv("PRGPU_PP_SORT") && atoi(getenv("PRGPU_PP_SORT")) != 0 ? 1u : 0u;
 	a.leaf_bias		  = getenv("PRGPU_PP_LEAF_BIAS") ? std::max(1, atoi(getenv("PRGPU_PP_LEAF_BIAS"))) : 100;
 	a.gstats		  = gstats;
 	a.direct_map	  = all_in_flight ? 1u : 0u;

@@ -84,6 +84,9 @@ struct prgpu_scene {
 		uint32_t *active_a = nullptr, *active_b = nullptr, *counters = nullptr, *h_counters = nullptr;
 		uint32_t *dead_a = nullptr, *dead_b = nullptr; // streaming mode: paths that ended in the current / previous round
 		uint32_t *dead_cur = nullptr, *dead_prev = nullptr;
+		uint32_t *sort_keys_a = nullptr, *sort_keys_b = nullptr, *sort_active = nullptr; // PRGPU_SORT_RAYS (experiment): allocated on first use
+		void* sort_temp = nullptr;
+		size_t sort_temp_bytes = 0;
 		uint32_t n_dead_prev = 0;
 		prd::TraceWorkspace ws_closest, ws_shadow;
 		prd::PathState ps; // shadow-queue pointers offset to this group's region
@@ -601,6 +604,26 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 int enqueue_vertex(prgpu_scene* s, prgpu_scene::Group& g)
 {
 	hipStream_t st = g.s_main;
+	const bool sort_rays = getenv("PRGPU_SORT_RAYS") && atoi(getenv("PRGPU_SORT_RAYS")) != 0; // experiment, off: profiles/r03_global_sort.json
+	if (sort_rays && g.active != nullptr && g.n_active > 0) { // secondary rays (the primary wave runs in Morton order of the pixels anyway)
+		if (!g.sort_temp) {
+			int rc = s->alloc(g.sort_keys_a, g.n_slots);
+			rc	   = rc == PRGPU_OK ? s->alloc(g.sort_keys_b, g.n_slots) : rc;
+			rc	   = rc == PRGPU_OK ? s->alloc(g.sort_active, g.n_slots) : rc;
+			if (rc != PRGPU_OK)
+				return rc;
+			g.sort_temp_bytes = prd::sort_active_temp_bytes(g.n_slots);
+			unsigned char* tmp = nullptr;
+			rc = s->alloc(tmp, g.sort_temp_bytes);
+			if (rc != PRGPU_OK)
+				return rc;
+			g.sort_temp = tmp;
+		}
+		s->time_begin(5, st);
+		prd::launch_sort_active(s->sc, g.ps, g.active, g.n_active, g.sort_keys_a, g.sort_keys_b, g.sort_active, g.sort_temp, g.sort_temp_bytes, st);
+		s->time_end(st);
+		g.active = g.sort_active; // the shading pass reads the same list (g.next is written, never this one)
+	}
 	s->time_begin(1, st);
 	prd::launch_trace_closest(s->sc, g.ps, g.active, g.slot_begin, g.n_active, s->instrument, g.ws_closest, g.counters, s->gstats, st);
 	s->time_end(st);

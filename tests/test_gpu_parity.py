@@ -319,12 +319,23 @@ def test_persistent_kernel_tiny_and_ragged_films(monkeypatch, w, h):
     assert_parity(g, o, exact=True)
 
 
+def test_sorted_ray_lists_of_the_lockstep_pipeline_do_not_change_results(monkeypatch):
+    """PRGPU_SORT_RAYS=1 (experiment, profiles/r03_global_sort.json): every path depth's ray list radix-sorted by origin cell and direction octant."""
+    sc = scene.cornell_soup(192, 108, spp=4, n_triangles=20_000)
+    ref = _render_mode(monkeypatch, "lockstep", sc, [4])
+    monkeypatch.setenv("PRGPU_SORT_RAYS", "1")
+    out = _render_mode(monkeypatch, "lockstep", sc, [4])
+    for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+        assert np.array_equal(a, b)
+    assert ref[2] == out[2]
+
+
 def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypatch):
     sc = scene.cornell_soup(192, 108, spp=4, n_triangles=20_000)
     ref = _render_mode(monkeypatch, "lockstep", sc, [4])
     for env in (dict(PRGPU_PP_SLOTS="256", PRGPU_PP_OCCUPANCY="2"), dict(PRGPU_PP_SLOTS="1024", PRGPU_PP_SHADE_PARTIAL="1"),
                 dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_PARTIAL_ACT="4"),
-                dict(PRGPU_PP_BOTH="65", PRGPU_PP_REFILL_MIN="16"), dict(PRGPU_PP_BOTH="20"), dict(PRGPU_PP_SORT="1"), dict(PRGPU_PP_SHADER="1"),
+                dict(PRGPU_PP_BOTH="65", PRGPU_PP_REFILL_MIN="16"), dict(PRGPU_PP_BOTH="20"), dict(PRGPU_PP_FIN_BATCH="1"), dict(PRGPU_PP_FIN_BATCH="48"), dict(PRGPU_PP_SHADER="1"),
                 dict(PRGPU_PP_SHADER="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"), dict(PRGPU_PP_RESIDENT="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"),
                 dict(PRGPU_PP_LEAF_BIAS="160")):
         for k, v in env.items():
