@@ -196,6 +196,15 @@ enum { PRGPU_LIGHT_ENVIRONMENT = 0, PRGPU_LIGHT_DISTANT = 1, PRGPU_LIGHT_SKY = 2
 enum { PRGPU_SKYF_EXTEND = 1u,        /* `:extend` (default true): the distribution covers elevations -pi/2..pi/2, the ground half scaled
                                          by GROUND_PENALTY = 0.001 (sky.cpp:23,127-159); without it directions below the horizon are black */
        PRGPU_SKYF_COMPENSATION = 2u }; /* `:compensation` (default false): Distribution2D::applyCompensation (Distribution2D.cpp:38-76) */
+enum { PRGPU_ENVF_TEXTURED = 16u,     /* ENVIRONMENT: the radiance is `radiance` (any plain node, e.g. 1 or D65) times an IMAGE in latitude /
+                                         longitude layout: `table_offset` -> elevation_count rows x azimuth_count columns x 3 Jakob-Hanika
+                                         coefficients in spectral_tables (what a PR:Parametric image holds, ParametricImageNode,
+                                         src/loader/shader/ImageNode.cpp:48-73; an RGB image is converted texel by texel with
+                                         prgpu_rgb_to_coeffs), looked up at the texel under (u, 1 - v) -- closest-texel interpolation, u periodic,
+                                         v clamped; uv = Spherical::uv_from_normal of the local direction (environment.cpp:56).  With more than one
+                                         row and column the light samples a Distribution2D over sin(theta) x radiance with the 1 / (2 pi^2 sin theta)
+                                         Jacobian (environment.cpp:70-101,178-199) instead of the cosine hemisphere; PRGPU_SKYF_COMPENSATION applies */
+       PRGPU_ENVF_NO_DISTRIBUTION = 32u }; /* `:distribution false`: cosine-hemisphere sampling even with an image */
 enum { PRGPU_SKYF_CLOUDY = 8u };      /* CIE_SKY: 'cloudy_sky' (c1 = (1 + 2 z) / 3, c2 = 0.7777777); without it 'uniform_sky' (c1 = c2 = 1) */
 enum { PRGPU_LIGHTF_SUN_DELTA = 4u };  /* DISTANT standing in for SunDeltaLight: power() is the plain table lookup (sun.cpp:222-228)
                                          instead of NodeUtils::average (distant.cpp:93) -- an ulp in the light-selection weights */
@@ -204,12 +213,12 @@ typedef struct prgpu_light {
 	uint32_t kind;
 	uint32_t radiance;     /* spectrum index: ENVIRONMENT `radiance`, DISTANT `irradiance`, SUN the sun's TABLE node; unused for SKY */
 	uint32_t background;   /* ENVIRONMENT: `background` spectrum index, or PRGPU_INVALID_ID = radiance */
-	uint32_t flags;        /* SKY: PRGPU_SKYF_* */
+	uint32_t flags;        /* SKY: PRGPU_SKYF_*; ENVIRONMENT: PRGPU_ENVF_* (| PRGPU_SKYF_COMPENSATION) */
 	float    direction[3]; /* DISTANT: `direction` (default 0 0 1); SUN: ElevationAzimuth::toDirection() of the sun position */
 	float    cos_theta;    /* SUN: cos(SUN_VIS_RADIUS * radius), SUN_VIS_RADIUS = 0.5358 deg / 2 (sun.cpp:24,36) */
 	float    transform[16];
-	uint32_t table_offset; /* SKY: first float of the table in prgpu_scene_desc::spectral_tables */
-	uint32_t azimuth_count, elevation_count; /* SKY: table resolution (`azimuth_resolution` 512, `elevation_resolution` 256) */
+	uint32_t table_offset; /* SKY: first float of the table in prgpu_scene_desc::spectral_tables; textured ENVIRONMENT: of the coefficient image */
+	uint32_t azimuth_count, elevation_count; /* SKY: table resolution (`azimuth_resolution` 512, `elevation_resolution` 256); textured ENVIRONMENT: image width, height */
 	float    ground_brightness; /* CIE_SKY: `ground_brightness` (default 0.2) */
 } prgpu_light;
 

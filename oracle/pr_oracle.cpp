@@ -2386,8 +2386,78 @@ Blob cie_sky_radiance(const Scene& s, const Scene::InfLight& il, const Blob& wl,
 	const Blob za = zenith * (c1 * a), gb = ground * (il.l.ground_brightness * c2 * b);
 	return blob4(za[0] + gb[0], za[1] + gb[1], za[2] + gb[2], za[3] + gb[3]) * denom;
 }
+// ---- textured environment light (environment.cpp with a ParametricImageNode radiance, loader/shader/ImageNode.cpp:48-73) ----
+// The image crosses the boundary as Jakob-Hanika coefficients per texel (PRGPU_ENVF_TEXTURED); OpenImageIO's texture lookup is a third-party
+// piece that is not in the tree: what is restated is its closest-texel mode at (s, t) = (u, 1 - v), u periodic, v clamped.
+inline Blob env_image_eval(const Scene& s, const Scene::InfLight& il, const Blob& wl, float u, float v)
+{
+	const uint32_t W = il.l.azimuth_count, H = il.l.elevation_count;
+	const float fu	 = u - std::floor(u);
+	const uint32_t col = std::min(W - 1u, (uint32_t)(fu * (float)W));
+	const float tv	   = std::min(1.0f, std::max(0.0f, 1.0f - v));
+	const uint32_t row = std::min(H - 1u, (uint32_t)(tv * (float)H));
+	const float* c	   = s.tables.data() + il.l.table_offset + 3u * (size_t(row) * W + col);
+	const float p[3]   = { c[0], c[1], c[2] };
+	const Blob base	   = spectrum_eval(s, il.l.radiance, wl);
+	return blob4(base[0] * upsample(p, wl[0]), base[1] * upsample(p, wl[1]), base[2] * upsample(p, wl[2]), base[3] * upsample(p, wl[3]));
+}
+// Spherical::uv_from_normal (Spherical.h:8-26): (phi / pi / 2, theta / pi), through the shared fp32 atan2 / acos
+inline void uv_from_direction(V3 D, float& u, float& v)
+{
+	const float x = (D.x == 0 && D.y == 0) ? 1e-5f : D.x;
+	float phi	  = atan2_fp32(D.y, x);
+	phi			  = phi < 0 ? phi + 2 * PR_PI_F : phi;
+	const float theta = safe_acos(D.z);
+	u = (phi * PR_INV_PI_F) / 2;
+	v = theta * PR_INV_PI_F;
+}
+inline float env_direction_factor(float v) // environment.cpp:71-73,85-87
+{
+	float sn, cs;
+	sincos_rad(v * PR_PI_F, sn, cs);
+	const float denom = 2 * PR_PI_F * PR_PI_F * sn;
+	return (denom <= PR_EPS) ? 0.0f : 1.0f / denom;
+}
+// EnvironmentLightFactory::create (environment.cpp:176-199)
+void env_build_distribution(const Scene& s, Scene::InfLight& il)
+{
+	const uint32_t W = il.l.azimuth_count, H = il.l.elevation_count;
+	if ((il.l.flags & PRGPU_ENVF_NO_DISTRIBUTION) || W <= 1 || H <= 1)
+		return;
+	const Blob WVLS = blob4(560.0f, 540.0f, 400.0f, 600.0f);
+	il.dist.generate(W, H, [&](uint32_t x, uint32_t y) {
+		const float u = (x + 0.5f) / (float)W, v = (y + 0.5f) / (float)H;
+		const float sinTheta = std::sin(PR_PI_F * v);
+		const Blob r		 = env_image_eval(s, il, WVLS, u, v);
+		const float val		 = sinTheta * std::max(std::max(r[0], r[1]), std::max(r[2], r[3]));
+		return (val <= PR_EPS) ? 0.0f : val;
+	});
+	if (il.l.flags & PRGPU_SKYF_COMPENSATION)
+		il.dist.apply_compensation();
+}
+// NodeUtils::average (shader/NodeUtils.cpp:7-47): the mean over a 32 x 32 grid of texture coordinates visited in Morton order
+Blob env_image_average(const Scene& s, const Scene::InfLight& il, const Blob& wl)
+{
+	auto compact = [](uint32_t x) {
+		x &= 0x55555555u;
+		x = (x | (x >> 1)) & 0x33333333u;
+		x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+		x = (x | (x >> 4)) & 0x00FF00FFu;
+		x = (x | (x >> 8)) & 0x0000FFFFu;
+		return x;
+	};
+	Blob sum = env_image_eval(s, il, wl, 0.0f, 0.0f);
+	for (uint32_t i = 1; i < 1024u; ++i) {
+		const Blob v = env_image_eval(s, il, wl, compact(i) / 32.0f, compact(i >> 1) / 32.0f);
+		for (int k = 0; k < 4; ++k)
+			sum[k] += v[k];
+	}
+	return sum / 1024.0f;
+}
 Blob inf_light_power(const Scene& s, const Scene::InfLight& il, const Blob& wl)
 {
+	if (il.l.kind == PRGPU_LIGHT_ENVIRONMENT && (il.l.flags & PRGPU_ENVF_TEXTURED))
+		return env_image_average(s, il, wl);
 	if (il.l.kind == PRGPU_LIGHT_CIE_SKY)
 		return cie_sky_radiance(s, il, wl, v3(0, 0, 1)); // cie_sky.cpp:80
 	if (il.l.kind == PRGPU_LIGHT_SKY)
@@ -2399,6 +2469,17 @@ Blob inf_light_power(const Scene& s, const Scene::InfLight& il, const Blob& wl)
 // IInfiniteLight::eval for direction `dir` (pointing away from the scene): environment.cpp:53-73, sky.cpp:51-79, sun.cpp:61-77
 void inf_light_eval(const Scene& s, const Scene::InfLight& il, V3 dir, const Blob& wl, bool camera_ray, Blob& radiance, float& direction_pdf_s)
 {
+	if (il.l.kind == PRGPU_LIGHT_ENVIRONMENT && (il.l.flags & PRGPU_ENVF_TEXTURED)) { // environment.cpp:53-73
+		const V3 ld = mat3_mul(il.inv_nm, dir);
+		float u, v;
+		uv_from_direction(ld, u, v);
+		radiance = (camera_ray && il.l.background != INVALID) ? spectrum_eval(s, il.l.background, wl) : env_image_eval(s, il, wl, u, v);
+		if (il.dist.w)
+			direction_pdf_s = il.dist.continuous_pdf(u, v) * env_direction_factor(v);
+		else
+			direction_pdf_s = std::fabs(ld.z) * PR_INV_PI_F;
+		return;
+	}
 	switch (il.l.kind) {
 	case PRGPU_LIGHT_SKY: {
 		const ElevationAzimuth ea = ea_from_direction(mat3_mul(il.inv_nm, dir));
@@ -2444,6 +2525,26 @@ void inf_light_eval(const Scene& s, const Scene::InfLight& il, V3 dir, const Blo
 // IInfiniteLight::sampleDir: distant.cpp:58-77, environment.cpp:75-116 (no distribution), sky.cpp:81-98, sun.cpp:79-88
 void inf_light_sample_dir(const Scene& s, const Scene::InfLight& il, float rnd0, float rnd1, const Blob& wl, V3& outgoing, float& direction_pdf_s, Blob& radiance)
 {
+	if (il.l.kind == PRGPU_LIGHT_ENVIRONMENT && (il.l.flags & PRGPU_ENVF_TEXTURED)) { // environment.cpp:75-101
+		float u, v;
+		V3 lo;
+		if (il.dist.w) {
+			il.dist.sample_continuous(rnd0, rnd1, u, v, direction_pdf_s);
+			float st, ct, sp, cp; // Spherical::cartesian_from_uv: theta = v pi, phi = u 2 pi
+			sincos_rad(v * PR_PI_F, st, ct);
+			sincos_rad(u * 2 * PR_PI_F, sp, cp);
+			lo = v3(st * cp, st * sp, ct);
+			direction_pdf_s *= env_direction_factor(v);
+		} else { // (the radiance is looked up at the random numbers, not at the direction's coordinates: as there)
+			u				= rnd0;
+			v				= rnd1;
+			lo				= cos_hemi(rnd0, rnd1);
+			direction_pdf_s = lo.z * PR_INV_PI_F;
+		}
+		outgoing = mat3_mul(il.nm, lo);
+		radiance = env_image_eval(s, il, wl, u, v);
+		return;
+	}
 	switch (il.l.kind) {
 	case PRGPU_LIGHT_DISTANT:
 		outgoing		= il.outgoing;
@@ -4252,6 +4353,12 @@ int scene_setup(Scene& s, const prgpu_scene_desc* d)
 		}
 		if (il.l.kind == PRGPU_LIGHT_SKY)
 			sky_build_distribution(il);
+		if (il.l.kind == PRGPU_LIGHT_ENVIRONMENT && (il.l.flags & PRGPU_ENVF_TEXTURED)) {
+			const uint64_t need = uint64_t(il.l.azimuth_count) * il.l.elevation_count * 3u;
+			if (il.l.azimuth_count == 0 || il.l.elevation_count == 0 || uint64_t(il.l.table_offset) + need > s.tables.size())
+				return fail("bad environment image");
+			env_build_distribution(s, il);
+		}
 		s.inf_lights.push_back(std::move(il));
 	}
 	setup_camera(s);

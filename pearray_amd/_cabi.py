@@ -20,6 +20,7 @@ PRINCIPLED_PARAMS = ("diffuse_transmission", "specular_transmission", "specular_
                      "sheen_tint", "clearcoat", "clearcoat_gloss")
 ENTITY_MESH, ENTITY_PLANE, ENTITY_SPHERE, ENTITY_QUADRIC = 0, 1, 2, 3
 LIGHT_ENVIRONMENT, LIGHT_DISTANT, LIGHT_SKY, LIGHT_SUN, LIGHT_CIE_SKY = 0, 1, 2, 3, 4
+ENVF_TEXTURED, ENVF_NO_DISTRIBUTION = 16, 32
 SKYF_EXTEND, SKYF_COMPENSATION, SKYF_CLOUDY = 1, 2, 8
 SKY_BANDS = 11
 LPE_MAX, LPE_MAX_STATES = 4, 32

@@ -1387,8 +1387,51 @@ __device__ __forceinline__ Blob cie_sky_radiance(const DevScene& sc, const DevIn
 }
 // IInfiniteLight::eval for a ray that leaves the scene in direction `dir`: EnvironmentLight (environment.cpp:53-73; camera rays see the
 // background), SkyLight (sky.cpp:51-79), SunLight (sun.cpp:61-77).  Delta lights (DISTANT) are never evaluated.
+// textured ENVIRONMENT light (PRGPU_ENVF_TEXTURED): the `radiance` node times ParametricImageNode::eval (loader/shader/ImageNode.cpp:48-73)
+// at the texel under (u, 1 - v) -- closest-texel interpolation, u periodic, v clamped
+__device__ __forceinline__ Blob env_image_eval(const DevScene& sc, const DevInfLight& il, const Blob& wl, float u, float v)
+{
+	const uint32_t W = il.az_count, H = il.el_count;
+	const float fu	 = u - floorf(u);
+	const uint32_t col = min(W - 1u, (uint32_t)(fu * (float)W));
+	const float tv	   = fminf(1.0f, fmaxf(0.0f, 1.0f - v));
+	const uint32_t row = min(H - 1u, (uint32_t)(tv * (float)H));
+	const float* c	   = sc.tables + il.table_offset + 3u * (size_t(row) * W + col);
+	const float p[3]   = { c[0], c[1], c[2] };
+	const Blob base	   = spectrum_eval(sc, il.radiance, wl);
+	return blob4(base.v[0] * upsample(p, wl.v[0]), base.v[1] * upsample(p, wl.v[1]), base.v[2] * upsample(p, wl.v[2]), base.v[3] * upsample(p, wl.v[3]));
+}
+// Spherical::uv_from_normal (base/math/Spherical.h:8-26) through the shared fp32 atan2 / acos: u = phi / (2 pi), v = theta / pi
+__device__ __forceinline__ void uv_from_direction(V3 D, float& u, float& v)
+{
+	const float x = (D.x == 0.0f && D.y == 0.0f) ? 1e-5f : D.x;
+	float phi	  = pr_atan2(D.y, x);
+	phi			  = phi < 0.0f ? phi + 2 * PR_PI_F : phi;
+	const float theta = safe_acos(D.z);
+	u = (phi * PR_INV_PI_F) / 2;
+	v = theta * PR_INV_PI_F;
+}
+// 1 / (2 pi^2 sin(v pi)) (environment.cpp:71-73,85-87)
+__device__ __forceinline__ float env_jacobian(float v)
+{
+	float s, c;
+	pr_sincos_rad(v * PR_PI_F, s, c);
+	const float denom = 2 * PR_PI_F * PR_PI_F * s;
+	return denom <= PR_EPS ? 0.0f : 1.0f / denom;
+}
 __device__ __forceinline__ void inf_light_eval(const DevScene& sc, const DevInfLight& il, V3 dir, const Blob& wl, bool camera_ray, Blob& radiance, float& dir_pdf)
 {
+	if (il.kind == PRGPU_LIGHT_ENVIRONMENT && (il.flags & PRGPU_ENVF_TEXTURED)) { // EnvironmentLight::eval (environment.cpp:53-73)
+		const V3 ld = mat3_mul(il.inv_nm, dir);
+		float u, v;
+		uv_from_direction(ld, u, v);
+		radiance = (camera_ray && il.background != INVALID) ? spectrum_eval(sc, il.background, wl) : env_image_eval(sc, il, wl, u, v);
+		if (il.dist_w)
+			dir_pdf = distribution2d_pdf(sc.sky_cdf + il.dist_offset, il.dist_w, il.dist_h, u, v) * env_jacobian(v);
+		else
+			dir_pdf = fabsf(ld.z) * PR_INV_PI_F;
+		return;
+	}
 	if (il.kind == PRGPU_LIGHT_SKY) {
 		const ElAz ea	  = ea_from_direction(mat3_mul(il.inv_nm, dir));
 		const bool extend = (il.flags & PRGPU_SKYF_EXTEND) != 0;
@@ -1430,6 +1473,24 @@ __device__ __forceinline__ void inf_light_sample(const DevScene& sc, const DevIn
 		L		 = v3(il.outgoing[0], il.outgoing[1], il.outgoing[2]);
 		dir_pdf	 = 1.0f;
 		radiance = spectrum_eval(sc, il.radiance, wl);
+	} else if (il.kind == PRGPU_LIGHT_ENVIRONMENT && (il.flags & PRGPU_ENVF_TEXTURED)) { // EnvironmentLight::sampleDir (environment.cpp:75-101)
+		float u, v;
+		V3 lo;
+		if (il.dist_w) {
+			distribution2d_sample(sc.sky_cdf + il.dist_offset, il.dist_w, il.dist_h, d0, d1, u, v, dir_pdf);
+			float st, ct, sp, cp; // Spherical::cartesian_from_uv: theta = v pi, phi = u 2 pi
+			pr_sincos_rad(v * PR_PI_F, st, ct);
+			pr_sincos_rad(u * 2 * PR_PI_F, sp, cp);
+			lo = v3(st * cp, st * sp, ct);
+			dir_pdf *= env_jacobian(v);
+		} else {
+			u		= d0;
+			v		= d1;
+			lo		= cos_hemi(d0, d1);
+			dir_pdf = lo.z * PR_INV_PI_F;
+		}
+		L		 = mat3_mul(il.nm, lo);
+		radiance = env_image_eval(sc, il, wl, u, v);
 	} else if (il.kind == PRGPU_LIGHT_SKY) {
 		float u, v;
 		distribution2d_sample(sc.sky_cdf + il.dist_offset, il.dist_w, il.dist_h, d0, d1, u, v, dir_pdf);
@@ -2152,152 +2213,6 @@ __device__ __forceinline__ uint32_t ring_take(uint32_t* q, uint32_t cap_mask, ui
 }
 
 
-// ---- four lanes per ray (thin waves: small tile shares) -----------------------------------------------------------------
-// A wave whose lanes hold one ray each spends most of a step's time issuing the ~230 instructions of four slab tests (or ~380 of three
-// triangle tests) for however few rays it holds, and only one KIND of record moves per step.  With few paths per lane -- a rank's share
-// of an 8-GPU frame -- nothing is gained from 64 rays per wave that are not there: the chain of dependent steps of the deepest pixels
-// is what a launch waits for.  In this mode a QUAD of lanes shares a ray (all four hold the same ray state): at an inner node lane k
-// tests child k, at a leaf lane k tests triangle k, the quad votes with DPP (no LDS, no extra memory traffic: the four lanes read
-// the same record), and inner quads and leaf quads both move in every step.  Same tests on the same values, same (t, triangle id)
-// rule: same results.  The stack is the quad's four LDS columns (64 entries).
-constexpr int QP_XOR1 = 0xB1, QP_XOR2 = 0x4E, QP_XOR3 = 0x1B, QP_LANE0 = 0x00; // quad_perm [1,0,3,2], [2,3,0,1], [3,2,1,0], [0,0,0,0]
-template <int CTRL>
-__device__ __forceinline__ uint32_t qperm_u(uint32_t v)
-{
-	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ float qperm_f(float v)
-{
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-constexpr int QUAD_STACK = 4 * STACK_LDS;
-__device__ __forceinline__ uint2* quad_entry(uint2* qbase, int e) { return qbase + (e >> 2) * TRAV_BLOCK + (e & 3); }
-
-// One step of every quad of the wave.  `qbase`: the quad's stack (column of its first lane), `qsp`: its size; returns false on stack overflow.
-template <bool SPH, bool CLS>
-__device__ __forceinline__ bool quad_step(const DevScene& sc, Trav& s, uint2* qbase, int& qsp, bool has_ray, uint32_t ql, uint32_t& n_inner_recs, uint32_t& n_leaf_recs)
-{
-	bool ok				= true;
-	const bool at_inner = has_ray && (s.cur & REC_LEAF_BIT) == 0;
-	const bool at_leaf	= has_ray && s.cur != REC_EMPTY && (s.cur & REC_LEAF_BIT) != 0;
-	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
-	float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
-	float2 tv[5];
-	uint32_t leaf_count = 0, leaf_classes = 0;
-	if (at_inner) {
-		q0 = rec[0];
-		q1 = rec[1];
-		q2 = rec[2];
-		q3 = rec[3];
-	}
-	if (at_leaf) {
-		const float* f = reinterpret_cast<const float*>(rec);
-		if (ql < 3u) {
-			const float2* t2 = reinterpret_cast<const float2*>(f + 10u * ql); // 40 bytes from a multiple of 8
-#pragma unroll
-			for (int i = 0; i < 5; ++i)
-				tv[i] = t2[i];
-		}
-		leaf_count	 = __float_as_uint(f[30]);
-		leaf_classes = __float_as_uint(f[31]);
-	}
-	if (at_inner) {
-		if (ql == 0u)
-			++n_inner_recs;
-		const uint32_t eb = __float_as_uint(q0.w);
-		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
-		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
-		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
-		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
-		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
-		const uint32_t sh8 = 8u * ql;
-		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
-		const float axk = __fmaf_rn((float)((wnx >> sh8) & 0xFFu), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn((float)((wfx >> sh8) & 0xFFu), sx, dx) * s.r.inv_d.x;
-		const float ayk = __fmaf_rn((float)((wny >> sh8) & 0xFFu), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn((float)((wfy >> sh8) & 0xFFu), sy, dy) * s.r.inv_d.y;
-		const float azk = __fmaf_rn((float)((wnz >> sh8) & 0xFFu), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn((float)((wfz >> sh8) & 0xFFu), sz, dz) * s.r.inv_d.z;
-		const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
-		const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
-		const uint32_t c = __float_as_uint(ql == 0u ? q3.x : (ql == 1u ? q3.y : (ql == 2u ? q3.z : q3.w)));
-		const bool h	 = t0 <= t1 * 1.000001f + s.r.eps_t && c != REC_EMPTY; // acceptance rule of box_hit
-		// the quad's vote: how many children are hit, and this one's place among them by entry distance (ties: lower child first)
-		const float tk = h ? t0 : INFINITY;
-		const float ta = qperm_f<QP_XOR1>(tk), tb = qperm_f<QP_XOR2>(tk), tc = qperm_f<QP_XOR3>(tk);
-		const uint32_t ja = ql ^ 1u, jb = ql ^ 2u, jc = ql ^ 3u;
-		const uint32_t rank = ((ta < tk || (ta == tk && ja < ql)) ? 1u : 0u) + ((tb < tk || (tb == tk && jb < ql)) ? 1u : 0u) + ((tc < tk || (tc == tk && jc < ql)) ? 1u : 0u);
-		const uint32_t hh = h ? 1u : 0u;
-		const uint32_t nh = hh + qperm_u<QP_XOR1>(hh) + qperm_u<QP_XOR2>(hh) + qperm_u<QP_XOR3>(hh);
-		if (h && rank >= 1u) { // far-to-near below the nearest, which is visited next
-			const int e = qsp + (int)(nh - 1u - rank);
-			if (e < QUAD_STACK)
-				*quad_entry(qbase, e) = make_uint2(c, __float_as_uint(t0));
-			else
-				ok = false;
-		}
-		uint32_t c0 = (h && rank == 0u) ? c : 0u; // (a child is never unit 0, the root)
-		c0 |= qperm_u<QP_XOR1>(c0);
-		c0 |= qperm_u<QP_XOR2>(c0);
-		s.cur = nh ? c0 : REC_EMPTY;
-		qsp += nh ? (int)nh - 1 : 0;
-	}
-	if (at_leaf) {
-		if (ql == 0u)
-			++n_leaf_recs;
-		float t = INFINITY, u = 0.0f, v = 0.0f;
-		uint32_t tri = INVALID, cls = 0u;
-		if (ql < leaf_count) {
-			const float f[10] = { tv[0].x, tv[0].y, tv[1].x, tv[1].y, tv[2].x, tv[2].y, tv[3].x, tv[3].y, tv[4].x, tv[4].y };
-			const uint32_t prim = __float_as_uint(f[9]);
-			float tt, uu = 0.0f, vv = 0.0f;
-			bool hit;
-			if (SPH && (prim & PRIM_SPHERE_BIT))
-				hit = sphere_hit(s.r, v3(f[0], f[1], f[2]), f[3], s.tmin, s.best.t, tt);
-			else
-				hit = woop(s.r, v3(f[0], f[1], f[2]), v3(f[3], f[4], f[5]), v3(f[6], f[7], f[8]), tt, uu, vv) && tt > s.tmin;
-			if (hit) {
-				t	= tt;
-				u	= uu;
-				v	= vv;
-				tri = prim & ~PRIM_SPHERE_BIT;
-				cls = (leaf_classes >> (8u * ql)) & 0xFFu;
-			}
-		}
-		// the quad's nearest hit by (t, triangle id), in two exchanges
-#define PR_QMIN(CTRL)                                                                   \
-	{                                                                                   \
-		const float ot = qperm_f<CTRL>(t), ou = qperm_f<CTRL>(u), ov = qperm_f<CTRL>(v); \
-		const uint32_t otri = qperm_u<CTRL>(tri), ocls = qperm_u<CTRL>(cls);            \
-		const bool better = ot < t || (ot == t && otri < tri);                          \
-		t = better ? ot : t; u = better ? ou : u; v = better ? ov : v;                  \
-		tri = better ? otri : tri; cls = better ? ocls : cls;                           \
-	}
-		PR_QMIN(QP_XOR1)
-		PR_QMIN(QP_XOR2)
-#undef PR_QMIN
-		if (tri != INVALID) {
-			if (s.any) {
-				if (t <= s.best.t)
-					s.best.tri = tri;
-			} else if (t < s.best.t || (t == s.best.t && tri < s.best.tri)) {
-				s.best = Hit{ t, u, v, tri };
-				if (CLS)
-					s.cls = cls;
-			}
-		}
-		s.cur = REC_EMPTY;
-		if (s.any && s.best.tri != INVALID) // occluded: done
-			qsp = 0;
-	}
-	// next record: the nearest stack entry that can still matter
-	while (has_ray && s.cur == REC_EMPTY && qsp > 0) {
-		--qsp;
-		const uint2 e = *quad_entry(qbase, qsp);
-		if (still_reachable(s.r, __uint_as_float(e.y), s.best.t))
-			s.cur = e.x;
-	}
-	return ok;
-}
-
 struct PersistentArgs {
 	const uint32_t* owned; // Morton-ordered list of the pixels this device renders
 	uint32_t n_owned;
@@ -2315,7 +2230,6 @@ struct PersistentArgs {
 	uint32_t shader_wave; // 1: the block's last wave only shades (any batch size, never holds rays); the others trace and help
 	uint32_t shade_help;  // ... with full batches once this many vertices wait
 	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
-	uint32_t quad;		  // 1: four lanes per ray (quad_step): small tile shares, where a launch waits for chains of dependent steps, not for lanes
 	int fin_batch;		  // finished rays of a wave are written out once this many lanes hold one (or the wave is under-occupied); 1: at once
 	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
 	// resident pixels (see path_persistent): per block `bl_cap` list entries (pixel) and state words (samples done | samples handed out << 16),
@@ -2411,10 +2325,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	s.any			  = false;
 	bool has_ray	  = false;
 	uint32_t my_entry = 0;
-	const bool quad	  = a.quad != 0u;							  // wave-uniform (launch-uniform)
-	const uint32_t ql = lane & 3u;								  // quad mode: the child / triangle this lane tests
-	uint2* const qbase = sh.stack + (threadIdx.x & ~3u);		  // ... and the quad's stack
-	int qsp			  = 0;
+
 	uint32_t spins	  = 0;
 	unsigned long long t_idle_since = 0;
 	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, wleaf = 0, sbatches = 0, slanes = 0;
@@ -2678,21 +2589,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		if (!shader && idle != 0ull && n_queued > 0u && (n_queued >= a.refill_min || first_tracer)) {
 			const unsigned long long t0r = COUNT ? wall_clock64() : 0ull;
 			uint32_t first;
-			// (quad mode: a ray goes to an idle QUAD; its first lane takes the entry and hands it to the other three)
-			const unsigned long long takers = quad ? __ballot(!has_ray && ql == 0u) : idle;
-			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(takers), first);
-			const uint32_t r = __popcll(takers & ((1ull << lane) - 1ull));
-			bool got		 = !has_ray && (!quad || ql == 0u) && r < n;
-			uint32_t taken	 = 0;
-			if (got)
-				taken = ring_take(sh.q_ray, RAY_MASK, first + r);
-			if (quad) {
-				taken = qperm_u<QP_LANE0>(taken);
-				got	  = qperm_u<QP_LANE0>(got ? 1u : 0u) != 0u;
-			}
-			if (got) {
-				my_entry			= taken;
-				qsp					= 0;
+			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(idle), first);
+			const uint32_t r = __popcll(idle & ((1ull << lane) - 1ull));
+			if (!has_ray && r < n) {
+				my_entry			= ring_take(sh.q_ray, RAY_MASK, first + r);
 				const uint32_t slot = slot0 + (my_entry & ~PP_ANY);
 				const bool any		= (my_entry & PP_ANY) != 0;
 				const float4 ro = any ? ps.sh_o[slot] : ps.ray_o[slot], rd = any ? ps.sh_d[slot] : ps.ray_d[slot];
@@ -2745,23 +2645,6 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		}
 		spins = 0;
 		for (;;) {
-			if (quad) { // four lanes per ray: every quad moves, whatever kind of record it is at
-				if (COUNT && lane == 0)
-					++witers;
-				const unsigned long long t0q = COUNT ? wall_clock64() : 0ull;
-				uint32_t ni = 0, nl = 0;
-				if (!quad_step<(FEATS & FEAT_SPHERES) != 0, (NQ > 1)>(sc, s, qbase, qsp, has_ray, ql, ni, nl)) { // stack overflow: loud, not wrong
-					__hip_atomic_store(&sh.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-					atomicExch(a.error, 2u);
-				}
-				if (COUNT) {
-					cn_c += s.any ? 0 : ni;
-					cn_a += s.any ? ni : 0;
-					cl_c += s.any ? 0 : nl;
-					cl_a += s.any ? nl : 0;
-					t_inner += wall_clock64() - t0q;
-				}
-			} else {
 			// one kind of record per wave step (see trace_persistent)
 			const bool at_leaf	= has_ray && s.cur != REC_EMPTY && (s.cur & REC_LEAF_BIT) != 0; // (a finished ray waits for its write-out, below)
 			const bool at_inner = has_ray && (s.cur & REC_LEAF_BIT) == 0;
@@ -2819,7 +2702,6 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				else
 					t_leaf += wall_clock64() - t0s;
 			}
-			} // !quad
 			// Finished rays are written out in batches: the write-out releases the hit to the block (it waits for the wave's global stores,
 			// about a microsecond during which none of the wave's rays moves), and a finished lane has nothing to do anyway until the wave
 			// refills -- so wait until `fin_batch` lanes are done, or until the wave is short of running rays and wants new ones.
@@ -2836,9 +2718,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				bool last	   = false;
 				uint32_t entry = 0;
 				int qcls	   = 0;
-				if (fin && quad && ql != 0u)
-					has_ray = false; // (the quad's first lane writes the result out)
-				else if (fin) {
+				if (fin) {
 					const uint32_t slot_l = my_entry & ~PP_ANY;
 					const uint32_t slot	  = slot0 + slot_l;
 					// A shadow ray only reports whether it reached the light: one flag in the slot's pending word.  Its fragment (direct.cpp:329-351)
@@ -3448,10 +3328,6 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.leaf_bias		  = getenv("PRGPU_PP_LEAF_BIAS") ? std::max(1, atoi(getenv("PRGPU_PP_LEAF_BIAS"))) : 100;
 	a.gstats		  = gstats;
 	a.direct_map	  = all_in_flight ? 1u : 0u;
-	// four lanes per ray when the launch has few paths per lane (every owned pixel in flight at once and fewer than 1.6 per lane);
-	// PRGPU_PP_QUAD=0 / 1 forces it off / on
-	a.quad			  = getenv("PRGPU_PP_QUAD") ? (atoi(getenv("PRGPU_PP_QUAD")) != 0 ? 1u : 0u)
-										  : (all_in_flight && uint64_t(n_owned) * 10u < uint64_t(g.n_blocks) * PP_BLOCK * 16u ? 1u : 0u);
 	a.fin_batch		  = getenv("PRGPU_PP_FIN_BATCH") ? std::min(64, std::max(1, atoi(getenv("PRGPU_PP_FIN_BATCH")))) : 16;
 	// resident pixels: more pixels than slots and more than one sample per pixel in this launch (PRGPU_PP_RESIDENT=0: a pixel keeps its slot)
 	const bool resident_ok = !(getenv("PRGPU_PP_RESIDENT") && atoi(getenv("PRGPU_PP_RESIDENT")) == 0);

@@ -239,8 +239,47 @@ V4 cie_sky_zenith(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl)
 }
 // IInfiniteLight::power: environment / distant average their node (environment.cpp, distant.cpp:93), the sky returns its zenith
 // radiance (sky.cpp:113: ElevationAzimuth::fromDirection((0, 0, 1)) = {pi/2, 0}), the sun looks its spectrum up (sun.cpp:106-112,222-228)
+// textured ENVIRONMENT (PRGPU_ENVF_TEXTURED): `radiance` node x ParametricImageNode::eval (src/loader/shader/ImageNode.cpp:48-73) at the
+// texel under (u, 1 - v): closest-texel interpolation, u periodic, v clamped -- the arithmetic of env_image_eval on the device
+V4 env_image_eval(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl, float u, float v)
+{
+	const uint32_t W = l.azimuth_count, H = l.elevation_count;
+	const float fu	 = u - std::floor(u);
+	const uint32_t col = std::min(W - 1u, (uint32_t)(fu * (float)W));
+	const float tv	   = std::min(1.0f, std::max(0.0f, 1.0f - v));
+	const uint32_t row = std::min(H - 1u, (uint32_t)(tv * (float)H));
+	const float* c	   = d->spectral_tables + l.table_offset + 3u * (size_t(row) * W + col);
+	const V4 base	   = eval_spectrum(d, l.radiance, wl);
+	V4 r;
+	for (int k = 0; k < 4; ++k)
+		r.v[k] = base.v[k] * sigmoid_poly(c, wl.v[k]);
+	return r;
+}
+// NodeUtils::average over the 32 x 32 UV grid in Morton order (shader/NodeUtils.cpp:7-47, math/Bits.h morton_2_xy)
+V4 env_image_average(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl)
+{
+	auto compact = [](uint32_t x) {
+		x &= 0x55555555u;
+		x = (x | (x >> 1)) & 0x33333333u;
+		x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+		x = (x | (x >> 4)) & 0x00FF00FFu;
+		x = (x | (x >> 8)) & 0x0000FFFFu;
+		return x;
+	};
+	V4 sum{ { 0, 0, 0, 0 } };
+	for (uint32_t i = 0; i < 1024u; ++i) {
+		const V4 v = env_image_eval(d, l, wl, compact(i) / 32.0f, compact(i >> 1) / 32.0f);
+		for (int k = 0; k < 4; ++k)
+			sum.v[k] = i == 0 ? v.v[k] : sum.v[k] + v.v[k];
+	}
+	for (int k = 0; k < 4; ++k)
+		sum.v[k] /= 1024.0f;
+	return sum;
+}
 V4 inf_light_power(const prgpu_scene_desc* d, const prgpu_light& l, const V4& wl)
 {
+	if (l.kind == PRGPU_LIGHT_ENVIRONMENT && (l.flags & PRGPU_ENVF_TEXTURED))
+		return env_image_average(d, l, wl);
 	if (l.kind == PRGPU_LIGHT_SKY)
 		return sky_radiance(d, l, wl, 0.5f * 3.14159265358979323846f - 0.0f, 0.0f);
 	if (l.kind == PRGPU_LIGHT_CIE_SKY)
@@ -614,6 +653,53 @@ void infinite_light_tables(const prgpu_scene_desc* d, HostTables& t)
 			}
 			L.cos_theta = src.cos_theta;
 			L.cone_pdf	= 0.15915494309189533577f / (1 - src.cos_theta); // Sampling::uniform_cone_pdf (Sampling.h:110-114)
+		}
+		if (src.kind == PRGPU_LIGHT_ENVIRONMENT && (src.flags & PRGPU_ENVF_TEXTURED)) {
+			L.table_offset = src.table_offset;
+			L.az_count	   = src.azimuth_count;
+			L.el_count	   = src.elevation_count;
+			// EnvironmentLightFactory::create (environment.cpp:176-199): a distribution over sin(theta) x the brightest of four preset
+			// wavelengths at the texel centres, when the image has more than one row and column and `distribution` is not switched off
+			if (!(src.flags & PRGPU_ENVF_NO_DISTRIBUTION) && src.azimuth_count > 1 && src.elevation_count > 1) {
+				const uint32_t W = src.azimuth_count, H = src.elevation_count;
+				L.dist_offset = (uint32_t)t.sky_cdf.size();
+				L.dist_w	  = W;
+				L.dist_h	  = H;
+				const V4 probe{ { 560.0f, 540.0f, 400.0f, 600.0f } };
+				std::vector<std::vector<float>> cond(H);
+				std::vector<float> integrals(H, 0.0f), row(W), marginal;
+				for (uint32_t y = 0; y < H; ++y) {
+					const float v		 = (y + 0.5f) / (float)H;
+					const float sinTheta = std::sin(3.14159265358979323846f * v);
+					for (uint32_t x = 0; x < W; ++x) {
+						const V4 r		= env_image_eval(d, src, probe, (x + 0.5f) / (float)W, v);
+						const float val = sinTheta * std::max(std::max(r.v[0], r.v[1]), std::max(r.v[2], r.v[3]));
+						row[x]			= val <= EPS_F ? 0.0f : val;
+					}
+					make_cdf(row, cond[y], &integrals[y]);
+				}
+				if (src.flags & PRGPU_SKYF_COMPENSATION) { // Distribution2D::applyCompensation (Distribution2D.cpp:38-76)
+					std::vector<float> avgs(H, 0.0f);
+					for (uint32_t y = 0; y < H; ++y) {
+						for (uint32_t x = 0; x < W; ++x)
+							avgs[y] += cond[y][x + 1] - cond[y][x];
+						avgs[y] /= W;
+					}
+					float single_avg = 0;
+					for (float f : avgs)
+						single_avg += f;
+					single_avg /= H;
+					for (uint32_t y = 0; y < H; ++y) {
+						for (uint32_t x = 0; x < W; ++x)
+							row[x] = std::max(0.0f, (cond[y][x + 1] - cond[y][x]) - single_avg);
+						make_cdf(row, cond[y], &integrals[y]);
+					}
+				}
+				make_cdf(integrals, marginal, nullptr);
+				t.sky_cdf.insert(t.sky_cdf.end(), marginal.begin(), marginal.end());
+				for (uint32_t y = 0; y < H; ++y)
+					t.sky_cdf.insert(t.sky_cdf.end(), cond[y].begin(), cond[y].end());
+			}
 		}
 		if (src.kind == PRGPU_LIGHT_SKY) { // SkyLight::buildDistribution (sky.cpp:127-159)
 			const bool extend = (src.flags & PRGPU_SKYF_EXTEND) != 0;
@@ -1068,6 +1154,18 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 		}
 		if (l.radiance >= d->n_spectra || (l.background != PRGPU_INVALID_ID && l.background >= d->n_spectra))
 			return bad("infinite light spectrum index out of range");
+		if (l.kind == PRGPU_LIGHT_ENVIRONMENT && (l.flags & PRGPU_ENVF_TEXTURED)) {
+			if (l.azimuth_count == 0 || l.elevation_count == 0 || l.azimuth_count > 16384 || l.elevation_count > 16384)
+				return bad("textured environment light: image size must be 1..16384 per axis");
+			const uint64_t need = uint64_t(l.azimuth_count) * l.elevation_count * 3u;
+			if (!d->spectral_tables || uint64_t(l.table_offset) + need > d->n_spectral_table_values)
+				return bad("textured environment light: image outside spectral_tables");
+			for (uint64_t k = 0; k < need; ++k)
+				if (!std::isfinite(d->spectral_tables[l.table_offset + k]))
+					return bad("textured environment light: coefficients must be finite");
+		} else if (l.kind != PRGPU_LIGHT_ENVIRONMENT && (l.flags & (PRGPU_ENVF_TEXTURED | PRGPU_ENVF_NO_DISTRIBUTION))) {
+			return bad("PRGPU_ENVF_* flags on a light that is not an environment light");
+		}
 		if (l.kind == PRGPU_LIGHT_SUN) {
 			if (d->spectra[l.radiance].kind != PRGPU_SPEC_TABLE)
 				return bad("sun light: radiance must be a TABLE node (the 64 samples of 360-760 nm, sun.cpp:21-23)");

@@ -998,13 +998,9 @@ int check_watchdog(prgpu_scene* s)
 	uint32_t flag = 0;
 	HIP_TRY(hipMemcpy(&flag, s->pp_error, sizeof(flag), hipMemcpyDeviceToHost));
 	if (flag) { // report once, then keep the scene unusable: the frame is incomplete and the pixel RNG streams have moved on
-		const bool overflow = flag == 2u;
 		flag = 0;
 		HIP_TRY(hipMemcpy(s->pp_error, &flag, sizeof(flag), hipMemcpyHostToDevice));
 		s->poisoned = true;
-		if (overflow)
-			return fail(PRGPU_EDEVICE, "persistent path kernel: a traversal stack of the four-lanes-per-ray mode overflowed (more than 64 pending nodes: a degenerate tree); "
-									   "render with PRGPU_PP_QUAD=0; the scene object must be recreated");
 		return fail(PRGPU_EDEVICE, "persistent path kernel: a wave timed out waiting for queued work (internal error); the scene object must be recreated");
 	}
 	return PRGPU_OK;

@@ -236,9 +236,33 @@ class SceneBuilder:
         self.lights.append(l)
         return len(self.lights) - 1
 
-    def environment_light(self, radiance, background=None, transform=IDENTITY):
-        """(light :type 'env' :radiance r [:background b]), environment.cpp:152-205 (untextured)"""
-        return self._light(abi.LIGHT_ENVIRONMENT, radiance, background, (0, 0, 1), transform)
+    def environment_light(self, radiance, background=None, transform=IDENTITY, image=None, distribution=True, compensation=False):
+        """(light :type 'env' :radiance r [:background b]), environment.cpp:152-205.  `image`: float32 [height, width, 3] Jakob-Hanika
+        coefficients (a latitude / longitude map: row 0 = the zenith, +z) that multiply `radiance` texel by texel -- the textured
+        environment light; with more than one row and column it is importance-sampled unless `distribution` is False."""
+        k = self._light(abi.LIGHT_ENVIRONMENT, radiance, background, (0, 0, 1), transform)
+        if image is not None:
+            image = np.ascontiguousarray(image, dtype=np.float32)
+            assert image.ndim == 3 and image.shape[2] == 3
+            l = self.lights[k]
+            l.flags = abi.ENVF_TEXTURED | (0 if distribution else abi.ENVF_NO_DISTRIBUTION) | (abi.SKYF_COMPENSATION if compensation else 0)
+            l.table_offset = len(self.tables)
+            l.elevation_count, l.azimuth_count = image.shape[0], image.shape[1]
+            self.tables.extend(image.reshape(-1).tolist())
+        return k
+
+    def rgb_image_to_coefficients(self, rgb):
+        """An RGB image (float [H, W, 3], linear sRGB in [0, 1]) as the coefficient image a textured light takes (prgpu_rgb_to_coeffs per
+        distinct colour: NonParametricImageNode converts every lookup the same way, ImageNode.cpp:150-175)."""
+        rgb = np.asarray(rgb, dtype=np.float32)
+        out = np.zeros_like(rgb)
+        cache = {}
+        for idx in np.ndindex(rgb.shape[:2]):
+            key = tuple(float(c) for c in rgb[idx])
+            if key not in cache:
+                cache[key] = rgb_to_coeffs(key)
+            out[idx] = cache[key]
+        return out
 
     def distant_light(self, irradiance, direction=(0, 0, 1), transform=IDENTITY):
         """(light :type 'distant' :direction d :irradiance e), distant.cpp:112-121"""

@@ -319,44 +319,6 @@ def test_persistent_kernel_tiny_and_ragged_films(monkeypatch, w, h):
     assert_parity(g, o, exact=True)
 
 
-@pytest.mark.parametrize("what", ["soup", "glass", "rough", "c5", "spheres", "quadrics", "share"])
-def test_four_lanes_per_ray_traversal_is_bit_exact(monkeypatch, what):
-    """PRGPU_PP_QUAD=1: the persistent kernel's traversal for thin waves -- a quad of lanes per ray, one child / triangle per lane, DPP
-    votes -- on every kind of leaf content and material class; automatically chosen for a small tile share (`share`)."""
-    monkeypatch.setenv("PRGPU_MODE", "persistent")
-    if what != "share":
-        monkeypatch.setenv("PRGPU_PP_QUAD", "1")
-    tiles = None
-    if what == "soup":
-        sc = scene.cornell_soup(160, 120, spp=5, n_triangles=40_000)
-    elif what == "glass":
-        sc = scene.cornell_glassy(96, 96, spp=5, ior="bk7")
-    elif what == "rough":
-        sc = scene.cornell_rough(96, 80, spp=5)
-    elif what == "c5":
-        sc = _complex_c5(128, 72, 4)
-    elif what == "spheres":
-        b = scene.SceneBuilder(80, 60)
-        b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, 4
-        T = np.array([[1, 0, 0, 0], [0, 0.8, 0.6, 2.0], [0, -0.6, 0.8, 3.2], [0, 0, 0, 1]], dtype=np.float32)
-        b.set_camera(T, width=0.9, height=0.675, near=0.01, far=100.0, local_direction=(0, 0, -1), local_up=(0, 1, 0), local_right=(1, 0, 0))
-        white = b.lambert(b.refl(0.7, 0.7, 0.7))
-        b.add_plane(white, x_axis=(1, 0, 0), y_axis=(0, 0, -1), width=8, height=8, centering=True)
-        for m, r, pos in ((white, 0.5, (-1.2, 0.5, 0.0)), (b.dielectric(b.lookup_index("bk7")), 0.6, (0.0, 0.6, 0.4)), (b.conductor(), 0.6, (1.3, 0.6, -0.2))):
-            M = np.eye(4, dtype=np.float32); M[:3, 3] = pos
-            b.add_sphere(m, radius=r, transform=M)
-        b.environment_light(b.smul(b.illuminant_d65(), b.illum(0.3, 0.35, 0.45)))
-        sc = b.build()
-    elif what == "quadrics":
-        import test_quadrics
-        sc = scene.PrcScene(source=test_quadrics.QUADRIC_SCENE % (72, 48, 4))
-    else:
-        sc = scene.cornell_soup(640, 360, spp=4, n_triangles=100_000)
-        tiles = tiling.tiles_for_rank(640, 360, 3, 8, tile=16)
-    g, o = render_both(sc, iters=4, tiles=tiles)
-    assert_parity(g, o, exact=True)
-
-
 def test_sorted_ray_lists_of_the_lockstep_pipeline_do_not_change_results(monkeypatch):
     """PRGPU_SORT_RAYS=1 (experiment, profiles/r03_global_sort.json): every path depth's ray list radix-sorted by origin cell and direction octant."""
     sc = scene.cornell_soup(192, 108, spp=4, n_triangles=20_000)
@@ -375,8 +337,7 @@ def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypat
                 dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_PARTIAL_ACT="4"),
                 dict(PRGPU_PP_BOTH="65", PRGPU_PP_REFILL_MIN="16"), dict(PRGPU_PP_BOTH="20"), dict(PRGPU_PP_FIN_BATCH="1"), dict(PRGPU_PP_FIN_BATCH="48"), dict(PRGPU_PP_SHADER="1"),
                 dict(PRGPU_PP_SHADER="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"), dict(PRGPU_PP_RESIDENT="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"),
-                dict(PRGPU_PP_LEAF_BIAS="160"), dict(PRGPU_PP_QUAD="1"), dict(PRGPU_PP_QUAD="1", PRGPU_PP_SHADER="1", PRGPU_PP_FIN_BATCH="1"),
-                dict(PRGPU_PP_QUAD="0", PRGPU_PP_SLOTS="256")):
+                dict(PRGPU_PP_LEAF_BIAS="160")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         out = _render_mode(monkeypatch, "persistent", sc, [4])
