@@ -454,8 +454,8 @@ int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance); /* ei
  * LPE_Parser.cpp / LPE_RegState.h: C first, then D S E L B R T . <T,E>, groups ( ), unions [ ], and * + ? {n} {n,m}.  Labelled tokens (<T,E,"label">) are
  * parsed and match nothing: a labelled token only matches path tokens carrying that label (LPE_Automaton.cpp:92-110) and the `direct`
  * integrator builds all its tokens with label 0.  Expressions that need more than PRGPU_LPE_MAX_STATES automaton states are
- * PRGPU_EUNSUPPORTED.  Enable before the first iteration; needs a single-tap pixel filter and selects the persistent
- * pipeline.  prgpu_lpe_check only parses (0 = valid). */
+ * PRGPU_EUNSUPPORTED.  Enable before the first iteration; selects the persistent pipeline (with a multi-tap pixel filter the planes
+ * go through the same ring of iteration planes and tap gathering as the main one).  prgpu_lpe_check only parses (0 = valid). */
 #define PRGPU_LPE_MAX 4
 #define PRGPU_LPE_MAX_STATES 32
 int prgpu_lpe_check(const char* expression);

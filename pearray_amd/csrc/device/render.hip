@@ -603,11 +603,11 @@ __device__ __forceinline__ void apply_fragment(const PathState& ps, uint32_t pix
 		ps.iter_xyz[entry + 1] += xyz[1];
 		ps.iter_xyz[entry + 2] += xyz[2];
 		for (uint32_t k = 0; lpe_mask != 0u && k < PRGPU_LPE_MAX; ++k)
-			if (lpe_mask & (1u << k)) {
+			if (lpe_mask & (1u << k)) { // (the expression's planes are laid out like the main ones: `entry` addresses the sample's plane of a ring)
 				float* plane = ps.lpe->iter[k];
-				plane[3 * pixel + 0] += xyz[0];
-				plane[3 * pixel + 1] += xyz[1];
-				plane[3 * pixel + 2] += xyz[2];
+				plane[entry + 0] += xyz[0];
+				plane[entry + 1] += xyz[1];
+				plane[entry + 2] += xyz[2];
 			}
 	}
 }
@@ -864,11 +864,12 @@ __device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState&
 	if (with_lpe && ps.lpe) { // the path starts with its camera token (direct.cpp:67)
 		const DevLpe& L	   = *ps.lpe;
 		L.state[slot]	   = lpe_step(ps.lpe, 0u, LPE_SYM_CAMERA);
+		const size_t lentry = (ps.plane_stride ? size_t(iter - ps.iter_base) * ps.plane_stride : size_t(0)) + size_t(3) * pixel;
 		for (uint32_t k = 0; k < L.n; ++k) {
-			float* plane		 = L.iter[k];
-			plane[3 * pixel + 0] = 0.0f;
-			plane[3 * pixel + 1] = 0.0f;
-			plane[3 * pixel + 2] = 0.0f;
+			float* plane	  = L.iter[k];
+			plane[lentry + 0] = 0.0f;
+			plane[lentry + 1] = 0.0f;
+			plane[lentry + 2] = 0.0f;
 		}
 	}
 	{

@@ -265,6 +265,15 @@ int prgpu_outputs_save(prgpu_scene* s, const prgpu_output_channel* ch, uint32_t 
 				rc = prgpu_download_aov(s, c.variable, a.data());
 				if (rc != PRGPU_OK)
 					return rc;
+				// A shading-point channel with a light path expression (BLEND_*_LPE, LocalFrameOutputDevice.cpp:230-249,285-301) takes the
+				// entries whose path matches.  Shading points are pushed at the FIRST vertex only, with the path as it stands there: the
+				// camera token alone (direct.cpp:67,86-87) -- so the channel is the plain one if the expression accepts "C", and empty otherwise.
+				const std::string aov_expr(c.lpe, strnlen(c.lpe, sizeof(c.lpe)));
+				if (!aov_expr.empty()) {
+					const uint8_t camera_token = 0u * 3u + 2u;
+					if (prgpu_lpe_match(aov_expr.c_str(), &camera_token, 1) != 1)
+						std::fill(a.begin(), a.end(), 0.0f);
+				}
 				static const char* suffix[3] = { ".x", ".y", ".z" };
 				for (uint32_t k = 0; k < nc; ++k) {
 					planes.emplace_back(np);

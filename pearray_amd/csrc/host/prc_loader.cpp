@@ -876,11 +876,13 @@ struct Loader {
 			// the colour channel keeps an empty name (R, G, B); every other channel is named after its variable
 			std::string name = (found->kind == PRGPU_CHANNEL_SPECTRAL && found->variable == PRGPU_SPECTRAL_OUTPUT) ? std::string() : canonical(found->kind, found->variable);
 			if (!lpe.empty()) {
-				if (!(found->kind == PRGPU_CHANNEL_SPECTRAL && found->variable == PRGPU_SPECTRAL_OUTPUT)) {
-					warn(where(c) + ": light path expressions are provided for colour channels only (channel skipped)");
+				// colour channels (fragments whose path matches, LocalFrameOutputDevice.cpp:99-113) and shading-point channels (entries
+				// whose path matches, :230-249,285-301); raw variance planes and counters have no such variant there
+				if (!((found->kind == PRGPU_CHANNEL_SPECTRAL && found->variable == PRGPU_SPECTRAL_OUTPUT) || found->kind == PRGPU_CHANNEL_3D || found->kind == PRGPU_CHANNEL_1D)) {
+					warn(where(c) + ": light path expressions are provided for colour and shading-point channels only (channel skipped)");
 					continue;
 				}
-				name += "[" + lpe + "]"; // OutputSpecification.cpp:323-324
+				name += "[" + lpe + "]"; // OutputSpecification.cpp:323-324,335-336,349-350
 				std::strncpy(ch.lpe, lpe.c_str(), sizeof(ch.lpe) - 1);
 			}
 			if (name.size() >= sizeof(ch.name)) {

@@ -895,6 +895,19 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 				prd::launch_resolve(s->sc, pr, i, s->stream);
 				s->time_end(s->stream);
 			}
+			if (s->ps.lpe) { // the light path expressions' planes resolve like the main one (LocalFrameOutputDevice.cpp:99-113: same weights)
+				prd::PathState pl  = s->ps;
+				pl.online_mean	   = nullptr; // (the estimator follows the main plane only)
+				pl.online_variance = nullptr;
+				pl.lpe			   = nullptr;
+				for (uint32_t k = 0; k < s->lpe_host.n; ++k) {
+					pl.out_xyz = s->lpe_host.out[k];
+					for (uint32_t i = b; i < e; ++i) {
+						pl.iter_xyz = s->lpe_host.iter[k] + size_t(i - b) * ps.plane_stride;
+						prd::launch_resolve(s->sc, pl, i, s->stream);
+					}
+				}
+			}
 			HIP_TRY(hipGetLastError());
 		}
 		b = e;
@@ -1701,8 +1714,6 @@ int prgpu_enable_lpe(prgpu_scene* s, uint32_t n, const char* const* expressions)
 		return fail(PRGPU_EINVAL, "light path expressions are already enabled");
 	if (!n)
 		return PRGPU_OK;
-	if (!s->sc.single_tap)
-		return fail(PRGPU_EUNSUPPORTED, "light path expressions need a single-tap pixel filter (block or radius 0)");
 	HIP_TRY(hipSetDevice(s->device));
 	prd::DevLpe host;
 	std::memset(&host, 0, sizeof(host));
@@ -1724,7 +1735,7 @@ int prgpu_enable_lpe(prgpu_scene* s, uint32_t n, const char* const* expressions)
 	const size_t ns = size_t(s->n_pixels) + prd::persistent_slot_padding();
 	int rc			= s->alloc(host.state, ns, true);
 	for (uint32_t k = 0; k < n && rc == PRGPU_OK; ++k) {
-		rc = s->alloc(host.iter[k], size_t(s->n_pixels) * 3, true);
+		rc = s->alloc(host.iter[k], size_t(s->n_pixels) * 3 * s->pp_planes, true); // multi-tap pixel filter: a ring of planes like the main one
 		if (rc == PRGPU_OK)
 			rc = s->alloc(host.out[k], size_t(s->n_pixels) * 3, true);
 	}

@@ -114,7 +114,7 @@ def test_lpe_planes_partition_the_image_in_the_checker():
     assert 0 < lamp.sum() < lamp.size * 0.2          # the lamp is seen directly by few pixels only
 
 
-def test_lpe_needs_a_single_tap_filter_and_no_labels_in_the_library():
+def test_lpe_argument_checks_in_the_library():
     lib = abi.load()
     arr = (C.c_char_p * 1)(b"CD*L")
     assert lib.prgpu_enable_lpe(None, 1, arr) == -1

@@ -129,24 +129,26 @@ def test_output_blocks_are_parsed_like_the_reference():
         (channel :type 'color' :color 'srgb') (channel :type 'n') (channel :type 'ng') (channel :type 'feedback')
         (channel :type 'color' :color 'srgb' :lpe 'CS*DL') (channel :type 'uv') (channel :type 'color' :lpe 'C((')
         (channel :type 'n' :lpe 'CDL') (channel :type 'color' :color 'xyz' :lpe 'C<TD"glass">*L'))
-      (output :name 'extra' (channel :type 'RGB' :color 'XYZ') (channel :type 'var') (channel :type 'd') (channel :type 'samples') (channel :type 'nope'))
+      (output :name 'extra' (channel :type 'RGB' :color 'XYZ') (channel :type 'var') (channel :type 'd') (channel :type 'samples') (channel :type 'nope')
+        (channel :type 'feedback' :lpe 'CDL'))
       (output (channel :type 'color')))"""
     s = scene.PrcScene(source=src)
     ch, n = s.outputs()
     got = [(ch[i].file, ch[i].kind, ch[i].variable, ch[i].tone, ch[i].name.decode()) for i in range(n)]
-    assert [ch[i].lpe.decode() for i in range(n)] == ["", "", "", "", "CS*DL", "", 'C<TD"glass">*L'] + [""] * 4
+    assert [ch[i].lpe.decode() for i in range(n)] == ["", "", "", "", "CS*DL", "", "CDL", 'C<TD"glass">*L'] + [""] * 4
     A = abi.AOV_NAMES.index
     assert got == [(0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, ""), (0, abi.CHANNEL_3D, A("normal"), 0, "normal"), (0, abi.CHANNEL_3D, A("normal_g"), 0, "normal_geometric"),
                    (0, abi.CHANNEL_COUNTER, 1, 0, "feedback"),
                    (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, "[CS*DL]"),     # OutputSpecification.cpp:323-324
                    (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_SRGB, ""),            # an invalid expression is dropped, the channel stays (:299-302)
+                   (0, abi.CHANNEL_3D, A("normal"), 0, "normal[CDL]"),        # a shading-point channel with an expression (:335-336)
                    (0, abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, '[C<TD"glass">*L]'), # a labelled token is legal (and matches nothing on this path)
                    (1, abi.CHANNEL_SPECTRAL, 0, abi.TONE_XYZ, ""), (1, abi.CHANNEL_SPECTRAL, 2, 0, "variance"), (1, abi.CHANNEL_1D, A("depth"), 0, "depth"),
                    (1, abi.CHANNEL_COUNTER, 0, 0, "sample_count")]
     lib = abi.load()
     assert lib.prgpu_prc_output_name(s._h, 0) == b"image" and lib.prgpu_prc_output_name(s._h, 1) == b"extra" and lib.prgpu_prc_output_name(s._h, 2) is None
     w = "\n".join(s.warnings)
-    assert "invalid or unsupported light path expression 'C(('" in w and "colour channels only" in w and "'uv' AOV" in w and "unknown channel type 'nope'" in w and "no name given" in w
+    assert "invalid or unsupported light path expression 'C(('" in w and "colour and shading-point channels only" in w and "'uv' AOV" in w and "unknown channel type 'nope'" in w and "no name given" in w
 
 
 @pytest.mark.gpu
@@ -183,7 +185,8 @@ def test_output_blocks_end_to_end(tmp_path):
       (entity :name 'floor' :type 'mesh' :mesh 'quad' :materials 'white' :scale 2)
       (entity :name 'lamp' :type 'mesh' :mesh 'quad' :materials 'white' :emission 'lamp' :rotation (euler 180 0 0) :position [0,2,0] :scale 0.3)
       (output :name 'image' (channel :type 'color' :color 'srgb') (channel :type 'n') (channel :type 'feedback') (channel :type 'depth') (channel :type 'variance')
-        (channel :type 'color' :color 'xyz' :lpe 'C.*L') (channel :type 'color' :color 'srgb' :lpe 'CDE') (channel :type 'color' :color 'xyz' :lpe 'CE'))
+        (channel :type 'color' :color 'xyz' :lpe 'C.*L') (channel :type 'color' :color 'srgb' :lpe 'CDE') (channel :type 'color' :color 'xyz' :lpe 'CE')
+        (channel :type 'ng' :lpe 'C.*') (channel :type 'p' :lpe 'CDL'))
       (output :name 'direct' (channel :type 'color' :color 'xyz' :lpe 'CDE')))"""
     s = scene.PrcScene(source=src)
     g = backend.RenderContext(s)
@@ -193,7 +196,10 @@ def test_output_blocks_end_to_end(tmp_path):
     assert [os.path.basename(p) for p in paths] == ["image.exr", "direct.exr"]
     img = read_exr_uncompressed(paths[0])
     lpe_names = ["[%s].%s" % (e, c) for e in ("C.*L", "CDE", "CE") for c in "RGB"]
-    assert sorted(img) == sorted(["R", "G", "B", "variance.R", "variance.G", "variance.B", "normal.x", "normal.y", "normal.z", "depth", "feedback"] + lpe_names)
+    aov_lpe = ["normal_geometric[C.*].%s" % c for c in "xyz"] + ["position[CDL].%s" % c for c in "xyz"]
+    assert sorted(img) == sorted(["R", "G", "B", "variance.R", "variance.G", "variance.B", "normal.x", "normal.y", "normal.z", "depth", "feedback"] + lpe_names + aov_lpe)
+    # shading points are pushed with the camera token only (direct.cpp:67,86-87): an expression that accepts "C" keeps the plane, any other empties it
+    assert np.abs(img["normal_geometric[C.*].y"]).max() > 0.9 and not img["position[CDL].x"].any() and not img["position[CDL].z"].any()
     xyz, smp, fb = g.output()
     rgb = backend.tonemap(xyz)
     direct = read_exr_uncompressed(paths[1])
