@@ -2670,18 +2670,6 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			if (go_inner || go_leaf) {
 				const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
 				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3]; // an inner record, or the first half of a leaf
-#ifdef PR_EXPERIMENT_EXTRA_LOAD
-				{ // EXPERIMENT: PR_EXPERIMENT_EXTRA_LOAD more lane-loads of the same line per step (is the step bound by lane-loads?)
-					const float4* r2 = rec;
-					asm volatile("" : "+v"(r2));
-					for (int e = 0; e < PR_EXPERIMENT_EXTRA_LOAD; ++e) {
-						const float4 qx = r2[e & 3];
-						asm volatile("" : "+v"(r2));
-						if (qx.x == 1.2345e-30f && qx.y == 5.4321e-30f)
-							s.tmin += 1.0f;
-					}
-				}
-#endif
 				if (go_inner) {
 					if (COUNT) {
 						cn_c += s.any ? 0 : 1;
