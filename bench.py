@@ -21,6 +21,8 @@ sys.path.insert(0, ROOT)
 
 W, H, SPP, NTRI = 1920, 1080, 1024, 1_000_000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the achievable copy rate
+ROOFLINE_ITERS = 16    # iterations of the launch the roofline is measured on (and of the instrumented launch that counts its records):
+                       # long enough that the fill and the drain of a launch do not colour the lane statistics
 
 
 def native_oracle():
@@ -123,7 +125,7 @@ def pmc_traffic(kernel_signature):
     return None, None, reason or "no profiles/r*_pmc_summary.json"
 
 
-def roofline(ctx, rank, iters=8, variant="0u"):
+def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u"):
     """Roofline of the dominant kernel, measured live on this rank: HIP events on the launch stream around every launch
     (pass 1), node/triangle record counters of the instrumented kernel variant (pass 2; same pixels, statistically identical
     iterations).  Algorithmic bytes = rays x (32 B ray + 16 B result) + 64 B x inner + 128 B x leaf BVH records fetched."""
@@ -224,8 +226,8 @@ def main():
         workload = ("C4: Cornell box + %d-triangle soup (%d triangles), %dx%d, `direct` integrator (NEE+MIS+RR, depth 64), "
                     "sobol %d-spp schedule, hero wavelengths (spd CMIS), %d iterations timed" % (args.triangles - 32, args.triangles, width, height, SPP, args.steps))
         variant, what = "0u", "the same 1M-triangle scene"
-    if args.steps + args.warmup + 16 > spp:
-        raise SystemExit("steps + warmup (+ 16 roofline iterations) exceed the %d-spp schedule" % spp)
+    if args.steps + args.warmup + 2 * ROOFLINE_ITERS > spp:
+        raise SystemExit("steps + warmup (+ %d roofline iterations) exceed the %d-spp schedule" % (2 * ROOFLINE_ITERS, spp))
     t0 = time.time()
     ctx = backend.RenderContext(sc, device=local)
     t_create = time.time() - t0

@@ -44,9 +44,19 @@ struct PersistentGeometry {
 PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, uint32_t max_slots_per_block);
 uint32_t persistent_slot_padding(); // per-slot arrays need n_pixels + this many entries
 uint32_t persistent_block_threads(); // 256 or 768 (PR_PP_BLOCK)
+// What a host may tune in the persistent kernel without changing a result (prgpu_api.hip reads the PRGPU_PP_* knobs into this)
+struct PersistentTuning {
+	uint32_t slots	  = 512; // path slots per block of 256 lanes (256 .. 512)
+	int shade_min	  = 64;	 // a shading pass starts once this many vertices of one class wait ...
+	int shade_partial = 16;	 // ... or this many when no ray is queued and the wave is short of rays anyway
+	int fin_batch	  = 16;	 // finished rays are written out once this many lanes of a wave hold one
+	int occupancy	  = 3;	 // waves per SIMD the kernel variant is compiled for (3: 168 VGPRs, 2: 256)
+	int shader_wave	  = -1;	 // 1 / 0: a dedicated shading wave per block or not; -1: when every owned pixel is in flight at once
+	bool resident	  = true; // pixels stay with a block, not with a slot (off: a slot keeps its pixel for all samples of a launch)
+};
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
-							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int refill_min, int both_below, int occupancy, int shader_wave, int shade_help,
-							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st);
+							bool count, const TraceWorkspace& ws, const PersistentTuning& tune, bool shader_wave, uint32_t* next_pixel, uint32_t* error,
+							unsigned long long* gstats, hipStream_t st);
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st);
 // lockstep pipeline, PRGPU_SORT_RAYS=1 (experiment): the active list ordered by (Morton code of the ray origin, direction octant)
 size_t sort_active_temp_bytes(uint32_t n_max);

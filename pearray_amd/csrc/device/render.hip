@@ -2224,13 +2224,9 @@ struct PersistentArgs {
 	uint2* spill;
 	int refill_below;
 	uint32_t shade_min; // shade as soon as this many vertices wait (<= 64)
-	uint32_t shade_partial; // ... or this many when no rays are queued and the wave has fewer than partial_act rays in flight
-	int partial_act;
-	int both_below;		 // a wave with fewer rays in flight than this steps inner nodes AND leaves in one step
-	uint32_t refill_min; // waves other than the block's first one refill only when at least this many rays are queued
-	uint32_t shader_wave; // 1: the block's last wave only shades (any batch size, never holds rays); the others trace and help
-	uint32_t shade_help;  // ... with full batches once this many vertices wait
-	int leaf_bias;		  // majority vote of a wave step: inner nodes when n_inner * 100 >= n_leaf * leaf_bias (100 = plain majority)
+	uint32_t shade_partial; // ... or this many when no rays are queued and the wave is short of rays anyway (fewer than refill_below in flight)
+	uint32_t shader_wave; // 1: the block's last wave only shades (any batch size, never holds rays); the others trace and help with full
+						  // batches once PP_SHADE_HELP vertices wait
 	int fin_batch;		  // finished rays of a wave are written out once this many lanes hold one (or the wave is under-occupied); 1: at once
 	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
 	// resident pixels (see path_persistent): per block `bl_cap` list entries (pixel) and state words (samples done | samples handed out << 16),
@@ -2242,6 +2238,7 @@ struct PersistentArgs {
 	uint32_t* slot_unit;
 	unsigned long long* gstats;
 };
+constexpr uint32_t PP_SHADE_HELP = 128u;
 constexpr uint32_t BL_UNWRITTEN = 0xFFFFFFFEu, BL_HOLE = 0xFFFFFFFFu; // list entry reserved but not yet written / reserved when the frame had no pixel left
 
 template <bool COUNT, uint32_t FEATS>
@@ -2337,8 +2334,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	const uint32_t shader_idx = 3u; // one wave in four (rotating it with the block's dispatch layer, so that the shading waves of the blocks that
 									// share a CU sit on different SIMDs, changes nothing: 2.38 - 2.43 ms per iteration at 1/8 of the C4 frame either way)
 	const bool shader		  = a.shader_wave != 0u && ((threadIdx.x >> 6) & 3u) == shader_idx;
-	const bool first_tracer	  = (threadIdx.x >> 6) == ((a.shader_wave != 0u && shader_idx == 0u) ? 1u : 0u); // the wave that takes a thin supply of rays
-	const uint32_t shade_full = a.shader_wave != 0u ? a.shade_help : a.shade_min;
+	const uint32_t shade_full = a.shader_wave != 0u ? PP_SHADE_HELP : a.shade_min;
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
 		// the fullest class queue decides: a pass shades one class
@@ -2360,7 +2356,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		else if (a.shader_wave != 0u)
 			shade_now = n_shade >= shade_full || (n_queued == 0u && n_shade > 0u && n_act == 0);
 		else
-			shade_now = n_shade >= a.shade_min || (n_queued == 0u && ((n_shade >= a.shade_partial && n_act < a.partial_act) || (n_shade > 0u && n_act == 0)));
+			shade_now = n_shade >= a.shade_min || (n_queued == 0u && ((n_shade >= a.shade_partial && n_act < a.refill_below) || (n_shade > 0u && n_act == 0)));
 		if (shade_now) {
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.shade_head[cls], &sh.shade_tail[cls], 64u, first);
@@ -2583,11 +2579,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		}
 
 		// ---- trace: hand queued rays to the idle lanes
-		// Hand queued rays to the idle lanes.  When few rays are queued only the block's first wave takes them: the other waves
-		// wait for at least `refill_min`, so that a thin supply of rays fills a few waves instead of keeping every wave stepping
-		// with a handful of lanes (a wave step costs the same with 3 lanes as with 64).
+		// Hand queued rays to the idle lanes.  (Measured and dropped: holding a thin supply back for the block's first wave, so that it fills
+		// a few waves instead of keeping every wave stepping with a handful of lanes -- higher lane utilisation, same time.)
 		const unsigned long long idle = __ballot(!has_ray);
-		if (!shader && idle != 0ull && n_queued > 0u && (n_queued >= a.refill_min || first_tracer)) {
+		if (!shader && idle != 0ull && n_queued > 0u) {
 			const unsigned long long t0r = COUNT ? wall_clock64() : 0ull;
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(idle), first);
@@ -2653,13 +2648,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			const int n_inner	= __popcll(__ballot(at_inner));
 			if (COUNT && lane == 0)
 				++witers;
-			// A thinly occupied wave (few rays in flight: small tile shares, the end of a render call) advances BOTH kinds in one
-			// step -- every ray moves each step, which halves its latency, and divergence costs little with few lanes; a well
-			// filled wave takes the majority kind only.  Either way the record is fetched before the branch, so the two kinds'
-			// memory latencies overlap.
-			const bool both		= n_inner + n_leaf < a.both_below;
-			const bool do_inner = both ? n_inner > 0 : n_inner * 100 >= n_leaf * a.leaf_bias;
-			const bool go_inner = do_inner && at_inner, go_leaf = (both || !do_inner) && at_leaf;
+			// The majority kind only; the record is fetched before the branch.  (Measured and dropped: advancing BOTH kinds in one step in
+			// thinly occupied waves -- 30 % fewer, proportionally longer steps --, and a bias of the vote towards either kind.)
+			const bool do_inner = n_inner >= n_leaf;
+			const bool go_inner = do_inner && at_inner, go_leaf = !do_inner && at_leaf;
 			// (Measured and dropped, see DESIGN.md: a cooperative fetch -- eight lanes reading one record's eight chunks, handed over
 			// through an LDS staging buffer: 2x the raw gather rate in tools/micro/gather_bench.hip but 11 % slower here; 4-byte
 			// packed stack entries to make room for a 4th wave per SIMD: +5 % time, and the 4th wave bought nothing; postponed
@@ -2746,7 +2738,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				for (int q = 1; q < NQ + 1; ++q)
 					nsh = max(nsh, lds_load(&sh.shade_tail[q]) - lds_load(&sh.shade_head[q]));
 				const uint32_t nq = lds_load(&sh.ray_tail) - lds_load(&sh.ray_head);
-				if (wave_bcast0(((nq > 0u && (nq >= a.refill_min || first_tracer)) || nsh >= shade_full || (a.shader_wave == 0u && nsh >= a.shade_partial && active < a.partial_act)) ? 1u : 0u))
+				if (wave_bcast0((nq > 0u || nsh >= shade_full || (a.shader_wave == 0u && nsh >= a.shade_partial)) ? 1u : 0u)) // (active < refill_below here)
 					break;
 			}
 		}
@@ -3277,14 +3269,10 @@ PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, ui
 	// for each of 768 blocks, and rounding that up to 384 would leave 93 blocks without work)
 	const uint32_t per_block = (n_owned + max_blocks - 1) / std::max(1u, max_blocks);
 	const uint32_t cap		 = std::min((uint32_t)PP_SLOTS_MAX, std::max(256u, max_slots_per_block / 64u * 64u));
-	static const uint32_t min_slots = getenv("PRGPU_PP_MIN_SLOTS") ? (uint32_t)std::min(256, std::max(1, atoi(getenv("PRGPU_PP_MIN_SLOTS")))) : 256u;
-	g.slots_per_block		 = std::min(cap, std::max(min_slots, per_block));
-	// more pixels than slots (dynamic hand-out): the traversal-bound C4 frame likes 320 slots per block of 256 lanes a little better
-	// (13.3 vs 13.5 - 13.7 ms per iteration at 512; 256: 14.6), every shading-heavy scene likes 512 much better (fuller shading passes:
-	// C5 134 vs 126 Msamples/s, rough Cornell 257 vs 228, glass 287 vs 266) -- 512 stays; PRGPU_PP_DYN_SLOTS for experiments
-	static const uint32_t dyn_slots = getenv("PRGPU_PP_DYN_SLOTS") ? (uint32_t)std::min(PP_SLOTS_MAX, std::max(256, atoi(getenv("PRGPU_PP_DYN_SLOTS")) / 64 * 64)) : (uint32_t)PP_SLOTS_MAX;
-	if (per_block > cap)
-		g.slots_per_block = std::min(cap, dyn_slots);
+	g.slots_per_block		 = std::min(cap, std::max(256u, per_block));
+	// more pixels than slots (dynamic hand-out): the traversal-bound C4 frame likes 320 - 384 slots per block of 256 lanes a little better
+	// (2 %), every shading-heavy scene likes 512 better (fuller shading passes: C5 2 - 6 %, rough Cornell 257 vs 228 Msamples/s, glass 287
+	// vs 266) -- the cap stays 512 (profiles/r03_slots_blocks_sweep.log)
 	g.n_blocks				 = std::max(1u, std::min(max_blocks, (n_owned + g.slots_per_block - 1) / g.slots_per_block));
 	return g;
 }
@@ -3292,9 +3280,10 @@ uint32_t persistent_slot_padding() { return PP_SLOTS_MAX; }
 uint32_t persistent_block_threads() { return PP_BLOCK; }
 
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
-							bool count, const TraceWorkspace& ws, uint32_t max_slots_per_block, int shade_min, int shade_partial, int partial_act, int refill_min, int both_below, int occupancy, int shader_wave, int shade_help,
-							uint32_t* next_pixel, uint32_t* error, unsigned long long* gstats, hipStream_t st)
+							bool count, const TraceWorkspace& ws, const PersistentTuning& tune, bool shader_wave, uint32_t* next_pixel, uint32_t* error,
+							unsigned long long* gstats, hipStream_t st)
 {
+	const uint32_t max_slots_per_block = tune.slots;
 	const PersistentGeometry g = persistent_geometry(n_owned, ws.max_blocks, max_slots_per_block);
 	const bool all_in_flight   = uint64_t(g.n_blocks) * g.slots_per_block >= n_owned;
 	PersistentArgs a;
@@ -3307,19 +3296,14 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.iter_end		  = iter_end;
 	a.spill			  = ws.spill;
 	a.refill_below	  = ws.refill_below;
-	a.shade_min		  = (uint32_t)std::min(64, std::max(1, shade_min));
-	a.shade_partial	  = (uint32_t)std::min(64, std::max(1, shade_partial));
-	a.partial_act	  = std::min(ws.refill_below, std::max(1, partial_act));
-	a.refill_min	  = (uint32_t)std::min(64, std::max(1, refill_min));
-	a.both_below	  = std::min(65, std::max(0, both_below));
+	a.shade_min		  = (uint32_t)std::min(64, std::max(1, tune.shade_min));
+	a.shade_partial	  = (uint32_t)std::min(64, std::max(1, tune.shade_partial));
 	a.shader_wave	  = shader_wave ? 1u : 0u;
-	a.shade_help	  = (uint32_t)std::max(64, shade_help);
-	a.leaf_bias		  = getenv("PRGPU_PP_LEAF_BIAS") ? std::max(1, atoi(getenv("PRGPU_PP_LEAF_BIAS"))) : 100;
 	a.gstats		  = gstats;
 	a.direct_map	  = all_in_flight ? 1u : 0u;
-	a.fin_batch		  = getenv("PRGPU_PP_FIN_BATCH") ? std::min(64, std::max(1, atoi(getenv("PRGPU_PP_FIN_BATCH")))) : 16;
-	// resident pixels: more pixels than slots and more than one sample per pixel in this launch (PRGPU_PP_RESIDENT=0: a pixel keeps its slot)
-	const bool resident_ok = !(getenv("PRGPU_PP_RESIDENT") && atoi(getenv("PRGPU_PP_RESIDENT")) == 0);
+	a.fin_batch		  = std::min(64, std::max(1, tune.fin_batch));
+	// resident pixels: more pixels than slots and more than one sample per pixel in this launch (tune.resident false: a pixel keeps its slot)
+	const bool resident_ok = tune.resident;
 	a.bl_cap		  = (uint32_t)std::min<uint64_t>(n_owned, 2ull * ((n_owned + g.n_blocks - 1) / g.n_blocks) + 1024ull);
 	a.bl_list		  = ws.bl_list;
 	a.bl_word		  = ws.bl_word;
@@ -3343,7 +3327,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 										   { launch_pp_5_0, launch_pp_5_1, launch_pp_5_2, launch_pp_5_3 } };
 	const int variant = (sc.features & (FEAT_LPE | FEAT_QUADRICS)) ? 4
 						: (sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3)));
-	table[variant][(occupancy >= 3 ? 0 : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
+	table[variant][(tune.occupancy >= 3 ? 0 : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
 }
 
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * std::max(TRAV_BLOCK, PP_BLOCK) * STACK_SPILL; }

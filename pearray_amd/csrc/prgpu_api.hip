@@ -42,6 +42,66 @@ int set_last_error(int code, const std::string& msg) { return fail(code, msg); }
 } // namespace prgpu_host
 namespace {
 
+// ---- environment knobs: every one the library reads, in one place ------------------------------------------------------------------
+// Development and test aids.  None of them changes a rendered value (tests/test_gpu_parity.py runs the scheduling ones against the
+// checker); the defaults are the measured optima quoted in DESIGN.md.  Scene-shaping knobs are read once, when a scene is created.
+struct Knobs {
+	int mode = -1;						  // PRGPU_MODE=lockstep|streaming|persistent (0 / 1 / 2; -1: default = persistent)
+	bool mode_invalid = false;
+	prd::PersistentTuning pp;			  // PRGPU_PP_SLOTS, _SHADE_MIN, _SHADE_PARTIAL, _FIN_BATCH, _OCCUPANCY, _SHADER, _RESIDENT
+	bool pp_slots_set		   = false;
+	int pp_refill			   = 48;	  // PRGPU_PP_REFILL: a wave refills its idle lanes when fewer than this many hold a ray
+	int pp_blocks_per_cu	   = 0;		  // PRGPU_PP_BLOCKS_PER_CU (0: 768 threads per CU)
+	int pp_max_blocks		   = 0;		  // PRGPU_PP_MAX_BLOCKS (tests: a small grid, so that a small film has more pixels than path slots)
+	int pp_planes			   = 8;		  // PRGPU_PP_PLANES: iteration planes per launch with a multi-tap pixel filter
+	uint64_t pp_launch_samples = 128ull << 20; // PRGPU_PP_LAUNCH_SAMPLES: camera samples per bounded launch
+	int pp_launch_min_iters	   = 8;		  // PRGPU_PP_LAUNCH_MIN_ITERS
+	bool pp_tune_order		   = true;	  // PRGPU_PP_TUNE_ORDER=0: keep the strided pixel order of small tile shares
+	int groups				   = 1;		  // PRGPU_GROUPS: pixel groups of the wavefront pipelines on their own streams
+	bool sort_rays			   = false;	  // PRGPU_SORT_RAYS=1: lockstep pipeline with globally sorted ray lists (experiment, profiles/r03_global_sort.json)
+	bool trace_split		   = true;	  // PRGPU_TRACE_SPLIT=0: ray service without the split traversal
+	bool comm_force_rccl	   = false;	  // PRGPU_COMM_FORCE_RCCL=1: a real RCCL communicator even for one rank (tests)
+	uint32_t force_features	   = 0;		  // PRGPU_FORCE_FEATURES: run a scene with a larger kernel variant than it needs (measurement aid)
+	bool debug_counters		   = false;	  // PRGPU_DEBUG_COUNTERS: print the instrumented kernel's time split
+	const char* dump_block_life = nullptr; // PRGPU_DUMP_BLOCK_LIFE=<file>: per-block lifetimes of the last instrumented launch
+};
+Knobs read_knobs()
+{
+	auto num = [](const char* name, long long def, long long lo, long long hi) -> long long {
+		const char* env = getenv(name);
+		return env ? std::min(hi, std::max(lo, atoll(env))) : def;
+	};
+	Knobs k;
+	if (const char* env = getenv("PRGPU_MODE")) {
+		k.mode		   = std::strcmp(env, "lockstep") == 0 ? 0 : (std::strcmp(env, "streaming") == 0 ? 1 : (std::strcmp(env, "persistent") == 0 ? 2 : -1));
+		k.mode_invalid = k.mode < 0;
+	}
+	k.pp_slots_set		  = getenv("PRGPU_PP_SLOTS") != nullptr;
+	k.pp.slots			  = (uint32_t)num("PRGPU_PP_SLOTS", k.pp.slots, 256, 1 << 20);
+	k.pp.shade_min		  = (int)num("PRGPU_PP_SHADE_MIN", k.pp.shade_min, 1, 64);
+	k.pp.shade_partial	  = (int)num("PRGPU_PP_SHADE_PARTIAL", k.pp.shade_partial, 1, 64);
+	k.pp.fin_batch		  = (int)num("PRGPU_PP_FIN_BATCH", k.pp.fin_batch, 1, 64);
+	k.pp.occupancy		  = (int)num("PRGPU_PP_OCCUPANCY", k.pp.occupancy, 2, 3);
+	k.pp.shader_wave	  = (int)num("PRGPU_PP_SHADER", k.pp.shader_wave, -1, 1);
+	k.pp.resident		  = num("PRGPU_PP_RESIDENT", 1, 0, 1) != 0;
+	k.pp_refill			  = (int)num("PRGPU_PP_REFILL", k.pp_refill, 1, 64);
+	k.pp_blocks_per_cu	  = (int)num("PRGPU_PP_BLOCKS_PER_CU", 0, 0, 8);
+	k.pp_max_blocks		  = (int)num("PRGPU_PP_MAX_BLOCKS", 0, 0, 1 << 20);
+	k.pp_planes			  = (int)num("PRGPU_PP_PLANES", k.pp_planes, 1, 64);
+	k.pp_launch_samples	  = (uint64_t)num("PRGPU_PP_LAUNCH_SAMPLES", (long long)k.pp_launch_samples, 1, 1ll << 40);
+	k.pp_launch_min_iters = (int)num("PRGPU_PP_LAUNCH_MIN_ITERS", k.pp_launch_min_iters, 1, 1 << 15);
+	k.pp_tune_order		  = num("PRGPU_PP_TUNE_ORDER", 1, 0, 1) != 0;
+	k.groups			  = (int)num("PRGPU_GROUPS", k.groups, 1, 16);
+	k.sort_rays			  = num("PRGPU_SORT_RAYS", 0, 0, 1) != 0;
+	k.trace_split		  = num("PRGPU_TRACE_SPLIT", 1, 0, 1) != 0;
+	k.comm_force_rccl	  = num("PRGPU_COMM_FORCE_RCCL", 0, 0, 1) != 0;
+	if (const char* env = getenv("PRGPU_FORCE_FEATURES"))
+		k.force_features = (uint32_t)strtoul(env, nullptr, 0);
+	k.debug_counters  = getenv("PRGPU_DEBUG_COUNTERS") != nullptr;
+	k.dump_block_life = getenv("PRGPU_DUMP_BLOCK_LIFE");
+	return k;
+}
+
 struct TimedLaunch {
 	hipEvent_t start, stop;
 	int family;
@@ -68,9 +128,8 @@ struct prgpu_scene {
 	// single-tap pixel filter (the reference default); all three produce identical images.
 	enum Mode { LOCKSTEP, STREAMING, PERSISTENT };
 	Mode mode = LOCKSTEP;
-	uint32_t pp_slots = 512;
+	Knobs knobs;			// the environment knobs as they stood when the scene was created
 	uint32_t pp_planes = 1; // iteration planes of the persistent pipeline (> 1 with a multi-tap pixel filter)
-	int pp_shade_min  = 64, pp_shade_partial = 16, pp_partial_act = 64, pp_refill_min = 1, pp_both_below = 0, pp_occupancy = 3, pp_shader_wave = -1 /* auto: see render_persistent */, pp_shade_help = 128;
 	uint32_t *pp_pixel = nullptr, *pp_next = nullptr, *pp_error = nullptr; // persistent kernel: slot -> pixel, pixel hand-out counter, watchdog flag
 	unsigned long long* gstats = nullptr;
 	prd::TraceWorkspace ws;	   // workspace of the ray-service launches
@@ -109,8 +168,6 @@ struct prgpu_scene {
 	uint32_t order_tuned_at = 0; // iteration count the pixel order was last tuned at (tune_pixel_order)
 	bool poisoned = false; // a device-side error was reported: further render calls are refused
 	uint32_t reduced_at = 0xFFFFFFFFu; // iteration count at which prgpu_reduce summed the ranks' frames in place (0xFFFFFFFF: not yet)
-	uint64_t pp_launch_samples = 128ull << 20; // persistent mode: camera samples per launch (render calls are cut into bounded launches)
-	uint32_t pp_launch_min_iters = 8;
 
 	template <typename T>
 	int alloc(T*& ptr, size_t count, bool zero = false)
@@ -189,9 +246,7 @@ int apply_tiles(prgpu_scene* s, const prgpu_tile* tiles, uint32_t n_tiles)
 	// (1/8 of the C4 frame: 2.96 -> 2.75 ms per iteration).  With more pixels than slots the plain Morton order is faster (primary
 	// ray coherence; full frame 14.7 vs 15.4 ms), and slots pick up new pixels as they finish anyway.
 	{
-		uint32_t g = s->mode == prgpu_scene::PERSISTENT && uint64_t(s->n_slots) <= uint64_t(s->ws_pp.max_blocks) * s->pp_slots ? 4u : 0u;
-		if (const char* env = getenv("PRGPU_PIXEL_INTERLEAVE"))
-			g = (uint32_t)std::max(0, atoi(env));
+		const uint32_t g = s->mode == prgpu_scene::PERSISTENT && uint64_t(s->n_slots) <= uint64_t(s->ws_pp.max_blocks) * s->knobs.pp.slots ? 4u : 0u;
 		const uint32_t n_groups = g ? s->n_slots / g : 0u;
 		if (n_groups > 2) {
 			uint32_t stride = (uint32_t)(n_groups * 0.6180339887) | 1u;
@@ -386,8 +441,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 			sc.features |= prd::FEAT_PLANES;
 		else if (d->entities[e].kind == PRGPU_ENTITY_SPHERE)
 			sc.features |= prd::FEAT_SPHERES;
-	if (const char* env = getenv("PRGPU_FORCE_FEATURES")) // measurement aid: run a scene with a larger kernel variant than it needs (same results)
-		sc.features |= (uint32_t)strtoul(env, nullptr, 0) & prd::FEAT_ALL & ~(prd::FEAT_LPE | prd::FEAT_QUADRICS); // (those two need data the scene does not have)
+	// measurement aid: run a scene with a larger kernel variant than it needs (same results; LPE and quadrics need data the scene does not have)
+	sc.features |= read_knobs().force_features & prd::FEAT_ALL & ~(prd::FEAT_LPE | prd::FEAT_QUADRICS);
 	sc.scene_radius	 = t.scene_radius;
 	sc.wl_cdf_size	 = (uint32_t)t.wl_cdf.size();
 	sc.wl_u_offset	 = t.wl_u_offset;
@@ -461,9 +516,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	// persistent pipeline with a multi-tap pixel filter: a ring of iteration planes (pixels advance through their samples at their own
 	// pace, sample i of a pixel lands in plane i - iter_base; after the launch k_resolve gathers the filter taps plane by plane, exactly
 	// like the lockstep pipeline does after each of its iterations)
-	s->pp_planes = t.single_tap ? 1u : 8u;
-	if (const char* env = getenv("PRGPU_PP_PLANES"))
-		s->pp_planes = t.single_tap ? 1u : (uint32_t)std::min(64, std::max(1, atoi(env)));
+	s->pp_planes = t.single_tap ? 1u : (uint32_t)s->knobs.pp_planes;
 	AL(ps.iter_xyz, size_t(np) * 3 * s->pp_planes, true);
 	ps.plane_stride = 0;
 	ps.iter_base	= 0;
@@ -483,46 +536,17 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(s->dead_b, np, false);
 	AL(ps.iter, ns, true);
 	AL(ps.cost, np, true);
-	// streaming (pixels advance through their samples independently) is bit-identical for single-tap filters but measured
-	// ~6% slower than the iteration-synchronous pipeline on MI355X (finished paths wait one round before their pixel's
-	// next sample starts); it stays available behind PRGPU_STREAMING=1
+	// streaming (pixels advance through their samples independently) is bit-identical for single-tap filters but measured ~6 % slower than
+	// the iteration-synchronous pipeline on MI355X (finished paths wait one round before their pixel's next sample starts)
 	s->mode = prgpu_scene::PERSISTENT;
-	if (t.single_tap && getenv("PRGPU_STREAMING") && atoi(getenv("PRGPU_STREAMING")) != 0)
-		s->mode = prgpu_scene::STREAMING;
-	if (const char* env = getenv("PRGPU_MODE")) {
-		if (std::strcmp(env, "streaming") == 0)
-			s->mode = t.single_tap ? prgpu_scene::STREAMING : prgpu_scene::LOCKSTEP; // streaming folds per pixel: single-tap filters only
-		else if (std::strcmp(env, "persistent") == 0)
-			s->mode = prgpu_scene::PERSISTENT;
-		else if (std::strcmp(env, "lockstep") == 0)
-			s->mode = prgpu_scene::LOCKSTEP;
-		else
-			return fail(PRGPU_EINVAL, "PRGPU_MODE must be lockstep, streaming or persistent");
-	}
+	if (s->knobs.mode_invalid)
+		return fail(PRGPU_EINVAL, "PRGPU_MODE must be lockstep, streaming or persistent");
+	if (s->knobs.mode == 0)
+		s->mode = prgpu_scene::LOCKSTEP;
+	else if (s->knobs.mode == 1)
+		s->mode = t.single_tap ? prgpu_scene::STREAMING : prgpu_scene::LOCKSTEP; // streaming folds per pixel: single-tap filters only
 	if ((s->sc.features & prd::FEAT_QUADRICS) && s->mode != prgpu_scene::PERSISTENT)
 		return fail(PRGPU_EUNSUPPORTED, "quadric entities are traced by the persistent pipeline only");
-	if (const char* env = getenv("PRGPU_PP_SLOTS"))
-		s->pp_slots = (uint32_t)std::max(256, atoi(env));
-	if (const char* env = getenv("PRGPU_PP_OCCUPANCY"))
-		s->pp_occupancy = atoi(env);
-	if (const char* env = getenv("PRGPU_PP_SHADE_PARTIAL"))
-		s->pp_shade_partial = atoi(env);
-	if (const char* env = getenv("PRGPU_PP_SHADER"))
-		s->pp_shader_wave = atoi(env);
-	if (const char* env = getenv("PRGPU_PP_SHADE_HELP"))
-		s->pp_shade_help = atoi(env);
-	if (const char* env = getenv("PRGPU_PP_BOTH"))
-		s->pp_both_below = atoi(env);
-	if (const char* env = getenv("PRGPU_PP_REFILL_MIN"))
-		s->pp_refill_min = atoi(env);
-	if (const char* env = getenv("PRGPU_PP_PARTIAL_ACT"))
-		s->pp_partial_act = atoi(env);
-	if (const char* env = getenv("PRGPU_PP_SHADE_MIN"))
-		s->pp_shade_min = atoi(env);
-	if (const char* env = getenv("PRGPU_PP_LAUNCH_SAMPLES"))
-		s->pp_launch_samples = (uint64_t)std::max(1ll, atoll(env));
-	if (const char* env = getenv("PRGPU_PP_LAUNCH_MIN_ITERS"))
-		s->pp_launch_min_iters = (uint32_t)std::max(1, atoi(env));
 	AL(s->pp_pixel, ns, false);
 	AL(s->pp_next, 1, true);
 	AL(s->pp_error, 1, true);
@@ -530,12 +554,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	{ // persistent traversal grid: a few blocks of 256 threads per CU (32 KB of LDS stack each)
 		hipDeviceProp_t prop;
 		HIP_TRY(hipGetDeviceProperties(&prop, device));
-		uint32_t blocks_per_cu = 2; // measured best on MI355X: fewer, longer-lived waves waste less in the drain phase
-		if (const char* env = getenv("PRGPU_BLOCKS_PER_CU"))
-			blocks_per_cu = (uint32_t)std::min(8, std::max(1, atoi(env)));
-		int refill = 44;
-		if (const char* env = getenv("PRGPU_REFILL"))
-			refill = std::min(64, std::max(1, atoi(env)));
+		const uint32_t blocks_per_cu = 2; // wavefront pipelines; measured best on MI355X: fewer, longer-lived waves waste less in the drain phase
+		const int refill			 = 44;
 		const uint32_t max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * blocks_per_cu;
 		auto make_ws = [&](prd::TraceWorkspace& w, uint32_t n_blocks) -> int {
 			w.max_blocks   = n_blocks;
@@ -546,21 +566,19 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		};
 		// the ray service (IArchive surface) runs three blocks per CU: 8 M incoherent closest-hit rays in the C4 scene take 8.0 instead of
 		// 10.3 ms, and 6.9 ms with the split traversal (profiles/r02_trace_split_prototype.log); the wavefront pipelines gain nothing from it
-		rc = make_ws(s->ws, getenv("PRGPU_BLOCKS_PER_CU") ? max_blocks : (uint32_t)std::max(1, prop.multiProcessorCount) * 3u);
+		rc = make_ws(s->ws, (uint32_t)std::max(1, prop.multiProcessorCount) * 3u);
 		if (rc != PRGPU_OK)
 			return rc;
 		{ // persistent path kernel: its own grid (measured best: 3 blocks per CU at 3 waves per SIMD, refill below 48 lanes)
 			uint32_t pp_blocks_per_cu = 768u / prd::persistent_block_threads(); // twelve waves per CU either way
-			if (!getenv("PRGPU_PP_SLOTS"))
-				s->pp_slots = 512u * (prd::persistent_block_threads() / 256u);
-			if (const char* env = getenv("PRGPU_PP_BLOCKS_PER_CU"))
-				pp_blocks_per_cu = (uint32_t)std::min(8, std::max(1, atoi(env)));
-			s->ws_pp.max_blocks	  = (uint32_t)std::max(1, prop.multiProcessorCount) * pp_blocks_per_cu;
-			if (const char* env = getenv("PRGPU_PP_MAX_BLOCKS")) // tests: a small grid, so that a small film has more pixels than path slots
-				s->ws_pp.max_blocks = (uint32_t)std::min<int64_t>(s->ws_pp.max_blocks, std::max(1, atoi(env)));
-			s->ws_pp.refill_below = 48;
-			if (const char* env = getenv("PRGPU_PP_REFILL"))
-				s->ws_pp.refill_below = std::min(64, std::max(1, atoi(env)));
+			if (!s->knobs.pp_slots_set)
+				s->knobs.pp.slots = 512u * (prd::persistent_block_threads() / 256u);
+			if (s->knobs.pp_blocks_per_cu)
+				pp_blocks_per_cu = (uint32_t)s->knobs.pp_blocks_per_cu;
+			s->ws_pp.max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * pp_blocks_per_cu;
+			if (s->knobs.pp_max_blocks)
+				s->ws_pp.max_blocks = std::min(s->ws_pp.max_blocks, (uint32_t)s->knobs.pp_max_blocks);
+			s->ws_pp.refill_below = s->knobs.pp_refill;
 			AL(s->ws_pp.spill, prd::trace_workspace_spill_entries(s->ws_pp.max_blocks), false);
 			// resident pixels (launch_path_persistent): room for every block to list twice its fair share of the frame
 			s->ws_pp.bl_entries = 2 * size_t(np) + size_t(s->ws_pp.max_blocks) * 1026u;
@@ -570,9 +588,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		}
 		if (rc != PRGPU_OK)
 			return rc;
-		uint32_t n_groups = 1; // pipelined pixel groups (measured: 1 is fastest on MI355X); PRGPU_GROUPS overrides (1..16)
-		if (const char* env = getenv("PRGPU_GROUPS"))
-			n_groups = (uint32_t)std::min(16, std::max(1, atoi(env)));
+		uint32_t n_groups = (uint32_t)s->knobs.groups; // pipelined pixel groups (measured: 1 is fastest on MI355X)
 		if (np < 64u * 1024u)
 			n_groups = 1; // tiny films: nothing to overlap
 		s->groups.resize(n_groups);
@@ -604,7 +620,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 int enqueue_vertex(prgpu_scene* s, prgpu_scene::Group& g)
 {
 	hipStream_t st = g.s_main;
-	const bool sort_rays = getenv("PRGPU_SORT_RAYS") && atoi(getenv("PRGPU_SORT_RAYS")) != 0; // experiment, off: profiles/r03_global_sort.json
+	const bool sort_rays = s->knobs.sort_rays; // experiment, off: profiles/r03_global_sort.json
 	if (sort_rays && g.active != nullptr && g.n_active > 0) { // secondary rays (the primary wave runs in Morton order of the pixels anyway)
 		if (!g.sort_temp) {
 			int rc = s->alloc(g.sort_keys_a, g.n_slots);
@@ -862,13 +878,13 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	// watchdog is never near a legitimate wait.  Per-pixel state lives in the planes, so consecutive launches continue exactly
 	// where the previous one stopped (identical results for any chunking).
 	const uint64_t per_iter = std::max<uint64_t>(1, s->n_slots);
-	uint32_t chunk			= (uint32_t)std::min<uint64_t>(1u << 15, std::max<uint64_t>(s->pp_launch_min_iters, s->pp_launch_samples / per_iter));
+	uint32_t chunk			= (uint32_t)std::min<uint64_t>(1u << 15, std::max<uint64_t>((uint64_t)s->knobs.pp_launch_min_iters, s->knobs.pp_launch_samples / per_iter));
 	// A small tile share (every owned pixel in flight at once, no slot ever takes a second pixel) is bound by the LATENCY of a pixel's
 	// chain of samples, not by throughput: there the block's last wave only shades (batches of any size, the moment a vertex waits)
 	// and the other three only trace, so that no ray in flight is parked behind a shading pass (1/8 of the C4 frame: 2.62 -> 2.30 ms
 	// per iteration, 1/16: 2.23 -> 1.83).  With more pixels than slots the shared scheme is faster (full frame 13.7 vs 14.3 ms).
-	const bool all_in_flight = uint64_t(s->n_slots) <= uint64_t(s->ws_pp.max_blocks) * s->pp_slots;
-	const int shader_wave	 = s->pp_shader_wave >= 0 ? s->pp_shader_wave : (all_in_flight ? 1 : 0);
+	const bool all_in_flight = uint64_t(s->n_slots) <= uint64_t(s->ws_pp.max_blocks) * s->knobs.pp.slots;
+	const bool shader_wave	 = s->knobs.pp.shader_wave >= 0 ? s->knobs.pp.shader_wave != 0 : all_in_flight;
 	if (!all_in_flight)
 		ps.cost = nullptr; // the per-pixel path cost only serves tune_pixel_order
 	const bool ring			= !s->sc.single_tap; // multi-tap filter: one launch fills at most pp_planes iteration planes
@@ -880,11 +896,7 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 		const uint32_t e = (uint32_t)std::min<uint64_t>(iter_end, uint64_t(b) + chunk);
 		ps.iter_base = b;
 		s->time_begin(6, s->stream);
-		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument, s->ws_pp, s->pp_slots, s->pp_shade_min, s->pp_shade_partial, s->pp_partial_act, s->pp_refill_min, s->pp_both_below,
-									s->pp_occupancy, shader_wave, s->pp_shade_help,
-									s->pp_next,
-									s->pp_error,
-									s->gstats, s->stream);
+		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument, s->ws_pp, s->knobs.pp, shader_wave, s->pp_next, s->pp_error, s->gstats, s->stream);
 		s->time_end(s->stream);
 		HIP_TRY(hipGetLastError());
 		if (ring) { // filter taps + running mean, iteration by iteration in order (FrameOutputDevice.cpp:202-221)
@@ -930,15 +942,12 @@ int tune_pixel_order(prgpu_scene* s)
 	if (s->mode != prgpu_scene::PERSISTENT || s->next_iteration < std::max(4u, 2u * s->order_tuned_at) || !s->n_slots)
 		return PRGPU_OK;
 	s->order_tuned_at = s->next_iteration;
-	if (const char* env = getenv("PRGPU_PP_TUNE_ORDER"))
-		if (atoi(env) == 0)
-			return PRGPU_OK;
-	const prd::PersistentGeometry g = prd::persistent_geometry(s->n_slots, s->ws_pp.max_blocks, s->pp_slots);
+	if (!s->knobs.pp_tune_order)
+		return PRGPU_OK;
+	const prd::PersistentGeometry g = prd::persistent_geometry(s->n_slots, s->ws_pp.max_blocks, s->knobs.pp.slots);
 	if (uint64_t(g.n_blocks) * g.slots_per_block < s->n_slots || g.n_blocks != s->ws_pp.max_blocks || g.n_blocks % 3u != 0u)
 		return PRGPU_OK; // pixels are handed out dynamically, or the grid is not three full layers
-	float r1 = 1.12f, r2 = 1.25f; // measured optimum on 1/8 of the C4 frame (2.29 -> 2.20 ms per iteration); larger ratios shift too much WORK onto the fast layer
-	if (const char* env = getenv("PRGPU_PP_LAYER_SPEED"))
-		(void)sscanf(env, "%f,%f", &r1, &r2);
+	const float r1 = 1.12f, r2 = 1.25f; // measured optimum on 1/8 of the C4 frame (2.29 -> 2.20 ms per iteration); larger ratios shift too much WORK onto the fast layer
 	const uint32_t n = s->n_slots, spb = g.slots_per_block, B = g.n_blocks, LB = B / 3u;
 	std::vector<uint32_t> owned(n), cost(s->n_pixels);
 	HIP_TRY(hipMemcpy(owned.data(), s->ps.pixel, size_t(n) * 4, hipMemcpyDeviceToHost));
@@ -1083,6 +1092,7 @@ int prgpu_scene_create(const prgpu_scene_desc* desc, int device, prgpu_scene** o
 	if (v != PRGPU_OK)
 		return fail(v, err);
 	prgpu_scene* s = new prgpu_scene();
+	s->knobs	   = read_knobs();
 	const int rc   = create_impl(desc, device, s);
 	if (rc != PRGPU_OK) {
 		const std::string keep = g_error;
@@ -1201,7 +1211,7 @@ int prgpu_sync(prgpu_scene* s)
 		if (rc != PRGPU_OK)
 			return rc;
 	}
-	if (const char* path = s->instrument && s->mode == prgpu_scene::PERSISTENT ? getenv("PRGPU_DUMP_BLOCK_LIFE") : nullptr) { // diagnostics: one line per block of the last instrumented launch
+	if (const char* path = s->instrument && s->mode == prgpu_scene::PERSISTENT ? read_knobs().dump_block_life : nullptr) { // diagnostics: one line per block of the last instrumented launch
 		const size_t bt = prd::persistent_block_threads();
 		std::vector<uint2> rows(size_t(s->ws_pp.max_blocks) * bt);
 		HIP_TRY(hipMemcpy(rows.data(), s->ws_pp.spill, rows.size() * sizeof(uint2), hipMemcpyDeviceToHost));
@@ -1282,7 +1292,7 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 	out->shade_ticks		= host[PRGPU_STAT_COUNT + 8];
 	out->idle_ticks			= host[PRGPU_STAT_COUNT + 9];
 	out->total_ticks		= host[PRGPU_STAT_COUNT + 10];
-	if (getenv("PRGPU_DEBUG_COUNTERS")) // development: split-traversal time split and the shader clock (cycles per 100 MHz tick)
+	if (read_knobs().debug_counters) // development: split-traversal time split and the shader clock (cycles per 100 MHz tick)
 		if (host[PRGPU_STAT_COUNT + 10]) {
 			const double T = double(host[PRGPU_STAT_COUNT + 10]);
 			fprintf(stderr, "[prgpu] wave time: shading %.1f %%, idle %.1f %%, leaf steps %.1f %%, inner steps %.1f %%, refill %.1f %%, ray ends %.1f %%; of the shading: vertices %.1f %%, camera paths %.1f %%; shader clock %.0f MHz\n",
@@ -1371,7 +1381,7 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	s->time_begin(1, s->stream);
 	// closest-hit service rays take the split traversal (leaf tests through an LDS task queue: identical results, 17 % faster) unless
 	// PRGPU_TRACE_SPLIT=0 or the tree has too many records for the 24-bit task field
-	const bool split = !(getenv("PRGPU_TRACE_SPLIT") && atoi(getenv("PRGPU_TRACE_SPLIT")) == 0);
+	const bool split = read_knobs().trace_split;
 	if (split && s->sc.n_leaf > 0 && s->sc.n_inner + 2ull * s->sc.n_leaf < (1ull << 24) && !(s->sc.features & prd::FEAT_SPHERES)) {
 		prd::launch_service_closest_split(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, const_cast<uint32_t*>(s->sc.tri_slot), s->gstats, s->stream);
 	} else
@@ -1516,7 +1526,7 @@ int prgpu_comm_create(const uint8_t id[PRGPU_COMM_ID_BYTES], int n_ranks, int ra
 	*out = nullptr;
 	if (n_ranks < 1 || rank < 0 || rank >= n_ranks)
 		return fail(PRGPU_EINVAL, "rank must be in [0, n_ranks)");
-	const bool force = getenv("PRGPU_COMM_FORCE_RCCL") && atoi(getenv("PRGPU_COMM_FORCE_RCCL")) != 0; // tests: a real one-rank communicator
+	const bool force = read_knobs().comm_force_rccl; // tests: a real one-rank communicator
 	prgpu_comm* c	 = new prgpu_comm();
 	c->n_ranks		 = n_ranks;
 	c->rank			 = rank;

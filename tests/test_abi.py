@@ -31,7 +31,26 @@ def test_the_pearray_side_adapter_and_the_docs_only_use_declared_entry_points():
         for name in set(re.findall(r"\b(prgpu_[a-z0-9_]+)\s*\(", text)):
             assert name in abi.SYMBOLS or name == "prgpu_init", (rel, name)   # prgpu_init: SURVEY's proposed name, mentioned as replaced
         for name in set(re.findall(r"\b(PRGPU_[A-Z0-9_]+)\b", text)):
-            assert re.search(r"\b%s\b" % name, header) or name.startswith(("PRGPU_PP_", "PRGPU_MODE", "PRGPU_COMM_", "PRGPU_TRACE_", "PRGPU_LIBRARY", "PRGPU_DUMP", "PRGPU_BLOCKS", "PRGPU_GROUPS")), (rel, name)
+            assert re.search(r"\b%s\b" % name, header) or name.startswith(("PRGPU_PP_", "PRGPU_MODE", "PRGPU_COMM_", "PRGPU_TRACE_", "PRGPU_LIBRARY", "PRGPU_DUMP", "PRGPU_GROUPS")), (rel, name)
+
+
+def test_environment_knobs_are_read_in_one_place():
+    """Every PRGPU_* environment knob of the library is read by read_knobs() in prgpu_api.hip (one table, documented there); no other
+    translation unit calls getenv, and the Python side only adds PRGPU_LIBRARY (an A/B build of the same ABI)."""
+    csrc = os.path.join(ROOT, "pearray_amd", "csrc")
+    api = open(os.path.join(csrc, "prgpu_api.hip")).read()
+    body = api[api.index("Knobs read_knobs()"):]
+    body = body[:body.index("\n}\n") + 3]
+    assert api.count("getenv(") == body.count("getenv("), "a getenv outside read_knobs()"
+    for dirpath, _, files in os.walk(csrc):
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".h", ".inl")) and f != "prgpu_api.hip":
+                assert "getenv" not in open(os.path.join(dirpath, f), errors="replace").read(), f
+    knobs = set(re.findall(r'"(PRGPU_[A-Z0-9_]+)"', body))
+    assert 15 <= len(knobs) <= 24, sorted(knobs)
+    for name in knobs:   # each knob is explained where it is declared
+        assert name.replace("PRGPU_", "") in api[api.index("struct Knobs {"):api.index("Knobs read_knobs()")].replace("PRGPU_PP_SLOTS, _SHADE_MIN, _SHADE_PARTIAL, _FIN_BATCH, _OCCUPANCY, _SHADER, _RESIDENT",
+               "PP_SLOTS PP_SHADE_MIN PP_SHADE_PARTIAL PP_FIN_BATCH PP_OCCUPANCY PP_SHADER PP_RESIDENT"), name
 
 
 def test_struct_layouts_match_the_header(tmp_path):

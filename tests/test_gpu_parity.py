@@ -240,6 +240,44 @@ def test_tile_sharding_sums_to_whole_and_matches_oracle_rank():
     assert np.array_equal(acc, ref) and np.array_equal(acc_smp, ref_smp)
 
 
+def test_one_process_drives_several_ranks_from_host_threads():
+    """one process (or one host thread) per GPU.  Here one process drives four 'ranks' from four host threads
+    at once (all on device 0: each scene object has its own stream and planes, and the library keeps no state between scene objects
+    apart from the thread-local error string) -- the rank frames add up bit for bit to the unsharded frame, and a failing call on one
+    thread does not disturb the message another thread reads."""
+    import threading
+    W, H, spp, world = 160, 96, 6, 4
+    sc = scene.cornell_box(W, H, spp=spp)
+    whole = backend.RenderContext(sc); whole.start(); whole.waitForFinish()
+    ref, ref_smp, _ = whole.output()
+    out, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            g = backend.RenderContext(sc)
+            g.setTiles(tiling.tiles_for_rank(W, H, rank, world, tile=16))
+            for _ in range(spp):  # several short launches per rank, interleaved with the other threads' launches
+                g.render(1)
+            g.waitForFinish()
+            lib = abi.load()
+            assert lib.prgpu_render(g._h, 0, 1) != 0   # out of order: fails on THIS thread ...
+            assert b"in order" in lib.prgpu_last_error()  # ... and this thread reads its own message
+            out[rank] = g.output()
+            g.close()
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    acc = sum(o[0] for o in out)
+    acc_smp = sum(o[1] for o in out)
+    assert np.array_equal(acc, ref) and np.array_equal(acc_smp, ref_smp)
+
+
 def test_filter_apron_crosses_tile_ownership():
     """Radius-2 filter with sharded ownership: aprons spill into pixels the rank does not own (mergeLocal)."""
     W, H, spp = 48, 48, 3
@@ -334,10 +372,10 @@ def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypat
     sc = scene.cornell_soup(192, 108, spp=4, n_triangles=20_000)
     ref = _render_mode(monkeypatch, "lockstep", sc, [4])
     for env in (dict(PRGPU_PP_SLOTS="256", PRGPU_PP_OCCUPANCY="2"), dict(PRGPU_PP_SLOTS="1024", PRGPU_PP_SHADE_PARTIAL="1"),
-                dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_PARTIAL_ACT="4"),
-                dict(PRGPU_PP_BOTH="65", PRGPU_PP_REFILL_MIN="16"), dict(PRGPU_PP_BOTH="20"), dict(PRGPU_PP_FIN_BATCH="1"), dict(PRGPU_PP_FIN_BATCH="48"), dict(PRGPU_PP_SHADER="1"),
+                dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_REFILL="20"),
+                dict(PRGPU_PP_FIN_BATCH="1"), dict(PRGPU_PP_FIN_BATCH="48"), dict(PRGPU_PP_SHADER="1"),
                 dict(PRGPU_PP_SHADER="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"), dict(PRGPU_PP_RESIDENT="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"),
-                dict(PRGPU_PP_LEAF_BIAS="160")):
+                dict(PRGPU_PP_LAUNCH_SAMPLES="1", PRGPU_PP_LAUNCH_MIN_ITERS="1", PRGPU_PP_TUNE_ORDER="0")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         out = _render_mode(monkeypatch, "persistent", sc, [4])
