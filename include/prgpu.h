@@ -152,7 +152,7 @@ typedef struct prgpu_emission {
  * Described as ONE placeholder triangle whose three indices name the same vertex (never hit); primitive id 0;
  * N = normalMatrix * normalize(gradient(invTransform * P)), Tangent::frame, uv = 0 (quadric.cpp:95-108).  The occlusion callback of
  * the reference tests the UNBOUNDED surface from the box's entry on (no clip to the box's exit or the ray's extent): kept.
- * Emissive quadrics are rejected (the reference's sampleParameterPoint is a stub with pdf 0).  Persistent pipeline only. */
+ * Emissive quadrics are rejected (the reference's sampleParameterPoint is a stub with pdf 0).  Every pipeline and the ray service trace them. */
 enum { PRGPU_ENTITY_MESH = 0, PRGPU_ENTITY_PLANE = 1, PRGPU_ENTITY_SPHERE = 2, PRGPU_ENTITY_QUADRIC = 3 };
 typedef struct prgpu_entity {
 	uint32_t first_tri;

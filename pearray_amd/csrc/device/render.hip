@@ -261,6 +261,30 @@ __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& s, Stack& st
 	trav_leaf_rec<M, true>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
 }
 
+// The scene's quadric entities (Embree user geometries in the reference, entities/quadric.cpp:131-231), tested once per ray when a lane
+// picks the ray up: a closest-hit ray starts its BVH walk with the nearest quadric hit as its limit, an occlusion ray that a quadric
+// occludes gets an unreachable limit, so that the root step ends it (REC_EMPTY must not enter a step loop: it carries the leaf bit).
+template <bool CLS>
+__device__ __forceinline__ void trav_quadrics(const DevScene& sc, Trav& s, bool any)
+{
+	for (uint32_t k = 0; k < sc.n_quadrics; ++k) {
+		const DevQuadric& Q = sc.quadrics[k];
+		float tq;
+		if (quadric_hit(Q, sc.entities[Q.entity].m, s.r.o, s.r.d, s.tmin, s.best.t, any, tq)) {
+			if (any) {
+				s.best.tri = Q.tri;
+				s.best.t   = -INFINITY;
+				break;
+			}
+			if (tq < s.best.t || (tq == s.best.t && Q.tri < s.best.tri)) {
+				s.best = Hit{ tq, 0.0f, 0.0f, Q.tri };
+				if (CLS)
+					s.cls = sc.tri_class[Q.tri];
+			}
+		}
+	}
+}
+
 // Persistent traversal loop shared by the four tracing kernels.  `load(i, o, d, tmin, tmax)` reads ray i,
 // `store(i, best)` writes its result.
 template <bool ANY, bool COUNT, typename LoadF, typename StoreF>
@@ -296,6 +320,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_
 						float tmin, tmax;
 						load(i, o, d, tmin, tmax);
 						trav_begin(s, st, o, d, tmin, tmax, sc.eps_t);
+						if (sc.n_quadrics) // (wavefront pipelines and the ray service: a run-time test; the path kernel compiles it per variant)
+							trav_quadrics<false>(sc, s, ANY);
 						my_ray	= i;
 						has_ray = true;
 					}
@@ -2029,7 +2055,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 	if (i < n_active) {
 		slot = active ? active[i] : slot_base + i;
 		if (sc.features)
-			shade_vertex<(FEAT_ALL & ~(FEAT_LPE | FEAT_QUADRICS))>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz); // light path expressions and quadric entities run in the persistent pipeline only
+			shade_vertex<(FEAT_ALL & ~FEAT_LPE)>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz); // (light path expressions run in the persistent pipeline only)
 		else
 			shade_vertex<0u>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 	}
@@ -2595,25 +2621,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				trav_begin(s, st, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, any ? rd.w - 0.001f : rd.w, sc.eps_t); // tfar rule: Scene.cpp:275
 				s.any	= any;
 				has_ray = true;
-				if (FEATS & FEAT_QUADRICS) { // the scene's quadric entities, once per ray: a hit bounds the BVH walk, an occluded shadow ray skips it
-					for (uint32_t k = 0; k < sc.n_quadrics; ++k) {
-						const DevQuadric& Q = sc.quadrics[k];
-						float tq;
-						if (quadric_hit(Q, sc.entities[Q.entity].m, s.r.o, s.r.d, s.tmin, s.best.t, any, tq)) {
-							if (any) { // occluded: nothing in the BVH is reachable any more, the root step ends the ray (REC_EMPTY must not
-									   // enter the step loop: it carries the leaf bit)
-								s.best.tri = Q.tri;
-								s.best.t   = -INFINITY;
-								break;
-							}
-							if (tq < s.best.t || (tq == s.best.t && Q.tri < s.best.tri)) {
-								s.best = Hit{ tq, 0.0f, 0.0f, Q.tri };
-								if (NQ > 1)
-									s.cls = sc.tri_class[Q.tri];
-							}
-						}
-					}
-				}
+				if (FEATS & FEAT_QUADRICS) // the scene's quadric entities, once per ray: a hit bounds the BVH walk, an occluded shadow ray skips it
+					trav_quadrics<(NQ > 1)>(sc, s, any);
 			}
 			if (COUNT)
 				t_refill += wall_clock64() - t0r;

@@ -545,8 +545,6 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		s->mode = prgpu_scene::LOCKSTEP;
 	else if (s->knobs.mode == 1)
 		s->mode = t.single_tap ? prgpu_scene::STREAMING : prgpu_scene::LOCKSTEP; // streaming folds per pixel: single-tap filters only
-	if ((s->sc.features & prd::FEAT_QUADRICS) && s->mode != prgpu_scene::PERSISTENT)
-		return fail(PRGPU_EUNSUPPORTED, "quadric entities are traced by the persistent pipeline only");
 	AL(s->pp_pixel, ns, false);
 	AL(s->pp_next, 1, true);
 	AL(s->pp_error, 1, true);
@@ -1347,8 +1345,6 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 		return fail(PRGPU_EINVAL, "null argument");
 	if (n == 0)
 		return PRGPU_OK;
-	if (s->sc.features & prd::FEAT_QUADRICS)
-		return fail(PRGPU_EUNSUPPORTED, "the ray service does not trace quadric entities");
 	HIP_TRY(hipSetDevice(s->device));
 	float *d_org = nullptr, *d_dir = nullptr, *d_tmin = nullptr, *d_tmax = nullptr, *d_u = nullptr, *d_v = nullptr, *d_t = nullptr;
 	uint32_t *d_e = nullptr, *d_p = nullptr;
@@ -1382,7 +1378,7 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	// closest-hit service rays take the split traversal (leaf tests through an LDS task queue: identical results, 17 % faster) unless
 	// PRGPU_TRACE_SPLIT=0 or the tree has too many records for the 24-bit task field
 	const bool split = read_knobs().trace_split;
-	if (split && s->sc.n_leaf > 0 && s->sc.n_inner + 2ull * s->sc.n_leaf < (1ull << 24) && !(s->sc.features & prd::FEAT_SPHERES)) {
+	if (split && s->sc.n_leaf > 0 && s->sc.n_inner + 2ull * s->sc.n_leaf < (1ull << 24) && !(s->sc.features & (prd::FEAT_SPHERES | prd::FEAT_QUADRICS))) {
 		prd::launch_service_closest_split(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, const_cast<uint32_t*>(s->sc.tri_slot), s->gstats, s->stream);
 	} else
 		prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->gstats, s->stream);
@@ -1410,8 +1406,6 @@ int prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* d
 		return fail(PRGPU_EINVAL, "null argument");
 	if (n == 0)
 		return PRGPU_OK;
-	if (s->sc.features & prd::FEAT_QUADRICS)
-		return fail(PRGPU_EUNSUPPORTED, "the ray service does not trace quadric entities");
 	HIP_TRY(hipSetDevice(s->device));
 	float *d_org = nullptr, *d_dir = nullptr, *d_tmin = nullptr, *d_dist = nullptr;
 	uint8_t* d_occ = nullptr;

@@ -226,16 +226,43 @@ def test_gpu_quadric_scene_is_bit_exact_and_shards_over_tiles():
     for k in range(len(exprs)):
         assert np.array_equal(gl.lpe(k), ol.lpe(k)), exprs[k]
     assert gl.lpe(1).any() and gl.lpe(2).any()                       # through the glass ellipsoid, off the metal cylinder
-    # the other pipelines and the ray service say what they do not do
-    with pytest.raises(abi.PrgpuError, match="ray service"):
-        g.traceRays(np.zeros((1, 3), np.float32), np.array([[0, 0, 1]], np.float32), np.full(1, 1e-4, np.float32), np.full(1, np.inf, np.float32))
-    with pytest.raises(abi.PrgpuError, match="ray service"):
-        g.traceShadowRays(np.zeros((1, 3), np.float32), np.array([[0, 0, 1]], np.float32), np.full(1, 1e-4, np.float32), np.full(1, 10.0, np.float32))
 
 
 @pytest.mark.gpu
-def test_gpu_quadrics_are_rejected_outside_the_persistent_pipeline(monkeypatch):
+@pytest.mark.parametrize("mode", ["lockstep", "streaming"])
+def test_gpu_quadrics_in_the_wavefront_pipelines(monkeypatch, mode):
+    """The quadric test sits where a lane picks a ray up, in every tracing kernel: the lockstep and streaming pipelines render the scene
+    like the persistent kernel and the checker do, bit for bit."""
     from pearray_amd import backend
-    monkeypatch.setenv("PRGPU_MODE", "lockstep")
-    with pytest.raises(abi.PrgpuError, match="persistent pipeline"):
-        backend.RenderContext(scene.PrcScene(source=QUADRIC_SCENE % (32, 24, 2)))
+    monkeypatch.setenv("PRGPU_MODE", mode)
+    s = scene.PrcScene(source=QUADRIC_SCENE % (96, 72, 6))
+    g = backend.RenderContext(s); g.render(2); g.render(4); g.waitForFinish()
+    o = ob.OracleScene(s); o.render(6, threads=16)
+    gx, gs, gf = g.output(); ox, os_, of = o.output()
+    assert np.array_equal(g.primaryHits()[0], o.primary_hits()[0])
+    assert np.array_equal(gs, os_) and np.array_equal(gf, of) and g.statistics() == o.statistics()
+    assert np.array_equal(gx, ox)
+
+
+@pytest.mark.gpu
+def test_gpu_ray_service_traces_quadrics():
+    """prgpu_trace_closest / prgpu_trace_any (the IArchive surface) over a scene with quadric entities: entity, primitive, distance and
+    occlusion equal the checker's for rays through the cone, the cylinder, the ellipsoid, the hyperboloid and past them -- including the
+    reference's occlusion callback, which reports the unbounded surface behind a quadric's box."""
+    from pearray_amd import backend
+    s = scene.PrcScene(source=QUADRIC_SCENE % (32, 24, 1))
+    g, o = backend.RenderContext(s), ob.OracleScene(s)
+    rng = np.random.default_rng(11)
+    n = 20000
+    org = np.stack([rng.uniform(-3, 3, n), rng.uniform(0.05, 3, n), rng.uniform(-3, 5, n)], 1).astype(np.float32)
+    target = np.stack([rng.uniform(-2, 2, n), rng.uniform(0, 1.5, n), rng.uniform(-2, 1, n)], 1).astype(np.float32)
+    d = target - org; d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    tmin, tmax = np.full(n, 1e-4, np.float32), np.full(n, np.inf, np.float32)
+    tmax[::7] = 2.5                                                      # some rays end before they reach anything
+    ge, gp, gu, gv, gt = g.traceRays(org, d, tmin, tmax)
+    oe, op, ou, ov, ot = o.trace_closest(org, d, tmin, tmax)
+    assert np.array_equal(ge, oe) and np.array_equal(gp, op) and np.array_equal(gt, ot) and np.array_equal(gu, ou) and np.array_equal(gv, ov)
+    hit_kinds = set(np.unique(ge).tolist())
+    assert {0, 2, 3, 4, 5} <= hit_kinds                                  # floor, cone, cylinder, ellipsoid, hyperboloid
+    dist = rng.uniform(0.5, 8, n).astype(np.float32)
+    assert np.array_equal(g.traceShadowRays(org, d, tmin, dist), o.trace_any(org, d, tmin, dist))
