@@ -802,6 +802,35 @@ def test_c4_full_resolution_one_iteration_bit_exact():
     assert_parity(g, o, exact=True)
 
 
+def test_c4_headline_config_runs_its_whole_schedule(monkeypatch):
+    """BASELINE config C4 to the end: 1920 x 1080 x 1024 spp (2.12 G camera samples, seventeen bounded launches of the persistent kernel).
+    The checker cannot follow that far (45 minutes), so the size-independent properties stand in: no pixel has more than its 1024 samples, the
+    frame is finite, the statistics add up, the first iteration of the run equals the checker-verified one (test above), and a second run cut into
+    different launches (PRGPU_PP_LAUNCH_SAMPLES) and different render calls gives the same frame bit for bit."""
+    W, H, SPP = 1920, 1080, 1024
+    sc = scene.cornell_soup(W, H, spp=SPP, n_triangles=1_000_000)
+    a = backend.RenderContext(sc)
+    a.render(1); a.waitForFinish()
+    first = a.output()[0].copy()
+    a.render(SPP - 1); a.waitForFinish()
+    xa, sa, fa = a.output()
+    st = a.statistics()
+    assert sa.max() == SPP and np.isfinite(xa).all() and not fa.any()          # (the plane counts the samples that pushed a fragment)
+    assert st["pixel_samples"] == W * H * SPP and st["primary_rays"] == W * H * SPP
+    assert st["camera_rays"] == st["primary_rays"] + st["bounce_rays"]
+    assert 4.0 < st["camera_depth"] / st["pixel_samples"] < 4.1                              # mean path depth of the scene (4.054)
+    monkeypatch.setenv("PRGPU_PP_LAUNCH_SAMPLES", str(40 << 20))                             # 20 iterations per launch instead of 61
+    b = backend.RenderContext(sc)
+    b.render(1); b.waitForFinish()
+    assert np.array_equal(b.output()[0], first)
+    for n in (300, 23, 700):
+        b.render(n)
+    b.waitForFinish()
+    xb, sb, fb = b.output()
+    assert np.array_equal(xa, xb) and np.array_equal(sa, sb) and b.statistics() == st
+    assert xa[..., 1].mean() > 0.01
+
+
 def test_c5_full_resolution_one_iteration_bit_exact():
     """BASELINE config C5 at its full size: examples/complex.prc as shipped (its sky light's Hosek-Wilkie table built by the library),
     1920 x 1080 -- two whole iterations against the checker, bit for bit."""
