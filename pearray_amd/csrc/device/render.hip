@@ -655,7 +655,7 @@ __device__ __forceinline__ void fold_iteration(const PathState& ps, uint32_t pix
 		}
 		ps.out_xyz[3 * pixel + c] = (ps.out_xyz[3 * pixel + c] * itm1 + value[c]) / it;
 	}
-	if (with_lpe && ps.lpe) // the expressions' planes average like the main one (persistent kernel variant with FEAT_LPE only)
+	if (with_lpe && ps.lpe) // the expressions' planes average like the main one (single-tap filters: folded per pixel)
 		for (uint32_t k = 0; k < ps.lpe->n; ++k) {
 			float* out		  = ps.lpe->out[k];
 			const float* iter_ = ps.lpe->iter[k];
@@ -920,7 +920,7 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene sc, PathState ps, uint3
 	const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
 	if (local < n_slots) {
 		ps.iter[slot_base + local] = iter;
-		camera_path(sc, ps, slot_base + local, iter, bs);
+		camera_path(sc, ps, slot_base + local, iter, bs, ps.lpe != nullptr);
 	}
 	stats_flush(bs, gstats);
 }
@@ -941,10 +941,10 @@ __global__ void __launch_bounds__(256) k_regen(DevScene sc, PathState ps, const 
 		const uint32_t pixel = ps.pixel[slot];
 		const uint32_t iter	 = ps.iter[slot];
 		const float v[3] = { ps.iter_xyz[3 * pixel], ps.iter_xyz[3 * pixel + 1], ps.iter_xyz[3 * pixel + 2] };
-		fold_iteration(ps, pixel, iter, v);
+		fold_iteration(ps, pixel, iter, v, ps.lpe != nullptr);
 		if (iter + 1 < iter_end) {
 			ps.iter[slot] = iter + 1;
-			camera_path(sc, ps, slot, iter + 1, bs);
+			camera_path(sc, ps, slot, iter + 1, bs, ps.lpe != nullptr);
 			alive = true;
 		}
 	}
@@ -2054,8 +2054,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene sc, PathState ps, const 
 	float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
 	if (i < n_active) {
 		slot = active ? active[i] : slot_base + i;
-		if (sc.features)
-			shade_vertex<(FEAT_ALL & ~FEAT_LPE)>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz); // (light path expressions run in the persistent pipeline only)
+		if (ps.lpe) // light path expressions: the body that carries the automaton states (wave-uniform choice, like the other two)
+			shade_vertex<FEAT_ALL>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
+		else if (sc.features)
+			shade_vertex<(FEAT_ALL & ~FEAT_LPE)>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 		else
 			shade_vertex<0u>(sc, ps, slot, bs, alive, want_shadow, sh_o, sh_d, sh_xyz);
 	}
@@ -2103,7 +2105,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_shadow(DevScene sc, PathSt
 				ps.feedback[pixel] |= fb;
 		} else {
 			const float xyz[3] = { x.x, x.y, x.z };
-			apply_fragment(ps, pixel, entry, fbs & 0xFFu, xyz);
+			apply_fragment(ps, pixel, entry, fbs & 0xFFu, xyz, (fbs >> 16) & 0xFu); // (bits 16..19: the expressions the NEE path matches; 0 without any)
 		}
 	};
 	trace_persistent<true, COUNT>(sc, n, queue_head, spill, refill_below, load, store, gstats);

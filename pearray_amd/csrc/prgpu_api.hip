@@ -737,6 +737,17 @@ int render_iteration(prgpu_scene* s, uint32_t iter)
 	s->time_begin(4, s->stream);
 	prd::launch_resolve(s->sc, s->ps, iter, s->stream);
 	s->time_end(s->stream);
+	if (s->ps.lpe) { // the light path expressions' planes resolve like the main one (LocalFrameOutputDevice.cpp:99-113: same weights)
+		prd::PathState pl  = s->ps;
+		pl.online_mean	   = nullptr; // (the estimator follows the main plane only)
+		pl.online_variance = nullptr;
+		pl.lpe			   = nullptr;
+		for (uint32_t k = 0; k < s->lpe_host.n; ++k) {
+			pl.out_xyz	= s->lpe_host.out[k];
+			pl.iter_xyz = s->lpe_host.iter[k];
+			prd::launch_resolve(s->sc, pl, iter, s->stream);
+		}
+	}
 	HIP_TRY(hipEventRecord(s->ev_resolve, s->stream));
 	s->resolve_recorded = true;
 	HIP_TRY(hipGetLastError());
@@ -1753,8 +1764,7 @@ int prgpu_enable_lpe(prgpu_scene* s, uint32_t n, const char* const* expressions)
 	s->ps.lpe	= dev;
 	for (auto& g : s->groups)
 		g.ps.lpe = dev;
-	s->sc.features |= prd::FEAT_LPE;
-	s->mode = prgpu_scene::PERSISTENT; // the planes are folded per pixel by the persistent kernel
+	s->sc.features |= prd::FEAT_LPE; // (selects the top variant of the persistent kernel; the wavefront pipelines test ps.lpe)
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	return PRGPU_OK;
 }

@@ -1228,6 +1228,30 @@ def test_light_path_expression_planes_with_multi_tap_pixel_filters(flt, r):
     assert np.array_equal(g.lpe(0), g.output()[0])
 
 
+@pytest.mark.parametrize("mode", ["lockstep", "streaming"])
+@pytest.mark.parametrize("flt,r", [(abi.FILTER_BLOCK, 0), (abi.FILTER_GAUSSIAN, 2)])
+def test_light_path_expression_planes_in_the_wavefront_pipelines(monkeypatch, mode, flt, r):
+    """The automaton states ride in every pipeline: the lockstep and streaming wavefronts (k_raygen / k_shade / k_trace_shadow / k_resolve,
+    k_regen) produce the planes the persistent kernel and the checker produce -- bit for bit with a single-tap filter; with a multi-tap one
+    (lockstep: streaming folds per pixel and falls back to it) equal to the persistent pipeline's bit for bit and to the checker to 1e-5."""
+    sc = scene.cornell_glassy(64, 48, spp=6, filter=flt, filter_radius=r)
+    exprs = ["C.*L", "C<T,S>+<R,D>E", "CD*E", "C[DS]*<R,S>[DS]*E"]
+    monkeypatch.setenv("PRGPU_MODE", "persistent")
+    ref = backend.RenderContext(sc); ref.enableLPE(exprs); ref.render(6); ref.waitForFinish()
+    monkeypatch.setenv("PRGPU_MODE", mode)
+    g = backend.RenderContext(sc); g.enableLPE(exprs)
+    for n in (2, 1, 3):
+        g.render(n)
+    g.waitForFinish()
+    o = ob.OracleScene(sc); o.enable_lpe(exprs); o.render(6, threads=8)
+    assert np.array_equal(g.output()[0], ref.output()[0]) and g.statistics() == ref.statistics()
+    for k in range(len(exprs)):
+        assert np.array_equal(g.lpe(k), ref.lpe(k)), (mode, exprs[k])
+        assert (np.array_equal(g.lpe(k), o.lpe(k)) if r == 0 else rel_l2(g.lpe(k), o.lpe(k)) <= 1e-5), (mode, exprs[k])
+        assert g.lpe(k).any()
+    assert np.array_equal(g.lpe(0), g.output()[0])
+
+
 def test_lpe_planes_shard_over_tiles_and_pass_the_reduce(monkeypatch):
     """The LPE planes of the ranks' tile shares are zero outside the share and add up to the planes of the unsharded frame; prgpu_reduce
     carries them (a genuine one-rank RCCL communicator: the sum over one rank is the identity)."""
