@@ -4937,6 +4937,23 @@ float orc_agh_sample(float u, float N, float C) { return agh_sample(u, N, C); }
 float orc_agh_pdf(float lambda, float N) { return agh_pdf(lambda, N); }
 float orc_safe_acos(float x) { return safe_acos(x); }
 void orc_sincos_rad(float x, float* s, float* c) { sincos_rad(x, *s, *c); }
+// Spherical::uv_from_normal / cartesian_from_uv (base/math/Spherical.h:22-26,49-53) as the environment light and the sphere light use them;
+// pinned by the round trips of the reference's src/tests/sphere.cpp:12-67
+void orc_uv_from_normal(const float n[3], float uv[2]) { uv_from_direction(v3(n[0], n[1], n[2]), uv[0], uv[1]); }
+void orc_cartesian_from_uv(float u, float v, float out[3])
+{
+	float st, ct, sp, cp;
+	sincos_rad(v * PR_PI_F, st, ct);
+	sincos_rad(u * 2 * PR_PI_F, sp, cp);
+	out[0] = st * cp; out[1] = st * sp; out[2] = ct;
+}
+// BoundingBox::intersectsRange (geometry/BoundingBox.cpp:50-70) as the quadric callbacks use it; pinned by src/tests/boundingbox.cpp:128-280
+int orc_box_range(const float lo[3], const float hi[3], const float o[3], const float d[3], float range[2])
+{
+	const BoxRange r = box_range(v3(lo[0], lo[1], lo[2]), v3(hi[0], hi[1], hi[2]), v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2]));
+	range[0] = r.entry; range[1] = r.exit;
+	return r.exit >= r.entry ? 1 : 0; // IntersectionRange::Successful (BoundingBox.cpp:68)
+}
 void orc_reflect(const float v[3], float out[3]) // Scattering::reflect(V) in shading space (Scattering.h:69-72)
 {
 	out[0] = -v[0]; out[1] = -v[1]; out[2] = v[2];

@@ -119,6 +119,10 @@ def bind(lib):
     lib.orc_safe_acos.restype = C.c_float
     lib.orc_safe_acos.argtypes = [C.c_float]
     lib.orc_sincos_rad.argtypes = [C.c_float, _F32P, _F32P]
+    lib.orc_uv_from_normal.argtypes = [_F32P, _F32P]
+    lib.orc_cartesian_from_uv.argtypes = [C.c_float, C.c_float, _F32P]
+    lib.orc_box_range.restype = C.c_int
+    lib.orc_box_range.argtypes = [_F32P, _F32P, _F32P, _F32P, _F32P]
     lib.orc_material_eval.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _F32P, _F32P, _F32P, C.POINTER(C.c_int)]
     lib.orc_rough_sample.argtypes = [C.c_void_p, C.c_uint32, _F32P, _F32P, _U64P, _F32P, _F32P, _F32P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.orc_set_tile_grid.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
