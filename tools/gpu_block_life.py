@@ -30,6 +30,8 @@ print("slowest blocks:", [(int(rows[i, 0]), round(float(life[i]), 3), int(work[i
 print("fastest blocks:", [(int(rows[i, 0]), round(float(life[i]), 3), int(work[i])) for i in order[:6]])
 cost = ctx.pathCost().astype(np.float64).reshape(-1)
 own = cost > 0
+if not own.any():   # the per-pixel path cost is only kept while every owned pixel is in flight at once (small tile shares)
+    sys.exit(0)
 c = cost[own] / (8 + iters)      # vertices per sample (the warm-up iterations count too)
 inbox = c > 1.5
 print("owned pixels %d, in-box %d; vertices per sample: mean %.2f, in-box mean %.2f p50 %.2f p90 %.2f p99 %.2f p99.9 %.2f max %.2f" % (
