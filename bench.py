@@ -101,6 +101,9 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+PMC_EXTRA = {}   # issue / texture-path occupancy of the same launches, from the same summary (filled by pmc_traffic)
+
+
 def pmc_traffic(kernel_signature):
     """HBM-side bytes per ITERATION of the dominant kernel from the newest committed rocprofv3 --pmc summary (PMC counters cannot
     be read from inside this process): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- the gfx950 correction of MI355X_MICROARCH.md (HBM:
@@ -120,6 +123,13 @@ def pmc_traffic(kernel_signature):
             continue
         for name, k in summ["kernels"].items():
             if kernel_signature in name.replace(" ", "") and "FETCH_SIZE_per_iteration" in k:
+                PMC_EXTRA.clear()
+                cycles = k.get("GRBM_GUI_ACTIVE_per_iteration", 0.0) / 8.0    # summed over the 8 XCDs
+                if cycles and "SQ_INSTS_VALU_per_iteration" in k:              # what the kernel is really bound by
+                    PMC_EXTRA.update({"valu_issue_busy": round(k["SQ_INSTS_VALU_per_iteration"] * 4.0 / (1024.0 * cycles), 3),  # 1024 SIMDs, 4 cycles per wave64 instruction
+                                      "ta_busy": round(k.get("TA_TA_BUSY_sum_per_iteration", 0.0) / (256.0 * cycles), 3),
+                                      "l2_hit": round(k["TCC_HIT_sum_per_iteration"] / (k["TCC_HIT_sum_per_iteration"] + k["TCC_MISS_sum_per_iteration"]), 3)
+                                      if "TCC_HIT_sum_per_iteration" in k else None})
                 return (2.0 * k["FETCH_SIZE_per_iteration"] + k["WRITE_SIZE_per_iteration"]) * 1024.0, rel, None
         reason = reason or "%s holds no counters for %s" % (rel, kernel_signature)
     return None, None, reason or "no profiles/r*_pmc_summary.json"
@@ -166,7 +176,8 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u"):
     records = d["nodes_closest"] + d["leaves_closest"] + d["nodes_any"] + d["leaves_any"]
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1) if traffic_bytes else None,
-            "traffic_bytes_per_launch": traffic_bytes, "traffic_source": src, "traffic_unavailable": why_not, "kernel": kernel, "avg_launch_ms": round(avg_ms, 4),
+            "traffic_bytes_per_launch": traffic_bytes, "traffic_source": src, "traffic_unavailable": why_not, "pmc": dict(PMC_EXTRA) if traffic_bytes else None,
+            "kernel": kernel, "avg_launch_ms": round(avg_ms, 4),
             "launches": n, "iterations_per_launch": iters_per_launch, "algorithmic_bytes_per_launch": round(alg_bytes),
             "algorithmic_bytes_per_closest_ray": round(bytes_closest / max(d["rays_closest"], 1), 1),
             "algorithmic_bytes_per_occlusion_ray": round(bytes_any / max(d["rays_any"], 1), 1),
