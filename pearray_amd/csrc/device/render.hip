@@ -2166,6 +2166,14 @@ __global__ void __launch_bounds__(256) k_resolve(DevScene sc, PathState ps, uint
 #ifndef PR_PP_SLOTS_MAX
 #define PR_PP_SLOTS_MAX (PP_BLOCK == 768 ? 1536 : 512) // slots per block; more than 512 per 256 lanes was never faster (C5: 13.7 ms at 512, 15.8 at 768, 17.1 at 1024)
 #endif
+// Wave priorities (s_setprio) of the three short phases that feed other waves: a shading pass, a ray pick-up, a write-out of finished rays.
+// Traversal steps run at 0.  Measured together: C4 -0.7 %, 1/8 share -1 %, C5 -4 % time (profiles/r03_shading_priority_ab.log).
+#ifndef PR_FIN_PRIO
+#define PR_FIN_PRIO 2
+#endif
+#ifndef PR_REFILL_PRIO
+#define PR_REFILL_PRIO 2
+#endif
 #ifndef PR_SHADE_PRIO
 #define PR_SHADE_PRIO 3 // wave priority during a shading pass (0: none), see path_persistent
 #endif
@@ -2623,6 +2631,9 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 		// a few waves instead of keeping every wave stepping with a handful of lanes -- higher lane utilisation, same time.)
 		const unsigned long long idle = __ballot(!has_ray);
 		if (!shader && idle != 0ull && n_queued > 0u) {
+#if PR_REFILL_PRIO
+			__builtin_amdgcn_s_setprio(PR_REFILL_PRIO);
+#endif
 			const unsigned long long t0r = COUNT ? wall_clock64() : 0ull;
 			uint32_t first;
 			const uint32_t n = ring_claim(&sh.ray_head, &sh.ray_tail, (uint32_t)__popcll(idle), first);
@@ -2638,6 +2649,9 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				if (FEATS & FEAT_QUADRICS) // the scene's quadric entities, once per ray: a hit bounds the BVH walk, an occluded shadow ray skips it
 					trav_quadrics<(NQ > 1)>(sc, s, any);
 			}
+#if PR_REFILL_PRIO
+			__builtin_amdgcn_s_setprio(0);
+#endif
 			if (COUNT)
 				t_refill += wall_clock64() - t0r;
 		}
@@ -2719,6 +2733,9 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			}
 			const unsigned long long t0f = COUNT ? wall_clock64() : 0ull;
 			if (__any(fin)) {
+#if PR_FIN_PRIO
+				__builtin_amdgcn_s_setprio(PR_FIN_PRIO);
+#endif
 				bool last	   = false;
 				uint32_t entry = 0;
 				int qcls	   = 0;
@@ -2750,6 +2767,9 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				}
 				for (int q = 0; q < NQ + 1; ++q)
 					ring_push(sh.q_shade[q], SHADE_MASK, &sh.shade_tail[q], last && qcls == q, entry);
+#if PR_FIN_PRIO
+				__builtin_amdgcn_s_setprio(0);
+#endif
 				if (COUNT)
 					t_fin += wall_clock64() - t0f;
 			}
