@@ -1446,6 +1446,7 @@ int prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* d
 // ---- multi-GPU reduce over RCCL --------------------------------------------------------------------------------------------
 // RCCL is bound at run time (dlopen by soname): a host that already carries one (PyTorch bundles its own librccl.so.1) keeps using
 // that copy, and a single-GPU host never needs the library at all.
+} // extern "C" (the run-time binding below is C++)
 namespace {
 typedef int nccl_result_t;
 struct NcclId {
@@ -1498,6 +1499,7 @@ Rccl& rccl()
 // ncclDataType_t / ncclRedOp_t values of rccl.h (stable since NCCL 2.0)
 constexpr int NCCL_UINT32 = 3, NCCL_FLOAT32 = 7, NCCL_SUM = 0, NCCL_MAX = 2;
 } // namespace
+extern "C" {
 
 struct prgpu_comm {
 	int n_ranks = 1, rank = 0, device = 0;
