@@ -23,13 +23,13 @@ ctx.setInstrumentation(True); ctx.render(iters); ctx.waitForFinish(); ctx.setIns
 b = ctx.traceCounters()
 d = {k: b[k] - a[k] for k in b if isinstance(b[k], int)}
 rc, ra = max(d["rays_closest"], 1), max(d["rays_any"], 1)
-steps = d["wave_steps_closest"] + (0 if os.environ.get("SPLIT_STEPS_INCLUDE_LEAF", "1") == "1" else d["wave_steps_any"])
+steps = d["wave_steps_closest"]   # (the persistent kernel counts every wave step here, whichever kind of ray its lanes hold)
 recs = d["nodes_closest"] + d["leaves_closest"] + d["nodes_any"] + d["leaves_any"]
 tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("PRGPU_"))
 print("[%s] %s share 1/%d: %.3f ms/iteration (plain kernel)" % (tag, which, world, dt))
 print("  per iteration: closest rays %.2f M, occlusion rays %.2f M; inner/leaf records per closest ray %.2f / %.2f, per occlusion ray %.2f / %.2f"
       % (rc / iters / 1e6, ra / iters / 1e6, d["nodes_closest"] / rc, d["leaves_closest"] / rc, d["nodes_any"] / ra, d["leaves_any"] / ra))
-print("  wave steps per iteration %.2f M (of which leaf steps %.2f M); records per step %.1f (lane utilisation %.3f)"
-      % (steps / iters / 1e6, d["wave_steps_any"] / iters / 1e6, recs / max(steps, 1), recs / max(64 * steps, 1)))
+print("  wave steps per iteration %.2f M; records per step %.1f (lane utilisation %.3f)"
+      % (steps / iters / 1e6, recs / max(steps, 1), recs / max(64 * steps, 1)))
 print("  shading passes per iteration %.1f k, fill %.3f; wave time: shading %.1f %%, idle %.1f %%"
       % (d["shade_batches"] / iters / 1e3, d["shade_lanes"] / max(64 * d["shade_batches"], 1), 100.0 * d["shade_ticks"] / max(d["total_ticks"], 1), 100.0 * d["idle_ticks"] / max(d["total_ticks"], 1)))
