@@ -1,6 +1,6 @@
 """Randomised parity: scenes nobody designed.  A seeded generator throws together geometry (boxes of random pose and size, loose triangles,
 plane / sphere / quadric entities), materials of every closure the path knows (Lambert, mirror, smooth and rough dielectric and conductor,
-principled), lights (an emissive panel plus any of environment, distant, sun, CIE sky), one of the four cameras, and render settings
+principled), lights (an emissive panel, now and then a second emitter, plus any of plain or textured environment, distant, sun, CIE sky, Hosek sky), one of the four cameras, and render settings
 (sampler, spectral mapper, MIS, NEE, hero wavelengths, depth limits, pixel filter) -- the HIP path must reproduce the checker on every one:
 primary hit ids, sample and feedback planes, the eleven statistics, and the frame bit for bit (single-tap filters) or to 1e-5 (multi-tap)."""
 import os
@@ -34,9 +34,11 @@ BOX_P = [[-1, -1, -1], [1, -1, -1], [1, 1, -1], [-1, 1, -1], [-1, -1, 1], [1, -1
 BOX_F = [[0, 3, 2, 1], [4, 5, 6, 7], [0, 1, 5, 4], [2, 3, 7, 6], [1, 2, 6, 5], [0, 4, 7, 3]]
 
 
-def _material(b, rng):
+def _material(b, rng, textured=False):
     kind = rng.integers(0, 9)
-    c = lambda lo=0.2, hi=0.9: b.refl(*rng.uniform(lo, hi, 3))   # noqa: E731
+    plain = lambda lo=0.2, hi=0.9: b.refl(*rng.uniform(lo, hi, 3))   # noqa: E731
+    # with texture coordinates around, reflectances may be checkerboards of two colours (CheckerboardNode: unscaled, isotropic, anisotropic)
+    c = (lambda lo=0.2, hi=0.9: b.checkerboard(plain(lo, hi), plain(lo, hi), *([None, None], [4.0, None], [3.0, 7.0])[int(rng.integers(3))])) if textured else plain   # noqa: E731
     if kind == 0 or kind == 1:
         return b.lambert(c())
     if kind == 2:
@@ -69,7 +71,7 @@ def random_scene(seed, width=56, height=40):
     s.filter, s.filter_radius = (int(rng.choice([abi.FILTER_GAUSSIAN, abi.FILTER_TRIANGLE, abi.FILTER_LANCZOS])), int(rng.integers(1, 3))) if multi_tap else (abi.FILTER_BLOCK, 0)
     # a floor, an emissive panel, then whatever the dice say
     floor = b.lambert(b.refl(0.6, 0.6, 0.6))
-    light = rng.integers(0, 5)   # 0: the panel alone; 1 .. 4: plus an infinite light
+    light = rng.integers(0, 7)   # 0: the panel alone; 1 .. 6: plus an infinite light
     if light == 0 or rng.integers(2):   # a closed room (always when the panel is the only light): paths bounce until roulette ends them
         room = np.eye(4, dtype=np.float32); room[0, 0] = room[1, 1] = 8.5; room[2, 2] = 3.0; room[2, 3] = 3.0
         b.add_mesh(BOX_P, BOX_F if light == 0 else BOX_F[:1] + BOX_F[2:], b.lambert(b.refl(*rng.uniform(0.4, 0.8, 3))), transform=room)   # (open to the sky: no ceiling)
@@ -80,16 +82,21 @@ def random_scene(seed, width=56, height=40):
     for _ in range(int(rng.integers(2, 6))):
         pos = [rng.uniform(-2.5, 2.5), rng.uniform(-2.5, 2.5), rng.uniform(0.3, 2.0)]
         what = rng.integers(0, 7)
-        m = _material(b, rng)
+        textured = what <= 2 and rng.integers(3) == 0
+        m = _material(b, rng, textured)
+        emission = b.diffuse_emission(b.illum(*rng.uniform(1, 4, 3))) if what in (2, 4, 5) and rng.integers(5) == 0 else None   # a second, small light
         if what <= 2:
-            b.add_mesh(BOX_P, BOX_F, m, transform=_xf(rng, pos, rng.uniform(0.2, 0.8, 3)))
+            P = np.asarray(BOX_P, dtype=np.float32)
+            b.add_mesh(BOX_P, BOX_F, m, transform=_xf(rng, pos, rng.uniform(0.2, 0.8, 3)), emission=emission,
+                       normals=(P / np.linalg.norm(P, axis=1, keepdims=True)).tolist() if rng.integers(3) == 0 else None,     # smooth-shaded box
+                       uvs=((P[:, :2] + 1) / 2).tolist() if textured else None)
         elif what == 3:   # a handful of loose triangles
             p = rng.uniform(-0.8, 0.8, (12, 3)).astype(np.float32)
             b.add_mesh(p.tolist(), [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]], m, transform=_xf(rng, pos, 1.0))
         elif what == 4:
-            b.add_sphere(m, radius=float(rng.uniform(0.3, 0.8)), transform=_xf(rng, pos, 1.0))
+            b.add_sphere(m, radius=float(rng.uniform(0.3, 0.8)), transform=_xf(rng, pos, 1.0), emission=emission)
         elif what == 5:
-            b.add_plane(m, width=float(rng.uniform(0.5, 2)), height=float(rng.uniform(0.5, 2)), centering=True, transform=_xf(rng, pos, 1.0))
+            b.add_plane(m, width=float(rng.uniform(0.5, 2)), height=float(rng.uniform(0.5, 2)), centering=True, transform=_xf(rng, pos, 1.0), emission=emission)
         else:
             b.add_quadric(m, [1.0, float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 3)), -0.25], (-0.6, -0.6, -0.6), (0.6, 0.6, 0.6), transform=_xf(rng, pos, 1.0))
     if light == 1:
@@ -98,6 +105,11 @@ def random_scene(seed, width=56, height=40):
         b.distant_light(b.illum(2, 2, 2), direction=tuple(rng.uniform(-1, 1, 2)) + (-1.0,))
     elif light == 3:
         b.cie_sky_light(b.illum(1, 1, 1.2), cloudy=bool(rng.integers(2)))
+    elif light == 5:
+        b.sun_light((2.0e3 * (0.6 + 0.4 * np.sin(np.arange(64) * 0.11 + rng.uniform(0, 3)))).astype(np.float32), float(rng.uniform(0.3, 1.4)), float(rng.uniform(0, 6)), radius=float(rng.choice([0.5, 1.0, 6.0])))
+    elif light == 6:   # textured environment: a random low-resolution map, importance sampled or not
+        img = rng.uniform(0.0, 1.0, (int(rng.integers(2, 6)), int(rng.integers(2, 9)), 3)) ** 3
+        b.environment_light(b.illuminant_d65(), image=b.rgb_image_to_coefficients(img.astype(np.float32)), distribution=bool(rng.integers(3)), compensation=bool(rng.integers(4) == 0))
     elif light == 4:
         b.sky_light(scene.hosek_sky_table(float(rng.uniform(0.2, 1.3)), float(rng.uniform(0, 6)), turbidity=float(rng.uniform(2, 6)), elevation_count=16, azimuth_count=32), extend=bool(rng.integers(2)))
     eye = np.array([rng.uniform(-1, 1), -7.0 + rng.uniform(-1, 1), rng.uniform(1.0, 3.0)])
@@ -126,9 +138,13 @@ N_SCENES = int(os.environ.get("PRGPU_TEST_RANDOM_SCENES", "40"))   # more for a 
 def test_random_scene_matches_the_checker(seed):
     sc, multi_tap = random_scene(seed)
     g = backend.RenderContext(sc)
+    o = ob.OracleScene(sc)
+    if seed % 5 == 0:   # a rank's tile share instead of the whole film
+        from pearray_amd import tiling
+        tiles = tiling.tiles_for_rank(sc.width, sc.height, seed % 3, 3, tile=8)
+        g.setTiles(tiles); o.set_tiles(tiles)
     g.render(1); g.render(3)
     g.waitForFinish()
-    o = ob.OracleScene(sc)
     o.render(4, threads=8)
     gx, gs, gf = g.output(); ox, os_, of = o.output()
     assert np.array_equal(g.primaryHits()[0], o.primary_hits()[0]) and np.array_equal(g.primaryHits()[1], o.primary_hits()[1]), "primary hits"
