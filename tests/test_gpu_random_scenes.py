@@ -131,7 +131,7 @@ def random_scene(seed, width=56, height=40):
     return b.build(), multi_tap
 
 
-N_SCENES = int(os.environ.get("PRGPU_TEST_RANDOM_SCENES", "40"))   # more for a soak run: 600 scenes pass (round 3)
+N_SCENES = int(os.environ.get("PRGPU_TEST_RANDOM_SCENES", "40"))   # more for a soak run: 800 scenes pass (round 3)
 
 
 @pytest.mark.parametrize("seed", list(range(1, N_SCENES + 1)))
