@@ -81,7 +81,7 @@ def random_scene(seed, width=56, height=40):
     b.add_mesh([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]], [[0, 3, 2, 1]], floor, emission=lamp, transform=_xf(rng, [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(3, 4.5)], rng.uniform(0.4, 1.2)))
     for _ in range(int(rng.integers(2, 6))):
         pos = [rng.uniform(-2.5, 2.5), rng.uniform(-2.5, 2.5), rng.uniform(0.3, 2.0)]
-        what = rng.integers(0, 7)
+        what = rng.integers(0, 9)
         textured = what <= 2 and rng.integers(3) == 0
         m = _material(b, rng, textured)
         emission = b.diffuse_emission(b.illum(*rng.uniform(1, 4, 3))) if what in (2, 4, 5) and rng.integers(5) == 0 else None   # a second, small light
@@ -97,6 +97,17 @@ def random_scene(seed, width=56, height=40):
             b.add_sphere(m, radius=float(rng.uniform(0.3, 0.8)), transform=_xf(rng, pos, 1.0), emission=emission)
         elif what == 5:
             b.add_plane(m, width=float(rng.uniform(0.5, 2)), height=float(rng.uniform(0.5, 2)), centering=True, transform=_xf(rng, pos, 1.0), emission=emission)
+        elif what == 7:   # the same box twice, different materials: every hit on it is an exact tie, the smaller triangle index must win in both trees
+            T = _xf(rng, pos, rng.uniform(0.3, 0.7, 3))
+            b.add_mesh(BOX_P, BOX_F, m, transform=T)
+            b.add_mesh(BOX_P, BOX_F, _material(b, rng), transform=T)
+        elif what == 8:   # degenerate and sliver triangles among ordinary ones, far from the origin of their own mesh
+            p = (rng.uniform(-0.5, 0.5, (12, 3)) + 40.0).astype(np.float32)
+            p[4] = p[3]; p[5] = p[3]                          # a point
+            p[7] = (p[6] + p[8]) / 2                          # three collinear vertices
+            p[10] = p[9] + np.float32(1e-6)                   # a sliver
+            T = _xf(rng, pos, 1.0); T[:3, 3] -= T[:3, :3] @ np.full(3, 40.0, np.float32)
+            b.add_mesh(p.tolist(), [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]], m, transform=T)
         else:
             b.add_quadric(m, [1.0, float(rng.uniform(0.5, 2)), float(rng.uniform(0.5, 3)), -0.25], (-0.6, -0.6, -0.6), (0.6, 0.6, 0.6), transform=_xf(rng, pos, 1.0))
     if light == 1:
