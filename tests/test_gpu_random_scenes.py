@@ -177,3 +177,28 @@ def test_random_scene_in_the_wavefront_pipelines(monkeypatch, seed, mode):
     g = backend.RenderContext(sc); g.render(2); g.render(2); g.waitForFinish()
     assert g.statistics() == ref.statistics() and np.array_equal(g.output()[1], ref.output()[1])
     assert np.array_equal(g.output()[0], ref.output()[0])
+
+
+@pytest.mark.parametrize("seed", [2, 5, 9, 14, 20, 27, 33, 38])
+def test_random_scene_ray_service(seed):
+    """prgpu_trace_closest / prgpu_trace_any over the same random scenes (ties, degenerate triangles, spheres and quadrics included): entity,
+    primitive, barycentrics, distance and occlusion equal the checker's tree walk, and the checker's brute-force loop over every primitive."""
+    sc, _ = random_scene(seed)
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(1000 + seed)
+    n = 6000
+    org = np.stack([rng.uniform(-4, 4, n), rng.uniform(-7, 4, n), rng.uniform(0.05, 4, n)], 1).astype(np.float32)
+    d = np.stack([rng.uniform(-3, 3, n), rng.uniform(-3, 3, n), rng.uniform(0, 2.5, n)], 1).astype(np.float32) - org
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[::11] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, len(d[::11]))] * rng.choice([-1.0, 1.0], (len(d[::11]), 1)).astype(np.float32)   # axis-parallel rays
+    tmin, tmax = np.full(n, 1e-4, np.float32), np.full(n, np.inf, np.float32)
+    tmax[::5] = rng.uniform(0.5, 5, len(tmax[::5])).astype(np.float32)
+    got = g.traceRays(org, d, tmin, tmax)
+    for brute in (False, True):
+        want = o.trace_closest(org, d, tmin, tmax, brute=brute)
+        for a, b, what in zip(got, want, ("entity", "primitive", "u", "v", "t")):
+            assert np.array_equal(a, b), (what, brute, int((a != b).sum()))
+    dist = rng.uniform(0.3, 9, n).astype(np.float32)
+    occ = g.traceShadowRays(org, d, tmin, dist)
+    assert np.array_equal(occ, o.trace_any(org, d, tmin, dist)) and np.array_equal(occ, o.trace_any(org, d, tmin, dist, brute=True))
+    assert 0.05 < occ.mean() < 0.999
