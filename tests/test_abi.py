@@ -53,6 +53,24 @@ def test_environment_knobs_are_read_in_one_place():
                "PP_SLOTS PP_SHADE_MIN PP_SHADE_PARTIAL PP_FIN_BATCH PP_OCCUPANCY PP_SHADER PP_RESIDENT"), name
 
 
+FOLDED_PROBES = {"gpu_probe_modes.py", "gpu_probe_shares.py", "gpu_probe_share8.py", "gpu_share_ranks.py", "gpu_sweep_share8.sh"}
+
+
+def test_measurement_probes_are_the_ones_the_readme_names():
+    """tools/gpu_* are reproducible entry points, not a scrap heap: each one is named in README.md, and every probe or profile file that
+    README.md, DESIGN.md or INTEGRATION.md point to exists."""
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    for f in sorted(os.listdir(os.path.join(ROOT, "tools"))):
+        if f.startswith("gpu_"):
+            assert ("tools/" + f) in readme or f in readme, f
+    for doc in ("README.md", "DESIGN.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for rel in set(re.findall(r"`((?:tools|profiles|integration|oracle/ref)/[A-Za-z0-9_./-]+\.(?:py|sh|json|log|csv|txt|c|cpp))`", text)):
+            if "r01_" in rel or "r02_" in rel or "{" in rel or "*" in rel or os.path.basename(rel) in FOLDED_PROBES:
+                continue   # (history: DESIGN section 7 says which round-1 / round-2 probes were folded into the current ones)
+            assert os.path.exists(os.path.join(ROOT, rel)), (doc, rel)
+
+
 def test_struct_layouts_match_the_header(tmp_path):
     """sizeof/offsetof of every ABI struct as seen by a C compiler equal the ctypes mirror."""
     import subprocess
