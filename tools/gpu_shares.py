@@ -16,7 +16,7 @@ for world in worlds:
     for rank in range(world):
         ctx = backend.RenderContext(sc)
         if world > 1:
-            ctx.setTiles(tiling.tiles_for_rank(W, H, rank, world, tile=64 if world <= 2 else 16))
+            ctx.setTiles(tiling.tiles_for_rank(W, H, rank, world, tile=int(os.environ.get("SHARE_TILE", 64 if world <= 2 else 16))))   # SHARE_TILE: try another deal
         ctx.render(8); ctx.waitForFinish()          # warm-up (and the depth statistics tune_pixel_order wants)
         t = time.time(); ctx.render(iters); ctx.waitForFinish(); times.append((time.time() - t) / iters * 1e3)
         ctx.close()
