@@ -202,3 +202,31 @@ def test_random_scene_ray_service(seed):
     occ = g.traceShadowRays(org, d, tmin, dist)
     assert np.array_equal(occ, o.trace_any(org, d, tmin, dist)) and np.array_equal(occ, o.trace_any(org, d, tmin, dist, brute=True))
     assert 0.05 < occ.mean() < 0.999
+
+
+LPES = ["CE", "CDE", "C.*L", "C<T,S>+.*L", "C[DS]*<R,S>[DS]*E", "CD+L", "C.*B", "C<R,D>{1,2}E", "CS*DL", "C.+<T.>.*"]
+
+
+@pytest.mark.parametrize("seed", [4, 6, 12, 13, 16, 21, 24, 29, 35, 36, 38, 40])
+def test_random_scene_output_planes(seed):
+    """The output device over the same random scenes: shading-point AOV planes, the online mean / variance estimator and the planes of four
+    randomly drawn light path expressions equal the checker's (bit for bit with a single-tap pixel filter, 1e-5 with a multi-tap one)."""
+    sc, multi_tap = random_scene(seed)
+    rng = np.random.default_rng(5000 + seed)
+    exprs = [str(e) for e in rng.choice(LPES, 4, replace=False)]
+    aovs = [str(a) for a in rng.choice(abi.AOV_NAMES, 4, replace=False)]
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    for x in (g, o):
+        (x.enableAOVs if x is g else x.enable_aovs)(aovs)
+        (x.enableVariance if x is g else x.enable_variance)()
+        (x.enableLPE if x is g else x.enable_lpe)(exprs)
+    g.render(2); g.render(2); g.waitForFinish()
+    o.render(4, threads=8)
+    same = (lambda a, b: np.array_equal(a, b)) if not multi_tap else (lambda a, b: np.linalg.norm((a - b).ravel()) <= 1e-5 * max(np.linalg.norm(b.ravel()), 1e-20))
+    assert same(g.output()[0], o.output()[0]) and g.statistics() == o.statistics()
+    for k, e in enumerate(exprs):
+        assert same(g.lpe(k), o.lpe(k)), e
+    for a in aovs:
+        assert np.array_equal(g.aov(a), o.aov(a)), a          # (AOV sums are per pixel, no filter taps)
+    gm, gv = g.variance(); om, ov = o.variance()
+    assert same(gm, om) and same(gv, ov)
