@@ -59,7 +59,7 @@ def random_scene(seed, width=56, height=40):
     b = scene.SceneBuilder(width, height)
     s = b.settings
     s.aa_sampler = int(rng.choice([abi.SAMPLER_RANDOM, abi.SAMPLER_MJITT, abi.SAMPLER_SOBOL, abi.SAMPLER_HALTON, abi.SAMPLER_HAMMERSLEY, abi.SAMPLER_UNIFORM, abi.SAMPLER_STRATIFIED]))
-    s.aa_samples = 4
+    s.aa_samples = max(4, int(os.environ.get("PRGPU_TEST_RANDOM_ITERS", "4")))
     s.mapper = int(rng.choice([abi.MAPPER_SPD_CMIS, abi.MAPPER_SPD_CMIS, abi.MAPPER_RANDOM, abi.MAPPER_SPD_HERO, abi.MAPPER_CIE, abi.MAPPER_AGH_CMIS]))
     s.mis = int(rng.integers(2))
     s.nee = int(rng.integers(5) != 0)
@@ -142,21 +142,23 @@ def random_scene(seed, width=56, height=40):
     return b.build(), multi_tap
 
 
+SOAK_ITERS = int(os.environ.get("PRGPU_TEST_RANDOM_ITERS", "4"))                      # soak runs: more samples per pixel (the sampler schedule is 4: set both) ...
+SOAK_FILM = tuple(int(v) for v in os.environ.get("PRGPU_TEST_RANDOM_FILM", "56x40").split("x"))   # ... and a larger film (with PRGPU_PP_MAX_BLOCKS: more pixels than path slots)
 N_SCENES = int(os.environ.get("PRGPU_TEST_RANDOM_SCENES", "40"))   # more for a soak run: 800 scenes pass (round 3)
 
 
 @pytest.mark.parametrize("seed", list(range(1, N_SCENES + 1)))
 def test_random_scene_matches_the_checker(seed):
-    sc, multi_tap = random_scene(seed)
+    sc, multi_tap = random_scene(seed, *SOAK_FILM)
     g = backend.RenderContext(sc)
     o = ob.OracleScene(sc)
     if seed % 5 == 0:   # a rank's tile share instead of the whole film
         from pearray_amd import tiling
         tiles = tiling.tiles_for_rank(sc.width, sc.height, seed % 3, 3, tile=8)
         g.setTiles(tiles); o.set_tiles(tiles)
-    g.render(1); g.render(3)
+    g.render(1); g.render(SOAK_ITERS - 1)
     g.waitForFinish()
-    o.render(4, threads=8)
+    o.render(SOAK_ITERS, threads=8)
     gx, gs, gf = g.output(); ox, os_, of = o.output()
     assert np.array_equal(g.primaryHits()[0], o.primary_hits()[0]) and np.array_equal(g.primaryHits()[1], o.primary_hits()[1]), "primary hits"
     assert np.array_equal(gs, os_) and np.array_equal(gf, of), "sample / feedback planes"
