@@ -15,9 +15,11 @@ struct BvhBuildInput {
 	const uint8_t* tri_class = nullptr; // device, or null: per-triangle material class, copied into the leaf records (float 31: one byte per slot)
 };
 struct BvhBuildOutput {
-	Rec64* recs = nullptr; // device, addressed in 64-byte units: n_inner inner records (one unit each, unit 0 is the root), then from
-						   // unit leaf_unit0 (even) n_leaf leaf records of two units each
-	uint32_t n_inner = 0, n_leaf = 0, leaf_unit0 = 0;
+	Rec64* recs = nullptr; // device, addressed in 64-byte units: unit 0 is the root inner record; from unit 2 on the child groups of the
+						   // n_inner inner records (one unit each; a record's children lie contiguously, its leaves -- two units each,
+						   // 128-byte aligned -- first)
+	uint32_t* leaf_units = nullptr; // device, n_leaf entries: the unit of every leaf record (the caller frees it)
+	uint32_t n_inner = 0, n_leaf = 0, n_units = 0;
 };
 bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err);
 } // namespace prd

@@ -7,8 +7,8 @@
 // own bounds, so one sort + one radix-tree pass yields the same two-level structure: the top of the
 // tree separates entities, each entity's subtree is an LBVH over its own triangles.
 //
-// Layout produced (see pr_device.h): 64-byte quantised 4-wide inner nodes and 128-byte leaves (radix tree collapsed by
-// pulling grandchildren up) and leaves of 1..3 triangles in Morton order.
+// Layout produced (see pr_device.h): quantised 4-wide inner nodes (64-byte records, 48 bytes used) whose children lie contiguously from
+// one base unit, and 128-byte leaves of 1..3 triangles (radix tree collapsed by pulling grandchildren up).
 #include "bvh.h"
 
 #include <hipcub/hipcub.hpp>
@@ -251,18 +251,20 @@ __global__ void k_depth_and_flags(int n, const int* __restrict__ parent, const i
 
 struct ChildRef {
 	float lo[3], hi[3];
-	uint32_t ref;
+	bool leaf;
+	uint32_t id; // leaf: compacted leaf index (leaf_idx of its first sorted triangle); inner: compacted inner index (inner_idx of the radix node)
 };
-// reference to the subtree `c` (radix-tree child code: >= 0 internal, < 0 single triangle ~pos) as a child of an inner record
+// the subtree `c` (radix-tree child code: >= 0 internal, < 0 single triangle ~pos) as a child of an inner record
 __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
 											   const int* __restrict__ range_first, const int* __restrict__ range_last, const float* __restrict__ boxes,
-											   const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx, uint32_t leaf_unit0)
+											   const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx)
 {
 	ChildRef r;
 	expandable = false;
 	if (c < 0) {
 		tri_box(wv, sorted_tri[~c], r.lo, r.hi);
-		r.ref = REC_LEAF_BIT | (leaf_unit0 + 2u * leaf_idx[~c]);
+		r.leaf = true;
+		r.id   = leaf_idx[~c];
 	} else {
 		for (int a = 0; a < 3; ++a) {
 			r.lo[a] = boxes[6 * c + a];
@@ -270,20 +272,55 @@ __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const fl
 		}
 		const int cnt = range_last[c] - range_first[c] + 1;
 		if (cnt <= 3) {
-			r.ref = REC_LEAF_BIT | (leaf_unit0 + 2u * leaf_idx[range_first[c]]);
+			r.leaf = true;
+			r.id   = leaf_idx[range_first[c]];
 		} else {
-			r.ref	   = inner_idx[c]; // valid only when c is at even depth; odd-depth nodes get expanded by the caller
+			r.leaf	   = false;
+			r.id	   = inner_idx[c]; // valid only when c is at even depth; odd-depth nodes get expanded by the caller
 			expandable = true;
 		}
 	}
 	pad_box(r.lo, r.hi);
 	return r;
 }
+// The <= 4 children of inner record i, LEAVES FIRST (a record's children lie contiguously from one base unit and leaves are 128-byte
+// aligned: base even, leaves of two units each first, inner records of one unit after them), otherwise in radix-tree order.
+__device__ __forceinline__ int gather_children(int i, ChildRef* ch, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+											   const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
+											   const float* __restrict__ boxes, const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx)
+{
+	ChildRef tmp[4];
+	int nc = 0;
+	for (int side = 0; side < 2; ++side) {
+		const int c = side == 0 ? left[i] : right[i];
+		bool expandable;
+		const ChildRef direct = make_child(c, expandable, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+		if (!expandable) {
+			tmp[nc++] = direct;
+		} else { // odd-depth internal node with > 3 triangles: pull its two children up
+			bool e2;
+			tmp[nc++] = make_child(left[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+			tmp[nc++] = make_child(right[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+		}
+	}
+	int n = 0;
+	for (int k = 0; k < nc; ++k)
+		if (tmp[k].leaf)
+			ch[n++] = tmp[k];
+	for (int k = 0; k < nc; ++k)
+		if (!tmp[k].leaf)
+			ch[n++] = tmp[k];
+	return nc;
+}
 
-// Pack <= 4 children into a 64-byte inner record (layout: pr_device.h).  The child boxes (already padded) become bytes on a
-// power-of-two grid anchored at the lower corner of their union; every byte is checked against the decode the traversal
-// performs (origin + byte * step, one rounding), so the decoded box always contains the padded fp32 box.
-__device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int nc)
+// Pack <= 4 children into an inner record (layout: pr_device.h).  The child boxes (already padded) become bytes on a power-of-two
+// grid anchored just below the lower corner of their union.  The traversal never forms a plane's coordinate: it evaluates
+// t = byte * (step * inv_d) + (origin - o) * inv_d in one fma, which differs from the slab distance of the EXACT plane
+// origin + byte * step by <= 3 u |t| + 2 u * 255 * step * |inv_d| (u = 2^-24).  The absolute part is less than 2^-15 step * |inv_d|, so
+// every byte is chosen -- and checked here in double precision, where origin + byte * step is exact -- such that the exact plane lies
+// at least MARGIN = 2^-14 step OUTSIDE the padded fp32 box.  offs[k] = unit offset of child k from the record's base.
+constexpr double GRID_MARGIN = 1.0 / 16384.0; // in grid steps
+__device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int nc, uint32_t base_unit, const uint32_t* offs)
 {
 	float org[3];
 	uint32_t ebyte[3];
@@ -294,24 +331,30 @@ __device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int n
 			lo = fminf(lo, ch[k].lo[a]);
 			hi = fmaxf(hi, ch[k].hi[a]);
 		}
-		org[a] = lo;
-		// 2^e >= extent / 255, kept inside the normal exponent range so that the step decodes as (byte << 23); the loop is bounded
-		// whatever the input (non-finite coordinates end in the full-grid fallback below instead of spinning)
-		int e = (int)fminf(fmaxf((float)ilogbf(fmaxf((hi - lo) * (1.0f / 255.0f), 1e-30f)) + 1.0f, -126.0f), 127.0f);
-		bool fits = false;
-		for (; e <= 127 && !fits; ++e) {
-			const float s = ldexpf(1.0f, e), inv_s = ldexpf(1.0f, -e);
-			fits		  = true;
+		// 2^e >= (extent + what the origin's rounding and the margins add) / 255, kept inside [-100, 30] so that the step decodes as
+		// (byte << 23) and step * inv_d (|inv_d| <= 2^80) stays finite and normal; the loop is bounded whatever the input
+		const float ext_eff = (hi - lo) + 4.0f * fmaxf(fabsf(lo), fabsf(hi)) * 1.1920929e-7f;
+		int e				= (int)fminf(fmaxf((float)ilogbf(fmaxf(ext_eff * (1.0f / 255.0f), 1e-30f)), -100.0f), 30.0f);
+		bool fits			= false;
+		float o				= lo;
+		for (; e <= 30 && !fits; ++e) {
+			const double s = ldexp(1.0, e), m = s * GRID_MARGIN;
+			// grid origin: the largest float <= lo - margin
+			o = (float)((double)lo - m);
+			if ((double)o > (double)lo - m)
+				o = nextafterf(o, -INFINITY);
+			fits = true;
 			for (int k = 0; k < nc; ++k) {
-				int ql = (int)floorf((ch[k].lo[a] - lo) * inv_s);
-				ql	   = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
-				while (ql > 0 && __fmaf_rn((float)ql, s, lo) > ch[k].lo[a])
-					--ql;
-				int qh = (int)ceilf((ch[k].hi[a] - lo) * inv_s);
-				qh	   = qh < 0 ? 0 : qh;
-				while (qh <= 255 && __fmaf_rn((float)qh, s, lo) < ch[k].hi[a])
-					++qh;
-				if (qh > 255) {
+				const double want_lo = (double)ch[k].lo[a] - m, want_hi = (double)ch[k].hi[a] + m;
+				double ql = floor((want_lo - (double)o) / s);
+				ql		  = ql < 0.0 ? 0.0 : (ql > 255.0 ? 255.0 : ql);
+				while (ql > 0.0 && (double)o + ql * s > want_lo)
+					ql -= 1.0;
+				double qh = ceil((want_hi - (double)o) / s);
+				qh		  = qh < 0.0 ? 0.0 : qh;
+				while (qh <= 255.0 && (double)o + qh * s < want_hi)
+					qh += 1.0;
+				if (qh > 255.0 || (double)o + ql * s > want_lo) {
 					fits = false;
 					break;
 				}
@@ -320,11 +363,12 @@ __device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int n
 			}
 		}
 		--e; // the exponent of the last attempt
-		if (!fits)
-			for (int k = 0; k < nc; ++k) { // lower bound = origin, upper bound = origin + 255 * 2^127 = +inf
+		if (!fits) // coordinates beyond SCENE_COORD_MAX or not finite (scene_create rejects both): the full grid
+			for (int k = 0; k < nc; ++k) {
 				qlo[a][k] = 0u;
 				qhi[a][k] = 255u;
 			}
+		org[a]	 = o;
 		ebyte[a] = (uint32_t)(e + 127);
 	}
 	uint32_t w[16];
@@ -341,41 +385,116 @@ __device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int n
 			w[4 + a] |= l << (8 * k); // q1.xyz = lo.x, lo.y, lo.z (one byte per child)
 			w[7 + a] |= h << (8 * k); // q1.w, q2.xy = hi.x, hi.y, hi.z
 		}
-		w[12 + k] = used ? ch[k].ref : REC_EMPTY; // q3 = child refs
+		const int src = used ? k : 0; // unused slot: child 0's payload (a valid record whatever happens)
+		w[11] |= ((offs[src] << 1) | (ch[src].leaf ? REC_LEAF_BIT : 0u)) << (8 * k);
 	}
+	w[10]	   = 2u * base_unit;
 	uint4* dst = reinterpret_cast<uint4*>(rec);
 	for (int q = 0; q < 4; ++q)
 		dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
-__global__ void k_emit_inner(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
-							 const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
-							 const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
-							 const uint32_t* __restrict__ leaf_idx, uint32_t leaf_unit0, Rec64* __restrict__ recs)
+// 6a. units the children of inner record i occupy (even: the next record's leaves stay 128-byte aligned)
+__global__ void k_group_sizes(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+							  const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
+							  const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
+							  const uint32_t* __restrict__ leaf_idx, uint32_t* __restrict__ gsize)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n - 1 || !inner_flag[i])
 		return;
 	ChildRef ch[4];
-	int nc = 0;
-	for (int side = 0; side < 2; ++side) {
-		const int c = side == 0 ? left[i] : right[i];
-		bool expandable;
-		const ChildRef direct = make_child(c, expandable, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, leaf_unit0);
-		if (!expandable) {
-			ch[nc++] = direct;
-		} else { // odd-depth internal node with > 3 triangles: pull its two children up
-			bool e2;
-			ch[nc++] = make_child(left[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, leaf_unit0);
-			ch[nc++] = make_child(right[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx, leaf_unit0);
+	const int nc = gather_children(i, ch, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
+	uint32_t units = 0;
+	for (int k = 0; k < nc; ++k)
+		units += ch[k].leaf ? 2u : 1u;
+	gsize[inner_idx[i]] = (units + 1u) & ~1u;
+}
+// 6b. where every record goes: the children of inner record i from unit 2 + gbase[i] on (units 0, 1 = the root record and its pad)
+__global__ void k_assign_units(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+							   const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
+							   const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
+							   const uint32_t* __restrict__ leaf_idx, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ inner_unit,
+							   uint32_t* __restrict__ leaf_unit)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n - 1 || !inner_flag[i])
+		return;
+	if (i == 0)
+		inner_unit[inner_idx[0]] = 0u;
+	ChildRef ch[4];
+	const int nc  = gather_children(i, ch, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
+	uint32_t unit = 2u + gbase[inner_idx[i]];
+	for (int k = 0; k < nc; ++k) {
+		if (ch[k].leaf)
+			leaf_unit[ch[k].id] = unit;
+		else
+			inner_unit[ch[k].id] = unit;
+		unit += ch[k].leaf ? 2u : 1u;
+	}
+}
+// 6c. the inner records
+__global__ void k_emit_inner(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+							 const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
+							 const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
+							 const uint32_t* __restrict__ leaf_idx, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ inner_unit,
+							 Rec64* __restrict__ recs)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n - 1 || !inner_flag[i])
+		return;
+	ChildRef ch[4];
+	const int nc = gather_children(i, ch, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
+	uint32_t offs[4] = { 0u, 0u, 0u, 0u }, off = 0u;
+	for (int k = 0; k < nc; ++k) {
+		offs[k] = off;
+		off += ch[k].leaf ? 2u : 1u;
+	}
+	write_inner_q(recs + inner_unit[inner_idx[i]], ch, nc, 2u + gbase[inner_idx[i]], offs);
+}
+
+// 6d. self-check of the emitted structure, before any ray walks it (a bad child ref would be an out-of-bounds access in every tracing kernel):
+// every child of every inner record lies inside the array, leaves on even units with 1..3 triangles, inner children with sane exponents.
+__global__ void k_validate(uint32_t n_inner, const uint32_t* __restrict__ inner_unit, const Rec64* __restrict__ recs, uint32_t n_units, uint32_t* __restrict__ bad)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_inner)
+		return;
+	const uint32_t unit = inner_unit[i];
+	if (unit >= n_units) {
+		atomicAdd(bad, 1u);
+		return;
+	}
+	const uint32_t* w	= reinterpret_cast<const uint32_t*>(recs + unit);
+	const uint32_t base = w[10], pw = w[11];
+	bool ok				= (base & 1u) == 0u && base >= 4u;
+	for (int a = 0; a < 3 && ok; ++a) {
+		const uint32_t e = (w[3] >> (8 * a)) & 0xFFu;
+		ok				 = e >= 27u && e <= 157u; // 2^-100 .. 2^30
+	}
+	for (int k = 0; k < 4 && ok; ++k) {
+		const uint32_t ref = base + ((pw >> (8 * k)) & 0xFFu), cu = ref >> 1;
+		if (ref & REC_LEAF_BIT) {
+			ok = (cu & 1u) == 0u && cu + 2u <= n_units;
+			if (ok) {
+				const uint32_t cnt = reinterpret_cast<const uint32_t*>(recs + cu)[30];
+				ok				   = cnt >= 1u && cnt <= 3u;
+			}
+		} else {
+			ok = cu + 1u <= n_units;
+			if (ok) {
+				const uint32_t ce = reinterpret_cast<const uint32_t*>(recs + cu)[3] & 0xFFu;
+				ok				  = ce >= 27u && ce <= 157u;
+			}
 		}
 	}
-	write_inner_q(recs + inner_idx[i], ch, nc);
+	if (!ok)
+		atomicAdd(bad, 1u);
 }
 
 // leaf record: triangle k occupies floats [10k, 10k+10): v0, v1, v2, original triangle index; float 30 = count, float 31 = material classes
 __global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const uint32_t* __restrict__ leaf_flag,
-							  const uint32_t* __restrict__ leaf_count, const uint32_t* __restrict__ leaf_idx, uint32_t leaf_unit0, Rec64* __restrict__ recs,
+							  const uint32_t* __restrict__ leaf_count, const uint32_t* __restrict__ leaf_idx, const uint32_t* __restrict__ leaf_unit, Rec64* __restrict__ recs,
 							  const uint8_t* __restrict__ tri_class)
 {
 	const uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -408,13 +527,14 @@ __global__ void k_emit_leaves(uint32_t n, const float4* __restrict__ wv, const u
 	}
 	f[30]		= __uint_as_float(cnt);
 	f[31]		= __uint_as_float(classes); // material class of the triangle in slot k in byte k (the persistent kernel's shade queues bin by it)
-	float4* dst = reinterpret_cast<float4*>(recs + leaf_unit0 + 2u * leaf_idx[pos]);
+	float4* dst = reinterpret_cast<float4*>(recs + leaf_unit[leaf_idx[pos]]);
 	for (int q = 0; q < 8; ++q)
 		dst[q] = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
 }
 
 // tiny scenes (n <= 3): one inner record whose only child is the single leaf
-__global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, Rec64* __restrict__ recs, const uint8_t* __restrict__ tri_class)
+__global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, Rec64* __restrict__ recs, uint32_t* __restrict__ leaf_unit,
+							 const uint8_t* __restrict__ tri_class)
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0)
 		return;
@@ -458,9 +578,12 @@ __global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const ui
 		only.lo[a] = lo[a];
 		only.hi[a] = hi[a];
 	}
-	only.ref = REC_LEAF_BIT | 2u;
-	write_inner_q(recs, &only, 1);
-	float4* d1 = reinterpret_cast<float4*>(recs + 2);
+	only.leaf			 = true;
+	only.id				 = 0u;
+	const uint32_t off0[4] = { 0u, 0u, 0u, 0u };
+	write_inner_q(recs, &only, 1, 2u, off0);
+	leaf_unit[0] = 2u;
+	float4* d1	 = reinterpret_cast<float4*>(recs + 2);
 	for (int q = 0; q < 8; ++q)
 		d1[q] = make_float4(leaf[4 * q], leaf[4 * q + 1], leaf[4 * q + 2], leaf[4 * q + 3]);
 }
@@ -484,13 +607,15 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 	float4* wv = nullptr;
 	uint32_t *ebounds = nullptr, *vals = nullptr, *vals_sorted = nullptr, *arrive = nullptr;
 	uint32_t *inner_flag = nullptr, *inner_idx = nullptr, *leaf_flag = nullptr, *leaf_cnt = nullptr, *leaf_idx = nullptr;
+	uint32_t *gsize = nullptr, *gbase = nullptr, *inner_unit = nullptr;
 	uint64_t *keys = nullptr, *keys_sorted = nullptr;
 	int *left = nullptr, *right = nullptr, *rf = nullptr, *rl = nullptr, *parent = nullptr;
 	float* boxes = nullptr;
 	void *temp = nullptr, *temp2 = nullptr;
 	size_t temp_bytes = 0, temp2_bytes = 0, t2a = 0, t2b = 0;
 	bool ok = false;
-	out.recs = nullptr;
+	out.recs	   = nullptr;
+	out.leaf_units = nullptr;
 	{
 		HIPC(hipMalloc(&wv, sizeof(float4) * 3 * size_t(n)));
 		HIPC(hipMalloc(&ebounds, sizeof(uint32_t) * 6 * in.n_entities));
@@ -516,10 +641,12 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 		HIPC(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
 		if (n <= 3) {
 			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * 4));
-			hipLaunchKernelGGL(k_tiny_scene, dim3(1), dim3(64), 0, stream, n, wv, vals_sorted, out.recs, in.tri_class);
-			out.n_inner	   = 1;
-			out.n_leaf	   = 1;
-			out.leaf_unit0 = 2;
+			HIPC(hipMemsetAsync(out.recs, 0, sizeof(Rec64) * 4, stream));
+			HIPC(hipMalloc(&out.leaf_units, sizeof(uint32_t)));
+			hipLaunchKernelGGL(k_tiny_scene, dim3(1), dim3(64), 0, stream, n, wv, vals_sorted, out.recs, out.leaf_units, in.tri_class);
+			out.n_inner = 1;
+			out.n_leaf	= 1;
+			out.n_units = 4;
 		} else {
 			HIPC(hipMalloc(&left, sizeof(int) * (n - 1)));
 			HIPC(hipMalloc(&right, sizeof(int) * (n - 1)));
@@ -555,11 +682,53 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipStreamSynchronize(stream));
 			out.n_inner = last[0] + last[1];
 			out.n_leaf	= last[2] + last[3];
-			out.leaf_unit0 = (out.n_inner + 1u) & ~1u; // leaves are 128-byte aligned
-			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * (size_t(out.leaf_unit0) + 2 * size_t(out.n_leaf))));
-			hipLaunchKernelGGL(k_emit_inner, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes,
-							   inner_flag, inner_idx, leaf_idx, out.leaf_unit0, out.recs);
-			hipLaunchKernelGGL(k_emit_leaves, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, leaf_flag, leaf_cnt, leaf_idx, out.leaf_unit0, out.recs, in.tri_class);
+			// second pass (round 4): the children of a record lie contiguously from one base unit -- every inner record says how many units
+			// its children take, a prefix sum places the groups, then every record is written where its parent expects it
+			HIPC(hipMalloc(&gsize, sizeof(uint32_t) * (size_t(out.n_inner) + 1)));
+			HIPC(hipMalloc(&gbase, sizeof(uint32_t) * (size_t(out.n_inner) + 1)));
+			HIPC(hipMalloc(&inner_unit, sizeof(uint32_t) * std::max<size_t>(out.n_inner, 1)));
+			HIPC(hipMalloc(&out.leaf_units, sizeof(uint32_t) * std::max<size_t>(out.n_leaf, 1)));
+			HIPC(hipMemsetAsync(gsize, 0, sizeof(uint32_t) * (size_t(out.n_inner) + 1), stream));
+			hipLaunchKernelGGL(k_group_sizes, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gsize);
+			HIPC(hipGetLastError());
+			{
+				size_t t3 = 0;
+				HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, t3, gsize, gbase, (int)out.n_inner + 1, stream));
+				if (t3 > temp2_bytes) {
+					(void)hipFree(temp2);
+					temp2 = nullptr;
+					HIPC(hipMalloc(&temp2, t3));
+					temp2_bytes = t3;
+				}
+				HIPC(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, gsize, gbase, (int)out.n_inner + 1, stream));
+			}
+			uint32_t group_units = 0; // gbase[n_inner] = the sum of all group sizes
+			HIPC(hipMemcpyAsync(&group_units, gbase + out.n_inner, 4, hipMemcpyDeviceToHost, stream));
+			HIPC(hipStreamSynchronize(stream));
+			out.n_units = 2u + group_units;
+			if (size_t(out.n_units) >= (size_t(1) << 31)) {
+				err = "the BVH needs more than 2^31 record units";
+				goto done;
+			}
+			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * size_t(out.n_units)));
+			HIPC(hipMemsetAsync(out.recs, 0, sizeof(Rec64) * size_t(out.n_units), stream));
+			hipLaunchKernelGGL(k_assign_units, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gbase,
+							   inner_unit, out.leaf_units);
+			hipLaunchKernelGGL(k_emit_inner, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gbase,
+							   inner_unit, out.recs);
+			hipLaunchKernelGGL(k_emit_leaves, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, leaf_flag, leaf_cnt, leaf_idx, out.leaf_units, out.recs, in.tri_class);
+			HIPC(hipGetLastError());
+			{ // gsize is free again: its first word takes the count of bad records
+				uint32_t bad = 0;
+				HIPC(hipMemsetAsync(gsize, 0, sizeof(uint32_t), stream));
+				hipLaunchKernelGGL(k_validate, dim3((out.n_inner + B - 1) / B), dim3(B), 0, stream, out.n_inner, inner_unit, out.recs, out.n_units, gsize);
+				HIPC(hipMemcpyAsync(&bad, gsize, 4, hipMemcpyDeviceToHost, stream));
+				HIPC(hipStreamSynchronize(stream));
+				if (bad != 0u) {
+					err = "internal error: " + std::to_string(bad) + " inner records failed the structure check";
+					goto done;
+				}
+			}
 		}
 		HIPC(hipGetLastError());
 		HIPC(hipStreamSynchronize(stream));
@@ -569,10 +738,12 @@ done:
 	(void)hipFree(wv); (void)hipFree(ebounds); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted);
 	(void)hipFree(left); (void)hipFree(right); (void)hipFree(rf); (void)hipFree(rl); (void)hipFree(parent); (void)hipFree(boxes); (void)hipFree(arrive);
 	(void)hipFree(inner_flag); (void)hipFree(inner_idx); (void)hipFree(leaf_flag); (void)hipFree(leaf_cnt); (void)hipFree(leaf_idx);
-	(void)hipFree(temp); (void)hipFree(temp2);
+	(void)hipFree(temp); (void)hipFree(temp2); (void)hipFree(gsize); (void)hipFree(gbase); (void)hipFree(inner_unit);
 	if (!ok) {
 		(void)hipFree(out.recs);
-		out.recs = nullptr;
+		(void)hipFree(out.leaf_units);
+		out.recs	   = nullptr;
+		out.leaf_units = nullptr;
 	}
 	return ok;
 }

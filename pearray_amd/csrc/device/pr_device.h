@@ -44,20 +44,35 @@ constexpr float CIE_Y_NORM	   = CIE_Y_NORM_SUM * CIE_DELTA;
 
 // ---- device BVH ---------------------------------------------------------------------------------
 // The BVH is addressed in 64-byte units; unit 0 is the root inner record.
-//   inner (one unit, 64 B): a 4-wide node whose child boxes are bytes on a per-record power-of-two grid:
-//          q0 = origin.xyz, exponent bytes (ex | ey << 8 | ez << 16; grid step of axis a = 2^(e_a - 127));
-//          q1 = lo.x, lo.y, lo.z, hi.x (one byte per child in each word); q2 = hi.y, hi.z, 0, 0; q3 = four child refs.
-//          decoded bound = origin + byte * step (exact product, one rounding); the builder checks every byte against this
-//          decode, so the decoded box always contains the padded fp32 child box.
+//   inner (one unit; 48 of its 64 bytes are used and fetched): a 4-wide node whose child boxes are bytes on a per-record
+//          power-of-two grid and whose children lie CONTIGUOUSLY from one base unit (leaves first, then inner records):
+//          q0 = grid origin.xyz, exponent bytes (ex | ey << 8 | ez << 16; grid step of axis a = 2^(e_a - 127));
+//          q1 = lo.x, lo.y, lo.z, hi.x (one byte per child in each word); q2 = hi.y, hi.z, base ref (2 * first child unit),
+//          payload bytes (byte k = (unit offset of child k from the base) << 1 | leaf bit; an unused slot repeats child 0's payload
+//          and carries an inverted byte box, which fails the slab test -- and is harmless should it ever pass).
+//          The decoded plane origin + byte * step (EXACT, never formed by the traversal) lies at least 2^-14 grid steps outside
+//          the padded fp32 child box: the builder checks every byte in double precision (bvh.hip, write_inner_q); that margin
+//          pays for the fused one-fma-per-plane slab arithmetic of the traversal step.
 //   leaf  (two units, 128 B = one L2 line, 128-byte aligned): triangle k (k < 3) in floats [10k, 10k+10) = v0, v1, v2
-//          (world space), original triangle index; float 30 = triangle count
-// child ref: unit index | REC_LEAF_BIT for leaves, REC_EMPTY for an unused slot.
+//          (world space), original triangle index; float 30 = triangle count, float 31 = material classes
+// child ref: 2 * unit index | REC_LEAF_BIT for leaves; REC_EMPTY = no record.
 struct __attribute__((aligned(64))) Rec64 {
 	float4 q[4];
 };
 static_assert(sizeof(Rec64) == 64, "Rec64 must be 64 bytes");
-constexpr uint32_t REC_LEAF_BIT = 0x80000000u;
+constexpr uint32_t REC_LEAF_BIT = 1u;
 constexpr uint32_t REC_EMPTY	= 0xFFFFFFFFu;
+// the record a ref names (ref & ~1 = 2 * unit, 32 bytes per half unit)
+__host__ __device__ __forceinline__ const float4* rec_ptr(const Rec64* recs, uint32_t ref)
+{
+	return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(recs) + size_t(ref & ~REC_LEAF_BIT) * 32u);
+}
+// Acceptance rule of the quantised slab test and of the stack re-check: entry <= exit * SLAB_REL + eps_t.  box_hit below states the
+// reference rule (factor 1.000001f = 1 + 16 u, u = 2^-24, slack eps); SLAB_REL = 1 + 48 u and eps_t = eps * (1 + 2^-16) absorb the
+// <= 5.1 u relative difference between the fused plane distances and box_hit's on the padded box.
+constexpr float SLAB_REL		= 1.0000028610229492f; // 0x3F800018
+constexpr float INV_D_MAX		= 1.2089258196146292e24f; // 2^80: reciprocal direction of an axis-parallel ray (finite: step * inv_d and byte * step * inv_d stay finite)
+constexpr float SCENE_COORD_MAX = 268435456.0f;			  // 2^28: largest |coordinate| a scene may hold (grid steps stay <= 2^30)
 
 struct DevEntity {
 	float m[12];  // rows 0..2 of the entity transform
@@ -769,9 +784,8 @@ __device__ __forceinline__ RayPre ray_prepare(V3 o, V3 d, float eps_t)
 	r.Sx	= comp(d, kx) / comp(d, kz);
 	r.Sy	= comp(d, ky) / comp(d, kz);
 	r.Sz	= 1.0f / comp(d, kz);
-	// reciprocal direction, +-inf (axis-parallel rays) replaced by +-FLT_MAX so that the slab test never forms 0*inf
-	r.inv_d = v3(fminf(fmaxf(1.0f / d.x, -3.402823466e+38f), 3.402823466e+38f), fminf(fmaxf(1.0f / d.y, -3.402823466e+38f), 3.402823466e+38f),
-				 fminf(fmaxf(1.0f / d.z, -3.402823466e+38f), 3.402823466e+38f));
+	// reciprocal direction, +-inf (axis-parallel rays) replaced by +-2^80 so that the slab test never forms 0*inf or inf - inf
+	r.inv_d = v3(fminf(fmaxf(1.0f / d.x, -INV_D_MAX), INV_D_MAX), fminf(fmaxf(1.0f / d.y, -INV_D_MAX), INV_D_MAX), fminf(fmaxf(1.0f / d.z, -INV_D_MAX), INV_D_MAX));
 	return r;
 }
 __device__ __forceinline__ bool woop(const RayPre& r, V3 p0, V3 p1, V3 p2, float& t, float& u, float& v)
@@ -1384,7 +1398,7 @@ static __device__ __noinline__ void sphere_light_sample(const DevShapeLight& P, 
 // same acceptance rule for a box entry distance that was computed earlier (stack entries, re-checks)
 __device__ __forceinline__ bool still_reachable(const RayPre& r, float tentry, float limit)
 {
-	return tentry <= limit * 1.000001f + r.eps_t;
+	return tentry <= __fmaf_rn(limit, SLAB_REL, r.eps_t);
 }
 
 // ---- light path expressions: the automaton states of a path, advanced token by token (LPE_Automaton.h:17-33) ----

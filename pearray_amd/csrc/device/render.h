@@ -65,7 +65,7 @@ void launch_sort_active(const DevScene& sc, const PathState& ps, const uint32_t*
 void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
 							uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, unsigned long long* gstats,
 							hipStream_t st);
-void launch_tri_slot(const DevScene& sc, uint32_t* tri_slot, hipStream_t st); // fills DevScene::tri_slot from the leaf records
+void launch_tri_slot(const DevScene& sc, const uint32_t* leaf_units /* unit of every leaf record (BvhBuildOutput) */, uint32_t* tri_slot, hipStream_t st); // fills DevScene::tri_slot from the leaf records
 void launch_service_closest_split(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
 								  uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, uint32_t* tri_slot,
 								  unsigned long long* gstats, hipStream_t st); // prototype, see render.hip

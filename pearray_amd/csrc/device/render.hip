@@ -43,7 +43,6 @@ constexpr int PP_BLOCK		= PR_PP_BLOCK;
 constexpr int TRAV_BLOCK	= PR_TU >= 1 ? PP_BLOCK : 256; // the persistent-kernel units hold nothing but that kernel
 constexpr int STACK_LDS		= 16;
 constexpr int STACK_SPILL	= 64;  // additional entries per thread in global memory
-constexpr bool ANY_SORTED	= false; // near-to-far order for occlusion rays measured slightly slower than unsorted (fewer ALU ops win)
 
 struct Stack {
 	uint2* lds;		 // this lane's column: entry e at lds[e * TRAV_BLOCK]
@@ -60,10 +59,11 @@ struct Stack {
 			++base;
 		}
 	}
-	// branch-free conditional push (requires reserve): the slot is written either way, the size only grows when valid
-	__device__ __forceinline__ void push_if(bool valid, uint32_t ref, float t)
+	// branch-free conditional push (requires reserve): the slot is written either way, the size only grows when valid.
+	// `key` = the child's sort key (entry distance with the low byte replaced by the child's payload, see trav_inner_rec)
+	__device__ __forceinline__ void push_if(bool valid, uint32_t ref, uint32_t key)
 	{
-		lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK] = make_uint2(ref, __float_as_uint(t));
+		lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK] = make_uint2(ref, key);
 		sp += valid ? 1 : 0;
 	}
 	__device__ __forceinline__ uint2 pop()
@@ -107,99 +107,83 @@ __device__ __forceinline__ void trav_begin(Trav& s, STK& st, V3 o, V3 d, float t
 	st.reset();
 }
 
-// slab test of child k of an inner record (same arithmetic as box_hit)
-__device__ __forceinline__ bool child_hit(const RayPre& r, float lox, float loy, float loz, float hix, float hiy, float hiz, float tmin, float limit, float& tentry)
-{
-	const float lo[3] = { lox, loy, loz }, hi[3] = { hix, hiy, hiz };
-	return box_hit(r, lo, hi, tmin, limit, tentry);
-}
-
-// next record after the current one is used up: the closest stack entry that can still matter
+// next record after the current one is used up: the closest stack entry that can still matter.  A stack entry carries the child's
+// sort key: its entry distance (>= tmin >= 0) with the low byte replaced by payload bits, i.e. rounded down by < 2^-15 relative.  The
+// re-check still_reachable(key & ~0xFF, limit) is done on the bit patterns: for k = key with its low byte cleared and a threshold
+// T >= 0, k <= T as floats <=> key <= (bits(T) | 0xFF) as integers (a negative or NaN threshold keeps the entry: conservative).
 template <int M, typename STK>
 __device__ __forceinline__ void trav_pop(Trav& s, STK& st)
 {
+	const uint32_t thr = __float_as_uint(__fmaf_rn(s.best.t, SLAB_REL, s.r.eps_t)) | 0xFFu;
 	while (s.cur == REC_EMPTY && st.sp > 0) {
 		const uint2 e = st.pop();
-		if (M == MODE_ANY || still_reachable(s.r, __uint_as_float(e.y), s.best.t))
+		if (M == MODE_ANY || e.y <= thr)
 			s.cur = e.x;
 	}
 }
 
-// Inner step: fetch the 4-wide node (one 64-byte unit), decode the four quantised child boxes (bound = origin + byte * step:
-// the product is exact, so the fused form rounds once), test them with the arithmetic of box_hit, continue with the nearest
-// hit child and push the others far-to-near.  MODE_ANY: order does not matter, children are pushed unsorted (in
-// MODE_MIXED occlusion lanes share the sorted code of the closest-hit lanes; occlusion is order independent).
+// Inner step, slab part: the four quantised child boxes of a record against the lane's ray.  A plane's distance is ONE fma,
+// t = byte * (step * inv_d) + (origin - o) * inv_d: step is a power of two, so A = step * inv_d is exact, and against the two-rounding
+// form ((origin - o) + byte * step) * inv_d the result differs by <= 3 u |t| + 255 |A| * 2 u (u = 2^-24) -- the absolute part is what the
+// builder's 2^-14-step margin around every child box pays for, the relative part goes into SLAB_REL.  Hit ids
+// do not depend on which conservative boxes a ray visits: a hit is argmin (t, triangle index) over the triangles that pass the
+// watertight test (leaf_test).  key[k] = entry distance of child k with its low byte replaced by the child's payload (unit offset
+// from the record's base ref << 1 | leaf bit), 0xFFFFFFFF for a miss: sorting the keys as integers sorts the children near to far
+// (entry distances are >= tmin >= 0) and carries each child's ref along for free.
 #define PR_UB(w, k) ((float)(((w) >> (8 * (k))) & 0xFFu)) /* byte k of a packed word as a float: v_cvt_f32_ubyteK */
-template <int M, typename STK>
-__device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3)
+__device__ __forceinline__ void inner_keys(const Trav& s, const float4& q0, const float4& q1, const float4& q2, uint32_t key[4])
 {
-	float t[4];
-	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
-	bool h[4];
-	{
-		const uint32_t eb = __float_as_uint(q0.w);
-		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
-		// near / far plane of each axis picked by the sign of the direction -- the value min(a, b) / max(a, b) of box_hit would
-		// select (the decode and the slab distance are monotonic in the byte), for all four children at once
-		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
-		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
-		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
-		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
-		// plane - origin as (node origin - ray origin) + byte * step: the product is exact, so this rounds twice like the two-step
-		// form (decode the plane, subtract the origin) but costs one operation less per plane
-		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const float axk = __fmaf_rn(PR_UB(wnx, k), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn(PR_UB(wfx, k), sx, dx) * s.r.inv_d.x;
-			const float ayk = __fmaf_rn(PR_UB(wny, k), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn(PR_UB(wfy, k), sy, dy) * s.r.inv_d.y;
-			const float azk = __fmaf_rn(PR_UB(wnz, k), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn(PR_UB(wfz, k), sz, dz) * s.r.inv_d.z;
-			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
-			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
-			t[k]		   = t0;
-			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY; // acceptance rule of box_hit
-		}
-	}
+	const uint32_t eb = __float_as_uint(q0.w);
+	const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
+	// near / far plane of each axis picked by the sign of the direction, for all four children at once
+	const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
+	const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
+	const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
+	const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
+	const float Ax = sx * s.r.inv_d.x, Ay = sy * s.r.inv_d.y, Az = sz * s.r.inv_d.z;
+	const float Bx = (q0.x - s.r.o.x) * s.r.inv_d.x, By = (q0.y - s.r.o.y) * s.r.inv_d.y, Bz = (q0.z - s.r.o.z) * s.r.inv_d.z;
+	const uint32_t pw = __float_as_uint(q2.w);
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
-		t[k] = h[k] ? t[k] : INFINITY;
-		c[k] = h[k] ? c[k] : REC_EMPTY;
+		const float axk = __fmaf_rn(PR_UB(wnx, k), Ax, Bx), bxk = __fmaf_rn(PR_UB(wfx, k), Ax, Bx);
+		const float ayk = __fmaf_rn(PR_UB(wny, k), Ay, By), byk = __fmaf_rn(PR_UB(wfy, k), Ay, By);
+		const float azk = __fmaf_rn(PR_UB(wnz, k), Az, Bz), bzk = __fmaf_rn(PR_UB(wfz, k), Az, Bz);
+		const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
+		const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
+		const bool h   = t0 <= __fmaf_rn(t1, SLAB_REL, s.r.eps_t);
+		// bytes 3..1 of t0, byte k of the payload word (v_perm_b32)
+		key[k] = h ? __builtin_amdgcn_perm(__float_as_uint(t0), pw, 0x07060500u | (uint32_t)k) : 0xFFFFFFFFu;
 	}
-	if (M != MODE_ANY || ANY_SORTED) {
-		// sort the four (t, ref) pairs ascending: 5-comparator network (misses carry t = +inf and sort last)
-#define PR_CSWAP(a, b)                                          \
-	{                                                           \
-		const bool sw	  = t[b] < t[a];                        \
-		const float ta = t[a], tb = t[b];                       \
-		const uint32_t ca = c[a], cb = c[b];                    \
-		t[a] = sw ? tb : ta; t[b] = sw ? ta : tb;               \
-		c[a] = sw ? cb : ca; c[b] = sw ? ca : cb;               \
+}
+// ... sort part: continue with the nearest hit child and push the others far to near (occlusion rays share the sorted code: their
+// result does not depend on the order).  5-comparator network on the integer keys (misses sort last).
+template <int M, typename STK>
+__device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2)
+{
+	uint32_t key[4];
+	inner_keys(s, q0, q1, q2, key);
+#define PR_CSWAP(a, b)                                  \
+	{                                                   \
+		const uint32_t lo = min(key[a], key[b]);        \
+		key[b]			  = max(key[a], key[b]);        \
+		key[a]			  = lo;                         \
 	}
-		PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
 #undef PR_CSWAP
-	} else {
-		// compact the hits to the front (order irrelevant for occlusion)
-#define PR_CMOVE(a, b)                                          \
-	{                                                           \
-		const bool mv = c[a] == REC_EMPTY;                      \
-		c[a] = mv ? c[b] : c[a];                                \
-		c[b] = mv ? REC_EMPTY : c[b];                           \
-	}
-		PR_CMOVE(0, 1) PR_CMOVE(2, 3) PR_CMOVE(1, 2) PR_CMOVE(0, 1) PR_CMOVE(2, 3) PR_CMOVE(1, 2)
-#undef PR_CMOVE
-	}
+	const uint32_t base = __float_as_uint(q2.z);
 	st.reserve(3);
-	st.push_if(c[3] != REC_EMPTY, c[3], t[3]);
-	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
-	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
-	s.cur = c[0];
+	st.push_if(key[3] != 0xFFFFFFFFu, base + (key[3] & 0xFFu), key[3]);
+	st.push_if(key[2] != 0xFFFFFFFFu, base + (key[2] & 0xFFu), key[2]);
+	st.push_if(key[1] != 0xFFFFFFFFu, base + (key[1] & 0xFFu), key[1]);
+	s.cur = key[0] != 0xFFFFFFFFu ? base + (key[0] & 0xFFu) : REC_EMPTY;
 	trav_pop<M>(s, st);
 }
 template <int M>
 __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& st)
 {
-	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + s.cur);
-	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
-	trav_inner_rec<M>(s, st, q0, q1, q2, q3);
+	const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
+	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+	trav_inner_rec<M>(s, st, q0, q1, q2);
 }
 
 // Leaf step: fetch the leaf record (<= 3 triangles) and run the watertight test on each.
@@ -256,7 +240,7 @@ __device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0
 template <int M>
 __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& s, Stack& st)
 {
-	const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
+	const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
 	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
 	trav_leaf_rec<M, true>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
 }
@@ -2697,16 +2681,16 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			// instructions per step, 13 % slower.)
 			const unsigned long long t0s = COUNT ? wall_clock64() : 0ull;
 			if (go_inner || go_leaf) {
-				const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + (s.cur & ~REC_LEAF_BIT));
-				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3]; // an inner record, or the first half of a leaf
+				const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
+				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2]; // an inner record (48 of its 64 bytes are used), or the start of a leaf
 				if (go_inner) {
 					if (COUNT) {
 						cn_c += s.any ? 0 : 1;
 						cn_a += s.any ? 1 : 0;
 					}
-					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, q3);
+					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2);
 				} else {
-					const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+					const float4 q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
 					if (COUNT) {
 						cl_c += s.any ? 0 : 1;
 						cl_a += s.any ? 1 : 0;
@@ -2869,37 +2853,19 @@ constexpr uint32_t SPLIT_Q = 1024; // ring of leaf tasks (owner lane | leaf unit
 // inner step of the split traversal: hit children that are leaves become tasks at once (they never enter the stack), the inner ones
 // are sorted and pushed as in trav_inner_rec.  Returns nothing; *n_tasks = leaves queued by this lane.
 template <typename STK>
-__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, uint32_t* q, uint32_t* q_tail,
+__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, uint32_t* q, uint32_t* q_tail,
 												 uint32_t* pending_own, uint32_t tid, bool active, const uint32_t* q_head, uint32_t* overflow)
 {
-	float t[4] = { INFINITY, INFINITY, INFINITY, INFINITY };
-	uint32_t c[4] = { __float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w) };
-	bool h[4] = { false, false, false, false };
-	if (active) {
-		const uint32_t eb = __float_as_uint(q0.w);
-		const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
-		const bool nx = s.r.inv_d.x < 0.0f, ny = s.r.inv_d.y < 0.0f, nz = s.r.inv_d.z < 0.0f;
-		const uint32_t wlx = __float_as_uint(q1.x), wly = __float_as_uint(q1.y), wlz = __float_as_uint(q1.z);
-		const uint32_t whx = __float_as_uint(q1.w), why = __float_as_uint(q2.x), whz = __float_as_uint(q2.y);
-		const uint32_t wnx = nx ? whx : wlx, wfx = nx ? wlx : whx, wny = ny ? why : wly, wfy = ny ? wly : why, wnz = nz ? whz : wlz, wfz = nz ? wlz : whz;
-		const float dx = q0.x - s.r.o.x, dy = q0.y - s.r.o.y, dz = q0.z - s.r.o.z;
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const float axk = __fmaf_rn(PR_UB(wnx, k), sx, dx) * s.r.inv_d.x, bxk = __fmaf_rn(PR_UB(wfx, k), sx, dx) * s.r.inv_d.x;
-			const float ayk = __fmaf_rn(PR_UB(wny, k), sy, dy) * s.r.inv_d.y, byk = __fmaf_rn(PR_UB(wfy, k), sy, dy) * s.r.inv_d.y;
-			const float azk = __fmaf_rn(PR_UB(wnz, k), sz, dz) * s.r.inv_d.z, bzk = __fmaf_rn(PR_UB(wfz, k), sz, dz) * s.r.inv_d.z;
-			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
-			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
-			t[k]		   = t0;
-			h[k]		   = t0 <= t1 * 1.000001f + s.r.eps_t && c[k] != REC_EMPTY;
-		}
-	}
+	uint32_t key[4] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
+	if (active)
+		inner_keys(s, q0, q1, q2, key);
+	const uint32_t base = __float_as_uint(q2.z);
 	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts through three ballots)
 	bool lf[4];
 	uint32_t cnt = 0;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) {
-		lf[k] = h[k] && (c[k] & REC_LEAF_BIT) != 0u;
+		lf[k] = key[k] != 0xFFFFFFFFu && (key[k] & REC_LEAF_BIT) != 0u;
 		cnt += lf[k] ? 1u : 0u;
 	}
 	{
@@ -2908,44 +2874,39 @@ __device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4&
 		const unsigned long long b0 = __ballot((cnt & 1u) != 0u), b1 = __ballot((cnt & 2u) != 0u), b2 = __ballot((cnt & 4u) != 0u);
 		const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);
 		if (total != 0u) {
-			uint32_t base = 0;
+			uint32_t pos0 = 0;
 			if (lane == 0)
-				base = __hip_atomic_fetch_add(q_tail, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			base = wave_bcast0(base);
-			if (lane == 0 && base + total - lds_load(q_head) > SPLIT_Q) // cannot happen while callers keep the ring below a quarter full and a
+				pos0 = __hip_atomic_fetch_add(q_tail, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			pos0 = wave_bcast0(pos0);
+			if (lane == 0 && pos0 + total - lds_load(q_head) > SPLIT_Q) // cannot happen while callers keep the ring below a quarter full and a
 				__hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // step adds at most 256 per wave; loud if it does
-			uint32_t pos = base + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
+			uint32_t pos = pos0 + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
 			if (cnt)
 				__hip_atomic_fetch_add(pending_own, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
-				if (lf[k])
-					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], ((c[k] & ~REC_LEAF_BIT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (lf[k]) // task = leaf unit << 8 | owner lane (the ref is 2 * unit | 1)
+					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], (((base + (key[k] & 0xFFu)) >> 1) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
 	if (!active)
 		return;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const bool in = h[k] && !lf[k];
-		t[k]		  = in ? t[k] : INFINITY;
-		c[k]		  = in ? c[k] : REC_EMPTY;
-	}
-#define PR_CSWAP(a, b)                                          \
-	{                                                           \
-		const bool sw	  = t[b] < t[a];                        \
-		const float ta = t[a], tb = t[b];                       \
-		const uint32_t ca = c[a], cb = c[b];                    \
-		t[a] = sw ? tb : ta; t[b] = sw ? ta : tb;               \
-		c[a] = sw ? cb : ca; c[b] = sw ? ca : cb;               \
+	for (int k = 0; k < 4; ++k)
+		key[k] = lf[k] ? 0xFFFFFFFFu : key[k];
+#define PR_CSWAP(a, b)                                  \
+	{                                                   \
+		const uint32_t lo = min(key[a], key[b]);        \
+		key[b]			  = max(key[a], key[b]);        \
+		key[a]			  = lo;                         \
 	}
 	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
 #undef PR_CSWAP
 	st.reserve(3);
-	st.push_if(c[3] != REC_EMPTY, c[3], t[3]);
-	st.push_if(c[2] != REC_EMPTY, c[2], t[2]);
-	st.push_if(c[1] != REC_EMPTY, c[1], t[1]);
-	s.cur = c[0];
+	st.push_if(key[3] != 0xFFFFFFFFu, base + (key[3] & 0xFFu), key[3]);
+	st.push_if(key[2] != 0xFFFFFFFFu, base + (key[2] & 0xFFu), key[2]);
+	st.push_if(key[1] != 0xFFFFFFFFu, base + (key[1] & 0xFFu), key[1]);
+	s.cur = key[0] != 0xFFFFFFFFu ? base + (key[0] & 0xFFu) : REC_EMPTY;
 	trav_pop<MODE_CLOSEST>(s, st);
 }
 
@@ -2958,12 +2919,12 @@ struct SplitShared {
 	uint32_t q[SPLIT_Q];
 	uint32_t q_head, q_tail, overflow;
 };
-__global__ void k_tri_slot(DevScene sc, uint32_t* __restrict__ tri_slot)
+__global__ void k_tri_slot(DevScene sc, const uint32_t* __restrict__ leaf_units, uint32_t* __restrict__ tri_slot)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= sc.n_leaf)
 		return;
-	const uint32_t unit = ((sc.n_inner + 1u) & ~1u) + 2u * i;
+	const uint32_t unit = leaf_units[i];
 	const float* f		= reinterpret_cast<const float*>(sc.recs + unit);
 	const uint32_t cnt	= __float_as_uint(f[30]);
 	for (uint32_t k = 0; k < cnt && k < 3u; ++k)
@@ -3100,17 +3061,16 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene s
 						__builtin_amdgcn_s_sleep(1);
 				{
 					const bool act = has_ray && s.cur != REC_EMPTY; // every such lane is at an inner node: leaves never stay in s.cur
-					float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+					float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
 					if (act) {
 						s.best.t = __uint_as_float((uint32_t)(__hip_atomic_load(&sh.best[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
 						++cn;
-						const float4* __restrict__ rec = reinterpret_cast<const float4*>(sc.recs + s.cur);
+						const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
 						q0 = rec[0];
 						q1 = rec[1];
 						q2 = rec[2];
-						q3 = rec[3];
 					}
-					trav_inner_split(s, st, q0, q1, q2, q3, sh.q, &sh.q_tail, &sh.pending[tid], tid, act, &sh.q_head, &sh.overflow);
+					trav_inner_split(s, st, q0, q1, q2, sh.q, &sh.q_tail, &sh.pending[tid], tid, act, &sh.q_head, &sh.overflow);
 				}
 				spins = 0;
 			} else { // every ray of the wave waits for tasks another wave holds
@@ -3244,10 +3204,10 @@ void launch_service_closest(const DevScene& sc, uint32_t n, const float* org, co
 	hipLaunchKernelGGL(k_service_closest, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
 					   ws.spill, ws.refill_below, gstats);
 }
-void launch_tri_slot(const DevScene& sc, uint32_t* tri_slot, hipStream_t st)
+void launch_tri_slot(const DevScene& sc, const uint32_t* leaf_units, uint32_t* tri_slot, hipStream_t st)
 {
 	if (sc.n_leaf)
-		hipLaunchKernelGGL(k_tri_slot, grid_for(sc.n_leaf), dim3(256), 0, st, sc, tri_slot);
+		hipLaunchKernelGGL(k_tri_slot, grid_for(sc.n_leaf), dim3(256), 0, st, sc, leaf_units, tri_slot);
 }
 void launch_service_closest_split(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* tmax,
 								  uint32_t* entity, uint32_t* prim, float* u, float* v, float* t, const TraceWorkspace& ws, uint32_t* tri_slot,

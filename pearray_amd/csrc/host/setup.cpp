@@ -1215,7 +1215,9 @@ int build_tables(const prgpu_scene_desc* d, HostTables& t, std::string& err)
 					scale = std::max(scale, std::fabs(w[r]));
 			}
 		}
-		t.eps_t = 8e-6f * scale;
+		// eps of the reference rule (box_hit) times (1 + 2^-16): the quantised slab test's share of the rounding (pr_device.h, SLAB_REL)
+		t.eps_t		  = 8e-6f * scale * 1.0000152587890625f;
+		t.coord_scale = scale;
 	}
 	// Russian roulette: min(1, 0.9^(L - soft)) with the 1e-4 cut, indexed by path length
 	const prgpu_settings& c = d->settings;

@@ -39,6 +39,7 @@ struct HostTables {
 	uint32_t single_tap = 0;
 	float centre_weight = 1.0f;
 	float eps_t = 0.0f; // slab-test slack (pr_device.h box_hit)
+	float coord_scale = 0.0f; // largest |coordinate| of the world-space scene and the camera origin
 };
 
 // returns PRGPU_OK or an error code with `err` set

@@ -119,6 +119,7 @@ struct prgpu_scene {
 	prgpu_settings cfg{};
 	uint32_t n_pixels = 0, n_slots = 0;
 	std::vector<void*> allocations;
+	uint32_t bvh_units = 0; // 64-byte units of the BVH record array
 	// frame planes owned by the library (may be replaced by prgpu_bind_framebuffer)
 	float* own_xyz = nullptr;
 	uint32_t *own_samples = nullptr, *own_feedback = nullptr;
@@ -462,6 +463,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.single_tap	 = t.single_tap;
 	sc.centre_weight = t.centre_weight;
 	sc.eps_t		 = t.eps_t;
+	if (!(t.coord_scale <= prd::SCENE_COORD_MAX)) // also catches NaN / inf
+		return fail(PRGPU_EINVAL, "scene coordinates must be finite and at most 2^28 in magnitude (the BVH's quantisation grid)");
 	sc.n_tris		 = d->n_triangles;
 
 	// device LBVH
@@ -470,15 +473,18 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	if (!prd::build_lbvh(bin, bout, s->stream, err))
 		return fail(PRGPU_EDEVICE, "LBVH build failed: " + err);
 	s->allocations.push_back(bout.recs);
+	if (bout.leaf_units)
+		s->allocations.push_back(bout.leaf_units); // unit of every leaf record (4 bytes per leaf; only launch_tri_slot reads it)
 	sc.recs	   = bout.recs;
 	sc.n_inner = bout.n_inner;
 	sc.n_leaf  = bout.n_leaf;
+	s->bvh_units = bout.n_units;
 	{ // triangle -> leaf slot (the split traversal re-tests the winning triangle of a ray for u, v)
 		uint32_t* map = nullptr;
 		const int rc2 = s->alloc(map, std::max<size_t>(1, d->n_triangles), true);
 		if (rc2 != PRGPU_OK)
 			return rc2;
-		prd::launch_tri_slot(sc, map, s->stream);
+		prd::launch_tri_slot(sc, bout.leaf_units, map, s->stream);
 		sc.tri_slot = map;
 	}
 
@@ -1389,7 +1395,7 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	// closest-hit service rays take the split traversal (leaf tests through an LDS task queue: identical results, 17 % faster) unless
 	// PRGPU_TRACE_SPLIT=0 or the tree has too many records for the 24-bit task field
 	const bool split = read_knobs().trace_split;
-	if (split && s->sc.n_leaf > 0 && s->sc.n_inner + 2ull * s->sc.n_leaf < (1ull << 24) && !(s->sc.features & (prd::FEAT_SPHERES | prd::FEAT_QUADRICS))) {
+	if (split && s->sc.n_leaf > 0 && s->bvh_units < (1u << 24) && !(s->sc.features & (prd::FEAT_SPHERES | prd::FEAT_QUADRICS))) {
 		prd::launch_service_closest_split(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, const_cast<uint32_t*>(s->sc.tri_slot), s->gstats, s->stream);
 	} else
 		prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->gstats, s->stream);
