@@ -386,9 +386,9 @@ __device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int n
 			w[7 + a] |= h << (8 * k); // q1.w, q2.xy = hi.x, hi.y, hi.z
 		}
 		const int src = used ? k : 0; // unused slot: child 0's payload (a valid record whatever happens)
-		w[11] |= ((offs[src] << 1) | (ch[src].leaf ? REC_LEAF_BIT : 0u)) << (8 * k);
+		w[11] |= ((offs[src] << REC_UNIT_SHIFT) | (ch[src].leaf ? REC_LEAF_BIT : 0u)) << (8 * k);
 	}
-	w[10]	   = 2u * base_unit;
+	w[10]	   = base_unit << REC_UNIT_SHIFT;
 	uint4* dst = reinterpret_cast<uint4*>(rec);
 	for (int q = 0; q < 4; ++q)
 		dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
@@ -467,13 +467,14 @@ __global__ void k_validate(uint32_t n_inner, const uint32_t* __restrict__ inner_
 	}
 	const uint32_t* w	= reinterpret_cast<const uint32_t*>(recs + unit);
 	const uint32_t base = w[10], pw = w[11];
-	bool ok				= (base & 1u) == 0u && base >= 4u;
+	bool ok				= (base & 3u) == 0u && base >= (2u << REC_UNIT_SHIFT);
 	for (int a = 0; a < 3 && ok; ++a) {
 		const uint32_t e = (w[3] >> (8 * a)) & 0xFFu;
 		ok				 = e >= 27u && e <= 157u; // 2^-100 .. 2^30
 	}
 	for (int k = 0; k < 4 && ok; ++k) {
-		const uint32_t ref = base + ((pw >> (8 * k)) & 0xFFu), cu = ref >> 1;
+		const uint32_t ref = base + ((pw >> (8 * k)) & 0xFFu), cu = ref >> REC_UNIT_SHIFT;
+		ok				   = ok && (ref & 2u) == 0u;
 		if (ref & REC_LEAF_BIT) {
 			ok = (cu & 1u) == 0u && cu + 2u <= n_units;
 			if (ok) {
@@ -706,8 +707,8 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipMemcpyAsync(&group_units, gbase + out.n_inner, 4, hipMemcpyDeviceToHost, stream));
 			HIPC(hipStreamSynchronize(stream));
 			out.n_units = 2u + group_units;
-			if (size_t(out.n_units) >= (size_t(1) << 31)) {
-				err = "the BVH needs more than 2^31 record units";
+			if (size_t(out.n_units) >= (size_t(1) << 30)) {
+				err = "the BVH needs more than 2^30 record units";
 				goto done;
 			}
 			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * size_t(out.n_units)));

@@ -47,25 +47,26 @@ constexpr float CIE_Y_NORM	   = CIE_Y_NORM_SUM * CIE_DELTA;
 //   inner (one unit; 48 of its 64 bytes are used and fetched): a 4-wide node whose child boxes are bytes on a per-record
 //          power-of-two grid and whose children lie CONTIGUOUSLY from one base unit (leaves first, then inner records):
 //          q0 = grid origin.xyz, exponent bytes (ex | ey << 8 | ez << 16; grid step of axis a = 2^(e_a - 127));
-//          q1 = lo.x, lo.y, lo.z, hi.x (one byte per child in each word); q2 = hi.y, hi.z, base ref (2 * first child unit),
-//          payload bytes (byte k = (unit offset of child k from the base) << 1 | leaf bit; an unused slot repeats child 0's payload
+//          q1 = lo.x, lo.y, lo.z, hi.x (one byte per child in each word); q2 = hi.y, hi.z, base ref (4 * first child unit),
+//          payload bytes (byte k = (unit offset of child k from the base) << 2 | leaf bit; an unused slot repeats child 0's payload
 //          and carries an inverted byte box, which fails the slab test -- and is harmless should it ever pass).
 //          The decoded plane origin + byte * step (EXACT, never formed by the traversal) lies at least 2^-14 grid steps outside
 //          the padded fp32 child box: the builder checks every byte in double precision (bvh.hip, write_inner_q); that margin
 //          pays for the fused one-fma-per-plane slab arithmetic of the traversal step.
 //   leaf  (two units, 128 B = one L2 line, 128-byte aligned): triangle k (k < 3) in floats [10k, 10k+10) = v0, v1, v2
 //          (world space), original triangle index; float 30 = triangle count, float 31 = material classes
-// child ref: 2 * unit index | REC_LEAF_BIT for leaves; REC_EMPTY = no record.
+// child ref: 4 * unit index | REC_LEAF_BIT for leaves (a record's address is base + 16 * (ref & ~3): one v_lshl_add_u64); REC_EMPTY = no record.
 struct __attribute__((aligned(64))) Rec64 {
 	float4 q[4];
 };
 static_assert(sizeof(Rec64) == 64, "Rec64 must be 64 bytes");
 constexpr uint32_t REC_LEAF_BIT = 1u;
 constexpr uint32_t REC_EMPTY	= 0xFFFFFFFFu;
-// the record a ref names (ref & ~1 = 2 * unit, 32 bytes per half unit)
+constexpr uint32_t REC_UNIT_SHIFT = 2u; // ref = unit << 2 | leaf bit
+// the record a ref names (ref & ~3 = 4 * unit, 16 bytes per quarter unit)
 __host__ __device__ __forceinline__ const float4* rec_ptr(const Rec64* recs, uint32_t ref)
 {
-	return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(recs) + size_t(ref & ~REC_LEAF_BIT) * 32u);
+	return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(recs) + (size_t(ref & ~3u) << 4));
 }
 // Acceptance rule of the quantised slab test and of the stack re-check: entry <= exit * SLAB_REL + eps_t.  box_hit below states the
 // reference rule (factor 1.000001f = 1 + 16 u, u = 2^-24, slack eps); SLAB_REL = 1 + 48 u and eps_t = eps * (1 + 2^-16) absorb the

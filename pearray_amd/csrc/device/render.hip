@@ -23,6 +23,17 @@
 
 namespace prd {
 
+// Wave-uniform lane sets as 64-bit masks in scalar registers: a vote, a count (forced into a 32-bit scalar: a 64-bit comparison of two
+// counts would be done by the vector unit) and the way back from a mask to a lane predicate (free: it becomes the exec mask).
+__device__ __forceinline__ unsigned long long lane_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ int wave_popc(unsigned long long m)
+{
+	int n = __builtin_popcountll(m);
+	asm volatile("" : "+s"(n));
+	return n;
+}
+
 struct Hit {
 	float t, u, v;
 	uint32_t tri; // original triangle index, INVALID on miss
@@ -128,7 +139,7 @@ __device__ __forceinline__ void trav_pop(Trav& s, STK& st)
 // builder's 2^-14-step margin around every child box pays for, the relative part goes into SLAB_REL.  Hit ids
 // do not depend on which conservative boxes a ray visits: a hit is argmin (t, triangle index) over the triangles that pass the
 // watertight test (leaf_test).  key[k] = entry distance of child k with its low byte replaced by the child's payload (unit offset
-// from the record's base ref << 1 | leaf bit), 0xFFFFFFFF for a miss: sorting the keys as integers sorts the children near to far
+// from the record's base ref << 2 | leaf bit), 0xFFFFFFFF for a miss: sorting the keys as integers sorts the children near to far
 // (entry distances are >= tmin >= 0) and carries each child's ref along for free.
 #define PR_UB(w, k) ((float)(((w) >> (8 * (k))) & 0xFFu)) /* byte k of a packed word as a float: v_cvt_f32_ubyteK */
 __device__ __forceinline__ void inner_keys(const Trav& s, const float4& q0, const float4& q1, const float4& q2, uint32_t key[4])
@@ -315,34 +326,38 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_
 		}
 		if (!__any(has_ray))
 			break;
+		unsigned long long m_has = lane_ballot(has_ray); // the lanes that hold a ray, as a scalar mask (see path_persistent)
 		for (;;) {
 			// One path per wave step: the lanes at inner nodes or the lanes at leaves, whichever are more.  The other
 			// lanes wait, so every instruction of the step runs for the majority instead of both paths for a few.
-			const bool at_leaf		= has_ray && (s.cur & REC_LEAF_BIT) != 0;
-			const bool at_inner		= has_ray && !at_leaf;
-			const int n_leaf		= __popcll(__ballot(at_leaf));
-			const int n_inner		= __popcll(__ballot(at_inner));
+			const unsigned long long m_lb	 = lane_ballot((s.cur & REC_LEAF_BIT) != 0u);
+			const unsigned long long m_leaf	 = m_has & m_lb, m_inner = m_has & ~m_lb;
+			const int n_leaf = wave_popc(m_leaf), n_inner = wave_popc(m_inner);
 			if (COUNT && lane == 0)
 				++witers;
-			if (n_inner >= n_leaf) {
-				if (at_inner) {
+			const bool do_inner = n_inner >= n_leaf;
+			if (lane_in(do_inner ? m_inner : m_leaf)) {
+				if (do_inner) {
 					if (COUNT)
 						++cn;
 					trav_inner<ANY>(sc, s, st);
+				} else {
+					if (COUNT)
+						++cl;
+					trav_leaf<ANY>(sc, s, st);
 				}
-			} else if (at_leaf) {
-				if (COUNT)
-					++cl;
-				trav_leaf<ANY>(sc, s, st);
 			}
-			if (has_ray && s.cur == REC_EMPTY) {
-				store(my_ray, s.best);
-				has_ray = false;
+			const unsigned long long m_done = m_has & lane_ballot(s.cur == REC_EMPTY);
+			if (m_done != 0ull) {
+				if (lane_in(m_done))
+					store(my_ray, s.best);
+				m_has &= ~m_done;
 			}
-			const int active = __popcll(__ballot(has_ray));
+			const int active = wave_popc(m_has);
 			if (active == 0 || (!exhausted && active < refill_below))
 				break;
 		}
+		has_ray = lane_in(m_has);
 	}
 	if (COUNT) {
 		if (cn)
@@ -2661,18 +2676,23 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			continue;
 		}
 		spins = 0;
+		// The stepping loop keeps its lane sets as wave-uniform 64-bit masks in scalar registers (which lanes hold a ray, which of them wait
+		// for their write-out) and turns a mask back into a lane predicate with inverse_ballot (free: it is the exec mask): the votes,
+		// counts and comparisons of a step are scalar instructions, 3 vector instructions per step remain for them (the leaf-bit and the
+		// end-of-ray tests of `cur`) where the per-lane booleans cost ~ 20.
+		unsigned long long m_has  = lane_ballot(has_ray);
+		unsigned long long m_wait = m_has & lane_ballot(s.cur == REC_EMPTY); // finished, waiting for the write-out below
 		for (;;) {
 			// one kind of record per wave step (see trace_persistent)
-			const bool at_leaf	= has_ray && s.cur != REC_EMPTY && (s.cur & REC_LEAF_BIT) != 0; // (a finished ray waits for its write-out, below)
-			const bool at_inner = has_ray && (s.cur & REC_LEAF_BIT) == 0;
-			const int n_leaf	= __popcll(__ballot(at_leaf));
-			const int n_inner	= __popcll(__ballot(at_inner));
+			const unsigned long long m_lb	 = lane_ballot((s.cur & REC_LEAF_BIT) != 0u);
+			const unsigned long long m_leaf	 = m_has & m_lb & ~m_wait; // (REC_EMPTY carries the leaf bit)
+			const unsigned long long m_inner = m_has & ~m_lb;
+			const int n_leaf = wave_popc(m_leaf), n_inner = wave_popc(m_inner);
 			if (COUNT && lane == 0)
 				++witers;
 			// The majority kind only; the record is fetched before the branch.  (Measured and dropped: advancing BOTH kinds in one step in
 			// thinly occupied waves -- 30 % fewer, proportionally longer steps --, and a bias of the vote towards either kind.)
 			const bool do_inner = n_inner >= n_leaf;
-			const bool go_inner = do_inner && at_inner, go_leaf = !do_inner && at_leaf;
 			// (Measured and dropped, see DESIGN.md: a cooperative fetch -- eight lanes reading one record's eight chunks, handed over
 			// through an LDS staging buffer: 2x the raw gather rate in tools/micro/gather_bench.hip but 11 % slower here; 4-byte
 			// packed stack entries to make room for a 4th wave per SIMD: +5 % time, and the 4th wave bought nothing; postponed
@@ -2680,10 +2700,10 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			// records from the delayed shrinking of best.t, 1.5 % slower; 8-wide quantised nodes: 23 % fewer inner records, 2.5x the
 			// instructions per step, 13 % slower.)
 			const unsigned long long t0s = COUNT ? wall_clock64() : 0ull;
-			if (go_inner || go_leaf) {
+			if (lane_in(do_inner ? m_inner : m_leaf)) {
 				const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
 				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2]; // an inner record (48 of its 64 bytes are used), or the start of a leaf
-				if (go_inner) {
+				if (do_inner) {
 					if (COUNT) {
 						cn_c += s.any ? 0 : 1;
 						cn_a += s.any ? 1 : 0;
@@ -2707,19 +2727,20 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			// Finished rays are written out in batches: the write-out releases the hit to the block (it waits for the wave's global stores,
 			// about a microsecond during which none of the wave's rays moves), and a finished lane has nothing to do anyway until the wave
 			// refills -- so wait until `fin_batch` lanes are done, or until the wave is short of running rays and wants new ones.
-			const bool done = has_ray && s.cur == REC_EMPTY;
-			bool fin		= done;
+			const unsigned long long m_done = m_has & lane_ballot(s.cur == REC_EMPTY);
+			unsigned long long m_fin		= m_done;
 			if (a.fin_batch > 1) {
-				const int n_done = __popcll(__ballot(done));
-				const int n_run	 = __popcll(__ballot(has_ray && !done));
+				const int n_done = wave_popc(m_done);
+				const int n_run	 = wave_popc(m_has & ~m_done);
 				if (n_done < a.fin_batch && n_run >= a.refill_below)
-					fin = false;
+					m_fin = 0ull;
 			}
 			const unsigned long long t0f = COUNT ? wall_clock64() : 0ull;
-			if (__any(fin)) {
+			if (m_fin != 0ull) {
 #if PR_FIN_PRIO
 				__builtin_amdgcn_s_setprio(PR_FIN_PRIO);
 #endif
+				const bool fin = lane_in(m_fin);
 				bool last	   = false;
 				uint32_t entry = 0;
 				int qcls	   = 0;
@@ -2747,8 +2768,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						qcls = QR; // no bounce ray followed: the path has ended
 					if (NQ > 1 && last && !(old & PP_DEAD)) // class of the material the slot's path ray hit (the shadow ray may finish last)
 						qcls = s.any ? (int)((old >> PP_CLS_SHIFT) & 3u) : (int)(s.cls & 3u);
-					has_ray = false;
 				}
+				m_has &= ~m_fin;
 				for (int q = 0; q < NQ + 1; ++q)
 					ring_push(sh.q_shade[q], SHADE_MASK, &sh.shade_tail[q], last && qcls == q, entry);
 #if PR_FIN_PRIO
@@ -2757,7 +2778,8 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				if (COUNT)
 					t_fin += wall_clock64() - t0f;
 			}
-			const int active = __popcll(__ballot(has_ray));
+			m_wait			 = m_done & m_has;
+			const int active = wave_popc(m_has);
 			if (active == 0)
 				break;
 			if (active < a.refill_below) { // under-occupied: leave if there is anything to refill from or to shade
@@ -2769,6 +2791,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					break;
 			}
 		}
+		has_ray = lane_in(m_has);
 	}
 	if (COUNT) {
 		if (cn_c)
@@ -2885,8 +2908,8 @@ __device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4&
 				__hip_atomic_fetch_add(pending_own, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
-				if (lf[k]) // task = leaf unit << 8 | owner lane (the ref is 2 * unit | 1)
-					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], (((base + (key[k] & 0xFFu)) >> 1) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				if (lf[k]) // task = leaf unit << 8 | owner lane (the ref is unit << 2 | 1)
+					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], (((base + (key[k] & 0xFFu)) >> REC_UNIT_SHIFT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
 	if (!active)
