@@ -5,7 +5,7 @@
 namespace prd {
 // gstats: PRGPU_STAT_COUNT statistics, then inner/leaf record counters of closest and any-hit traversal, then wave-iteration
 // counters, then the persistent kernel's shading passes / shaded vertices / time split
-constexpr int N_DEVICE_COUNTERS = PRGPU_STAT_COUNT + 18; // ... + diagnostics (PRGPU_DEBUG_COUNTERS): leaf-step / inner-step ticks, shader cycles, refill ticks, ray-end ticks
+constexpr int N_DEVICE_COUNTERS = PRGPU_STAT_COUNT + 30; // ... + diagnostics (PRGPU_DEBUG_COUNTERS): leaf-step / inner-step ticks, shader cycles, refill ticks, ray-end ticks
 
 // Scratch of one persistent traversal launch: queue head (u32) and the per-thread stack spill slab.
 // Launches that may run concurrently need separate workspaces.
@@ -44,18 +44,20 @@ struct PersistentGeometry {
 PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, uint32_t max_slots_per_block);
 uint32_t persistent_slot_padding(); // per-slot arrays need n_pixels + this many entries
 uint32_t persistent_block_threads(); // 256 or 768 (PR_PP_BLOCK)
+int shade_ticks_counter(); // index into gstats of the instrumented kernel's timers: ticks in shading passes, idle, alive (summed over waves)
 // What a host may tune in the persistent kernel without changing a result (prgpu_api.hip reads the PRGPU_PP_* knobs into this)
 struct PersistentTuning {
-	uint32_t slots	  = 512; // path slots per block of 256 lanes (256 .. 512)
+	uint32_t slots	  = 384; // path slots per block of 256 lanes (256 .. 512; round 4: 384 is 3 % faster than 512 on C4, profiles/r04_knobs.log)
 	int shade_min	  = 64;	 // a shading pass starts once this many vertices of one class wait ...
 	int shade_partial = 16;	 // ... or this many when no ray is queued and the wave is short of rays anyway
 	int fin_batch	  = 16;	 // finished rays are written out once this many lanes of a wave hold one
 	int occupancy	  = 3;	 // waves per SIMD the kernel variant is compiled for (3: 168 VGPRs, 2: 256)
-	int shader_wave	  = -1;	 // 1 / 0: a dedicated shading wave per block or not; -1: when every owned pixel is in flight at once
+	int shader_wave	  = -1;	 // 0 .. 2: dedicated shading waves per block; -1: one when every owned pixel is in flight at once, else by the
+							 // measured share of shading in the wave time of the scene's first launch (prgpu_api.hip, render_persistent)
 	bool resident	  = true; // pixels stay with a block, not with a slot (off: a slot keeps its pixel for all samples of a launch)
 };
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
-							bool count, const TraceWorkspace& ws, const PersistentTuning& tune, bool shader_wave, uint32_t* next_pixel, uint32_t* error,
+							bool count, const TraceWorkspace& ws, const PersistentTuning& tune, int shader_waves /* of a block's four: 0 .. 2 */, uint32_t* next_pixel, uint32_t* error,
 							unsigned long long* gstats, hipStream_t st);
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st);
 // lockstep pipeline, PRGPU_SORT_RAYS=1 (experiment): the active list ordered by (Morton code of the ray origin, direction octant)

@@ -40,7 +40,8 @@ struct Hit {
 };
 
 // indices into the extra device counters after the 11 statistics
-enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES, CNT_SHADE_TICKS, CNT_IDLE_TICKS, CNT_TOTAL_TICKS, CNT_LEAF_TICKS, CNT_INNER_TICKS, CNT_TOTAL_CYCLES, CNT_REFILL_TICKS, CNT_FIN_TICKS, CNT_CAMERA_TICKS, CNT_VERTEX_TICKS };
+enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CNT_TRIS_ANY, CNT_WAVE_ITERS_CLOSEST, CNT_WAVE_ITERS_ANY, CNT_SHADE_BATCHES, CNT_SHADE_LANES, CNT_SHADE_TICKS, CNT_IDLE_TICKS, CNT_TOTAL_TICKS, CNT_LEAF_TICKS, CNT_INNER_TICKS, CNT_TOTAL_CYCLES, CNT_REFILL_TICKS, CNT_FIN_TICKS, CNT_CAMERA_TICKS, CNT_VERTEX_TICKS,
+	   CNT_CLS_TICKS0, CNT_CLS_BATCHES0 = CNT_CLS_TICKS0 + 4, CNT_CLS_LANES0 = CNT_CLS_BATCHES0 + 4 }; // per shade queue (material classes, then ended paths): pass time, passes, lanes
 
 // ---- traversal ------------------------------------------------------------------------------------------------
 // Persistent waves pull rays from a queue head (one atomic per wave refill), walk the 4-wide BVH one
@@ -2263,7 +2264,7 @@ struct PersistentArgs {
 	int refill_below;
 	uint32_t shade_min; // shade as soon as this many vertices wait (<= 64)
 	uint32_t shade_partial; // ... or this many when no rays are queued and the wave is short of rays anyway (fewer than refill_below in flight)
-	uint32_t shader_wave; // 1: the block's last wave only shades (any batch size, never holds rays); the others trace and help with full
+	uint32_t shader_wave; // n > 0: the block's last n waves only shade (any batch size, never hold rays); the others trace and help with full
 						  // batches once PP_SHADE_HELP vertices wait
 	int fin_batch;		  // finished rays of a wave are written out once this many lanes hold one (or the wave is under-occupied); 1: at once
 	uint32_t direct_map;  // 1: every owned pixel is in flight at once and slot k renders owned[k] (no hand-out counter): the host decides which block gets which pixel
@@ -2366,12 +2367,14 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 	unsigned long long t_idle_since = 0;
 	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, wleaf = 0, sbatches = 0, slanes = 0;
 	unsigned long long t_shade = 0, t_idle = 0, t_leaf = 0, t_inner = 0, t_refill = 0, t_fin = 0, t_cam = 0, t_vert = 0;
+	unsigned long long t_cls[4] = { 0, 0, 0, 0 };
+	uint32_t b_cls[4] = { 0, 0, 0, 0 }, l_cls[4] = { 0, 0, 0, 0 };
 	const unsigned long long t_start = COUNT ? wall_clock64() : 0ull;
 	const unsigned long long c_start = COUNT ? (unsigned long long)clock64() : 0ull;
 
 	const uint32_t shader_idx = 3u; // one wave in four (rotating it with the block's dispatch layer, so that the shading waves of the blocks that
 									// share a CU sit on different SIMDs, changes nothing: 2.38 - 2.43 ms per iteration at 1/8 of the C4 frame either way)
-	const bool shader		  = a.shader_wave != 0u && ((threadIdx.x >> 6) & 3u) == shader_idx;
+	const bool shader		  = a.shader_wave != 0u && ((threadIdx.x >> 6) & 3u) + a.shader_wave > shader_idx; // the block's last `shader_wave` waves
 	const uint32_t shade_full = a.shader_wave != 0u ? PP_SHADE_HELP : a.shade_min;
 	for (;;) {
 		const int n_act	  = __popcll(__ballot(has_ray));
@@ -2621,6 +2624,13 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 #endif
 				if (COUNT)
 					t_shade += wall_clock64() - t0;
+				if (COUNT && lane == 0)
+					for (int q = 0; q < NQ + 1; ++q) // (wave-uniform class: a compile-time index keeps the arrays in registers)
+						if (q == cls) {
+							t_cls[q] += wall_clock64() - t0;
+							b_cls[q] += 1u;
+							l_cls[q] += n;
+						}
 			}
 			continue;
 		}
@@ -2821,6 +2831,11 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			atomicAdd(&a.gstats[CNT_CAMERA_TICKS], t_cam);
 			atomicAdd(&a.gstats[CNT_VERTEX_TICKS], t_vert);
 			atomicAdd(&a.gstats[CNT_TOTAL_CYCLES], (unsigned long long)clock64() - c_start);
+			for (int q = 0; q < NQ + 1; ++q) {
+				atomicAdd(&a.gstats[CNT_CLS_TICKS0 + q], t_cls[q]);
+				atomicAdd(&a.gstats[CNT_CLS_BATCHES0 + q], (unsigned long long)b_cls[q]);
+				atomicAdd(&a.gstats[CNT_CLS_LANES0 + q], (unsigned long long)l_cls[q]);
+			}
 		}
 		if (threadIdx.x == 0) // diagnostics (PRGPU_DUMP_BLOCK_LIFE): the block's lifetime and vertex count, in its own first spill entry (no longer needed)
 			a.spill[blockIdx.x * TRAV_BLOCK] = make_uint2((uint32_t)(wall_clock64() - t_start), sh.bs.v[PRGPU_STAT_CAMERA_DEPTH] + sh.bs.v[PRGPU_STAT_BACKGROUND_HITS]);
@@ -3304,9 +3319,10 @@ PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, ui
 }
 uint32_t persistent_slot_padding() { return PP_SLOTS_MAX; }
 uint32_t persistent_block_threads() { return PP_BLOCK; }
+int shade_ticks_counter() { return CNT_SHADE_TICKS; } // ... followed by CNT_IDLE_TICKS, CNT_TOTAL_TICKS
 
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
-							bool count, const TraceWorkspace& ws, const PersistentTuning& tune, bool shader_wave, uint32_t* next_pixel, uint32_t* error,
+							bool count, const TraceWorkspace& ws, const PersistentTuning& tune, int shader_waves, uint32_t* next_pixel, uint32_t* error,
 							unsigned long long* gstats, hipStream_t st)
 {
 	const uint32_t max_slots_per_block = tune.slots;
@@ -3324,7 +3340,7 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	a.refill_below	  = ws.refill_below;
 	a.shade_min		  = (uint32_t)std::min(64, std::max(1, tune.shade_min));
 	a.shade_partial	  = (uint32_t)std::min(64, std::max(1, tune.shade_partial));
-	a.shader_wave	  = shader_wave ? 1u : 0u;
+	a.shader_wave	  = PP_BLOCK == 256 ? (uint32_t)std::min(2, std::max(0, shader_waves)) : (shader_waves ? 1u : 0u);
 	a.gstats		  = gstats;
 	a.direct_map	  = all_in_flight ? 1u : 0u;
 	a.fin_batch		  = std::min(64, std::max(1, tune.fin_batch));

@@ -77,12 +77,12 @@ Knobs read_knobs()
 		k.mode_invalid = k.mode < 0;
 	}
 	k.pp_slots_set		  = getenv("PRGPU_PP_SLOTS") != nullptr;
-	k.pp.slots			  = (uint32_t)num("PRGPU_PP_SLOTS", k.pp.slots, 256, 1 << 20);
+	k.pp.slots			  = (uint32_t)num("PRGPU_PP_SLOTS", k.pp.slots, 256, prd::persistent_slot_padding()); // (= the kernel's PP_SLOTS_MAX: every user of the knob sees the value the kernel runs with)
 	k.pp.shade_min		  = (int)num("PRGPU_PP_SHADE_MIN", k.pp.shade_min, 1, 64);
 	k.pp.shade_partial	  = (int)num("PRGPU_PP_SHADE_PARTIAL", k.pp.shade_partial, 1, 64);
 	k.pp.fin_batch		  = (int)num("PRGPU_PP_FIN_BATCH", k.pp.fin_batch, 1, 64);
 	k.pp.occupancy		  = (int)num("PRGPU_PP_OCCUPANCY", k.pp.occupancy, 2, 3);
-	k.pp.shader_wave	  = (int)num("PRGPU_PP_SHADER", k.pp.shader_wave, -1, 1);
+	k.pp.shader_wave	  = (int)num("PRGPU_PP_SHADER", k.pp.shader_wave, -1, 2);
 	k.pp.resident		  = num("PRGPU_PP_RESIDENT", 1, 0, 1) != 0;
 	k.pp_refill			  = (int)num("PRGPU_PP_REFILL", k.pp_refill, 1, 64);
 	k.pp_blocks_per_cu	  = (int)num("PRGPU_PP_BLOCKS_PER_CU", 0, 0, 8);
@@ -120,6 +120,9 @@ struct prgpu_scene {
 	uint32_t n_pixels = 0, n_slots = 0;
 	std::vector<void*> allocations;
 	uint32_t bvh_units = 0; // 64-byte units of the BVH record array
+	int pp_shader_waves = -1; // persistent kernel: dedicated shading waves per block, decided after the first launch (-1: not yet)
+	double pp_shading_share = 0.0; // ... from this measured share of shading passes in the wave time
+	uint64_t pp_launches = 0;
 	// frame planes owned by the library (may be replaced by prgpu_bind_framebuffer)
 	float* own_xyz = nullptr;
 	uint32_t *own_samples = nullptr, *own_feedback = nullptr;
@@ -576,7 +579,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		{ // persistent path kernel: its own grid (measured best: 3 blocks per CU at 3 waves per SIMD, refill below 48 lanes)
 			uint32_t pp_blocks_per_cu = 768u / prd::persistent_block_threads(); // twelve waves per CU either way
 			if (!s->knobs.pp_slots_set)
-				s->knobs.pp.slots = 512u * (prd::persistent_block_threads() / 256u);
+				s->knobs.pp.slots = prd::PersistentTuning().slots * (prd::persistent_block_threads() / 256u);
 			if (s->knobs.pp_blocks_per_cu)
 				pp_blocks_per_cu = (uint32_t)s->knobs.pp_blocks_per_cu;
 			s->ws_pp.max_blocks = (uint32_t)std::max(1, prop.multiProcessorCount) * pp_blocks_per_cu;
@@ -899,7 +902,26 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	// and the other three only trace, so that no ray in flight is parked behind a shading pass (1/8 of the C4 frame: 2.62 -> 2.30 ms
 	// per iteration, 1/16: 2.23 -> 1.83).  With more pixels than slots the shared scheme is faster (full frame 13.7 vs 14.3 ms).
 	const bool all_in_flight = uint64_t(s->n_slots) <= uint64_t(s->ws_pp.max_blocks) * s->knobs.pp.slots;
-	const bool shader_wave	 = s->knobs.pp.shader_wave >= 0 ? s->knobs.pp.shader_wave != 0 : all_in_flight;
+	// With more pixels than slots the number of shading waves follows the scene: a wave that shades parks its rays in flight, so a scene
+	// whose vertices are expensive (C5: sky / sun light sampling, rough closures -- 29 % of the wave time in shading passes at a fill of
+	// 0.77) loses that share of its traversal capacity in EVERY wave, while one wave of four that does nothing else serves the same load
+	// with fuller passes (C5 + 7 %, C4 - 10 %: profiles/r04_knobs.log).  The first launch of a scene therefore runs the INSTRUMENTED variant
+	// of the kernel (same results; it times its shading passes), and later launches use round(4 * share) shading waves, at most two.
+	// (Two clock reads per pass in the plain kernel were measured instead: 4 % slower on C4 -- the timers' scalar registers spill.)
+	const bool calibrating = s->knobs.pp.shader_wave < 0 && !all_in_flight;
+	auto decide = [&]() -> int { // after the calibration launch: read its timers, once
+		if (!calibrating || s->pp_shader_waves >= 0 || s->pp_launches == 0)
+			return PRGPU_OK;
+		HIP_TRY(hipStreamSynchronize(s->stream));
+		unsigned long long t[3] = { 0, 0, 0 }; // shading, idle, alive
+		HIP_TRY(hipMemcpy(t, s->gstats + prd::shade_ticks_counter(), sizeof(t), hipMemcpyDeviceToHost));
+		const double share	= t[2] > 0 ? double(t[0]) / double(t[2]) : 0.0;
+		s->pp_shader_waves	= share >= 0.22 ? (share >= 0.45 ? 2 : 1) : 0;
+		s->pp_shading_share = share;
+		if (s->knobs.debug_counters)
+			fprintf(stderr, "[prgpu] shading passes took %.1f %% of the first launch's wave time: %d dedicated shading wave(s) per block from now on\n", 100.0 * share, s->pp_shader_waves);
+		return PRGPU_OK;
+	};
 	if (!all_in_flight)
 		ps.cost = nullptr; // the per-pixel path cost only serves tune_pixel_order
 	const bool ring			= !s->sc.single_tap; // multi-tap filter: one launch fills at most pp_planes iteration planes
@@ -908,12 +930,18 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 		ps.plane_stride = 3u * s->n_pixels;
 	}
 	for (uint32_t b = iter_begin; b < iter_end;) {
-		const uint32_t e = (uint32_t)std::min<uint64_t>(iter_end, uint64_t(b) + chunk);
+		const int rc_decide = decide();
+		if (rc_decide != PRGPU_OK)
+			return rc_decide;
+		const bool calibration = calibrating && s->pp_shader_waves < 0; // the scene's first launch: instrumented, at most 8 iterations
+		const uint32_t e	   = (uint32_t)std::min<uint64_t>(iter_end, uint64_t(b) + (calibration ? std::min(chunk, 8u) : chunk));
+		const int shader_wave  = s->knobs.pp.shader_wave >= 0 ? s->knobs.pp.shader_wave : (all_in_flight ? 1 : std::max(0, s->pp_shader_waves));
 		ps.iter_base = b;
 		s->time_begin(6, s->stream);
-		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument, s->ws_pp, s->knobs.pp, shader_wave, s->pp_next, s->pp_error, s->gstats, s->stream);
+		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument || calibration, s->ws_pp, s->knobs.pp, shader_wave, s->pp_next, s->pp_error, s->gstats, s->stream);
 		s->time_end(s->stream);
 		HIP_TRY(hipGetLastError());
+		++s->pp_launches;
 		if (ring) { // filter taps + running mean, iteration by iteration in order (FrameOutputDevice.cpp:202-221)
 			prd::PathState pr = s->ps;
 			for (uint32_t i = b; i < e; ++i) {
@@ -1314,6 +1342,11 @@ int prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out)
 					100 * host[PRGPU_STAT_COUNT + 8] / T, 100 * host[PRGPU_STAT_COUNT + 9] / T, 100 * host[PRGPU_STAT_COUNT + 11] / T, 100 * host[PRGPU_STAT_COUNT + 12] / T,
 					100 * host[PRGPU_STAT_COUNT + 14] / T, 100 * host[PRGPU_STAT_COUNT + 15] / T, 100 * host[PRGPU_STAT_COUNT + 17] / T, 100 * host[PRGPU_STAT_COUNT + 16] / T,
 					100.0 * double(host[PRGPU_STAT_COUNT + 13]) / T);
+			for (int q = 0; q < 4; ++q) // per shade queue: the material classes, then (last used) the ended paths
+				if (host[PRGPU_STAT_COUNT + 22 + q])
+					fprintf(stderr, "[prgpu]   shade queue %d: %.1f %% of wave time, %.0f passes, fill %.3f, %.2f us per pass\n", q, 100 * host[PRGPU_STAT_COUNT + 18 + q] / T,
+							double(host[PRGPU_STAT_COUNT + 22 + q]), double(host[PRGPU_STAT_COUNT + 26 + q]) / (64.0 * double(host[PRGPU_STAT_COUNT + 22 + q])),
+							0.01 * double(host[PRGPU_STAT_COUNT + 18 + q]) / double(host[PRGPU_STAT_COUNT + 22 + q]));
 		}
 	return PRGPU_OK;
 }

@@ -373,7 +373,7 @@ def test_persistent_kernel_slot_and_policy_knobs_do_not_change_results(monkeypat
     ref = _render_mode(monkeypatch, "lockstep", sc, [4])
     for env in (dict(PRGPU_PP_SLOTS="256", PRGPU_PP_OCCUPANCY="2"), dict(PRGPU_PP_SLOTS="1024", PRGPU_PP_SHADE_PARTIAL="1"),
                 dict(PRGPU_PP_BLOCKS_PER_CU="1", PRGPU_PP_REFILL="64"), dict(PRGPU_PP_SHADE_MIN="8", PRGPU_PP_REFILL="20"),
-                dict(PRGPU_PP_FIN_BATCH="1"), dict(PRGPU_PP_FIN_BATCH="48"), dict(PRGPU_PP_SHADER="1"),
+                dict(PRGPU_PP_FIN_BATCH="1"), dict(PRGPU_PP_FIN_BATCH="48"), dict(PRGPU_PP_SHADER="1"), dict(PRGPU_PP_SHADER="2", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"),
                 dict(PRGPU_PP_SHADER="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"), dict(PRGPU_PP_RESIDENT="0", PRGPU_PP_SLOTS="256", PRGPU_PP_MAX_BLOCKS="12"),
                 dict(PRGPU_PP_LAUNCH_SAMPLES="1", PRGPU_PP_LAUNCH_MIN_ITERS="1", PRGPU_PP_TUNE_ORDER="0")):
         for k, v in env.items():
@@ -403,6 +403,25 @@ def test_resident_pixel_scheduling_of_the_persistent_kernel_is_bit_exact(monkeyp
     for n in (3, 2, 1, 1):
         g2.render(n)
     g2.waitForFinish()
+    for a, b in zip(g.output(), g2.output()):
+        assert np.array_equal(a, b)
+    assert g.statistics() == g2.statistics()
+
+
+def test_shading_waves_chosen_after_the_first_launch_do_not_change_results(monkeypatch):
+    """More pixels than slots: the first launch of a scene measures the share of shading in its wave time, later launches run with
+    0 .. 2 dedicated shading waves per block (render_persistent).  A shading-heavy scene (rough closures, environment light) rendered in
+    several calls -- the decision falls between them -- equals the oracle and a one-call render."""
+    monkeypatch.setenv("PRGPU_MODE", "persistent")
+    monkeypatch.setenv("PRGPU_PP_MAX_BLOCKS", "6")
+    monkeypatch.setenv("PRGPU_PP_SLOTS", "256")
+    sc = scene.cornell_rough(96, 80, spp=6)
+    g, o = render_both(sc, iters=6)
+    assert_parity(g, o, exact=True)
+    g2 = backend.RenderContext(sc)
+    for n in (2, 1, 3):
+        g2.render(n)
+        g2.waitForFinish()
     for a, b in zip(g.output(), g2.output()):
         assert np.array_equal(a, b)
     assert g.statistics() == g2.statistics()
