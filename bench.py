@@ -189,6 +189,35 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u"):
             "family_ms_per_iter": {k: round(v[0] / iters, 3) for k, v in fam.items() if v[1]}}
 
 
+def secondary_c5(device, steps=20, warmup=8):
+    """BASELINE config C5 (examples/complex.prc) beside the headline line: the same timed region and roofline on one GPU, without a CPU leg.
+    (BASELINE names 8 GPUs for C5; a one-GPU figure is what a one-GPU box can measure -- tools/gpu_shares.py holds its tile-share table.)"""
+    import torch
+    from pearray_amd import backend, scene
+    sc = scene.ArrayScene(os.path.join(ROOT, "tests", "golden", "scenes", "complex_c5.npz"))
+    sc.desc.settings.width, sc.desc.settings.height = W, H
+    ctx = backend.RenderContext(sc, device=device)
+    ctx.render(warmup)
+    ctx.waitForFinish()
+    before = ctx.statistics()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.render(steps)
+    ctx.waitForFinish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    after = ctx.statistics()
+    samples = after["pixel_samples"] - before["pixel_samples"]
+    rays = sum(after[k] - before[k] for k in ("primary_rays", "bounce_rays", "shadow_rays"))
+    out = {"workload": "C5: examples/complex.prc (%d triangles + 4 spheres, sky + sun, glass / rough conductor / principled materials), %dx%d, `direct` "
+                       "integrator, sobol %d-spp schedule, hero wavelengths (spd CMIS), %d iterations timed on ONE GPU" % (sc.desc.n_triangles, W, H, sc.desc.settings.aa_samples, steps),
+           "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+           "mrays_per_s": round(rays / dt / 1e6, 2), "mean_path_depth": round((after["camera_depth"] - before["camera_depth"]) / max(samples, 1), 3),
+           "roofline": roofline(ctx, 0, variant="255u")}
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +230,7 @@ def main():
                     help="c4 (default, the BASELINE headline): 1M-triangle Cornell box; c5: examples/complex.prc (sky + sun, glass, rough conductor, "
                          "principled, spheres) from its committed array fixture, sobol 4096-spp schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C5 object (`secondary`) a default one-GPU C4 run appends to its line")
     ap.add_argument("--profile-only", action="store_true", help="skip roofline/cpu passes (for rocprofv3 runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank renders on device 0 and the collectives run over gloo "
@@ -245,7 +275,8 @@ def main():
     # tiles dealt round-robin along the Z-order curve; the slowest rank's share decides (tools/gpu_probe_share8.py with RANK_PROBE / TILE,
     # ms per iteration, max over ranks): N = 8: 16x16 tiles 2.38, 32x32 2.47, 64x64 2.39 (rank 0 alone 2.20), 8x8 2.40;
     # N = 4: 4.28 / 4.31 / 4.39; N = 2: 7.67 / 7.53 / 7.45 -- small tiles balance better, large ones keep more coherence
-    tiles = tiling.tiles_for_rank(width, height, rank, world, tile=64 if world <= 2 else 16) if world > 1 else []
+    tile_px = 64 if world <= 2 else 16
+    tiles = tiling.tiles_for_rank(width, height, rank, world, tile=tile_px) if world > 1 else []
     ctx.setTiles(tiles)
     xyz = torch.zeros((height, width, 3), dtype=torch.float32, device=dev)
     smp = torch.zeros((height, width), dtype=torch.int32, device=dev)
@@ -304,11 +335,13 @@ def main():
     t0 = time.perf_counter()
     ctx.render(args.steps)                      # K iterations of the hot path
     ctx.waitForFinish()
+    dt_render = time.perf_counter() - t0        # this rank's share, before it waits for the others in the reduce
     reduce_frame()                              # RCCL sum onto rank 0 (a checked no-op at N=1)
     barrier()
     dt = time.perf_counter() - t0
     after = ctx.statistics()
     dt = distributed.max_scalar(dt, device=dev)
+    render_ms = [x / args.steps * 1e3 for x in distributed.gather_scalars(dt_render, device=dev)]   # per rank, ms per step
     samples = distributed.sum_scalar(after["pixel_samples"] - before["pixel_samples"], device=dev)
     rays = distributed.sum_scalar(sum(after[k] - before[k] for k in ("primary_rays", "bounce_rays", "shadow_rays")), device=dev)
     depth = distributed.sum_scalar(after["camera_depth"] - before["camera_depth"], device=dev)
@@ -319,6 +352,10 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "samples_per_step": int(samples / args.steps), "parallelism": "tiles%d" % world,
+                   "tile_px": tile_px if world > 1 else None,
+                   # a rank's own render time per step (before the reduce): max - min is imbalance, min is the per-rank latency floor
+                   "rank_render_ms_per_step": {"min": round(min(render_ms), 4), "max": round(max(render_ms), 4), "slowest_rank": int(np.argmax(render_ms)),
+                                               "all": [round(x, 4) for x in render_ms]},
                    "collective": "none (one rank)" if world == 1 else ("prgpu_reduce (RCCL from libprgpu)" if comm is not None else "torch.distributed.reduce"),
                    "mrays_per_s": round(rays / dt / 1e6, 2), "mean_path_depth": round(depth / max(samples, 1), 3),
                    "scene_create_s": round(t_create, 3)},
@@ -330,7 +367,9 @@ def main():
         ref.render(args.warmup + args.steps)
         ref.waitForFinish()
         rxyz, rsmp, _ = ref.output()
-        out["frame_check"] = {"xyz_equal": bool(np.array_equal(xyz.cpu().numpy(), rxyz)), "samples_equal": bool(np.array_equal(smp.cpu().numpy(), rsmp))}
+        # (prgpu_reduce leaves the sums in root-side planes the downloads read; the torch.distributed fallback sums into the bound tensors)
+        gxyz, gsmp = (ctx.output()[:2]) if comm is not None else (xyz.cpu().numpy(), smp.cpu().numpy())
+        out["frame_check"] = {"xyz_equal": bool(np.array_equal(gxyz, rxyz)), "samples_equal": bool(np.array_equal(gsmp, rsmp))}
         ref.close()
     if not args.profile_only:
         out["roofline"] = roofline(ctx, rank, variant=variant)
@@ -338,6 +377,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sc, what=what)
         if rank != 0:
             out.pop("roofline", None)
+        if rank == 0 and world == 1 and args.workload == "c4" and not args.no_secondary and (width, height, args.triangles) == (W, H, NTRI):
+            ctx.close()   # free the C4 scene's planes first
+            out["secondary"] = secondary_c5(local)
 
     if args.rehearse_on_one_gpu:
         out["rehearsal"] = "all ranks on device 0, gloo collectives: not a result"

@@ -409,10 +409,11 @@ int  prgpu_kernel_time_ms(prgpu_scene* s, const char* family, double* total_ms, 
  * Replaces the reference's ways of combining image tiles: FrameOutputDevice::mergeLocal inside one process
  * (src/loader/output/FrameOutputDevice.cpp:83-200) and `--itx/--ity` image tiles (src/core/renderer/RenderFactory.cpp:16-42) summed
  * offline by tools/pr_imagemerge.py.  Every rank (one process or host thread per GPU) creates the SAME scene, takes its tiles with
- * prgpu_set_tiles, renders, and calls prgpu_reduce once: RCCL over xGMI sums the XYZ and sample-count planes and ORs the feedback
- * plane onto `root`'s framebuffer (the bound one, or the library's).  No collective runs while rendering.
+ * prgpu_set_tiles, renders, and calls prgpu_reduce: RCCL over xGMI sums the XYZ and sample-count planes and ORs the feedback
+ * plane into planes the library keeps on `root` for that purpose.  No collective runs while rendering.
  *   rank 0:  prgpu_comm_unique_id(id);  ship the 128 bytes to the other ranks (MPI, a socket, a file -- the host's business)
  *   all:     prgpu_comm_create(id, n_ranks, rank, device, &comm);  ...render...;  prgpu_reduce(scene, comm, 0);  prgpu_sync(scene);
+ *   root:    prgpu_download* read the reduced frame.
  * With n_ranks == 1 no RCCL call is made and prgpu_reduce only validates its arguments. */
 #define PRGPU_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
 typedef struct prgpu_comm prgpu_comm;
@@ -420,11 +421,13 @@ int  prgpu_comm_unique_id(uint8_t id[PRGPU_COMM_ID_BYTES]);
 int  prgpu_comm_create(const uint8_t id[PRGPU_COMM_ID_BYTES], int n_ranks, int rank, int device, prgpu_comm** out);
 void prgpu_comm_destroy(prgpu_comm* comm);
 int  prgpu_comm_size(const prgpu_comm* comm);   /* n_ranks, or PRGPU_EINVAL */
-/* Asynchronous on the scene's stream (after the render calls queued there); prgpu_sync / prgpu_download wait for it.  In place:
- * on `root` the planes hold the sums afterwards, on the other ranks they are unchanged.  ONE reduce per frame: with more than one
- * rank a second call on the same scene object returns PRGPU_EINVAL (the root's copies of the other ranks' pixels already hold their
- * totals, a second sum would add them again) -- except when the first one ran before anything was rendered (all planes zero:
- * warming the communicator up). */
+/* Asynchronous on the scene's stream (after the render calls queued there); prgpu_sync / prgpu_download wait for it.  Every rank
+ * sends its own planes (XYZ, samples, feedback and, when enabled, AOV / variance / light path expression planes), which stay untouched;
+ * `root` receives the sums in planes of their own, and its prgpu_download* calls read THOSE until its next prgpu_render call (a
+ * framebuffer bound with prgpu_bind_framebuffer keeps the rank's own pixels).  So a frame may be reduced again after more iterations
+ * -- every K iterations for a preview (the reference's periodic image dumps, src/client/ImageUpdateObserver.cpp:41-60): a reduce at 4
+ * and at 8 iterations leaves what one reduce at 8 leaves.  A collective: every rank of the communicator must make the same calls in
+ * the same order; it fails before anything is enqueued or not at all. */
 int  prgpu_reduce(prgpu_scene* s, prgpu_comm* comm, int root);
 
 /* -- shading-point AOVs and image files ------------------------------------------------------
@@ -454,8 +457,8 @@ int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance); /* ei
  * LPE_Parser.cpp / LPE_RegState.h: C first, then D S E L B R T . <T,E>, groups ( ), unions [ ], and * + ? {n} {n,m}.  Labelled tokens (<T,E,"label">) are
  * parsed and match nothing: a labelled token only matches path tokens carrying that label (LPE_Automaton.cpp:92-110) and the `direct`
  * integrator builds all its tokens with label 0.  Expressions that need more than PRGPU_LPE_MAX_STATES automaton states are
- * PRGPU_EUNSUPPORTED.  Enable before the first iteration; selects the persistent pipeline (with a multi-tap pixel filter the planes
- * go through the same ring of iteration planes and tap gathering as the main one).  prgpu_lpe_check only parses (0 = valid). */
+ * PRGPU_EUNSUPPORTED.  Enable before the first iteration; every pipeline (persistent, lockstep, streaming) carries the planes (with a
+ * multi-tap pixel filter they go through the same tap gathering as the main one).  prgpu_lpe_check only parses (0 = valid). */
 #define PRGPU_LPE_MAX 4
 #define PRGPU_LPE_MAX_STATES 32
 int prgpu_lpe_check(const char* expression);

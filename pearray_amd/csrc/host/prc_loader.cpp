@@ -523,9 +523,24 @@ struct Loader {
 				const float* data = out.tables.data() + n.table_offset;
 				return data[index] * (1 - t) + data[index + 1] * t;
 			}
+			case PRGPU_SPEC_SELLMEIER: { // Scattering::sellmeier (base/math/Scattering.h:219-242), as spectrum_leaf on the device
+				const uint32_t nc = n.table_count / 2;
+				const float* B	  = out.tables.data() + n.table_offset;
+				const float* C	  = B + nc;
+				const float lq	  = wl / 1000;
+				const float lq2	  = lq * lq;
+				float value		  = 1.0f;
+				for (uint32_t i = 0; i < nc; ++i)
+					value += B[i] * lq2 / (lq2 - C[i]);
+				return std::sqrt(value);
+			}
 			default: return 0.0f;
 			}
 		};
+		// a checkerboard is asked at UV (0, 0), where the sky model's ShadingContext stands (SkyModel.cpp:30-34): the even cell, i.e. the
+		// operand resolve_texture (render.hip) picks there
+		for (int guard = 0; id < out.spectra.size() && out.spectra[id].kind == PRGPU_SPEC_CHECKER && guard < 64; ++guard)
+			id = out.spectra[id].rhs;
 		if (id >= out.spectra.size())
 			return 0.0f;
 		const prgpu_spectrum& n = out.spectra[id];

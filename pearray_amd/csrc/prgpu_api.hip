@@ -171,7 +171,18 @@ struct prgpu_scene {
 	prd::DevLpe lpe_host{}; // host copy of the light path expression block (plane pointers for downloads and the reduce)
 	uint32_t order_tuned_at = 0; // iteration count the pixel order was last tuned at (tune_pixel_order)
 	bool poisoned = false; // a device-side error was reported: further render calls are refused
-	uint32_t reduced_at = 0xFFFFFFFFu; // iteration count at which prgpu_reduce summed the ranks' frames in place (0xFFFFFFFF: not yet)
+	uint32_t reduced_at = 0xFFFFFFFFu; // iteration count of the last prgpu_reduce (0xFFFFFFFF: none yet)
+	// Root-side destination of prgpu_reduce (round 4: the rank's own planes stay untouched, so a frame can be reduced again after more
+	// iterations -- a preview every K iterations; FrameOutputDevice::mergeLocal sums into the frame the same way,
+	// FrameOutputDevice.cpp:83-221).  Allocated by the first reduce through a real communicator on its root.
+	struct Reduced {
+		float* xyz = nullptr;
+		uint32_t *samples = nullptr, *feedback = nullptr;
+		float *online_mean = nullptr, *online_variance = nullptr;
+		float* aov[PRGPU_AOV_COUNT] = {};
+		std::vector<float*> lpe;
+		bool valid = false; // downloads read these planes: set by a reduce on its root, cleared by the next render call
+	} reduced;
 
 	template <typename T>
 	int alloc(T*& ptr, size_t count, bool zero = false)
@@ -1226,6 +1237,7 @@ int prgpu_render(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	HIP_TRY(hipSetDevice(s->device));
 	if (iter_end == iter_begin)
 		return PRGPU_OK;
+	s->reduced.valid = false; // the reduced frame is stale from here on: downloads read the rank's own planes until the next reduce
 	if (s->mode != prgpu_scene::LOCKSTEP) {
 		const int rc = s->mode == prgpu_scene::PERSISTENT ? render_persistent(s, iter_begin, iter_end) : render_streaming(s, iter_begin, iter_end);
 		if (rc != PRGPU_OK)
@@ -1274,11 +1286,11 @@ int prgpu_download(prgpu_scene* s, float* xyz, uint32_t* samples, uint32_t* feed
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	if (xyz)
-		HIP_TRY(hipMemcpy(xyz, s->ps.out_xyz, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(xyz, s->reduced.valid ? s->reduced.xyz : s->ps.out_xyz, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
 	if (samples)
-		HIP_TRY(hipMemcpy(samples, s->ps.samples, size_t(s->n_pixels) * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(samples, s->reduced.valid ? s->reduced.samples : s->ps.samples, size_t(s->n_pixels) * 4, hipMemcpyDeviceToHost));
 	if (feedback)
-		HIP_TRY(hipMemcpy(feedback, s->ps.feedback, size_t(s->n_pixels) * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(feedback, s->reduced.valid ? s->reduced.feedback : s->ps.feedback, size_t(s->n_pixels) * 4, hipMemcpyDeviceToHost));
 	return PRGPU_OK;
 }
 
@@ -1627,37 +1639,60 @@ int prgpu_reduce(prgpu_scene* s, prgpu_comm* c, int root)
 		return fail(PRGPU_EINVAL, "null argument");
 	if (root < 0 || root >= c->n_ranks)
 		return fail(PRGPU_EINVAL, "root must be a rank of the communicator");
-	// The reduce sums IN PLACE into the root's planes: afterwards the root's copies of the other ranks' pixels hold their totals, and a
-	// second reduce after more rendering would add the new totals on top.  One reduce per frame -- except before anything was rendered
-	// (all planes zero: warming the communicator up), which may be repeated.
-	if (c->n_ranks > 1) {
-		if (s->reduced_at != 0xFFFFFFFFu && s->reduced_at != 0u)
-			return fail(PRGPU_EINVAL, "prgpu_reduce: this scene's frame has already been reduced (after " + std::to_string(s->reduced_at)
-										  + " iterations); the in-place sum cannot be repeated -- create the scene again for another frame");
+	if (!c->nccl) { // one rank without RCCL: the frame is already complete, downloads read the rank's own planes
 		s->reduced_at = s->next_iteration;
+		return PRGPU_OK;
 	}
-	if (!c->nccl)
-		return PRGPU_OK; // one rank: the frame is already complete
 	if (c->device != s->device)
 		return fail(PRGPU_EINVAL, "the communicator and the scene live on different devices");
 	HIP_TRY(hipSetDevice(s->device));
+	// Every rank sends its own planes (its pixels' running means, zeros elsewhere); the root receives the sums in planes of their own,
+	// which its downloads read until the next render call.  The rank's own planes are untouched, so rendering may go on and the frame
+	// may be reduced again (every K iterations for a preview): a reduce at 4 and at 8 iterations leaves what one reduce at 8 leaves.
+	// All ranks must call it alike (it is a collective); it fails before any collective is enqueued or not at all.
+	const bool is_root = c->rank == root;
+	prgpu_scene::Reduced& R = s->reduced;
+	if (is_root) {
+		auto need = [&](auto*& p, size_t count) -> int { return p ? PRGPU_OK : s->alloc(p, count, false); };
+		int rc = need(R.xyz, size_t(s->n_pixels) * 3);
+		if (rc == PRGPU_OK)
+			rc = need(R.samples, s->n_pixels);
+		if (rc == PRGPU_OK)
+			rc = need(R.feedback, s->n_pixels);
+		if (rc == PRGPU_OK && s->ps.online_mean) {
+			rc = need(R.online_mean, size_t(s->n_pixels) * 3);
+			if (rc == PRGPU_OK)
+				rc = need(R.online_variance, size_t(s->n_pixels) * 3);
+		}
+		for (uint32_t k = 0; rc == PRGPU_OK && k < PRGPU_AOV_COUNT; ++k)
+			if (s->ps.aov[k])
+				rc = need(R.aov[k], size_t(s->n_pixels) * prgpu_aov_channels(k));
+		R.lpe.resize(s->lpe_host.n, nullptr);
+		for (uint32_t k = 0; rc == PRGPU_OK && k < s->lpe_host.n; ++k)
+			rc = need(R.lpe[k], size_t(s->n_pixels) * 3);
+		if (rc != PRGPU_OK)
+			return rc;
+	}
 	Rccl& r = rccl();
 	// one group = one fused launch: XYZ (fp32 sum), sample counts (u32 sum), feedback bits (a pixel's bits are only ever set by the
 	// rank that owns it, so MAX over the ranks is the OR of mergeLocal, FrameOutputDevice.cpp:121)
 	NCCL_TRY(r.GroupStart());
-	NCCL_TRY(r.Reduce(s->ps.out_xyz, s->ps.out_xyz, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
-	NCCL_TRY(r.Reduce(s->ps.samples, s->ps.samples, size_t(s->n_pixels), NCCL_UINT32, NCCL_SUM, root, c->nccl, s->stream));
-	NCCL_TRY(r.Reduce(s->ps.feedback, s->ps.feedback, size_t(s->n_pixels), NCCL_UINT32, NCCL_MAX, root, c->nccl, s->stream));
+	NCCL_TRY(r.Reduce(s->ps.out_xyz, is_root ? R.xyz : s->ps.out_xyz, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+	NCCL_TRY(r.Reduce(s->ps.samples, is_root ? R.samples : s->ps.samples, size_t(s->n_pixels), NCCL_UINT32, NCCL_SUM, root, c->nccl, s->stream));
+	NCCL_TRY(r.Reduce(s->ps.feedback, is_root ? R.feedback : s->ps.feedback, size_t(s->n_pixels), NCCL_UINT32, NCCL_MAX, root, c->nccl, s->stream));
 	if (s->ps.online_mean) { // every pixel's estimator lives on the rank that owns the pixel, zero elsewhere (single-tap filters)
-		NCCL_TRY(r.Reduce(s->ps.online_mean, s->ps.online_mean, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
-		NCCL_TRY(r.Reduce(s->ps.online_variance, s->ps.online_variance, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+		NCCL_TRY(r.Reduce(s->ps.online_mean, is_root ? R.online_mean : s->ps.online_mean, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+		NCCL_TRY(r.Reduce(s->ps.online_variance, is_root ? R.online_variance : s->ps.online_variance, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
 	}
 	for (uint32_t k = 0; k < PRGPU_AOV_COUNT; ++k) // shading-point AOV sums: plain sums of the owner's samples
 		if (s->ps.aov[k])
-			NCCL_TRY(r.Reduce(s->ps.aov[k], s->ps.aov[k], size_t(s->n_pixels) * prgpu_aov_channels(k), NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+			NCCL_TRY(r.Reduce(s->ps.aov[k], is_root ? R.aov[k] : s->ps.aov[k], size_t(s->n_pixels) * prgpu_aov_channels(k), NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
 	for (uint32_t k = 0; k < s->lpe_host.n; ++k) // light path expression planes: folded sums of the owner's matching fragments, zero elsewhere
-		NCCL_TRY(r.Reduce(s->lpe_host.out[k], s->lpe_host.out[k], size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+		NCCL_TRY(r.Reduce(s->lpe_host.out[k], is_root ? R.lpe[k] : s->lpe_host.out[k], size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
 	NCCL_TRY(r.GroupEnd());
+	s->reduced_at = s->next_iteration; // (after the last collective was enqueued)
+	if (is_root)
+		R.valid = true;
 	return PRGPU_OK;
 }
 
@@ -1722,9 +1757,9 @@ int prgpu_download_variance(prgpu_scene* s, float* mean, float* variance)
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipStreamSynchronize(s->stream));
 	if (mean)
-		HIP_TRY(hipMemcpy(mean, s->ps.online_mean, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(mean, s->reduced.valid && s->reduced.online_mean ? s->reduced.online_mean : s->ps.online_mean, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
 	if (variance)
-		HIP_TRY(hipMemcpy(variance, s->ps.online_variance, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(variance, s->reduced.valid && s->reduced.online_variance ? s->reduced.online_variance : s->ps.online_variance, size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
 	return PRGPU_OK;
 }
 
@@ -1818,7 +1853,7 @@ int prgpu_download_lpe(prgpu_scene* s, uint32_t index, float* xyz)
 		return fail(PRGPU_EINVAL, "no such light path expression");
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipStreamSynchronize(s->stream));
-	HIP_TRY(hipMemcpy(xyz, s->lpe_host.out[index], size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(xyz, s->reduced.valid && index < s->reduced.lpe.size() ? s->reduced.lpe[index] : s->lpe_host.out[index], size_t(s->n_pixels) * 12, hipMemcpyDeviceToHost));
 	return PRGPU_OK;
 }
 
@@ -1840,7 +1875,7 @@ int prgpu_download_aov(prgpu_scene* s, uint32_t aov, float* out)
 		return fail(PRGPU_EINVAL, "AOV not enabled");
 	HIP_TRY(hipSetDevice(s->device));
 	HIP_TRY(hipStreamSynchronize(s->stream));
-	HIP_TRY(hipMemcpy(out, s->ps.aov[aov], size_t(s->n_pixels) * prgpu_aov_channels(aov) * sizeof(float), hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(out, s->reduced.valid && s->reduced.aov[aov] ? s->reduced.aov[aov] : s->ps.aov[aov], size_t(s->n_pixels) * prgpu_aov_channels(aov) * sizeof(float), hipMemcpyDeviceToHost));
 	return PRGPU_OK;
 }
 

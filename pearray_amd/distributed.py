@@ -43,3 +43,14 @@ def sum_scalar(value, device=None):
 
 def max_scalar(value, device=None):
     return _scalar(value, dist.ReduceOp.MAX, device)
+
+
+def gather_scalars(value, device=None):
+    """One float per rank, in rank order, on every rank (diagnostics: which rank was slowest)."""
+    n = world()[1]
+    if n == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
+    out = [torch.zeros_like(t) for _ in range(n)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

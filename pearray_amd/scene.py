@@ -238,7 +238,8 @@ class SceneBuilder:
 
     def environment_light(self, radiance, background=None, transform=IDENTITY, image=None, distribution=True, compensation=False):
         """(light :type 'env' :radiance r [:background b]), environment.cpp:152-205.  `image`: float32 [height, width, 3] Jakob-Hanika
-        coefficients (a latitude / longitude map: row 0 = the zenith, +z) that multiply `radiance` texel by texel -- the textured
+        coefficients (a latitude / longitude map in FILE scanline order under the reference's lookup t = 1 - v, v = theta / pi: row 0 = the
+        nadir, -z, the LAST row = the zenith, +z; environment.cpp:53-101) that multiply `radiance` texel by texel -- the textured
         environment light; with more than one row and column it is importance-sampled unless `distribution` is False."""
         k = self._light(abi.LIGHT_ENVIRONMENT, radiance, background, (0, 0, 1), transform)
         if image is not None:
@@ -575,6 +576,9 @@ class ArrayScene:
                 if skies:
                     t = np.ascontiguousarray(skies.pop(0), dtype=np.float32)
                 else:  # the Hosek-Wilkie table of the light's SkyModel, rebuilt from the stored parameters
+                    if i not in params:
+                        raise ValueError("%s: sky light %d has neither a table nor stored sky_params (a cache written before they were kept): "
+                                         "pass sky_tables=[...] or regenerate the file with save_scene_npz(..., sky_params=...)" % (path, i))
                     el, az, tu = (float(v) for v in params[i][:3])
                     t = hosek_sky_table(el, az, tu, [float(a) for a in params[i][3:]], l.elevation_count, l.azimuth_count)
                 assert t.shape == (l.elevation_count, l.azimuth_count, abi.SKY_BANDS), "sky table shape %s" % (t.shape,)

@@ -12,7 +12,8 @@ from test_oracle_skysun import WL, light_eval, light_sample
 
 
 def two_blob_image(h=16, w=32):
-    """A dark sky with two bright patches: one near the zenith (row 2), a dimmer reddish one low in the opposite direction."""
+    """A dark sky with two bright patches: one near the nadir (rows 2-3: row 0 is the nadir, the last row the zenith -- the lookup is
+    row = (1 - v) * h with v = theta / pi, OIIO's t = 1 - v of environment.cpp:53-101), a dimmer reddish one in rows 9-10 on the other side."""
     rgb = np.full((h, w, 3), 0.02, np.float32)
     rgb[2:4, 5:9] = (0.9, 0.9, 0.8)
     rgb[9:11, 20:24] = (0.8, 0.3, 0.1)
@@ -60,7 +61,7 @@ def test_importance_sampled_integral_equals_the_sum_over_texels():
     est = np.mean([r[0] / p for _, p, r in (light_sample(o, 0, float(rng.random()), float(rng.random())) for _ in range(6000))])
     h, w = 16, 32
     total = 0.0
-    for row in range(h):       # row 0 is the zenith: v = 1 - (row + 0.5) / h ... the lookup flips v (t = 1 - v)
+    for row in range(h):       # row 0 is the NADIR: v = 1 - (row + 0.5) / h, theta = pi * v ... the lookup flips v (t = 1 - v)
         v = 1 - (row + 0.5) / h
         for col in range(w):
             th, ph = np.pi * v, 2 * np.pi * (col + 0.5) / w
@@ -122,3 +123,21 @@ def test_gpu_textured_environment_in_every_pipeline(monkeypatch):
         out = tg._render_mode(monkeypatch, mode, sc, [4])
         for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
             assert np.array_equal(a, b), mode
+
+
+def test_orientation_of_the_map_last_row_is_the_zenith():
+    """Orientation, which the integrals above cannot see: radiance towards +z comes from the LAST row of the image, towards -z from row 0
+    (row = (1 - v) * h, v = theta / pi), and a bright last row lights an upward-facing floor where a bright first row does not."""
+    def sky(bright_row):
+        rgb = np.full((8, 16, 3), 0.01, np.float32)
+        rgb[bright_row] = (0.9, 0.9, 0.9)
+        return rgb
+    up, down = ob.OracleScene(env_scene(image=sky(7))), ob.OracleScene(env_scene(image=sky(0)))
+    assert light_eval(up, 0, (0.05, 0.0, 0.99875))[0][0] > 20 * light_eval(up, 0, (0.05, 0.0, -0.99875))[0][0]
+    assert light_eval(down, 0, (0.05, 0.0, -0.99875))[0][0] > 20 * light_eval(down, 0, (0.05, 0.0, 0.99875))[0][0]
+
+    def floor_y(image):
+        o = ob.OracleScene(env_scene(size=16, spp=64, mapper=abi.MAPPER_RANDOM, image=image))
+        o.render(64, threads=8)
+        return float(o.output()[0][..., 1].mean())
+    assert floor_y(sky(7)) > 5 * floor_y(sky(0))

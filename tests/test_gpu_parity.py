@@ -544,6 +544,53 @@ def test_reduce_one_rank_noop_and_a_real_rccl_communicator(monkeypatch):
     real.close()
 
 
+def test_a_frame_may_be_reduced_again_after_more_iterations(monkeypatch):
+    """Progressive reduce ('optionally every K iterations for preview'): prgpu_reduce sums into planes of the root's
+    own, the rank's planes stay untouched -- rendering goes on and the frame is reduced again.  A genuine RCCL communicator (one rank: the
+    sum is a copy from the rank's planes into the root-side planes): a reduce at 4 and at 8 iterations leaves what one reduce at 8 leaves,
+    the frame read between the two is the 4-iteration frame, and AOV / variance / light path expression planes travel the same way."""
+    monkeypatch.setenv("PRGPU_COMM_FORCE_RCCL", "1")
+    sc = scene.cornell_glassy(80, 64, spp=8)
+
+    def fresh():
+        g = backend.RenderContext(sc)
+        g.enableAOVs(["normal", "depth"])
+        g.enableVariance()
+        return g
+
+    comm = backend.Communicator(1, 0)
+    a = fresh()
+    a.render(4)
+    a.reduce(comm)
+    a.waitForFinish()
+    mid = a.output()
+    a.render(4)                      # the rank's own planes were not touched by the reduce
+    own = a.output()                 # (no reduce since the last render call: the rank's own planes)
+    a.reduce(comm)
+    a.waitForFinish()
+    twice = a.output()
+    var_twice = a.variance()
+    aov_twice = [a.aov("normal"), a.aov("depth")]
+    b = fresh()
+    b.render(8)
+    b.reduce(comm)
+    b.waitForFinish()
+    once = b.output()
+    for x, y in zip(once, twice):
+        assert np.array_equal(x, y)
+    for x, y in zip(once, own):
+        assert np.array_equal(x, y)
+    for x, y in zip(list(b.variance()) + [b.aov("normal"), b.aov("depth")], list(var_twice) + aov_twice):
+        assert np.array_equal(x, y)
+    c = fresh()
+    c.render(4)
+    c.waitForFinish()
+    for x, y in zip(c.output(), mid):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(mid[0], once[0])
+    comm.close()
+
+
 @pytest.mark.parametrize("config", ["C2", "C3", "C3b"])
 def test_baseline_configs_at_full_resolution(config):
     """BASELINE configs C2 (sphere + area light 512x512, mjitt 64 spp schedule), C3 (cornellbox 1024x1024, mjitt 256 spp schedule) and
