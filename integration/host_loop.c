@@ -2,11 +2,13 @@
  * (no Python, no torch, no C++ runtime on the host side).  It does for one scene file what PearRay's client does around its integrator
  * (src/client/main.cpp:120-260: load the scene, create the render context, run the iterations, save the frame):
  *
- *     host_loop <scene.prc> <iterations> <frame.raw> [width height]
+ *     host_loop <scene.prc> <iterations> <frame.raw> [width height [lookahead]]
  *
  * writes the XYZ running mean as width * height * 3 little-endian floats followed by width * height uint32 sample counts, and prints the
  * eleven RenderStatistics counters.  Exit code 0, or the negative prgpu status with prgpu_last_error() on stderr -- on a machine without
  * a HIP device that is PRGPU_ENODEVICE from prgpu_scene_create: the library has no CPU fallback.
+ * lookahead K > 0: the loop of the PearRay adapter (integration/pr_pl_int_gpu_direct.cpp) -- launches of K iterations queued without
+ * waiting, the frame fetched after every launch (what an image observer would show) -- instead of one call per iteration; same frame.
  * Build:  gcc -std=c99 -I include integration/host_loop.c -L pearray_amd/csrc -lprgpu -Wl,-rpath,$PWD/pearray_amd/csrc -o host_loop
  * (tests/test_c_host.py builds and runs it and compares the frame with the one the ctypes mirror renders.) */
 #include <stdio.h>
@@ -23,15 +25,16 @@ static int fail(const char* what, int rc, const char* message)
 
 int main(int argc, char** argv)
 {
-	if (argc != 4 && argc != 6) {
-		fprintf(stderr, "usage: %s scene.prc iterations frame.raw [width height]\n", argv[0]);
+	if (argc != 4 && argc != 6 && argc != 7) {
+		fprintf(stderr, "usage: %s scene.prc iterations frame.raw [width height [lookahead]]\n", argv[0]);
 		return 64;
 	}
 	const uint32_t iterations = (uint32_t)strtoul(argv[2], NULL, 10);
 
 	prgpu_prc_options opt;
 	memset(&opt, 0, sizeof opt);
-	if (argc == 6) {
+	const uint32_t lookahead = argc == 7 ? (uint32_t)strtoul(argv[6], NULL, 10) : 0u;
+	if (argc >= 6) {
 		opt.width  = (uint32_t)strtoul(argv[4], NULL, 10);
 		opt.height = (uint32_t)strtoul(argv[5], NULL, 10);
 	}
@@ -54,19 +57,36 @@ int main(int argc, char** argv)
 	if (rc != PRGPU_OK)
 		return fail("prgpu_scene_create", rc, prgpu_last_error());
 
-	/* one render call per iteration, like RenderContext's loop (RenderContext.cpp:242-258); one call for all of them is as valid */
-	for (uint32_t it = 0; it < iterations && rc == PRGPU_OK; ++it)
-		rc = prgpu_render(scene, it, it + 1);
+	float* xyz		  = (float*)malloc((size_t)w * h * 3 * sizeof(float));
+	uint32_t* samples = (uint32_t*)malloc((size_t)w * h * sizeof(uint32_t));
+	if (lookahead == 0) {
+		/* one render call per iteration, like RenderContext's loop (RenderContext.cpp:242-258); one call for all of them is as valid */
+		for (uint32_t it = 0; it < iterations && rc == PRGPU_OK; ++it)
+			rc = prgpu_render(scene, it, it + 1);
+	} else {
+		/* the adapter's loop: the next launch is queued BEFORE the frame of the previous one is fetched, so the device never waits for the host */
+		uint32_t issued = 0, previews = 0;
+		while (issued < iterations && rc == PRGPU_OK) {
+			const uint32_t end = issued + lookahead < iterations ? issued + lookahead : iterations;
+			rc				   = prgpu_render(scene, issued, end);
+			issued			   = end;
+			if (rc == PRGPU_OK && issued < iterations) { /* a preview: waits for the launches queued so far, like an observer's image update */
+				rc = prgpu_download(scene, xyz, samples, NULL);
+				++previews;
+			}
+		}
+		fprintf(stderr, "host_loop: %u launches of <= %u iterations, %u previews\n", (iterations + lookahead - 1) / lookahead, lookahead, previews);
+	}
 	if (rc == PRGPU_OK)
 		rc = prgpu_sync(scene);
 	if (rc != PRGPU_OK) {
 		const int code = fail("prgpu_render", rc, prgpu_last_error());
+		free(xyz);
+		free(samples);
 		prgpu_scene_destroy(scene);
 		return code;
 	}
 
-	float* xyz		  = (float*)malloc((size_t)w * h * 3 * sizeof(float));
-	uint32_t* samples = (uint32_t*)malloc((size_t)w * h * sizeof(uint32_t));
 	uint64_t stats[PRGPU_STAT_COUNT];
 	rc = prgpu_download(scene, xyz, samples, /*feedback*/ NULL);
 	if (rc == PRGPU_OK)

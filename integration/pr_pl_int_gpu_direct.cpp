@@ -9,8 +9,16 @@
 // walk Scene -- it hands the SAME scene file the host is loading to the library's own loader (prgpu_prc_load_file), which produces
 // the flat prgpu_scene_desc, the Hosek-Wilkie tables of `sky` lights included (prgpu_sky_table: SkyModel.cpp:15-56 restated).
 // How the frame comes back: results bypass the per-fragment queue (RenderTileSession::pushSpectralFragment is a per-sample virtual
-// call); at onEnd() the XYZ / sample-count / feedback planes, the shading-point AOVs, the online mean / variance and the
-// light path expression planes are downloaded into the host's FrameOutputDevice buffers.
+// call).  The XYZ / sample-count / feedback planes, the shading-point AOVs, the online mean / variance and the light path
+// expression planes are downloaded into the host's FrameOutputDevice buffers every `lookahead` iterations (an iteration callback,
+// RenderContext.h:110) and at onEnd(), so that the host's observers (src/client/ImageUpdateObserver.cpp:41-60, the network and tev
+// observers) see the frame grow while the device renders.
+// How the device stays busy: the host's loop is one (tile, iteration) at a time with a barrier per iteration (RenderContext.cpp:234-296);
+// the device's unit is a LAUNCH of many iterations.  The first onTile of iteration i that finds nothing issued for it queues
+// prgpu_render(i, min(i + lookahead, total)) WITHOUT waiting; the host's iterations inside that range only account their samples.  The
+// only waits are the frame deliveries above (prgpu_download waits for the stream) -- at most `lookahead` iterations are ever queued
+// ahead of what the host has seen, which also bounds what a soft stop (RenderContext::isStopping) still renders.  Progressive
+// rendering (RenderSettings::progressive: no sample count is known, maxSampleCount() == 0) uses a lookahead of one iteration.
 #include "Environment.h"
 #include "Logger.h"
 #include "SceneLoadContext.h"
@@ -27,11 +35,13 @@
 #include <prgpu.h>
 
 #include <atomic>
+#include <mutex>
 
 namespace PR {
 struct GpuDirectSetup {
 	std::filesystem::path SceneFile;						// the .prc being loaded (SceneLoadContext::currentFile)
 	prgpu_settings Integrator;								// `direct` parameters (direct.cpp:500-515)
+	uint32 Lookahead = 16;									// iterations per device launch / between frame deliveries
 };
 
 // flatten(ctx): everything the device needs, from the scene FILE
@@ -96,14 +106,24 @@ public:
 		uint32 n = 0;
 		if (const prgpu_output_channel* ch = prgpu_prc_outputs(mFile, &n))
 			prgpu_outputs_enable(mScene, ch, n); // the AOV planes the (output ...) blocks ask for
-		mNextIteration = 0;
+		mIssuedUntil = 0;
+		mTotal		 = ctx->settings().maxSampleCount(); // 0: progressive, no end known (RenderSettings.cpp:76-88)
+		mLookahead	 = mTotal == 0 ? 1u : std::max<uint32>(1, mSetup.Lookahead);
+		// deliver the frame every `lookahead` iterations: called by the last thread of an iteration (RenderContext.cpp:273-296)
+		ctx->addIterationCallback([this](const RenderIteration& it) {
+			if (it.Pass == 0 && it.Iteration % mLookahead == 0)
+				deliver();
+		});
 	}
 
-	void onEnd() override
+	void onEnd() override { deliver(); }
+
+	// the frame so far -> the host's frame buffers (FrameBuffer.h:98-147, [pixel*3+c]); waits for the launches queued so far
+	void deliver()
 	{
 		if (!mScene || !mContext)
 			return;
-		// the frame: XYZ running mean, sample counts, feedback bits -> the host's frame buffers (FrameBuffer.h:98-147, [pixel*3+c])
+		std::lock_guard<std::mutex> guard(mDeviceMutex);
 		for (const auto& dev : mContext->output()->outputDevices()) {
 			auto frame = std::dynamic_pointer_cast<FrameOutputDevice>(dev);
 			if (!frame)
@@ -140,16 +160,24 @@ public:
 		return std::make_shared<IntGpuDirectInstance>(this);
 	}
 
-	// RenderThread::main hands every (tile, iteration) to onTile from N threads (RenderThread.cpp:36-70).  The device renders ALL
-	// tiles of an iteration in one call, so the first thread that sees a new iteration issues it; the others only account their
-	// samples, which keeps the host's iteration barrier, progress display and stop handling working (RenderContext.cpp:234-296).
+	// RenderThread::main hands every (tile, iteration) to onTile from N threads (RenderThread.cpp:36-70).  The device renders ALL tiles
+	// of MANY iterations in one launch: the first thread that meets an iteration nothing has been issued for queues the next
+	// `lookahead` iterations and returns at once; every other call only accounts its samples, which keeps the host's iteration barrier,
+	// progress display and stop handling working (RenderContext.cpp:234-296).
 	void renderIteration(uint32 iteration)
 	{
-		uint32 expected = iteration;
-		if (mNextIteration.compare_exchange_strong(expected, iteration + 1)) {
-			if (prgpu_render(mScene, iteration, iteration + 1) != PRGPU_OK || prgpu_sync(mScene) != PRGPU_OK)
-				PR_LOG(L_ERROR) << "[gpu_direct] " << prgpu_last_error() << std::endl;
-		}
+		if (iteration < mIssuedUntil.load(std::memory_order_acquire))
+			return;
+		std::lock_guard<std::mutex> guard(mDeviceMutex);
+		const uint32 begin = mIssuedUntil.load(std::memory_order_relaxed);
+		if (iteration < begin)
+			return; // another thread was faster
+		uint32 end = begin + mLookahead;
+		if (mTotal != 0)
+			end = std::min<uint32>(end, std::max<uint32>(mTotal, begin + 1));
+		if (prgpu_render(mScene, begin, end) != PRGPU_OK) // asynchronous: queued on the scene's stream
+			PR_LOG(L_ERROR) << "[gpu_direct] " << prgpu_last_error() << std::endl;
+		mIssuedUntil.store(end, std::memory_order_release);
 	}
 
 private:
@@ -157,7 +185,10 @@ private:
 	RenderContext* mContext = nullptr;
 	prgpu_prc* mFile		= nullptr;
 	prgpu_scene* mScene		= nullptr;
-	std::atomic<uint32> mNextIteration{ 0 };
+	std::atomic<uint32> mIssuedUntil{ 0 }; // iterations [0, mIssuedUntil) are queued on (or done by) the device
+	uint32 mTotal	  = 0;				   // iterations of the render (0: progressive)
+	uint32 mLookahead = 1;
+	std::mutex mDeviceMutex; // one thread at a time talks to the scene object
 };
 
 void IntGpuDirectInstance::onTile(RenderTileSession& session)
@@ -192,6 +223,7 @@ public:
 		setup.Integrator.nee				= p.getBool("nee", true);
 		setup.Integrator.direct				= p.getBool("direct", true);
 		setup.Integrator.emissive_scatter	= p.getBool("emissive_scatter", true);
+		setup.Lookahead						= p.getUInt("lookahead", setup.Lookahead);
 		return std::make_shared<IntGpuDirectFactory>(setup);
 	}
 
@@ -212,6 +244,7 @@ public:
 			.Bool("nee", "Next event estimation", true)
 			.Bool("direct", "Direct hits of lights", true)
 			.Bool("emissive_scatter", "Emissive surfaces scatter", true)
+			.UInt("lookahead", "Iterations per device launch and between frame deliveries", 16)
 			.Specification()
 			.get();
 	}

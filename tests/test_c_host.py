@@ -58,3 +58,9 @@ def test_c_host_renders_what_the_ctypes_mirror_renders(tmp_path):
     st = g.statistics()
     counters = [int(t) for t in r.stdout.split(";")[1].split()]
     assert r.stdout.startswith("96 x 64, 5 iterations;") and len(counters) == 11 and sorted(counters) == sorted(st.values())
+    # the PearRay adapter's loop (launches of `lookahead` iterations queued without waiting, a preview fetched after each): the same frame
+    ahead = tmp_path / "frame_lookahead.raw"
+    r2 = subprocess.run([str(exe), SCENE, "5", str(ahead), "96", "64", "2"], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr
+    assert "3 launches of <= 2 iterations, 2 previews" in r2.stderr
+    assert np.array_equal(np.fromfile(str(ahead), dtype=np.uint8), raw) and r2.stdout == r.stdout
