@@ -12,6 +12,7 @@ import pytest
 
 import oracle_binding as ob
 from pearray_amd import scene
+from pearray_amd import _cabi as abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -57,3 +58,110 @@ def test_gpu_render_matches_the_mitsuba_render_of_the_evaluation_scene():
     # luminance because Mitsuba renders RGB reflectances and PearRay the measured spectra
     assert np.abs(white - 1).max() < 0.08 and abs(white.mean() - 1) < 0.03, white
     assert interior < 0.10 and everything < 0.15, (interior, everything)  # measured 0.083 / 0.12 from 128 to 2048 spp: systematic, not noise
+
+
+# ---- coloured spectra: a known answer of our own, and what an RGB view of the walls changes against Mitsuba ----------------------------
+def _cie2006():
+    """The renderer's own CIE 2006 2-degree tables (390..830 nm @ 1 nm), read from the product's table file as numbers."""
+    import re
+    txt = open(os.path.join(os.path.dirname(HERE), "pearray_amd", "csrc", "tables", "pr_tables.inl")).read()
+    return [np.array([float(v.strip().rstrip("f")) for v in re.search(r"PR_CIE2006_%s\[441\] = \{(.*?)\};" % c, txt, re.S).group(1).split(",") if v.strip()]) for c in "XYZ"]
+
+
+def _table(m, lam):
+    v = np.asarray(m["values"], float)
+    return np.interp((lam - m["start"]) / (m["end"] - m["start"]) * (len(v) - 1), np.arange(len(v)), v)   # constant beyond the ends, like EquidistantSpectrum
+
+
+@pytest.mark.parametrize("material", ["white", "red", "green"])
+def test_coloured_reflectance_under_a_coloured_light_has_the_colour_of_the_spectral_integral(material):
+    """The form-factor scene of the reference's validity.py with MEASURED spectra: a diffuse plane with the evaluation scene's white / red /
+    green reflectance under its luminaire's spectrum, direct light only.  Pixel XYZ = F(p) * integral(albedo * light * cmf) / integral(ybar):
+    geometry (F, pinned by test_analytic_form_factor) times a one-line numeric integral -- a known answer for everything colour goes
+    through (table lookup of both spectra, wavelength sampling and its pdf, the hero-wavelength weights, CIE accumulation), which the
+    flat-spectrum tests cannot see and which the comparison with Mitsuba leaves open on the coloured walls."""
+    from test_oracle_render import _form_factor
+    import json
+    data = json.load(open(os.path.join(os.path.dirname(HERE), "pearray_amd", "data", "cbox_eval.json")))
+    W, spp = 24, 1024
+    b = scene.SceneBuilder(W, W)
+    s = b.settings
+    s.aa_sampler, s.aa_samples, s.max_ray_depth, s.direct, s.filter, s.filter_radius, s.mapper = abi.SAMPLER_MJITT, spp, 1, 0, abi.FILTER_BLOCK, 0, abi.MAPPER_RANDOM
+    m, e = data["materials"][material], data["emission"]
+    plane = b.lambert(b.spectrum_table(m["start"], m["end"], m["values"]))
+    ems = b.diffuse_emission(b.spectrum_table(e["start"], e["end"], e["values"]))
+    b.add_mesh([[-2, -2, 0], [2, -2, 0], [2, 2, 0], [-2, 2, 0]], [[0, 1, 2], [0, 2, 3]], plane, normals=[[0, 0, 1]] * 4)
+    b.add_mesh([[-0.5, -0.5, 2], [-0.5, 0.5, 2], [0.5, 0.5, 2], [0.5, -0.5, 2]], [[0, 1, 2], [0, 2, 3]], plane, emission=ems, normals=[[0, 0, -1]] * 4)
+    T = np.eye(4, dtype=np.float32)
+    T[2, 3] = 1.0
+    b.set_camera(T, width=2.0, height=2.0, local_direction=(0, 0, -1), local_right=(1, 0, 0), local_up=(0, 1, 0))
+    o = ob.OracleScene(b.build())
+    o.render(spp, threads=8)
+    xyz, smp, fb = o.output()
+    assert (fb == 0).all()
+    lam = np.arange(390, 831, 1.0)
+    X, Y, Z = _cie2006()
+    product = _table(m, lam) * _table(e, lam)
+    colour = np.array([(c * product).sum() for c in (X, Y, Z)]) / Y.sum()
+    lo, hi = W // 2 - 4, W // 2 + 4
+    F = np.mean([_form_factor((2 * (px / W - 0.5), -2 * (py / W - 0.5))) for py in range(lo, hi) for px in range(lo, hi)])
+    got = xyz[lo:hi, lo:hi].reshape(-1, 3).mean(axis=0)
+    assert np.allclose(got, F * colour, rtol=0.025, atol=0.004 * F * colour[1]), (material, got, F * colour)
+
+
+def _cie1931():
+    import re
+    txt = open(os.path.join(os.path.dirname(HERE), "pearray_amd", "csrc", "tables", "pr_tables.inl")).read()
+    return [np.array([float(v.strip().rstrip("f")) for v in re.search(r"PR_CIE1931_%s\[95\] = \{(.*?)\};" % c, txt, re.S).group(1).split(",") if v.strip()]) for c in "XYZ"]
+
+
+def test_red_wall_difference_is_rgb_against_spectral_and_the_green_wall_stays_open():
+    """What is behind the coloured walls' 10 - 30 % against Mitsuba.  (1) First bounce, analytically: the sRGB of the product spectrum
+    (a spectral renderer) against the product of the sRGBs (an RGB renderer) -- luminance 0.79 for red x light, 0.96 for white, 1.03 for
+    green: an RGB renderer shows the red wall 18 % brighter relative to the white ones than a spectral one, the green wall 6 % darker.
+    (2) The evaluation scene with both walls' spectra replaced by (refl r g b) of their own sRGB colour (Jakob-Hanika upsampling, the smooth
+    spectrum an RGB workflow implies): the RED wall's blocks then agree with Mitsuba to 5 % (0.86 with the measured spectrum); the GREEN
+    wall's do not move (1.30 either way) -- that difference is NOT an RGB-against-spectral effect and no test here explains it; the white
+    surfaces around it agree to 1 - 3 %, the form factor test above pins our green under this very light to 2.5 %."""
+    import json
+    data = json.load(open(os.path.join(os.path.dirname(HERE), "pearray_amd", "data", "cbox_eval.json")))
+    X, Y, Z = _cie1931()
+    lam = np.arange(360, 831, 5.0)
+    M = np.array([[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]])
+    srgb = lambda spectrum: M @ (np.array([(c * spectrum).sum() for c in (X, Y, Z)]) / Y.sum())
+    lum = lambda c: float(c @ np.array([0.2126, 0.7152, 0.0722]))
+    light = _table(data["emission"], lam)
+    first = {n: lum(srgb(_table(data["materials"][n], lam) * light)) / lum(srgb(_table(data["materials"][n], lam)) * srgb(light)) for n in ("white", "red", "green")}
+    assert abs(first["red"] / first["white"] - 0.82) < 0.03 and abs(first["green"] / first["white"] - 1.065) < 0.03, first
+
+    def walls(upsampled, w=64, spp=192):
+        b = scene.SceneBuilder(w, w)
+        s = b.settings
+        s.aa_sampler, s.aa_samples, s.max_ray_depth, s.mapper, s.filter, s.filter_radius = abi.SAMPLER_SOBOL, spp, 6, abi.MAPPER_RANDOM, abi.FILTER_TRIANGLE, 0
+        mats = {}
+        for n, m in data["materials"].items():
+            rgb = np.clip(srgb(_table(m, lam)), 0.0, 1.0)
+            mats[n] = b.lambert(b.refl(*rgb) if upsampled and n in ("red", "green") else b.spectrum_table(m["start"], m["end"], m["values"]))
+        e = data["emission"]
+        ems = b.diffuse_emission(b.spectrum_table(e["start"], e["end"], e["values"]))
+        for ent in data["entities"]:
+            T = np.eye(4, dtype=np.float32)
+            if ent["position"]:
+                T[:3, 3] = ent["position"]
+            b.add_mesh(ent["p"], ent["faces"], mats[ent["material"]], normals=ent.get("n"), emission=ems if ent["emission"] else None, transform=T)
+        cam = data["camera"]
+        T = np.eye(4, dtype=np.float32)
+        T[:3, 3] = cam["position"]
+        b.set_camera(T, width=cam["width"][0], height=cam["height"][0], near=cam["near"][0], far=cam["far"][0], local_direction=cam["local_direction"],
+                     local_right=cam["local_right"], local_up=cam["local_up"])
+        o = ob.OracleScene(b.build())
+        o.render(spp, threads=8)
+        k = w // 16
+        ya = np.minimum(o.output()[0].reshape(w, w, 3)[..., 1], 2.0).reshape(16, k, 16, k).mean(axis=(1, 3))
+        ratio = ya / mitsuba_luminance()
+        return float(ratio[4:12, 0:2].mean()), float(ratio[4:12, 14:16].mean())   # the red wall's blocks (image left), the green wall's
+
+    red_m, green_m = walls(False)
+    red_u, green_u = walls(True)
+    assert red_m < 0.90 and abs(red_u - 1) < 0.07, (red_m, red_u)          # measured 0.86 -> 0.95
+    assert green_m > 1.2 and abs(green_u - green_m) < 0.06, (green_m, green_u)   # measured 1.30 -> 1.30: open
