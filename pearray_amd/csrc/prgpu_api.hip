@@ -102,6 +102,35 @@ Knobs read_knobs()
 	return k;
 }
 
+// Named ranges for rocprofv3 --marker-trace around the entry points that take time (scene build, render, reduce, download): the
+// counterpart of the reference's PR_PROFILE_THIS scopes (src/base/Profiler.h:53-106).  roctx is bound at run time (it ships with ROCm's
+// profilers, the library must load without them); without it a range costs one branch.
+struct TraceRange {
+	typedef int (*PushFn)(const char*);
+	typedef int (*PopFn)();
+	static PushFn& push_fn() { static PushFn f = nullptr; return f; }
+	static PopFn& pop_fn() { static PopFn f = nullptr; return f; }
+	static bool bind()
+	{
+		static const bool bound = [] {
+			for (const char* name : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" })
+				if (void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+					push_fn() = reinterpret_cast<PushFn>(dlsym(lib, "roctxRangePushA"));
+					pop_fn()  = reinterpret_cast<PopFn>(dlsym(lib, "roctxRangePop"));
+					if (push_fn() && pop_fn())
+						return true;
+				}
+			return false;
+		}();
+		return bound;
+	}
+	bool active;
+	explicit TraceRange(const char* name) : active(bind()) { if (active) (void)push_fn()(name); }
+	~TraceRange() { if (active) (void)pop_fn()(); }
+	TraceRange(const TraceRange&) = delete;
+	TraceRange& operator=(const TraceRange&) = delete;
+};
+
 struct TimedLaunch {
 	hipEvent_t start, stop;
 	int family;
@@ -484,8 +513,11 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	// device LBVH
 	prd::BvhBuildInput bin{ d->n_triangles, d->n_entities, sc.positions, sc.indices, sc.tri_entity, sc.entities, sc.tri_class };
 	prd::BvhBuildOutput bout;
-	if (!prd::build_lbvh(bin, bout, s->stream, err))
-		return fail(PRGPU_EDEVICE, "LBVH build failed: " + err);
+	{
+		TraceRange bvh_range("prgpu_scene_create: LBVH build");
+		if (!prd::build_lbvh(bin, bout, s->stream, err))
+			return fail(PRGPU_EDEVICE, "LBVH build failed: " + err);
+	}
 	s->allocations.push_back(bout.recs);
 	if (bout.leaf_units)
 		s->allocations.push_back(bout.leaf_units); // unit of every leaf record (4 bytes per leaf; only launch_tri_slot reads it)
@@ -1138,6 +1170,7 @@ int prgpu_write_rgb_coeff_table(const char* path, uint32_t resolution, int threa
 
 int prgpu_scene_create(const prgpu_scene_desc* desc, int device, prgpu_scene** out)
 {
+	TraceRange trace_range("prgpu_scene_create");
 	if (!out)
 		return fail(PRGPU_EINVAL, "null output handle");
 	*out = nullptr;
@@ -1228,6 +1261,7 @@ int prgpu_bind_framebuffer(prgpu_scene* s, void* d_xyz, void* d_samples, void* d
 
 int prgpu_render(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 {
+	TraceRange trace_range("prgpu_render");
 	if (!s)
 		return fail(PRGPU_EINVAL, "null scene");
 	if (s->poisoned)
@@ -1281,6 +1315,7 @@ int prgpu_sync(prgpu_scene* s)
 
 int prgpu_download(prgpu_scene* s, float* xyz, uint32_t* samples, uint32_t* feedback)
 {
+	TraceRange trace_range("prgpu_download");
 	if (!s)
 		return fail(PRGPU_EINVAL, "null scene");
 	HIP_TRY(hipSetDevice(s->device));
@@ -1635,6 +1670,7 @@ int prgpu_comm_size(const prgpu_comm* c) { return c ? c->n_ranks : fail(PRGPU_EI
 
 int prgpu_reduce(prgpu_scene* s, prgpu_comm* c, int root)
 {
+	TraceRange trace_range("prgpu_reduce");
 	if (!s || !c)
 		return fail(PRGPU_EINVAL, "null argument");
 	if (root < 0 || root >= c->n_ranks)
