@@ -2,7 +2,7 @@
 # Profile a workload on the GPU box: one rocprofv3 kernel-trace pass (timing) and separate --pmc passes (FETCH_SIZE, WRITE_SIZE,
 # L2 hit/miss, SQ counters), each with --kernel-trace only.  Run through gpurun from the repo root:
 #   gpurun --timeout 1100 -- 'bash tools/gpu_profile.sh r02 c4'      (c4 = bench.py; c5 | rough | metal_all = tools/profile_scene.py)
-# then, back in the container:  python tools/profile_to_summary.py r02 8   (8 = iterations rendered in each --pmc pass)
+# then, back in the container:  python tools/profile_to_summary.py r02 8   (8 = iterations the PLAIN kernel renders in each --pmc pass)
 TAG=${1:-prof}
 WHAT=${2:-c4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 if [ "$WHAT" = "c4" ]; then
   TRACE="python3 $R/bench.py --steps 16 --warmup 8 --profile-only"
-  PMC="python3 $R/bench.py --steps 7 --warmup 1 --profile-only"
+  PMC="python3 $R/bench.py --steps 8 --warmup 1 --profile-only"   # (the warm-up launch is the scene's calibration launch: the instrumented variant; the plain kernel renders 8 iterations)
 else
   TRACE="python3 $R/tools/profile_scene.py $WHAT 16"
   PMC="python3 $R/tools/profile_scene.py $WHAT 8"

@@ -1,4 +1,4 @@
-"""Render exactly N iterations of a named scene (no checks, no instrumentation): the program rocprofv3 wraps for the scenes bench.py
+"""Render N iterations of a named scene in one launch of the plain kernel, after a warm-up of 8 (no checks, no instrumentation): the program rocprofv3 wraps for the scenes bench.py
 does not cover.  usage: python3 tools/profile_scene.py c5|rough|metal_all|share8 N   (share8 = rank 0's tiles of the C4 frame at 8 ranks)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +21,8 @@ ctx = backend.RenderContext(sc)
 if name.startswith("share"):
     from pearray_amd import tiling
     ctx.setTiles(tiling.tiles_for_rank(1920, 1080, 0, int(name[5:])))
-ctx.render(iters)
+ctx.render(8)          # the scene's first launch is its calibration launch (instrumented kernel variant, prgpu_api.hip render_persistent)
+ctx.waitForFinish()
+ctx.render(iters)      # ... the profiled one: the plain kernel, `iters` iterations in one launch
 ctx.waitForFinish()
 print("rendered %d iterations of %s: %s" % (iters, name, ctx.statistics()))

@@ -28,7 +28,7 @@ for sub in ("fetch", "write", "l2", "sq", "ta", "tcp"):
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_sha16: bench.py quotes a summary only for the build it was taken from)
 json.dump({"kernel_source_sha16": bench.kernel_source_sha16(), "command": "rocprofv3 --pmc <counter set> --kernel-trace -- python3 bench.py --steps %d --warmup 1 --profile-only "
-                      "(one pass per counter set; tools/gpu_profile.sh)" % (iters - 1),
+                      "(one pass per counter set; tools/gpu_profile.sh; the warm-up launch runs the instrumented variant, the plain kernel the %d steps)" % (iters, iters),
            "iterations_per_pass": iters,
            "note": "FETCH_SIZE/WRITE_SIZE in KiB as reported by rocprofv3; FETCH_SIZE under-reports wide reads by 2x on gfx950 "
                    "(MI355X_MICROARCH.md, HBM); *_per_iteration = total over the pass / iterations rendered (raygen-to-fold of every pixel once)",
