@@ -386,7 +386,8 @@ int  prgpu_set_instrumentation(prgpu_scene* s, int enabled);
 /* -- ray service (IArchive surface) --------------------------------------------------------- */
 /* Closest hit for n rays given as HOST SoA arrays (org/dir: 3*n, AoS xyz per ray).
  * Outputs (host): entity/prim u32 (PRGPU_INVALID_ID on miss), u,v barycentrics with
- * P = (1-u-v) v0 + u v1 + v v2 (Triangle.h:22-27), t.  Any output pointer may be NULL. */
+ * P = (1-u-v) v0 + u v1 + v v2 (Triangle.h:22-27), t.  Any output pointer may be NULL.  tmin[i] >= 0 (PRGPU_EINVAL otherwise: the
+ * traversal's box tests are conservative for non-negative entry distances; the reference's rays start at PR_EPSILON or later, Ray.h:25). */
 int  prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const float* dir,
                          const float* tmin, const float* tmax,
                          uint32_t* entity, uint32_t* prim, float* u, float* v, float* t);

@@ -1442,6 +1442,9 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 		return fail(PRGPU_EINVAL, "null argument");
 	if (n == 0)
 		return PRGPU_OK;
+	for (uint32_t i = 0; i < n; ++i) // the box tests of the traversal are conservative for entry distances >= 0
+		if (!(tmin[i] >= 0.0f))
+			return fail(PRGPU_EINVAL, "prgpu_trace_closest: tmin must not be negative (ray " + std::to_string(i) + ")");
 	HIP_TRY(hipSetDevice(s->device));
 	float *d_org = nullptr, *d_dir = nullptr, *d_tmin = nullptr, *d_tmax = nullptr, *d_u = nullptr, *d_v = nullptr, *d_t = nullptr;
 	uint32_t *d_e = nullptr, *d_p = nullptr;
@@ -1503,6 +1506,9 @@ int prgpu_trace_any(prgpu_scene* s, uint32_t n, const float* org, const float* d
 		return fail(PRGPU_EINVAL, "null argument");
 	if (n == 0)
 		return PRGPU_OK;
+	for (uint32_t i = 0; i < n; ++i)
+		if (!(tmin[i] >= 0.0f))
+			return fail(PRGPU_EINVAL, "prgpu_trace_any: tmin must not be negative (ray " + std::to_string(i) + ")");
 	HIP_TRY(hipSetDevice(s->device));
 	float *d_org = nullptr, *d_dir = nullptr, *d_tmin = nullptr, *d_dist = nullptr;
 	uint8_t* d_occ = nullptr;
