@@ -178,6 +178,34 @@ def test_ray_service_hit_ids_exact_soup_vs_brute_force(monkeypatch, split):
         assert np.array_equal(x, y)
 
 
+def test_ray_service_one_million_rays_in_the_one_million_triangle_scene(monkeypatch):
+    """The guard of round 4's box test (one fma per plane under the builder's margin): a million incoherent rays in the
+    headline scene through the device LBVH (both service kernels) against the checker's binned-SAH BVH2 with the REFERENCE box rule -- another
+    tree, another box test, the same argmin (t, triangle) -- and six hundred of them against the checker's exhaustive loop (no boxes at all).
+    A node dropped by a non-conservative test shows as a different or a missing hit."""
+    sc = scene.cornell_soup(8, 8, spp=1, n_triangles=1_000_000)
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(2024)
+    n = 1_000_000
+    org = (rng.random((n, 3)) * [1.9, 1.9, 1.85] + [-0.95, -0.95, 0.05]).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[::1000, 0] = 0.0          # some axis-parallel ones (not normalised on purpose: the service takes any direction)
+    d[500::1000, 1:] = 0.0
+    ref = o.trace_closest(org, d, 1e-4, np.inf)
+    for split in ("1", "0"):
+        monkeypatch.setenv("PRGPU_TRACE_SPLIT", split)
+        got = g.traceRays(org, d, 1e-4, np.inf)
+        for x, y in zip(got[:2], ref[:2]):          # entity and primitive ids
+            assert np.array_equal(x, y), split
+        assert np.array_equal(got[4], ref[4]), split   # and the distances, bit for bit
+    assert (ref[0] != 0xFFFFFFFF).mean() > 0.9
+    k = 600
+    brute = o.trace_closest(org[:k], d[:k], 1e-4, np.inf, brute=True)
+    for x, y in zip(got, brute):
+        assert np.array_equal(x[:k], y)
+
+
 def test_axis_aligned_and_grazing_rays():
     """Degenerate directions (zero components -> inf reciprocals) and rays in wall planes."""
     sc = scene.cornell_box(8, 8, spp=1)
