@@ -115,35 +115,41 @@ def _cie1931():
     return [np.array([float(v.strip().rstrip("f")) for v in re.search(r"PR_CIE1931_%s\[95\] = \{(.*?)\};" % c, txt, re.S).group(1).split(",") if v.strip()]) for c in "XYZ"]
 
 
-def test_red_wall_difference_is_rgb_against_spectral_and_the_green_wall_stays_open():
-    """What is behind the coloured walls' 10 - 30 % against Mitsuba.  (1) First bounce, analytically: the sRGB of the product spectrum
-    (a spectral renderer) against the product of the sRGBs (an RGB renderer) -- luminance 0.79 for red x light, 0.96 for white, 1.03 for
-    green: an RGB renderer shows the red wall 18 % brighter relative to the white ones than a spectral one, the green wall 6 % darker.
-    (2) The evaluation scene with both walls' spectra replaced by (refl r g b) of their own sRGB colour (Jakob-Hanika upsampling, the smooth
-    spectrum an RGB workflow implies): the RED wall's blocks then agree with Mitsuba to 5 % (0.86 with the measured spectrum); the GREEN
-    wall's do not move (1.30 either way) -- that difference is NOT an RGB-against-spectral effect and no test here explains it; the white
-    surfaces around it agree to 1 - 3 %, the form factor test above pins our green under this very light to 2.5 %."""
+def test_what_the_coloured_walls_difference_against_mitsuba_is_not():
+    """The coloured walls differ from Mitsuba's image by a ratio that varies ALONG each wall (red: 0.88 at the front edge to 1.22 at the back;
+    green: 0.92 at the back to 1.32 - 1.5 at the front; `tools/probe_cbox_walls.py`, `profiles/r04_cbox_walls.log`) while the white surfaces
+    agree to 1 %.  Two explanations are excluded here, with numbers: (1) the colour matching functions -- first bounce analytically, sRGB of
+    wall x light under CIE 1931 with the spectra zero outside 400..700 nm (Mitsuba) against CIE 2006 with constant extrapolation (PearRay):
+    luminance within 3 % for white, red and green; (2) an RGB-mode render on Mitsuba's side -- three scalar renders with every spectrum
+    replaced by its E-weighted sRGB channel, i.e. what an RGB renderer computes, show white surfaces 1.47 x too red against Mitsuba's image
+    (its R : G there is 0.495, the spectral prediction 0.52, the RGB emulation 0.31): the image is a spectral render.  The path depth limit
+    moves the wall ratios by < 0.05 (probe).  What remains is a difference between the two SCENES that the reference tree cannot settle
+    (Mitsuba's scene file is not in it); our own coloured-spectra arithmetic is pinned by the known answer above."""
     import json
     data = json.load(open(os.path.join(os.path.dirname(HERE), "pearray_amd", "data", "cbox_eval.json")))
-    X, Y, Z = _cie1931()
-    lam = np.arange(360, 831, 5.0)
     M = np.array([[3.2404542, -1.5371385, -0.4985314], [-0.9692660, 1.8760108, 0.0415560], [0.0556434, -0.2040259, 1.0572252]])
-    srgb = lambda spectrum: M @ (np.array([(c * spectrum).sum() for c in (X, Y, Z)]) / Y.sum())
     lum = lambda c: float(c @ np.array([0.2126, 0.7152, 0.0722]))
-    light = _table(data["emission"], lam)
-    first = {n: lum(srgb(_table(data["materials"][n], lam) * light)) / lum(srgb(_table(data["materials"][n], lam)) * srgb(light)) for n in ("white", "red", "green")}
-    assert abs(first["red"] / first["white"] - 0.82) < 0.03 and abs(first["green"] / first["white"] - 1.065) < 0.03, first
 
-    def walls(upsampled, w=64, spp=192):
+    def table(m, lam, zero_outside):
+        v = _table(m, lam)
+        return np.where((lam < m["start"]) | (lam > m["end"]), 0.0, v) if zero_outside else v
+
+    X31, Y31, Z31 = _cie1931()
+    X06, Y06, Z06 = _cie2006()
+    l31, l06 = np.arange(360, 831, 5.0), np.arange(390, 831, 1.0)
+    srgb31 = lambda s: M @ (np.array([(X31 * s).sum(), (Y31 * s).sum(), (Z31 * s).sum()]) / Y31.sum())
+    for n in ("white", "red", "green"):
+        a = srgb31(table(data["materials"][n], l31, True) * table(data["emission"], l31, True))
+        s = table(data["materials"][n], l06, False) * table(data["emission"], l06, False)
+        b = M @ (np.array([(X06 * s).sum(), (Y06 * s).sum(), (Z06 * s).sum()]) / Y06.sum())
+        assert abs(lum(b) / lum(a) - 1) < 0.04, (n, lum(b) / lum(a))
+
+    def scalar_render(c, w=64, spp=64):
         b = scene.SceneBuilder(w, w)
         s = b.settings
         s.aa_sampler, s.aa_samples, s.max_ray_depth, s.mapper, s.filter, s.filter_radius = abi.SAMPLER_SOBOL, spp, 6, abi.MAPPER_RANDOM, abi.FILTER_TRIANGLE, 0
-        mats = {}
-        for n, m in data["materials"].items():
-            rgb = np.clip(srgb(_table(m, lam)), 0.0, 1.0)
-            mats[n] = b.lambert(b.refl(*rgb) if upsampled and n in ("red", "green") else b.spectrum_table(m["start"], m["end"], m["values"]))
-        e = data["emission"]
-        ems = b.diffuse_emission(b.spectrum_table(e["start"], e["end"], e["values"]))
+        mats = {n: b.lambert(b.spectrum_const(float(np.clip(srgb31(table(m, l31, True))[c], 0, 1)))) for n, m in data["materials"].items()}
+        ems = b.diffuse_emission(b.spectrum_const(float(max(srgb31(table(data["emission"], l31, True))[c], 0))))
         for ent in data["entities"]:
             T = np.eye(4, dtype=np.float32)
             if ent["position"]:
@@ -157,11 +163,11 @@ def test_red_wall_difference_is_rgb_against_spectral_and_the_green_wall_stays_op
         o = ob.OracleScene(b.build())
         o.render(spp, threads=8)
         k = w // 16
-        ya = np.minimum(o.output()[0].reshape(w, w, 3)[..., 1], 2.0).reshape(16, k, 16, k).mean(axis=(1, 3))
-        ratio = ya / mitsuba_luminance()
-        return float(ratio[4:12, 0:2].mean()), float(ratio[4:12, 14:16].mean())   # the red wall's blocks (image left), the green wall's
+        return np.minimum(o.output()[0].reshape(w, w, 3)[..., 1], 4.0).reshape(16, k, 16, k).mean(axis=(1, 3))   # constant spectra: Y is the scalar solution
 
-    red_m, green_m = walls(False)
-    red_u, green_u = walls(True)
-    assert red_m < 0.90 and abs(red_u - 1) < 0.07, (red_m, red_u)          # measured 0.86 -> 0.95
-    assert green_m > 1.2 and abs(green_u - green_m) < 0.06, (green_m, green_u)   # measured 1.30 -> 1.30: open
+    blocks = np.array(json.load(open(os.path.join(HERE, "golden", "cbox_mitsuba_16x16.json")))["blocks"])
+    white = (slice(5, 12), slice(5, 8))
+    red, green = scalar_render(0)[white], scalar_render(1)[white]
+    assert (red / blocks[white][..., 0]).mean() > 1.3, (red / blocks[white][..., 0]).mean()            # measured 1.47: not an RGB-mode image
+    assert abs((blocks[white][..., 1] / blocks[white][..., 0]).mean() - 0.495) < 0.02                  # Mitsuba's white surfaces, G : R
+    assert (green / red).mean() < 0.36                                                                  # ... an RGB renderer's: 0.31
