@@ -38,8 +38,9 @@ def _worker(rank, world, port, out_path):
     distributed.reduce_framebuffer(fx, fs, dst=0)
     total = distributed.sum_scalar(float(tiling.owned_pixel_count(tiles) * spp))
     t_max = distributed.max_scalar(0.5 + rank)
+    per_rank = distributed.gather_scalars(10.0 + rank)      # bench.py's per-rank render times (config.rank_render_ms_per_step)
     if rank == 0:
-        np.savez(out_path, xyz=fx.numpy(), smp=fs.numpy(), total=total, tmax=t_max)
+        np.savez(out_path, xyz=fx.numpy(), smp=fs.numpy(), total=total, tmax=t_max, per_rank=np.array(per_rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,4 +56,4 @@ def test_two_rank_tile_sharding_reduces_to_the_full_frame(tmp_path):
     xyz, smp, _ = whole.output()
     got = np.load(out)
     assert np.array_equal(got["xyz"], xyz) and np.array_equal(got["smp"], smp.astype(np.int32))
-    assert got["total"] == 64 * 48 * 3 and got["tmax"] == 1.5
+    assert got["total"] == 64 * 48 * 3 and got["tmax"] == 1.5 and got["per_rank"].tolist() == [10.0, 11.0]
