@@ -48,6 +48,9 @@ enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CN
 // record per step and refill idle lanes when too few are active, so a few long rays do not hold 63 idle lanes.
 // The traversal stack lives in LDS (STACK_LDS entries per lane, bank-conflict free layout [entry][lane]); the
 // rare deeper stacks spill their oldest entries to a per-thread slab in HBM.
+#ifndef PR_PEEK
+#define PR_PEEK 0 // persistent path kernel: read the stack top ahead of every step (see path_persistent); the Makefile sets it per variant
+#endif
 #ifndef PR_PP_BLOCK
 #define PR_PP_BLOCK 256 // threads of a persistent-kernel block: 256 (three blocks per CU) or 768 (one block per CU: its twelve waves share one set of queues)
 #endif
@@ -77,6 +80,20 @@ struct Stack {
 	{
 		lds[(sp & (STACK_LDS - 1)) * TRAV_BLOCK] = make_uint2(ref, key);
 		sp += valid ? 1 : 0;
+	}
+	// the top entry, read ahead of a step that may pop it (any value when the stack is empty: never used then)
+	__device__ __forceinline__ uint2 peek() const { return lds[((sp - 1) & (STACK_LDS - 1)) * TRAV_BLOCK]; }
+	// pop with the top entry already in registers (peek() before the step; a step that pops has pushed nothing)
+	__device__ __forceinline__ uint2 pop_peeked(uint2 top)
+	{
+		--sp;
+		if (__builtin_expect(sp < base, 0)) {
+			base = sp;
+			top	 = make_uint2(REC_EMPTY, 0x7F800000u);
+			if (sp < STACK_SPILL)
+				top = spill[(uint32_t)sp * spill_stride];
+		}
+		return top;
 	}
 	__device__ __forceinline__ uint2 pop()
 	{
@@ -124,9 +141,14 @@ __device__ __forceinline__ void trav_begin(Trav& s, STK& st, V3 o, V3 d, float t
 // re-check still_reachable(key & ~0xFF, limit) is done on the bit patterns: for k = key with its low byte cleared and a threshold
 // T >= 0, k <= T as floats <=> key <= (bits(T) | 0xFF) as integers (a negative or NaN threshold keeps the entry: conservative).
 template <int M, typename STK>
-__device__ __forceinline__ void trav_pop(Trav& s, STK& st)
+__device__ __forceinline__ void trav_pop(Trav& s, STK& st, const uint2* top = nullptr)
 {
 	const uint32_t thr = __float_as_uint(__fmaf_rn(s.best.t, SLAB_REL, s.r.eps_t)) | 0xFFu;
+	if (top != nullptr && s.cur == REC_EMPTY && st.sp > 0) { // the first pop of a step: its entry was read before the step, off the critical path
+		const uint2 e = st.pop_peeked(*top);
+		if (M == MODE_ANY || e.y <= thr)
+			s.cur = e.x;
+	}
 	while (s.cur == REC_EMPTY && st.sp > 0) {
 		const uint2 e = st.pop();
 		if (M == MODE_ANY || e.y <= thr)
@@ -170,7 +192,7 @@ __device__ __forceinline__ void inner_keys(const Trav& s, const float4& q0, cons
 // ... sort part: continue with the nearest hit child and push the others far to near (occlusion rays share the sorted code: their
 // result does not depend on the order).  5-comparator network on the integer keys (misses sort last).
 template <int M, typename STK>
-__device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2)
+__device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const uint2* top = nullptr)
 {
 	uint32_t key[4];
 	inner_keys(s, q0, q1, q2, key);
@@ -188,14 +210,15 @@ __device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q
 	st.push_if(key[2] != 0xFFFFFFFFu, base + (key[2] & 0xFFu), key[2]);
 	st.push_if(key[1] != 0xFFFFFFFFu, base + (key[1] & 0xFFu), key[1]);
 	s.cur = key[0] != 0xFFFFFFFFu ? base + (key[0] & 0xFFu) : REC_EMPTY;
-	trav_pop<M>(s, st);
+	trav_pop<M>(s, st, top);
 }
 template <int M>
 __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& st)
 {
 	const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
 	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-	trav_inner_rec<M>(s, st, q0, q1, q2);
+	const uint2 top = st.peek(); // (see path_persistent)
+	trav_inner_rec<M>(s, st, q0, q1, q2, &top);
 }
 
 // Leaf step: fetch the leaf record (<= 3 triangles) and run the watertight test on each.
@@ -238,7 +261,7 @@ __device__ __forceinline__ void leaf_test(Trav& s, const float4& q0, const float
 }
 template <int M, bool SPH, bool CLS = false, typename STK>
 __device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, const float4& q4,
-											  const float4& q5, const float4& q6, const float4& q7)
+											  const float4& q5, const float4& q6, const float4& q7, const uint2* top = nullptr)
 {
 	const bool ANY = M == MODE_ANY || (M == MODE_MIXED && s.any);
 	leaf_test<M, SPH, CLS>(s, q0, q1, q2, q3, q4, q5, q6, q7);
@@ -247,14 +270,15 @@ __device__ __forceinline__ void trav_leaf_rec(Trav& s, STK& st, const float4& q0
 		st.reset();
 		return;
 	}
-	trav_pop<M>(s, st);
+	trav_pop<M>(s, st, top);
 }
 template <int M>
 __device__ __forceinline__ void trav_leaf(const DevScene& sc, Trav& s, Stack& st)
 {
 	const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
 	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
-	trav_leaf_rec<M, true>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
+	const uint2 top = st.peek();
+	trav_leaf_rec<M, true>(s, st, q0, q1, q2, q3, q4, q5, q6, q7, &top);
 }
 
 // The scene's quadric entities (Embree user geometries in the reference, entities/quadric.cpp:131-231), tested once per ray when a lane
@@ -2713,19 +2737,25 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			if (lane_in(do_inner ? m_inner : m_leaf)) {
 				const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
 				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2]; // an inner record (48 of its 64 bytes are used), or the start of a leaf
+				// The entry a pop at the end of this step would take is read NOW: its LDS round trip overlaps the record fetch instead of
+				// standing between this step and the next one's fetch (a step that pops has pushed nothing).  C4 + 1.5 %; the kernels
+				// with the large shading bodies pay for the two registers in spills (717 -> 758 for the all-features one, C5 - 1.5 %:
+				// profiles/r04_peek_ab.log), so it is a per-variant choice (Makefile: PR_PEEK).
+				const uint2 top_e	   = PR_PEEK ? st.peek() : make_uint2(0u, 0u);
+				const uint2* const top = PR_PEEK ? &top_e : nullptr;
 				if (do_inner) {
 					if (COUNT) {
 						cn_c += s.any ? 0 : 1;
 						cn_a += s.any ? 1 : 0;
 					}
-					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2);
+					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, top);
 				} else {
 					const float4 q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
 					if (COUNT) {
 						cl_c += s.any ? 0 : 1;
 						cl_a += s.any ? 1 : 0;
 					}
-					trav_leaf_rec<MODE_MIXED, (FEATS & FEAT_SPHERES) != 0, (NQ > 1)>(s, st, q0, q1, q2, q3, q4, q5, q6, q7);
+					trav_leaf_rec<MODE_MIXED, (FEATS & FEAT_SPHERES) != 0, (NQ > 1)>(s, st, q0, q1, q2, q3, q4, q5, q6, q7, top);
 				}
 			}
 			if (COUNT) {
