@@ -206,6 +206,69 @@ def test_ray_service_one_million_rays_in_the_one_million_triangle_scene(monkeypa
         assert np.array_equal(x[:k], y)
 
 
+def _stacked_sheets(n_sheets, dz=1e-3):
+    """n_sheets large triangles stacked along z, all with the bounding square [-1, 3]^2: the first half covers the corner x + y >= 2, the
+    second half the corner x + y <= 2.  Their centroids differ in z only (within a half), so the LBVH's nodes are z-slabs that a ray along z
+    crosses one and all: every inner step pushes three entries, 3 x depth entries by the time the first leaf is reached."""
+    z = (np.arange(n_sheets, dtype=np.float32) * np.float32(dz)).astype(np.float32)
+    upper = np.arange(n_sheets) < n_sheets // 2
+    pos = np.empty((n_sheets, 3, 3), dtype=np.float32)
+    pos[upper, 0, :2], pos[upper, 1, :2], pos[upper, 2, :2] = (3, 3), (-1, 3), (3, -1)
+    pos[~upper, 0, :2], pos[~upper, 1, :2], pos[~upper, 2, :2] = (-1, -1), (3, -1), (-1, 3)
+    pos[:, :, 2] = z[:, None]
+    return pos.reshape(-1, 3), np.arange(3 * n_sheets, dtype=np.uint32).reshape(-1, 3)
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_deep_traversal_stacks_spill_and_come_back(monkeypatch, split):
+    """Traversal stacks deeper than the 16 entries a lane holds in LDS: the oldest entries go to the lane's slab in HBM and come back when
+    the walk returns to them (Stack::reserve / pop, and the entry read ahead of a step, Stack::peek / pop_peeked).  16384 stacked sheets
+    give a 4-wide tree 7 levels deep whose every node a ray along z crosses: 21 entries before the first leaf.  Rays through the corner
+    the NEAR half covers end at once and throw the spilled entries away; rays through the other corner miss the whole near half, so the
+    walk works through every entry it spilled, near to far, until the first sheet of the far half.  Hits against the exhaustive loop."""
+    monkeypatch.setenv("PRGPU_TRACE_SPLIT", split)
+    pos, faces = _stacked_sheets(16384)
+    b = scene.SceneBuilder(8, 8)
+    b.settings.aa_samples = 1
+    b.add_mesh(pos, faces, b.lambert(b.spectrum_const(0.5)))
+    sc = b.build()
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(77)
+    n = 1024
+    xy = np.where(rng.random((n, 1)) < 0.5, rng.uniform(1.6, 2.4, (n, 2)), rng.uniform(-0.4, 0.4, (n, 2)))
+    org = np.concatenate([xy, np.full((n, 1), -1.0)], 1).astype(np.float32)
+    d = np.tile(np.array([[0, 0, 1]], dtype=np.float32), (n, 1))
+    d[n // 2:, :2] = rng.normal(scale=0.01, size=(n - n // 2, 2))          # slightly oblique ones
+    back = slice(0, n, 4)                                                     # and from behind the stack, looking back
+    org[back, 2], d[back, 2] = 20.0, -1.0
+    a, c = g.traceRays(org, d, 1e-4, np.inf), o.trace_closest(org, d, 1e-4, np.inf, brute=True)
+    assert (c[0] != abi.INVALID_ID).all()
+    prim = c[1]
+    assert ((prim >= 8192) & (org[:, 2] < 0) & (xy.sum(1) < 2)).sum() > n // 8     # the rays that have to cross the near half first
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
+
+
+def test_deep_traversal_stacks_in_the_path_kernel():
+    """The same stacked sheets rendered: the persistent path kernel's steps (stack top read ahead of the record fetch) against the checker.
+    An orthographic camera looks along z, so that every camera ray crosses every node; in the corner the near half does not cover, a ray
+    works through 8192 sheets' leaves and every entry it spilled before it reaches its hit.  (Checked by mutation: built with profiles/r04_mutate_spill.patch and
+    -DPR_MUTATE_SPILL=1 -- spilled entries dropped on their way back -- this test and the ray-service one above fail, and so do the
+    full-resolution C4 tests; nothing else in the suite reaches a spilled entry.)"""
+    pos, faces = _stacked_sheets(16384)
+    b = scene.SceneBuilder(40, 32)
+    b.settings.aa_samples = 3
+    b.add_mesh(pos, faces, b.lambert(b.spectrum_const(0.7)))
+    light = np.array([[0.5, 0.5, -2.0], [1.5, 0.5, -2.0], [0.5, 1.5, -2.0]], dtype=np.float32)
+    b.add_mesh(light, np.array([[0, 1, 2]], dtype=np.uint32), b.lambert(b.spectrum_const(0.0)), emission=b.diffuse_emission(b.illuminant_d65()))
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (1.0, 1.0, -3.0)
+    b.set_camera(T, width=3.2, height=2.56, ortho=True)
+    g, o = render_both(b.build())
+    assert_parity(g, o, exact=True)
+    prim = g.primaryHits()[1].reshape(32, 40)
+    assert (prim == 8192).sum() > 200 and (prim == 0).sum() > 200      # both corners: behind the near half, and on its first sheet
+
+
 def test_axis_aligned_and_grazing_rays():
     """Degenerate directions (zero components -> inf reciprocals) and rays in wall planes."""
     sc = scene.cornell_box(8, 8, spp=1)
