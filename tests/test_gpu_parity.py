@@ -206,6 +206,99 @@ def test_ray_service_one_million_rays_in_the_one_million_triangle_scene(monkeypa
         assert np.array_equal(x[:k], y)
 
 
+def _lattice_sheet(cells=128):
+    """A flat sheet of 2 x cells^2 right triangles whose vertices lie on a power-of-two lattice (spacing 2 / cells, z = 0.5): every node's
+    grid step is a power of two that divides the spacing, so EVERY quantised box plane lies exactly the builder's margin (2^-14 step)
+    outside the vertices it bounds -- no half step of rounding-up slack anywhere, the case the margin and SLAB_REL exist for."""
+    h = 2.0 / cells
+    i, j = np.meshgrid(np.arange(cells + 1), np.arange(cells + 1), indexing="ij")
+    pos = np.stack([i * h - 1.0, j * h - 1.0, np.full(i.shape, 0.5)], -1).reshape(-1, 3).astype(np.float32)
+    idx = lambda a, b: a * (cells + 1) + b                                                    # noqa: E731
+    a, b = np.meshgrid(np.arange(cells), np.arange(cells), indexing="ij")
+    f0 = np.stack([idx(a, b), idx(a + 1, b), idx(a, b + 1)], -1).reshape(-1, 3)
+    f1 = np.stack([idx(a + 1, b + 1), idx(a, b + 1), idx(a + 1, b)], -1).reshape(-1, 3)
+    return pos, np.concatenate([f0, f1]).astype(np.uint32)
+
+
+@pytest.mark.parametrize("geometry", ["soup", "lattice"])
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_rays_aimed_at_triangle_vertices_and_edges(monkeypatch, split, geometry):
+    """The adversarial guard of the box test.  A random ray never tells a conservative box test from one without its
+    slack: the two differ only for rays that touch a box where the geometry touches it.  These rays do: each is aimed, from a distance of
+    ~100 leaf sizes, at a VERTEX of a triangle (the points that define the leaf boxes' planes, most of them extreme in two axes, i.e. on
+    a box edge, where entry and exit distance coincide) or at a point on an edge; rounding puts about a third of them inside the triangle.
+    Hits against the checker's SAH BVH2 with the reference box rule and, for a sample, its exhaustive loop.  (Checked by mutation,
+    profiles/r04_mutations.patch: see DESIGN.md for which removed slack this test catches.)"""
+    monkeypatch.setenv("PRGPU_TRACE_SPLIT", split)
+    pos, faces = scene.triangle_soup(30_000, seed=3, size=0.01) if geometry == "soup" else _lattice_sheet()
+    b = scene.SceneBuilder(8, 8)
+    b.settings.aa_samples = 1
+    b.add_mesh(pos, faces, b.lambert(b.spectrum_const(0.5)))
+    sc = b.build()
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(99)
+    n = 300_000
+    tri = rng.integers(0, len(faces), n)
+    P = pos[faces[tri]].astype(np.float64)                                    # n x 3 x 3
+    w = rng.random((n, 1))
+    target = np.where(rng.random((n, 1)) < 0.7, P[:, 0], P[:, 1] * w + P[:, 2] * (1 - w))   # a vertex, or a point on the opposite edge
+    org = (rng.random((n, 3)) * [1.9, 1.9, 1.85] + [-0.95, -0.95, 0.05]).astype(np.float32)
+    d = target - org.astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    a, c = g.traceRays(org, d, 1e-4, np.inf), o.trace_closest(org, d, 1e-4, np.inf)
+    aimed_hit = (c[1] == tri).mean()
+    assert 0.05 < aimed_hit < 0.9, aimed_hit                                  # a good share lands on the triangle aimed at, a good share beside it
+    if geometry == "lattice":                                                 # a closed sheet: whatever is aimed at its interior hits it
+        inner = np.abs(target[:, :2]).max(1) < 0.98
+        assert (c[0][inner] != abi.INVALID_ID).all()
+    for x, y in zip(a[:2], c[:2]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[4], c[4])
+    k = 3000
+    e = o.trace_closest(org[:k], d[:k], 1e-4, np.inf, brute=True)
+    for x, y in zip(a, e):
+        assert np.array_equal(x[:k], y)
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_rays_that_enter_a_box_just_before_they_hit(monkeypatch, split):
+    """The sharpest guard of the box test: hits within 1e-12 .. 1e-8 of a box plane, reached from OUTSIDE that plane, so that the ray is inside
+    the box for a sliver of its length before the hit -- less than the rounding of the plane distances when the slope across the plane is
+    small (1e-9 .. 1).  Such offsets exist in fp32 only next to zero: the lattice sheet's lines x = 0 and y = 0 are box planes of the
+    leaves on either side (up to the builder's margin), and the pierce points lie a hair beyond them.  A box test that is exact but not
+    conservative -- no margin around the quantised boxes, or no relative slack in the acceptance -- loses some of these hits (checked by
+    mutation, profiles/r04_mutations.patch; DESIGN.md section 4 has the table); all of them against the checker's exhaustive loop."""
+    monkeypatch.setenv("PRGPU_TRACE_SPLIT", split)
+    pos, faces = _lattice_sheet()
+    b = scene.SceneBuilder(8, 8)
+    b.settings.aa_samples = 1
+    b.add_mesh(pos, faces, b.lambert(b.spectrum_const(0.5)))
+    sc = b.build()
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(4242)
+    n = 60_000
+    axis = rng.integers(0, 2, n)                                              # the plane crossed: x = 0 or y = 0
+    side = rng.choice([-1.0, 1.0], n)                                         # ... towards +side
+    tau = 10.0 ** rng.uniform(-12, -8, n)                                     # pierce point this far beyond the plane
+    slope = 10.0 ** rng.uniform(-9, 0, n)                                     # direction component across the plane
+    P = np.zeros((n, 3)); P[:, 2] = 0.5
+    other = 1 - axis
+    P[np.arange(n), other] = rng.uniform(-0.9, 0.9, n)
+    P[np.arange(n), axis] = side * tau
+    d = np.zeros((n, 3))
+    d[np.arange(n), axis] = side * slope
+    d[np.arange(n), other] = rng.uniform(-1, 1, n)
+    d[:, 2] = rng.choice([-1.0, 1.0], n) * rng.uniform(0.2, 1.0, n)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t = rng.uniform(0.2, 1.0, n)
+    org = (P - d * t[:, None]).astype(np.float32)
+    d = d.astype(np.float32)
+    a, c = g.traceRays(org, d, 1e-4, np.inf), o.trace_closest(org, d, 1e-4, np.inf, brute=True)
+    assert (c[0] != abi.INVALID_ID).mean() > 0.99
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
+
+
 def _stacked_sheets(n_sheets, dz=1e-3):
     """n_sheets large triangles stacked along z, all with the bounding square [-1, 3]^2: the first half covers the corner x + y >= 2, the
     second half the corner x + y <= 2.  Their centroids differ in z only (within a half), so the LBVH's nodes are z-slabs that a ray along z
