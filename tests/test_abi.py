@@ -3,6 +3,7 @@ errors through codes + prgpu_last_error (no compute calls without a GPU)."""
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -133,6 +134,16 @@ def test_error_reporting_without_a_gpu():
     bad = (C.c_float * 3)(float("nan"), 0, 0)
     assert lib.prgpu_rgb_to_coeffs(bad, (C.c_float * 3)()) == -1
     assert lib.prgpu_render(None, 0, 1) == -1
+
+
+def test_a_missing_library_is_an_import_error_not_a_fallback(tmp_path):
+    """No CPU path behind the product: with the HIP library absent the host mirror refuses to load (a fresh interpreter, PRGPU_LIBRARY
+    pointing at nothing)."""
+    import subprocess
+    code = "from pearray_amd import _cabi\ntry:\n    _cabi.load()\nexcept ImportError as e:\n    print('refused:', 'no CPU fallback' in str(e))\n"
+    env = dict(os.environ, PRGPU_LIBRARY=str(tmp_path / "libprgpu_absent.so"))
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip() == "refused: True", out.stdout + out.stderr
 
 
 def test_scene_create_fails_loudly_without_device():
