@@ -1024,10 +1024,12 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 // Called from prgpu_sync (the stream is idle).
 int tune_pixel_order(prgpu_scene* s)
 {
-	// the estimate sharpens with the sample count: tune after 4 iterations, again whenever the count has grown eightfold.  (A tune costs ~ 6 ms
-	// of host time at 1/8 of the 1080p frame and buys ~ 4 % per iteration: re-tuning at every doubling put one inside the driver's 20-step
-	// timed region, 2.09 -> 2.38 ms per step, profiles/r04_share_timed_region.log.)
-	if (s->mode != prgpu_scene::PERSISTENT || s->next_iteration < std::max(4u, 8u * s->order_tuned_at) || !s->n_slots)
+	// the estimate sharpens with the sample count: tune at the first synchronisation point (the 5 x 5 box below takes the noise out of a
+	// one-iteration estimate), again at 64 iterations and whenever the count has grown eightfold since.  (A tune costs ~ 6 ms of host time
+	// at 1/8 of the 1080p frame and buys ~ 4 % per iteration: re-tuning at every doubling put one inside the driver's 20-step timed
+	// region, 2.09 -> 2.38 ms per step, profiles/r04_share_timed_region.log; with this schedule a warm-up of any length takes the first
+	// tune and a measurement of up to 63 iterations after it sees none.)
+	if (s->mode != prgpu_scene::PERSISTENT || s->next_iteration < (s->order_tuned_at == 0u ? 1u : std::max(64u, 8u * s->order_tuned_at)) || !s->n_slots)
 		return PRGPU_OK;
 	s->order_tuned_at = s->next_iteration;
 	if (!s->knobs.pp_tune_order)
