@@ -351,6 +351,32 @@ def test_rays_that_enter_a_box_just_before_they_hit(monkeypatch, split):
         assert np.array_equal(x, y)
 
 
+def test_rays_with_nan_or_infinite_components_miss_and_do_not_walk_the_tree():
+    """A degenerate normal upstream can hand the traversal a ray with a NaN in it.  No triangle test passes with a NaN, so such a ray
+    misses; what must not happen is that it walks the whole tree on the way (the box test's min / max drop NaNs): a NaN origin is moved
+    out of the world in ray_prepare, a NaN direction has its reciprocal clamped.  Results against the checker, and a bound on the time
+    (a full walk of the 300 k-triangle tree costs a wave ~ 4 ms; all of these together take less than one)."""
+    import time
+    sc = scene.cornell_soup(8, 8, spp=1, n_triangles=300_000)
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(8)
+    n = 4096
+    org = (rng.random((n, 3)) * [1.8, 1.8, 1.7] + [-0.9, -0.9, 0.1]).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    bad_o, bad_d = org.copy(), d.copy()
+    k = np.arange(n)
+    bad_o[k % 8 == 1, 0] = np.nan; bad_o[k % 8 == 2, 2] = np.nan; bad_o[k % 8 == 3, 1] = np.inf
+    bad_d[k % 8 == 4, 0] = np.nan; bad_d[k % 8 == 5] = np.nan; bad_d[k % 8 == 6, 2] = -np.inf
+    g.traceRays(org, d, 1e-4, np.inf)                                       # warm-up
+    t = time.time(); a = g.traceRays(bad_o, bad_d, 1e-4, np.inf); dt = time.time() - t
+    c = o.trace_closest(bad_o, bad_d, 1e-4, np.inf)
+    clean = (k % 8 == 0) | (k % 8 == 7)
+    assert (a[0][~clean] == abi.INVALID_ID).all() and (a[0][clean] != abi.INVALID_ID).mean() > 0.9
+    for x, y in zip(a[:2], c[:2]):
+        assert np.array_equal(x, y)
+    assert dt < 0.25, dt                                                    # 64 waves, each with NaN rays: a full walk each would be ~ 0.3 s
+
+
 def _stacked_sheets(n_sheets, dz=1e-3):
     """n_sheets large triangles stacked along z, all with the bounding square [-1, 3]^2: the first half covers the corner x + y >= 2, the
     second half the corner x + y <= 2.  Their centroids differ in z only (within a half), so the LBVH's nodes are z-slabs that a ray along z
