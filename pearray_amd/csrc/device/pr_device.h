@@ -760,15 +760,17 @@ struct RayPre {
 	V3 inv_d;
 	float eps_t; // absolute slack of the slab test, see box_hit
 };
+// A NaN in a ray's origin (a degenerate normal upstream: safe_position of a NaN normal) makes every slab distance NaN, and the conservative
+// min / max of the box test drop NaNs: such a ray would walk the WHOLE tree to find nothing (no triangle test passes with a NaN origin;
+// 12 ms per wave in the 1 M-triangle scene).  Moved out of the world it misses the root's children instead -- the same miss.  Applied where a
+// ray is BORN (the shading pass that writes it, the ray service's load), not in ray_prepare: three more live values there cost the path
+// kernel's stepping loop 1.4 % (profiles/r04_nan_origin_ab.log).  A NaN direction needs nothing: its reciprocal is clamped in ray_prepare.
+__device__ __forceinline__ V3 sane_origin(V3 o) { return v3(o.x == o.x ? o.x : 3.0e38f, o.y == o.y ? o.y : 3.0e38f, o.z == o.z ? o.z : 3.0e38f); }
 __device__ __forceinline__ RayPre ray_prepare(V3 o, V3 d, float eps_t)
 {
 	RayPre r;
 	r.eps_t		   = eps_t;
-	// A NaN in the origin (a degenerate normal upstream: safe_position of a NaN normal) makes every slab distance NaN, and the conservative
-	// min / max of the box test drop NaNs: such a ray would walk the WHOLE tree to find nothing (no triangle test passes with a NaN origin).
-	// Moved out of the world it misses the root's children instead -- the same result, 12 ms sooner per wave in the 1 M-triangle scene.
-	// (A NaN direction needs nothing: its reciprocal is clamped below.)
-	r.o			   = v3(o.x == o.x ? o.x : 3.0e38f, o.y == o.y ? o.y : 3.0e38f, o.z == o.z ? o.z : 3.0e38f);
+	r.o			   = o;
 	r.d			   = d;
 	const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
 	int kz = 0;

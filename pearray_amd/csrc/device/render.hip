@@ -339,7 +339,7 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_
 						V3 o, d;
 						float tmin, tmax;
 						load(i, o, d, tmin, tmax);
-						trav_begin(s, st, o, d, tmin, tmax, sc.eps_t);
+						trav_begin(s, st, sane_origin(o), d, tmin, tmax, sc.eps_t); // (rays of the ray service are the caller's)
 						if (sc.n_quadrics) // (wavefront pipelines and the ray service: a run-time test; the path kernel compiles it per variant)
 							trav_quadrics<false>(sc, s, ANY);
 						my_ray	= i;
@@ -1827,7 +1827,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 							mis = hf / (wvl_pdf * bsum(hf));
 						}
 						const V3 oN = dot(L, N) < 0 ? -N : N;
-						const V3 so = safe_position(P, L, oN);
+						const V3 so = sane_origin(safe_position(P, L, oN));
 						float xyz_vis[3];
 						const float xyz_occ[3] = { 0.0f, 0.0f, 0.0f };
 						const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, cie, blend, xyz_vis);
@@ -1929,7 +1929,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					}
 					const float distance = sqrtf(sqrD);
 					const V3 oN			 = dot(L, N) < 0 ? -N : N;
-					const V3 so			 = safe_position(P, L, oN);
+					const V3 so			 = sane_origin(safe_position(P, L, oN));
 					float xyz_vis[3];
 					const float xyz_occ[3] = { 0.0f, 0.0f, 0.0f };
 					const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, cie, blend, xyz_vis);
@@ -2034,7 +2034,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				}
 				if (cont) {
 					const V3 oN		 = dot(L, N) < 0 ? -N : N;
-					const V3 no		 = safe_position(P, L, oN);
+					const V3 no		 = sane_origin(safe_position(P, L, oN)); // (pr_device.h: a NaN origin must not reach the traversal)
 					const uint32_t nd = depth + 1;
 					if (nd < cfg.max_ray_depth) {
 						alive				= true;
@@ -3101,7 +3101,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene s
 					const uint32_t i = base + __popcll(idle & ((1ull << lane) - 1ull));
 					if (i < n) {
 						const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-						trav_begin(s, st, o, d, tmin_a[i], tmax_a[i], sc.eps_t);
+						trav_begin(s, st, sane_origin(o), d, tmin_a[i], tmax_a[i], sc.eps_t);
 						sh.rc[0][tid] = make_float4(o.x, o.y, o.z, __uint_as_float((uint32_t)s.r.kx | ((uint32_t)s.r.ky << 2) | ((uint32_t)s.r.kz << 4)));
 						sh.rc[1][tid] = make_float4(s.r.Sx, s.r.Sy, s.r.Sz, s.tmin);
 						__hip_atomic_store(&sh.best[tid], ((unsigned long long)__float_as_uint(tmax_a[i]) << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

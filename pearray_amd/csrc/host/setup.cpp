@@ -1128,6 +1128,9 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 	}
 	if (d->camera.kind > PRGPU_CAMERA_FISHEYE)
 		return bad("unknown camera kind");
+	for (int k = 0; k < 12; ++k) // (a NaN ray origin would walk the whole tree: pr_device.h, sane_origin)
+		if (!std::isfinite(d->camera.transform[k]))
+			return bad("camera transform must be finite");
 	if (d->camera.kind == PRGPU_CAMERA_FISHEYE && (d->camera.fisheye_map > PRGPU_FISHEYE_FULL || !(d->camera.fov > 0.0f) || !std::isfinite(d->camera.fov)))
 		return bad("fisheye camera: fov must be positive and finite, map one of PRGPU_FISHEYE_*");
 	if (d->camera.kind == PRGPU_CAMERA_SPHERICAL
