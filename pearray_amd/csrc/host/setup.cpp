@@ -1131,6 +1131,16 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 	for (int k = 0; k < 12; ++k) // (a NaN ray origin would walk the whole tree: pr_device.h, sane_origin)
 		if (!std::isfinite(d->camera.transform[k]))
 			return bad("camera transform must be finite");
+	{
+		const prgpu_camera& k = d->camera;
+		const float v[] = { k.width, k.height, k.near_t, k.fstop, k.aperture_radius, k.local_direction[0], k.local_direction[1], k.local_direction[2],
+							k.local_right[0], k.local_right[1], k.local_right[2], k.local_up[0], k.local_up[1], k.local_up[2] };
+		for (float x : v)
+			if (!std::isfinite(x))
+				return bad("camera parameters must be finite (only far may be infinite)");
+		if (std::isnan(k.far_t))
+			return bad("camera parameters must be finite (only far may be infinite)");
+	}
 	if (d->camera.kind == PRGPU_CAMERA_FISHEYE && (d->camera.fisheye_map > PRGPU_FISHEYE_FULL || !(d->camera.fov > 0.0f) || !std::isfinite(d->camera.fov)))
 		return bad("fisheye camera: fov must be positive and finite, map one of PRGPU_FISHEYE_*");
 	if (d->camera.kind == PRGPU_CAMERA_SPHERICAL

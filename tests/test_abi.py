@@ -133,6 +133,9 @@ def test_error_reporting_without_a_gpu():
     sc = scene.cornell_box(8, 8, spp=1)
     sc.desc.camera.transform[7] = float("nan")  # every camera ray would start at a NaN
     assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"camera" in lib.prgpu_last_error()
+    sc = scene.cornell_box(8, 8, spp=1)
+    sc.desc.camera.aperture_radius = float("nan")
+    assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"camera" in lib.prgpu_last_error()
     assert lib.prgpu_rgb_to_coeffs(None, None) == -1
     bad = (C.c_float * 3)(float("nan"), 0, 0)
     assert lib.prgpu_rgb_to_coeffs(bad, (C.c_float * 3)()) == -1
