@@ -135,7 +135,7 @@ def pmc_traffic(kernel_signature):
     return None, None, reason or "no profiles/r*_pmc_summary.json"
 
 
-def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u"):
+def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u", owned_fraction=1.0, pmc_workload=True):
     """Roofline of the dominant kernel, measured live on this rank: HIP events on the launch stream around every launch
     (pass 1), node/triangle record counters of the instrumented kernel variant (pass 2; same pixels, statistically identical
     iterations).  Algorithmic bytes = rays x (32 B ray + 16 B result) + 64 B x inner + 128 B x leaf BVH records fetched."""
@@ -172,12 +172,20 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u"):
     t_iter, src, why_not = pmc_traffic(substr)
     if t_iter is not None and not persistent:
         t_iter, why_not = None, "lockstep summaries are per launch of one path depth"
-    traffic_bytes = t_iter * iters_per_launch if t_iter is not None else None
+    if t_iter is not None and not pmc_workload:
+        t_iter, why_not = None, "the committed PMC summary is of the full-size workload, this run is not"
+    # The PMC summary is of the FULL frame.  A rank of an N-GPU job renders `owned_fraction` of the pixels, so its launch moves about
+    # that fraction of the bytes (the tiles are dealt round-robin along the Z-order curve: every rank sees the same mix of the image);
+    # quoting the full-frame bytes against a share's launch time gave a figure above the chip's peak (round 4 review).
+    traffic_bytes = t_iter * iters_per_launch * owned_fraction if t_iter is not None else None
     records = d["nodes_closest"] + d["leaves_closest"] + d["nodes_any"] + d["leaves_any"]
+    kinfo = ctx.pipelineInfo()
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1) if traffic_bytes else None,
             "traffic_bytes_per_launch": traffic_bytes, "traffic_source": src, "traffic_unavailable": why_not, "pmc": dict(PMC_EXTRA) if traffic_bytes else None,
-            "kernel": kernel, "avg_launch_ms": round(avg_ms, 4),
+            "traffic_scaled_to_owned_fraction": round(owned_fraction, 6) if (traffic_bytes and owned_fraction != 1.0) else None,
+            "kernel": kernel, "kernel_organisation": kinfo["kernel"], "shader_waves": kinfo["shader_waves"], "shading_share": round(kinfo["shading_share"], 4),
+            "grid": [kinfo["blocks"], kinfo["slots_per_block"]], "avg_launch_ms": round(avg_ms, 4),
             "launches": n, "iterations_per_launch": iters_per_launch, "algorithmic_bytes_per_launch": round(alg_bytes),
             "algorithmic_bytes_per_closest_ray": round(bytes_closest / max(d["rays_closest"], 1), 1),
             "algorithmic_bytes_per_occlusion_ray": round(bytes_any / max(d["rays_any"], 1), 1),
@@ -326,6 +334,26 @@ def main():
         else:
             distributed.reduce_framebuffer(xyz, smp)
 
+    def reduce_alone_ms():
+        """The collective alone, once more on the finished frame (a frame may be reduced again: prgpu.h), so that a SCALE line separates
+        render time, imbalance and the reduce: device time between HIP events around the RCCL group (kernel family "reduce"), or the
+        host's clock around the torch.distributed fallback (which sums in place: only called when its frame is not read afterwards)."""
+        if world == 1:
+            return 0.0
+        if comm is not None:
+            ctx.setTiming(True)
+            ms0 = ctx.kernelTime("reduce")[0]
+            ctx.reduce(comm, root=0)
+            ctx.waitForFinish()
+            ms = ctx.kernelTime("reduce")[0] - ms0
+            ctx.setTiming(False)
+            return ms
+        barrier()
+        t = time.perf_counter()
+        distributed.reduce_framebuffer(torch.zeros_like(xyz), torch.zeros_like(smp))
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) * 1e3
+
     if world > 1:  # warm the collective up while the frame is still all zeros (communicator channels, buffer registration)
         reduce_frame()
     ctx.render(args.warmup)
@@ -345,6 +373,9 @@ def main():
     samples = distributed.sum_scalar(after["pixel_samples"] - before["pixel_samples"], device=dev)
     rays = distributed.sum_scalar(sum(after[k] - before[k] for k in ("primary_rays", "bounce_rays", "shadow_rays")), device=dev)
     depth = distributed.sum_scalar(after["camera_depth"] - before["camera_depth"], device=dev)
+    own_samples = after["pixel_samples"] - before["pixel_samples"]
+    reduce_ms = distributed.max_scalar(reduce_alone_ms(), device=dev)
+    rccl_ranks, rccl_rank = comm.query() if comm is not None else (None, None)   # what the communicator itself says (rank 0 = the root)
 
     out = {
         "metric": "Msamples/s", "value": round(samples / dt / 1e6, 3), "unit": "Msamples/s", "n_gpus": world,
@@ -357,6 +388,11 @@ def main():
                    "rank_render_ms_per_step": {"min": round(min(render_ms), 4), "max": round(max(render_ms), 4), "slowest_rank": int(np.argmax(render_ms)),
                                                "all": [round(x, 4) for x in render_ms]},
                    "collective": "none (one rank)" if world == 1 else ("prgpu_reduce (RCCL from libprgpu)" if comm is not None else "torch.distributed.reduce"),
+                   # ncclCommCount / ncclCommUserRank of the communicator the reduce ran on, read on the root: null when no RCCL communicator exists
+                   # (one rank, or the host-staged rehearsal)
+                   "rccl_ranks": rccl_ranks if (comm is not None and world > 1) else None, "rccl_rank_of_root": rccl_rank if (comm is not None and world > 1) else None,
+                   "reduce_ms": round(reduce_ms, 4),   # the collective alone (max over ranks), repeated on the finished frame after the timed region
+                   "reduce_ms_in_timed_region": round((dt - max(x * args.steps * 1e-3 for x in render_ms)) * 1e3, 4),   # wall time after the slowest rank's render
                    "mrays_per_s": round(rays / dt / 1e6, 2), "mean_path_depth": round(depth / max(samples, 1), 3),
                    "scene_create_s": round(t_create, 3)},
     }
@@ -372,7 +408,8 @@ def main():
         out["frame_check"] = {"xyz_equal": bool(np.array_equal(gxyz, rxyz)), "samples_equal": bool(np.array_equal(gsmp, rsmp))}
         ref.close()
     if not args.profile_only:
-        out["roofline"] = roofline(ctx, rank, variant=variant)
+        out["roofline"] = roofline(ctx, rank, variant=variant, owned_fraction=own_samples / float(args.steps * width * height),
+                                   pmc_workload=(width, height) == (W, H) and (args.workload == "c5" or args.triangles == NTRI))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, what=what)
         if rank != 0:

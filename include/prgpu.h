@@ -48,7 +48,8 @@
 extern "C" {
 #endif
 
-#define PRGPU_API_VERSION 8
+#define PRGPU_API_VERSION 8 /* layout version of the structs below (prgpu_scene_desc::api_version); entry points added since keep it: round 5 added
+                               prgpu_pipeline_info_get, prgpu_comm_query, prgpu_reduced_planes */
 #define PRGPU_INVALID_ID 0xFFFFFFFFu /* PR_INVALID_ID, src/base/config/Constants.inl:6 */
 
 enum {
@@ -370,7 +371,12 @@ int  prgpu_bind_framebuffer(prgpu_scene* s, void* d_xyz, void* d_samples, void* 
 /* Render iterations [iter_begin, iter_end): one camera sample per owned pixel per iteration, and
  * the per-iteration running mean out = (out*(i-1) + iter)/i of FrameOutputDevice::onEndOfIteration.
  * Iterations must be rendered in order starting at 0 (pixel RNG streams are sequential).
- * Asynchronous w.r.t. the host; prgpu_sync / prgpu_download / prgpu_stats synchronise. */
+ * Asynchronous w.r.t. the host; prgpu_sync / prgpu_download / prgpu_stats synchronise -- with ONE exception per scene object: the
+ * persistent pipeline measures the share of shading in the wave time of a scene's first launch (at most 8 iterations, the instrumented
+ * variant of its kernel; its diagnostic counters are kept out of prgpu_trace_counters_get unless instrumentation is on) and the render
+ * call that issues the SECOND launch waits for the first and reads three timers back before it goes on (prgpu_pipeline_info_get reports
+ * what was chosen).  A host that wants no wait inside its own timed region renders a warm-up of >= 1 iteration first, or fixes the
+ * choice with PRGPU_PP_SHADER=0|1|2. */
 int  prgpu_render(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end);
 int  prgpu_sync(prgpu_scene* s);
 
@@ -380,6 +386,18 @@ int  prgpu_download(prgpu_scene* s, float* xyz, uint32_t* samples, uint32_t* fee
 int  prgpu_stats(prgpu_scene* s, uint64_t out[PRGPU_STAT_COUNT]);
 int  prgpu_film_size(prgpu_scene* s, uint32_t* width, uint32_t* height); /* RenderSettings::filmWidth / filmHeight of the scene */
 int  prgpu_trace_counters_get(prgpu_scene* s, prgpu_trace_counters* out);
+/* How the persistent pipeline runs this scene (scheduling only: no value of a frame depends on any of it). */
+enum { PRGPU_KERNEL_NONE = 0, PRGPU_KERNEL_THROUGHPUT = 1, PRGPU_KERNEL_LATENCY = 2 };
+typedef struct prgpu_pipeline_info {
+	uint32_t mode;                 /* 0 lockstep, 1 streaming, 2 persistent */
+	int32_t  shader_waves;         /* dedicated shading waves per block of the throughput kernel; -1: not decided yet (before the calibration launch) */
+	float    shading_share;        /* share of shading passes in the calibration launch's wave time that decided it */
+	uint32_t calibration_launches; /* instrumented launches spent on that measurement (0 when the knob or the tile share fixes the choice) */
+	uint32_t kernel;               /* PRGPU_KERNEL_* of the last launch: the block-queue throughput kernel or the wave-autonomous latency kernel */
+	uint32_t blocks, slots_per_block; /* grid of the last launch */
+	uint64_t launches;             /* persistent launches since the scene was created */
+} prgpu_pipeline_info;
+int  prgpu_pipeline_info_get(prgpu_scene* s, prgpu_pipeline_info* out);
 /* Enable/disable node+triangle counting inside the traversal kernels (slower; default off). */
 int  prgpu_set_instrumentation(prgpu_scene* s, int enabled);
 
@@ -421,15 +439,24 @@ typedef struct prgpu_comm prgpu_comm;
 int  prgpu_comm_unique_id(uint8_t id[PRGPU_COMM_ID_BYTES]);
 int  prgpu_comm_create(const uint8_t id[PRGPU_COMM_ID_BYTES], int n_ranks, int rank, int device, prgpu_comm** out);
 void prgpu_comm_destroy(prgpu_comm* comm);
-int  prgpu_comm_size(const prgpu_comm* comm);   /* n_ranks, or PRGPU_EINVAL */
+int  prgpu_comm_size(const prgpu_comm* comm);   /* n_ranks as given to prgpu_comm_create, or PRGPU_EINVAL */
+/* What the RCCL communicator ITSELF reports (ncclCommCount / ncclCommUserRank): evidence that the collective spans the ranks the host
+ * believes it does.  0 ranks / rank -1 for a one-rank communicator created without RCCL. */
+int  prgpu_comm_query(const prgpu_comm* comm, int* rccl_ranks, int* rccl_rank);
 /* Asynchronous on the scene's stream (after the render calls queued there); prgpu_sync / prgpu_download wait for it.  Every rank
  * sends its own planes (XYZ, samples, feedback and, when enabled, AOV / variance / light path expression planes), which stay untouched;
  * `root` receives the sums in planes of their own, and its prgpu_download* calls read THOSE until its next prgpu_render call (a
  * framebuffer bound with prgpu_bind_framebuffer keeps the rank's own pixels).  So a frame may be reduced again after more iterations
  * -- every K iterations for a preview (the reference's periodic image dumps, src/client/ImageUpdateObserver.cpp:41-60): a reduce at 4
  * and at 8 iterations leaves what one reduce at 8 leaves.  A collective: every rank of the communicator must make the same calls in
- * the same order; it fails before anything is enqueued or not at all. */
+ * the same order.  Argument and allocation errors are reported before anything is enqueued; an RCCL call that fails inside the group is
+ * reported after the group has been closed (never left open).  With prgpu_set_timing the reduce is the kernel family "reduce". */
 int  prgpu_reduce(prgpu_scene* s, prgpu_comm* comm, int root);
+/* DEVICE pointers of the root-side planes the last prgpu_reduce summed into (W*H*3 fp32, W*H u32, W*H u32), for a host that reads its
+ * frame on the device: a framebuffer bound with prgpu_bind_framebuffer holds only the rank's OWN pixels after a reduce.  Returns 1 and
+ * the pointers while they are current (a reduce through RCCL happened on this rank as root and no render call since), else 0 and NULLs
+ * -- then the rank's own planes are the frame.  Valid until the next prgpu_render / prgpu_scene_destroy. */
+int  prgpu_reduced_planes(prgpu_scene* s, void** d_xyz, void** d_samples, void** d_feedback);
 
 /* -- shading-point AOVs and image files ------------------------------------------------------
  * LocalFrameOutputDevice::commitShadingPoints (src/loader/output/LocalFrameOutputDevice.cpp:252-283): every camera sample whose

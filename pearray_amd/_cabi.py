@@ -148,6 +148,11 @@ def default_settings(width, height):
 
 
 # Entry points declared by include/prgpu.h: name -> (restype, argtypes)
+class PipelineInfo(C.Structure):  # prgpu_pipeline_info
+    _fields_ = [("mode", C.c_uint32), ("shader_waves", C.c_int32), ("shading_share", C.c_float), ("calibration_launches", C.c_uint32),
+                ("kernel", C.c_uint32), ("blocks", C.c_uint32), ("slots_per_block", C.c_uint32), ("launches", C.c_uint64)]
+
+
 class SkyParams(C.Structure):  # prgpu_sky_params
     _fields_ = [("sun_elevation", C.c_float), ("sun_azimuth", C.c_float), ("turbidity", C.c_float), ("albedo", C.c_float * 11)]
 
@@ -179,6 +184,9 @@ SYMBOLS = {
     "prgpu_comm_create": (C.c_int, [_U8P, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
     "prgpu_comm_destroy": (None, [_VP]),
     "prgpu_comm_size": (C.c_int, [_VP]),
+    "prgpu_comm_query": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "prgpu_reduced_planes": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
+    "prgpu_pipeline_info_get": (C.c_int, [_VP, C.POINTER(PipelineInfo)]),
     "prgpu_reduce": (C.c_int, [_VP, _VP, C.c_int]),
     "prgpu_film_size": (C.c_int, [_VP, _U32P, _U32P]),
     "prgpu_enable_variance": (C.c_int, [_VP]),

@@ -59,8 +59,26 @@ class RenderContext:
                                                   C.c_void_p(feedback_ptr) if feedback_ptr else None))
 
     def reduce(self, comm, root=0):
-        """Sum this rank's frame onto `root` (RCCL over xGMI); asynchronous on the scene's stream."""
+        """Sum every rank's frame into planes the library keeps on `root` (RCCL over xGMI); asynchronous on the scene's stream.  The
+        rank's own planes -- and a framebuffer bound with bindFramebuffer -- keep the rank's OWN pixels: on the root output() /
+        outputAOV() / ... read the sums until the next render call, and reducedPlanes() hands out their device pointers."""
         abi.check(self.lib.prgpu_reduce(self._h, comm._h, int(root)))
+
+    def reducedPlanes(self):
+        """Device pointers (xyz, samples, feedback) of the root-side sums of the last reduce, or None when the rank's own planes are the frame."""
+        x, s, f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rc = self.lib.prgpu_reduced_planes(self._h, C.byref(x), C.byref(s), C.byref(f))
+        if rc < 0:
+            abi.check(rc)
+        return (x.value, s.value, f.value) if rc == 1 else None
+
+    def pipelineInfo(self):
+        """How the persistent pipeline runs this scene (prgpu_pipeline_info): scheduling facts only."""
+        info = abi.PipelineInfo()
+        abi.check(self.lib.prgpu_pipeline_info_get(self._h, C.byref(info)))
+        out = {f: getattr(info, f) for f, _ in info._fields_}
+        out["kernel"] = {0: "none", 1: "throughput", 2: "latency"}.get(out["kernel"], str(out["kernel"]))
+        return out
 
     def setInstrumentation(self, on):
         abi.check(self.lib.prgpu_set_instrumentation(self._h, 1 if on else 0))
@@ -230,6 +248,12 @@ class Communicator:
     @property
     def size(self):
         return self.lib.prgpu_comm_size(self._h)
+
+    def query(self):
+        """(ranks, rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank); (0, -1) without RCCL."""
+        n, r = C.c_int(), C.c_int()
+        abi.check(self.lib.prgpu_comm_query(self._h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
 
     def close(self):
         if self._h:

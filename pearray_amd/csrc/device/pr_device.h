@@ -761,11 +761,19 @@ struct RayPre {
 	float eps_t; // absolute slack of the slab test, see box_hit
 };
 // A NaN in a ray's origin (a degenerate normal upstream: safe_position of a NaN normal) makes every slab distance NaN, and the conservative
-// min / max of the box test drop NaNs: such a ray would walk the WHOLE tree to find nothing (no triangle test passes with a NaN origin;
-// 12 ms per wave in the 1 M-triangle scene).  Moved out of the world it misses the root's children instead -- the same miss.  Applied where a
-// ray is BORN (the shading pass that writes it, the ray service's load), not in ray_prepare: three more live values there cost the path
-// kernel's stepping loop 1.4 % (profiles/r04_nan_origin_ab.log).  A NaN direction needs nothing: its reciprocal is clamped in ray_prepare.
-__device__ __forceinline__ V3 sane_origin(V3 o) { return v3(o.x == o.x ? o.x : 3.0e38f, o.y == o.y ? o.y : 3.0e38f, o.z == o.z ? o.z : 3.0e38f); }
+// min / max of the box test drop NaNs; an infinite one makes them +-inf, and `inf <= inf * F + eps` passes: either ray would walk the WHOLE
+// tree to find nothing (no triangle test passes with such an origin; 12 ms per wave in the 1 M-triangle scene).  The ray is therefore ENDED
+// where it is born (the shading pass that writes it, the ray service's load): its extent becomes -inf, so the exit distance of every
+// box is -inf, no child of the root passes and the result is the same miss.  (Round 4 moved the origin to 3e38 instead, which still
+// overflowed (q0 - o) * inv_d to +inf for negative directions and walked the tree after all.)  Not in ray_prepare: three more live
+// values there cost the path kernel's stepping loop 1.4 % (profiles/r04_nan_origin_ab.log).  A NaN direction needs nothing: its
+// reciprocal is clamped in ray_prepare.
+__device__ __forceinline__ V3 sane_ray(V3 o, float& tmax)
+{
+	const bool ok = fabsf(o.x) <= 3.0e38f && fabsf(o.y) <= 3.0e38f && fabsf(o.z) <= 3.0e38f; // false for NaN and +-inf
+	tmax		  = ok ? tmax : -INFINITY;
+	return ok ? o : v3(0.0f, 0.0f, 0.0f);
+}
 __device__ __forceinline__ RayPre ray_prepare(V3 o, V3 d, float eps_t)
 {
 	RayPre r;

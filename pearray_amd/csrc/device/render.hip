@@ -128,7 +128,8 @@ template <typename STK>
 __device__ __forceinline__ void trav_begin(Trav& s, STK& st, V3 o, V3 d, float tmin, float tmax, float eps_t)
 {
 	s.r	   = ray_prepare(o, d, eps_t);
-	s.tmin = tmin;
+	s.tmin = tmin + 0.0f; // -0.0 -> +0.0: the children's sort keys and the stack re-check compare entry distances as integers (valid for +0 and above;
+						  // negative starts are refused: prgpu_trace_*, validate_desc for the camera's near distance)
 	s.best = Hit{ tmax, 0.0f, 0.0f, INVALID };
 	s.cur  = 0u; // root
 	s.any  = false;
@@ -339,7 +340,8 @@ __device__ __forceinline__ void trace_persistent(const DevScene& sc, uint32_t n_
 						V3 o, d;
 						float tmin, tmax;
 						load(i, o, d, tmin, tmax);
-						trav_begin(s, st, sane_origin(o), d, tmin, tmax, sc.eps_t); // (rays of the ray service are the caller's)
+						const V3 so = sane_ray(o, tmax); // (rays of the ray service are the caller's)
+						trav_begin(s, st, so, d, tmin, tmax, sc.eps_t);
 						if (sc.n_quadrics) // (wavefront pipelines and the ray service: a run-time test; the path kernel compiles it per variant)
 							trav_quadrics<false>(sc, s, ANY);
 						my_ray	= i;
@@ -1827,7 +1829,8 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 							mis = hf / (wvl_pdf * bsum(hf));
 						}
 						const V3 oN = dot(L, N) < 0 ? -N : N;
-						const V3 so = sane_origin(safe_position(P, L, oN));
+						float sh_far = INFINITY; // distance = PR_INF (direct.cpp:329)
+						const V3 so	 = sane_ray(safe_position(P, L, oN), sh_far);
 						float xyz_vis[3];
 						const float xyz_occ[3] = { 0.0f, 0.0f, 0.0f };
 						const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, cie, blend, xyz_vis);
@@ -1837,7 +1840,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 							atomicAdd(&bs.v[PRGPU_STAT_SHADOW_RAYS], 1u);
 							want_shadow = true;
 							sh_o		= make_float4(so.x, so.y, so.z, SHADOW_RAY_MIN);
-							sh_d		= make_float4(L.x, L.y, L.z, INFINITY); // distance = PR_INF (direct.cpp:329)
+							sh_d		= make_float4(L.x, L.y, L.z, sh_far);
 							const uint32_t m_nee = with_lpe ? lpe_accepting(ps.lpe, lpe_step(ps.lpe, lpe_step(ps.lpe, lpe, scatter_symbol(mat, Vt, Lt)), LPE_SYM_BACKGROUND)) : 0u; // direct.cpp:338-342
 							sh_xyz		= make_float4(xyz_vis[0], xyz_vis[1], xyz_vis[2], __uint_as_float(fb_vis | (fb_occ << 8) | (m_nee << 16)));
 						} else {
@@ -1927,9 +1930,9 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					} else {
 						mis = hf / (wvl_pdf * bsum(hf));
 					}
-					const float distance = sqrtf(sqrD);
-					const V3 oN			 = dot(L, N) < 0 ? -N : N;
-					const V3 so			 = sane_origin(safe_position(P, L, oN));
+					float distance = sqrtf(sqrD);
+					const V3 oN	   = dot(L, N) < 0 ? -N : N;
+					const V3 so	   = sane_ray(safe_position(P, L, oN), distance); // (an origin that is not finite ends the ray: pr_device.h)
 					float xyz_vis[3];
 					const float xyz_occ[3] = { 0.0f, 0.0f, 0.0f };
 					const uint32_t fb_vis = fragment_value(sc, mis, throughput, grp_imp, connectionW / lightPdfS2.v[0], mono, cie, blend, xyz_vis);
@@ -2034,12 +2037,13 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 				}
 				if (cont) {
 					const V3 oN		 = dot(L, N) < 0 ? -N : N;
-					const V3 no		 = sane_origin(safe_position(P, L, oN)); // (pr_device.h: a NaN origin must not reach the traversal)
+					float far_t		 = INFINITY;
+					const V3 no		 = sane_ray(safe_position(P, L, oN), far_t); // (pr_device.h: an origin that is not finite must not reach the traversal)
 					const uint32_t nd = depth + 1;
 					if (nd < cfg.max_ray_depth) {
 						alive				= true;
 						ps.ray_o[slot]		= make_float4(no.x, no.y, no.z, BOUNCE_RAY_MIN);
-						ps.ray_d[slot]		= make_float4(L.x, L.y, L.z, INFINITY);
+						ps.ray_d[slot]		= make_float4(L.x, L.y, L.z, far_t);
 						ps.throughput[slot] = to4(throughput);
 						ps.path_pdf[slot]	= to4(path_pdf);
 						ps.prev_pdf[slot]	= to4(prev_pdf);
@@ -2640,7 +2644,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					const bool pany		 = has_ray && (my_entry & PP_ANY) != 0;
 					const float4 ro = pany ? ps.sh_o[pslot] : ps.ray_o[pslot], rd = pany ? ps.sh_d[pslot] : ps.ray_d[pslot];
 					s.r	   = ray_prepare(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), sc.eps_t);
-					s.tmin = ro.w;
+					s.tmin = ro.w + 0.0f; // (as trav_begin)
 					s.any  = pany;
 				}
 #if PR_SHADE_PRIO
@@ -3101,10 +3105,12 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene s
 					const uint32_t i = base + __popcll(idle & ((1ull << lane) - 1ull));
 					if (i < n) {
 						const V3 o = v3(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-						trav_begin(s, st, sane_origin(o), d, tmin_a[i], tmax_a[i], sc.eps_t);
-						sh.rc[0][tid] = make_float4(o.x, o.y, o.z, __uint_as_float((uint32_t)s.r.kx | ((uint32_t)s.r.ky << 2) | ((uint32_t)s.r.kz << 4)));
+						float tmax_i = tmax_a[i];
+						const V3 so = sane_ray(o, tmax_i);
+						trav_begin(s, st, so, d, tmin_a[i], tmax_i, sc.eps_t);
+						sh.rc[0][tid] = make_float4(so.x, so.y, so.z, __uint_as_float((uint32_t)s.r.kx | ((uint32_t)s.r.ky << 2) | ((uint32_t)s.r.kz << 4)));
 						sh.rc[1][tid] = make_float4(s.r.Sx, s.r.Sy, s.r.Sz, s.tmin);
-						__hip_atomic_store(&sh.best[tid], ((unsigned long long)__float_as_uint(tmax_a[i]) << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						__hip_atomic_store(&sh.best[tid], ((unsigned long long)__float_as_uint(tmax_i) << 32) | 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 						my_ray	= i;
 						has_ray = true;
 					}

@@ -1140,6 +1140,10 @@ int validate_desc(const prgpu_scene_desc* d, std::string& err)
 				return bad("camera parameters must be finite (only far may be infinite)");
 		if (std::isnan(k.far_t))
 			return bad("camera parameters must be finite (only far may be infinite)");
+		// the primary rays start at `near` (perspective.cpp:54-55): the traversal orders and re-checks entry distances by their bit pattern,
+		// which needs them >= +0 (render.hip, trav_pop) -- a negative start (or -0.0) would silently drop pushed siblings
+		if (k.near_t < 0.0f || std::signbit(k.near_t))
+			return bad("camera: near must not be negative");
 	}
 	if (d->camera.kind == PRGPU_CAMERA_FISHEYE && (d->camera.fisheye_map > PRGPU_FISHEYE_FULL || !(d->camera.fov > 0.0f) || !std::isfinite(d->camera.fov)))
 		return bad("fisheye camera: fov must be positive and finite, map one of PRGPU_FISHEYE_*");

@@ -64,6 +64,7 @@ struct Knobs {
 	uint32_t force_features	   = 0;		  // PRGPU_FORCE_FEATURES: run a scene with a larger kernel variant than it needs (measurement aid)
 	bool debug_counters		   = false;	  // PRGPU_DEBUG_COUNTERS: print the instrumented kernel's time split
 	const char* dump_block_life = nullptr; // PRGPU_DUMP_BLOCK_LIFE=<file>: per-block lifetimes of the last instrumented launch
+	int trace_ranges		   = -1;	  // PRGPU_TRACE_RANGES=1: load the roctx library for the named ranges even when no profiler brought it along; 0: never emit ranges
 };
 Knobs read_knobs()
 {
@@ -99,6 +100,7 @@ Knobs read_knobs()
 		k.force_features = (uint32_t)strtoul(env, nullptr, 0);
 	k.debug_counters  = getenv("PRGPU_DEBUG_COUNTERS") != nullptr;
 	k.dump_block_life = getenv("PRGPU_DUMP_BLOCK_LIFE");
+	k.trace_ranges	  = (int)num("PRGPU_TRACE_RANGES", -1, -1, 1);
 	return k;
 }
 
@@ -112,14 +114,28 @@ struct TraceRange {
 	static PopFn& pop_fn() { static PopFn f = nullptr; return f; }
 	static bool bind()
 	{
+		// Only when a profiler is already in the process (rocprofv3 preloads the roctx library: RTLD_NOLOAD finds it without loading
+		// anything), or when PRGPU_TRACE_RANGES=1 asks for it: a production host does not get the roctx / rocprofiler-register stack
+		// pulled into it for a diagnostics feature.  RTLD_LOCAL; a candidate that lacks the two symbols is closed again.
 		static const bool bound = [] {
-			for (const char* name : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" })
-				if (void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
-					push_fn() = reinterpret_cast<PushFn>(dlsym(lib, "roctxRangePushA"));
-					pop_fn()  = reinterpret_cast<PopFn>(dlsym(lib, "roctxRangePop"));
-					if (push_fn() && pop_fn())
-						return true;
-				}
+			const int knob	 = read_knobs().trace_ranges;
+			const bool force = knob == 1;
+			if (knob == 0)
+				return false;
+			for (const char* name : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" }) {
+				void* lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+				if (!lib && force)
+					lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+				if (!lib)
+					continue;
+				push_fn() = reinterpret_cast<PushFn>(dlsym(lib, "roctxRangePushA"));
+				pop_fn()  = reinterpret_cast<PopFn>(dlsym(lib, "roctxRangePop"));
+				if (push_fn() && pop_fn())
+					return true;
+				push_fn() = nullptr;
+				pop_fn()  = nullptr;
+				dlclose(lib);
+			}
 			return false;
 		}();
 		return bound;
@@ -135,8 +151,8 @@ struct TimedLaunch {
 	hipEvent_t start, stop;
 	int family;
 };
-const char* const FAMILY_NAMES[] = { "raygen", "trace_closest", "shade", "trace_any", "resolve", "sort", "path" };
-constexpr int N_FAMILIES		 = 7;
+const char* const FAMILY_NAMES[] = { "raygen", "trace_closest", "shade", "trace_any", "resolve", "sort", "path", "reduce" };
+constexpr int N_FAMILIES		 = 8;
 
 } // namespace
 
@@ -152,6 +168,9 @@ struct prgpu_scene {
 	int pp_shader_waves = -1; // persistent kernel: dedicated shading waves per block, decided after the first launch (-1: not yet)
 	double pp_shading_share = 0.0; // ... from this measured share of shading passes in the wave time
 	uint64_t pp_launches = 0;
+	int pp_calibration_tries = 0; // calibration launches so far (a launch whose timers read zero does not decide anything: try again, three times at most)
+	unsigned long long *gstats_before = nullptr, *gstats_after = nullptr; // the calibration launch's counters: copies of gstats taken on the stream around it
+	uint32_t pp_last_blocks = 0, pp_last_slots = 0, pp_last_kernel = 0; // grid and organisation (PRGPU_KERNEL_*) of the last persistent launch (prgpu_pipeline_info_get)
 	// frame planes owned by the library (may be replaced by prgpu_bind_framebuffer)
 	float* own_xyz = nullptr;
 	uint32_t *own_samples = nullptr, *own_feedback = nullptr;
@@ -601,6 +620,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(s->pp_next, 1, true);
 	AL(s->pp_error, 1, true);
 	AL(s->gstats, prd::N_DEVICE_COUNTERS, true);
+	AL(s->gstats_before, prd::N_DEVICE_COUNTERS, true);
+	AL(s->gstats_after, prd::N_DEVICE_COUNTERS, true);
 	{ // persistent traversal grid: a few blocks of 256 threads per CU (32 KB of LDS stack each)
 		hipDeviceProp_t prop;
 		HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -952,17 +973,21 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	// of the kernel (same results; it times its shading passes), and later launches use round(4 * share) shading waves, at most two.
 	// (Two clock reads per pass in the plain kernel were measured instead: 4 % slower on C4 -- the timers' scalar registers spill.)
 	const bool calibrating = s->knobs.pp.shader_wave < 0 && !all_in_flight;
-	auto decide = [&]() -> int { // after the calibration launch: read its timers, once
-		if (!calibrating || s->pp_shader_waves >= 0 || s->pp_launches == 0)
+	auto decide = [&]() -> int { // after a calibration launch: read its timers (the launch's own: copies of the counters taken around it)
+		if (!calibrating || s->pp_shader_waves >= 0 || s->pp_calibration_tries == 0)
 			return PRGPU_OK;
-		HIP_TRY(hipStreamSynchronize(s->stream));
-		unsigned long long t[3] = { 0, 0, 0 }; // shading, idle, alive
-		HIP_TRY(hipMemcpy(t, s->gstats + prd::shade_ticks_counter(), sizeof(t), hipMemcpyDeviceToHost));
-		const double share	= t[2] > 0 ? double(t[0]) / double(t[2]) : 0.0;
+		HIP_TRY(hipStreamSynchronize(s->stream)); // (the one host synchronisation inside prgpu_render, once per scene: include/prgpu.h)
+		unsigned long long t0[3] = { 0, 0, 0 }, t1[3] = { 0, 0, 0 }; // shading, idle, alive
+		HIP_TRY(hipMemcpy(t0, s->gstats_before + prd::shade_ticks_counter(), sizeof(t0), hipMemcpyDeviceToHost));
+		HIP_TRY(hipMemcpy(t1, s->gstats_after + prd::shade_ticks_counter(), sizeof(t1), hipMemcpyDeviceToHost));
+		const unsigned long long shading = t1[0] - t0[0], alive = t1[2] - t0[2];
+		if (alive == 0ull && s->pp_calibration_tries < 3) // a launch too small to time anything decides nothing: the next one calibrates again
+			return PRGPU_OK;
+		const double share	= alive > 0ull ? double(shading) / double(alive) : 0.0;
 		s->pp_shader_waves	= share >= 0.22 ? (share >= 0.45 ? 2 : 1) : 0;
 		s->pp_shading_share = share;
 		if (s->knobs.debug_counters)
-			fprintf(stderr, "[prgpu] shading passes took %.1f %% of the first launch's wave time: %d dedicated shading wave(s) per block from now on\n", 100.0 * share, s->pp_shader_waves);
+			fprintf(stderr, "[prgpu] shading passes took %.1f %% of the calibration launch's wave time: %d dedicated shading wave(s) per block from now on\n", 100.0 * share, s->pp_shader_waves);
 		return PRGPU_OK;
 	};
 	if (!all_in_flight)
@@ -980,11 +1005,25 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 		const uint32_t e	   = (uint32_t)std::min<uint64_t>(iter_end, uint64_t(b) + (calibration ? std::min(chunk, 8u) : chunk));
 		const int shader_wave  = s->knobs.pp.shader_wave >= 0 ? s->knobs.pp.shader_wave : (all_in_flight ? 1 : std::max(0, s->pp_shader_waves));
 		ps.iter_base = b;
+		const size_t gbytes = sizeof(unsigned long long) * prd::N_DEVICE_COUNTERS;
+		if (calibration) // the launch's counters = a copy of them after it minus a copy before it, both taken on the stream
+			HIP_TRY(hipMemcpyAsync(s->gstats_before, s->gstats, gbytes, hipMemcpyDeviceToDevice, s->stream));
 		s->time_begin(6, s->stream);
 		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument || calibration, s->ws_pp, s->knobs.pp, shader_wave, s->pp_next, s->pp_error, s->gstats, s->stream);
 		s->time_end(s->stream);
 		HIP_TRY(hipGetLastError());
+		if (calibration) {
+			HIP_TRY(hipMemcpyAsync(s->gstats_after, s->gstats, gbytes, hipMemcpyDeviceToDevice, s->stream));
+			if (!s->instrument) // the user did not ask for the instrumented variant: its diagnostic counters (everything after the 11 statistics) go back to what they were
+				HIP_TRY(hipMemcpyAsync(s->gstats + PRGPU_STAT_COUNT, s->gstats_before + PRGPU_STAT_COUNT, gbytes - sizeof(unsigned long long) * PRGPU_STAT_COUNT, hipMemcpyDeviceToDevice, s->stream));
+			++s->pp_calibration_tries;
+		}
 		++s->pp_launches;
+		{
+			const prd::PersistentGeometry g = prd::persistent_geometry(s->n_slots, s->ws_pp.max_blocks, s->knobs.pp.slots);
+			s->pp_last_blocks = g.n_blocks;
+			s->pp_last_slots  = g.slots_per_block;
+		}
 		if (ring) { // filter taps + running mean, iteration by iteration in order (FrameOutputDevice.cpp:202-221)
 			prd::PathState pr = s->ps;
 			for (uint32_t i = b; i < e; ++i) {
@@ -1132,27 +1171,7 @@ int prgpu_device_count(void)
 	return n;
 }
 
-void prgpu_settings_default(prgpu_settings* s)
-{
-	std::memset(s, 0, sizeof(*s));
-	s->width = 1920; // RenderSettings.cpp:25-26
-	s->height = 1080;
-	s->seed = 42;
-	s->aa_sampler = PRGPU_SAMPLER_SOBOL; // SamplerManager.cpp:16-43
-	s->aa_samples = 128;
-	s->lens_samples = s->time_samples = s->spectral_samples = 1;
-	s->mapper = PRGPU_MAPPER_SPD_CMIS; // SpectralMapperManager.cpp:29-33
-	s->filter = PRGPU_FILTER_MITCHELL; // FilterManager.cpp:16,36
-	s->filter_radius = 1;
-	s->max_ray_depth = 64; // direct.cpp:34-39
-	s->soft_max_ray_depth = 4;
-	s->mis = PRGPU_MIS_BALANCE;
-	s->nee = s->direct = s->emissive_scatter = 1;
-	s->spectral_start = 390.0f;
-	s->spectral_end = 830.0f;
-	s->spectral_hero = 1;
-	s->spectral_mono = 0;
-}
+// (prgpu_settings_default lives in host/settings.cpp: plain C++, shared with the host-side sanitizer build)
 
 int prgpu_rgb_to_coeffs(const float rgb[3], float coeffs[3])
 {
@@ -1557,6 +1576,8 @@ struct Rccl {
 	nccl_result_t (*GroupEnd)()												= nullptr;
 	nccl_result_t (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
 	const char* (*GetErrorString)(nccl_result_t)							= nullptr;
+	nccl_result_t (*CommCount)(void*, int*)									= nullptr; // what the communicator itself reports (prgpu_comm_query)
+	nccl_result_t (*CommUserRank)(void*, int*)								= nullptr;
 	std::string error;
 };
 Rccl& rccl()
@@ -1586,6 +1607,8 @@ Rccl& rccl()
 	r.GroupEnd		 = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
 	r.Reduce		 = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
 	r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+	r.CommCount		 = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+	r.CommUserRank	 = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
 	if (!ok) {
 		r.error = "RCCL library lacks an expected entry point";
 		r.lib	= nullptr;
@@ -1678,6 +1701,23 @@ void prgpu_comm_destroy(prgpu_comm* c)
 
 int prgpu_comm_size(const prgpu_comm* c) { return c ? c->n_ranks : fail(PRGPU_EINVAL, "null communicator"); }
 
+int prgpu_comm_query(const prgpu_comm* c, int* rccl_ranks, int* rccl_rank)
+{
+	if (!c)
+		return fail(PRGPU_EINVAL, "null communicator");
+	int n = 0, r = -1; // a one-rank communicator without RCCL: no collective library is involved
+	if (c->nccl) {
+		Rccl& lib = rccl();
+		NCCL_TRY(lib.CommCount(c->nccl, &n));
+		NCCL_TRY(lib.CommUserRank(c->nccl, &r));
+	}
+	if (rccl_ranks)
+		*rccl_ranks = n;
+	if (rccl_rank)
+		*rccl_rank = r;
+	return PRGPU_OK;
+}
+
 int prgpu_reduce(prgpu_scene* s, prgpu_comm* c, int root)
 {
 	TraceRange trace_range("prgpu_reduce");
@@ -1721,24 +1761,73 @@ int prgpu_reduce(prgpu_scene* s, prgpu_comm* c, int root)
 	}
 	Rccl& r = rccl();
 	// one group = one fused launch: XYZ (fp32 sum), sample counts (u32 sum), feedback bits (a pixel's bits are only ever set by the
-	// rank that owns it, so MAX over the ranks is the OR of mergeLocal, FrameOutputDevice.cpp:121)
+	// rank that owns it, so MAX over the ranks is the OR of mergeLocal, FrameOutputDevice.cpp:121).  A call that fails inside the group
+	// is remembered and the group is CLOSED all the same (an open group would leave this thread's later RCCL calls queued for ever and
+	// the peers blocked in theirs); the first failure is what the caller gets.
 	NCCL_TRY(r.GroupStart());
-	NCCL_TRY(r.Reduce(s->ps.out_xyz, is_root ? R.xyz : s->ps.out_xyz, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
-	NCCL_TRY(r.Reduce(s->ps.samples, is_root ? R.samples : s->ps.samples, size_t(s->n_pixels), NCCL_UINT32, NCCL_SUM, root, c->nccl, s->stream));
-	NCCL_TRY(r.Reduce(s->ps.feedback, is_root ? R.feedback : s->ps.feedback, size_t(s->n_pixels), NCCL_UINT32, NCCL_MAX, root, c->nccl, s->stream));
+	nccl_result_t first_error = 0;
+	const char* first_what	  = nullptr;
+	auto reduce = [&](const void* src, void* dst, size_t count, int type, int op, const char* what) {
+		if (first_error != 0)
+			return;
+		const nccl_result_t rc = r.Reduce(src, dst, count, type, op, root, c->nccl, s->stream);
+		if (rc != 0) {
+			first_error = rc;
+			first_what	= what;
+		}
+	};
+	s->time_begin(7, s->stream);
+	reduce(s->ps.out_xyz, is_root ? R.xyz : s->ps.out_xyz, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, "ncclReduce(xyz)");
+	reduce(s->ps.samples, is_root ? R.samples : s->ps.samples, size_t(s->n_pixels), NCCL_UINT32, NCCL_SUM, "ncclReduce(samples)");
+	reduce(s->ps.feedback, is_root ? R.feedback : s->ps.feedback, size_t(s->n_pixels), NCCL_UINT32, NCCL_MAX, "ncclReduce(feedback)");
 	if (s->ps.online_mean) { // every pixel's estimator lives on the rank that owns the pixel, zero elsewhere (single-tap filters)
-		NCCL_TRY(r.Reduce(s->ps.online_mean, is_root ? R.online_mean : s->ps.online_mean, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
-		NCCL_TRY(r.Reduce(s->ps.online_variance, is_root ? R.online_variance : s->ps.online_variance, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+		reduce(s->ps.online_mean, is_root ? R.online_mean : s->ps.online_mean, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, "ncclReduce(online mean)");
+		reduce(s->ps.online_variance, is_root ? R.online_variance : s->ps.online_variance, size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, "ncclReduce(online variance)");
 	}
 	for (uint32_t k = 0; k < PRGPU_AOV_COUNT; ++k) // shading-point AOV sums: plain sums of the owner's samples
 		if (s->ps.aov[k])
-			NCCL_TRY(r.Reduce(s->ps.aov[k], is_root ? R.aov[k] : s->ps.aov[k], size_t(s->n_pixels) * prgpu_aov_channels(k), NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
+			reduce(s->ps.aov[k], is_root ? R.aov[k] : s->ps.aov[k], size_t(s->n_pixels) * prgpu_aov_channels(k), NCCL_FLOAT32, NCCL_SUM, "ncclReduce(aov)");
 	for (uint32_t k = 0; k < s->lpe_host.n; ++k) // light path expression planes: folded sums of the owner's matching fragments, zero elsewhere
-		NCCL_TRY(r.Reduce(s->lpe_host.out[k], is_root ? R.lpe[k] : s->lpe_host.out[k], size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, root, c->nccl, s->stream));
-	NCCL_TRY(r.GroupEnd());
+		reduce(s->lpe_host.out[k], is_root ? R.lpe[k] : s->lpe_host.out[k], size_t(s->n_pixels) * 3, NCCL_FLOAT32, NCCL_SUM, "ncclReduce(lpe)");
+	const nccl_result_t end_rc = r.GroupEnd(); // always: see above
+	s->time_end(s->stream);
+	if (first_error != 0)
+		return fail(PRGPU_EDEVICE, std::string(first_what) + " failed: " + (r.GetErrorString ? r.GetErrorString(first_error) : "?") + " (the group was closed)");
+	if (end_rc != 0)
+		return fail(PRGPU_EDEVICE, std::string("ncclGroupEnd failed: ") + (r.GetErrorString ? r.GetErrorString(end_rc) : "?"));
 	s->reduced_at = s->next_iteration; // (after the last collective was enqueued)
 	if (is_root)
 		R.valid = true;
+	return PRGPU_OK;
+}
+
+int prgpu_reduced_planes(prgpu_scene* s, void** d_xyz, void** d_samples, void** d_feedback)
+{
+	if (!s)
+		return fail(PRGPU_EINVAL, "null scene");
+	const bool v = s->reduced.valid;
+	if (d_xyz)
+		*d_xyz = v ? static_cast<void*>(s->reduced.xyz) : nullptr;
+	if (d_samples)
+		*d_samples = v ? static_cast<void*>(s->reduced.samples) : nullptr;
+	if (d_feedback)
+		*d_feedback = v ? static_cast<void*>(s->reduced.feedback) : nullptr;
+	return v ? 1 : 0;
+}
+
+int prgpu_pipeline_info_get(prgpu_scene* s, prgpu_pipeline_info* out)
+{
+	if (!s || !out)
+		return fail(PRGPU_EINVAL, "null argument");
+	std::memset(out, 0, sizeof(*out));
+	out->mode			 = s->mode == prgpu_scene::PERSISTENT ? 2u : (s->mode == prgpu_scene::STREAMING ? 1u : 0u);
+	out->shader_waves	 = s->knobs.pp.shader_wave >= 0 ? s->knobs.pp.shader_wave : s->pp_shader_waves;
+	out->shading_share	 = (float)s->pp_shading_share;
+	out->launches		 = s->pp_launches;
+	out->calibration_launches = (uint32_t)s->pp_calibration_tries;
+	out->blocks			 = s->pp_last_blocks;
+	out->slots_per_block = s->pp_last_slots;
+	out->kernel			 = s->pp_last_kernel;
 	return PRGPU_OK;
 }
 

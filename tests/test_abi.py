@@ -133,6 +133,10 @@ def test_error_reporting_without_a_gpu():
     sc = scene.cornell_box(8, 8, spp=1)
     sc.desc.camera.transform[7] = float("nan")  # every camera ray would start at a NaN
     assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"camera" in lib.prgpu_last_error()
+    for near in (-1e-3, -0.0):  # primary rays start at `near`; the traversal compares entry distances by their bit pattern (>= +0 only)
+        sc = scene.cornell_box(8, 8, spp=1)
+        sc.desc.camera.near_t = near
+        assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"near" in lib.prgpu_last_error()
     sc = scene.cornell_box(8, 8, spp=1)
     sc.desc.camera.aperture_radius = float("nan")
     assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"camera" in lib.prgpu_last_error()

@@ -377,6 +377,74 @@ def test_rays_with_nan_or_infinite_components_miss_and_do_not_walk_the_tree():
     assert dt < 0.25, dt                                                    # 64 waves, each with NaN rays: a full walk each would be ~ 0.3 s
 
 
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_rays_whose_whole_origin_is_nan_or_infinite_end_at_the_root(monkeypatch, split):
+    """Round 4 moved a NaN origin to 3e38, which still walked the tree: with a negative (or NaN, i.e. clamped to -2^80) reciprocal direction
+    (g - 3e38) * inv_d overflows to +inf, entry and exit distance of every box are +inf and `inf <= inf * F + eps` passes -- for rays whose
+    extent is infinite, which is every bounce ray.  Now such a ray is ended where it is born (extent -inf: no child of the root passes).
+    All-NaN and all-infinite origins with negative, NaN and axis-parallel directions and tmax = inf: results against the checker for the
+    closest-hit and the occlusion service, and a bound on the time (one such ray in every wave: a full walk of the 300 k-triangle tree costs
+    a wave ~ 4 ms)."""
+    import time
+    monkeypatch.setenv("PRGPU_TRACE_SPLIT", split)
+    sc = scene.cornell_soup(8, 8, spp=1, n_triangles=300_000)
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(18)
+    n = 8192
+    org = (rng.random((n, 3)) * [1.8, 1.8, 1.7] + [-0.9, -0.9, 0.1]).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    bad_o, bad_d = org.copy(), d.copy()
+    k = np.arange(n)
+    neg = -np.abs(d); neg[np.abs(neg) < 0.05] = -0.05                       # every reciprocal negative and |1 / d| > 1.13
+    bad_o[k % 16 == 1] = np.nan; bad_d[k % 16 == 1] = neg[k % 16 == 1]
+    bad_o[k % 16 == 2] = np.nan; bad_d[k % 16 == 2] = np.nan               # NaN reciprocals are clamped to -2^80
+    bad_o[k % 16 == 3] = -np.inf; bad_d[k % 16 == 3] = neg[k % 16 == 3]
+    bad_o[k % 16 == 4] = np.inf; bad_d[k % 16 == 4] = -neg[k % 16 == 4]
+    bad_o[k % 16 == 5] = [np.nan, 0.5, np.inf]; bad_d[k % 16 == 5] = [0.0, 0.0, -1.0]
+    bad_o[k % 16 == 6] = np.nan; bad_d[k % 16 == 6] = [-1.0, 0.0, 0.0]
+    clean = (k % 16 == 0) | (k % 16 >= 7)
+    g.traceRays(org, d, 1e-4, np.inf)                                       # warm-up
+    t = time.time(); a = g.traceRays(bad_o, bad_d, 1e-4, np.inf); dt = time.time() - t
+    c = o.trace_closest(bad_o, bad_d, 1e-4, np.inf)
+    assert (a[0][~clean] == abi.INVALID_ID).all() and (a[0][clean] != abi.INVALID_ID).mean() > 0.9
+    for x, y in zip(a[:2], c[:2]):
+        assert np.array_equal(x, y)
+    assert dt < 0.25, dt                                                    # 128 waves, each with such rays
+    t = time.time(); occ = g.traceShadowRays(bad_o, bad_d, 1e-4, np.inf); dt = time.time() - t
+    assert np.array_equal(occ, o.trace_any(bad_o, bad_d, 1e-4, np.inf)) and not occ[~clean].any()
+    assert dt < 0.25, dt
+
+
+def _soup_with_normals(width, height, spp, n_triangles, zero_normals):
+    b = scene.SceneBuilder(width, height)
+    b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, spp
+    mats = scene._cornell_into(b)
+    pos, faces = scene.triangle_soup(n_triangles)
+    nrm = np.zeros_like(pos) if zero_normals else np.tile(np.float32([0, 0, 1]), (len(pos), 1))
+    b.add_mesh(pos, faces, mats["backWall"], normals=nrm)
+    return b.build()
+
+
+def test_a_bounce_ray_born_from_a_degenerate_normal_ends_at_once():
+    """The path kernel's side of the same guard: a mesh whose vertex normals are all zero gives every hit on it a NaN shading normal,
+    safe_position hands the bounce ray an all-NaN origin (and a NaN direction), and its extent is infinite.  The frame must equal the
+    checker's, and such rays must not walk the tree: the same scene with sound normals bounds the time."""
+    import time
+    sc = _soup_with_normals(64, 64, 4, 20_000, True)
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    g.start(); g.waitForFinish()
+    o.render(4, threads=8)
+    assert_parity(g, o)
+    g.close()
+    times = []
+    for zero in (False, True):
+        ctx = backend.RenderContext(_soup_with_normals(256, 256, 8, 300_000, zero))
+        ctx.render(2); ctx.waitForFinish()
+        t = time.time(); ctx.render(6); ctx.waitForFinish(); times.append(time.time() - t)
+        ctx.close()
+    assert times[1] < 2.0 * times[0] + 0.05, times                        # (a full walk per NaN ray: tens of times slower)
+
+
 def _stacked_sheets(n_sheets, dz=1e-3):
     """n_sheets large triangles stacked along z, all with the bounding square [-1, 3]^2: the first half covers the corner x + y >= 2, the
     second half the corner x + y <= 2.  Their centroids differ in z only (within a half), so the LBVH's nodes are z-slabs that a ray along z
