@@ -101,6 +101,20 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
+def gather_ceiling():
+    """Attainable rate of dependent per-lane record gathers at the traversal loop's own shape (waves per CU, lane fill, record mix, table
+    size, arithmetic per step, L2 locality), measured with tools/micro/gather_ceiling.hip and committed under profiles/: G records/s."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gather_ceiling.json")), reverse=True):
+        try:
+            with open(path) as f:
+                g = json.load(f)
+            return float(g["g_records_per_s"][g["quoted"]]) * 1e9, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 PMC_EXTRA = {}   # issue / texture-path occupancy of the same launches, from the same summary (filled by pmc_traffic)
 
 
@@ -156,9 +170,11 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u", owned_fraction=1.0, 
     bytes_closest = d["rays_closest"] * per_ray + tc1["node_bytes"] * d["nodes_closest"] + tc1["leaf_bytes"] * d["leaves_closest"]
     bytes_any = d["rays_any"] * per_ray + tc1["node_bytes"] * d["nodes_any"] + tc1["leaf_bytes"] * d["leaves_any"]
     persistent = fam["path"][1] > 0
+    kinfo = ctx.pipelineInfo()
     if persistent:
         # one launch = `iters` iterations of everything: closest-hit and occlusion traversal + shading, fused
-        kernel, substr = "k_path_persistent_occ3", "k_path_persistent_occ3<false,%s>" % variant  # the instantiation the scene's features select
+        name = "k_path_latency" if kinfo["kernel"] == "latency" else "k_path_persistent_occ3"
+        kernel, substr = name, "%s<false,%s>" % (name, variant)  # the instantiation the scene's features select
         ms, n = fam["path"]
         alg_bytes = (bytes_closest + bytes_any) / n          # per launch
         iters_per_launch = iters / n
@@ -179,7 +195,11 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u", owned_fraction=1.0, 
     # quoting the full-frame bytes against a share's launch time gave a figure above the chip's peak (round 4 review).
     traffic_bytes = t_iter * iters_per_launch * owned_fraction if t_iter is not None else None
     records = d["nodes_closest"] + d["leaves_closest"] + d["nodes_any"] + d["leaves_any"]
-    kinfo = ctx.pipelineInfo()
+    inner = d["nodes_closest"] + d["nodes_any"]
+    records_per_s = records / n / (avg_ms * 1e-3)
+    ceiling, ceiling_src = gather_ceiling() if variant == "0u" else (None, None)   # (measured at the C4 loop's shape: record mix, table size, lane fill)
+    # the same bytes with an inner record counted as the 48 bytes the step loads instead of the 64-byte unit the memory side moves
+    achieved48 = (alg_bytes - 16.0 * inner / n) / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1) if traffic_bytes else None,
             "traffic_bytes_per_launch": traffic_bytes, "traffic_source": src, "traffic_unavailable": why_not, "pmc": dict(PMC_EXTRA) if traffic_bytes else None,
@@ -192,6 +212,13 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u", owned_fraction=1.0, 
             "nodes_per_closest_ray": round(d["nodes_closest"] / max(d["rays_closest"], 1), 2),
             "leaves_per_closest_ray": round(d["leaves_closest"] / max(d["rays_closest"], 1), 2),
             "rays_per_launch": round((d["rays_closest"] + d["rays_any"]) / n),
+            # records fetched per second against the attainable rate of dependent per-lane gathers at this loop's own shape
+            # (tools/micro/gather_ceiling.hip, profiles/r05_gather_ceiling.txt): what the memory pipeline allows, L2 locality included
+            "records_per_s": round(records_per_s), "gather_ceiling_records_per_s": ceiling, "gather_frac": round(records_per_s / ceiling, 4) if ceiling else None,
+            "gather_ceiling_source": ceiling_src,
+            "frac_with_48_byte_inner_records": round(achieved48 / HBM_PEAK_GBS, 4),
+            "peak_note": "8 TB/s is the HBM3E spec peak; the 125 MB working set lives in the 256 MiB Infinity Cache and FETCH_SIZE counts fabric requests "
+                         "(the guide's ceiling for random gathers out of a table of this size is 7.4 - 7.9 TB/s)",
             "lane_utilisation": round(records / max(64 * (d["wave_steps_closest"] + d["wave_steps_any"]), 1), 3),
             "shade_pass_fill": round(d["shade_lanes"] / max(64 * d["shade_batches"], 1), 3) if d["shade_batches"] else None,
             "family_ms_per_iter": {k: round(v[0] / iters, 3) for k, v in fam.items() if v[1]}}

@@ -41,7 +41,6 @@ struct WaveArgs {
 	uint32_t* slot_index; // per slot: position of its current pixel in `owned`
 	int refill_below;	  // the stepping loop is left for a refill / a shading pass when fewer lanes than this hold a running ray
 	uint32_t shade_min;	  // a shading pass starts once this many vertices of one class wait (or the lanes run short of rays)
-	uint32_t shade_urgent_depth; // ... or at once for a path at least this deep (0: off): the deep chains are what a small share waits for
 	unsigned long long* gstats;
 };
 
@@ -124,7 +123,6 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 		sh_head[q] = sh_tail[q] = 0;
 	sh_tail[QR]	  = S;
 	uint32_t live = S;	  // slots that still own, or may still acquire, a pixel
-	uint32_t urgent = 0u; // bit q: a vertex of a path at least shade_urgent_depth deep waits in shade queue q
 
 	uint32_t cn_c = 0, cl_c = 0, cn_a = 0, cl_a = 0, witers = 0, sbatches = 0, slanes = 0;
 	unsigned long long t_shade = 0;
@@ -143,13 +141,9 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 			}
 		}
 		const uint32_t n_queued = ray_tail - ray_head;
-		// ---- shade: enough vertices wait, or the lanes are short of rays and nothing is queued for them, or a deep path waits
-		const bool shade_now = n_shade >= a.shade_min || (n_shade > 0u && ((n_queued == 0u && n_act < a.refill_below) || urgent != 0u));
+		// ---- shade: enough vertices wait, or the lanes are short of rays and nothing is queued for them
+		const bool shade_now = n_shade >= a.shade_min || (n_shade > 0u && n_queued == 0u && n_act < a.refill_below);
 		if (shade_now) {
-			if (urgent != 0u) { // the deep path's class, not the fullest one
-				cls = __builtin_ctz(urgent);
-				urgent &= urgent - 1u;
-			}
 			uint32_t first = 0u, n = 0u; // (compile-time indices only: the head / tail arrays stay in scalar registers)
 #pragma unroll
 			for (int q = 0; q < NQ + 1; ++q)
@@ -188,7 +182,6 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 			}
 			bool alive = false, want_shadow = false;
 			float4 sh_o = make_float4(0, 0, 0, 0), sh_d = sh_o, sh_xyz = sh_o;
-			const uint32_t depth_in = (a.shade_urgent_depth != 0u && mine && !regen_pass) ? (ps.flags[slot] & 0xFFu) : 0u; // the vertex about to be shaded
 			if (regen_pass) {
 			} else if (NQ > 1 && cls == 1) { // wave-uniform: the body with the rough / principled closures
 				if (mine)
@@ -243,8 +236,7 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 					ps.sh_d[slot]	= sh_d;
 					ps.sh_xyz[slot] = sh_xyz;
 				}
-				// rays in flight | flags | depth of the vertex the path ray leads to (bits 16..23: what makes a finished ray's slot "urgent")
-				pend[slot_l] = (alive ? 1u : 0u) + (want_shadow ? 1u + PP_SHADOW : 0u) + (alive ? 0u : PP_DEAD) + ((regen_pass ? 0u : min(depth_in + 1u, 255u)) << 16);
+				pend[slot_l] = (alive ? 1u : 0u) + (want_shadow ? 1u + PP_SHADOW : 0u) + (alive ? 0u : PP_DEAD);
 			}
 			pw_push(sh.q_shade[wv][QR], SHADE_MASK, sh_tail[QR], to_regen, slot_l);
 			pw_push(q_ray, RAY_MASK, ray_tail, want_shadow, slot_l | PP_ANY);
@@ -325,7 +317,6 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 				bool last	   = false;
 				uint32_t entry = 0;
 				int qcls	   = 0;
-				bool deep	   = false;
 				if (fin) {
 					const uint32_t slot_l = my_entry & ~PP_ANY;
 					uint32_t add		  = 0xFFFFFFFFu; // -1
@@ -345,17 +336,11 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 						qcls = QR;
 					if (NQ > 1 && last && !(old & PP_DEAD))
 						qcls = s.any ? (int)((old >> PP_CLS_SHIFT) & 3u) : (int)(s.cls & 3u);
-					if (a.shade_urgent_depth != 0u && last && !(old & PP_DEAD))
-						deep = ((old >> 16) & 0xFFu) + 1u >= a.shade_urgent_depth;
 				}
 				m_has &= ~m_done;
 #pragma unroll
 				for (int q = 0; q < NQ + 1; ++q)
 					pw_push(sh.q_shade[wv][q], SHADE_MASK, sh_tail[q], last && qcls == q, entry);
-				if (a.shade_urgent_depth != 0u)
-#pragma unroll
-					for (int q = 0; q < NQ; ++q)
-						urgent |= lane_ballot(deep && qcls == q) != 0ull ? (1u << q) : 0u;
 			}
 			const int active = wave_popc(m_has);
 			if (active == 0)
@@ -364,7 +349,7 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 #pragma unroll
 			for (int q = 1; q < NQ + 1; ++q)
 				nsh = max(nsh, sh_tail[q] - sh_head[q]);
-			if (nsh >= a.shade_min || urgent != 0u) // a pass is due
+			if (nsh >= a.shade_min) // a pass is due
 				break;
 			if (active < a.refill_below && (ray_tail != ray_head || nsh != 0u)) // under-occupied: leave if there is anything to refill from or to shade
 				break;

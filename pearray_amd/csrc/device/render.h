@@ -42,7 +42,8 @@ struct PersistentGeometry {
 	uint32_t n_blocks, slots_per_block;
 };
 PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, uint32_t max_slots_per_block);
-uint32_t persistent_slot_padding(); // per-slot arrays need n_pixels + this many entries
+uint32_t persistent_slot_padding(); // slots per block of the throughput kernel at most (PRGPU_PP_SLOTS is clamped to it)
+uint32_t slot_array_padding();	   // per-slot arrays need n_pixels + this many entries (either organisation rounds its slot count up)
 uint32_t persistent_block_threads(); // 256 or 768 (PR_PP_BLOCK)
 int shade_ticks_counter(); // index into gstats of the instrumented kernel's timers: ticks in shading passes, idle, alive (summed over waves)
 // What a host may tune in the persistent kernel without changing a result (prgpu_api.hip reads the PRGPU_PP_* knobs into this)
@@ -59,6 +60,21 @@ struct PersistentTuning {
 void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end,
 							bool count, const TraceWorkspace& ws, const PersistentTuning& tune, int shader_waves /* of a block's four: 0 .. 2 */, uint32_t* next_pixel, uint32_t* error,
 							unsigned long long* gstats, hipStream_t st);
+// The latency organisation of the same kernel (device/path_wave.inl): a WAVE owns 64 .. 256 path slots with wave-private queues, two blocks
+// per CU at two waves per SIMD -- for tile shares whose pixel count is about the chip's lane count, where a launch lasts as long as its
+// deepest pixel's chain of vertices.  Same frame, bit for bit.
+struct LatencyGeometry {
+	uint32_t n_blocks, slots_per_wave, total_slots;
+};
+struct LatencyTuning {
+	uint32_t slots_per_wave = 256; // cap; the launcher takes the smallest multiple of 64 that puts every owned pixel in flight
+	int shade_min			= 48;  // a shading pass starts once this many vertices of one class wait ...
+	int refill_below		= 40;  // ... or when fewer lanes than this hold a running ray and nothing is queued for the idle ones
+};
+LatencyGeometry latency_geometry(uint32_t n_owned, uint32_t max_blocks_throughput, uint32_t max_slots_per_wave);
+bool latency_variant_built(uint32_t features);
+void launch_path_latency(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end, bool count,
+						 const TraceWorkspace& ws, const LatencyTuning& tune, uint32_t* error, unsigned long long* gstats, hipStream_t st);
 void launch_resolve(const DevScene& sc, const PathState& ps, uint32_t iter, hipStream_t st);
 // lockstep pipeline, PRGPU_SORT_RAYS=1 (experiment): the active list ordered by (Morton code of the ray origin, direction octant)
 size_t sort_active_temp_bytes(uint32_t n_max);

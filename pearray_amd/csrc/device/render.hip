@@ -12,7 +12,7 @@
 // unit 0 holds the wavefront (lockstep / streaming) kernels, the ray service and the launchers; units (v, s) hold ONE instantiation of the
 // persistent path kernel each (launch_pp_<v>_<s>).  The device functions above the kernels are shared source, not shared objects.
 #ifndef PR_TU
-#error "compile with -DPR_TU=0..4 (see the Makefile)"
+#error "compile with -DPR_TU=0..5 or 11..15 (see the Makefile)"
 #endif
 #include "render.h"
 
@@ -50,6 +50,9 @@ enum { CNT_NODES_CLOSEST = PRGPU_STAT_COUNT, CNT_TRIS_CLOSEST, CNT_NODES_ANY, CN
 // rare deeper stacks spill their oldest entries to a per-thread slab in HBM.
 #ifndef PR_PEEK
 #define PR_PEEK 0 // persistent path kernel: read the stack top ahead of every step (see path_persistent); the Makefile sets it per variant
+#endif
+#ifndef PR_PL_VARIANTS
+#define PR_PL_VARIANTS 31 // bit v - 1: the library holds the latency organisation of kernel variant v (development builds leave the large ones out)
 #endif
 #ifndef PR_PP_BLOCK
 #define PR_PP_BLOCK 256 // threads of a persistent-kernel block: 256 (three blocks per CU) or 768 (one block per CU: its twelve waves share one set of queues)
@@ -1583,14 +1586,14 @@ __device__ __forceinline__ uint32_t scatter_symbol(const prgpu_material& m, V3 V
 
 template <uint32_t FEATS>
 __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState& ps, uint32_t slot, BlockStats& bs, bool& alive, bool& want_shadow,
-											 float4& sh_o, float4& sh_d, float4& sh_xyz)
+											 float4& sh_o, float4& sh_d, float4& sh_xyz, const float4* hit_src = nullptr /* the slot's hit when it is not in ps.hit (latency kernel: LDS) */)
 {
 	const prgpu_settings& cfg = sc.cfg;
 	const uint32_t pixel = ps.pixel[slot];
 	const size_t entry	 = iter_entry(ps, slot, pixel);
 	const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
 	const V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
-	const float4 hit4  = ps.hit[slot];
+	const float4 hit4  = hit_src ? *hit_src : ps.hit[slot];
 	const uint32_t tri = __float_as_uint(hit4.w);
 	uint32_t flags	   = ps.flags[slot];
 	if (flags & FLAG_NO_RAY) // the camera had no ray for this sample (camera_path): nothing was traced, nothing is splatted
@@ -2889,6 +2892,8 @@ __global__ void __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu
 	path_persistent<COUNT, FEATS>(sc, ps, a);
 }
 
+#include "path_wave.inl"
+
 #if PR_TU == 0
 // ---- ray service kernels (IArchive surface) ------------------------------------------------------------
 __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
@@ -3306,24 +3311,49 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 #define PR_PP_DECL(V, S) void launch_pp_##V##_##S(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st);
 #define PR_PP_DECL4(V) PR_PP_DECL(V, 0) PR_PP_DECL(V, 1) PR_PP_DECL(V, 2) PR_PP_DECL(V, 3)
 PR_PP_DECL4(1) PR_PP_DECL4(2) PR_PP_DECL4(3) PR_PP_DECL4(4) PR_PP_DECL4(5)
+#define PR_PL_DECL(V) void launch_pl_##V##_0(const DevScene& sc, const PathState& ps, const WaveArgs& a, dim3 grid, hipStream_t st); \
+	void launch_pl_##V##_1(const DevScene& sc, const PathState& ps, const WaveArgs& a, dim3 grid, hipStream_t st);
+PR_PL_DECL(1) PR_PL_DECL(2) PR_PL_DECL(3) PR_PL_DECL(4) PR_PL_DECL(5)
 #if PR_TU >= 1
 #ifndef PR_SUB
 #error "compile the persistent-kernel units with -DPR_SUB=0..3"
 #endif
-#if PR_TU == 1
+// units 11..15 hold the latency organisation of variants 1..5 (a literal: it is pasted into the launcher's name)
+#if PR_TU == 1 || PR_TU == 11
+#define PR_VARIANT 1
+#elif PR_TU == 2 || PR_TU == 12
+#define PR_VARIANT 2
+#elif PR_TU == 3 || PR_TU == 13
+#define PR_VARIANT 3
+#elif PR_TU == 4 || PR_TU == 14
+#define PR_VARIANT 4
+#else
+#define PR_VARIANT 5
+#endif
+#if PR_VARIANT == 1
 #define PR_PP_FEATS 0u
-#elif PR_TU == 2
+#elif PR_VARIANT == 2
 #define PR_PP_FEATS FEAT_DELTA_MATERIALS
-#elif PR_TU == 3
+#elif PR_VARIANT == 3
 #define PR_PP_FEATS FEAT_NO_ROUGH
-#elif PR_TU == 4
+#elif PR_VARIANT == 4
 #define PR_PP_FEATS FEAT_NO_LPE
 #else
 #define PR_PP_FEATS FEAT_ALL // + light path expressions: their state tracking costs the all-features kernel 7 % (C5 135 -> 125 Msamples/s), so it is its own variant
 #endif
-#define PR_PP_CAT2(V, S) launch_pp_##V##_##S
-#define PR_PP_CAT(V, S) PR_PP_CAT2(V, S)
-void PR_PP_CAT(PR_TU, PR_SUB)(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st)
+#define PR_PP_CAT2(P, V, S) launch_##P##_##V##_##S
+#define PR_PP_CAT(P, V, S) PR_PP_CAT2(P, V, S)
+#if PR_TU > 10
+void PR_PP_CAT(pl, PR_VARIANT, PR_SUB)(const DevScene& sc, const PathState& ps, const WaveArgs& a, dim3 grid, hipStream_t st)
+{
+#if PR_SUB == 0
+	hipLaunchKernelGGL((k_path_latency<false, PR_PP_FEATS>), grid, dim3(TRAV_BLOCK), 0, st, sc, ps, a);
+#else
+	hipLaunchKernelGGL((k_path_latency<true, PR_PP_FEATS>), grid, dim3(TRAV_BLOCK), 0, st, sc, ps, a);
+#endif
+}
+#else
+void PR_PP_CAT(pp, PR_VARIANT, PR_SUB)(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st)
 {
 	const dim3 block(TRAV_BLOCK);
 #if PR_SUB == 0
@@ -3336,6 +3366,7 @@ void PR_PP_CAT(PR_TU, PR_SUB)(const DevScene& sc, const PathState& ps, const Per
 	hipLaunchKernelGGL((k_path_persistent<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
 #endif
 }
+#endif
 #endif // PR_TU >= 1
 
 #if PR_TU == 0
@@ -3346,7 +3377,10 @@ PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, ui
 	// for each of 768 blocks, and rounding that up to 384 would leave 93 blocks without work)
 	const uint32_t per_block = (n_owned + max_blocks - 1) / std::max(1u, max_blocks);
 	const uint32_t cap		 = std::min((uint32_t)PP_SLOTS_MAX, std::max(256u, max_slots_per_block / 64u * 64u));
-	g.slots_per_block		 = std::min(cap, std::max(256u, per_block));
+	// (a film with fewer pixels than the grid has lanes is spread over ALL blocks, 64 slots at least: a block's three tracing waves step at the
+	// same pace whatever their fill, so 256 paths in a quarter of the blocks take three times as long as 85 in each of them --
+	// profiles/r05_small_films.log)
+	g.slots_per_block		 = std::min(cap, std::max(64u, per_block));
 	// more pixels than slots (dynamic hand-out): the traversal-bound C4 frame likes 320 - 384 slots per block of 256 lanes a little better
 	// (2 %), every shading-heavy scene likes 512 better (fuller shading passes: C5 2 - 6 %, rough Cornell 257 vs 228 Msamples/s, glass 287
 	// vs 266) -- the cap stays 512 (profiles/r03_slots_blocks_sweep.log)
@@ -3354,6 +3388,7 @@ PersistentGeometry persistent_geometry(uint32_t n_owned, uint32_t max_blocks, ui
 	return g;
 }
 uint32_t persistent_slot_padding() { return PP_SLOTS_MAX; }
+uint32_t slot_array_padding() { return std::max<uint32_t>(PP_SLOTS_MAX, (TRAV_BLOCK / 64u) * PW_SLOTS_MAX); } // (the latency grid rounds up to whole blocks of four waves)
 uint32_t persistent_block_threads() { return PP_BLOCK; }
 int shade_ticks_counter() { return CNT_SHADE_TICKS; } // ... followed by CNT_IDLE_TICKS, CNT_TOTAL_TICKS
 
@@ -3406,6 +3441,82 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	const int variant = (sc.features & (FEAT_LPE | FEAT_QUADRICS)) ? 4
 						: (sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3)));
 	table[variant][(tune.occupancy >= 3 ? 0 : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
+}
+
+// The latency organisation (path_wave.inl): waves that own their paths.  Grid: as many waves as the pixels need at `slots_per_wave` slots
+// each, at most ws.max_blocks / 3 * 2 blocks (two blocks of four waves per CU where the throughput kernel runs three); with more
+// pixels than slots a slot renders its pixels one after the other.
+LatencyGeometry latency_geometry(uint32_t n_owned, uint32_t max_blocks_throughput, uint32_t max_slots_per_wave)
+{
+	LatencyGeometry g;
+	const uint32_t waves_per_block = TRAV_BLOCK / 64u;
+	const uint32_t max_blocks	   = std::max(1u, max_blocks_throughput * 2u / 3u);
+	const uint32_t max_waves	   = max_blocks * waves_per_block;
+	const uint32_t cap			   = std::min((uint32_t)PW_SLOTS_MAX, std::max(64u, max_slots_per_wave / 64u * 64u));
+	// the smallest multiple of 64 slots per wave that puts every pixel in flight at once, if one exists below the cap
+	uint32_t spw = ((n_owned + max_waves - 1u) / max_waves + 63u) / 64u * 64u;
+	spw			 = std::min(cap, std::max(64u, spw));
+	g.slots_per_wave = spw;
+	const uint32_t waves = std::max(1u, std::min(max_waves, (n_owned + spw - 1u) / spw));
+	g.n_blocks			 = (waves + waves_per_block - 1u) / waves_per_block;
+	g.total_slots		 = g.n_blocks * waves_per_block * spw;
+	return g;
+}
+bool latency_variant_built(uint32_t features)
+{
+	const int variant = (features & (FEAT_LPE | FEAT_QUADRICS)) ? 4 : (features == 0 ? 0 : ((features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3)));
+	return ((PR_PL_VARIANTS >> variant) & 1u) != 0u;
+}
+void launch_path_latency(const DevScene& sc, const PathState& ps, const uint32_t* owned, uint32_t n_owned, uint32_t iter_begin, uint32_t iter_end, bool count,
+						 const TraceWorkspace& ws, const LatencyTuning& tune, uint32_t* error, unsigned long long* gstats, hipStream_t st)
+{
+	const LatencyGeometry g = latency_geometry(n_owned, ws.max_blocks, tune.slots_per_wave);
+	WaveArgs a;
+	a.owned			 = owned;
+	a.n_owned		 = n_owned;
+	a.error			 = error;
+	a.slots_per_wave = g.slots_per_wave;
+	a.total_slots	 = g.total_slots;
+	a.iter_begin	 = iter_begin;
+	a.iter_end		 = iter_end;
+	a.spill			 = ws.spill;
+	a.slot_index	 = ws.slot_unit;
+	a.refill_below	 = std::min(64, std::max(1, tune.refill_below));
+	a.shade_min		 = (uint32_t)std::min(64, std::max(1, tune.shade_min));
+	a.gstats		 = gstats;
+	typedef void (*LaunchFn)(const DevScene&, const PathState&, const WaveArgs&, dim3, hipStream_t);
+	// (a variant the library was built without -- PR_PL_VARIANTS, a development aid -- has no entry: the host asks latency_variant_built first)
+	static const LaunchFn table[5][2] = {
+#if PR_PL_VARIANTS & 1
+		{ launch_pl_1_0, launch_pl_1_1 },
+#else
+		{ nullptr, nullptr },
+#endif
+#if PR_PL_VARIANTS & 2
+		{ launch_pl_2_0, launch_pl_2_1 },
+#else
+		{ nullptr, nullptr },
+#endif
+#if PR_PL_VARIANTS & 4
+		{ launch_pl_3_0, launch_pl_3_1 },
+#else
+		{ nullptr, nullptr },
+#endif
+#if PR_PL_VARIANTS & 8
+		{ launch_pl_4_0, launch_pl_4_1 },
+#else
+		{ nullptr, nullptr },
+#endif
+#if PR_PL_VARIANTS & 16
+		{ launch_pl_5_0, launch_pl_5_1 },
+#else
+		{ nullptr, nullptr },
+#endif
+	};
+	const int variant = (sc.features & (FEAT_LPE | FEAT_QUADRICS)) ? 4
+						: (sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3)));
+	if (LaunchFn fn = table[variant][count ? 1 : 0])
+		fn(sc, ps, a, dim3(g.n_blocks), st);
 }
 
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * std::max(TRAV_BLOCK, PP_BLOCK) * STACK_SPILL; }

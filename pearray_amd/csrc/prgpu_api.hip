@@ -50,6 +50,9 @@ struct Knobs {
 	bool mode_invalid = false;
 	prd::PersistentTuning pp;			  // PRGPU_PP_SLOTS, _SHADE_MIN, _SHADE_PARTIAL, _FIN_BATCH, _OCCUPANCY, _SHADER, _RESIDENT
 	bool pp_slots_set		   = false;
+	int pp_kernel			   = 0;		  // PRGPU_PP_KERNEL=throughput|latency (1 / 2; 0: by the size of the tile share, render_persistent)
+	bool pp_kernel_invalid	   = false;
+	prd::LatencyTuning pl;				  // PRGPU_PL_SLOTS, _SHADE_MIN, _REFILL: the latency organisation's slots per wave (cap), shading and refill thresholds
 	int pp_refill			   = 48;	  // PRGPU_PP_REFILL: a wave refills its idle lanes when fewer than this many hold a ray
 	int pp_blocks_per_cu	   = 0;		  // PRGPU_PP_BLOCKS_PER_CU (0: 768 threads per CU)
 	int pp_max_blocks		   = 0;		  // PRGPU_PP_MAX_BLOCKS (tests: a small grid, so that a small film has more pixels than path slots)
@@ -77,6 +80,13 @@ Knobs read_knobs()
 		k.mode		   = std::strcmp(env, "lockstep") == 0 ? 0 : (std::strcmp(env, "streaming") == 0 ? 1 : (std::strcmp(env, "persistent") == 0 ? 2 : -1));
 		k.mode_invalid = k.mode < 0;
 	}
+	if (const char* env = getenv("PRGPU_PP_KERNEL")) {
+		k.pp_kernel			= std::strcmp(env, "throughput") == 0 ? 1 : (std::strcmp(env, "latency") == 0 ? 2 : (std::strcmp(env, "auto") == 0 ? 0 : -1));
+		k.pp_kernel_invalid = k.pp_kernel < 0;
+	}
+	k.pl.slots_per_wave	  = (uint32_t)num("PRGPU_PL_SLOTS", k.pl.slots_per_wave, 64, 256);
+	k.pl.shade_min		  = (int)num("PRGPU_PL_SHADE_MIN", k.pl.shade_min, 1, 64);
+	k.pl.refill_below	  = (int)num("PRGPU_PL_REFILL", k.pl.refill_below, 1, 64);
 	k.pp_slots_set		  = getenv("PRGPU_PP_SLOTS") != nullptr;
 	k.pp.slots			  = (uint32_t)num("PRGPU_PP_SLOTS", k.pp.slots, 256, prd::persistent_slot_padding()); // (= the kernel's PP_SLOTS_MAX: every user of the knob sees the value the kernel runs with)
 	k.pp.shade_min		  = (int)num("PRGPU_PP_SHADE_MIN", k.pp.shade_min, 1, 64);
@@ -563,7 +573,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		if (rc != PRGPU_OK)                       \
 			return rc;                            \
 	} while (0)
-	const size_t ns = size_t(np) + prd::persistent_slot_padding(); // per-slot arrays: the persistent kernel rounds its slot count up
+	const size_t ns = size_t(np) + prd::slot_array_padding(); // per-slot arrays: the persistent kernels round their slot count up
 	AL(ps.rng, np, false);
 	HIP_TRY(hipMemcpyAsync(ps.rng, t.rng.data(), size_t(np) * 8, hipMemcpyHostToDevice, s->stream));
 	AL(ps.pixel, np, false);
@@ -612,6 +622,8 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	s->mode = prgpu_scene::PERSISTENT;
 	if (s->knobs.mode_invalid)
 		return fail(PRGPU_EINVAL, "PRGPU_MODE must be lockstep, streaming or persistent");
+	if (s->knobs.pp_kernel_invalid)
+		return fail(PRGPU_EINVAL, "PRGPU_PP_KERNEL must be auto, throughput or latency");
 	if (s->knobs.mode == 0)
 		s->mode = prgpu_scene::LOCKSTEP;
 	else if (s->knobs.mode == 1)
@@ -949,6 +961,17 @@ int render_streaming(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 // ---- persistent mode ------------------------------------------------------------------------------------------
 // One launch per render call: see k_path_persistent (device/render.hip).  Same per-pixel arithmetic and fragment order as
 // the other two modes, hence identical images.
+// The latency organisation runs a scene when the knob asks for it, or (auto) when the tile share is small enough that every owned pixel
+// is in flight at once in it -- and the library holds that variant of it, and the throughput kernel was not built one block per CU.
+bool use_latency_kernel(const prgpu_scene* s)
+{
+	if (s->knobs.pp_kernel == 1 || prd::persistent_block_threads() != 256u || !prd::latency_variant_built(s->sc.features))
+		return false;
+	if (s->knobs.pp_kernel == 2)
+		return true;
+	return false; // auto: decided by measurement
+}
+
 int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 {
 	if (!s->n_slots)
@@ -972,7 +995,11 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 	// with fuller passes (C5 + 7 %, C4 - 10 %: profiles/r04_knobs.log).  The first launch of a scene therefore runs the INSTRUMENTED variant
 	// of the kernel (same results; it times its shading passes), and later launches use round(4 * share) shading waves, at most two.
 	// (Two clock reads per pass in the plain kernel were measured instead: 4 % slower on C4 -- the timers' scalar registers spill.)
-	const bool calibrating = s->knobs.pp.shader_wave < 0 && !all_in_flight;
+	// Which organisation of the kernel (render.h): the latency one for tile shares whose pixels are about as many as the chip's lanes
+	// (every pixel in flight at once in both organisations: a launch lasts as long as its deepest pixel's chain of vertices), the
+	// throughput one for everything larger.  PRGPU_PP_KERNEL fixes the choice (tests run both against the checker).
+	const bool latency = use_latency_kernel(s);
+	const bool calibrating = s->knobs.pp.shader_wave < 0 && !all_in_flight && !latency;
 	auto decide = [&]() -> int { // after a calibration launch: read its timers (the launch's own: copies of the counters taken around it)
 		if (!calibrating || s->pp_shader_waves >= 0 || s->pp_calibration_tries == 0)
 			return PRGPU_OK;
@@ -990,8 +1017,8 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 			fprintf(stderr, "[prgpu] shading passes took %.1f %% of the calibration launch's wave time: %d dedicated shading wave(s) per block from now on\n", 100.0 * share, s->pp_shader_waves);
 		return PRGPU_OK;
 	};
-	if (!all_in_flight)
-		ps.cost = nullptr; // the per-pixel path cost only serves tune_pixel_order
+	if (latency ? prd::latency_geometry(s->n_slots, s->ws_pp.max_blocks, s->knobs.pl.slots_per_wave).total_slots < s->n_slots : !all_in_flight)
+		ps.cost = nullptr; // the per-pixel path cost is kept while every owned pixel is in flight at once (it serves tune_pixel_order)
 	const bool ring			= !s->sc.single_tap; // multi-tap filter: one launch fills at most pp_planes iteration planes
 	if (ring) {
 		chunk			= std::min(chunk, s->pp_planes);
@@ -1009,7 +1036,10 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 		if (calibration) // the launch's counters = a copy of them after it minus a copy before it, both taken on the stream
 			HIP_TRY(hipMemcpyAsync(s->gstats_before, s->gstats, gbytes, hipMemcpyDeviceToDevice, s->stream));
 		s->time_begin(6, s->stream);
-		prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument || calibration, s->ws_pp, s->knobs.pp, shader_wave, s->pp_next, s->pp_error, s->gstats, s->stream);
+		if (latency)
+			prd::launch_path_latency(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument, s->ws_pp, s->knobs.pl, s->pp_error, s->gstats, s->stream);
+		else
+			prd::launch_path_persistent(s->sc, ps, s->ps.pixel, s->n_slots, b, e, s->instrument || calibration, s->ws_pp, s->knobs.pp, shader_wave, s->pp_next, s->pp_error, s->gstats, s->stream);
 		s->time_end(s->stream);
 		HIP_TRY(hipGetLastError());
 		if (calibration) {
@@ -1019,10 +1049,16 @@ int render_persistent(prgpu_scene* s, uint32_t iter_begin, uint32_t iter_end)
 			++s->pp_calibration_tries;
 		}
 		++s->pp_launches;
-		{
+		if (latency) {
+			const prd::LatencyGeometry g = prd::latency_geometry(s->n_slots, s->ws_pp.max_blocks, s->knobs.pl.slots_per_wave);
+			s->pp_last_blocks = g.n_blocks;
+			s->pp_last_slots  = g.slots_per_wave * (prd::persistent_block_threads() / 64u);
+			s->pp_last_kernel = PRGPU_KERNEL_LATENCY;
+		} else {
 			const prd::PersistentGeometry g = prd::persistent_geometry(s->n_slots, s->ws_pp.max_blocks, s->knobs.pp.slots);
 			s->pp_last_blocks = g.n_blocks;
 			s->pp_last_slots  = g.slots_per_block;
+			s->pp_last_kernel = PRGPU_KERNEL_THROUGHPUT;
 		}
 		if (ring) { // filter taps + running mean, iteration by iteration in order (FrameOutputDevice.cpp:202-221)
 			prd::PathState pr = s->ps;
@@ -1068,8 +1104,8 @@ int tune_pixel_order(prgpu_scene* s)
 	// at 1/8 of the 1080p frame and buys ~ 4 % per iteration: re-tuning at every doubling put one inside the driver's 20-step timed
 	// region, 2.09 -> 2.38 ms per step, profiles/r04_share_timed_region.log; with this schedule a warm-up of any length takes the first
 	// tune and a measurement of up to 63 iterations after it sees none.)
-	if (s->mode != prgpu_scene::PERSISTENT || s->next_iteration < (s->order_tuned_at == 0u ? 1u : std::max(64u, 8u * s->order_tuned_at)) || !s->n_slots)
-		return PRGPU_OK;
+	if (s->mode != prgpu_scene::PERSISTENT || s->next_iteration < (s->order_tuned_at == 0u ? 1u : std::max(64u, 8u * s->order_tuned_at)) || !s->n_slots || use_latency_kernel(s))
+		return PRGPU_OK; // (the latency organisation has no dispatch layers to sort pixels into)
 	s->order_tuned_at = s->next_iteration;
 	if (!s->knobs.pp_tune_order)
 		return PRGPU_OK;
@@ -1958,7 +1994,7 @@ int prgpu_enable_lpe(prgpu_scene* s, uint32_t n, const char* const* expressions)
 		std::fill(table + prd::LPE_STATES * 15u, table + prd::LPE_TABLE_BYTES, 0);
 		std::copy(accepting.begin(), accepting.end(), table + prd::LPE_STATES * 15u);
 	}
-	const size_t ns = size_t(s->n_pixels) + prd::persistent_slot_padding();
+	const size_t ns = size_t(s->n_pixels) + prd::slot_array_padding();
 	int rc			= s->alloc(host.state, ns, true);
 	for (uint32_t k = 0; k < n && rc == PRGPU_OK; ++k) {
 		rc = s->alloc(host.iter[k], size_t(s->n_pixels) * 3 * s->pp_planes, true); // multi-tap pixel filter: a ring of planes like the main one

@@ -415,6 +415,43 @@ def test_rays_whose_whole_origin_is_nan_or_infinite_end_at_the_root(monkeypatch,
     assert dt < 0.25, dt
 
 
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_rays_from_far_outside_the_scene_need_the_relative_slack_of_the_box_test(monkeypatch, split):
+    """The witness of SLAB_REL.  Inside the scene the padding of every box (pad_box: 4e-6 x the largest coordinate)
+    is a hundred times the rounding of a plane's distance, so the relative factor F' = 1 + 48 u of the acceptance test never decides
+    anything -- round 4's mutant with F' = 1 and eps' = 0 passed every test.  It decides for a ray that STARTS far away: the distance to a
+    plane is then ~ D and carries a rounding error of ~ 3 u D, which exceeds the padding once D is more than ~ 20 scene sizes; entry and
+    exit distance of a flat box (an axis-parallel triangle's leaf) then come out in the wrong order by up to a few u D.  Rays from
+    D = 200 .. 5000 scene sizes aimed at the vertices and edges of axis-parallel triangles on a lattice, against the checker's exhaustive
+    loop (no tree, no box test).  With F' = 1, eps' = 0 this test fails (profiles/r05_mutations.log)."""
+    monkeypatch.setenv("PRGPU_TRACE_SPLIT", split)
+    pos, faces = _lattice_sheet(64)
+    b = scene.SceneBuilder(8, 8)
+    b.settings.aa_samples = 1
+    b.add_mesh(pos, faces, b.lambert(b.spectrum_const(0.5)))
+    sc = b.build()
+    g, o = backend.RenderContext(sc), ob.OracleScene(sc)
+    rng = np.random.default_rng(1234)
+    n = 60_000
+    tri = rng.integers(0, len(faces), n)
+    P = pos[faces[tri]].astype(np.float64)
+    w = rng.random((n, 1))
+    target = np.where(rng.random((n, 1)) < 0.5, P[:, 0], P[:, 1] * w + P[:, 2] * (1 - w))
+    away = rng.normal(size=(n, 3)); away[:, 2] = np.abs(away[:, 2]) + 0.05      # from above the sheet, at every slant
+    away /= np.linalg.norm(away, axis=1, keepdims=True)
+    dist = 10.0 ** rng.uniform(np.log10(200.0), np.log10(5000.0), (n, 1)) * 2.0    # scene size 2
+    org = (target + away * dist).astype(np.float32)
+    d = target - org.astype(np.float64)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    a = g.traceRays(org, d, 1e-4, np.inf)
+    c = o.trace_closest(org, d, 1e-4, np.inf, brute=True)
+    hit = (c[0] != abi.INVALID_ID).mean()
+    assert 0.3 < hit <= 1.0, hit
+    for x, y in zip(a[:2], c[:2]):
+        assert np.array_equal(x, y), (np.flatnonzero(x != y)[:5], (x != y).sum())
+    assert np.array_equal(a[4], c[4])
+
+
 def _soup_with_normals(width, height, spp, n_triangles, zero_normals):
     b = scene.SceneBuilder(width, height)
     b.settings.aa_sampler, b.settings.aa_samples = abi.SAMPLER_SOBOL, spp

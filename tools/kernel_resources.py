@@ -21,7 +21,7 @@ for obj in sorted(glob.glob(os.path.join(ROOT, "pearray_amd", "csrc", "build", "
         if not name:
             continue
         demangled = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0]
-        if "k_path_persistent" not in demangled and "k_trace" not in demangled and "k_service" not in demangled and "k_shade" not in demangled:
+        if "k_path_persistent" not in demangled and "k_path_latency" not in demangled and "k_trace" not in demangled and "k_service" not in demangled and "k_shade" not in demangled:
             continue
         out[demangled + " [" + os.path.basename(obj) + "]"] = {
             "vgpr_count": int(get("vgpr_count")), "agpr_count": int(block.split()[0]), "sgpr_count": int(get("sgpr_count")),
