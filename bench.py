@@ -95,7 +95,7 @@ def kernel_source_sha16():
     """Fingerprint of the device sources the hot kernel is built from; a PMC summary taken from another build is not quoted."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("pearray_amd/csrc/device/render.hip", "pearray_amd/csrc/device/pr_device.h", "pearray_amd/csrc/device/bvh.hip"):
+    for f in ("pearray_amd/csrc/device/render.hip", "pearray_amd/csrc/device/path_wave.inl", "pearray_amd/csrc/device/pr_device.h", "pearray_amd/csrc/device/bvh.hip"):
         with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

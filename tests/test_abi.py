@@ -75,6 +75,16 @@ def test_measurement_probes_are_the_ones_the_readme_names():
             assert os.path.exists(os.path.join(ROOT, rel)), (doc, rel)
 
 
+def test_profiles_index_is_current():
+    """profiles/INDEX.md lists every committed measurement with the documents and sources that cite it (tools/make_profiles_index.py writes it)."""
+    import subprocess
+    names = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if f != "INDEX.md"]
+    index = open(os.path.join(ROOT, "profiles", "INDEX.md")).read()
+    for f in names:
+        assert "`%s`" % f in index, "profiles/%s is not in profiles/INDEX.md: run python tools/make_profiles_index.py" % f
+    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_profiles_index.py"), "--check"]).returncode == 0, "profiles/INDEX.md is stale: run python tools/make_profiles_index.py"
+
+
 def test_struct_layouts_match_the_header(tmp_path):
     """sizeof/offsetof of every ABI struct as seen by a C compiler equal the ctypes mirror."""
     import subprocess
