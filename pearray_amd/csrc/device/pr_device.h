@@ -997,28 +997,31 @@ __device__ __forceinline__ V3 refract_shading(float eta, V3 w)
 	return neg ? -r : r;
 }
 constexpr float DIELECTRIC_AIR = 1.0002926f; // dielectric.cpp:17
-// Fresnel::conductor (base/math/Fresnel.h:33-59)
-__device__ __forceinline__ float fresnel_conductor(float cosI, float n_in, float n_out, float k)
+// Unpolarised Fresnel reflectance of a conductor of complex index n_metal + i k_metal seen from a medium of index n_medium: the closed form that
+// Fresnel::conductor evaluates (src/base/math/Fresnel.h:33-57).  The ORDER of the fp32 operations is the reference's (bit parity with the checker
+// depends on it, including the two fused sumProd terms); the naming and the comments are this file's: with c = |cos theta|, s2 = sin^2 theta and the
+// relative index (n, k), d = n^2 - k^2 - s2 and root = sqrt(d^2 + 4 n^2 k^2) = a^2 + b^2 of the textbook form, the s-polarised reflectance is
+// (root + c^2 - 2 c a) / (root + c^2 + 2 c a) with a = sqrt((root + d) / 2), and the p-polarised one is that times
+// (c^2 root + s2^2 - 2 c a s2) / (c^2 root + s2^2 + 2 c a s2).
+__device__ __forceinline__ float fresnel_conductor(float cos_theta, float n_medium, float n_metal, float k_metal)
 {
-	if (cosI < 0)
-		cosI = -cosI;
-	const float eta	   = n_out / n_in;
-	const float kappa  = k / n_in;
-	const float cosI2  = cosI * cosI;
-	const float sinI2  = 1 - cosI2;
-	const float eta2   = eta * eta;
-	const float kappa2 = kappa * kappa;
-	const float t0	   = eta2 - kappa2 - sinI2;
-	const float ap	   = sqrtf(sum_prod(t0, t0, 4 * eta2, kappa2));
-	const float t1	   = ap + cosI2;
-	const float a	   = sqrtf((ap + t0) / 2);
-	const float t2	   = 2 * cosI * a;
-	const float perp2  = (t1 - t2) / (t1 + t2);
-	const float t3	   = sum_prod(cosI2, ap, sinI2, sinI2);
-	const float t4	   = t2 * sinI2;
-	const float para2  = perp2 * (t3 - t4) / (t3 + t4);
-	const float R	   = (para2 + perp2) / 2;
-	return fminf(fmaxf(R, 0.0f), 1.0f);
+	const float c	  = cos_theta < 0 ? -cos_theta : cos_theta;
+	const float n	  = n_metal / n_medium;
+	const float k	  = k_metal / n_medium;
+	const float c2	  = c * c;
+	const float s2	  = 1 - c2;
+	const float n2	  = n * n;
+	const float k2	  = k * k;
+	const float d	  = n2 - k2 - s2;
+	const float root  = sqrtf(sum_prod(d, d, 4 * n2, k2));
+	const float sum	  = root + c2;
+	const float a	  = sqrtf((root + d) / 2);
+	const float cross = 2 * c * a;
+	const float r_s	  = (sum - cross) / (sum + cross);
+	const float q	  = sum_prod(c2, root, s2, s2);
+	const float w	  = cross * s2;
+	const float r_p	  = r_s * (q - w) / (q + w);
+	return fminf(fmaxf((r_p + r_s) / 2, 0.0f), 1.0f);
 }
 
 // ---- rough (GGX microfacet) materials ----------------------------------------------------------------

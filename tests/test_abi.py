@@ -75,6 +75,22 @@ def test_measurement_probes_are_the_ones_the_readme_names():
             assert os.path.exists(os.path.join(ROOT, rel)), (doc, rel)
 
 
+def test_a_one_rank_communicator_needs_no_rccl_and_says_so():
+    """prgpu_comm_create(n_ranks = 1) makes no RCCL call (and needs no device); prgpu_comm_query then reports that no collective library is
+    involved (0 ranks, rank -1) -- on a multi-GPU job it returns ncclCommCount / ncclCommUserRank, which bench.py prints."""
+    lib = abi.load()
+    os.environ.pop("PRGPU_COMM_FORCE_RCCL", None)
+    h = C.c_void_p()
+    assert lib.prgpu_comm_create(None, 1, 0, 0, C.byref(h)) == 0
+    n, r = C.c_int(7), C.c_int(7)
+    assert lib.prgpu_comm_query(h, C.byref(n), C.byref(r)) == 0 and (n.value, r.value) == (0, -1)
+    assert lib.prgpu_comm_size(h) == 1
+    lib.prgpu_comm_destroy(h)
+    assert lib.prgpu_comm_query(None, C.byref(n), C.byref(r)) == -1
+    assert lib.prgpu_comm_create(None, 2, 0, 0, C.byref(h)) == -1 and b"unique id" in lib.prgpu_last_error()   # several ranks need rank 0's id
+    assert lib.prgpu_reduced_planes(None, None, None, None) == -1 and lib.prgpu_pipeline_info_get(None, None) == -1
+
+
 def test_profiles_index_is_current():
     """profiles/INDEX.md lists every committed measurement with the documents and sources that cite it (tools/make_profiles_index.py writes it)."""
     import subprocess

@@ -926,12 +926,21 @@ def test_a_frame_may_be_reduced_again_after_more_iterations(monkeypatch):
         return g
 
     comm = backend.Communicator(1, 0)
+    assert comm.query() == (1, 0) and comm.size == 1      # ncclCommCount / ncclCommUserRank of the communicator itself (a real one: PRGPU_COMM_FORCE_RCCL)
     a = fresh()
+    assert a.reducedPlanes() is None                     # nothing reduced yet: the rank's own planes are the frame
     a.render(4)
+    a.setTiming(True)
     a.reduce(comm)
     a.waitForFinish()
+    ms, launches = a.kernelTime("reduce")                 # the collective alone: HIP events around the RCCL group (bench.py: config.reduce_ms)
+    assert launches == 1 and 0.0 < ms < 1000.0
+    a.setTiming(False)
+    planes = a.reducedPlanes()                            # device pointers of the root-side sums, for a host that keeps its frame on the device
+    assert planes is not None and all(planes) and len(set(planes)) == 3
     mid = a.output()
     a.render(4)                      # the rank's own planes were not touched by the reduce
+    assert a.reducedPlanes() is None                     # (a render call makes the reduced frame stale)
     own = a.output()                 # (no reduce since the last render call: the rank's own planes)
     a.reduce(comm)
     a.waitForFinish()

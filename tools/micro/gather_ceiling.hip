@@ -14,7 +14,7 @@
 // hold -- the kernel's L2 hit rate on C4 is 0.47), the rest is uniform over the table (L2 hit rate ~ 4 MiB / table).
 // It prints G records/s and ns per dependent step, so that the kernel's 71.6 G records/s can be read against the attainable rate AT ITS
 // OWN SHAPE (profiles/r05_gather_ceiling.txt; bench.py quotes the "per-lane, 12 waves, 39 lanes, 140/340 instructions" line).
-//   build: hipcc --offload-arch=gfx950 -O3 tools/micro/gather_ceiling.hip -o tools/micro/gather_ceiling      run: tools/micro/gather_ceiling [table MB] [hot fraction] [hot MB]
+//   build: hipcc --offload-arch=gfx950 -O3 tools/micro/gather_ceiling.hip -o tools/micro/gather_ceiling      run: tools/micro/gather_ceiling [table MB] [hot fraction] [hot MB] [inner records per ray] [leaf records per ray]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -150,7 +150,7 @@ int main(int argc, char** argv)
 	hipEvent_t a, b;
 	hipEventCreate(&a);
 	hipEventCreate(&b);
-	const double inner_per_ray = 41.25, leaf_per_ray = 9.36; // C4, bench.py
+	const double inner_per_ray = argc > 4 ? atof(argv[4]) : 41.25, leaf_per_ray = argc > 5 ? atof(argv[5]) : 9.36; // records per ray (default: C4, bench.py)
 	const uint32_t leaf_threshold = (uint32_t)(4294967296.0 * leaf_per_ray / (inner_per_ray + leaf_per_ray));
 	const uint32_t hot_threshold = (uint32_t)(4294967295.0 * hot), hot_units = (uint32_t)(hot_mb * 1e6 / 64.0) & ~1u;
 	printf("table %.0f MB (%u units of 64 B), %d CUs; records per ray %.2f inner (48 of 64 B loaded) + %.2f leaf (128 B); one kind per wave step; %.0f %% of the fetches in a hot set of %.1f MB\n",
