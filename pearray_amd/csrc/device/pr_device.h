@@ -15,6 +15,7 @@
 #ifndef PR_INLINE_CLOSURES
 #define PR_INLINE_CLOSURES 0
 #endif
+
 #if PR_INLINE_CLOSURES
 #define PR_CLOSURE __forceinline__
 #else
@@ -208,6 +209,9 @@ struct DevScene {
 	float eps_t; // slab-test slack: 8e-6 * max |coordinate| over world vertices and the camera origin
 	const DevQuadric* quadrics; // quadric entities, or null (last: see DevEntity::has_uvs)
 	uint32_t n_quadrics;
+	const float4* shade_rec; // one 128-byte SHADING RECORD per triangle (round 5): floats 0..8 the three vertices' local normals (zeros without), 9..17 their local
+							 // positions, 18..23 their texture coordinates (zeros without), 24 entity id, 25 material id -- copies of what geometry_point used to
+							 // gather from the index, vertex, normal, uv, entity-id and material-id buffers (six to nine cache lines, two dependent round trips)
 };
 
 // Per-path state, SoA, indexed by slot (= position of the pixel in the Morton-ordered owned list).

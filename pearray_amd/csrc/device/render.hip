@@ -492,9 +492,12 @@ __device__ __forceinline__ uint32_t prim_id(const DevScene& sc, uint32_t tri)
 template <uint32_t FEATS>
 __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri, float u, float v, V3 P, GeomPoint& g)
 {
-	const uint32_t e   = sc.tri_entity[tri];
+	// the triangle's shading record (DevScene::shade_rec): one 128-byte line with what the mesh branch below needs -- MeshBase::getFace
+	// (mesh/MeshBase.inl:96-134) gathers the same values through the index buffer
+	const float4* __restrict__ sr = sc.shade_rec + size_t(8) * tri;
+	const float4 r0 = sr[0], r1 = sr[1], r2 = sr[2], r3 = sr[3], r4 = sr[4], r5 = sr[5], r6 = sr[6];
+	const uint32_t e   = __float_as_uint(r6.x);
 	const DevEntity& E = sc.entities[e];
-	const uint32_t i0 = sc.indices[3 * tri], i1 = sc.indices[3 * tri + 1], i2 = sc.indices[3 * tri + 2];
 	V3 N, Nx, Ny;
 	if ((FEATS & FEAT_SPHERES) && E.kind == PRGPU_ENTITY_SPHERE) { // SphereEntity::provideGeometryPoint (sphere.cpp:118-129)
 		g.N = normalized(P - v3(E.m[3], E.m[7], E.m[11]));
@@ -540,23 +543,26 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 		return;
 	}
 	const bool has_uv = (FEATS & FEAT_TEXTURES) && E.has_uvs != 0u; // MeshEntity<.., HasUV> (mesh.cpp:205-228)
+	const V3 n0 = v3(r0.x, r0.y, r0.z), n1 = v3(r0.w, r1.x, r1.y), n2 = v3(r1.z, r1.w, r2.x);
+	const V3 p0 = v3(r2.y, r2.z, r2.w), p1 = v3(r3.x, r3.y, r3.z), p2 = v3(r3.w, r4.x, r4.y);
+	const float uv0[2] = { r4.z, r4.w }, uv1[2] = { r5.x, r5.y }, uv2[2] = { r5.z, r5.w };
 	if (FEATS & (FEAT_TEXTURES | FEAT_AOVS)) {
-		if (has_uv) { // Face::interpolateUVs (Face.h:39-45) = Triangle::interpolate (Triangle.h:23-27)
+		if (has_uv) {
 			for (int c = 0; c < 2; ++c)
-				g.uv[c] = (sc.uvs[2 * i1 + c] * u + sc.uvs[2 * i2 + c] * v) + sc.uvs[2 * i0 + c] * (1 - u - v);
+				g.uv[c] = (uv1[c] * u + uv2[c] * v) + uv0[c] * (1 - u - v);
 		} else {
 			g.uv[0] = u;
 			g.uv[1] = v;
 		}
 	}
 	if (E.has_normals) {
-		N = tri_interp(load3(sc.normals, i0), load3(sc.normals, i1), load3(sc.normals, i2), u, v);
-		if (has_uv) { // Face::tangentFromUV (Face.h:80-98) with the interpolated, unnormalised normal
-			const V3 dp1 = load3(sc.positions, i1) - load3(sc.positions, i0), dp2 = load3(sc.positions, i2) - load3(sc.positions, i0);
-			const float du1 = sc.uvs[2 * i1] - sc.uvs[2 * i0], dv1 = sc.uvs[2 * i1 + 1] - sc.uvs[2 * i0 + 1];
-			const float du2 = sc.uvs[2 * i2] - sc.uvs[2 * i0], dv2 = sc.uvs[2 * i2 + 1] - sc.uvs[2 * i0 + 1];
+		N = tri_interp(n0, n1, n2, u, v);
+		if (has_uv) {
+			const V3 dp1 = p1 - p0, dp2 = p2 - p0;
+			const float du1 = uv1[0] - uv0[0], dv1 = uv1[1] - uv0[1];
+			const float du2 = uv2[0] - uv0[0], dv2 = uv2[1] - uv0[1];
 			const float det = diff_prod(dv2, du1, dv1, du2);
-			if (det <= PR_EPS) { // Tangent::frame
+			if (det <= PR_EPS) {
 				frame_duff(N, Nx, Ny);
 				Nx = normalized_or_zero(Nx);
 				Ny = normalized_or_zero(Ny);
@@ -571,8 +577,8 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 			frame_duff(N, Nx, Ny);
 		}
 	} else {
-		Nx = load3(sc.positions, i1) - load3(sc.positions, i0);
-		Ny = load3(sc.positions, i2) - load3(sc.positions, i0);
+		Nx = p1 - p0;
+		Ny = p2 - p0;
 		N  = cross(Nx, Ny);
 	}
 	g.N		   = normalized(mat3_mul(E.nm, N));
@@ -580,7 +586,7 @@ __device__ __forceinline__ void geometry_point(const DevScene& sc, uint32_t tri,
 	g.Ny	   = normalized(mat3_mul(E.nm, Ny));
 	g.entity   = e;
 	g.prim	   = tri - E.first_tri;
-	g.material = sc.tri_material[tri];
+	g.material = __float_as_uint(r6.y);
 	g.emission = E.emission;
 }
 
@@ -1619,9 +1625,9 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	const bool with_lpe	 = (FEATS & FEAT_LPE) && ps.lpe != nullptr;
 	uint32_t lpe		 = with_lpe ? ps.lpe->state[slot] : 0u; // automaton states after the path's tokens so far
 
-	if (depth == 0) {
-		ps.prim_entity[pixel] = tri == INVALID ? INVALID : sc.tri_entity[tri];
-		ps.prim_prim[pixel]	  = tri == INVALID ? INVALID : prim_id(sc, tri);
+	if (depth == 0 && tri == INVALID) { // (a hit's ids are written below, once the geometry point has them)
+		ps.prim_entity[pixel] = INVALID;
+		ps.prim_prim[pixel]	  = INVALID;
 	}
 	if (tri == INVALID) {
 		atomicAdd(&bs.v[PRGPU_STAT_BACKGROUND_HITS], 1u);
@@ -1681,6 +1687,10 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 		const V3 P = ray_o + ray_d * hit4.x;
 		GeomPoint gp;
 		geometry_point<FEATS>(sc, tri, hit4.y, hit4.z, P, gp);
+		if (depth == 0) { // primary-visibility plane (prgpu_download_primary_hits): entity and Embree primID of the camera ray's hit
+			ps.prim_entity[pixel] = gp.entity;
+			ps.prim_prim[pixel]	  = gp.prim;
+		}
 		const V3 N		   = gp.N;
 		const float NdotV  = dot(ray_d, N);
 		const V3 dP		   = ray_o - P;

@@ -407,6 +407,27 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		UP(sc.tri_class, cls);
 	}
 	UP(sc.entities, t.entities);
+	{ // shading records: 128 bytes per triangle with the values geometry_point reads (copies: the arithmetic on them is unchanged; pr_device.h, DevScene::shade_rec)
+		std::vector<float> rec(size_t(32) * d->n_triangles, 0.0f);
+		for (uint32_t i = 0; i < d->n_triangles; ++i) {
+			float* r = rec.data() + size_t(32) * i;
+			const uint32_t e = t.tri_entity[i];
+			for (int k = 0; k < 3; ++k) {
+				const uint32_t v = d->indices[3 * i + k];
+				for (int c = 0; c < 3; ++c) {
+					r[3 * k + c]	 = d->normals && d->entities[e].has_normals ? d->normals[3 * size_t(v) + c] : 0.0f;
+					r[9 + 3 * k + c] = d->positions[3 * size_t(v) + c];
+				}
+				for (int c = 0; c < 2; ++c)
+					r[18 + 2 * k + c] = d->uvs ? d->uvs[2 * size_t(v) + c] : 0.0f;
+			}
+			std::memcpy(&r[24], &e, 4);
+			std::memcpy(&r[25], &d->tri_material[i], 4);
+		}
+		const float* up = nullptr;
+		UP(up, rec);
+		sc.shade_rec = reinterpret_cast<const float4*>(up);
+	}
 	{
 		std::vector<prd::DevMaterial> mats(std::max<uint32_t>(1, d->n_materials));
 		std::memset(mats.data(), 0, mats.size() * sizeof(prd::DevMaterial));
