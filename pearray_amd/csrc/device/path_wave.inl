@@ -169,7 +169,7 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 			if (mine) { // the NEE fragment of the slot's previous vertex, now that its shadow ray has reported
 				const uint32_t pw = pend[slot_l];
 				if (pw & PP_SHADOW) {
-					const float4 x		 = ps.sh_xyz[slot];
+					const float4 x		 = ps.st[slot].sh_xyz;
 					const uint32_t fbs	 = __float_as_uint(x.w);
 					const uint32_t pixel = ps.pixel[slot];
 					if (pw & PP_VISIBLE) {
@@ -201,7 +201,7 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 					iter  = ps.iter[slot];
 					index = a.slot_index[slot];
 					if (ps.cost)
-						ps.cost[pixel] += (ps.flags[slot] & 0xFFu) + 1u;
+						ps.cost[pixel] += (ps.st[slot].flags & 0xFFu) + 1u;
 					if (!ps.plane_stride) {
 						const float v[3] = { ps.iter_xyz[3 * pixel], ps.iter_xyz[3 * pixel + 1], ps.iter_xyz[3 * pixel + 2] };
 						fold_iteration(ps, pixel, iter, v, (FEATS & FEAT_LPE) != 0u);
@@ -232,9 +232,9 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 			live -= (uint32_t)wave_popc(lane_ballot(retired));
 			if (mine && !retired) {
 				if (want_shadow) {
-					ps.sh_o[slot]	= sh_o;
-					ps.sh_d[slot]	= sh_d;
-					ps.sh_xyz[slot] = sh_xyz;
+					ps.st[slot].sh_o	= sh_o;
+					ps.st[slot].sh_d	= sh_d;
+					ps.st[slot].sh_xyz = sh_xyz;
 				}
 				pend[slot_l] = (alive ? 1u : 0u) + (want_shadow ? 1u + PP_SHADOW : 0u) + (alive ? 0u : PP_DEAD);
 			}
@@ -244,7 +244,7 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 			{ // rays in flight were parked during the pass: rebuild their traversal constants (same values)
 				const uint32_t pslot = slot0 + (has_ray ? (my_entry & ~PP_ANY) : 0u);
 				const bool pany		 = has_ray && (my_entry & PP_ANY) != 0;
-				const float4 ro = pany ? ps.sh_o[pslot] : ps.ray_o[pslot], rd = pany ? ps.sh_d[pslot] : ps.ray_d[pslot];
+				const float4 ro = pany ? ps.st[pslot].sh_o : ps.st[pslot].ray_o, rd = pany ? ps.st[pslot].sh_d : ps.st[pslot].ray_d;
 				s.r	   = ray_prepare(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), sc.eps_t);
 				s.tmin = ro.w + 0.0f; // (as trav_begin)
 				s.any  = pany;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 				my_entry			= q_ray[(ray_head + r) & RAY_MASK];
 				const uint32_t slot = slot0 + (my_entry & ~PP_ANY);
 				const bool any		= (my_entry & PP_ANY) != 0;
-				const float4 ro = any ? ps.sh_o[slot] : ps.ray_o[slot], rd = any ? ps.sh_d[slot] : ps.ray_d[slot];
+				const float4 ro = any ? ps.st[slot].sh_o : ps.st[slot].ray_o, rd = any ? ps.st[slot].sh_d : ps.st[slot].ray_d;
 				trav_begin(s, st, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, any ? rd.w - 0.001f : rd.w, sc.eps_t); // tfar rule: Scene.cpp:275
 				s.any	= any;
 				has_ray = true;

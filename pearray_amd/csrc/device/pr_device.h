@@ -214,24 +214,27 @@ struct DevScene {
 							 // gather from the index, vertex, normal, uv, entity-id and material-id buffers (six to nine cache lines, two dependent round trips)
 };
 
-// Per-path state, SoA, indexed by slot (= position of the pixel in the Morton-ordered owned list).
+// Per-path state of one slot: 256 bytes = two 128-byte lines (round 5; thirteen arrays before: a vertex pass's lanes hold arbitrary slots, so every
+// array cost every lane a line of its own -- thirteen lines read and eight written per vertex, ~ 1.7 KB of 128-byte fabric lines for 300 useful
+// bytes).  Line 0 is what a ray pick-up or write-out touches (the ray, the hit, the flags, the shadow ray), line 1 the rest of what a pass reads.
+struct __attribute__((aligned(128))) SlotState {
+	float4 ray_o, ray_d; // o.xyz, tmin | d.xyz, tmax
+	float4 hit;			 // t, u, v, original triangle index bits (INVALID on miss)
+	uint32_t flags, pad[3]; // depth | mono << 8 | last_delta << 9 | last_emissive << 10 ...
+	float4 sh_o, sh_d;	 // persistent kernels: the slot's shadow ray (o.xyz, tmin | d.xyz, distance)
+	float4 wl, wl_pdf;
+	float4 cie_x, cie_y, cie_z; // CIE XYZ responses of the four wavelengths of the path (CIE::eval, computed once per camera sample)
+	float4 throughput, path_pdf, prev_pdf;
+	float4 last_pos; // previous path vertex (TraversalContext::LastPosition, direct.cpp:55,175), kept for scenes with plane lights
+	float4 sh_xyz;	 // persistent kernels: the shadow ray's fragment (xyz if visible, w = feedback bits)
+};
+static_assert(sizeof(SlotState) == 256, "SlotState must be two 128-byte lines");
+// Per-path state indexed by slot (= position of the pixel in the Morton-ordered owned list), and the per-pixel planes.
 struct PathState {
 	uint64_t* rng;	 // per PIXEL
 	uint32_t* pixel; // slot -> pixel
-	float4* ray_o;	 // o.xyz, tmin
-	float4* ray_d;	 // d.xyz, tmax
-	float4* wl;
-	float4* wl_pdf;
-	float4* cie_x;	 // CIE XYZ responses of the four wavelengths of the path (CIE::eval, computed once per camera sample)
-	float4* cie_y;
-	float4* cie_z;
-	float4* throughput;
-	float4* path_pdf;
-	float4* prev_pdf;
-	float4* last_pos; // previous path vertex (TraversalContext::LastPosition, direct.cpp:55,175), kept for scenes with plane lights
-	uint32_t* flags; // depth | mono<<8 | last_delta<<9 | last_emissive<<10
+	struct SlotState* st; // per-slot path state, one 256-byte record per slot (below)
 	uint32_t* iter;	 // sample index of the path currently living in the slot
-	float4* hit;	 // t,u,v, original tri index bits (INVALID on miss)
 	// shadow queue records
 	float4* sh_o;	   // o.xyz, tmin
 	float4* sh_d;	   // d.xyz, distance

@@ -898,30 +898,30 @@ __device__ __forceinline__ bool camera_path(const DevScene& sc, const PathState&
 	const bool mono	   = cfg.spectral_mono || !cfg.spectral_hero; // RenderTile.cpp:123-124
 	ps.rng[pixel]	   = rnd;
 	if (has_ray) {
-		ps.ray_o[slot] = make_float4(o.x, o.y, o.z, cam.near_t);
-		ps.ray_d[slot] = make_float4(d.x, d.y, d.z, cam.far_t);
+		ps.st[slot].ray_o = make_float4(o.x, o.y, o.z, cam.near_t);
+		ps.st[slot].ray_d = make_float4(d.x, d.y, d.z, cam.far_t);
 	} else { // an empty interval: the traversal misses at the root
-		ps.ray_o[slot] = make_float4(o.x, o.y, o.z, 1.0f);
-		ps.ray_d[slot] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+		ps.st[slot].ray_o = make_float4(o.x, o.y, o.z, 1.0f);
+		ps.st[slot].ray_d = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
 	}
-	ps.wl[slot]		   = to4(wl);
-	ps.wl_pdf[slot]	   = to4(wl_pdf);
+	ps.st[slot].wl		   = to4(wl);
+	ps.st[slot].wl_pdf	   = to4(wl_pdf);
 	{ // the path's wavelengths are fixed: evaluate the CIE response once instead of once per fragment
 		float c0[3], c1[3], c2[3], c3[3];
 		cie_eval(sc.cie, wl.v[0], c0);
 		cie_eval(sc.cie, wl.v[1], c1);
 		cie_eval(sc.cie, wl.v[2], c2);
 		cie_eval(sc.cie, wl.v[3], c3);
-		ps.cie_x[slot] = make_float4(c0[0], c1[0], c2[0], c3[0]);
-		ps.cie_y[slot] = make_float4(c0[1], c1[1], c2[1], c3[1]);
-		ps.cie_z[slot] = make_float4(c0[2], c1[2], c2[2], c3[2]);
+		ps.st[slot].cie_x = make_float4(c0[0], c1[0], c2[0], c3[0]);
+		ps.st[slot].cie_y = make_float4(c0[1], c1[1], c2[1], c3[1]);
+		ps.st[slot].cie_z = make_float4(c0[2], c1[2], c2[2], c3[2]);
 	}
-	ps.throughput[slot] = make_float4(1, 1, 1, 1);
-	ps.path_pdf[slot]  = make_float4(1, 1, 1, 1);
-	ps.prev_pdf[slot]  = make_float4(1, 1, 1, 1);
+	ps.st[slot].throughput = make_float4(1, 1, 1, 1);
+	ps.st[slot].path_pdf  = make_float4(1, 1, 1, 1);
+	ps.st[slot].prev_pdf  = make_float4(1, 1, 1, 1);
 	if (sc.features & FEAT_SHAPE_LIGHTS)
-		ps.last_pos[slot] = make_float4(0, 0, 0, 0); // TraversalContext::LastPosition starts at the world origin (direct.cpp:55)
-	ps.flags[slot]	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA | (has_ray ? 0u : FLAG_NO_RAY);
+		ps.st[slot].last_pos = make_float4(0, 0, 0, 0); // TraversalContext::LastPosition starts at the world origin (direct.cpp:55)
+	ps.st[slot].flags	   = 0u | (mono ? (FLAG_MONO | FLAG_GROUP_MONO) : 0u) | FLAG_LAST_DELTA | (has_ray ? 0u : FLAG_NO_RAY);
 	if (with_lpe && ps.lpe) { // the path starts with its camera token (direct.cpp:67)
 		const DevLpe& L	   = *ps.lpe;
 		L.state[slot]	   = lpe_step(ps.lpe, 0u, LPE_SYM_CAMERA);
@@ -1002,7 +1002,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 	}
 	auto load = [&](uint32_t i, V3& o, V3& d, float& tmin, float& tmax) {
 		const uint32_t slot = active ? active[i] : slot_base + i;
-		const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+		const float4 ro = ps.st[slot].ray_o, rd = ps.st[slot].ray_d;
 		o	 = v3(ro.x, ro.y, ro.z);
 		d	 = v3(rd.x, rd.y, rd.z);
 		tmin = ro.w;
@@ -1010,7 +1010,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 	};
 	auto store = [&](uint32_t i, const Hit& h) {
 		const uint32_t slot = active ? active[i] : slot_base + i;
-		ps.hit[slot]		= make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+		ps.st[slot].hit		= make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
 	};
 	trace_persistent<false, COUNT>(sc, n_active, queue_head, spill, refill_below, load, store, gstats);
 }
@@ -1018,7 +1018,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_trace_closest(DevScene sc, PathS
 #endif // PR_TU == 0
 // handleCameraVertex / handleDirectHit / handleNEE / handleScattering (direct.cpp:73-412), Walker::traverse
 // (vcm/Walker.h:23-54), handleZero (:459-464), IntegratorUtils::handleBackgroundGroup (IntegratorUtils.h:16-53).
-// Processes the path vertex of `slot` whose closest hit is in ps.hit[slot]: adds emission, prepares the NEE shadow ray
+// Processes the path vertex of `slot` whose closest hit is in ps.st[slot].hit: adds emission, prepares the NEE shadow ray
 // (returned in sh_*, want_shadow) and the next bounce ray (written to the slot, alive).
 // FEATS = the FEAT_* bits compiled in.  FEATS = 0 is the lean variant for scenes with Lambert materials, mesh entities and area lights only
 // (DevScene::features == 0, e.g. the C4 benchmark scene): delta and rough materials, infinite lights, planes, spheres, textures and AOVs
@@ -1597,27 +1597,27 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 	const prgpu_settings& cfg = sc.cfg;
 	const uint32_t pixel = ps.pixel[slot];
 	const size_t entry	 = iter_entry(ps, slot, pixel);
-	const float4 ro = ps.ray_o[slot], rd = ps.ray_d[slot];
+	const float4 ro = ps.st[slot].ray_o, rd = ps.st[slot].ray_d;
 	const V3 ray_o = v3(ro.x, ro.y, ro.z), ray_d = v3(rd.x, rd.y, rd.z);
-	const float4 hit4  = hit_src ? *hit_src : ps.hit[slot];
+	const float4 hit4  = hit_src ? *hit_src : ps.st[slot].hit;
 	const uint32_t tri = __float_as_uint(hit4.w);
-	uint32_t flags	   = ps.flags[slot];
+	uint32_t flags	   = ps.st[slot].flags;
 	if (flags & FLAG_NO_RAY) // the camera had no ray for this sample (camera_path): nothing was traced, nothing is splatted
 		return;
 	const uint32_t depth = flags & 0xFFu;
 	const bool mono		 = (flags & FLAG_MONO) != 0;
-	const Blob wl		 = from4(ps.wl[slot]);
-	const Blob wvl_pdf	 = from4(ps.wl_pdf[slot]);
+	const Blob wl		 = from4(ps.st[slot].wl);
+	const Blob wvl_pdf	 = from4(ps.st[slot].wl_pdf);
 	PathCie cie;
 	{
-		const float4 cx = ps.cie_x[slot], cy = ps.cie_y[slot], cz = ps.cie_z[slot];
+		const float4 cx = ps.st[slot].cie_x, cy = ps.st[slot].cie_y, cz = ps.st[slot].cie_z;
 		cie.x[0] = cx.x; cie.x[1] = cx.y; cie.x[2] = cx.z; cie.x[3] = cx.w;
 		cie.y[0] = cy.x; cie.y[1] = cy.y; cie.y[2] = cy.z; cie.y[3] = cy.w;
 		cie.z[0] = cz.x; cie.z[1] = cz.y; cie.z[2] = cz.z; cie.z[3] = cz.w;
 	}
-	Blob throughput		 = from4(ps.throughput[slot]);
-	Blob path_pdf		 = from4(ps.path_pdf[slot]);
-	Blob prev_pdf		 = from4(ps.prev_pdf[slot]);
+	Blob throughput		 = from4(ps.st[slot].throughput);
+	Blob path_pdf		 = from4(ps.st[slot].path_pdf);
+	Blob prev_pdf		 = from4(ps.st[slot].prev_pdf);
 	const Blob grp_imp	 = (flags & FLAG_GROUP_MONO) ? hero_only() : blob(1.0f); // RenderTile.cpp:126-127 (importance of the ray group)
 	const float blend	 = 1.0f;
 	const bool power_mis = cfg.mis == PRGPU_MIS_POWER;
@@ -1741,7 +1741,7 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const float selProb	 = sc.light_cdf[lid + 1] - sc.light_cdf[lid];
 					float posPDF		 = 1.0f / sc.entities[gp.entity].world_area;
 					if ((FEATS & FEAT_SHAPE_LIGHTS) && sc.entities[gp.entity].kind == PRGPU_ENTITY_PLANE) { // seen from the previous vertex (plane.cpp:184-195)
-						const float4 lpos = ps.last_pos[slot];
+						const float4 lpos = ps.st[slot].last_pos;
 						posPDF			  = plane_light_pdf(sc.shape_lights[gp.entity], P, v3(lpos.x, lpos.y, lpos.z));
 					} else if ((FEATS & FEAT_SHAPE_LIGHTS) && sc.entities[gp.entity].kind == PRGPU_ENTITY_SPHERE) {
 						posPDF = 2 * sc.shape_lights[gp.entity].pdf_cache; // sphere.cpp:118
@@ -2055,14 +2055,14 @@ __device__ __forceinline__ void shade_vertex(const DevScene& sc, const PathState
 					const uint32_t nd = depth + 1;
 					if (nd < cfg.max_ray_depth) {
 						alive				= true;
-						ps.ray_o[slot]		= make_float4(no.x, no.y, no.z, BOUNCE_RAY_MIN);
-						ps.ray_d[slot]		= make_float4(L.x, L.y, L.z, far_t);
-						ps.throughput[slot] = to4(throughput);
-						ps.path_pdf[slot]	= to4(path_pdf);
-						ps.prev_pdf[slot]	= to4(prev_pdf);
+						ps.st[slot].ray_o		= make_float4(no.x, no.y, no.z, BOUNCE_RAY_MIN);
+						ps.st[slot].ray_d		= make_float4(L.x, L.y, L.z, far_t);
+						ps.st[slot].throughput = to4(throughput);
+						ps.st[slot].path_pdf	= to4(path_pdf);
+						ps.st[slot].prev_pdf	= to4(prev_pdf);
 						if ((FEATS & FEAT_SHAPE_LIGHTS) && (sc.features & FEAT_SHAPE_LIGHTS))
-							ps.last_pos[slot] = make_float4(P.x, P.y, P.z, 0.0f); // current.LastPosition (direct.cpp:175)
-						ps.flags[slot]		= (flags & ~0xFFu) | nd;
+							ps.st[slot].last_pos = make_float4(P.x, P.y, P.z, 0.0f); // current.LastPosition (direct.cpp:175)
+						ps.st[slot].flags		= (flags & ~0xFFu) | nd;
 						if (with_lpe)
 							ps.lpe->state[slot] = lpe;
 						atomicAdd(&bs.v[PRGPU_STAT_CAMERA_RAYS], 1u);
@@ -2465,7 +2465,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				if (mine) { // the NEE fragment of the slot's previous vertex, now that its shadow ray has reported (see the end of the ray loop)
 					const uint32_t pw = lds_load(&sh.pending[slot_l]);
 					if (pw & PP_SHADOW) {
-						const float4 x		 = ps.sh_xyz[slot];
+						const float4 x		 = ps.st[slot].sh_xyz;
 						const uint32_t fbs	 = __float_as_uint(x.w);
 						const uint32_t pixel = ps.pixel[slot];
 						if (pw & PP_VISIBLE) {
@@ -2500,7 +2500,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					if (pixel != INVALID) {
 						iter = ps.iter[slot];
 						if (ps.cost)
-							ps.cost[pixel] += (ps.flags[slot] & 0xFFu) + 1u;
+							ps.cost[pixel] += (ps.st[slot].flags & 0xFFu) + 1u;
 						if (!ps.plane_stride) { // single-tap filter: the sample folds into the running mean right here; with a ring of
 												// planes the launch only fills the planes and k_resolve gathers the taps afterwards
 							const float v[3] = { ps.iter_xyz[3 * pixel], ps.iter_xyz[3 * pixel + 1], ps.iter_xyz[3 * pixel + 2] };
@@ -2641,9 +2641,9 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 					__hip_atomic_fetch_sub(&sh.live, (uint32_t)n_retired, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 				if (mine && !retired) {
 					if (want_shadow) {
-						ps.sh_o[slot]	= sh_o;
-						ps.sh_d[slot]	= sh_d;
-						ps.sh_xyz[slot] = sh_xyz;
+						ps.st[slot].sh_o	= sh_o;
+						ps.st[slot].sh_d	= sh_d;
+						ps.st[slot].sh_xyz = sh_xyz;
 					}
 					__hip_atomic_store(&sh.pending[slot_l], (alive ? 1u : 0u) + (want_shadow ? 1u + PP_SHADOW : 0u) + (alive ? 0u : PP_DEAD), __ATOMIC_RELAXED,
 									   __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2655,7 +2655,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				  // holding them in registers across the shading code
 					const uint32_t pslot = slot0 + (has_ray ? (my_entry & ~PP_ANY) : 0u);
 					const bool pany		 = has_ray && (my_entry & PP_ANY) != 0;
-					const float4 ro = pany ? ps.sh_o[pslot] : ps.ray_o[pslot], rd = pany ? ps.sh_d[pslot] : ps.ray_d[pslot];
+					const float4 ro = pany ? ps.st[pslot].sh_o : ps.st[pslot].ray_o, rd = pany ? ps.st[pslot].sh_d : ps.st[pslot].ray_d;
 					s.r	   = ray_prepare(v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), sc.eps_t);
 					s.tmin = ro.w + 0.0f; // (as trav_begin)
 					s.any  = pany;
@@ -2692,7 +2692,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 				my_entry			= ring_take(sh.q_ray, RAY_MASK, first + r);
 				const uint32_t slot = slot0 + (my_entry & ~PP_ANY);
 				const bool any		= (my_entry & PP_ANY) != 0;
-				const float4 ro = any ? ps.sh_o[slot] : ps.ray_o[slot], rd = any ? ps.sh_d[slot] : ps.ray_d[slot];
+				const float4 ro = any ? ps.st[slot].sh_o : ps.st[slot].ray_o, rd = any ? ps.st[slot].sh_d : ps.st[slot].ray_d;
 				trav_begin(s, st, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, any ? rd.w - 0.001f : rd.w, sc.eps_t); // tfar rule: Scene.cpp:275
 				s.any	= any;
 				has_ray = true;
@@ -2813,7 +2813,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						if (s.best.tri == INVALID)
 							add += PP_VISIBLE;
 					} else {
-						ps.hit[slot] = make_float4(s.best.t, s.best.u, s.best.v, __uint_as_float(s.best.tri));
+						ps.st[slot].hit = make_float4(s.best.t, s.best.u, s.best.v, __uint_as_float(s.best.tri));
 						if (NQ > 1) // the class of the material it hit travels in the pending word (the leaf record carried it: no lookup here)
 							add += (s.cls & 3u) << PP_CLS_SHIFT;
 					}
@@ -3218,7 +3218,7 @@ __global__ void __launch_bounds__(256) k_ray_sort_keys(PathState ps, const uint3
 	if (i >= n)
 		return;
 	const uint32_t slot = active[i];
-	const float4 o = ps.ray_o[slot], d = ps.ray_d[slot];
+	const float4 o = ps.st[slot].ray_o, d = ps.st[slot].ray_d;
 	const float inv = radius > 0.0f ? 256.0f / radius : 0.0f; // (o + R) / (2 R) * 512
 	const uint32_t qx = (uint32_t)fminf(fmaxf((o.x + radius) * inv, 0.0f), 511.0f), qy = (uint32_t)fminf(fmaxf((o.y + radius) * inv, 0.0f), 511.0f),
 				   qz = (uint32_t)fminf(fmaxf((o.z + radius) * inv, 0.0f), 511.0f);

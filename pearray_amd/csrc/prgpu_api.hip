@@ -598,19 +598,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	AL(ps.rng, np, false);
 	HIP_TRY(hipMemcpyAsync(ps.rng, t.rng.data(), size_t(np) * 8, hipMemcpyHostToDevice, s->stream));
 	AL(ps.pixel, np, false);
-	AL(ps.ray_o, ns, false);
-	AL(ps.ray_d, ns, false);
-	AL(ps.wl, ns, false);
-	AL(ps.wl_pdf, ns, false);
-	AL(ps.cie_x, ns, false);
-	AL(ps.cie_y, ns, false);
-	AL(ps.cie_z, ns, false);
-	AL(ps.throughput, ns, false);
-	AL(ps.path_pdf, ns, false);
-	AL(ps.prev_pdf, ns, false);
-	AL(ps.last_pos, ns, false);
-	AL(ps.flags, ns, false);
-	AL(ps.hit, ns, false);
+	AL(ps.st, ns, false);
 	AL(ps.sh_o, ns, false);
 	AL(ps.sh_d, ns, false);
 	AL(ps.sh_xyz, ns, false);
