@@ -174,7 +174,8 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u", owned_fraction=1.0, 
     if persistent:
         # one launch = `iters` iterations of everything: closest-hit and occlusion traversal + shading, fused
         name = "k_path_latency" if kinfo["kernel"] == "latency" else "k_path_persistent_occ3"
-        kernel, substr = name, "%s<false,%s>" % (name, variant)  # the instantiation the scene's features select
+        # the instantiation the scene's features (and, for the throughput kernel, the width of its BVH records) select
+        kernel, substr = name, "%s<false,%s%s>" % (name, variant, "" if kinfo["kernel"] == "latency" else (",true" if kinfo["bvh_width"] == 6 else ",false"))
         ms, n = fam["path"]
         alg_bytes = (bytes_closest + bytes_any) / n          # per launch
         iters_per_launch = iters / n
@@ -199,13 +200,16 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u", owned_fraction=1.0, 
     records_per_s = records / n / (avg_ms * 1e-3)
     ceiling, ceiling_src = gather_ceiling() if variant == "0u" else (None, None)   # (measured at the C4 loop's shape: record mix, table size, lane fill)
     # the same bytes with an inner record counted as the 48 bytes the step loads instead of the 64-byte unit the memory side moves
-    achieved48 = (alg_bytes - 16.0 * inner / n) / (avg_ms * 1e-3) / 1e9
+    # (a six-wide tree's step loads all 64)
+    achieved48 = (alg_bytes - (16.0 if kinfo["bvh_width"] == 4 else 0.0) * inner / n) / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": round(traffic_bytes / (avg_ms * 1e-3) / 1e9, 1) if traffic_bytes else None,
             "traffic_bytes_per_launch": traffic_bytes, "traffic_source": src, "traffic_unavailable": why_not, "pmc": dict(PMC_EXTRA) if traffic_bytes else None,
             "traffic_scaled_to_owned_fraction": round(owned_fraction, 6) if (traffic_bytes and owned_fraction != 1.0) else None,
             "kernel": kernel, "kernel_organisation": kinfo["kernel"], "shader_waves": kinfo["shader_waves"], "shading_share": round(kinfo["shading_share"], 4),
             "grid": [kinfo["blocks"], kinfo["slots_per_block"]], "avg_launch_ms": round(avg_ms, 4),
+            # children per inner record, chosen per scene by the builder from its estimate of either tree (inner records per ray through the scene's box)
+            "bvh_width": kinfo["bvh_width"], "bvh_cost_estimate": {"4_wide": round(kinfo["bvh_cost_4_wide"], 2), "6_wide": round(kinfo["bvh_cost_6_wide"], 2)},
             "launches": n, "iterations_per_launch": iters_per_launch, "algorithmic_bytes_per_launch": round(alg_bytes),
             "algorithmic_bytes_per_closest_ray": round(bytes_closest / max(d["rays_closest"], 1), 1),
             "algorithmic_bytes_per_occlusion_ray": round(bytes_any / max(d["rays_any"], 1), 1),

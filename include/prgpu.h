@@ -396,6 +396,8 @@ typedef struct prgpu_pipeline_info {
 	uint32_t kernel;               /* PRGPU_KERNEL_* of the last launch: the block-queue throughput kernel or the wave-autonomous latency kernel */
 	uint32_t blocks, slots_per_block; /* grid of the last launch */
 	uint64_t launches;             /* persistent launches since the scene was created */
+	uint32_t bvh_width;            /* children per inner record of the scene's BVH: 4 or 6 (PRGPU_BVH_WIDTH; chosen per scene by default) */
+	float    bvh_cost_4_wide, bvh_cost_6_wide; /* the builder's estimate for either tree: inner records a ray through the scene's box visits (0: not computed) */
 } prgpu_pipeline_info;
 int  prgpu_pipeline_info_get(prgpu_scene* s, prgpu_pipeline_info* out);
 /* Enable/disable node+triangle counting inside the traversal kernels (slower; default off). */

@@ -214,12 +214,15 @@ __device__ __forceinline__ void pad_box(float* lo, float* hi)
 	}
 }
 
-// 6. collapse the radix tree into the 4-wide traversal structure.
-// Inner nodes (64 bytes) hold up to four quantised child boxes, leaves (128 bytes, one L2 line) hold up
-// to three triangles.  Rules (all decidable per node, no top-down pass):
-//   * a subtree with <= 3 triangles whose parent has > 3 is a LEAF record (these partition the triangles);
-//   * an internal node at EVEN depth with > 3 triangles is an INNER record; its children are its radix-tree
-//     children, each replaced by its own two children when it is an (odd-depth) internal node with > 3 triangles.
+// 6. collapse the radix tree into the traversal structure.
+// Inner nodes (64 bytes) hold up to four or up to six quantised child boxes, leaves (128 bytes, one L2 line) hold up to three triangles.
+//   * a subtree with <= 3 triangles whose parent has > 3 is a LEAF record (these partition the triangles) -- under either collapse;
+//   * FOUR-WIDE, the parity collapse (decidable per node, no top-down pass): an internal node at EVEN depth with > 3 triangles is an INNER
+//     record; its children are its radix-tree children, each replaced by its own two children when it is an (odd-depth) internal node
+//     with > 3 triangles;
+//   * SIX-WIDE, the greedy collapse (gather_children with a width, k_mark_records top-down from the root): a record's children start as its
+//     radix node's two children, and while there are fewer than six the one of largest surface area that is not a leaf is replaced by its two.
+// build_lbvh computes both sets of records' expected visits per ray (k_area_sum) and keeps the cheaper tree; a six-wide step counts 1.35 x.
 __global__ void k_depth_and_flags(int n, const int* __restrict__ parent, const int* __restrict__ range_first, const int* __restrict__ range_last,
 								  uint32_t* __restrict__ inner_flag /* n-1 */, uint32_t* __restrict__ leaf_flag /* n */, uint32_t* __restrict__ leaf_count /* n */)
 {
@@ -253,13 +256,21 @@ struct ChildRef {
 	float lo[3], hi[3];
 	bool leaf;
 	uint32_t id; // leaf: compacted leaf index (leaf_idx of its first sorted triangle); inner: compacted inner index (inner_idx of the radix node)
+	int node;	 // the radix-tree child code the subtree came from (>= 0 internal, < 0 single triangle ~pos)
 };
+constexpr int MAX_WIDE = 6; // children an inner record can hold at most
+// What a traversal step on a six-wide record costs against one on a four-wide record (two more slab tests, a 12- instead of a 5-comparator
+// sort, two more pushes, 64 instead of 48 bytes), as the ratio of the two trees' estimates at which either renders a frame equally fast:
+// eight scenes rendered with both trees (profiles/r05_bvh_width.log) -- six-wide wins where estimate6 / estimate4 <= 0.66 (meshes of uneven
+// density, small scenes: - 3 .. - 7 % time), loses where it is >= 0.76 (uniform triangle soups: + 5 .. + 10 %).
+constexpr double WIDE_STEP_COST = 1.35;
 // the subtree `c` (radix-tree child code: >= 0 internal, < 0 single triangle ~pos) as a child of an inner record
 __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
 											   const int* __restrict__ range_first, const int* __restrict__ range_last, const float* __restrict__ boxes,
 											   const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx)
 {
 	ChildRef r;
+	r.node	   = c;
 	expandable = false;
 	if (c < 0) {
 		tri_box(wv, sorted_tri[~c], r.lo, r.hi);
@@ -283,24 +294,60 @@ __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const fl
 	pad_box(r.lo, r.hi);
 	return r;
 }
-// The <= 4 children of inner record i, LEAVES FIRST (a record's children lie contiguously from one base unit and leaves are 128-byte
+// The children of inner record i, LEAVES FIRST (a record's children lie contiguously from one base unit and leaves are 128-byte
 // aligned: base even, leaves of two units each first, inner records of one unit after them), otherwise in radix-tree order.
-__device__ __forceinline__ int gather_children(int i, ChildRef* ch, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
-											   const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
-											   const float* __restrict__ boxes, const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx)
+// width == 0: the PARITY collapse -- the radix node's grandchildren (inner records are the radix nodes at even depth, k_depth_and_flags).
+// width >= 2: the GREEDY collapse -- start from the two radix children and, while fewer than `width`, replace the child of largest
+// surface area that is not a leaf by its own two children; which radix nodes are records then follows top-down (k_mark_records).
+__device__ __forceinline__ float half_area(const ChildRef& c)
 {
-	ChildRef tmp[4];
+	const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+	return dx * dy + dy * dz + dz * dx;
+}
+__device__ int gather_children(int i, ChildRef* ch, int width, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+							   const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
+							   const float* __restrict__ boxes, const uint32_t* __restrict__ inner_idx, const uint32_t* __restrict__ leaf_idx)
+{
+	ChildRef tmp[MAX_WIDE];
 	int nc = 0;
-	for (int side = 0; side < 2; ++side) {
-		const int c = side == 0 ? left[i] : right[i];
-		bool expandable;
-		const ChildRef direct = make_child(c, expandable, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
-		if (!expandable) {
-			tmp[nc++] = direct;
-		} else { // odd-depth internal node with > 3 triangles: pull its two children up
-			bool e2;
-			tmp[nc++] = make_child(left[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
-			tmp[nc++] = make_child(right[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+	if (width == 0) {
+		for (int side = 0; side < 2; ++side) {
+			const int c = side == 0 ? left[i] : right[i];
+			bool expandable;
+			const ChildRef direct = make_child(c, expandable, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+			if (!expandable) {
+				tmp[nc++] = direct;
+			} else { // odd-depth internal node with > 3 triangles: pull its two children up
+				bool e2;
+				tmp[nc++] = make_child(left[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+				tmp[nc++] = make_child(right[c], e2, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+			}
+		}
+	} else {
+		bool ex[MAX_WIDE];
+		tmp[0] = make_child(left[i], ex[0], wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+		tmp[1] = make_child(right[i], ex[1], wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+		nc	   = 2;
+		while (nc < width) {
+			int best	= -1;
+			float bestA = -1.0f;
+			for (int k = 0; k < nc; ++k) {
+				const float A = half_area(tmp[k]);
+				if (ex[k] && A > bestA) {
+					best  = k;
+					bestA = A;
+				}
+			}
+			if (best < 0)
+				break;
+			const int c = tmp[best].node;
+			for (int k = nc; k > best + 1; --k) {
+				tmp[k] = tmp[k - 1];
+				ex[k]  = ex[k - 1];
+			}
+			tmp[best]	  = make_child(left[c], ex[best], wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+			tmp[best + 1] = make_child(right[c], ex[best + 1], wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
+			++nc;
 		}
 	}
 	int n = 0;
@@ -312,8 +359,39 @@ __device__ __forceinline__ int gather_children(int i, ChildRef* ch, const float4
 			ch[n++] = tmp[k];
 	return nc;
 }
+// Expected inner records a random ray that hits the scene's box walks through, times the root's area: the sum of the areas of the
+// radix nodes that are records (a record's box is its radix node's box).  The two collapses are compared on it (build_lbvh).
+__global__ void k_area_sum(int n, const uint32_t* __restrict__ flag, const float* __restrict__ boxes, double* __restrict__ sum)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	double a	= 0.0;
+	if (i < n - 1 && flag[i]) {
+		const double dx = (double)boxes[6 * i + 3] - boxes[6 * i], dy = (double)boxes[6 * i + 4] - boxes[6 * i + 1], dz = (double)boxes[6 * i + 5] - boxes[6 * i + 2];
+		a				= dx * dy + dy * dz + dz * dx;
+	}
+	for (int o = 32; o > 0; o >>= 1)
+		a += __shfl_down(a, o, 64);
+	if ((threadIdx.x & 63) == 0 && a != 0.0)
+		atomicAdd(sum, a);
+}
+// Greedy collapse, one level of the top-down pass: the inner children of the records in `front` are records themselves
+__global__ void k_mark_records(int n_front, const int* __restrict__ front, int width, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
+							   const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
+							   const float* __restrict__ boxes, uint32_t* __restrict__ inner_flag, int* __restrict__ next, uint32_t* __restrict__ n_next)
+{
+	const int t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_front)
+		return;
+	ChildRef ch[MAX_WIDE];
+	const int nc = gather_children(front[t], ch, width, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_flag /* ids unused here */, inner_flag);
+	for (int k = 0; k < nc; ++k)
+		if (!ch[k].leaf) {
+			inner_flag[ch[k].node]		= 1u;
+			next[atomicAdd(n_next, 1u)] = ch[k].node;
+		}
+}
 
-// Pack <= 4 children into an inner record (layout: pr_device.h).  The child boxes (already padded) become bytes on a power-of-two
+// Pack <= 6 children into an inner record (layout: pr_device.h; a four-wide tree's records leave the last two slots empty).  The child boxes (already padded) become bytes on a power-of-two
 // grid anchored just below the lower corner of their union.  The traversal never forms a plane's coordinate: it evaluates
 // t = byte * (step * inv_d) + (origin - o) * inv_d in one fma, which differs from the slab distance of the EXACT plane
 // origin + byte * step by <= 3 u |t| + 2 u * 255 * step * |inv_d| (u = 2^-24).  The absolute part is less than 2^-15 step * |inv_d|, so
@@ -324,7 +402,7 @@ __device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int n
 {
 	float org[3];
 	uint32_t ebyte[3];
-	uint32_t qlo[3][4], qhi[3][4];
+	uint32_t qlo[3][MAX_WIDE], qhi[3][MAX_WIDE];
 	for (int a = 0; a < 3; ++a) {
 		float lo = INFINITY, hi = -INFINITY;
 		for (int k = 0; k < nc; ++k) {
@@ -389,13 +467,24 @@ __device__ void write_inner_q(Rec64* __restrict__ rec, const ChildRef* ch, int n
 		w[11] |= ((offs[src] << REC_UNIT_SHIFT) | (ch[src].leaf ? REC_LEAF_BIT : 0u)) << (8 * k);
 	}
 	w[10]	   = base_unit << REC_UNIT_SHIFT;
+	for (int k = 4; k < 6; ++k) { // q3: children 4, 5 (inverted boxes in a 4-wide tree, whose steps do not load it)
+		const bool used = k < nc;
+		const int j		= k - 4;
+		const uint32_t lx = used ? qlo[0][k] : 255u, ly = used ? qlo[1][k] : 255u, lz = used ? qlo[2][k] : 255u;
+		const uint32_t hx = used ? qhi[0][k] : 0u, hy = used ? qhi[1][k] : 0u, hz = used ? qhi[2][k] : 0u;
+		w[12] |= (lx << (8 * j)) | (ly << (16 + 8 * j));
+		w[13] |= (hx << (8 * j)) | (hy << (16 + 8 * j));
+		w[14] |= (lz << (8 * j)) | (hz << (16 + 8 * j));
+		const int src = used ? k : 0;
+		w[15] |= ((offs[src] << REC_UNIT_SHIFT) | (ch[src].leaf ? REC_LEAF_BIT : 0u)) << (8 * j);
+	}
 	uint4* dst = reinterpret_cast<uint4*>(rec);
 	for (int q = 0; q < 4; ++q)
 		dst[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
 }
 
 // 6a. units the children of inner record i occupy (even: the next record's leaves stay 128-byte aligned)
-__global__ void k_group_sizes(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+__global__ void k_group_sizes(int n, int width, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
 							  const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
 							  const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
 							  const uint32_t* __restrict__ leaf_idx, uint32_t* __restrict__ gsize)
@@ -403,15 +492,15 @@ __global__ void k_group_sizes(int n, const float4* __restrict__ wv, const uint32
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n - 1 || !inner_flag[i])
 		return;
-	ChildRef ch[4];
-	const int nc = gather_children(i, ch, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
+	ChildRef ch[MAX_WIDE];
+	const int nc = gather_children(i, ch, width, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
 	uint32_t units = 0;
 	for (int k = 0; k < nc; ++k)
 		units += ch[k].leaf ? 2u : 1u;
 	gsize[inner_idx[i]] = (units + 1u) & ~1u;
 }
 // 6b. where every record goes: the children of inner record i from unit 2 + gbase[i] on (units 0, 1 = the root record and its pad)
-__global__ void k_assign_units(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+__global__ void k_assign_units(int n, int width, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
 							   const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
 							   const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
 							   const uint32_t* __restrict__ leaf_idx, const uint32_t* __restrict__ gbase, uint32_t* __restrict__ inner_unit,
@@ -422,8 +511,8 @@ __global__ void k_assign_units(int n, const float4* __restrict__ wv, const uint3
 		return;
 	if (i == 0)
 		inner_unit[inner_idx[0]] = 0u;
-	ChildRef ch[4];
-	const int nc  = gather_children(i, ch, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
+	ChildRef ch[MAX_WIDE];
+	const int nc  = gather_children(i, ch, width, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
 	uint32_t unit = 2u + gbase[inner_idx[i]];
 	for (int k = 0; k < nc; ++k) {
 		if (ch[k].leaf)
@@ -434,7 +523,7 @@ __global__ void k_assign_units(int n, const float4* __restrict__ wv, const uint3
 	}
 }
 // 6c. the inner records
-__global__ void k_emit_inner(int n, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
+__global__ void k_emit_inner(int n, int width, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri, const int* __restrict__ left,
 							 const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
 							 const float* __restrict__ boxes, const uint32_t* __restrict__ inner_flag, const uint32_t* __restrict__ inner_idx,
 							 const uint32_t* __restrict__ leaf_idx, const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ inner_unit,
@@ -443,9 +532,9 @@ __global__ void k_emit_inner(int n, const float4* __restrict__ wv, const uint32_
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n - 1 || !inner_flag[i])
 		return;
-	ChildRef ch[4];
-	const int nc = gather_children(i, ch, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
-	uint32_t offs[4] = { 0u, 0u, 0u, 0u }, off = 0u;
+	ChildRef ch[MAX_WIDE];
+	const int nc = gather_children(i, ch, width, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_idx, leaf_idx);
+	uint32_t offs[MAX_WIDE] = { 0u, 0u, 0u, 0u, 0u, 0u }, off = 0u;
 	for (int k = 0; k < nc; ++k) {
 		offs[k] = off;
 		off += ch[k].leaf ? 2u : 1u;
@@ -472,8 +561,8 @@ __global__ void k_validate(uint32_t n_inner, const uint32_t* __restrict__ inner_
 		const uint32_t e = (w[3] >> (8 * a)) & 0xFFu;
 		ok				 = e >= 27u && e <= 157u; // 2^-100 .. 2^30
 	}
-	for (int k = 0; k < 4 && ok; ++k) {
-		const uint32_t ref = base + ((pw >> (8 * k)) & 0xFFu), cu = ref >> REC_UNIT_SHIFT;
+	for (int k = 0; k < MAX_WIDE && ok; ++k) {
+		const uint32_t ref = base + (((k < 4 ? pw : w[15]) >> (8 * (k & 3))) & 0xFFu), cu = ref >> REC_UNIT_SHIFT;
 		ok				   = ok && (ref & 2u) == 0u;
 		if (ref & REC_LEAF_BIT) {
 			ok = (cu & 1u) == 0u && cu + 2u <= n_units;
@@ -610,7 +699,10 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 	uint32_t *inner_flag = nullptr, *inner_idx = nullptr, *leaf_flag = nullptr, *leaf_cnt = nullptr, *leaf_idx = nullptr;
 	uint32_t *gsize = nullptr, *gbase = nullptr, *inner_unit = nullptr;
 	uint64_t *keys = nullptr, *keys_sorted = nullptr;
-	int *left = nullptr, *right = nullptr, *rf = nullptr, *rl = nullptr, *parent = nullptr;
+	int *left = nullptr, *right = nullptr, *rf = nullptr, *rl = nullptr, *parent = nullptr, *front = nullptr, *front_next = nullptr;
+	double* front_count = nullptr;
+	uint32_t* greedy_flag = nullptr;
+	int width = 0; // gather_children: 0 = the parity collapse, MAX_WIDE = the greedy one
 	float* boxes = nullptr;
 	void *temp = nullptr, *temp2 = nullptr;
 	size_t temp_bytes = 0, temp2_bytes = 0, t2a = 0, t2b = 0;
@@ -669,6 +761,44 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			hipLaunchKernelGGL(k_fit_bounds, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, parent, boxes, arrive);
 			hipLaunchKernelGGL(k_depth_and_flags, dim3(G), dim3(B), 0, stream, (int)n, parent, rf, rl, inner_flag, leaf_flag, leaf_cnt);
 			HIPC(hipGetLastError());
+			if (in.width != 4) { // the greedy collapse: which radix nodes are records follows top-down from the root, one launch per level
+				HIPC(hipMalloc(&greedy_flag, sizeof(uint32_t) * n));
+				HIPC(hipMalloc(&front, sizeof(int) * n));
+				HIPC(hipMalloc(&front_next, sizeof(int) * n));
+				HIPC(hipMalloc(&front_count, sizeof(double) * 3)); // (the two area sums live behind the counter)
+				HIPC(hipMemsetAsync(greedy_flag, 0, sizeof(uint32_t) * n, stream));
+				HIPC(hipMemsetAsync(front_count, 0, sizeof(double) * 3, stream));
+				const uint32_t one = 1u;
+				const int root	   = 0;
+				HIPC(hipMemcpyAsync(greedy_flag, &one, 4, hipMemcpyHostToDevice, stream));
+				HIPC(hipMemcpyAsync(front, &root, 4, hipMemcpyHostToDevice, stream));
+				uint32_t n_front = 1u;
+				while (n_front != 0u) {
+					HIPC(hipMemsetAsync(front_count, 0, sizeof(uint32_t), stream));
+					hipLaunchKernelGGL(k_mark_records, dim3((n_front + B - 1) / B), dim3(B), 0, stream, (int)n_front, front, MAX_WIDE, wv, vals_sorted, left, right, rf, rl, boxes,
+									   greedy_flag, front_next, reinterpret_cast<uint32_t*>(front_count));
+					HIPC(hipMemcpyAsync(&n_front, front_count, 4, hipMemcpyDeviceToHost, stream));
+					HIPC(hipStreamSynchronize(stream));
+					std::swap(front, front_next);
+				}
+				double sums[3] = { 0.0, 0.0, 0.0 };
+				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, inner_flag, boxes, front_count + 1);
+				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, greedy_flag, boxes, front_count + 2);
+				float root_box[6];
+				HIPC(hipMemcpyAsync(sums, front_count, sizeof(sums), hipMemcpyDeviceToHost, stream));
+				HIPC(hipMemcpyAsync(root_box, boxes, sizeof(root_box), hipMemcpyDeviceToHost, stream));
+				HIPC(hipStreamSynchronize(stream));
+				const double rx = (double)root_box[3] - root_box[0], ry = (double)root_box[4] - root_box[1], rz = (double)root_box[5] - root_box[2];
+				const double ra = std::max(rx * ry + ry * rz + rz * rx, 1e-300);
+				out.cost4 = (float)(sums[1] / ra);
+				out.cost6 = (float)(sums[2] / ra);
+				// width 0: six-wide where its tree saves more records than its longer step costs (WIDE_STEP_COST: measured)
+				if (in.width == 6 || (double)out.cost6 * WIDE_STEP_COST < (double)out.cost4) {
+					width	 = MAX_WIDE;
+					out.wide = true;
+					std::swap(inner_flag, greedy_flag);
+				}
+			}
 			HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, t2a, inner_flag, inner_idx, (int)n, stream));
 			HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, t2b, leaf_flag, leaf_idx, (int)n, stream));
 			temp2_bytes = std::max(t2a, t2b);
@@ -690,7 +820,7 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipMalloc(&inner_unit, sizeof(uint32_t) * std::max<size_t>(out.n_inner, 1)));
 			HIPC(hipMalloc(&out.leaf_units, sizeof(uint32_t) * std::max<size_t>(out.n_leaf, 1)));
 			HIPC(hipMemsetAsync(gsize, 0, sizeof(uint32_t) * (size_t(out.n_inner) + 1), stream));
-			hipLaunchKernelGGL(k_group_sizes, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gsize);
+			hipLaunchKernelGGL(k_group_sizes, dim3(G), dim3(B), 0, stream, (int)n, width, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gsize);
 			HIPC(hipGetLastError());
 			{
 				size_t t3 = 0;
@@ -713,9 +843,9 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			}
 			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * size_t(out.n_units)));
 			HIPC(hipMemsetAsync(out.recs, 0, sizeof(Rec64) * size_t(out.n_units), stream));
-			hipLaunchKernelGGL(k_assign_units, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gbase,
+			hipLaunchKernelGGL(k_assign_units, dim3(G), dim3(B), 0, stream, (int)n, width, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gbase,
 							   inner_unit, out.leaf_units);
-			hipLaunchKernelGGL(k_emit_inner, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gbase,
+			hipLaunchKernelGGL(k_emit_inner, dim3(G), dim3(B), 0, stream, (int)n, width, wv, vals_sorted, left, right, rf, rl, boxes, inner_flag, inner_idx, leaf_idx, gbase,
 							   inner_unit, out.recs);
 			hipLaunchKernelGGL(k_emit_leaves, dim3(G), dim3(B), 0, stream, n, wv, vals_sorted, leaf_flag, leaf_cnt, leaf_idx, out.leaf_units, out.recs, in.tri_class);
 			HIPC(hipGetLastError());
@@ -739,6 +869,7 @@ done:
 	(void)hipFree(wv); (void)hipFree(ebounds); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted);
 	(void)hipFree(left); (void)hipFree(right); (void)hipFree(rf); (void)hipFree(rl); (void)hipFree(parent); (void)hipFree(boxes); (void)hipFree(arrive);
 	(void)hipFree(inner_flag); (void)hipFree(inner_idx); (void)hipFree(leaf_flag); (void)hipFree(leaf_cnt); (void)hipFree(leaf_idx);
+	(void)hipFree(front); (void)hipFree(front_next); (void)hipFree(front_count); (void)hipFree(greedy_flag);
 	(void)hipFree(temp); (void)hipFree(temp2); (void)hipFree(gsize); (void)hipFree(gbase); (void)hipFree(inner_unit);
 	if (!ok) {
 		(void)hipFree(out.recs);

@@ -292,6 +292,10 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 			if (lane_in(do_inner ? m_inner : m_leaf)) {
 				const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
 				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+				const bool wide = sc.bvh_wide != 0u;
+				float4 qw		= make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				if (wide && do_inner)
+					qw = rec[3];
 				const uint2 top_e	   = PR_PEEK ? st.peek() : make_uint2(0u, 0u);
 				const uint2* const top = PR_PEEK ? &top_e : nullptr;
 				if (do_inner) {
@@ -299,7 +303,7 @@ __device__ __forceinline__ void path_wave(const DevScene& sc, const PathState& p
 						cn_c += s.any ? 0 : 1;
 						cn_a += s.any ? 1 : 0;
 					}
-					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, top);
+					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, qw, wide, top);
 				} else {
 					const float4 q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
 					if (COUNT) {

@@ -45,12 +45,15 @@ constexpr float CIE_Y_NORM	   = CIE_Y_NORM_SUM * CIE_DELTA;
 
 // ---- device BVH ---------------------------------------------------------------------------------
 // The BVH is addressed in 64-byte units; unit 0 is the root inner record.
-//   inner (one unit; 48 of its 64 bytes are used and fetched): a 4-wide node whose child boxes are bytes on a per-record
-//          power-of-two grid and whose children lie CONTIGUOUSLY from one base unit (leaves first, then inner records):
+//   inner (one unit): a node of up to FOUR children (the first 48 bytes; a step loads only those) or up to SIX (all 64 bytes) -- one width per
+//          scene, DevScene::bvh_wide, chosen by the builder (bvh.hip) -- whose child boxes are bytes on a per-record power-of-two grid and
+//          whose children lie CONTIGUOUSLY from one base unit (leaves first, then inner records):
 //          q0 = grid origin.xyz, exponent bytes (ex | ey << 8 | ez << 16; grid step of axis a = 2^(e_a - 127));
-//          q1 = lo.x, lo.y, lo.z, hi.x (one byte per child in each word); q2 = hi.y, hi.z, base ref (4 * first child unit),
+//          q1 = lo.x, lo.y, lo.z, hi.x (one byte per child 0..3 in each word); q2 = hi.y, hi.z, base ref (4 * first child unit),
 //          payload bytes (byte k = (unit offset of child k from the base) << 2 | leaf bit; an unused slot repeats child 0's payload
-//          and carries an inverted byte box, which fails the slab test -- and is harmless should it ever pass).
+//          and carries an inverted byte box, which fails the slab test -- and is harmless should it ever pass);
+//          q3 = children 4, 5: lo.x4 lo.x5 lo.y4 lo.y5 | hi.x4 hi.x5 hi.y4 hi.y5 | lo.z4 lo.z5 hi.z4 hi.z5 | payload4 payload5 (inverted boxes in a
+//          four-wide tree; the word pairing lets one select per axis pick the near and the far planes of both children).
 //          The decoded plane origin + byte * step (EXACT, never formed by the traversal) lies at least 2^-14 grid steps outside
 //          the padded fp32 child box: the builder checks every byte in double precision (bvh.hip, write_inner_q); that margin
 //          pays for the fused one-fma-per-plane slab arithmetic of the traversal step.
@@ -167,6 +170,7 @@ struct DevCamera {
 struct DevScene {
 	const Rec64* recs;
 	uint32_t n_tris, n_inner, n_leaf;
+	uint32_t bvh_wide; // 1: the inner records hold up to SIX children (q3 in use, a step loads all 64 bytes), 0: four (48 bytes)
 	const float* positions;
 	const float* normals;
 	const float* uvs; // 2 per vertex, or null

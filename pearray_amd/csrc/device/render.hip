@@ -8,7 +8,7 @@
 //
 // No MFMA: no stage is a dense contraction.  The kernels are latency/bandwidth bound on BVH-node and
 // triangle fetches (64-byte inner and 128-byte leaf records, see DESIGN.md for the bytes-per-ray model).
-// This file is compiled twenty-one times (Makefile: -DPR_TU=0..5, -DPR_SUB=0..3) so that the large kernels build in parallel: translation
+// This file is compiled thirty-five times (Makefile: -DPR_TU=0..5, 11..15, -DPR_SUB=0..5) so that the large kernels build in parallel: translation
 // unit 0 holds the wavefront (lockstep / streaming) kernels, the ray service and the launchers; units (v, s) hold ONE instantiation of the
 // persistent path kernel each (launch_pp_<v>_<s>).  The device functions above the kernels are shared source, not shared objects.
 #ifndef PR_TU
@@ -169,7 +169,7 @@ __device__ __forceinline__ void trav_pop(Trav& s, STK& st, const uint2* top = nu
 // from the record's base ref << 2 | leaf bit), 0xFFFFFFFF for a miss: sorting the keys as integers sorts the children near to far
 // (entry distances are >= tmin >= 0) and carries each child's ref along for free.
 #define PR_UB(w, k) ((float)(((w) >> (8 * (k))) & 0xFFu)) /* byte k of a packed word as a float: v_cvt_f32_ubyteK */
-__device__ __forceinline__ void inner_keys(const Trav& s, const float4& q0, const float4& q1, const float4& q2, uint32_t key[4])
+__device__ __forceinline__ void inner_keys(const Trav& s, const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool wide, uint32_t key[6])
 {
 	const uint32_t eb = __float_as_uint(q0.w);
 	const float sx = __uint_as_float((eb & 0xFFu) << 23), sy = __uint_as_float(((eb >> 8) & 0xFFu) << 23), sz = __uint_as_float(((eb >> 16) & 0xFFu) << 23);
@@ -192,24 +192,46 @@ __device__ __forceinline__ void inner_keys(const Trav& s, const float4& q0, cons
 		// bytes 3..1 of t0, byte k of the payload word (v_perm_b32)
 		key[k] = h ? __builtin_amdgcn_perm(__float_as_uint(t0), pw, 0x07060500u | (uint32_t)k) : 0xFFFFFFFFu;
 	}
+	if (wide) { // children 4, 5 (record layout: pr_device.h); `wide` is a property of the scene: a scalar branch
+		const uint32_t ea = __float_as_uint(q3.x), eh = __float_as_uint(q3.y), ez = __float_as_uint(q3.z), pw2 = __float_as_uint(q3.w);
+		const uint32_t enx = nx ? eh : ea, efx = nx ? ea : eh, eny = ny ? eh : ea, efy = ny ? ea : eh;
+		const uint32_t ezn = nz ? (ez >> 16) : ez, ezf = nz ? ez : (ez >> 16);
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const float axk = __fmaf_rn(PR_UB(enx, k), Ax, Bx), bxk = __fmaf_rn(PR_UB(efx, k), Ax, Bx);
+			const float ayk = __fmaf_rn(PR_UB(eny, 2 + k), Ay, By), byk = __fmaf_rn(PR_UB(efy, 2 + k), Ay, By);
+			const float azk = __fmaf_rn(PR_UB(ezn, k), Az, Bz), bzk = __fmaf_rn(PR_UB(ezf, k), Az, Bz);
+			const float t0 = fmaxf(fmaxf(axk, ayk), fmaxf(azk, s.tmin));
+			const float t1 = fminf(fminf(bxk, byk), fminf(bzk, s.best.t));
+			const bool h   = t0 <= __fmaf_rn(t1, SLAB_REL, s.r.eps_t);
+			key[4 + k]	   = h ? __builtin_amdgcn_perm(__float_as_uint(t0), pw2, 0x07060500u | (uint32_t)k) : 0xFFFFFFFFu;
+		}
+	}
 }
 // ... sort part: continue with the nearest hit child and push the others far to near (occlusion rays share the sorted code: their
 // result does not depend on the order).  5-comparator network on the integer keys (misses sort last).
 template <int M, typename STK>
-__device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const uint2* top = nullptr)
+__device__ __forceinline__ void trav_inner_rec(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, bool wide, const uint2* top = nullptr)
 {
-	uint32_t key[4];
-	inner_keys(s, q0, q1, q2, key);
+	uint32_t key[6];
+	inner_keys(s, q0, q1, q2, q3, wide, key);
 #define PR_CSWAP(a, b)                                  \
 	{                                                   \
 		const uint32_t lo = min(key[a], key[b]);        \
 		key[b]			  = max(key[a], key[b]);        \
 		key[a]			  = lo;                         \
 	}
-	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
-#undef PR_CSWAP
 	const uint32_t base = __float_as_uint(q2.z);
-	st.reserve(3);
+	if (wide) { // 12-comparator network for six keys, then the two farthest
+		PR_CSWAP(0, 5) PR_CSWAP(1, 3) PR_CSWAP(2, 4) PR_CSWAP(1, 2) PR_CSWAP(3, 4) PR_CSWAP(0, 3) PR_CSWAP(2, 5) PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(4, 5) PR_CSWAP(1, 2) PR_CSWAP(3, 4)
+		st.reserve(5);
+		st.push_if(key[5] != 0xFFFFFFFFu, base + (key[5] & 0xFFu), key[5]);
+		st.push_if(key[4] != 0xFFFFFFFFu, base + (key[4] & 0xFFu), key[4]);
+	} else {
+		PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+		st.reserve(3);
+	}
+#undef PR_CSWAP
 	st.push_if(key[3] != 0xFFFFFFFFu, base + (key[3] & 0xFFu), key[3]);
 	st.push_if(key[2] != 0xFFFFFFFFu, base + (key[2] & 0xFFu), key[2]);
 	st.push_if(key[1] != 0xFFFFFFFFu, base + (key[1] & 0xFFu), key[1]);
@@ -221,8 +243,12 @@ __device__ __forceinline__ void trav_inner(const DevScene& sc, Trav& s, Stack& s
 {
 	const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
 	const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+	const bool wide = sc.bvh_wide != 0u;
+	float4 q3		= make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (wide)
+		q3 = rec[3];
 	const uint2 top = st.peek(); // (see path_persistent)
-	trav_inner_rec<M>(s, st, q0, q1, q2, &top);
+	trav_inner_rec<M>(s, st, q0, q1, q2, q3, wide, &top);
 }
 
 // Leaf step: fetch the leaf record (<= 3 triangles) and run the watertight test on each.
@@ -2321,7 +2347,9 @@ struct PersistentArgs {
 constexpr uint32_t PP_SHADE_HELP = 128u;
 constexpr uint32_t BL_UNWRITTEN = 0xFFFFFFFEu, BL_HOLE = 0xFFFFFFFFu; // list entry reserved but not yet written / reserved when the frame had no pixel left
 
-template <bool COUNT, uint32_t FEATS>
+// WIDE: the scene's inner records hold four children (0), six (1), or whatever the scene says (2: a scalar branch per step -- measured 5 % slower
+// than either constant in the 168-register kernel, so that one is compiled for both)
+template <bool COUNT, uint32_t FEATS, int WIDE>
 __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathState& ps, const PersistentArgs& a)
 {
 	// material classes: 0 = everything but the rough / principled closures, 1 = those (only kernels that contain them have the queue)
@@ -2753,7 +2781,11 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 			const unsigned long long t0s = COUNT ? wall_clock64() : 0ull;
 			if (lane_in(do_inner ? m_inner : m_leaf)) {
 				const float4* __restrict__ rec = rec_ptr(sc.recs, s.cur);
-				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2]; // an inner record (48 of its 64 bytes are used), or the start of a leaf
+				const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2]; // an inner record (48 of its 64 bytes are used in a 4-wide tree), or the start of a leaf
+				const bool wide = WIDE == 2 ? sc.bvh_wide != 0u : WIDE == 1;
+				float4 qw		= make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				if (wide && do_inner) // a 6-wide tree: the record's last quarter (scalar conditions)
+					qw = rec[3];
 				// The entry a pop at the end of this step would take is read NOW: its LDS round trip overlaps the record fetch instead of
 				// standing between this step and the next one's fetch (a step that pops has pushed nothing).  C4 + 1.5 %; the kernels
 				// with the large shading bodies pay for the two registers in spills (717 -> 758 for the all-features one, C5 - 1.5 %:
@@ -2765,7 +2797,7 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 						cn_c += s.any ? 0 : 1;
 						cn_a += s.any ? 1 : 0;
 					}
-					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, top);
+					trav_inner_rec<MODE_MIXED>(s, st, q0, q1, q2, qw, wide, top);
 				} else {
 					const float4 q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
 					if (COUNT) {
@@ -2894,12 +2926,12 @@ __device__ __forceinline__ void path_persistent(const DevScene& sc, const PathSt
 template <bool COUNT, uint32_t FEATS>
 __global__ void __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) k_path_persistent(DevScene sc, PathState ps, PersistentArgs a)
 {
-	path_persistent<COUNT, FEATS>(sc, ps, a);
+	path_persistent<COUNT, FEATS, 2>(sc, ps, a);
 }
-template <bool COUNT, uint32_t FEATS>
+template <bool COUNT, uint32_t FEATS, bool WIDE>
 __global__ void __launch_bounds__(TRAV_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3))) k_path_persistent_occ3(DevScene sc, PathState ps, PersistentArgs a)
 {
-	path_persistent<COUNT, FEATS>(sc, ps, a);
+	path_persistent<COUNT, FEATS, WIDE ? 1 : 0>(sc, ps, a);
 }
 
 #include "path_wave.inl"
@@ -2944,8 +2976,11 @@ __device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4&
 												 uint32_t* pending_own, uint32_t tid, bool active, const uint32_t* q_head, uint32_t* overflow)
 {
 	uint32_t key[4] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
-	if (active)
-		inner_keys(s, q0, q1, q2, key);
+	if (active) {
+		uint32_t k6[6];
+		inner_keys(s, q0, q1, q2, q0, false, k6); // (4-wide trees only: prgpu_api.hip keeps the split traversal for them)
+		key[0] = k6[0], key[1] = k6[1], key[2] = k6[2], key[3] = k6[3];
+	}
 	const uint32_t base = __float_as_uint(q2.z);
 	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts through three ballots)
 	bool lf[4];
@@ -3319,14 +3354,14 @@ void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const 
 // ---- persistent path kernel: one translation unit per kernel (feature-mask variant x {3, 2 waves per SIMD} x {plain, instrumented}) ----
 [[maybe_unused]] constexpr uint32_t FEAT_NO_LPE = FEAT_ALL & ~(FEAT_LPE | FEAT_QUADRICS), FEAT_NO_ROUGH = FEAT_NO_LPE & ~FEAT_ROUGH_MATERIALS; // quadric entities ride in the top variant
 #define PR_PP_DECL(V, S) void launch_pp_##V##_##S(const DevScene& sc, const PathState& ps, const PersistentArgs& a, dim3 grid, hipStream_t st);
-#define PR_PP_DECL4(V) PR_PP_DECL(V, 0) PR_PP_DECL(V, 1) PR_PP_DECL(V, 2) PR_PP_DECL(V, 3)
+#define PR_PP_DECL4(V) PR_PP_DECL(V, 0) PR_PP_DECL(V, 1) PR_PP_DECL(V, 2) PR_PP_DECL(V, 3) PR_PP_DECL(V, 4) PR_PP_DECL(V, 5)
 PR_PP_DECL4(1) PR_PP_DECL4(2) PR_PP_DECL4(3) PR_PP_DECL4(4) PR_PP_DECL4(5)
 #define PR_PL_DECL(V) void launch_pl_##V##_0(const DevScene& sc, const PathState& ps, const WaveArgs& a, dim3 grid, hipStream_t st); \
 	void launch_pl_##V##_1(const DevScene& sc, const PathState& ps, const WaveArgs& a, dim3 grid, hipStream_t st);
 PR_PL_DECL(1) PR_PL_DECL(2) PR_PL_DECL(3) PR_PL_DECL(4) PR_PL_DECL(5)
 #if PR_TU >= 1
 #ifndef PR_SUB
-#error "compile the persistent-kernel units with -DPR_SUB=0..3"
+#error "compile the persistent-kernel units with -DPR_SUB=0..5"
 #endif
 // units 11..15 hold the latency organisation of variants 1..5 (a literal: it is pasted into the launcher's name)
 #if PR_TU == 1 || PR_TU == 11
@@ -3367,13 +3402,17 @@ void PR_PP_CAT(pp, PR_VARIANT, PR_SUB)(const DevScene& sc, const PathState& ps, 
 {
 	const dim3 block(TRAV_BLOCK);
 #if PR_SUB == 0
-	hipLaunchKernelGGL((k_path_persistent_occ3<false, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+	hipLaunchKernelGGL((k_path_persistent_occ3<false, PR_PP_FEATS, false>), grid, block, 0, st, sc, ps, a);
 #elif PR_SUB == 1
-	hipLaunchKernelGGL((k_path_persistent_occ3<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+	hipLaunchKernelGGL((k_path_persistent_occ3<true, PR_PP_FEATS, false>), grid, block, 0, st, sc, ps, a);
 #elif PR_SUB == 2
 	hipLaunchKernelGGL((k_path_persistent<false, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
-#else
+#elif PR_SUB == 3
 	hipLaunchKernelGGL((k_path_persistent<true, PR_PP_FEATS>), grid, block, 0, st, sc, ps, a);
+#elif PR_SUB == 4 // the 3-waves-per-SIMD kernel for scenes whose inner records hold six children
+	hipLaunchKernelGGL((k_path_persistent_occ3<false, PR_PP_FEATS, true>), grid, block, 0, st, sc, ps, a);
+#else
+	hipLaunchKernelGGL((k_path_persistent_occ3<true, PR_PP_FEATS, true>), grid, block, 0, st, sc, ps, a);
 #endif
 }
 #endif
@@ -3445,12 +3484,12 @@ void launch_path_persistent(const DevScene& sc, const PathState& ps, const uint3
 	// out spheres, AOVs + textures or infinite / shape lights + planes instead changes nothing).  A variant for delta + rough materials
 	// only was measured and dropped: the closures dominate such scenes, 156 vs 154 Msamples/s.
 	typedef void (*LaunchFn)(const DevScene&, const PathState&, const PersistentArgs&, dim3, hipStream_t);
-	static const LaunchFn table[5][4] = { { launch_pp_1_0, launch_pp_1_1, launch_pp_1_2, launch_pp_1_3 }, { launch_pp_2_0, launch_pp_2_1, launch_pp_2_2, launch_pp_2_3 },
-										   { launch_pp_3_0, launch_pp_3_1, launch_pp_3_2, launch_pp_3_3 }, { launch_pp_4_0, launch_pp_4_1, launch_pp_4_2, launch_pp_4_3 },
-										   { launch_pp_5_0, launch_pp_5_1, launch_pp_5_2, launch_pp_5_3 } };
+#define PR_PP_ROW(V) { launch_pp_##V##_0, launch_pp_##V##_1, launch_pp_##V##_2, launch_pp_##V##_3, launch_pp_##V##_4, launch_pp_##V##_5 }
+	static const LaunchFn table[5][6] = { PR_PP_ROW(1), PR_PP_ROW(2), PR_PP_ROW(3), PR_PP_ROW(4), PR_PP_ROW(5) };
+#undef PR_PP_ROW
 	const int variant = (sc.features & (FEAT_LPE | FEAT_QUADRICS)) ? 4
 						: (sc.features == 0 ? 0 : ((sc.features & ~FEAT_DELTA_MATERIALS) == 0 ? 1 : ((sc.features & FEAT_ROUGH_MATERIALS) == 0 ? 2 : 3)));
-	table[variant][(tune.occupancy >= 3 ? 0 : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
+	table[variant][(tune.occupancy >= 3 ? (sc.bvh_wide ? 4 : 0) : 2) + (count ? 1 : 0)](sc, ps, a, grid, st);
 }
 
 // The latency organisation (path_wave.inl): waves that own their paths.  Grid: as many waves as the pixels need at `slots_per_wave` slots

@@ -67,6 +67,8 @@ struct Knobs {
 	uint32_t force_features	   = 0;		  // PRGPU_FORCE_FEATURES: run a scene with a larger kernel variant than it needs (measurement aid)
 	bool debug_counters		   = false;	  // PRGPU_DEBUG_COUNTERS: print the instrumented kernel's time split
 	const char* dump_block_life = nullptr; // PRGPU_DUMP_BLOCK_LIFE=<file>: per-block lifetimes of the last instrumented launch
+	int bvh_width			   = 0;		  // PRGPU_BVH_WIDTH=auto|4|6: children per inner BVH record (0 = auto: the tree whose estimated cost is lower, device/bvh.hip)
+	bool bvh_width_invalid	   = false;
 	int trace_ranges		   = -1;	  // PRGPU_TRACE_RANGES=1: load the roctx library for the named ranges even when no profiler brought it along; 0: never emit ranges
 };
 Knobs read_knobs()
@@ -83,6 +85,10 @@ Knobs read_knobs()
 	if (const char* env = getenv("PRGPU_PP_KERNEL")) {
 		k.pp_kernel			= std::strcmp(env, "throughput") == 0 ? 1 : (std::strcmp(env, "latency") == 0 ? 2 : (std::strcmp(env, "auto") == 0 ? 0 : -1));
 		k.pp_kernel_invalid = k.pp_kernel < 0;
+	}
+	if (const char* env = getenv("PRGPU_BVH_WIDTH")) {
+		k.bvh_width			= std::strcmp(env, "auto") == 0 ? 0 : (std::strcmp(env, "4") == 0 ? 4 : (std::strcmp(env, "6") == 0 ? 6 : -1));
+		k.bvh_width_invalid = k.bvh_width < 0;
 	}
 	k.pl.slots_per_wave	  = (uint32_t)num("PRGPU_PL_SLOTS", k.pl.slots_per_wave, 64, 256);
 	k.pl.shade_min		  = (int)num("PRGPU_PL_SHADE_MIN", k.pl.shade_min, 1, 64);
@@ -175,6 +181,7 @@ struct prgpu_scene {
 	uint32_t n_pixels = 0, n_slots = 0;
 	std::vector<void*> allocations;
 	uint32_t bvh_units = 0; // 64-byte units of the BVH record array
+	float bvh_cost4 = 0.0f, bvh_cost6 = 0.0f; // the builder's estimates for the 4- and the 6-wide tree (prgpu_pipeline_info)
 	int pp_shader_waves = -1; // persistent kernel: dedicated shading waves per block, decided after the first launch (-1: not yet)
 	double pp_shading_share = 0.0; // ... from this measured share of shading passes in the wave time
 	uint64_t pp_launches = 0;
@@ -562,6 +569,9 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 
 	// device LBVH
 	prd::BvhBuildInput bin{ d->n_triangles, d->n_entities, sc.positions, sc.indices, sc.tri_entity, sc.entities, sc.tri_class };
+	if (s->knobs.bvh_width_invalid)
+		return fail(PRGPU_EINVAL, "PRGPU_BVH_WIDTH must be auto, 4 or 6");
+	bin.width = s->knobs.bvh_width;
 	prd::BvhBuildOutput bout;
 	{
 		TraceRange bvh_range("prgpu_scene_create: LBVH build");
@@ -573,6 +583,9 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 		s->allocations.push_back(bout.leaf_units); // unit of every leaf record (4 bytes per leaf; only launch_tri_slot reads it)
 	sc.recs	   = bout.recs;
 	sc.n_inner = bout.n_inner;
+	sc.bvh_wide = bout.wide ? 1u : 0u;
+	s->bvh_cost4 = bout.cost4;
+	s->bvh_cost6 = bout.cost6;
 	sc.n_leaf  = bout.n_leaf;
 	s->bvh_units = bout.n_units;
 	{ // triangle -> leaf slot (the split traversal re-tests the winning triangle of a ray for u, v)
@@ -1546,7 +1559,7 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	// closest-hit service rays take the split traversal (leaf tests through an LDS task queue: identical results, 17 % faster) unless
 	// PRGPU_TRACE_SPLIT=0 or the tree has too many records for the 24-bit task field
 	const bool split = read_knobs().trace_split;
-	if (split && s->sc.n_leaf > 0 && s->bvh_units < (1u << 24) && !(s->sc.features & (prd::FEAT_SPHERES | prd::FEAT_QUADRICS))) {
+	if (!s->sc.bvh_wide && split && s->sc.n_leaf > 0 && s->bvh_units < (1u << 24) && !(s->sc.features & (prd::FEAT_SPHERES | prd::FEAT_QUADRICS))) {
 		prd::launch_service_closest_split(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, const_cast<uint32_t*>(s->sc.tri_slot), s->gstats, s->stream);
 	} else
 		prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->gstats, s->stream);
@@ -1873,6 +1886,9 @@ int prgpu_pipeline_info_get(prgpu_scene* s, prgpu_pipeline_info* out)
 	out->blocks			 = s->pp_last_blocks;
 	out->slots_per_block = s->pp_last_slots;
 	out->kernel			 = s->pp_last_kernel;
+	out->bvh_width		 = s->sc.bvh_wide ? 6u : 4u;
+	out->bvh_cost_4_wide = s->bvh_cost4;
+	out->bvh_cost_6_wide = s->bvh_cost6;
 	return PRGPU_OK;
 }
 

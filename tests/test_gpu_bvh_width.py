@@ -1,0 +1,116 @@
+"""Inner BVH records of four or of six children (pearray_amd/csrc/device/bvh.hip: the parity collapse of the radix tree into 4-wide records, or
+the greedy collapse by surface area into 6-wide ones; PRGPU_BVH_WIDTH=auto|4|6, `auto` = the tree whose estimated cost is lower).  The
+structure replaces Embree's BVH build behind rtcCommitScene (src/core/scene/Scene.cpp:88-120); which conservative boxes a ray visits never
+reaches a result -- a hit is argmin (t, primitive id) over the primitives that pass the watertight test -- so every frame, hit id, plane and
+statistic must be the CPU checker's bit for bit under EITHER width.  The suite's other modules run with `auto`; this one forces each width
+through the adversarial traversal tests, the random scenes and the benchmark scenes at a small size."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import test_gpu_parity as P
+import test_gpu_random_scenes as R
+from pearray_amd import _cabi as abi
+from pearray_amd import backend, scene
+from test_gpu_parity import assert_parity, render_both
+
+pytestmark = pytest.mark.gpu
+WIDTHS = ["4", "6"]
+
+
+@pytest.fixture(params=WIDTHS)
+def width(request, monkeypatch):
+    monkeypatch.setenv("PRGPU_BVH_WIDTH", request.param)
+    return int(request.param)
+
+
+def test_frames_are_bit_exact_and_the_scene_reports_its_tree(width):
+    for sc, iters in ((scene.cornell_box(96, 80, spp=5), 5), (scene.cornell_soup(160, 96, spp=4, n_triangles=30_000), 4), (scene.cornell_glassy(96, 64, spp=5), 5),
+                      (scene.cornell_rough(96, 80, spp=4), 4), (P._complex_c5(160, 90, 4), 4)):
+        g, o = render_both(sc, iters=iters)
+        assert_parity(g, o, exact=True)
+        info = g.pipelineInfo()
+        assert info["bvh_width"] == width
+        assert (info["bvh_cost_6_wide"] > 0 and info["bvh_cost_4_wide"] > 0) if width == 6 else info["bvh_cost_6_wide"] == 0    # width 4: the greedy pass is not run
+        g.close()
+
+
+def test_the_ray_service_on_either_tree(width, monkeypatch):
+    P.test_ray_service_hit_ids_exact_cornell()
+    for split in ("1", "0"):     # (a six-wide tree is walked without the split traversal whatever the knob says)
+        P.test_ray_service_hit_ids_exact_soup_vs_brute_force(monkeypatch, split)
+    for seed in (2, 9, 20, 33):
+        R.test_random_scene_ray_service(seed)
+
+
+def test_adversarial_rays_on_either_tree(width, monkeypatch):
+    """Rays at vertices and edges, rays that enter a box just before they hit, rays from far outside (the relative slack of the box test),
+    axis-parallel and grazing rays, trees far from the origin and at other scales: the quantised boxes of a six-wide record are built and
+    tested by the same code as a four-wide record's (write_inner_q, inner_keys), two more of them."""
+    for geometry in ("soup", "lattice"):
+        P.test_rays_aimed_at_triangle_vertices_and_edges(monkeypatch, "0", geometry)
+    P.test_rays_that_enter_a_box_just_before_they_hit(monkeypatch, "0")
+    P.test_rays_from_far_outside_the_scene_need_the_relative_slack_of_the_box_test(monkeypatch, "0")
+    P.test_rays_whose_whole_origin_is_nan_or_infinite_end_at_the_root(monkeypatch, "0")
+    P.test_axis_aligned_and_grazing_rays()
+    for offset, scale in (((1000.0, -500.0, 250.0), 1.0), ((0.0, 0.0, 0.0), 1e-3), ((3.0e4, 1.0e4, -2.0e4), 300.0)):
+        P.test_quantised_nodes_far_from_the_origin_and_at_other_scales(offset, scale)
+
+
+def test_deep_stacks_on_either_tree(width, monkeypatch):
+    """A six-wide step pushes up to five entries (a four-wide one three): the 16-entry LDS window spills earlier and the entries come back."""
+    P.test_deep_traversal_stacks_spill_and_come_back(monkeypatch, "0")
+    P.test_deep_traversal_stacks_in_the_path_kernel()
+
+
+@pytest.mark.parametrize("seed", [1, 4, 5, 8, 13, 17, 22, 26, 30, 37])
+def test_random_scenes_on_either_tree(width, seed):
+    R.test_random_scene_matches_the_checker(seed)
+
+
+def test_the_wavefront_pipelines_and_the_latency_organisation_on_a_six_wide_tree(monkeypatch):
+    monkeypatch.setenv("PRGPU_BVH_WIDTH", "6")
+    sc = scene.cornell_soup(160, 96, spp=4, n_triangles=30_000)
+    ref = backend.RenderContext(sc); ref.render(4); ref.waitForFinish()
+    assert ref.pipelineInfo()["bvh_width"] == 6
+    for env in (dict(PRGPU_MODE="lockstep"), dict(PRGPU_MODE="streaming"), dict(PRGPU_MODE="persistent", PRGPU_PP_KERNEL="latency")):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            g = backend.RenderContext(sc); g.render(2); g.render(2); g.waitForFinish()
+            assert g.statistics() == ref.statistics()
+            for a, b in zip(g.output(), ref.output()):
+                assert np.array_equal(a, b)
+            g.close()
+
+
+def test_auto_takes_the_tree_whose_estimate_is_lower_and_both_trees_count_their_records(monkeypatch):
+    """`auto`: six-wide where its tree's estimate x 1.35 (what the longer step costs, device/bvh.hip WIDE_STEP_COST) is below the four-wide
+    tree's.  And the estimate means something: the tree it calls cheaper is the one whose rays fetch fewer inner records."""
+    sc = scene.cornell_soup(192, 108, spp=4, n_triangles=50_000)
+    g = backend.RenderContext(sc)
+    info = g.pipelineInfo()
+    assert info["bvh_cost_4_wide"] > 0 and info["bvh_cost_6_wide"] > 0
+    assert info["bvh_width"] == (6 if info["bvh_cost_6_wide"] * 1.35 < info["bvh_cost_4_wide"] else 4)
+    g.close()
+    inner = {}
+    for w in WIDTHS:
+        monkeypatch.setenv("PRGPU_BVH_WIDTH", w)
+        ctx = backend.RenderContext(sc)
+        ctx.setInstrumentation(True)
+        ctx.render(4)
+        ctx.waitForFinish()
+        tc = ctx.traceCounters()
+        inner[w] = (tc["nodes_closest"] + tc["nodes_any"]) / max(tc["rays_closest"] + tc["rays_any"], 1)
+        ctx.close()
+    assert inner["6"] < inner["4"], inner                       # fewer, longer steps
+    assert info["bvh_cost_6_wide"] < info["bvh_cost_4_wide"]
+
+
+def test_an_unknown_width_is_refused(monkeypatch):
+    monkeypatch.setenv("PRGPU_BVH_WIDTH", "8")
+    sc = scene.cornell_box(8, 8, spp=1)
+    h = C.c_void_p()
+    assert abi.load().prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"PRGPU_BVH_WIDTH" in abi.load().prgpu_last_error()

@@ -26,7 +26,9 @@ rc, ra = max(d["rays_closest"], 1), max(d["rays_any"], 1)
 steps = d["wave_steps_closest"]   # (the persistent kernel counts every wave step here, whichever kind of ray its lanes hold)
 recs = d["nodes_closest"] + d["leaves_closest"] + d["nodes_any"] + d["leaves_any"]
 tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("PRGPU_"))
-print("[%s] %s share 1/%d: %.3f ms/iteration (plain kernel)" % (tag, which, world, dt))
+info = ctx.pipelineInfo()
+print("[%s] %s share 1/%d: %.3f ms/iteration (plain kernel); BVH %d-wide (estimates: 4-wide %.2f, 6-wide %.2f inner records per ray through the scene's box)"
+      % (tag, which, world, dt, info["bvh_width"], info["bvh_cost_4_wide"], info["bvh_cost_6_wide"]))
 print("  per iteration: closest rays %.2f M, occlusion rays %.2f M; inner/leaf records per closest ray %.2f / %.2f, per occlusion ray %.2f / %.2f"
       % (rc / iters / 1e6, ra / iters / 1e6, d["nodes_closest"] / rc, d["leaves_closest"] / rc, d["nodes_any"] / ra, d["leaves_any"] / ra))
 print("  wave steps per iteration %.2f M; records per step %.1f (lane utilisation %.3f)"
