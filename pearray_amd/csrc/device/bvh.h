@@ -13,6 +13,7 @@ struct BvhBuildInput {
 	const uint32_t* tri_entity; // device
 	const DevEntity* entities;	// device
 	const uint8_t* tri_class = nullptr; // device, or null: per-triangle material class, copied into the leaf records (float 31: one byte per slot)
+	uint32_t stack_capacity = 0xFFFFFFFFu; // entries a traversal stack holds (render.h, trace_stack_capacity): a tree whose deepest walk needs more is refused
 	int width = 0; // children per inner record: 4 (a record = a radix node at even depth and its grandchildren), 6 (greedy collapse by surface area), 0 = the one that costs less (bvh.hip)
 };
 struct BvhBuildOutput {
@@ -21,6 +22,7 @@ struct BvhBuildOutput {
 						   // 128-byte aligned -- first)
 	uint32_t* leaf_units = nullptr; // device, n_leaf entries: the unit of every leaf record (the caller frees it)
 	uint32_t n_inner = 0, n_leaf = 0, n_units = 0;
+	uint32_t stack_bound = 0;		// entries the deepest walk of the tree can hold at once (every child of every record on a root-to-leaf path hit)
 	bool wide = false;				// the records hold up to six children (DevScene::bvh_wide)
 	float cost4 = 0.0f, cost6 = 0.0f; // expected inner records per ray through the scene's box, 4-wide / 6-wide tree (0: not computed)
 };

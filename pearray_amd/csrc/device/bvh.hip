@@ -224,7 +224,8 @@ __device__ __forceinline__ void pad_box(float* lo, float* hi)
 //     radix node's two children, and while there are fewer than six the one of largest surface area that is not a leaf is replaced by its two.
 // build_lbvh computes both sets of records' expected visits per ray (k_area_sum) and keeps the cheaper tree; a six-wide step counts 1.35 x.
 __global__ void k_depth_and_flags(int n, const int* __restrict__ parent, const int* __restrict__ range_first, const int* __restrict__ range_last,
-								  uint32_t* __restrict__ inner_flag /* n-1 */, uint32_t* __restrict__ leaf_flag /* n */, uint32_t* __restrict__ leaf_count /* n */)
+								  uint32_t* __restrict__ inner_flag /* n-1 */, uint32_t* __restrict__ leaf_flag /* n */, uint32_t* __restrict__ leaf_count /* n */,
+								  uint32_t* __restrict__ max_record_depth)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n - 1) {
@@ -233,6 +234,8 @@ __global__ void k_depth_and_flags(int n, const int* __restrict__ parent, const i
 			++depth;
 		const int cnt = range_last[i] - range_first[i] + 1;
 		inner_flag[i] = ((depth & 1) == 0 && cnt > 3) ? 1u : 0u;
+		if (inner_flag[i])
+			atomicMax(max_record_depth, (uint32_t)depth / 2u); // records above this one on its way from the root
 		if (cnt <= 3) {
 			const int p	   = parent[i];
 			const int pcnt = range_last[p] - range_first[p] + 1; // i != root here because cnt(root) = n > 3
@@ -257,6 +260,7 @@ struct ChildRef {
 	bool leaf;
 	uint32_t id; // leaf: compacted leaf index (leaf_idx of its first sorted triangle); inner: compacted inner index (inner_idx of the radix node)
 	int node;	 // the radix-tree child code the subtree came from (>= 0 internal, < 0 single triangle ~pos)
+	int count;	 // triangles below it
 };
 constexpr int MAX_WIDE = 6; // children an inner record can hold at most
 // What a traversal step on a six-wide record costs against one on a four-wide record (two more slab tests, a 12- instead of a 5-comparator
@@ -272,6 +276,7 @@ __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const fl
 	ChildRef r;
 	r.node	   = c;
 	expandable = false;
+	r.count	   = 1;
 	if (c < 0) {
 		tri_box(wv, sorted_tri[~c], r.lo, r.hi);
 		r.leaf = true;
@@ -282,6 +287,7 @@ __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const fl
 			r.hi[a] = boxes[6 * c + 3 + a];
 		}
 		const int cnt = range_last[c] - range_first[c] + 1;
+		r.count		  = cnt;
 		if (cnt <= 3) {
 			r.leaf = true;
 			r.id   = leaf_idx[range_first[c]];
@@ -329,11 +335,13 @@ __device__ int gather_children(int i, ChildRef* ch, int width, const float4* __r
 		tmp[1] = make_child(right[i], ex[1], wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
 		nc	   = 2;
 		while (nc < width) {
+			// the largest child; of equally large ones (coincident geometry: identical boxes all the way down) the one with the most triangles,
+			// or the expansion would run down one spine and leave a tree as deep as a list
 			int best	= -1;
 			float bestA = -1.0f;
 			for (int k = 0; k < nc; ++k) {
 				const float A = half_area(tmp[k]);
-				if (ex[k] && A > bestA) {
+				if (ex[k] && (A > bestA || (A == bestA && tmp[k].count > tmp[best].count))) {
 					best  = k;
 					bestA = A;
 				}
@@ -377,16 +385,21 @@ __global__ void k_area_sum(int n, const uint32_t* __restrict__ flag, const float
 // Greedy collapse, one level of the top-down pass: the inner children of the records in `front` are records themselves
 __global__ void k_mark_records(int n_front, const int* __restrict__ front, int width, const float4* __restrict__ wv, const uint32_t* __restrict__ sorted_tri,
 							   const int* __restrict__ left, const int* __restrict__ right, const int* __restrict__ range_first, const int* __restrict__ range_last,
-							   const float* __restrict__ boxes, uint32_t* __restrict__ inner_flag, int* __restrict__ next, uint32_t* __restrict__ n_next)
+							   const float* __restrict__ boxes, uint32_t* __restrict__ inner_flag, int* __restrict__ next, uint32_t* __restrict__ n_next,
+							   uint32_t* __restrict__ stack_bound /* per radix node: entries a walk can hold when it reaches the record */, uint32_t* __restrict__ max_stack_bound)
 {
 	const int t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n_front)
 		return;
 	ChildRef ch[MAX_WIDE];
 	const int nc = gather_children(front[t], ch, width, wv, sorted_tri, left, right, range_first, range_last, boxes, inner_flag /* ids unused here */, inner_flag);
+	// a step on this record pushes at most nc - 1 entries on top of what the walk already holds
+	const uint32_t below = stack_bound[front[t]] + (uint32_t)(nc - 1);
+	atomicMax(max_stack_bound, below);
 	for (int k = 0; k < nc; ++k)
 		if (!ch[k].leaf) {
 			inner_flag[ch[k].node]		= 1u;
+			stack_bound[ch[k].node]		= below;
 			next[atomicAdd(n_next, 1u)] = ch[k].node;
 		}
 }
@@ -701,6 +714,7 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 	uint64_t *keys = nullptr, *keys_sorted = nullptr;
 	int *left = nullptr, *right = nullptr, *rf = nullptr, *rl = nullptr, *parent = nullptr, *front = nullptr, *front_next = nullptr;
 	double* front_count = nullptr;
+	uint32_t *stack_bound = nullptr, *bounds_dev = nullptr, bounds_host[2] = { 0u, 0u };
 	uint32_t* greedy_flag = nullptr;
 	int width = 0; // gather_children: 0 = the parity collapse, MAX_WIDE = the greedy one
 	float* boxes = nullptr;
@@ -759,12 +773,16 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipMemsetAsync(leaf_cnt, 0, sizeof(uint32_t) * n, stream));
 			hipLaunchKernelGGL(k_radix_tree, dim3(G), dim3(B), 0, stream, (int)n, keys_sorted, left, right, rf, rl, parent);
 			hipLaunchKernelGGL(k_fit_bounds, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, parent, boxes, arrive);
-			hipLaunchKernelGGL(k_depth_and_flags, dim3(G), dim3(B), 0, stream, (int)n, parent, rf, rl, inner_flag, leaf_flag, leaf_cnt);
+			HIPC(hipMalloc(&bounds_dev, sizeof(uint32_t) * 2));
+			HIPC(hipMemsetAsync(bounds_dev, 0, sizeof(uint32_t) * 2, stream));
+			hipLaunchKernelGGL(k_depth_and_flags, dim3(G), dim3(B), 0, stream, (int)n, parent, rf, rl, inner_flag, leaf_flag, leaf_cnt, bounds_dev);
 			HIPC(hipGetLastError());
 			if (in.width != 4) { // the greedy collapse: which radix nodes are records follows top-down from the root, one launch per level
 				HIPC(hipMalloc(&greedy_flag, sizeof(uint32_t) * n));
 				HIPC(hipMalloc(&front, sizeof(int) * n));
 				HIPC(hipMalloc(&front_next, sizeof(int) * n));
+				HIPC(hipMalloc(&stack_bound, sizeof(uint32_t) * n));
+				HIPC(hipMemsetAsync(stack_bound, 0, sizeof(uint32_t), stream)); // the root's
 				HIPC(hipMalloc(&front_count, sizeof(double) * 3)); // (the two area sums live behind the counter)
 				HIPC(hipMemsetAsync(greedy_flag, 0, sizeof(uint32_t) * n, stream));
 				HIPC(hipMemsetAsync(front_count, 0, sizeof(double) * 3, stream));
@@ -776,7 +794,7 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 				while (n_front != 0u) {
 					HIPC(hipMemsetAsync(front_count, 0, sizeof(uint32_t), stream));
 					hipLaunchKernelGGL(k_mark_records, dim3((n_front + B - 1) / B), dim3(B), 0, stream, (int)n_front, front, MAX_WIDE, wv, vals_sorted, left, right, rf, rl, boxes,
-									   greedy_flag, front_next, reinterpret_cast<uint32_t*>(front_count));
+									   greedy_flag, front_next, reinterpret_cast<uint32_t*>(front_count), stack_bound, bounds_dev + 1);
 					HIPC(hipMemcpyAsync(&n_front, front_count, 4, hipMemcpyDeviceToHost, stream));
 					HIPC(hipStreamSynchronize(stream));
 					std::swap(front, front_next);
@@ -785,6 +803,7 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, inner_flag, boxes, front_count + 1);
 				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, greedy_flag, boxes, front_count + 2);
 				float root_box[6];
+				HIPC(hipMemcpyAsync(bounds_host, bounds_dev, sizeof(bounds_host), hipMemcpyDeviceToHost, stream));
 				HIPC(hipMemcpyAsync(sums, front_count, sizeof(sums), hipMemcpyDeviceToHost, stream));
 				HIPC(hipMemcpyAsync(root_box, boxes, sizeof(root_box), hipMemcpyDeviceToHost, stream));
 				HIPC(hipStreamSynchronize(stream));
@@ -793,7 +812,13 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 				out.cost4 = (float)(sums[1] / ra);
 				out.cost6 = (float)(sums[2] / ra);
 				// width 0: six-wide where its tree saves more records than its longer step costs (WIDE_STEP_COST: measured)
-				if (in.width == 6 || (double)out.cost6 * WIDE_STEP_COST < (double)out.cost4) {
+				const uint32_t bound4 = 3u * (bounds_host[0] + 1u), bound6 = bounds_host[1];
+				out.stack_bound		  = bound4;
+				// ... of the trees whose deepest walk fits the traversal stack (a walk that ran out of stack would drop subtrees silently)
+				const bool fit4 = bound4 <= in.stack_capacity, fit6 = bound6 <= in.stack_capacity;
+				const bool cheaper6 = (double)out.cost6 * WIDE_STEP_COST < (double)out.cost4;
+				if (in.width == 6 || (cheaper6 ? (fit6 || !fit4) : (!fit4 && fit6))) {
+					out.stack_bound = bound6;
 					width	 = MAX_WIDE;
 					out.wide = true;
 					std::swap(inner_flag, greedy_flag);
@@ -810,7 +835,15 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipMemcpyAsync(&last[1], inner_flag + (n - 1), 4, hipMemcpyDeviceToHost, stream));
 			HIPC(hipMemcpyAsync(&last[2], leaf_idx + (n - 1), 4, hipMemcpyDeviceToHost, stream));
 			HIPC(hipMemcpyAsync(&last[3], leaf_flag + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+			HIPC(hipMemcpyAsync(bounds_host, bounds_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 			HIPC(hipStreamSynchronize(stream));
+			if (!out.wide)
+				out.stack_bound = 3u * (bounds_host[0] + 1u); // a four-wide step pushes at most three entries, at every record from the root down
+			if (out.stack_bound > in.stack_capacity) {
+				err = "the BVH of this scene is " + std::to_string(out.stack_bound) + " stack entries deep in the worst case, the traversal stack holds "
+					  + std::to_string(in.stack_capacity);
+				goto done;
+			}
 			out.n_inner = last[0] + last[1];
 			out.n_leaf	= last[2] + last[3];
 			// second pass (round 4): the children of a record lie contiguously from one base unit -- every inner record says how many units
@@ -869,7 +902,7 @@ done:
 	(void)hipFree(wv); (void)hipFree(ebounds); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted);
 	(void)hipFree(left); (void)hipFree(right); (void)hipFree(rf); (void)hipFree(rl); (void)hipFree(parent); (void)hipFree(boxes); (void)hipFree(arrive);
 	(void)hipFree(inner_flag); (void)hipFree(inner_idx); (void)hipFree(leaf_flag); (void)hipFree(leaf_cnt); (void)hipFree(leaf_idx);
-	(void)hipFree(front); (void)hipFree(front_next); (void)hipFree(front_count); (void)hipFree(greedy_flag);
+	(void)hipFree(front); (void)hipFree(front_next); (void)hipFree(front_count); (void)hipFree(greedy_flag); (void)hipFree(stack_bound); (void)hipFree(bounds_dev);
 	(void)hipFree(temp); (void)hipFree(temp2); (void)hipFree(gsize); (void)hipFree(gbase); (void)hipFree(inner_unit);
 	if (!ok) {
 		(void)hipFree(out.recs);

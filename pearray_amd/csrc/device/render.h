@@ -21,6 +21,7 @@ struct TraceWorkspace {
 	size_t bl_entries	 = 0;
 };
 size_t trace_workspace_spill_entries(uint32_t max_blocks);
+uint32_t trace_stack_capacity(); // entries a lane's traversal stack holds (LDS window + spill slab)
 
 // slot_base: first slot of the pixel group when `active` is null (identity list of the primary wave)
 void launch_raygen(const DevScene& sc, const PathState& ps, uint32_t slot_base, uint32_t n_slots, uint32_t iter, unsigned long long* gstats, hipStream_t st);

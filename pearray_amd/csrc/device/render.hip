@@ -3568,6 +3568,7 @@ void launch_path_latency(const DevScene& sc, const PathState& ps, const uint32_t
 		fn(sc, ps, a, dim3(g.n_blocks), st);
 }
 
+uint32_t trace_stack_capacity() { return (uint32_t)(STACK_LDS + STACK_SPILL); }
 size_t trace_workspace_spill_entries(uint32_t max_blocks) { return size_t(max_blocks) * std::max(TRAV_BLOCK, PP_BLOCK) * STACK_SPILL; }
 #endif // PR_TU == 0
 

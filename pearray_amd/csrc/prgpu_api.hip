@@ -181,6 +181,7 @@ struct prgpu_scene {
 	uint32_t n_pixels = 0, n_slots = 0;
 	std::vector<void*> allocations;
 	uint32_t bvh_units = 0; // 64-byte units of the BVH record array
+	uint32_t bvh_stack_bound = 0;
 	float bvh_cost4 = 0.0f, bvh_cost6 = 0.0f; // the builder's estimates for the 4- and the 6-wide tree (prgpu_pipeline_info)
 	int pp_shader_waves = -1; // persistent kernel: dedicated shading waves per block, decided after the first launch (-1: not yet)
 	double pp_shading_share = 0.0; // ... from this measured share of shading passes in the wave time
@@ -572,6 +573,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	if (s->knobs.bvh_width_invalid)
 		return fail(PRGPU_EINVAL, "PRGPU_BVH_WIDTH must be auto, 4 or 6");
 	bin.width = s->knobs.bvh_width;
+	bin.stack_capacity = prd::trace_stack_capacity();
 	prd::BvhBuildOutput bout;
 	{
 		TraceRange bvh_range("prgpu_scene_create: LBVH build");
@@ -586,6 +588,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	sc.bvh_wide = bout.wide ? 1u : 0u;
 	s->bvh_cost4 = bout.cost4;
 	s->bvh_cost6 = bout.cost6;
+	s->bvh_stack_bound = bout.stack_bound;
 	sc.n_leaf  = bout.n_leaf;
 	s->bvh_units = bout.n_units;
 	{ // triangle -> leaf slot (the split traversal re-tests the winning triangle of a ray for u, v)
@@ -1889,6 +1892,7 @@ int prgpu_pipeline_info_get(prgpu_scene* s, prgpu_pipeline_info* out)
 	out->bvh_width		 = s->sc.bvh_wide ? 6u : 4u;
 	out->bvh_cost_4_wide = s->bvh_cost4;
 	out->bvh_cost_6_wide = s->bvh_cost6;
+	out->bvh_stack_bound = s->bvh_stack_bound;
 	return PRGPU_OK;
 }
 

@@ -114,3 +114,51 @@ def test_an_unknown_width_is_refused(monkeypatch):
     sc = scene.cornell_box(8, 8, spp=1)
     h = C.c_void_p()
     assert abi.load().prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) == -1 and b"PRGPU_BVH_WIDTH" in abi.load().prgpu_last_error()
+
+
+def _deep_chain_scene(duplicates):
+    """A radix tree that is ONE CHAIN: triangle m sits where Morton bit m alone is set (axis m mod 3, level m // 3 of its 16), so that every split peels one
+    triangle off; `duplicates` more triangles share the deepest cell and hang a balanced subtree below the chain's end.  A wall behind them bounds the entity."""
+    pts = []
+    for level in range(16):
+        for axis in range(3):
+            p = np.zeros(3); p[axis] = 2.0 ** -(level + 1)
+            pts.append(p)
+    pts += [np.zeros(3)] * duplicates
+    pts = np.array(pts, dtype=np.float64) * 8.0
+    tri = np.array([[0, 0, 0], [1e-4, 0, 0], [0, 1e-4, 0]], dtype=np.float64)
+    pos = (pts[:, None, :] + tri[None]).reshape(-1, 3)
+    pos = np.concatenate([pos, np.array([[8.0, 8.0, 8.0], [8.0 - 1e-4, 8.0, 8.0], [8.0, 8.0 - 1e-4, 8.0]])]).astype(np.float32)   # the far corner of the bounds
+    b = scene.SceneBuilder(24, 16)
+    b.settings.aa_samples = 2
+    b.add_mesh(pos, np.arange(len(pos), dtype=np.uint32).reshape(-1, 3), b.lambert(b.spectrum_const(0.6)))
+    light = np.array([[-1.0, -1.0, 9.0], [9.0, -1.0, 9.0], [-1.0, 9.0, 9.0]], dtype=np.float32)
+    b.add_mesh(light, np.array([[0, 1, 2]], dtype=np.uint32), b.lambert(b.spectrum_const(0.0)), emission=b.diffuse_emission(b.illuminant_d65()))
+    return b.build()
+
+
+def test_a_tree_too_deep_for_the_traversal_stack_is_refused_not_walked(monkeypatch):
+    """A lane's traversal stack holds 80 entries (16 in LDS + 64 spilled); a walk that needed more would drop subtrees without a word.  The builder
+    knows the worst case of the tree it built (every child of every record on the deepest path hit): `auto` only takes a tree that fits, a forced
+    width whose tree does not fit is an error at scene creation, and the tree that fits renders the checker's frame."""
+    lib = abi.load()
+    sc = _deep_chain_scene(duplicates=2000)            # chain of 48 + a subtree of 11 levels: the four-wide tree is 3 x 30 = 90 entries deep
+    monkeypatch.setenv("PRGPU_BVH_WIDTH", "4")
+    h = C.c_void_p()
+    assert lib.prgpu_scene_create(C.byref(sc.desc), 0, C.byref(h)) != 0
+    assert b"stack" in lib.prgpu_last_error() and b"80" in lib.prgpu_last_error(), lib.prgpu_last_error()
+    monkeypatch.setenv("PRGPU_BVH_WIDTH", "auto")
+    g, o = render_both(sc, iters=2)
+    info = g.pipelineInfo()
+    assert info["bvh_width"] == 6 and 0 < info["bvh_stack_bound"] <= 80, info
+    assert_parity(g, o, exact=True)
+    rng = np.random.default_rng(5)
+    org = rng.uniform(-1, 9, (4000, 3)).astype(np.float32)
+    d = rng.normal(size=(4000, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    org[::2] = (np.array([4.0, 4.0, 4.0]) - 6.0 * d[::2]).astype(np.float32)   # half of them through the middle, towards the origin's corner
+    got, want = g.traceRays(org, d, 1e-4, np.inf), o.trace_closest(org, d, 1e-4, np.inf, brute=True)
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    # ordinary scenes are nowhere near the limit
+    g2 = backend.RenderContext(scene.cornell_soup(64, 48, spp=1, n_triangles=200_000))
+    assert 0 < g2.pipelineInfo()["bvh_stack_bound"] <= 48, g2.pipelineInfo()
