@@ -2967,26 +2967,29 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest(DevScene sc, uin
 // 64-bit LDS minimum over (t, triangle id) -- exactly the reference's rule "closer, or equally close with the smaller id".  A ray is
 // finished when its stack is empty and none of its tasks is outstanding; u, v come from one more test of the winning triangle
 // (found through tri_slot: triangle -> leaf unit and slot).  Inner steps see the best t one batch late (more records visited).
-constexpr uint32_t SPLIT_Q = 1024; // ring of leaf tasks (owner lane | leaf unit << 8)
+// ring of leaf tasks (owner lane | leaf unit << 8): a wave's inner step adds at most 64 x 4 tasks (six-wide trees: 64 x 6) on top of a quarter of the ring
+template <bool WIDE>
+struct SplitRing {
+	static constexpr uint32_t N = WIDE ? 2048u : 1024u;
+};
 // ---- split traversal: leaf tests handed to whole waves through an LDS task queue (ray service, k_service_closest_split: one block-wide queue) ----
 // inner step of the split traversal: hit children that are leaves become tasks at once (they never enter the stack), the inner ones
 // are sorted and pushed as in trav_inner_rec.  Returns nothing; *n_tasks = leaves queued by this lane.
-template <typename STK>
-__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, uint32_t* q, uint32_t* q_tail,
+template <bool WIDE, typename STK>
+__device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4& q0, const float4& q1, const float4& q2, const float4& q3, uint32_t* q, uint32_t* q_tail,
 												 uint32_t* pending_own, uint32_t tid, bool active, const uint32_t* q_head, uint32_t* overflow)
 {
-	uint32_t key[4] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
-	if (active) {
-		uint32_t k6[6];
-		inner_keys(s, q0, q1, q2, q0, false, k6); // (4-wide trees only: prgpu_api.hip keeps the split traversal for them)
-		key[0] = k6[0], key[1] = k6[1], key[2] = k6[2], key[3] = k6[3];
-	}
+	constexpr int NW		= WIDE ? 6 : 4;
+	constexpr uint32_t SQ	= SplitRing<WIDE>::N;
+	uint32_t key[6] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu };
+	if (active)
+		inner_keys(s, q0, q1, q2, q3, WIDE, key);
 	const uint32_t base = __float_as_uint(q2.z);
-	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts through three ballots)
-	bool lf[4];
+	// leaves -> tasks: one ring allocation per wave (prefix sum of the per-lane counts -- at most 6 -- through three ballots)
+	bool lf[NW];
 	uint32_t cnt = 0;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) {
+	for (int k = 0; k < NW; ++k) {
 		lf[k] = key[k] != 0xFFFFFFFFu && (key[k] & REC_LEAF_BIT) != 0u;
 		cnt += lf[k] ? 1u : 0u;
 	}
@@ -3000,21 +3003,21 @@ __device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4&
 			if (lane == 0)
 				pos0 = __hip_atomic_fetch_add(q_tail, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			pos0 = wave_bcast0(pos0);
-			if (lane == 0 && pos0 + total - lds_load(q_head) > SPLIT_Q) // cannot happen while callers keep the ring below a quarter full and a
+			if (lane == 0 && pos0 + total - lds_load(q_head) > SQ) // cannot happen while callers keep the ring below a quarter full and a
 				__hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // step adds at most 256 per wave; loud if it does
 			uint32_t pos = pos0 + (uint32_t)__popcll(b0 & below) + 2u * (uint32_t)__popcll(b1 & below) + 4u * (uint32_t)__popcll(b2 & below);
 			if (cnt)
 				__hip_atomic_fetch_add(pending_own, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-			for (int k = 0; k < 4; ++k)
+			for (int k = 0; k < NW; ++k)
 				if (lf[k]) // task = leaf unit << 8 | owner lane (the ref is unit << 2 | 1)
-					__hip_atomic_store(&q[(pos++) & (SPLIT_Q - 1u)], (((base + (key[k] & 0xFFu)) >> REC_UNIT_SHIFT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					__hip_atomic_store(&q[(pos++) & (SQ - 1u)], (((base + (key[k] & 0xFFu)) >> REC_UNIT_SHIFT) << 8) | tid, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 	}
 	if (!active)
 		return;
 #pragma unroll
-	for (int k = 0; k < 4; ++k)
+	for (int k = 0; k < NW; ++k)
 		key[k] = lf[k] ? 0xFFFFFFFFu : key[k];
 #define PR_CSWAP(a, b)                                  \
 	{                                                   \
@@ -3022,9 +3025,16 @@ __device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4&
 		key[b]			  = max(key[a], key[b]);        \
 		key[a]			  = lo;                         \
 	}
-	PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+	if (WIDE) {
+		PR_CSWAP(0, 5) PR_CSWAP(1, 3) PR_CSWAP(2, 4) PR_CSWAP(1, 2) PR_CSWAP(3, 4) PR_CSWAP(0, 3) PR_CSWAP(2, 5) PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(4, 5) PR_CSWAP(1, 2) PR_CSWAP(3, 4)
+		st.reserve(5);
+		st.push_if(key[5] != 0xFFFFFFFFu, base + (key[5] & 0xFFu), key[5]);
+		st.push_if(key[4] != 0xFFFFFFFFu, base + (key[4] & 0xFFu), key[4]);
+	} else {
+		PR_CSWAP(0, 1) PR_CSWAP(2, 3) PR_CSWAP(0, 2) PR_CSWAP(1, 3) PR_CSWAP(1, 2)
+		st.reserve(3);
+	}
 #undef PR_CSWAP
-	st.reserve(3);
 	st.push_if(key[3] != 0xFFFFFFFFu, base + (key[3] & 0xFFu), key[3]);
 	st.push_if(key[2] != 0xFFFFFFFFu, base + (key[2] & 0xFFu), key[2]);
 	st.push_if(key[1] != 0xFFFFFFFFu, base + (key[1] & 0xFFu), key[1]);
@@ -3033,12 +3043,13 @@ __device__ __forceinline__ void trav_inner_split(Trav& s, STK& st, const float4&
 }
 
 constexpr bool COUNT_SPLIT_STEPS = true;
+template <bool WIDE>
 struct SplitShared {
 	uint2 stack[STACK_LDS * TRAV_BLOCK];
 	float4 rc[2][TRAV_BLOCK];			   // per owner lane: (o.xyz, packed kx/ky/kz), (Sx, Sy, Sz, tmin)
 	unsigned long long best[TRAV_BLOCK];   // (t bits << 32) | triangle id
 	uint32_t pending[TRAV_BLOCK];		   // tasks of the lane's ray not yet merged
-	uint32_t q[SPLIT_Q];
+	uint32_t q[SplitRing<WIDE>::N];
 	uint32_t q_head, q_tail, overflow;
 };
 __global__ void k_tri_slot(DevScene sc, const uint32_t* __restrict__ leaf_units, uint32_t* __restrict__ tri_slot)
@@ -3052,14 +3063,16 @@ __global__ void k_tri_slot(DevScene sc, const uint32_t* __restrict__ leaf_units,
 	for (uint32_t k = 0; k < cnt && k < 3u; ++k)
 		tri_slot[__float_as_uint(f[10 * k + 9]) & ~PRIM_SPHERE_BIT] = (unit << 2) | k;
 }
+template <bool WIDE>
 __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene sc, uint32_t n, const float* __restrict__ org, const float* __restrict__ dir,
 																	 const float* __restrict__ tmin_a, const float* __restrict__ tmax_a, uint32_t* entity,
 																	 uint32_t* prim, float* u, float* v, float* t, uint32_t* queue_head, uint2* spill,
 																	 const uint32_t* __restrict__ tri_slot, int refill_below, unsigned long long* gstats)
 {
-	__shared__ SplitShared sh;
+	constexpr uint32_t SQ = SplitRing<WIDE>::N;
+	__shared__ SplitShared<WIDE> sh;
 	const uint32_t tid = threadIdx.x, lane = tid & 63u;
-	for (uint32_t i = tid; i < SPLIT_Q; i += TRAV_BLOCK)
+	for (uint32_t i = tid; i < SQ; i += TRAV_BLOCK)
 		sh.q[i] = PP_EMPTY;
 	sh.pending[tid] = 0;
 	if (tid == 0)
@@ -3085,7 +3098,7 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene s
 		if (nt == 0u)
 			return false;
 		if (lane < nt) {
-			const uint32_t task	 = ring_take(sh.q, SPLIT_Q - 1u, first + lane);
+			const uint32_t task	 = ring_take(sh.q, SQ - 1u, first + lane);
 			const uint32_t owner = task & 0xFFu, unit = task >> 8;
 			RayPre r;
 			const float4 ra = sh.rc[0][owner], rb = sh.rc[1][owner];
@@ -3179,13 +3192,13 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene s
 			} else if (can_inner) {
 				if (COUNT_SPLIT_STEPS && lane == 0)
 					++witers;
-				// room for the (at most 4 x 64) tasks of this step
-				while (wave_bcast0(lds_load(&sh.q_tail) - lds_load(&sh.q_head)) > SPLIT_Q / 4u)
+				// room for the (at most 4 x 64, six-wide trees 6 x 64) tasks of this step
+				while (wave_bcast0(lds_load(&sh.q_tail) - lds_load(&sh.q_head)) > SQ / 4u)
 					if (!leaf_batch())
 						__builtin_amdgcn_s_sleep(1);
 				{
 					const bool act = has_ray && s.cur != REC_EMPTY; // every such lane is at an inner node: leaves never stay in s.cur
-					float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0;
+					float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
 					if (act) {
 						s.best.t = __uint_as_float((uint32_t)(__hip_atomic_load(&sh.best[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 32));
 						++cn;
@@ -3193,8 +3206,10 @@ __global__ void __launch_bounds__(TRAV_BLOCK) k_service_closest_split(DevScene s
 						q0 = rec[0];
 						q1 = rec[1];
 						q2 = rec[2];
+						if (WIDE)
+							q3 = rec[3];
 					}
-					trav_inner_split(s, st, q0, q1, q2, sh.q, &sh.q_tail, &sh.pending[tid], tid, act, &sh.q_head, &sh.overflow);
+					trav_inner_split<WIDE>(s, st, q0, q1, q2, q3, sh.q, &sh.q_tail, &sh.pending[tid], tid, act, &sh.q_head, &sh.overflow);
 				}
 				spins = 0;
 			} else { // every ray of the wave waits for tasks another wave holds
@@ -3338,8 +3353,12 @@ void launch_service_closest_split(const DevScene& sc, uint32_t n, const float* o
 								  unsigned long long* gstats, hipStream_t st)
 {
 	(void)hipMemsetAsync(ws.queue_head, 0, sizeof(uint32_t), st);
-	hipLaunchKernelGGL(k_service_closest_split, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
-					   ws.spill, tri_slot, ws.refill_below, gstats);
+	if (sc.bvh_wide)
+		hipLaunchKernelGGL(k_service_closest_split<true>, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
+						   ws.spill, tri_slot, ws.refill_below, gstats);
+	else
+		hipLaunchKernelGGL(k_service_closest_split<false>, trav_grid(ws, n), dim3(TRAV_BLOCK), 0, st, sc, n, org, dir, tmin, tmax, entity, prim, u, v, t, ws.queue_head,
+						   ws.spill, tri_slot, ws.refill_below, gstats);
 }
 void launch_service_any(const DevScene& sc, uint32_t n, const float* org, const float* dir, const float* tmin, const float* distance,
 						uint8_t* occluded, const TraceWorkspace& ws, unsigned long long* gstats, hipStream_t st)

@@ -1562,7 +1562,7 @@ int prgpu_trace_closest(prgpu_scene* s, uint32_t n, const float* org, const floa
 	// closest-hit service rays take the split traversal (leaf tests through an LDS task queue: identical results, 17 % faster) unless
 	// PRGPU_TRACE_SPLIT=0 or the tree has too many records for the 24-bit task field
 	const bool split = read_knobs().trace_split;
-	if (!s->sc.bvh_wide && split && s->sc.n_leaf > 0 && s->bvh_units < (1u << 24) && !(s->sc.features & (prd::FEAT_SPHERES | prd::FEAT_QUADRICS))) {
+	if (split && s->sc.n_leaf > 0 && s->bvh_units < (1u << 24) && !(s->sc.features & (prd::FEAT_SPHERES | prd::FEAT_QUADRICS))) {
 		prd::launch_service_closest_split(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, const_cast<uint32_t*>(s->sc.tri_slot), s->gstats, s->stream);
 	} else
 		prd::launch_service_closest(s->sc, n, d_org, d_dir, d_tmin, d_tmax, d_e, d_p, d_u, d_v, d_t, s->ws, s->gstats, s->stream);

@@ -39,7 +39,7 @@ def test_frames_are_bit_exact_and_the_scene_reports_its_tree(width):
 
 def test_the_ray_service_on_either_tree(width, monkeypatch):
     P.test_ray_service_hit_ids_exact_cornell()
-    for split in ("1", "0"):     # (a six-wide tree is walked without the split traversal whatever the knob says)
+    for split in ("1", "0"):     # the split traversal (compiled for both widths) and the classic kernel
         P.test_ray_service_hit_ids_exact_soup_vs_brute_force(monkeypatch, split)
     for seed in (2, 9, 20, 33):
         R.test_random_scene_ray_service(seed)
