@@ -713,7 +713,8 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 	uint32_t *gsize = nullptr, *gbase = nullptr, *inner_unit = nullptr;
 	uint64_t *keys = nullptr, *keys_sorted = nullptr;
 	int *left = nullptr, *right = nullptr, *rf = nullptr, *rl = nullptr, *parent = nullptr, *front = nullptr, *front_next = nullptr;
-	double* front_count = nullptr;
+	uint32_t* front_count = nullptr; // records found for the next level of the greedy collapse's top-down pass
+	double* area_sums = nullptr;	 // [0] the parity tree's records, [1] the greedy tree's
 	uint32_t *stack_bound = nullptr, *bounds_dev = nullptr, bounds_host[2] = { 0u, 0u };
 	uint32_t* greedy_flag = nullptr;
 	int width = 0; // gather_children: 0 = the parity collapse, MAX_WIDE = the greedy one
@@ -783,9 +784,10 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 				HIPC(hipMalloc(&front_next, sizeof(int) * n));
 				HIPC(hipMalloc(&stack_bound, sizeof(uint32_t) * n));
 				HIPC(hipMemsetAsync(stack_bound, 0, sizeof(uint32_t), stream)); // the root's
-				HIPC(hipMalloc(&front_count, sizeof(double) * 3)); // (the two area sums live behind the counter)
+				HIPC(hipMalloc(&front_count, sizeof(uint32_t)));
+				HIPC(hipMalloc(&area_sums, sizeof(double) * 2));
 				HIPC(hipMemsetAsync(greedy_flag, 0, sizeof(uint32_t) * n, stream));
-				HIPC(hipMemsetAsync(front_count, 0, sizeof(double) * 3, stream));
+				HIPC(hipMemsetAsync(area_sums, 0, sizeof(double) * 2, stream));
 				const uint32_t one = 1u;
 				const int root	   = 0;
 				HIPC(hipMemcpyAsync(greedy_flag, &one, 4, hipMemcpyHostToDevice, stream));
@@ -794,23 +796,23 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 				while (n_front != 0u) {
 					HIPC(hipMemsetAsync(front_count, 0, sizeof(uint32_t), stream));
 					hipLaunchKernelGGL(k_mark_records, dim3((n_front + B - 1) / B), dim3(B), 0, stream, (int)n_front, front, MAX_WIDE, wv, vals_sorted, left, right, rf, rl, boxes,
-									   greedy_flag, front_next, reinterpret_cast<uint32_t*>(front_count), stack_bound, bounds_dev + 1);
+									   greedy_flag, front_next, front_count, stack_bound, bounds_dev + 1);
 					HIPC(hipMemcpyAsync(&n_front, front_count, 4, hipMemcpyDeviceToHost, stream));
 					HIPC(hipStreamSynchronize(stream));
 					std::swap(front, front_next);
 				}
-				double sums[3] = { 0.0, 0.0, 0.0 };
-				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, inner_flag, boxes, front_count + 1);
-				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, greedy_flag, boxes, front_count + 2);
+				double sums[2] = { 0.0, 0.0 };
+				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, inner_flag, boxes, area_sums);
+				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, greedy_flag, boxes, area_sums + 1);
 				float root_box[6];
 				HIPC(hipMemcpyAsync(bounds_host, bounds_dev, sizeof(bounds_host), hipMemcpyDeviceToHost, stream));
-				HIPC(hipMemcpyAsync(sums, front_count, sizeof(sums), hipMemcpyDeviceToHost, stream));
+				HIPC(hipMemcpyAsync(sums, area_sums, sizeof(sums), hipMemcpyDeviceToHost, stream));
 				HIPC(hipMemcpyAsync(root_box, boxes, sizeof(root_box), hipMemcpyDeviceToHost, stream));
 				HIPC(hipStreamSynchronize(stream));
 				const double rx = (double)root_box[3] - root_box[0], ry = (double)root_box[4] - root_box[1], rz = (double)root_box[5] - root_box[2];
 				const double ra = std::max(rx * ry + ry * rz + rz * rx, 1e-300);
-				out.cost4 = (float)(sums[1] / ra);
-				out.cost6 = (float)(sums[2] / ra);
+				out.cost4 = (float)(sums[0] / ra);
+				out.cost6 = (float)(sums[1] / ra);
 				// width 0: six-wide where its tree saves more records than its longer step costs (WIDE_STEP_COST: measured)
 				const uint32_t bound4 = 3u * (bounds_host[0] + 1u), bound6 = bounds_host[1];
 				out.stack_bound		  = bound4;
@@ -902,7 +904,7 @@ done:
 	(void)hipFree(wv); (void)hipFree(ebounds); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted);
 	(void)hipFree(left); (void)hipFree(right); (void)hipFree(rf); (void)hipFree(rl); (void)hipFree(parent); (void)hipFree(boxes); (void)hipFree(arrive);
 	(void)hipFree(inner_flag); (void)hipFree(inner_idx); (void)hipFree(leaf_flag); (void)hipFree(leaf_cnt); (void)hipFree(leaf_idx);
-	(void)hipFree(front); (void)hipFree(front_next); (void)hipFree(front_count); (void)hipFree(greedy_flag); (void)hipFree(stack_bound); (void)hipFree(bounds_dev);
+	(void)hipFree(front); (void)hipFree(front_next); (void)hipFree(front_count); (void)hipFree(area_sums); (void)hipFree(greedy_flag); (void)hipFree(stack_bound); (void)hipFree(bounds_dev);
 	(void)hipFree(temp); (void)hipFree(temp2); (void)hipFree(gsize); (void)hipFree(gbase); (void)hipFree(inner_unit);
 	if (!ok) {
 		(void)hipFree(out.recs);
