@@ -1,6 +1,6 @@
 """Inner BVH records of four against six children (PRGPU_BVH_WIDTH) over a set of scenes: the builder's estimate of either tree, the width
 `auto` takes, inner / leaf records per ray and ms per iteration under each forced width -- and whether `auto` took the faster one.
-usage: python tools/gpu_bvh_width.py [scene ...]     (GPU box; scenes: c4 c5 soup100k soup4m box glassy rough sheets; profiles/r05_bvh_width.log)"""
+usage: python tools/gpu_bvh_width.py [scene ...]     (GPU box; scenes: c4 c5 soup100k soup4m box glassy rough sheets clusters spheres terrain; profiles/r05_bvh_width.log)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -31,10 +31,61 @@ def c5():
     return sc
 
 
+def cornell_with(pos, faces):
+    """The Cornell box (camera, light, walls) with a mesh of its own inside instead of the uniform soup."""
+    b = scene.SceneBuilder(W, H)
+    b.settings.aa_sampler, b.settings.aa_samples = 0, 1024
+    b.settings.aa_sampler = scene.abi.SAMPLER_SOBOL
+    mats = scene._cornell_into(b)
+    b.add_mesh(pos.astype(np.float32), faces.astype(np.uint32), mats["backWall"])
+    return b.build()
+
+
+def clusters(n=1_000_000, k=96, seed=3):
+    """Triangles of uneven density: k Gaussian clusters whose radii span 1.5 decades, triangle size following the cluster's radius."""
+    rng = np.random.default_rng(seed)
+    centre = rng.uniform([-0.8, -0.8, 0.2], [0.8, 0.8, 1.7], (k, 3))
+    radius = 10.0 ** rng.uniform(-2.3, -0.8, k)
+    which = rng.integers(0, k, n)
+    c = centre[which] + rng.normal(size=(n, 3)) * radius[which, None]
+    c = np.clip(c, [-0.95, -0.95, 0.05], [0.95, 0.95, 1.9])
+    size = 0.15 * radius[which, None]
+    e1, e2 = rng.uniform(-1, 1, (n, 3)) * size, rng.uniform(-1, 1, (n, 3)) * size
+    pos = np.stack([c, c + e1, c + e2], 1).reshape(-1, 3)
+    return cornell_with(pos, np.arange(3 * n).reshape(n, 3))
+
+
+def spheres(count=60, nlat=48, nlon=96, seed=5):
+    """Tessellated spheres of different radii (closed regular meshes: what a modelled object looks like to the builder)."""
+    rng = np.random.default_rng(seed)
+    th, ph = np.linspace(0, np.pi, nlat + 1), np.linspace(0, 2 * np.pi, nlon, endpoint=False)
+    unit = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.sin(th), np.sin(ph)), np.outer(np.cos(th), np.ones_like(ph))], -1).reshape(-1, 3)
+    i, j = np.meshgrid(np.arange(nlat), np.arange(nlon), indexing="ij")
+    a, b_, c, d = i * nlon + j, i * nlon + (j + 1) % nlon, (i + 1) * nlon + j, (i + 1) * nlon + (j + 1) % nlon
+    quad = np.concatenate([np.stack([a, c, b_], -1).reshape(-1, 3), np.stack([b_, c, d], -1).reshape(-1, 3)])
+    pos, faces = [], []
+    for s_ in range(count):
+        r = 10.0 ** rng.uniform(-1.7, -0.7)
+        centre = rng.uniform([-0.8, -0.8, 0.2], [0.8, 0.8, 1.7])
+        faces.append(quad + len(pos) * len(unit)); pos.append(unit * r + centre)
+    return cornell_with(np.concatenate(pos), np.concatenate(faces))
+
+
+def terrain(n=1000):
+    """A height field of n x n cells (2 n^2 triangles) across the floor of the box."""
+    x = np.linspace(-0.95, 0.95, n + 1)
+    X, Y = np.meshgrid(x, x, indexing="ij")
+    Z = 0.25 + 0.12 * np.sin(7 * X) * np.cos(5 * Y) + 0.04 * np.sin(31 * X + 17 * Y) + 0.01 * np.sin(113 * X) * np.sin(97 * Y)
+    pos = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    a, b_, c, d = i * (n + 1) + j, i * (n + 1) + j + 1, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1
+    return cornell_with(pos, np.concatenate([np.stack([a, c, b_], -1).reshape(-1, 3), np.stack([b_, c, d], -1).reshape(-1, 3)]))
+
+
 SCENES = {"c4": lambda: scene.cornell_soup(W, H, spp=1024, n_triangles=1_000_000), "c5": c5,
           "soup100k": lambda: scene.cornell_soup(W, H, spp=1024, n_triangles=100_000), "soup4m": lambda: scene.cornell_soup(W, H, spp=1024, n_triangles=4_000_000),
           "box": lambda: scene.cornell_box(W, H, spp=1024), "glassy": lambda: scene.cornell_glassy(W, H, spp=1024), "rough": lambda: scene.cornell_rough(W, H, spp=1024),
-          "sheets": sheets}
+          "sheets": sheets, "clusters": clusters, "spheres": spheres, "terrain": terrain}
 
 
 def run(sc, width, iters=16):
