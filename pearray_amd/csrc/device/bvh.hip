@@ -12,6 +12,8 @@
 #include "bvh.h"
 
 #include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstring>
 
 namespace prd {
 namespace {
@@ -82,7 +84,7 @@ __device__ __forceinline__ uint64_t expand_bits_16(uint32_t v) // 16 bits -> eve
 
 // 2. key = entity (16 bits) | 48-bit Morton code of the triangle-box centre in the entity's bounds
 __global__ void k_morton(uint32_t n, const float4* __restrict__ wv, const uint32_t* __restrict__ tri_entity,
-						 const uint32_t* __restrict__ ebounds, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
+						 const uint32_t* __restrict__ ebounds, const uint32_t* __restrict__ entity_rank, uint64_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
 	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= n)
@@ -101,7 +103,7 @@ __global__ void k_morton(uint32_t n, const float4* __restrict__ wv, const uint32
 		q[k]			= (uint32_t)f;
 	}
 	const uint64_t morton = (expand_bits_16(q[0]) << 2) | (expand_bits_16(q[1]) << 1) | expand_bits_16(q[2]);
-	keys[t] = (uint64_t(e & 0xFFFFu) << 48) | morton;
+	keys[t] = (uint64_t(entity_rank[e] & 0xFFFFu) << 48) | morton;
 	vals[t] = t;
 }
 
@@ -224,8 +226,8 @@ __device__ __forceinline__ void pad_box(float* lo, float* hi)
 //     radix node's two children, and while there are fewer than six the one of largest surface area that is not a leaf is replaced by its two.
 // build_lbvh computes both sets of records' expected visits per ray (k_area_sum) and keeps the cheaper tree; a six-wide step counts 1.35 x.
 __global__ void k_depth_and_flags(int n, const int* __restrict__ parent, const int* __restrict__ range_first, const int* __restrict__ range_last,
-								  uint32_t* __restrict__ inner_flag /* n-1 */, uint32_t* __restrict__ leaf_flag /* n */, uint32_t* __restrict__ leaf_count /* n */,
-								  uint32_t* __restrict__ max_record_depth)
+								  uint32_t* __restrict__ inner_flag /* n-1: records of the even-depth collapse */, uint32_t* __restrict__ odd_flag /* ... of the odd-depth one */,
+								  uint32_t* __restrict__ leaf_flag /* n */, uint32_t* __restrict__ leaf_count /* n */, uint32_t* __restrict__ max_record_depth /* [2]: even, odd */)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n - 1) {
@@ -234,8 +236,11 @@ __global__ void k_depth_and_flags(int n, const int* __restrict__ parent, const i
 			++depth;
 		const int cnt = range_last[i] - range_first[i] + 1;
 		inner_flag[i] = ((depth & 1) == 0 && cnt > 3) ? 1u : 0u;
+		odd_flag[i]	  = (((depth & 1) == 1 || i == 0) && cnt > 3) ? 1u : 0u; // (the root is a record of two children there)
 		if (inner_flag[i])
 			atomicMax(max_record_depth, (uint32_t)depth / 2u); // records above this one on its way from the root
+		if (odd_flag[i])
+			atomicMax(max_record_depth + 1, ((uint32_t)depth + 1u) / 2u);
 		if (cnt <= 3) {
 			const int p	   = parent[i];
 			const int pcnt = range_last[p] - range_first[p] + 1; // i != root here because cnt(root) = n > 3
@@ -302,7 +307,8 @@ __device__ __forceinline__ ChildRef make_child(int c, bool& expandable, const fl
 }
 // The children of inner record i, LEAVES FIRST (a record's children lie contiguously from one base unit and leaves are 128-byte
 // aligned: base even, leaves of two units each first, inner records of one unit after them), otherwise in radix-tree order.
-// width == 0: the PARITY collapse -- the radix node's grandchildren (inner records are the radix nodes at even depth, k_depth_and_flags).
+// width == 0 | -1: the PARITY collapse -- the radix node's grandchildren; inner records are the radix nodes at even depth (0) or at odd depth
+// and the root (-1: k_depth_and_flags marks both sets, build_lbvh takes the one whose records a ray visits less).
 // width >= 2: the GREEDY collapse -- start from the two radix children and, while fewer than `width`, replace the child of largest
 // surface area that is not a leaf by its own two children; which radix nodes are records then follows top-down (k_mark_records).
 __device__ __forceinline__ float half_area(const ChildRef& c)
@@ -316,12 +322,12 @@ __device__ int gather_children(int i, ChildRef* ch, int width, const float4* __r
 {
 	ChildRef tmp[MAX_WIDE];
 	int nc = 0;
-	if (width == 0) {
+	if (width <= 0) {
 		for (int side = 0; side < 2; ++side) {
 			const int c = side == 0 ? left[i] : right[i];
 			bool expandable;
 			const ChildRef direct = make_child(c, expandable, wv, sorted_tri, range_first, range_last, boxes, inner_idx, leaf_idx);
-			if (!expandable) {
+			if (!expandable || (width < 0 && i == 0)) { // (odd-depth collapse: the root's two children are records themselves)
 				tmp[nc++] = direct;
 			} else { // odd-depth internal node with > 3 triangles: pull its two children up
 				bool e2;
@@ -702,26 +708,149 @@ __global__ void k_tiny_scene(uint32_t n, const float4* __restrict__ wv, const ui
 
 } // namespace
 
+namespace {
+// 16-bit codes for the sort key's entity field: the entity's path (0 = left, 1 = right, most significant bit first) in a binary tree over the
+// entities' world boxes.  A set is split where (area of the left box x its triangles + area of the right box x its triangles) is smallest over
+// the three axes' centroid orders; a side never takes more entities than the bits left can tell apart.  Entities without triangles share the
+// code of whoever comes last (they own no key).
+struct EntityBox {
+	float lo[3], hi[3];
+	double weight;
+	uint32_t id;
+};
+void entity_codes_split(std::vector<EntityBox>& set, size_t first, size_t count, uint32_t prefix, int bits_left, std::vector<uint32_t>& code)
+{
+	if (count == 1 || bits_left == 0) { // (bits_left == 0 with count > 1 cannot happen: the capacity rule below)
+		for (size_t k = 0; k < count; ++k)
+			code[set[first + k].id] = prefix;
+		return;
+	}
+	const size_t cap = size_t(1) << (bits_left - 1); // entities one side can still tell apart
+	double best_cost = INFINITY;
+	int best_axis	 = 0;
+	size_t best_left = count / 2;
+	std::vector<double> right_area(count), right_weight(count);
+	for (int axis = 0; axis < 3; ++axis) {
+		std::sort(set.begin() + first, set.begin() + first + count,
+				  [axis](const EntityBox& a, const EntityBox& b) { return a.lo[axis] + a.hi[axis] < b.lo[axis] + b.hi[axis] || (a.lo[axis] + a.hi[axis] == b.lo[axis] + b.hi[axis] && a.id < b.id); });
+		auto area = [](const float* lo, const float* hi) {
+			const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+			return dx * dy + dy * dz + dz * dx;
+		};
+		float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+		double w = 0.0;
+		for (size_t k = count; k-- > 1;) { // suffix boxes: right side = [k, count)
+			for (int a = 0; a < 3; ++a) {
+				lo[a] = std::min(lo[a], set[first + k].lo[a]);
+				hi[a] = std::max(hi[a], set[first + k].hi[a]);
+			}
+			w += set[first + k].weight;
+			right_area[k]	= area(lo, hi);
+			right_weight[k] = w;
+		}
+		for (int a = 0; a < 3; ++a) {
+			lo[a] = INFINITY;
+			hi[a] = -INFINITY;
+		}
+		w = 0.0;
+		for (size_t k = 1; k < count; ++k) { // left side = [0, k)
+			for (int a = 0; a < 3; ++a) {
+				lo[a] = std::min(lo[a], set[first + k - 1].lo[a]);
+				hi[a] = std::max(hi[a], set[first + k - 1].hi[a]);
+			}
+			w += set[first + k - 1].weight;
+			if (k > cap || count - k > cap)
+				continue;
+			const double cost = area(lo, hi) * w + right_area[k] * right_weight[k];
+			if (cost < best_cost) {
+				best_cost = cost;
+				best_axis = axis;
+				best_left = k;
+			}
+		}
+	}
+	// One more candidate, which no sweep over centroid orders can produce: the heaviest entity alone (a mesh that fills the room has its centroid in
+	// the middle of every order, and every sweep leaves it with half the walls)
+	size_t heavy = 0;
+	for (size_t k = 1; k < count; ++k)
+		if (set[first + k].weight > set[first + heavy].weight)
+			heavy = k;
+	{
+		auto area = [](const float* lo, const float* hi) {
+			const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+			return dx * dy + dy * dz + dz * dx;
+		};
+		float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+		double w = 0.0;
+		for (size_t k = 0; k < count; ++k)
+			if (k != heavy) {
+				for (int a = 0; a < 3; ++a) {
+					lo[a] = std::min(lo[a], set[first + k].lo[a]);
+					hi[a] = std::max(hi[a], set[first + k].hi[a]);
+				}
+				w += set[first + k].weight;
+			}
+		const double cost = area(lo, hi) * w + area(set[first + heavy].lo, set[first + heavy].hi) * set[first + heavy].weight;
+		if (count - 1 <= cap && cost <= best_cost) {
+			std::swap(set[first + heavy], set[first + count - 1]);
+			entity_codes_split(set, first, count - 1, prefix, bits_left - 1, code);
+			entity_codes_split(set, first + count - 1, 1, prefix | (1u << (bits_left - 1)), bits_left - 1, code);
+			return;
+		}
+	}
+	std::sort(set.begin() + first, set.begin() + first + count, [best_axis](const EntityBox& a, const EntityBox& b) {
+		return a.lo[best_axis] + a.hi[best_axis] < b.lo[best_axis] + b.hi[best_axis] || (a.lo[best_axis] + a.hi[best_axis] == b.lo[best_axis] + b.hi[best_axis] && a.id < b.id);
+	});
+	if (best_left > cap || count - best_left > cap) // (no admissible split was priced: non-finite boxes) -- halves always fit
+		best_left = count / 2;
+	entity_codes_split(set, first, best_left, prefix, bits_left - 1, code);
+	entity_codes_split(set, first + best_left, count - best_left, prefix | (1u << (bits_left - 1)), bits_left - 1, code);
+}
+void entity_codes(const std::vector<uint32_t>& ebounds, const std::vector<DevEntity>& ents, std::vector<uint32_t>& code)
+{
+	auto to_f = [](uint32_t u) { const uint32_t b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
+	std::vector<EntityBox> set;
+	for (uint32_t e = 0; e < (uint32_t)ents.size(); ++e) {
+		EntityBox b;
+		bool ok = ents[e].n_tris > 0;
+		for (int a = 0; a < 3; ++a) {
+			b.lo[a] = to_f(ebounds[6 * e + a]);
+			b.hi[a] = to_f(ebounds[6 * e + 3 + a]);
+			ok		= ok && b.lo[a] <= b.hi[a];
+		}
+		b.weight = (double)ents[e].n_tris;
+		b.id	 = e;
+		if (ok)
+			set.push_back(b);
+	}
+	if (!set.empty())
+		entity_codes_split(set, 0, set.size(), 0u, 16, code);
+}
+} // namespace
+
 bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream, std::string& err)
 {
 	const uint32_t n = in.n_tris;
 	const int B		 = 256;
 	const uint32_t G = (n + B - 1) / B;
 	float4* wv = nullptr;
-	uint32_t *ebounds = nullptr, *vals = nullptr, *vals_sorted = nullptr, *arrive = nullptr;
+	uint32_t *entity_rank = nullptr, *ebounds = nullptr, *vals = nullptr, *vals_sorted = nullptr, *arrive = nullptr;
 	uint32_t *inner_flag = nullptr, *inner_idx = nullptr, *leaf_flag = nullptr, *leaf_cnt = nullptr, *leaf_idx = nullptr;
 	uint32_t *gsize = nullptr, *gbase = nullptr, *inner_unit = nullptr;
 	uint64_t *keys = nullptr, *keys_sorted = nullptr;
 	int *left = nullptr, *right = nullptr, *rf = nullptr, *rl = nullptr, *parent = nullptr, *front = nullptr, *front_next = nullptr;
 	uint32_t* front_count = nullptr; // records found for the next level of the greedy collapse's top-down pass
-	double* area_sums = nullptr;	 // [0] the parity tree's records, [1] the greedy tree's
-	uint32_t *stack_bound = nullptr, *bounds_dev = nullptr, bounds_host[2] = { 0u, 0u };
+	double* area_sums = nullptr;	 // summed area of the records of the even-depth, the odd-depth and the greedy tree
+	uint32_t *stack_bound = nullptr, *bounds_dev = nullptr, *odd_flag = nullptr, bounds_host[3] = { 0u, 0u, 0u };
 	uint32_t* greedy_flag = nullptr;
-	int width = 0; // gather_children: 0 = the parity collapse, MAX_WIDE = the greedy one
+	int width = 0; // gather_children: 0 = the parity collapse on even depths, -1 = on odd depths, MAX_WIDE = the greedy one
 	float* boxes = nullptr;
 	void *temp = nullptr, *temp2 = nullptr;
 	size_t temp_bytes = 0, temp2_bytes = 0, t2a = 0, t2b = 0;
 	bool ok = false;
+	std::vector<uint32_t> codes[2]; // the sort key's entity field: ids, or paths in a tree over the entities' boxes
+	double best_cost = INFINITY;
+	int best_order	 = 0;
 	out.recs	   = nullptr;
 	out.leaf_units = nullptr;
 	{
@@ -742,11 +871,144 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipStreamSynchronize(stream));
 		}
 		hipLaunchKernelGGL(k_world_tris, dim3(G), dim3(B), 0, stream, n, in.positions, in.indices, in.tri_entity, in.entities, wv, ebounds);
-		hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, n, wv, in.tri_entity, ebounds, keys, vals);
-		HIPC(hipGetLastError());
+		{ // The key's upper 16 bits separate the entities; the radix tree splits on the highest differing bit, so these bits ARE the top of the
+		  // tree.  Two candidates: the entity ids as the scene description lists them, and the entity's path in a small binary tree built
+		  // over the entities' world boxes (entity_codes).  Which top is better depends on the scene in ways the codes cannot see (C4 loses
+		  // 3 % with the second, C5 gains 8 %), so the tree is built with both and the one with the lower estimate is kept.
+			std::vector<uint32_t> eb(6 * size_t(in.n_entities));
+			std::vector<DevEntity> ents(in.n_entities);
+			HIPC(hipMemcpyAsync(eb.data(), ebounds, eb.size() * 4, hipMemcpyDeviceToHost, stream));
+			HIPC(hipMemcpyAsync(ents.data(), in.entities, ents.size() * sizeof(DevEntity), hipMemcpyDeviceToHost, stream));
+			HIPC(hipStreamSynchronize(stream));
+			codes[0].assign(in.n_entities, 0u);
+			codes[1].assign(in.n_entities, 0u);
+			for (uint32_t e = 0; e < in.n_entities; ++e)
+				codes[0][e] = e;
+			entity_codes(eb, ents, codes[1]);
+			HIPC(hipMalloc(&entity_rank, sizeof(uint32_t) * std::max<size_t>(in.n_entities, 1)));
+		}
 		HIPC(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
 		HIPC(hipMalloc(&temp, temp_bytes));
-		HIPC(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
+		if (n > 3) {
+			HIPC(hipMalloc(&left, sizeof(int) * (n - 1)));
+			HIPC(hipMalloc(&right, sizeof(int) * (n - 1)));
+			HIPC(hipMalloc(&rf, sizeof(int) * (n - 1)));
+			HIPC(hipMalloc(&rl, sizeof(int) * (n - 1)));
+			HIPC(hipMalloc(&parent, sizeof(int) * (2 * size_t(n) - 1)));
+			HIPC(hipMalloc(&boxes, sizeof(float) * 6 * (n - 1)));
+			HIPC(hipMalloc(&arrive, sizeof(uint32_t) * (n - 1)));
+			HIPC(hipMalloc(&inner_flag, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&odd_flag, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&inner_idx, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&leaf_flag, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&leaf_cnt, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&leaf_idx, sizeof(uint32_t) * n));
+			HIPC(hipMalloc(&bounds_dev, sizeof(uint32_t) * 3)); // deepest record of the even- and of the odd-depth collapse, deepest walk of the greedy tree
+			HIPC(hipMalloc(&area_sums, sizeof(double) * 3));	// even-depth, odd-depth, greedy
+			if (in.width != 4) {
+				HIPC(hipMalloc(&greedy_flag, sizeof(uint32_t) * n));
+				HIPC(hipMalloc(&front, sizeof(int) * n));
+				HIPC(hipMalloc(&front_next, sizeof(int) * n));
+				HIPC(hipMalloc(&stack_bound, sizeof(uint32_t) * n));
+				HIPC(hipMalloc(&front_count, sizeof(uint32_t)));
+			}
+		}
+		const int n_orders = (n > 3 && in.n_entities > 1) ? 2 : 1;
+		for (int pass = 0, order = 0;; ++pass) {
+			HIPC(hipMemcpyAsync(entity_rank, codes[order].data(), codes[order].size() * 4, hipMemcpyHostToDevice, stream));
+			hipLaunchKernelGGL(k_morton, dim3(G), dim3(B), 0, stream, n, wv, in.tri_entity, ebounds, entity_rank, keys, vals);
+			HIPC(hipGetLastError());
+			HIPC(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, vals, vals_sorted, (int)n, 0, 64, stream));
+			if (n <= 3)
+				break;
+			width			= 0;
+			out.wide		= false;
+			out.cost4		= 0.0f;
+			out.cost6		= 0.0f;
+			out.stack_bound = 0;
+			HIPC(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * (n - 1), stream));
+			HIPC(hipMemsetAsync(inner_flag, 0, sizeof(uint32_t) * n, stream));
+			HIPC(hipMemsetAsync(odd_flag, 0, sizeof(uint32_t) * n, stream));
+			HIPC(hipMemsetAsync(leaf_flag, 0, sizeof(uint32_t) * n, stream));
+			HIPC(hipMemsetAsync(leaf_cnt, 0, sizeof(uint32_t) * n, stream));
+			HIPC(hipMemsetAsync(bounds_dev, 0, sizeof(uint32_t) * 3, stream));
+			HIPC(hipMemsetAsync(area_sums, 0, sizeof(double) * 3, stream));
+			hipLaunchKernelGGL(k_radix_tree, dim3(G), dim3(B), 0, stream, (int)n, keys_sorted, left, right, rf, rl, parent);
+			hipLaunchKernelGGL(k_fit_bounds, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, parent, boxes, arrive);
+			hipLaunchKernelGGL(k_depth_and_flags, dim3(G), dim3(B), 0, stream, (int)n, parent, rf, rl, inner_flag, odd_flag, leaf_flag, leaf_cnt, bounds_dev);
+			HIPC(hipGetLastError());
+			if (in.width != 4) { // the greedy collapse: which radix nodes are records follows top-down from the root, one launch per level
+				HIPC(hipMemsetAsync(stack_bound, 0, sizeof(uint32_t), stream)); // the root's
+				HIPC(hipMemsetAsync(greedy_flag, 0, sizeof(uint32_t) * n, stream));
+				const uint32_t one = 1u;
+				const int root	   = 0;
+				HIPC(hipMemcpyAsync(greedy_flag, &one, 4, hipMemcpyHostToDevice, stream));
+				HIPC(hipMemcpyAsync(front, &root, 4, hipMemcpyHostToDevice, stream));
+				uint32_t n_front = 1u;
+				while (n_front != 0u) {
+					HIPC(hipMemsetAsync(front_count, 0, sizeof(uint32_t), stream));
+					hipLaunchKernelGGL(k_mark_records, dim3((n_front + B - 1) / B), dim3(B), 0, stream, (int)n_front, front, MAX_WIDE, wv, vals_sorted, left, right, rf, rl, boxes,
+									   greedy_flag, front_next, front_count, stack_bound, bounds_dev + 2);
+					HIPC(hipMemcpyAsync(&n_front, front_count, 4, hipMemcpyDeviceToHost, stream));
+					HIPC(hipStreamSynchronize(stream));
+					std::swap(front, front_next);
+				}
+				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, greedy_flag, boxes, area_sums + 2);
+			}
+			{ // Which tree: the estimate of each (the inner records a ray through the scene's box is expected to visit = the summed area of the
+			  // tree's records over the root's), a six-wide step counted WIDE_STEP_COST times, among the trees whose deepest walk fits the
+			  // traversal stack (a walk that ran out of stack would drop subtrees silently).
+				double sums[3] = { 0.0, 0.0, 0.0 };
+				float root_box[6];
+				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, inner_flag, boxes, area_sums);
+				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, odd_flag, boxes, area_sums + 1);
+				HIPC(hipMemcpyAsync(bounds_host, bounds_dev, sizeof(bounds_host), hipMemcpyDeviceToHost, stream));
+				HIPC(hipMemcpyAsync(sums, area_sums, sizeof(sums), hipMemcpyDeviceToHost, stream));
+				HIPC(hipMemcpyAsync(root_box, boxes, sizeof(root_box), hipMemcpyDeviceToHost, stream));
+				HIPC(hipStreamSynchronize(stream));
+				const double rx = (double)root_box[3] - root_box[0], ry = (double)root_box[4] - root_box[1], rz = (double)root_box[5] - root_box[2];
+				const double ra = std::max(rx * ry + ry * rz + rz * rx, 1e-300);
+				// the two parity collapses differ in where every subtree's records start: which is the better one is luck of the scene's layout
+				// (C4: 3.9 % more inner records per ray with the wrong one), so both are priced
+				const uint32_t bound_even = 3u * (bounds_host[0] + 1u), bound_odd = 3u * (bounds_host[1] + 1u), bound6 = bounds_host[2];
+				const bool fit_even = bound_even <= in.stack_capacity, fit_odd = bound_odd <= in.stack_capacity;
+				const bool odd = fit_odd && (!fit_even || sums[1] < sums[0]);
+				const uint32_t bound4 = odd ? bound_odd : bound_even;
+				if (odd) {
+					width = -1;
+					std::swap(inner_flag, odd_flag);
+				}
+				out.cost4		= (float)(sums[odd ? 1 : 0] / ra);
+				out.stack_bound = bound4;
+				if (in.width != 4) {
+					out.cost6 = (float)(sums[2] / ra);
+					const bool fit4 = bound4 <= in.stack_capacity, fit6 = bound6 <= in.stack_capacity;
+					const bool cheaper6 = (double)out.cost6 * WIDE_STEP_COST < (double)out.cost4;
+					if (in.width == 6 || (cheaper6 ? (fit6 || !fit4) : (!fit4 && fit6))) {
+						out.stack_bound = bound6;
+						width			= MAX_WIDE;
+						out.wide		= true;
+						std::swap(inner_flag, greedy_flag);
+					}
+				}
+			}
+			{ // the next candidate for the top of the tree, or once more the better one if that is not the one just built
+				const double cost = out.wide ? (double)out.cost6 * WIDE_STEP_COST : (double)out.cost4;
+				if (pass < n_orders && cost < best_cost) {
+					best_cost  = cost;
+					best_order = order;
+				}
+				if (pass + 1 < n_orders) {
+					order = pass + 1;
+					continue;
+				}
+				if (pass + 1 == n_orders && best_order != order) {
+					order = best_order;
+					continue;
+				}
+				break;
+			}
+		}
 		if (n <= 3) {
 			HIPC(hipMalloc(&out.recs, sizeof(Rec64) * 4));
 			HIPC(hipMemsetAsync(out.recs, 0, sizeof(Rec64) * 4, stream));
@@ -756,76 +1018,6 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			out.n_leaf	= 1;
 			out.n_units = 4;
 		} else {
-			HIPC(hipMalloc(&left, sizeof(int) * (n - 1)));
-			HIPC(hipMalloc(&right, sizeof(int) * (n - 1)));
-			HIPC(hipMalloc(&rf, sizeof(int) * (n - 1)));
-			HIPC(hipMalloc(&rl, sizeof(int) * (n - 1)));
-			HIPC(hipMalloc(&parent, sizeof(int) * (2 * size_t(n) - 1)));
-			HIPC(hipMalloc(&boxes, sizeof(float) * 6 * (n - 1)));
-			HIPC(hipMalloc(&arrive, sizeof(uint32_t) * (n - 1)));
-			HIPC(hipMalloc(&inner_flag, sizeof(uint32_t) * n));
-			HIPC(hipMalloc(&inner_idx, sizeof(uint32_t) * n));
-			HIPC(hipMalloc(&leaf_flag, sizeof(uint32_t) * n));
-			HIPC(hipMalloc(&leaf_cnt, sizeof(uint32_t) * n));
-			HIPC(hipMalloc(&leaf_idx, sizeof(uint32_t) * n));
-			HIPC(hipMemsetAsync(arrive, 0, sizeof(uint32_t) * (n - 1), stream));
-			HIPC(hipMemsetAsync(inner_flag, 0, sizeof(uint32_t) * n, stream));
-			HIPC(hipMemsetAsync(leaf_flag, 0, sizeof(uint32_t) * n, stream));
-			HIPC(hipMemsetAsync(leaf_cnt, 0, sizeof(uint32_t) * n, stream));
-			hipLaunchKernelGGL(k_radix_tree, dim3(G), dim3(B), 0, stream, (int)n, keys_sorted, left, right, rf, rl, parent);
-			hipLaunchKernelGGL(k_fit_bounds, dim3(G), dim3(B), 0, stream, (int)n, wv, vals_sorted, left, right, parent, boxes, arrive);
-			HIPC(hipMalloc(&bounds_dev, sizeof(uint32_t) * 2));
-			HIPC(hipMemsetAsync(bounds_dev, 0, sizeof(uint32_t) * 2, stream));
-			hipLaunchKernelGGL(k_depth_and_flags, dim3(G), dim3(B), 0, stream, (int)n, parent, rf, rl, inner_flag, leaf_flag, leaf_cnt, bounds_dev);
-			HIPC(hipGetLastError());
-			if (in.width != 4) { // the greedy collapse: which radix nodes are records follows top-down from the root, one launch per level
-				HIPC(hipMalloc(&greedy_flag, sizeof(uint32_t) * n));
-				HIPC(hipMalloc(&front, sizeof(int) * n));
-				HIPC(hipMalloc(&front_next, sizeof(int) * n));
-				HIPC(hipMalloc(&stack_bound, sizeof(uint32_t) * n));
-				HIPC(hipMemsetAsync(stack_bound, 0, sizeof(uint32_t), stream)); // the root's
-				HIPC(hipMalloc(&front_count, sizeof(uint32_t)));
-				HIPC(hipMalloc(&area_sums, sizeof(double) * 2));
-				HIPC(hipMemsetAsync(greedy_flag, 0, sizeof(uint32_t) * n, stream));
-				HIPC(hipMemsetAsync(area_sums, 0, sizeof(double) * 2, stream));
-				const uint32_t one = 1u;
-				const int root	   = 0;
-				HIPC(hipMemcpyAsync(greedy_flag, &one, 4, hipMemcpyHostToDevice, stream));
-				HIPC(hipMemcpyAsync(front, &root, 4, hipMemcpyHostToDevice, stream));
-				uint32_t n_front = 1u;
-				while (n_front != 0u) {
-					HIPC(hipMemsetAsync(front_count, 0, sizeof(uint32_t), stream));
-					hipLaunchKernelGGL(k_mark_records, dim3((n_front + B - 1) / B), dim3(B), 0, stream, (int)n_front, front, MAX_WIDE, wv, vals_sorted, left, right, rf, rl, boxes,
-									   greedy_flag, front_next, front_count, stack_bound, bounds_dev + 1);
-					HIPC(hipMemcpyAsync(&n_front, front_count, 4, hipMemcpyDeviceToHost, stream));
-					HIPC(hipStreamSynchronize(stream));
-					std::swap(front, front_next);
-				}
-				double sums[2] = { 0.0, 0.0 };
-				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, inner_flag, boxes, area_sums);
-				hipLaunchKernelGGL(k_area_sum, dim3(G), dim3(B), 0, stream, (int)n, greedy_flag, boxes, area_sums + 1);
-				float root_box[6];
-				HIPC(hipMemcpyAsync(bounds_host, bounds_dev, sizeof(bounds_host), hipMemcpyDeviceToHost, stream));
-				HIPC(hipMemcpyAsync(sums, area_sums, sizeof(sums), hipMemcpyDeviceToHost, stream));
-				HIPC(hipMemcpyAsync(root_box, boxes, sizeof(root_box), hipMemcpyDeviceToHost, stream));
-				HIPC(hipStreamSynchronize(stream));
-				const double rx = (double)root_box[3] - root_box[0], ry = (double)root_box[4] - root_box[1], rz = (double)root_box[5] - root_box[2];
-				const double ra = std::max(rx * ry + ry * rz + rz * rx, 1e-300);
-				out.cost4 = (float)(sums[0] / ra);
-				out.cost6 = (float)(sums[1] / ra);
-				// width 0: six-wide where its tree saves more records than its longer step costs (WIDE_STEP_COST: measured)
-				const uint32_t bound4 = 3u * (bounds_host[0] + 1u), bound6 = bounds_host[1];
-				out.stack_bound		  = bound4;
-				// ... of the trees whose deepest walk fits the traversal stack (a walk that ran out of stack would drop subtrees silently)
-				const bool fit4 = bound4 <= in.stack_capacity, fit6 = bound6 <= in.stack_capacity;
-				const bool cheaper6 = (double)out.cost6 * WIDE_STEP_COST < (double)out.cost4;
-				if (in.width == 6 || (cheaper6 ? (fit6 || !fit4) : (!fit4 && fit6))) {
-					out.stack_bound = bound6;
-					width	 = MAX_WIDE;
-					out.wide = true;
-					std::swap(inner_flag, greedy_flag);
-				}
-			}
 			HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, t2a, inner_flag, inner_idx, (int)n, stream));
 			HIPC(hipcub::DeviceScan::ExclusiveSum(nullptr, t2b, leaf_flag, leaf_idx, (int)n, stream));
 			temp2_bytes = std::max(t2a, t2b);
@@ -837,11 +1029,8 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			HIPC(hipMemcpyAsync(&last[1], inner_flag + (n - 1), 4, hipMemcpyDeviceToHost, stream));
 			HIPC(hipMemcpyAsync(&last[2], leaf_idx + (n - 1), 4, hipMemcpyDeviceToHost, stream));
 			HIPC(hipMemcpyAsync(&last[3], leaf_flag + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-			HIPC(hipMemcpyAsync(bounds_host, bounds_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
 			HIPC(hipStreamSynchronize(stream));
-			if (!out.wide)
-				out.stack_bound = 3u * (bounds_host[0] + 1u); // a four-wide step pushes at most three entries, at every record from the root down
-			if (out.stack_bound > in.stack_capacity) {
+			if (out.stack_bound > in.stack_capacity) { // (a four-wide step pushes at most three entries, at every record from the root down: 3 x the deepest record)
 				err = "the BVH of this scene is " + std::to_string(out.stack_bound) + " stack entries deep in the worst case, the traversal stack holds "
 					  + std::to_string(in.stack_capacity);
 				goto done;
@@ -901,10 +1090,10 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 		ok = true;
 	}
 done:
-	(void)hipFree(wv); (void)hipFree(ebounds); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted);
+	(void)hipFree(wv); (void)hipFree(ebounds); (void)hipFree(entity_rank); (void)hipFree(keys); (void)hipFree(keys_sorted); (void)hipFree(vals); (void)hipFree(vals_sorted);
 	(void)hipFree(left); (void)hipFree(right); (void)hipFree(rf); (void)hipFree(rl); (void)hipFree(parent); (void)hipFree(boxes); (void)hipFree(arrive);
 	(void)hipFree(inner_flag); (void)hipFree(inner_idx); (void)hipFree(leaf_flag); (void)hipFree(leaf_cnt); (void)hipFree(leaf_idx);
-	(void)hipFree(front); (void)hipFree(front_next); (void)hipFree(front_count); (void)hipFree(area_sums); (void)hipFree(greedy_flag); (void)hipFree(stack_bound); (void)hipFree(bounds_dev);
+	(void)hipFree(front); (void)hipFree(front_next); (void)hipFree(front_count); (void)hipFree(area_sums); (void)hipFree(greedy_flag); (void)hipFree(stack_bound); (void)hipFree(bounds_dev); (void)hipFree(odd_flag);
 	(void)hipFree(temp); (void)hipFree(temp2); (void)hipFree(gsize); (void)hipFree(gbase); (void)hipFree(inner_unit);
 	if (!ok) {
 		(void)hipFree(out.recs);
