@@ -151,7 +151,7 @@ def default_settings(width, height):
 class PipelineInfo(C.Structure):  # prgpu_pipeline_info
     _fields_ = [("mode", C.c_uint32), ("shader_waves", C.c_int32), ("shading_share", C.c_float), ("calibration_launches", C.c_uint32),
                 ("kernel", C.c_uint32), ("blocks", C.c_uint32), ("slots_per_block", C.c_uint32), ("launches", C.c_uint64),
-                ("bvh_width", C.c_uint32), ("bvh_stack_bound", C.c_uint32), ("bvh_cost_4_wide", C.c_float), ("bvh_cost_6_wide", C.c_float)]
+                ("bvh_width", C.c_uint32), ("bvh_top", C.c_uint32), ("bvh_stack_bound", C.c_uint32), ("bvh_cost_4_wide", C.c_float), ("bvh_cost_6_wide", C.c_float)]
 
 
 class SkyParams(C.Structure):  # prgpu_sky_params

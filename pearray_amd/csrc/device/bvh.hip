@@ -221,10 +221,12 @@ __device__ __forceinline__ void pad_box(float* lo, float* hi)
 //   * a subtree with <= 3 triangles whose parent has > 3 is a LEAF record (these partition the triangles) -- under either collapse;
 //   * FOUR-WIDE, the parity collapse (decidable per node, no top-down pass): an internal node at EVEN depth with > 3 triangles is an INNER
 //     record; its children are its radix-tree children, each replaced by its own two children when it is an (odd-depth) internal node
-//     with > 3 triangles;
+//     with > 3 triangles -- or the same with the records at ODD depths below a root of two children: where every subtree's records start
+//     is luck of the scene's layout, so both are marked and priced;
 //   * SIX-WIDE, the greedy collapse (gather_children with a width, k_mark_records top-down from the root): a record's children start as its
 //     radix node's two children, and while there are fewer than six the one of largest surface area that is not a leaf is replaced by its two.
-// build_lbvh computes both sets of records' expected visits per ray (k_area_sum) and keeps the cheaper tree; a six-wide step counts 1.35 x.
+// build_lbvh computes every candidate's expected visits per ray (k_area_sum) and keeps the cheapest tree; a six-wide step counts 1.35 x.
+// It does so for two tops of the tree -- the sort key's entity field as the scene lists the entities, or as entity_codes orders them.
 __global__ void k_depth_and_flags(int n, const int* __restrict__ parent, const int* __restrict__ range_first, const int* __restrict__ range_last,
 								  uint32_t* __restrict__ inner_flag /* n-1: records of the even-depth collapse */, uint32_t* __restrict__ odd_flag /* ... of the odd-depth one */,
 								  uint32_t* __restrict__ leaf_flag /* n */, uint32_t* __restrict__ leaf_count /* n */, uint32_t* __restrict__ max_record_depth /* [2]: even, odd */)
@@ -922,6 +924,7 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 			if (n <= 3)
 				break;
 			width			= 0;
+			out.top			= order;
 			out.wide		= false;
 			out.cost4		= 0.0f;
 			out.cost6		= 0.0f;
@@ -993,7 +996,8 @@ bool build_lbvh(const BvhBuildInput& in, BvhBuildOutput& out, hipStream_t stream
 				}
 			}
 			{ // the next candidate for the top of the tree, or once more the better one if that is not the one just built
-				const double cost = out.wide ? (double)out.cost6 * WIDE_STEP_COST : (double)out.cost4;
+				const double cost = out.stack_bound > in.stack_capacity ? INFINITY // (no tree of this top fits the traversal stack)
+																		: (out.wide ? (double)out.cost6 * WIDE_STEP_COST : (double)out.cost4);
 				if (pass < n_orders && cost < best_cost) {
 					best_cost  = cost;
 					best_order = order;

@@ -181,7 +181,7 @@ struct prgpu_scene {
 	uint32_t n_pixels = 0, n_slots = 0;
 	std::vector<void*> allocations;
 	uint32_t bvh_units = 0; // 64-byte units of the BVH record array
-	uint32_t bvh_stack_bound = 0;
+	uint32_t bvh_stack_bound = 0, bvh_top = 0;
 	float bvh_cost4 = 0.0f, bvh_cost6 = 0.0f; // the builder's estimates for the 4- and the 6-wide tree (prgpu_pipeline_info)
 	int pp_shader_waves = -1; // persistent kernel: dedicated shading waves per block, decided after the first launch (-1: not yet)
 	double pp_shading_share = 0.0; // ... from this measured share of shading passes in the wave time
@@ -589,6 +589,7 @@ int create_impl(const prgpu_scene_desc* d, int device, prgpu_scene* s)
 	s->bvh_cost4 = bout.cost4;
 	s->bvh_cost6 = bout.cost6;
 	s->bvh_stack_bound = bout.stack_bound;
+	s->bvh_top = (uint32_t)bout.top;
 	sc.n_leaf  = bout.n_leaf;
 	s->bvh_units = bout.n_units;
 	{ // triangle -> leaf slot (the split traversal re-tests the winning triangle of a ray for u, v)
@@ -1893,6 +1894,7 @@ int prgpu_pipeline_info_get(prgpu_scene* s, prgpu_pipeline_info* out)
 	out->bvh_cost_4_wide = s->bvh_cost4;
 	out->bvh_cost_6_wide = s->bvh_cost6;
 	out->bvh_stack_bound = s->bvh_stack_bound;
+	out->bvh_top		 = s->bvh_top;
 	return PRGPU_OK;
 }
 

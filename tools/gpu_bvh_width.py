@@ -116,4 +116,4 @@ for name in (sys.argv[1:] or list(SCENES)):
     right = (auto["bvh_width"] == 6) == (r6[0] < r4[0])
     print("%-9s | %7.2f / %7.2f (%.3f) | %5d | %8.3f %8.2f %8.2f   | %8.3f %8.2f %8.2f   | %.3f %.3f %s"
           % (name, e4, e6, e6 / max(e4, 1e-30), auto["bvh_width"], r4[0], r4[1], r4[2], r6[0], r6[1], r6[2], r6[1] / max(r4[1], 1e-30), r6[0] / r4[0],
-             ("[stack bound %d]" % auto["bvh_stack_bound"]) if right else ("<- auto took the slower tree (%.1f %%)" % (100.0 * abs(r6[0] / r4[0] - 1.0)))), flush=True)
+             ("[top %d, stack bound %d]" % (auto["bvh_top"], auto["bvh_stack_bound"])) if right else ("<- auto took the slower tree (%.1f %%)" % (100.0 * abs(r6[0] / r4[0] - 1.0)))), flush=True)
