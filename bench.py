@@ -212,7 +212,7 @@ def roofline(ctx, rank, iters=ROOFLINE_ITERS, variant="0u", owned_fraction=1.0, 
             "bvh_width": kinfo["bvh_width"],
             "bvh_width_note": ("six-wide inner records: a third fewer records per ray than this scene's four-wide tree, so fewer algorithmic bytes -- across tree widths compare "
                                "Msamples/s, not frac" if kinfo["bvh_width"] == 6 else None),
-            "bvh_top": "surface-area tree over the entities" if kinfo["bvh_top"] else "entities in scene order", "bvh_stack_bound": kinfo["bvh_stack_bound"], "bvh_cost_estimate": {"4_wide": round(kinfo["bvh_cost_4_wide"], 2), "6_wide": round(kinfo["bvh_cost_6_wide"], 2)},
+            "bvh_top": ("entities in scene order", "surface-area tree over the entities", "Morton order of the entities")[kinfo["bvh_top"]], "bvh_stack_bound": kinfo["bvh_stack_bound"], "bvh_cost_estimate": {"4_wide": round(kinfo["bvh_cost_4_wide"], 2), "6_wide": round(kinfo["bvh_cost_6_wide"], 2)},
             "launches": n, "iterations_per_launch": iters_per_launch, "algorithmic_bytes_per_launch": round(alg_bytes),
             "algorithmic_bytes_per_closest_ray": round(bytes_closest / max(d["rays_closest"], 1), 1),
             "algorithmic_bytes_per_occlusion_ray": round(bytes_any / max(d["rays_any"], 1), 1),

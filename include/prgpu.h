@@ -397,7 +397,7 @@ typedef struct prgpu_pipeline_info {
 	uint32_t blocks, slots_per_block; /* grid of the last launch */
 	uint64_t launches;             /* persistent launches since the scene was created */
 	uint32_t bvh_width;            /* children per inner record of the scene's BVH: 4 or 6 (PRGPU_BVH_WIDTH; chosen per scene by default) */
-	uint32_t bvh_top;              /* the top of the tree (the sort key's entity field): 0 = the entities in the order of the scene description, 1 = by a surface-area tree over their boxes; the builder builds both and keeps the cheaper tree */
+	uint32_t bvh_top;              /* the top of the tree (the sort key's entity field): 0 = the entities in the order of the scene description, 1 = by a surface-area tree over their boxes, 2 = in the Morton order of their centres; the builder builds all three and keeps the cheapest tree */
 	uint32_t bvh_stack_bound;      /* entries the deepest walk of the tree can hold on a lane's traversal stack (a scene whose tree needs more than the stack holds is refused) */
 	float    bvh_cost_4_wide, bvh_cost_6_wide; /* the builder's estimate for either tree: inner records a ray through the scene's box visits (0: not computed) */
 } prgpu_pipeline_info;

@@ -23,7 +23,7 @@ struct BvhBuildOutput {
 	uint32_t* leaf_units = nullptr; // device, n_leaf entries: the unit of every leaf record (the caller frees it)
 	uint32_t n_inner = 0, n_leaf = 0, n_units = 0;
 	uint32_t stack_bound = 0;		// entries the deepest walk of the tree can hold at once (every child of every record on a root-to-leaf path hit)
-	int top = 0;					// the sort key's entity field: 0 = the entities as the scene lists them, 1 = their paths in a surface-area tree over their boxes
+	int top = 0;					// the sort key's entity field: 0 = the entities as the scene lists them, 1 = their paths in a surface-area tree over their boxes, 2 = the Morton order of their centres
 	bool wide = false;				// the records hold up to six children (DevScene::bvh_wide)
 	float cost4 = 0.0f, cost6 = 0.0f; // expected inner records per ray through the scene's box, 4-wide / 6-wide tree (0: not computed)
 };

@@ -110,10 +110,13 @@ def run(sc, width, iters=16):
 print("%-9s | %22s | %5s | %28s | %28s | %s" % ("scene", "estimate 4 / 6 (ratio)", "auto", "4-wide: ms, inner, leaf / ray", "6-wide: ms, inner, leaf / ray", "6 against 4: records, time"))
 for name in (sys.argv[1:] or list(SCENES)):
     sc = SCENES[name]()
-    _, _, _, auto = run(sc, "auto", iters=2)
+    ra = run(sc, "auto")
+    auto = ra[3]
     r4, r6 = run(sc, "4"), run(sc, "6")
     e4, e6 = auto["bvh_cost_4_wide"], auto["bvh_cost_6_wide"]
-    right = (auto["bvh_width"] == 6) == (r6[0] < r4[0])
+    best = min(r4[0], r6[0])
+    right = ra[0] <= 1.01 * best
+    print("%-9s   auto: %.3f ms, %.2f inner + %.2f leaf records per ray, %d-wide, top %d" % (name, ra[0], ra[1], ra[2], auto["bvh_width"], auto["bvh_top"]))
     print("%-9s | %7.2f / %7.2f (%.3f) | %5d | %8.3f %8.2f %8.2f   | %8.3f %8.2f %8.2f   | %.3f %.3f %s"
           % (name, e4, e6, e6 / max(e4, 1e-30), auto["bvh_width"], r4[0], r4[1], r4[2], r6[0], r6[1], r6[2], r6[1] / max(r4[1], 1e-30), r6[0] / r4[0],
-             ("[top %d, stack bound %d]" % (auto["bvh_top"], auto["bvh_stack_bound"])) if right else ("<- auto took the slower tree (%.1f %%)" % (100.0 * abs(r6[0] / r4[0] - 1.0)))), flush=True)
+             ("[top %d, stack bound %d]" % (auto["bvh_top"], auto["bvh_stack_bound"])) if right else ("<- auto is %.1f %% behind the better forced width" % (100.0 * (ra[0] / best - 1.0)))), flush=True)
