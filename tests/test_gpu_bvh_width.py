@@ -168,3 +168,27 @@ def test_a_tree_too_deep_for_the_traversal_stack_is_refused_not_walked(monkeypat
     # ordinary scenes are nowhere near the limit
     g2 = backend.RenderContext(scene.cornell_soup(64, 48, spp=1, n_triangles=200_000))
     assert 0 < g2.pipelineInfo()["bvh_stack_bound"] <= 48, g2.pipelineInfo()
+
+
+def test_thousands_of_entities_under_every_top_of_the_tree():
+    """The sort key's entity field is built three ways (scene order, a surface-area tree over the entities' boxes, the Morton order of their centres) and the
+    cheapest tree is kept: 3000 one- and two-triangle entities listed in RANDOM order, so that the scene's own order is the worst of the three, against the checker."""
+    rng = np.random.default_rng(12)
+    b = scene.SceneBuilder(48, 32)
+    b.settings.aa_samples = 2
+    mats = [b.lambert(b.spectrum_const(0.3 + 0.1 * k)) for k in range(5)]
+    centres = rng.uniform([-1, -1, 0.1], [1, 1, 1.9], (3000, 3))
+    for i, c in enumerate(centres):
+        n = 1 + (i % 2)
+        pos = (c[None, None, :] + rng.uniform(-0.03, 0.03, (n, 3, 3))).reshape(-1, 3).astype(np.float32)
+        b.add_mesh(pos, np.arange(3 * n, dtype=np.uint32).reshape(n, 3), mats[i % 5])
+    light = np.array([[-0.5, -0.5, 1.99], [0.5, -0.5, 1.99], [-0.5, 0.5, 1.99]], dtype=np.float32)
+    b.add_mesh(light, np.array([[0, 1, 2]], dtype=np.uint32), b.lambert(b.spectrum_const(0.0)), emission=b.diffuse_emission(b.illuminant_d65()))
+    T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.0, -3.5, 1.0)
+    b.set_camera(T, width=0.8, height=0.53, local_direction=(0, 1, 0), local_up=(0, 0, 1), local_right=(1, 0, 0))
+    sc = b.build()
+    g, o = render_both(sc, iters=2)
+    assert_parity(g, o, exact=True)
+    info = g.pipelineInfo()
+    assert info["bvh_top"] in (1, 2), info            # not the random order of the description
+    assert 0 < info["bvh_stack_bound"] <= 80
